@@ -1,0 +1,319 @@
+"""
+ORACLE -- TEST INFRASTRUCTURE ONLY.  Golden-vector generator; runs ONLY in the build container.
+
+Executes the reference's own ``homonim/kernel_model.py`` (read in place from /root/reference, never copied) on
+seeded inputs and writes small ``tests/golden/*.npz`` fixtures (inputs + expected outputs).  ``/root/reference``
+does not exist on the GPU box, so nothing but the ``.npz`` data travels.
+
+Third-party modules the reference imports but that are absent here (no network):
+
+* ``cv2`` (opencv-python-headless>=4.5, pyproject.toml:8) -- stand-in below implementing exactly the four entry
+  points the hot path calls (kernel_model.py:155-184,256-258,331-341,407-408) with OpenCV's documented semantics:
+  zero-border, centre-anchored, un-normalised window sums accumulated in float64; ``boxFilter(ddepth=-1)`` returns
+  the input depth, ``sqrBoxFilter(ddepth=-1)`` returns float64 for float input (OpenCV's own rule; confirmed
+  against the reference's PARAM GeoTIFF, which is reproduced bit-for-bit only with that depth).
+  This is a RESTATEMENT of the published algorithm, so the goldens pin the reference's *Python* (mask logic, numpy
+  operation order, dtype promotion) bit-for-bit, and the OpenCV boundary only by definition.  DESIGN.md says so.
+* ``rasterio`` (>=1.1, pyproject.toml:7) -- placeholder names only (``Affine``, ``CRS``, ``Window``, enums, ...);
+  base-class ``KernelModel.fit/apply`` never calls into GDAL.  ``fillnodata`` is the identity and COUNTS calls that
+  had holes inside the valid area, so no golden silently depends on in-painting.
+
+Usage:  python oracle/gen_golden.py            (writes tests/golden/*.npz + manifest.json)
+"""
+import importlib.util
+import json
+import os
+import sys
+import types
+from collections import namedtuple
+from enum import Enum, IntEnum
+
+import numpy as np
+
+REF_ROOT = '/root/reference'
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+GOLDEN_DIR = os.path.join(REPO, 'tests', 'golden')
+
+sys.path.insert(0, REPO)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# stand-in cv2
+def _win_sum(src, ksize, square):
+    kw, kh = int(ksize[0]), int(ksize[1])
+    rh, rw = kh // 2, kw // 2
+    h, w = src.shape
+    x = src.astype(np.float64)
+    if square:
+        x = x * x
+    pad = np.zeros((h + 2 * rh, w + 2 * rw), np.float64)
+    pad[rh:rh + h, rw:rw + w] = x
+    acc = np.zeros((h, w), np.float64)
+    for dy in range(kh):  # direct 2-D accumulation (deliberately a different order to oracle_np.box_sum)
+        for dx in range(kw):
+            acc += pad[dy:dy + h, dx:dx + w]
+    if square:
+        # cv::sqrBoxFilter: ``if (ddepth < 0) ddepth = sdepth < CV_32F ? CV_32F : CV_64F`` -- float32 in, float64 OUT.
+        # Pinned by the reference's own PARAM GeoTIFF: only this depth reproduces it (tests/test_oracle_golden.py).
+        return acc
+    out_dtype = src.dtype if src.dtype in (np.float32, np.float64) else np.float64
+    return acc.astype(out_dtype)
+
+
+def _make_cv2():
+    cv2 = types.ModuleType('cv2')
+    cv2.BORDER_CONSTANT = 0
+    cv2.MORPH_RECT = 0
+
+    def boxFilter(src, ddepth, ksize, normalize=True, borderType=None, **kw):
+        assert ddepth == -1 and normalize is False and borderType == cv2.BORDER_CONSTANT
+        return _win_sum(src, ksize, False)
+
+    def sqrBoxFilter(src, ddepth, ksize, normalize=True, borderType=None, **kw):
+        assert ddepth == -1 and normalize is False and borderType == cv2.BORDER_CONSTANT
+        return _win_sum(src, ksize, True)
+
+    def getStructuringElement(shape, ksize):
+        return np.ones((int(ksize[1]), int(ksize[0])), np.uint8)
+
+    def erode(src, se, borderType=None, borderValue=0, **kw):
+        kh, kw_ = se.shape
+        rh, rw = kh // 2, kw_ // 2
+        h, w = src.shape
+        pad = np.full((h + 2 * rh, w + 2 * rw), borderValue, src.dtype)
+        pad[rh:rh + h, rw:rw + w] = src
+        out = np.full((h, w), np.iinfo(src.dtype).max, src.dtype)
+        for dy in range(kh):
+            for dx in range(kw_):
+                out = np.minimum(out, pad[dy:dy + h, dx:dx + w])
+        return out
+
+    cv2.boxFilter, cv2.sqrBoxFilter = boxFilter, sqrBoxFilter
+    cv2.getStructuringElement, cv2.erode = getStructuringElement, erode
+    return cv2
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# stand-in rasterio (names only)
+FILL_CALLS = dict(total=0, with_holes=0)
+
+
+def _make_rasterio():
+    rio = types.ModuleType('rasterio')
+
+    class Affine(namedtuple('Affine', 'a b c d e f')):
+        pass
+
+    class CRS:
+        def __init__(self, name='EPSG:3857'):
+            self.name = name
+
+        def __eq__(self, other):
+            return isinstance(other, CRS) and other.name == self.name
+
+        def __hash__(self):
+            return hash(self.name)
+
+    class Window(namedtuple('Window', 'col_off row_off width height')):
+        pass
+
+    class _Placeholder:
+        pass
+
+    Resampling = IntEnum(
+        'Resampling', 'nearest bilinear cubic cubic_spline lanczos average mode gauss max min med q1 q3 sum rms',
+        start=0
+    )
+    MaskFlags = Enum('MaskFlags', 'all_valid per_dataset alpha nodata')
+    ColorInterp = Enum('ColorInterp', 'undefined gray palette red green blue alpha')
+
+    def fillnodata(image, mask=None, **kw):
+        FILL_CALLS['total'] += 1
+        if np.any(~np.asarray(mask, bool) & ~np.isnan(image)):
+            FILL_CALLS['with_holes'] += 1
+        return image
+
+    def _sub(name, **attrs):
+        m = types.ModuleType(f'rasterio.{name}')
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        setattr(rio, name, m)
+        sys.modules[f'rasterio.{name}'] = m
+        return m
+
+    rio.Affine = Affine
+    rio.DatasetReader = _Placeholder
+    rio.uint8, rio.float32 = 'uint8', 'float32'
+    _sub('enums', Resampling=Resampling, MaskFlags=MaskFlags, ColorInterp=ColorInterp)
+    _sub('fill', fillnodata=fillnodata)
+    _sub('crs', CRS=CRS)
+    _sub('transform', TransformMethodsMixin=type('TransformMethodsMixin', (), {}))
+    _sub(
+        'windows', Window=Window, WindowMethodsMixin=type('WindowMethodsMixin', (), {}),
+        transform=lambda window, transform: transform
+    )
+    _sub('warp', reproject=None, Resampling=Resampling)
+    _sub('errors', NotGeoreferencedWarning=type('NotGeoreferencedWarning', (UserWarning, ), {}))
+    _sub('vrt', WarpedVRT=_Placeholder)
+    _sub('io', DatasetWriter=_Placeholder)
+    _sub('dtypes', can_cast_dtype=lambda v, d: True)
+    _sub('drivers', raster_driver_extensions=lambda: {'tif': 'GTiff'})
+    return rio
+
+
+def load_reference():
+    """ Load homonim/{enums,errors,utils,raster_array,kernel_model}.py by path under a synthetic package. """
+    sys.modules['cv2'] = _make_cv2()
+    sys.modules['rasterio'] = _make_rasterio()
+    pkg = types.ModuleType('homonim')
+    pkg.__path__ = [os.path.join(REF_ROOT, 'homonim')]
+    sys.modules['homonim'] = pkg
+    mods = {}
+    for name in ('enums', 'errors', 'utils', 'raster_array', 'kernel_model'):
+        spec = importlib.util.spec_from_file_location(f'homonim.{name}', os.path.join(REF_ROOT, 'homonim', f'{name}.py'))
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[f'homonim.{name}'] = mod
+        spec.loader.exec_module(mod)
+        setattr(pkg, name, mod)
+        mods[name] = mod
+    return mods
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def make_inputs(h, w, seed, variant):
+    """ Seeded src/ref pairs with the nodata settings SURVEY.md section 8c lists. """
+    from oracle.oracle_np import synth_pair
+    if variant == 'nan_frame_holes':
+        src, ref = synth_pair(h, w, seed, 'frame+holes')
+        return src, np.nan, ref, np.nan
+    if variant == 'no_nodata':
+        src, ref = synth_pair(h, w, seed, 'none')
+        return src, None, ref, None
+    if variant == 'nan_nodata_clean':
+        src, ref = synth_pair(h, w, seed, 'none')
+        return src, np.nan, ref, np.nan
+    if variant == 'numeric_nodata':
+        # byte-like DN data with nodata 0 in src (a 2-px frame + scattered zeros) and nodata None in ref
+        rng = np.random.default_rng(1000 + seed)
+        src = np.round(rng.uniform(1, 255, (h, w))).astype(np.float32)
+        ref = np.round(0.8 * src + 20 + rng.normal(0, 4, (h, w))).astype(np.float32)
+        src[:2], src[-2:], src[:, :2], src[:, -2:] = 0, 0, 0, 0
+        src[rng.random((h, w)) < 0.01] = 0
+        return src, 0., ref, None
+    if variant == 'dn_like':
+        src, ref = synth_pair(h, w, seed, 'frame+holes', dn_like=True)
+        return src, np.nan, ref, np.nan
+    if variant == 'all_masked':
+        src, ref = synth_pair(h, w, seed, 'none')
+        src[:] = np.nan
+        return src, np.nan, ref, np.nan
+    raise ValueError(variant)
+
+
+def run_reference(mods, model, kernel_shape, find_r2, thresh, src, src_nodata, ref, ref_nodata):
+    """ KernelModel.fit on copies, then KernelModel.apply on the ORIGINAL source (the reference never re-uses the
+    fitted src_ra: SURVEY.md section 8b 'Trap'). """
+    import warnings
+    km, ra_mod, rio = mods['kernel_model'], mods['raster_array'], sys.modules['rasterio']
+    crs, tf = sys.modules['rasterio.crs'].CRS(), rio.Affine(1., 0., 0., 0., -1., 0.)
+    RasterArray = ra_mod.RasterArray
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        model_obj = km.KernelModel(model, kernel_shape, find_r2=find_r2, r2_inpaint_thresh=thresh)
+        src_fit = RasterArray(src.copy(), crs, tf, nodata=src_nodata)
+        ref_fit = RasterArray(ref.copy(), crs, tf, nodata=ref_nodata)
+        norm = None
+        if model == 'gain-blk-offset':
+            norm = km.KernelModel._fit_block_norm(
+                RasterArray(src.copy(), crs, tf, nodata=src_nodata), RasterArray(ref.copy(), crs, tf, nodata=ref_nodata)
+            )
+        with np.errstate(all='ignore'):
+            param_ra = model_obj.fit(src_fit, ref_fit)
+            src_apply = RasterArray(src.copy(), crs, tf, nodata=src_nodata)
+            corr_ra = model_obj.apply(src_apply, param_ra)
+    return param_ra.array, corr_ra.array, norm
+
+
+CASES = []
+for _model in ('gain', 'gain-blk-offset', 'gain-offset'):
+    for _k in ((1, 1), (3, 3), (5, 5), (5, 7), (15, 15)):
+        if _model == 'gain-offset' and _k == (1, 1):
+            continue  # ValueError by design (utils.py:123-125)
+        for _r2 in (False, True):
+            # the full nodata cross only at the default 5x5 kernel; other shapes on the NaN frame+holes input
+            variants = ('nan_frame_holes', 'no_nodata', 'numeric_nodata') if _k == (5, 5) else ('nan_frame_holes', )
+            for _variant in variants:
+                threshes = (None, 0.25) if _model == 'gain-offset' else (0.25, )
+                for _thresh in threshes:
+                    CASES.append(dict(model=_model, k=_k, find_r2=_r2, variant=_variant, thresh=_thresh))
+# a few extra: harsher DN-like distribution, all-masked block, taller-than-wide kernel
+CASES += [
+    dict(model='gain-offset', k=(5, 5), find_r2=True, variant='dn_like', thresh=None),
+    dict(model='gain-blk-offset', k=(5, 5), find_r2=True, variant='dn_like', thresh=0.25),
+    dict(model='gain-blk-offset', k=(5, 5), find_r2=False, variant='all_masked', thresh=0.25),
+    dict(model='gain', k=(7, 3), find_r2=True, variant='nan_frame_holes', thresh=0.25),
+    dict(model='gain-offset', k=(9, 9), find_r2=True, variant='nan_frame_holes', thresh=0.25),
+]
+
+
+def main():
+    mods = load_reference()
+    os.makedirs(GOLDEN_DIR, exist_ok=True)
+    h, w = 36, 52
+    manifest = dict(
+        numpy=np.__version__, reference='leftfield-geospatial/homonim v0.4.3 (/root/reference)',
+        shape=[h, w], note='cv2/rasterio are stand-ins (see oracle/gen_golden.py header); gain-blk-offset goldens are '
+        'the NumPy>=2 flavour (float64 normalised source)', cases=[]
+    )
+    arrays = {}
+    inputs_done = {}
+    for ci, case in enumerate(CASES):
+        seed = 7 + len(inputs_done)
+        vkey = case['variant']
+        if vkey not in inputs_done:
+            src, snd, ref, rnd = make_inputs(h, w, seed, vkey)
+            inputs_done[vkey] = (src, snd, ref, rnd)
+            arrays[f'in_{vkey}_src'] = src
+            arrays[f'in_{vkey}_ref'] = ref
+        src, snd, ref, rnd = inputs_done[vkey]
+        holes_before = FILL_CALLS['with_holes']
+        params, corr, norm = run_reference(
+            mods, case['model'], case['k'], case['find_r2'], case['thresh'], src, snd, ref, rnd
+        )
+        inpainted = FILL_CALLS['with_holes'] > holes_before
+        name = f'c{ci:03d}'
+        arrays[f'{name}_params'] = params
+        arrays[f'{name}_corr'] = corr
+        if norm is not None:
+            arrays[f'{name}_norm'] = norm
+        manifest['cases'].append(
+            dict(
+                name=name, model=case['model'], kernel_shape=list(case['k']), find_r2=case['find_r2'],
+                r2_inpaint_thresh=case['thresh'], variant=vkey,
+                src_nodata=(None if snd is None else ('nan' if np.isnan(snd) else float(snd))),
+                ref_nodata=(None if rnd is None else ('nan' if np.isnan(rnd) else float(rnd))),
+                inpaint_had_holes=bool(inpainted), param_dtype=str(params.dtype), corr_dtype=str(corr.dtype)
+            )
+        )
+    np.savez_compressed(os.path.join(GOLDEN_DIR, 'kernel_model_goldens.npz'), **arrays)
+
+    # reference conftest arrays (tests/conftest.py:74-89) run through gain-offset 5x5 -- the known-answer behind
+    # tests/data/parameter/*PARAM*.tif
+    a100 = np.array(range(1, 201), dtype='float32').reshape(20, 10)
+    a100[:, [0, -1]] = np.nan
+    a100[[0, -1], :] = np.nan
+    params, corr, _ = run_reference(mods, 'gain-offset', (5, 5), True, 0.25, a100, np.nan, a100.copy(), np.nan)
+    np.savez_compressed(os.path.join(GOLDEN_DIR, 'conftest_100cm_gain_offset_k5.npz'), src=a100, params=params, corr=corr)
+
+    manifest['fillnodata_calls'] = FILL_CALLS
+    with open(os.path.join(GOLDEN_DIR, 'manifest.json'), 'w') as f:
+        json.dump(manifest, f, indent=1)
+    n_holes = sum(c['inpaint_had_holes'] for c in manifest['cases'])
+    print(f'{len(CASES)} cases written; fillnodata calls: {FILL_CALLS}; cases with real in-paint holes: {n_holes}')
+    size = os.path.getsize(os.path.join(GOLDEN_DIR, 'kernel_model_goldens.npz'))
+    print(f'kernel_model_goldens.npz: {size / 1e6:.2f} MB')
+
+
+if __name__ == '__main__':
+    main()

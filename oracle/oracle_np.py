@@ -1,0 +1,297 @@
+"""
+ORACLE -- TEST INFRASTRUCTURE ONLY.  Not part of the product path.
+
+numpy restatement of the homonim sliding-window kernel-model fit/apply hot path
+(reference: /root/reference/homonim/kernel_model.py @ v0.4.3).  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this module; the
+product (``homonim_amd``) never does.
+
+What is restated, and from where
+--------------------------------
+* ``nan_equals``            <- homonim/utils.py:54-56
+* ``mask_of``               <- homonim/raster_array.py:298-308 (``RasterArray.mask``)
+* ``box_sum``               <- the call sites kernel_model.py:167-175,184,257-258,332-341 of
+                               ``cv.boxFilter`` / ``cv.sqrBoxFilter(normalize=False, BORDER_CONSTANT)``.
+                               OpenCV (opencv-python-headless>=4.5, un-pinned, pyproject.toml:8) is NOT in
+                               /root/reference and not installed here, so its published algorithm is
+                               restated: zero-padded kh x kw window sum anchored at the centre, accumulated
+                               in float64 (OpenCV picks sumType=CV_64F for CV_32F/CV_64F input).  boxFilter
+                               casts the result to the input depth; sqrBoxFilter squares in float64 and RETURNS
+                               float64 (its ddepth=-1 rule), see ``box_sum``.
+* ``r2_array``              <- kernel_model.py:142-214
+* ``fit_block_norm``        <- kernel_model.py:216-229
+* ``fit_gain``              <- kernel_model.py:231-274
+* ``fit_gain_blk_offset``   <- kernel_model.py:276-303   (NumPy>=2 flavour: normalised source is float64)
+* ``fit_gain_offset``       <- kernel_model.py:305-373   (in-paint branch: bookkeeping only, see below)
+* ``apply``                 <- kernel_model.py:442-463
+
+Pinning
+-------
+The Python part of this restatement is pinned bit-for-bit against golden vectors produced by executing the
+reference's own ``kernel_model.py`` in the build container (``oracle/gen_golden.py`` -> ``tests/golden/*.npz``).
+The OpenCV boundary itself (float64 accumulation, float64 sqrBoxFilter output) is pinned by the reference's own
+PARAM GeoTIFF (``tests/golden/ref_param_tif.npz``, written by the real homonim+OpenCV+GDAL stack), which this
+restatement reproduces bit-for-bit, and by the reference tests' known answers -- see DESIGN.md.
+
+All functions work on plain ndarrays + nodata scalars (no RasterArray), never mutate their inputs (they copy), and
+keep the reference's operation order so results are bitwise reproducible.
+"""
+from typing import Optional, Tuple
+
+import numpy as np
+
+F32 = np.float32
+NAN32 = np.float32(np.nan)
+
+
+def nan_equals(a, b):
+    """ utils.py:54-56 """
+    return (a == b) | (np.isnan(a) & np.isnan(b))
+
+
+def mask_of(array: np.ndarray, nodata) -> np.ndarray:
+    """ raster_array.py:298-308 -- valid-pixel mask of a 2-D array. """
+    if nodata is None:
+        return np.full(array.shape[-2:], True)
+    return ~nan_equals(array, nodata)
+
+
+def box_sum(x: np.ndarray, kernel_shape: Tuple[int, int], square: bool = False) -> np.ndarray:
+    """
+    cv.boxFilter / cv.sqrBoxFilter (normalize=False, borderType=BORDER_CONSTANT, ddepth=-1) restated.
+    ``kernel_shape`` is (kh, kw) (the reference passes ksize=(kw, kh)=kernel_shape[::-1]).
+    Accumulates in float64.  ``square=False`` (boxFilter) returns ``x.dtype``; ``square=True`` (sqrBoxFilter)
+    returns float64: OpenCV resolves ``ddepth=-1`` there as ``sdepth < CV_32F ? CV_32F : CV_64F``, so a float32
+    input yields a float64 sum-of-squares and everything downstream of it (m_den, the gain division, all of R2)
+    runs in float64 under numpy promotion.  Only this reproduces the reference's PARAM GeoTIFF bit-for-bit
+    (tests/test_oracle_golden.py::test_reference_param_tif).
+    """
+    kh, kw = int(kernel_shape[0]), int(kernel_shape[1])
+    rh, rw = kh // 2, kw // 2
+    h, w = x.shape
+    xd = x.astype(np.float64)
+    if square:
+        xd = xd * xd
+    pad = np.zeros((h + 2 * rh, w + 2 * rw), dtype=np.float64)
+    pad[rh:rh + h, rw:rw + w] = xd
+    # separable direct sums (order is immaterial while the float64 partial sums are exact -- DESIGN.md)
+    rows = np.zeros((h + 2 * rh, w), dtype=np.float64)
+    for dx in range(kw):
+        rows += pad[:, dx:dx + w]
+    out = np.zeros((h, w), dtype=np.float64)
+    for dy in range(kh):
+        out += rows[dy:dy + h, :]
+    return out if square else out.astype(x.dtype)
+
+
+def r2_array(
+    ref_array, src_array, param_array, mask=None, mask_sum=None, ref_sum=None, src_sum=None, ref2_sum=None,
+    src2_sum=None, src_ref_sum=None, dest_array=None, kernel_shape=(5, 5)
+):
+    """ kernel_model.py:142-214.  NOTE: like the reference, zero-fills ref/src in place when ``mask`` is None. """
+    if mask is None:
+        mask = ~nan_equals(src_array, np.nan) & ~nan_equals(ref_array, np.nan)  # :160-163
+        ref_array[~mask] = 0
+        src_array[~mask] = 0
+    if mask_sum is None:
+        mask_sum = box_sum(mask.astype(F32), kernel_shape)  # :167
+    if ref_sum is None:
+        ref_sum = box_sum(ref_array, kernel_shape)  # :169
+    if ref2_sum is None:
+        ref2_sum = box_sum(ref_array, kernel_shape, square=True)  # :171
+    if src2_sum is None:
+        src2_sum = box_sum(src_array, kernel_shape, square=True)  # :173
+    if src_ref_sum is None:
+        src_ref_sum = box_sum(src_array * ref_array, kernel_shape)  # :175
+
+    ss_tot_array = (mask_sum * ref2_sum) - (ref_sum ** 2)  # :179
+
+    if param_array.shape[0] > 1:
+        if src_sum is None:
+            src_sum = box_sum(src_array, kernel_shape)  # :184
+        ss_res_array = (
+            ((param_array[0] ** 2) * src2_sum) +
+            (2 * np.prod(param_array[:2], axis=0) * src_sum) -
+            (2 * param_array[0] * src_ref_sum) -
+            (2 * param_array[1] * ref_sum) +
+            ref2_sum + (mask_sum * (param_array[1] ** 2))
+        )  # :189-195
+    else:
+        ss_res_array = (((param_array[0] ** 2) * src2_sum) - (2 * param_array[0] * src_ref_sum) + ref2_sum)  # :201
+
+    ss_res_array *= mask_sum  # :203
+
+    if dest_array is None:
+        dest_array = np.full(src_array.shape, fill_value=np.nan, dtype=F32)  # :207-209
+
+    with np.errstate(all='ignore'):
+        np.divide(ss_res_array, ss_tot_array, out=dest_array, where=mask)  # :212
+        np.subtract(1, dest_array, out=dest_array, where=mask)  # :213
+    return dest_array
+
+
+def fit_block_norm(src, src_nodata, ref, ref_nodata) -> np.ndarray:
+    """ kernel_model.py:216-229 """
+    norm_model = np.zeros(2)
+    mask = mask_of(ref, ref_nodata) & mask_of(src, src_nodata)
+    if not np.any(mask):
+        return norm_model
+    with np.errstate(all='ignore'):
+        norm_model[0] = np.std(ref[mask]) / np.std(src[mask])
+        norm_model[1] = np.percentile(ref[mask], 1) - np.percentile(src[mask], 1) * norm_model[0]
+    return norm_model
+
+
+def _fit_gain_arrays(src_array, src_mask, ref_array, ref_mask, kernel_shape, find_r2):
+    """ kernel_model.py:231-274 on already-copied arrays (src may be float64 for gain-blk-offset). """
+    mask = ref_mask & src_mask  # :245
+    ref_array[~mask] = 0  # :246
+    src_array[~mask] = 0  # :247
+    src_sum = box_sum(src_array, kernel_shape)  # :257
+    ref_sum = box_sum(ref_array, kernel_shape)  # :258
+    param = np.full((3 if find_r2 else 2, *src_array.shape), np.nan, dtype=F32)  # :261
+    param[1, mask] = 0  # :262
+    with np.errstate(all='ignore'):
+        np.divide(ref_sum, src_sum, out=param[0], where=mask)  # :265
+    if find_r2:
+        r2_array(
+            ref_array, src_array, param[:1], mask=mask, ref_sum=ref_sum, src_sum=src_sum, dest_array=param[2],
+            kernel_shape=kernel_shape
+        )  # :269-272
+    return param
+
+
+def fit_gain(src, src_nodata, ref, ref_nodata, kernel_shape=(5, 5), find_r2=False) -> np.ndarray:
+    """ Model.gain: kernel_model.py:231-274.  Returns params (2|3, H, W) float32. """
+    src_array = np.array(src, dtype=F32, copy=True)
+    ref_array = np.array(ref, dtype=F32, copy=True)
+    return _fit_gain_arrays(
+        src_array, mask_of(src_array, src_nodata), ref_array, mask_of(ref_array, ref_nodata), kernel_shape, find_r2
+    )
+
+
+def fit_gain_blk_offset(
+    src, src_nodata, ref, ref_nodata, kernel_shape=(5, 5), find_r2=False, norm_model: Optional[np.ndarray] = None
+) -> Tuple[np.ndarray, np.ndarray]:
+    """
+    Model.gain_blk_offset: kernel_model.py:276-303, NumPy>=2 flavour (``src * np.float64`` promotes to float64).
+    ``norm_model`` may be injected (float64[2]) to isolate the window part from the block statistics.
+    Returns (params, norm_model).
+    """
+    src_array = np.array(src, dtype=F32, copy=True)
+    ref_array = np.array(ref, dtype=F32, copy=True)
+    if norm_model is None:
+        norm_model = fit_block_norm(src_array, src_nodata, ref_array, ref_nodata)  # :289
+    norm_model = np.asarray(norm_model, dtype=np.float64)
+    # src_ra.nodata = nan (:292; raster_array.py:334-351): masked pixels become nan, nodata None -> nan w/o change
+    if src_nodata is not None and not nan_equals(np.nan, src_nodata):
+        src_array[~mask_of(src_array, src_nodata)] = np.nan
+    with np.errstate(all='ignore'):
+        src_norm = (src_array * norm_model[0]) + norm_model[1]  # :295 -- float64 under NumPy>=2
+    assert src_norm.dtype == np.float64
+    param = _fit_gain_arrays(
+        src_norm, mask_of(src_norm, np.nan), ref_array, mask_of(ref_array, ref_nodata), kernel_shape, find_r2
+    )  # :298
+    with np.errstate(all='ignore'):
+        param[1] = param[0] * norm_model[1]  # :301
+        param[0] *= norm_model[0]  # :302
+    return param, norm_model
+
+
+def fit_gain_offset(
+    src, src_nodata, ref, ref_nodata, kernel_shape=(5, 5), find_r2=False, r2_inpaint_thresh: Optional[float] = 0.25
+) -> Tuple[np.ndarray, int]:
+    """
+    Model.gain_offset: kernel_model.py:305-373.
+    Returns (params, n_fail) where n_fail is the number of valid pixels failing the r2 mask test (:363).  The GDAL
+    ``fillnodata`` in-painting itself (:366) lives outside /root/reference and is NOT restated: when n_fail == 0 it
+    is the identity on valid pixels and the branch below reproduces the reference exactly; when n_fail > 0 the
+    params are returned as they stand BEFORE in-painting (callers must treat that case separately).
+    """
+    src_array = np.array(src, dtype=F32, copy=True)
+    ref_array = np.array(ref, dtype=F32, copy=True)
+    mask = mask_of(ref_array, ref_nodata) & mask_of(src_array, src_nodata)  # :319
+    ref_array[~mask] = 0
+    src_array[~mask] = 0
+    _find_r2 = find_r2 or (r2_inpaint_thresh is not None)  # :325
+
+    src_sum = box_sum(src_array, kernel_shape)  # :332
+    ref_sum = box_sum(ref_array, kernel_shape)  # :333
+    src_ref_sum = box_sum(src_array * ref_array, kernel_shape)  # :334
+    mask_sum = box_sum(mask.astype(F32), kernel_shape)  # :335-337
+    with np.errstate(all='ignore'):
+        m_num_array = (mask_sum * src_ref_sum) - (src_sum * ref_sum)  # :338
+        src2_sum = box_sum(src_array, kernel_shape, square=True)  # :341
+        m_den_array = (mask_sum * src2_sum) - (src_sum ** 2)  # :342
+
+        param = np.full((3 if _find_r2 else 2, *src_array.shape), np.nan, dtype=F32)  # :345
+        np.divide(m_num_array, m_den_array, out=param[0], where=mask)  # :348
+        np.divide(ref_sum - (param[0] * src_sum), mask_sum, out=param[1], where=mask)  # :351
+
+        if _find_r2:
+            r2_array(
+                ref_array, src_array, param[:2], mask=mask, mask_sum=mask_sum, ref_sum=ref_sum, src_sum=src_sum,
+                src2_sum=src2_sum, src_ref_sum=src_ref_sum, dest_array=param[2], kernel_shape=kernel_shape
+            )  # :355-359
+
+        n_fail = 0
+        if r2_inpaint_thresh is not None:
+            r2_mask = (param[2] > r2_inpaint_thresh) & (param[0] > 0) & mask  # :363
+            n_fail = int(np.count_nonzero(~r2_mask & mask))
+            if n_fail == 0:
+                # fillnodata(offset, r2_mask) leaves r2_mask pixels untouched and fills the rest (all of which are
+                # ~mask here); ``param_ra.mask = mask`` (:367) then resets every band at ~mask to nan.
+                param[:, ~mask] = np.nan
+                # :370-371 is a no-op (its where-mask ``~r2_mask & mask`` is empty)
+    return param, n_fail
+
+
+def apply(src, param) -> np.ndarray:
+    """ kernel_model.py:461 -- two float32 roundings, no FMA. """
+    with np.errstate(all='ignore'):
+        return (param[0] * np.asarray(src, dtype=F32)) + param[1]
+
+
+def fit(model: str, src, src_nodata, ref, ref_nodata, kernel_shape=(5, 5), find_r2=False, r2_inpaint_thresh=0.25,
+        norm_model=None):
+    """ kernel_model.py:411-440 dispatch.  Returns (params, aux) with aux = norm_model | n_fail | None. """
+    if model == 'gain':
+        return fit_gain(src, src_nodata, ref, ref_nodata, kernel_shape, find_r2), None
+    elif model == 'gain-blk-offset':
+        return fit_gain_blk_offset(src, src_nodata, ref, ref_nodata, kernel_shape, find_r2, norm_model)
+    elif model == 'gain-offset':
+        return fit_gain_offset(src, src_nodata, ref, ref_nodata, kernel_shape, find_r2, r2_inpaint_thresh)
+    raise ValueError(model)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# synthetic workload generator -- shared by golden generation, tests and the CPU-baseline sample
+def synth_pair(h: int, w: int, seed: int = 0, nodata_variant: str = 'none', dn_like: bool = False):
+    """
+    ``src ~ U[0.05, 1)``, ``ref = f32(g(x,y)*src + o(y) + N(0, 0.01))`` with smooth gain/offset fields.
+    nodata_variant: 'none' | 'frame+holes' (3-px NaN frame + 0.1 % random NaN pixels, independently in src & ref).
+    """
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    if dn_like:
+        src = rng.normal(1000., 150., (h, w)).astype(F32)
+        noise = rng.normal(0., 5., (h, w))
+    else:
+        src = rng.uniform(0.05, 1.0, (h, w)).astype(F32)
+        noise = rng.normal(0., 0.01, (h, w))
+    g = 1.2 + 0.3 * np.sin(xx / 97.) * np.cos(yy / 131.)
+    o = 0.05 * (1 + 0.5 * np.sin(yy / 211.))
+    if dn_like:
+        o = o * 1000.
+    ref = (g * src.astype(np.float64) + o + noise).astype(F32)
+    if nodata_variant == 'frame+holes':
+        for a in (src, ref):
+            a[:3, :] = np.nan
+            a[-3:, :] = np.nan
+            a[:, :3] = np.nan
+            a[:, -3:] = np.nan
+            holes = rng.random((h, w)) < 0.001
+            a[holes] = np.nan
+    elif nodata_variant != 'none':
+        raise ValueError(nodata_variant)
+    return src, ref

@@ -1,0 +1,63 @@
+""" pytest configuration: markers + shared golden-vector loaders. """
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+GOLDEN_DIR = os.path.join(REPO, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: test needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+def _nodata(v):
+    return None if v is None else (float('nan') if v == 'nan' else float(v))
+
+
+def load_golden_cases():
+    """ [(case dict with decoded nodata, lazily-indexed npz key prefix)] from tests/golden/manifest.json """
+    with open(os.path.join(GOLDEN_DIR, 'manifest.json')) as f:
+        manifest = json.load(f)
+    cases = []
+    for c in manifest['cases']:
+        c = dict(c)
+        c['src_nodata'] = _nodata(c['src_nodata'])
+        c['ref_nodata'] = _nodata(c['ref_nodata'])
+        c['kernel_shape'] = tuple(c['kernel_shape'])
+        cases.append(c)
+    return cases
+
+
+GOLDEN_CASES = load_golden_cases()
+
+
+def case_id(c):
+    k = c['kernel_shape']
+    return f"{c['name']}-{c['model']}-k{k[0]}x{k[1]}-r2{int(c['find_r2'])}-t{c['r2_inpaint_thresh']}-{c['variant']}"
+
+
+@pytest.fixture(scope='session')
+def goldens():
+    return np.load(os.path.join(GOLDEN_DIR, 'kernel_model_goldens.npz'))
+
+
+def assert_same_f32(actual, expected, what=''):
+    """ Bit-exact float32 comparison with NaN == NaN (any payload). """
+    actual = np.asarray(actual)
+    expected = np.asarray(expected)
+    assert actual.shape == expected.shape, f'{what}: shape {actual.shape} != {expected.shape}'
+    assert actual.dtype == expected.dtype, f'{what}: dtype {actual.dtype} != {expected.dtype}'
+    both_nan = np.isnan(actual) & np.isnan(expected)
+    same = (actual == expected) | both_nan
+    if not same.all():
+        idx = np.argwhere(~same)
+        i = tuple(idx[0])
+        raise AssertionError(
+            f'{what}: {idx.shape[0]} of {actual.size} elements differ; first at {i}: {actual[i]!r} != {expected[i]!r}'
+        )

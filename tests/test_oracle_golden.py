@@ -1,0 +1,83 @@
+"""
+CPU tests: the numpy oracle (oracle/oracle_np.py) against golden vectors produced by executing the reference's own
+kernel_model.py (oracle/gen_golden.py).  Bar: bit-exact float32 (NaN == NaN).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_CASES, GOLDEN_DIR, assert_same_f32, case_id
+from oracle import oracle_np as onp
+
+
+@pytest.mark.parametrize('case', GOLDEN_CASES, ids=case_id)
+def test_oracle_np_matches_reference_goldens(case, goldens):
+    src = goldens[f"in_{case['variant']}_src"]
+    ref = goldens[f"in_{case['variant']}_ref"]
+    exp_params = goldens[f"{case['name']}_params"]
+    exp_corr = goldens[f"{case['name']}_corr"]
+    assert not case['inpaint_had_holes']  # goldens never depend on the (un-restated) GDAL in-painting
+
+    params, aux = onp.fit(
+        case['model'], src, case['src_nodata'], ref, case['ref_nodata'], case['kernel_shape'], case['find_r2'],
+        case['r2_inpaint_thresh']
+    )
+    assert_same_f32(params, exp_params, 'params')
+    corr = onp.apply(src, params)
+    assert_same_f32(corr, exp_corr, 'corrected')
+    if case['model'] == 'gain-blk-offset':
+        np.testing.assert_array_equal(aux, goldens[f"{case['name']}_norm"])
+    if case['model'] == 'gain-offset' and case['r2_inpaint_thresh'] is not None:
+        assert aux == 0
+
+
+def test_oracle_np_known_answer_conftest_arrays():
+    """ reference tests/conftest.py:74-80 array vs itself, gain-offset 5x5: gain 1, offset 0, R2 1 (the known answer
+    behind tests/data/parameter/*PARAM*.tif and tests/test_kernel_model.py:41-81). """
+    g = np.load(os.path.join(GOLDEN_DIR, 'conftest_100cm_gain_offset_k5.npz'))
+    params, n_fail = onp.fit_gain_offset(g['src'], np.nan, g['src'].copy(), np.nan, (5, 5), True, 0.25)
+    assert_same_f32(params, g['params'], 'params')
+    mask = ~np.isnan(g['src'])
+    assert params[0][mask] == pytest.approx(1, abs=1e-2)
+    assert params[1][mask] == pytest.approx(0, abs=1e-2)
+    assert params[2][mask] == pytest.approx(1, abs=1e-3)
+    assert np.isnan(params[:, ~mask]).all()
+
+
+def test_box_sum_definition():
+    """ zero-border, centre-anchored, un-normalised; float64 accumulate -> input depth. """
+    x = np.arange(1, 13, dtype=np.float32).reshape(3, 4)
+    s = onp.box_sum(x, (3, 3))
+    assert s.dtype == np.float32
+    assert s[0, 0] == 1 + 2 + 5 + 6
+    assert s[1, 1] == x[0:3, 0:3].sum()
+    assert s[2, 3] == 7 + 8 + 11 + 12
+    s2 = onp.box_sum(x, (1, 3), square=True)
+    assert s2[0, 0] == 1 + 4 and s2[0, 1] == 1 + 4 + 9
+    s64 = onp.box_sum(x.astype(np.float64), (3, 1))
+    assert s64.dtype == np.float64 and s64[1, 0] == 1 + 5 + 9
+    # float64 accumulation: 2^24 + 1 + 1 is exact in f64, rounds once to f32
+    y = np.array([[2**24, 1, 1]], dtype=np.float32)
+    assert onp.box_sum(y, (1, 3))[0, 1] == np.float32(2**24 + 2)
+
+
+def test_reference_param_tif():
+    """
+    The reference's own golden data file tests/data/parameter/float_100cm_rgb_FUSE_cREF_mGAIN-OFFSET_k5_5_PARAM.tif
+    (decoded by oracle/decode_ref_param_tif.py), produced by the REAL homonim + OpenCV + GDAL stack: gain-offset 5x5,
+    r2_inpaint_thresh 0.25, source == reference == reference tests/conftest.py:74-80 array.  The oracle must
+    reproduce it bit-for-bit -- including the two pixels (16,4), (16,6) where gain = 1.0000079, which only happens
+    when sqrBoxFilter returns float64 (this is what pins the OpenCV boundary of the restatement).
+    """
+    g = np.load(os.path.join(GOLDEN_DIR, 'ref_param_tif.npz'))['params']
+    assert g.shape == (9, 20, 10)
+    src = np.array(range(1, 201), dtype='float32').reshape(20, 10)
+    src[:, [0, -1]] = np.nan
+    src[[0, -1], :] = np.nan
+    params, n_fail = onp.fit_gain_offset(src, np.nan, src.copy(), np.nan, (5, 5), True, 0.25)
+    assert n_fail == 0
+    for band_i in range(3):  # the file holds 3 identical source bands
+        for pi, pname in enumerate(('gain', 'offset', 'r2')):
+            assert_same_f32(params[pi], g[pi * 3 + band_i], f'{pname} (file band {pi * 3 + band_i + 1})')
+    assert params[0, 16, 4] == np.float32(1.0000079) and params[0, 16, 4] != 1  # the deviation is real
