@@ -1,0 +1,291 @@
+"""
+ctypes binding of include/homonim_hk.h (libhomonim_hk.so) -- the thin FFI layer between the Python host code and the
+hand-written HIP kernels.  This is the stub a homonim maintainer would add to homonim/kernel_model.py.
+
+There is NO CPU fallback: if the library is missing or no gfx950 device is present, every entry point raises
+``DeviceError`` loudly.
+"""
+import ctypes as C
+import math
+import os
+import threading
+from typing import Optional
+
+import numpy as np
+
+from homonim_amd.errors import DeviceError
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', 'libhomonim_hk.so')
+
+HK_OK, HK_ERR_ARG, HK_ERR_HIP, HK_ERR_NODEVICE, HK_ERR_UNSUPPORTED, HK_ERR_NOMEM = 0, -1, -2, -3, -4, -5
+MODEL_CODES = {'gain': 0, 'gain-blk-offset': 1, 'gain-offset': 2}
+NODATA_NONE, NODATA_NAN, NODATA_VALUE = 0, 1, 2
+
+
+class FitDesc(C.Structure):
+    _fields_ = [
+        ('model', C.c_int32), ('kh', C.c_int32), ('kw', C.c_int32), ('find_r2', C.c_int32),
+        ('has_r2_thresh', C.c_int32), ('r2_thresh', C.c_float), ('src_nodata_mode', C.c_int32),
+        ('src_nodata', C.c_float), ('ref_nodata_mode', C.c_int32), ('ref_nodata', C.c_float),
+    ]  # yapf: disable
+
+
+class DevJob(C.Structure):
+    _fields_ = [
+        ('src', C.c_void_p), ('ref', C.c_void_p), ('gain', C.c_void_p), ('offset', C.c_void_p), ('r2', C.c_void_p),
+        ('corr', C.c_void_p), ('norm', C.c_void_p), ('fail_count', C.c_void_p), ('n_bands', C.c_int32),
+        ('height', C.c_int32), ('width', C.c_int32), ('stride', C.c_int64), ('band_stride', C.c_int64),
+        ('seg_rows', C.c_int32), ('stream', C.c_int32),
+    ]  # yapf: disable
+
+
+_P = C.POINTER
+_f32p, _f64p, _u64p = _P(C.c_float), _P(C.c_double), _P(C.c_uint64)
+
+# name -> (restype, argtypes); kept in one table so tests can check every symbol of the header is exported
+SIGNATURES = {
+    'hk_backend_name': (C.c_char_p, []),
+    'hk_last_error': (C.c_char_p, []),
+    'hk_device_count': (C.c_int, [_P(C.c_int)]),
+    'hk_ctx_create': (C.c_int, [C.c_int, C.c_int, _P(C.c_void_p)]),
+    'hk_ctx_destroy': (C.c_int, [C.c_void_p]),
+    'hk_ctx_sync': (C.c_int, [C.c_void_p]),
+    'hk_block_norm': (C.c_int, [C.c_void_p, _P(FitDesc), _f32p, C.c_int64, _f32p, C.c_int64, C.c_int32, C.c_int32, _f64p]),
+    'hk_fit': (C.c_int, [C.c_void_p, _P(FitDesc), _f32p, C.c_int64, _f32p, C.c_int64, C.c_int32, C.c_int32, _f64p,
+                         _f32p, C.c_int32, _f64p, _u64p]),
+    'hk_apply': (C.c_int, [C.c_void_p, _f32p, C.c_int64, _f32p, C.c_int32, C.c_int32, _f32p]),
+    'hk_fit_apply': (C.c_int, [C.c_void_p, _P(FitDesc), _f32p, C.c_int64, _f32p, C.c_int64, C.c_int32, C.c_int32,
+                               _f64p, _f32p, C.c_int32, _f32p, _f64p, _u64p]),
+    'hk_dev_alloc': (C.c_int, [C.c_void_p, C.c_size_t, _P(C.c_void_p)]),
+    'hk_dev_free': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'hk_memcpy_h2d': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    'hk_memcpy_d2h': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    'hk_memset': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t]),
+    'hk_fit_apply_dev': (C.c_int, [C.c_void_p, _P(FitDesc), _P(DevJob)]),
+    'hk_block_norm_dev': (C.c_int, [C.c_void_p, _P(FitDesc), _P(DevJob), C.c_void_p]),
+    'hk_synth_fill_dev': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64,
+                                    C.c_int64, C.c_uint64, C.c_int32, C.c_int32]),
+    'hk_event_create': (C.c_int, [C.c_void_p, _P(C.c_void_p)]),
+    'hk_event_destroy': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'hk_event_record': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    'hk_event_elapsed_ms': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _P(C.c_float)]),
+    'hk_stream_sync': (C.c_int, [C.c_void_p, C.c_int32]),
+    'hk_selftest': (C.c_int, [C.c_void_p]),
+}  # yapf: disable
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def load_library():
+    """ dlopen libhomonim_hk.so and declare every prototype.  Raises DeviceError if it has not been built. """
+    global _lib
+    with _lib_lock:
+        if _lib is None:
+            if not os.path.exists(_LIB_PATH):
+                raise DeviceError(
+                    f'{_LIB_PATH} not found: build it with `python -m homonim_amd.build` (needs hipcc). '
+                    'homonim_amd has no CPU fallback.'
+                )
+            lib = C.CDLL(_LIB_PATH)
+            for name, (restype, argtypes) in SIGNATURES.items():
+                fn = getattr(lib, name)
+                fn.restype = restype
+                fn.argtypes = argtypes
+            _lib = lib
+    return _lib
+
+
+def _check(rc: int):
+    if rc == HK_OK:
+        return
+    msg = load_library().hk_last_error().decode('utf-8', 'replace')
+    if rc == HK_ERR_ARG:
+        raise ValueError(msg)
+    raise DeviceError(f'libhomonim_hk error {rc}: {msg}')
+
+
+def nodata_code(nodata):
+    """ RasterArray.nodata -> (mode, value) of the C ABI. """
+    if nodata is None:
+        return NODATA_NONE, 0.0
+    nodata = float(nodata)
+    if math.isnan(nodata):
+        return NODATA_NAN, float('nan')
+    return NODATA_VALUE, nodata
+
+
+def make_desc(model: str, kernel_shape, find_r2: bool, r2_inpaint_thresh: Optional[float], src_nodata, ref_nodata):
+    d = FitDesc()
+    d.model = MODEL_CODES[str(getattr(model, 'value', model))]
+    d.kh, d.kw = int(kernel_shape[0]), int(kernel_shape[1])
+    d.find_r2 = int(bool(find_r2))
+    d.has_r2_thresh = int(r2_inpaint_thresh is not None)
+    d.r2_thresh = float(r2_inpaint_thresh) if r2_inpaint_thresh is not None else 0.0
+    d.src_nodata_mode, d.src_nodata = nodata_code(src_nodata)
+    d.ref_nodata_mode, d.ref_nodata = nodata_code(ref_nodata)
+    return d
+
+
+def _as_f32_2d(a: np.ndarray, name: str) -> np.ndarray:
+    if a.ndim != 2:
+        raise ValueError(f'`{name}` must be 2-D')
+    if a.dtype != np.float32 or a.strides[1] != 4 or a.strides[0] % 4 != 0 or a.strides[0] < a.shape[1] * 4:
+        a = np.ascontiguousarray(a, dtype=np.float32)
+    return a
+
+
+def _ptr(a: np.ndarray, typ=_f32p):
+    return a.ctypes.data_as(typ)
+
+
+class Context:
+    """ One GPU context (hk_ctx): a device + a pool of streams.  Thread-safe; share it between worker threads. """
+
+    def __init__(self, device: int = 0, n_streams: int = 4):
+        self._lib = load_library()
+        h = C.c_void_p()
+        rc = self._lib.hk_ctx_create(int(device), int(n_streams), C.byref(h))
+        if rc != HK_OK:
+            raise DeviceError(
+                f"cannot create a GPU context on device {device}: {self._lib.hk_last_error().decode('utf-8', 'replace')}"
+            )
+        self._h = h
+        self.device = device
+        self.n_streams = n_streams
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self._lib.hk_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    def selftest(self):
+        _check(self._lib.hk_selftest(self._h))
+
+    def sync(self):
+        _check(self._lib.hk_ctx_sync(self._h))
+
+    # -- host-pointer calls (numpy in / numpy out) --------------------------------------------------------------------
+    def block_norm(self, desc: FitDesc, src: np.ndarray, ref: np.ndarray) -> np.ndarray:
+        src, ref = _as_f32_2d(src, 'src'), _as_f32_2d(ref, 'ref')
+        norm = np.zeros(2, np.float64)
+        _check(self._lib.hk_block_norm(self._h, C.byref(desc), _ptr(src), src.strides[0] // 4, _ptr(ref),
+                                       ref.strides[0] // 4, src.shape[0], src.shape[1], _ptr(norm, _f64p)))
+        return norm
+
+    def fit_apply(self, desc: FitDesc, src: np.ndarray, ref: np.ndarray, n_param_bands: int, want_params: bool,
+                  want_corr: bool, norm_in: Optional[np.ndarray] = None):
+        """ -> (params | None, corr | None, norm, r2_fail_count) """
+        src, ref = _as_f32_2d(src, 'src'), _as_f32_2d(ref, 'ref')
+        if src.shape != ref.shape:
+            raise ValueError("'ref_ra' and 'src_ra' must have the same CRS, transform and shape")
+        h, w = src.shape
+        params = np.empty((n_param_bands, h, w), np.float32) if want_params else None
+        corr = np.empty((h, w), np.float32) if want_corr else None
+        norm = np.zeros(2, np.float64)
+        fail = C.c_uint64(0)
+        nin = None
+        if norm_in is not None:
+            nin = np.ascontiguousarray(norm_in, dtype=np.float64)
+        args = (self._h, C.byref(desc), _ptr(src), src.strides[0] // 4, _ptr(ref), ref.strides[0] // 4, h, w,
+                _ptr(nin, _f64p) if nin is not None else None, _ptr(params) if want_params else None, n_param_bands)
+        if want_corr:
+            _check(self._lib.hk_fit_apply(*args, _ptr(corr), _ptr(norm, _f64p), C.byref(fail)))
+        else:
+            _check(self._lib.hk_fit(*args, _ptr(norm, _f64p), C.byref(fail)))
+        return params, corr, norm, int(fail.value)
+
+    def apply(self, src: np.ndarray, params: np.ndarray) -> np.ndarray:
+        src = _as_f32_2d(src, 'src')
+        params = np.ascontiguousarray(params[:2], dtype=np.float32)
+        if params.shape[-2:] != src.shape:
+            raise ValueError("'param_ra' and 'src_ra' must have the same CRS, transform and shape")
+        out = np.empty(src.shape, np.float32)
+        _check(self._lib.hk_apply(self._h, _ptr(src), src.strides[0] // 4, _ptr(params), src.shape[0], src.shape[1],
+                                  _ptr(out)))
+        return out
+
+    # -- device-resident helpers (bench / streaming) ------------------------------------------------------------------
+    def dev_alloc(self, nbytes: int) -> int:
+        p = C.c_void_p()
+        _check(self._lib.hk_dev_alloc(self._h, nbytes, C.byref(p)))
+        return p.value
+
+    def dev_free(self, dptr: int):
+        _check(self._lib.hk_dev_free(self._h, C.c_void_p(dptr)))
+
+    def h2d(self, dptr: int, arr: np.ndarray):
+        arr = np.ascontiguousarray(arr)
+        _check(self._lib.hk_memcpy_h2d(self._h, C.c_void_p(dptr), arr.ctypes.data_as(C.c_void_p), arr.nbytes))
+
+    def d2h(self, arr: np.ndarray, dptr: int, nbytes: Optional[int] = None):
+        assert arr.flags['C_CONTIGUOUS']
+        _check(self._lib.hk_memcpy_d2h(self._h, arr.ctypes.data_as(C.c_void_p), C.c_void_p(dptr),
+                                       arr.nbytes if nbytes is None else nbytes))
+
+    def memset(self, dptr: int, value: int, nbytes: int):
+        _check(self._lib.hk_memset(self._h, C.c_void_p(dptr), value, nbytes))
+
+    def fit_apply_dev(self, desc: FitDesc, job: DevJob):
+        _check(self._lib.hk_fit_apply_dev(self._h, C.byref(desc), C.byref(job)))
+
+    def block_norm_dev(self, desc: FitDesc, job: DevJob, norm_dptr: int):
+        _check(self._lib.hk_block_norm_dev(self._h, C.byref(desc), C.byref(job), C.c_void_p(norm_dptr)))
+
+    def synth_fill_dev(self, src_dptr, ref_dptr, n_bands, height, width, stride, band_stride, seed=0, nodata_variant=0,
+                       stream=0):
+        _check(self._lib.hk_synth_fill_dev(self._h, C.c_void_p(src_dptr), C.c_void_p(ref_dptr), n_bands, height, width,
+                                           stride, band_stride, seed, nodata_variant, stream))
+
+    def event(self) -> int:
+        e = C.c_void_p()
+        _check(self._lib.hk_event_create(self._h, C.byref(e)))
+        return e.value
+
+    def event_destroy(self, ev: int):
+        self._lib.hk_event_destroy(self._h, C.c_void_p(ev))
+
+    def event_record(self, ev: int, stream: int = 0):
+        _check(self._lib.hk_event_record(self._h, C.c_void_p(ev), stream))
+
+    def event_elapsed_ms(self, start: int, stop: int) -> float:
+        ms = C.c_float(0)
+        _check(self._lib.hk_event_elapsed_ms(self._h, C.c_void_p(start), C.c_void_p(stop), C.byref(ms)))
+        return float(ms.value)
+
+    def stream_sync(self, stream: int = 0):
+        _check(self._lib.hk_stream_sync(self._h, stream))
+
+
+_default_ctx = None
+_default_lock = threading.Lock()
+
+
+def default_context() -> Context:
+    """ Process-wide context on the device named by HOMONIM_AMD_DEVICE (else LOCAL_RANK, else 0). """
+    global _default_ctx
+    with _default_lock:
+        if _default_ctx is None:
+            dev = int(os.environ.get('HOMONIM_AMD_DEVICE', os.environ.get('LOCAL_RANK', '0')))
+            _default_ctx = Context(dev, n_streams=int(os.environ.get('HOMONIM_AMD_STREAMS', '4')))
+    return _default_ctx
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    load_library().hk_device_count(C.byref(n))
+    return int(n.value)

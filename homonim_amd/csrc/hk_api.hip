@@ -1,0 +1,513 @@
+// hk_api.hip -- C-ABI host layer of libhomonim_hk.so (declared in include/homonim_hk.h).
+//
+// Owns: one HIP device per context, a pool of streams each with a device staging slab, argument validation
+// (mirrors homonim/utils.py:104-133 and homonim/kernel_model.py:430-431,459-460 error behaviour as status codes),
+// and the dispatch to the gfx950 kernels in hk_kernels.hip / hk_norm.hip.  No global mutable state besides the
+// thread-local error string; any number of host threads may use one context (homonim/fuse.py:396-401).
+#include <hip/hip_runtime.h>
+
+#include <condition_variable>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "../../include/homonim_hk.h"
+#include "hk_kernels.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HK_HIP(expr)                                                                                       \
+    do {                                                                                                   \
+        hipError_t _e = (expr);                                                                            \
+        if (_e != hipSuccess)                                                                              \
+            return fail(HK_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+struct Slot {
+    hipStream_t stream = nullptr;
+    void* dev = nullptr;
+    size_t dev_bytes = 0;
+    bool busy = false;
+};
+
+constexpr int DEFAULT_SEG_ROWS = 128;
+constexpr int64_t ROW_ALIGN = 64;  // device rows padded to 64 elements (256 B)
+
+}  // namespace
+
+struct hk_ctx {
+    int device = 0;
+    std::vector<Slot> slots;
+    std::mutex mu;
+    std::condition_variable cv;
+    int xcd_remap = 0;
+};
+
+struct hk_event {
+    hipEvent_t ev;
+};
+
+namespace {
+
+struct SlotLease {
+    hk_ctx* ctx;
+    int idx;
+    SlotLease(hk_ctx* c) : ctx(c), idx(-1) {
+        std::unique_lock<std::mutex> lk(ctx->mu);
+        ctx->cv.wait(lk, [&] {
+            for (size_t i = 0; i < ctx->slots.size(); ++i)
+                if (!ctx->slots[i].busy) {
+                    idx = (int)i;
+                    return true;
+                }
+            return false;
+        });
+        ctx->slots[idx].busy = true;
+    }
+    ~SlotLease() {
+        {
+            std::lock_guard<std::mutex> lk(ctx->mu);
+            ctx->slots[idx].busy = false;
+        }
+        ctx->cv.notify_one();
+    }
+    Slot& slot() { return ctx->slots[idx]; }
+};
+
+int ensure_dev(Slot& s, size_t bytes) {
+    if (s.dev_bytes >= bytes) return HK_OK;
+    if (s.dev) {
+        HK_HIP(hipStreamSynchronize(s.stream));
+        HK_HIP(hipFree(s.dev));
+        s.dev = nullptr;
+        s.dev_bytes = 0;
+    }
+    const size_t want = bytes + bytes / 8;
+    if (hipMalloc(&s.dev, want) != hipSuccess) return fail(HK_ERR_NOMEM, "hipMalloc(%zu) failed", want);
+    s.dev_bytes = want;
+    return HK_OK;
+}
+
+bool needs_r2(const hk_fit_desc* d) {
+    return d->find_r2 || (d->model == HK_MODEL_GAIN_OFFSET && d->has_r2_thresh);
+}
+
+int validate_desc(const hk_fit_desc* d) {
+    if (!d) return fail(HK_ERR_ARG, "desc is NULL");
+    if (d->model < 0 || d->model > 2) return fail(HK_ERR_ARG, "unknown model %d", d->model);
+    // homonim/utils.py:121-132
+    if (d->kh < 1 || d->kw < 1) return fail(HK_ERR_ARG, "`kernel_shape` must be a minimum of one in both dimensions.");
+    if ((d->kh & 1) == 0 || (d->kw & 1) == 0) return fail(HK_ERR_ARG, "`kernel_shape` must be odd in both dimensions.");
+    if (d->model == HK_MODEL_GAIN_OFFSET && d->kh * d->kw < 2)
+        return fail(HK_ERR_ARG, "`kernel_shape` area should contain at least 2 elements for the gain-offset model.");
+    if (d->kh > 255) return fail(HK_ERR_UNSUPPORTED, "kernel height %d > 255 not supported", d->kh);
+    if (hk::overlap_lanes_for(d->kw / 2) > 24) return fail(HK_ERR_UNSUPPORTED, "kernel width %d too large", d->kw);
+    if (hk::fit_lds_bytes(d->kh) > 160 * 1024) return fail(HK_ERR_UNSUPPORTED, "kernel height %d exceeds the LDS ring", d->kh);
+    for (int m : {d->src_nodata_mode, d->ref_nodata_mode})
+        if (m < 0 || m > 2) return fail(HK_ERR_ARG, "bad nodata mode %d", m);
+    return HK_OK;
+}
+
+void fill_args(hk::FitArgs& a, const hk_fit_desc* d, int xcd_remap) {
+    a.rh = d->kh / 2;
+    a.rw = d->kw / 2;
+    a.overlap_lanes = hk::overlap_lanes_for(a.rw);
+    a.src_nd_mode = d->src_nodata_mode;
+    a.ref_nd_mode = d->ref_nodata_mode;
+    a.src_nodata = d->src_nodata;
+    a.ref_nodata = d->ref_nodata;
+    a.has_thresh = (d->model == HK_MODEL_GAIN_OFFSET) ? d->has_r2_thresh : 0;
+    a.r2_thresh = d->r2_thresh;
+    a.xcd_remap = xcd_remap;
+}
+
+void fill_grid(hk::FitArgs& a, int seg_rows) {
+    const int out_w = (hk::WAVE - 2 * a.overlap_lanes) * hk::PX;
+    a.seg_rows = seg_rows > 0 ? seg_rows : DEFAULT_SEG_ROWS;
+    if (a.seg_rows > a.height) a.seg_rows = a.height;
+    a.n_strips = (a.width + out_w - 1) / out_w;
+    a.n_segs = (a.height + a.seg_rows - 1) / a.seg_rows;
+    a.total_units = a.n_strips * a.n_segs * a.n_bands;
+}
+
+// The whole host-pointer path: stage in, (norm), fused kernel, stage out.  `corr_out`/`params_out` nullable.
+int run_host(hk_ctx* ctx, const hk_fit_desc* desc, const float* src, int64_t src_stride, const float* ref,
+             int64_t ref_stride, int32_t height, int32_t width, const double* norm_in, float* params_out,
+             int32_t n_param_bands, float* corr_out, double* norm_out, uint64_t* r2_fail_count, bool norm_only) {
+    if (!ctx) return fail(HK_ERR_ARG, "ctx is NULL");
+    int rc = validate_desc(desc);
+    if (rc) return rc;
+    if (!src || !ref) return fail(HK_ERR_ARG, "src/ref is NULL");
+    if (height < 1 || width < 1) return fail(HK_ERR_ARG, "empty raster %d x %d", height, width);
+    if (src_stride < width || ref_stride < width) return fail(HK_ERR_ARG, "row stride smaller than width");
+    const bool r2 = needs_r2(desc);
+    if (!norm_only) {
+        if (params_out && n_param_bands != (r2 ? 3 : 2))
+            return fail(HK_ERR_ARG, "n_param_bands must be %d for this model configuration", r2 ? 3 : 2);
+        if (!params_out && !corr_out) return fail(HK_ERR_ARG, "nothing to compute: params_out and corr_out are NULL");
+    }
+    HK_HIP(hipSetDevice(ctx->device));
+
+    const int64_t stride = (width + ROW_ALIGN - 1) / ROW_ALIGN * ROW_ALIGN;
+    const size_t plane = (size_t)stride * height * sizeof(float);
+    const bool blk = desc->model == HK_MODEL_GAIN_BLK_OFFSET;
+    const bool want_norm = blk || norm_only;
+    const size_t n_planes = 2 + (norm_only ? 0 : ((params_out ? (size_t)n_param_bands : 0) + (corr_out ? 1 : 0)));
+    const size_t aux_off = n_planes * plane;
+    const size_t ws_bytes = want_norm ? hk::norm_workspace_bytes(1) : 0;
+    const size_t total = aux_off + 256 + ws_bytes;
+
+    SlotLease lease(ctx);
+    Slot& sl = lease.slot();
+    rc = ensure_dev(sl, total);
+    if (rc) return rc;
+    char* base = static_cast<char*>(sl.dev);
+    float* d_src = reinterpret_cast<float*>(base);
+    float* d_ref = reinterpret_cast<float*>(base + plane);
+    size_t next = 2;
+    float *d_gain = nullptr, *d_off = nullptr, *d_r2 = nullptr, *d_corr = nullptr;
+    if (!norm_only) {
+        if (params_out) {
+            d_gain = reinterpret_cast<float*>(base + (next++) * plane);
+            d_off = reinterpret_cast<float*>(base + (next++) * plane);
+            if (n_param_bands == 3) d_r2 = reinterpret_cast<float*>(base + (next++) * plane);
+        }
+        if (corr_out) d_corr = reinterpret_cast<float*>(base + (next++) * plane);
+    }
+    double* d_norm = reinterpret_cast<double*>(base + aux_off);               // 2 doubles
+    unsigned long long* d_fail = reinterpret_cast<unsigned long long*>(base + aux_off + 64);
+    void* d_ws = base + aux_off + 256;
+
+    const size_t wbytes = (size_t)width * sizeof(float);
+    HK_HIP(hipMemcpy2DAsync(d_src, stride * sizeof(float), src, src_stride * sizeof(float), wbytes, height,
+                            hipMemcpyHostToDevice, sl.stream));
+    HK_HIP(hipMemcpy2DAsync(d_ref, stride * sizeof(float), ref, ref_stride * sizeof(float), wbytes, height,
+                            hipMemcpyHostToDevice, sl.stream));
+    HK_HIP(hipMemsetAsync(d_fail, 0, sizeof(unsigned long long), sl.stream));
+
+    if (want_norm) {
+        if (norm_in && !norm_only) {
+            HK_HIP(hipMemcpyAsync(d_norm, norm_in, 2 * sizeof(double), hipMemcpyHostToDevice, sl.stream));
+        } else {
+            hk::NormArgs na;
+            na.src = d_src, na.ref = d_ref, na.height = height, na.width = width, na.stride = stride;
+            na.band_stride = 0, na.n_bands = 1;
+            na.src_nd_mode = desc->src_nodata_mode, na.ref_nd_mode = desc->ref_nodata_mode;
+            na.src_nodata = desc->src_nodata, na.ref_nodata = desc->ref_nodata;
+            HK_HIP(hk::launch_block_norm(na, d_ws, d_norm, sl.stream));
+        }
+        if (norm_out) HK_HIP(hipMemcpyAsync(norm_out, d_norm, 2 * sizeof(double), hipMemcpyDeviceToHost, sl.stream));
+    }
+
+    if (!norm_only) {
+        hk::FitArgs a;
+        memset(&a, 0, sizeof(a));
+        a.src = d_src, a.ref = d_ref, a.gain = d_gain, a.offset = d_off, a.r2 = d_r2, a.corr = d_corr;
+        a.norm = blk ? d_norm : nullptr;
+        a.fail_count = d_fail;
+        a.height = height, a.width = width, a.stride = stride, a.band_stride = 0, a.n_bands = 1;
+        fill_args(a, desc, ctx->xcd_remap);
+        fill_grid(a, 0);
+        HK_HIP(hk::launch_fit_apply(a, desc->model, r2, sl.stream));
+
+        float* outs[4] = {d_gain, d_off, d_r2, nullptr};
+        if (params_out)
+            for (int b = 0; b < n_param_bands; ++b)
+                HK_HIP(hipMemcpy2DAsync(params_out + (size_t)b * height * width, wbytes, outs[b], stride * sizeof(float),
+                                        wbytes, height, hipMemcpyDeviceToHost, sl.stream));
+        if (corr_out)
+            HK_HIP(hipMemcpy2DAsync(corr_out, wbytes, d_corr, stride * sizeof(float), wbytes, height,
+                                    hipMemcpyDeviceToHost, sl.stream));
+        if (r2_fail_count)
+            HK_HIP(hipMemcpyAsync(r2_fail_count, d_fail, sizeof(uint64_t), hipMemcpyDeviceToHost, sl.stream));
+    }
+    HK_HIP(hipStreamSynchronize(sl.stream));
+    return HK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* hk_backend_name(void) { return "hip-gfx950"; }
+const char* hk_last_error(void) { return g_err; }
+
+int hk_device_count(int* count) {
+    if (!count) return fail(HK_ERR_ARG, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(HK_ERR_NODEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *count = n;
+    return HK_OK;
+}
+
+int hk_ctx_create(int device_id, int n_streams, hk_ctx** out) {
+    if (!out) return fail(HK_ERR_ARG, "ctx out-pointer is NULL");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 1)
+        return fail(HK_ERR_NODEVICE, "no HIP device available (libhomonim_hk needs an MI355X / gfx950 GPU)");
+    if (device_id < 0 || device_id >= n) return fail(HK_ERR_ARG, "device %d out of range [0, %d)", device_id, n);
+    if (n_streams < 1) n_streams = 1;
+    if (n_streams > 64) n_streams = 64;
+    HK_HIP(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    HK_HIP(hipGetDeviceProperties(&prop, device_id));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(HK_ERR_NODEVICE, "device %d is %s; this library is built for gfx950 only", device_id, prop.gcnArchName);
+    hk_ctx* ctx = new (std::nothrow) hk_ctx();
+    if (!ctx) return fail(HK_ERR_NOMEM, "out of host memory");
+    ctx->device = device_id;
+    ctx->slots.resize(n_streams);
+    const char* remap = getenv("HK_XCD_REMAP");
+    ctx->xcd_remap = remap ? atoi(remap) : 0;
+    for (auto& s : ctx->slots) {
+        hipError_t e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            hk_ctx_destroy(ctx);
+            return fail(HK_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+        }
+    }
+    *out = ctx;
+    return HK_OK;
+}
+
+int hk_ctx_destroy(hk_ctx* ctx) {
+    if (!ctx) return HK_OK;
+    hipSetDevice(ctx->device);
+    for (auto& s : ctx->slots) {
+        if (s.stream) hipStreamSynchronize(s.stream);
+        if (s.dev) hipFree(s.dev);
+        if (s.stream) hipStreamDestroy(s.stream);
+    }
+    delete ctx;
+    return HK_OK;
+}
+
+int hk_ctx_sync(hk_ctx* ctx) {
+    if (!ctx) return fail(HK_ERR_ARG, "ctx is NULL");
+    HK_HIP(hipSetDevice(ctx->device));
+    HK_HIP(hipDeviceSynchronize());
+    return HK_OK;
+}
+
+int hk_block_norm(hk_ctx* ctx, const hk_fit_desc* desc, const float* src, int64_t src_stride, const float* ref,
+                  int64_t ref_stride, int32_t height, int32_t width, double norm_out[2]) {
+    if (!norm_out) return fail(HK_ERR_ARG, "norm_out is NULL");
+    return run_host(ctx, desc, src, src_stride, ref, ref_stride, height, width, nullptr, nullptr, 0, nullptr, norm_out,
+                    nullptr, true);
+}
+
+int hk_fit(hk_ctx* ctx, const hk_fit_desc* desc, const float* src, int64_t src_stride, const float* ref,
+           int64_t ref_stride, int32_t height, int32_t width, const double* norm_in, float* params_out,
+           int32_t n_param_bands, double* norm_out, uint64_t* r2_fail_count) {
+    if (!params_out) return fail(HK_ERR_ARG, "params_out is NULL");
+    return run_host(ctx, desc, src, src_stride, ref, ref_stride, height, width, norm_in, params_out, n_param_bands,
+                    nullptr, norm_out, r2_fail_count, false);
+}
+
+int hk_fit_apply(hk_ctx* ctx, const hk_fit_desc* desc, const float* src, int64_t src_stride, const float* ref,
+                 int64_t ref_stride, int32_t height, int32_t width, const double* norm_in, float* params_out,
+                 int32_t n_param_bands, float* corr_out, double* norm_out, uint64_t* r2_fail_count) {
+    if (!corr_out) return fail(HK_ERR_ARG, "corr_out is NULL");
+    return run_host(ctx, desc, src, src_stride, ref, ref_stride, height, width, norm_in, params_out, n_param_bands,
+                    corr_out, norm_out, r2_fail_count, false);
+}
+
+int hk_apply(hk_ctx* ctx, const float* src, int64_t src_stride, const float* params, int32_t height, int32_t width,
+             float* out) {
+    if (!ctx) return fail(HK_ERR_ARG, "ctx is NULL");
+    if (!src || !params || !out) return fail(HK_ERR_ARG, "NULL pointer argument");
+    if (height < 1 || width < 1) return fail(HK_ERR_ARG, "empty raster %d x %d", height, width);
+    if (src_stride < width) return fail(HK_ERR_ARG, "row stride smaller than width");
+    HK_HIP(hipSetDevice(ctx->device));
+    const int64_t stride = (width + ROW_ALIGN - 1) / ROW_ALIGN * ROW_ALIGN;
+    const size_t plane = (size_t)stride * height * sizeof(float);
+    SlotLease lease(ctx);
+    Slot& sl = lease.slot();
+    int rc = ensure_dev(sl, 4 * plane);
+    if (rc) return rc;
+    char* base = static_cast<char*>(sl.dev);
+    float* d_src = reinterpret_cast<float*>(base);
+    float* d_gain = reinterpret_cast<float*>(base + plane);
+    float* d_off = reinterpret_cast<float*>(base + 2 * plane);
+    float* d_out = reinterpret_cast<float*>(base + 3 * plane);
+    const size_t wbytes = (size_t)width * sizeof(float);
+    HK_HIP(hipMemcpy2DAsync(d_src, stride * 4, src, src_stride * 4, wbytes, height, hipMemcpyHostToDevice, sl.stream));
+    HK_HIP(hipMemcpy2DAsync(d_gain, stride * 4, params, wbytes, wbytes, height, hipMemcpyHostToDevice, sl.stream));
+    HK_HIP(hipMemcpy2DAsync(d_off, stride * 4, params + (size_t)height * width, wbytes, wbytes, height,
+                            hipMemcpyHostToDevice, sl.stream));
+    HK_HIP(hk::launch_apply(d_src, d_gain, d_off, d_out, height, width, stride, sl.stream));
+    HK_HIP(hipMemcpy2DAsync(out, wbytes, d_out, stride * 4, wbytes, height, hipMemcpyDeviceToHost, sl.stream));
+    HK_HIP(hipStreamSynchronize(sl.stream));
+    return HK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+int hk_dev_alloc(hk_ctx* ctx, size_t bytes, void** dptr) {
+    if (!ctx || !dptr) return fail(HK_ERR_ARG, "NULL argument");
+    HK_HIP(hipSetDevice(ctx->device));
+    if (hipMalloc(dptr, bytes) != hipSuccess) return fail(HK_ERR_NOMEM, "hipMalloc(%zu) failed", bytes);
+    return HK_OK;
+}
+int hk_dev_free(hk_ctx* ctx, void* dptr) {
+    if (!ctx) return fail(HK_ERR_ARG, "ctx is NULL");
+    HK_HIP(hipSetDevice(ctx->device));
+    HK_HIP(hipFree(dptr));
+    return HK_OK;
+}
+int hk_memcpy_h2d(hk_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (!ctx) return fail(HK_ERR_ARG, "ctx is NULL");
+    HK_HIP(hipSetDevice(ctx->device));
+    HK_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return HK_OK;
+}
+int hk_memcpy_d2h(hk_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (!ctx) return fail(HK_ERR_ARG, "ctx is NULL");
+    HK_HIP(hipSetDevice(ctx->device));
+    HK_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return HK_OK;
+}
+int hk_memset(hk_ctx* ctx, void* dst, int value, size_t bytes) {
+    if (!ctx) return fail(HK_ERR_ARG, "ctx is NULL");
+    HK_HIP(hipSetDevice(ctx->device));
+    HK_HIP(hipMemset(dst, value, bytes));
+    return HK_OK;
+}
+
+static int check_job(hk_ctx* ctx, const hk_dev_job* job) {
+    if (!ctx || !job) return fail(HK_ERR_ARG, "NULL argument");
+    if (!job->src || !job->ref) return fail(HK_ERR_ARG, "job src/ref is NULL");
+    if (job->n_bands < 1 || job->height < 1 || job->width < 1) return fail(HK_ERR_ARG, "empty job");
+    if (job->stride < job->width || (job->stride % hk::PX) != 0)
+        return fail(HK_ERR_ARG, "job stride must be >= width and a multiple of %d elements", hk::PX);
+    if ((job->band_stride % hk::PX) != 0) return fail(HK_ERR_ARG, "band_stride must be a multiple of %d", hk::PX);
+    if (((uintptr_t)job->src | (uintptr_t)job->ref | (uintptr_t)job->gain | (uintptr_t)job->offset |
+         (uintptr_t)job->r2 | (uintptr_t)job->corr) & 15)
+        return fail(HK_ERR_ARG, "device planes must be 16-byte aligned");
+    if (job->stream < 0 || job->stream >= (int)ctx->slots.size()) return fail(HK_ERR_ARG, "bad stream index");
+    return HK_OK;
+}
+
+int hk_fit_apply_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* job) {
+    int rc = validate_desc(desc);
+    if (rc) return rc;
+    rc = check_job(ctx, job);
+    if (rc) return rc;
+    if (desc->model == HK_MODEL_GAIN_BLK_OFFSET && !job->norm) return fail(HK_ERR_ARG, "gain-blk-offset needs job->norm");
+    HK_HIP(hipSetDevice(ctx->device));
+    hk::FitArgs a;
+    memset(&a, 0, sizeof(a));
+    a.src = job->src, a.ref = job->ref, a.gain = job->gain, a.offset = job->offset, a.r2 = job->r2, a.corr = job->corr;
+    a.norm = job->norm;
+    a.fail_count = reinterpret_cast<unsigned long long*>(job->fail_count);
+    a.height = job->height, a.width = job->width, a.stride = job->stride, a.band_stride = job->band_stride;
+    a.n_bands = job->n_bands;
+    fill_args(a, desc, ctx->xcd_remap);
+    fill_grid(a, job->seg_rows);
+    HK_HIP(hk::launch_fit_apply(a, desc->model, needs_r2(desc), ctx->slots[job->stream].stream));
+    return HK_OK;
+}
+
+int hk_block_norm_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* job, double* norm_dev) {
+    int rc = validate_desc(desc);
+    if (rc) return rc;
+    rc = check_job(ctx, job);
+    if (rc) return rc;
+    if (!norm_dev) return fail(HK_ERR_ARG, "norm_dev is NULL");
+    HK_HIP(hipSetDevice(ctx->device));
+    Slot& sl = ctx->slots[job->stream];
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);  // the slab doubles as workspace of this stream
+        rc = ensure_dev(sl, hk::norm_workspace_bytes(job->n_bands));
+    }
+    if (rc) return rc;
+    hk::NormArgs na;
+    na.src = job->src, na.ref = job->ref, na.height = job->height, na.width = job->width, na.stride = job->stride;
+    na.band_stride = job->band_stride, na.n_bands = job->n_bands;
+    na.src_nd_mode = desc->src_nodata_mode, na.ref_nd_mode = desc->ref_nodata_mode;
+    na.src_nodata = desc->src_nodata, na.ref_nodata = desc->ref_nodata;
+    HK_HIP(hk::launch_block_norm(na, sl.dev, norm_dev, sl.stream));
+    return HK_OK;
+}
+
+int hk_synth_fill_dev(hk_ctx* ctx, float* src, float* ref, int32_t n_bands, int32_t height, int32_t width,
+                      int64_t stride, int64_t band_stride, uint64_t seed, int32_t nodata_variant, int32_t stream) {
+    if (!ctx || !src || !ref) return fail(HK_ERR_ARG, "NULL argument");
+    if (stream < 0 || stream >= (int)ctx->slots.size()) return fail(HK_ERR_ARG, "bad stream index");
+    HK_HIP(hipSetDevice(ctx->device));
+    HK_HIP(hk::launch_synth_fill(src, ref, n_bands, height, width, stride, band_stride, seed, nodata_variant,
+                                 ctx->slots[stream].stream));
+    return HK_OK;
+}
+
+int hk_event_create(hk_ctx* ctx, hk_event** ev) {
+    if (!ctx || !ev) return fail(HK_ERR_ARG, "NULL argument");
+    HK_HIP(hipSetDevice(ctx->device));
+    hk_event* e = new (std::nothrow) hk_event();
+    if (!e) return fail(HK_ERR_NOMEM, "out of host memory");
+    hipError_t he = hipEventCreate(&e->ev);
+    if (he != hipSuccess) {
+        delete e;
+        return fail(HK_ERR_HIP, "hipEventCreate: %s", hipGetErrorString(he));
+    }
+    *ev = e;
+    return HK_OK;
+}
+int hk_event_destroy(hk_ctx* ctx, hk_event* ev) {
+    if (!ctx || !ev) return HK_OK;
+    hipEventDestroy(ev->ev);
+    delete ev;
+    return HK_OK;
+}
+int hk_event_record(hk_ctx* ctx, hk_event* ev, int32_t stream) {
+    if (!ctx || !ev) return fail(HK_ERR_ARG, "NULL argument");
+    if (stream < 0 || stream >= (int)ctx->slots.size()) return fail(HK_ERR_ARG, "bad stream index");
+    HK_HIP(hipEventRecord(ev->ev, ctx->slots[stream].stream));
+    return HK_OK;
+}
+int hk_event_elapsed_ms(hk_ctx* ctx, hk_event* start, hk_event* stop, float* ms) {
+    if (!ctx || !start || !stop || !ms) return fail(HK_ERR_ARG, "NULL argument");
+    HK_HIP(hipEventSynchronize(stop->ev));
+    HK_HIP(hipEventElapsedTime(ms, start->ev, stop->ev));
+    return HK_OK;
+}
+int hk_stream_sync(hk_ctx* ctx, int32_t stream) {
+    if (!ctx) return fail(HK_ERR_ARG, "ctx is NULL");
+    if (stream < 0 || stream >= (int)ctx->slots.size()) return fail(HK_ERR_ARG, "bad stream index");
+    HK_HIP(hipStreamSynchronize(ctx->slots[stream].stream));
+    return HK_OK;
+}
+
+int hk_selftest(hk_ctx* ctx) {
+    if (!ctx) return fail(HK_ERR_ARG, "ctx is NULL");
+    HK_HIP(hipSetDevice(ctx->device));
+    int* d = nullptr;
+    HK_HIP(hipMalloc(&d, sizeof(int)));
+    HK_HIP(hipMemset(d, 0, sizeof(int)));
+    HK_HIP(hk::launch_selftest(d, ctx->slots[0].stream));
+    HK_HIP(hipStreamSynchronize(ctx->slots[0].stream));
+    int code = -1;
+    HK_HIP(hipMemcpy(&code, d, sizeof(int), hipMemcpyDeviceToHost));
+    HK_HIP(hipFree(d));
+    if (code != 0) return fail(HK_ERR_HIP, "cross-lane self-test failed (code 0x%x)", code);
+    return HK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,67 @@
+// hk_kernels.h -- launch interface between the C-ABI host layer (hk_api.hip) and the gfx950 kernels (hk_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hk {
+
+constexpr int PX = 4;      // pixels per lane per row (one 16-byte load)
+constexpr int WAVE = 64;   // gfx950 wavefront
+
+// Device-side argument block of the fused fit(+apply) kernel.  One wave = one (band, row-segment, column-strip) unit.
+struct FitArgs {
+    const float* src;
+    const float* ref;
+    float* gain;
+    float* offset;
+    float* r2;
+    float* corr;
+    const double* norm;              // n_bands x 2 (gain-blk-offset)
+    unsigned long long* fail_count;  // n_bands
+    int height, width;
+    long long stride;       // elements between rows
+    long long band_stride;  // elements between planes
+    int n_bands;
+    int seg_rows;           // output rows per unit
+    int n_strips, n_segs;   // units per band = n_strips * n_segs
+    int total_units;
+    int rh, rw;             // kernel radii (kh = 2*rh+1, kw = 2*rw+1)
+    int overlap_lanes;      // lanes per side that only feed neighbours: ceil(rw / PX)
+    int src_nd_mode, ref_nd_mode;
+    float src_nodata, ref_nodata;
+    int has_thresh;
+    float r2_thresh;
+    int xcd_remap;          // 1: blockIdx -> unit remap that keeps neighbouring units on one XCD
+};
+
+// model: 0 gain, 1 gain-blk-offset, 2 gain-offset.  with_r2: compute the R2 quantity set.
+hipError_t launch_fit_apply(const FitArgs& a, int model, bool with_r2, hipStream_t stream);
+// LDS bytes one wave needs for its ring of kh raw rows.
+size_t fit_lds_bytes(int kh);
+// lanes per side that overlap with the neighbouring strip for kernel half-width rw
+inline int overlap_lanes_for(int rw) { return (rw + PX - 1) / PX; }
+
+hipError_t launch_apply(const float* src, const float* gain, const float* offset, float* out, int height, int width,
+                        long long stride, hipStream_t stream);
+
+// Block statistics for gain-blk-offset (kernel_model.py:216-229), per band.
+struct NormArgs {
+    const float* src;
+    const float* ref;
+    int height, width;
+    long long stride, band_stride;
+    int n_bands;
+    int src_nd_mode, ref_nd_mode;
+    float src_nodata, ref_nodata;
+};
+// workspace: see norm_workspace_bytes(); norm_out: n_bands x 2 float64 on device.
+size_t norm_workspace_bytes(int n_bands);
+hipError_t launch_block_norm(const NormArgs& a, void* workspace, double* norm_out, hipStream_t stream);
+
+hipError_t launch_synth_fill(float* src, float* ref, int n_bands, int height, int width, long long stride,
+                             long long band_stride, unsigned long long seed, int nodata_variant, hipStream_t stream);
+
+// returns 0 on pass; writes a diagnostic code otherwise
+hipError_t launch_selftest(int* result_dev, hipStream_t stream);
+
+}  // namespace hk

@@ -1,0 +1,699 @@
+// hk_kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the homonim kernel-model hot path.
+//
+// Reference behaviour being reproduced: homonim/kernel_model.py (v0.4.3)
+//   _fit_gain :231-274, _fit_gain_blk_offset :276-303, _fit_gain_offset :305-373, _r2_array :142-214, apply :442-463,
+// with OpenCV's boxFilter/sqrBoxFilter (zero border, un-normalised, float64 accumulation; sqrBoxFilter RETURNS
+// float64) folded in.  See DESIGN.md "Numerics contract" for the exact expression order this file mirrors.
+//
+// Design (one wave = one unit, no workgroup barriers, no MFMA -- this is an HBM/VALU-bound stencil):
+//   * a wave owns a column strip of 64 lanes x 4 px (one 16-byte load per lane per row per input) and marches down
+//     a row segment; overlap lanes at both strip edges only feed their neighbours, so waves never talk to each other;
+//   * vertical window sums are running float64 column sums (add entering row, subtract leaving row -- OpenCV's own
+//     ColumnSum order); the leaving row is re-read from a wave-private LDS ring of kh raw rows (36 B per lane-row);
+//   * horizontal window sums combine per-lane prefix/suffix partial sums with neighbours' through DPP wave shifts
+//     (v_mov_b32_dpp wave_shr:1 / wave_shl:1) -- no LDS traffic, no barriers;
+//   * the 2x2 normal-equation solve, R2, the r2-mask test and gain*src+offset run in registers on the four pixels,
+//     in the reference's float32/float64 operation order (compiled with -ffp-contract=off; *_rn intrinsics);
+//   * each input byte is read from HBM once (+ (64/(64-2*ol)) x (seg+2rh)/seg halo), each output written once.
+#include "hk_kernels.h"
+
+#include <type_traits>
+
+namespace hk {
+
+// ---------------------------------------------------------------------------------------------------------------------
+// cross-lane primitives
+__device__ __forceinline__ int dpp_from_left(int v) {  // value of lane-1; lane 0 receives 0
+    return __builtin_amdgcn_update_dpp(0, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+__device__ __forceinline__ int dpp_from_right(int v) {  // value of lane+1; lane 63 receives 0
+    return __builtin_amdgcn_update_dpp(0, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+}
+__device__ __forceinline__ double dpp_from_left(double v) {
+    int lo = dpp_from_left(__double2loint(v)), hi = dpp_from_left(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double dpp_from_right(double v) {
+    int lo = dpp_from_right(__double2loint(v)), hi = dpp_from_right(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+// Which part of the neighbour lane `j` lanes to the left/right falls inside the window of output pixel i (0..3):
+// 0 = nothing, 1..3 = suffix/prefix of that length, 4 = the whole lane.
+__host__ __device__ constexpr int left_len(int rw, int i, int j) {
+    int lo = i - rw, first = -PX * j;
+    return lo <= first ? PX : (lo <= first + PX - 1 ? PX - (lo - first) : 0);
+}
+__host__ __device__ constexpr int right_len(int rw, int i, int j) {
+    int hi = i + rw, first = PX * j;
+    return hi >= first + PX - 1 ? PX : (hi >= first ? hi - first + 1 : 0);
+}
+__host__ __device__ constexpr bool need_left_from(int rw, int j0, int len, int ol) {
+    for (int j = j0; j <= ol; ++j)
+        for (int i = 0; i < PX; ++i)
+            if (left_len(rw, i, j) == len) return true;
+    return false;
+}
+__host__ __device__ constexpr bool need_right_from(int rw, int j0, int len, int ol) {
+    for (int j = j0; j <= ol; ++j)
+        for (int i = 0; i < PX; ++i)
+            if (right_len(rw, i, j) == len) return true;
+    return false;
+}
+
+// compile-time loop: f(std::integral_constant<int, I>) for I in [B, E)
+template <int B, int E, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
+// Horizontal window sums of half-width RW over the wave's 256 columns: lane holds V[0..3] (its 4 columns), receives
+// H[i] = sum of columns [i-RW, i+RW].  Everything below is resolved at compile time into straight-line code:
+// per lane 6 adds for the prefix/suffix partial sums, then per neighbour distance the needed DPP moves + adds
+// (RW = 2: 4 shifted values, 9 adds per 4 pixels).
+template <int RW, typename T>
+__device__ __forceinline__ void hsum(const T (&V)[PX], T (&H)[PX]) {
+    if constexpr (RW == 0) {
+#pragma unroll
+        for (int i = 0; i < PX; ++i) H[i] = V[i];
+    } else {
+        constexpr int OL = (RW + PX - 1) / PX;
+        T pre[PX + 1], suf[PX + 1];  // pre[k] = V[0..k-1], suf[k] = V[4-k..3]
+        pre[1] = V[0];
+        pre[2] = V[0] + V[1];
+        pre[3] = pre[2] + V[2];
+        suf[1] = V[3];
+        suf[2] = V[2] + V[3];
+        suf[3] = V[1] + suf[2];
+        pre[4] = suf[4] = pre[2] + suf[2];
+        static_for<0, PX>([&](auto I) {
+            constexpr int i = decltype(I)::value, lo = i - RW, hi = i + RW;
+            if constexpr (lo <= 0 && hi >= PX - 1)
+                H[i] = pre[PX];
+            else if constexpr (lo <= 0)
+                H[i] = pre[hi + 1];
+            else
+                H[i] = suf[PX - lo];
+        });
+        T ls[PX + 1], rp[PX + 1];
+#pragma unroll
+        for (int k = 1; k <= PX; ++k) {
+            ls[k] = suf[k];
+            rp[k] = pre[k];
+        }
+        static_for<1, OL + 1>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            static_for<1, PX + 1>([&](auto K) {
+                constexpr int k = decltype(K)::value;
+                if constexpr (need_left_from(RW, j, k, OL)) ls[k] = dpp_from_left(ls[k]);
+                if constexpr (need_right_from(RW, j, k, OL)) rp[k] = dpp_from_right(rp[k]);
+            });
+            static_for<0, PX>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                constexpr int ll = left_len(RW, i, j), rl = right_len(RW, i, j);
+                if constexpr (ll > 0) H[i] = H[i] + ls[ll];
+                if constexpr (rl > 0) H[i] = H[i] + rp[rl];
+            });
+        });
+    }
+}
+
+// Run-time half-width (any odd kernel width the template list does not cover): same algebra through ds_bpermute.
+template <typename T>
+__device__ __forceinline__ void hsum_rt(const T (&V)[PX], T (&H)[PX], int rw, int ol, int lane) {
+    T pre[PX + 1], suf[PX + 1];
+    pre[1] = V[0];
+    pre[2] = V[0] + V[1];
+    pre[3] = pre[2] + V[2];
+    suf[1] = V[3];
+    suf[2] = V[2] + V[3];
+    suf[3] = V[1] + suf[2];
+    pre[4] = suf[4] = pre[2] + suf[2];
+#pragma unroll
+    for (int i = 0; i < PX; ++i) {
+        const int lo = i - rw, hi = i + rw;
+        H[i] = (lo <= 0 && hi >= PX - 1) ? pre[PX] : (lo <= 0 ? pre[hi + 1] : suf[PX - lo]);
+    }
+    for (int j = 1; j <= ol; ++j) {
+        const bool has_l = lane - j >= 0, has_r = lane + j < WAVE;
+#pragma unroll
+        for (int k = 1; k <= PX; ++k) {
+            T lv = __shfl(suf[k], (lane - j) & (WAVE - 1));
+            T rv = __shfl(pre[k], (lane + j) & (WAVE - 1));
+            lv = has_l ? lv : T(0);
+            rv = has_r ? rv : T(0);
+#pragma unroll
+            for (int i = 0; i < PX; ++i) {
+                if (left_len(rw, i, j) == k) H[i] = H[i] + lv;
+                if (right_len(rw, i, j) == k) H[i] = H[i] + rv;
+            }
+        }
+    }
+}
+
+template <int RW, typename T>
+__device__ __forceinline__ void hsum_any(const T (&V)[PX], T (&H)[PX], int rw, int ol, int lane) {
+    if constexpr (RW >= 0)
+        hsum<RW, T>(V, H);
+    else
+        hsum_rt<T>(V, H, rw, ol, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool px_valid(float v, int mode, float nodata) {
+    // ~utils.nan_equals(v, nodata) (utils.py:54-56); mode 0: nodata is None -> always valid (raster_array.py:302-303)
+    return mode == 0 ? true : (mode == 1 ? !(v != v) : !(v == nodata));
+}
+
+__device__ __forceinline__ float qnan() { return __int_as_float(0x7fc00000); }
+
+struct RowRaw {
+    float4 s, r;
+};
+
+__device__ __forceinline__ RowRaw load_row(const float* __restrict__ sp, const float* __restrict__ rp, long long stride,
+                                           int row, int height, int x, int width, bool lane_full, bool lane_any) {
+    RowRaw o;
+    o.s = make_float4(0.f, 0.f, 0.f, 0.f);
+    o.r = o.s;
+    if (row >= 0 && row < height) {  // wave-uniform
+        const long long off = (long long)row * stride + x;
+        if (lane_full) {
+            o.s = *reinterpret_cast<const float4*>(sp + off);
+            o.r = *reinterpret_cast<const float4*>(rp + off);
+        } else if (lane_any) {
+            float s[PX], r[PX];
+#pragma unroll
+            for (int i = 0; i < PX; ++i) {
+                const bool in = x + i >= 0 && x + i < width;
+                s[i] = in ? sp[off + i] : 0.f;
+                r[i] = in ? rp[off + i] : 0.f;
+            }
+            o.s = make_float4(s[0], s[1], s[2], s[3]);
+            o.r = make_float4(r[0], r[1], r[2], r[3]);
+        }
+    }
+    return o;
+}
+
+// A processed row as it sits in the LDS ring: zero-filled source/reference + one validity byte per pixel.
+struct RowZ {
+    float s[PX], r[PX];
+    unsigned m;  // byte i = mask of pixel i (0/1)
+};
+
+template <int MODEL>
+__device__ __forceinline__ RowZ process_row(const RowRaw& raw, bool row_ok, unsigned colbits, const FitArgs& a, double n0,
+                                            double n1) {
+    const float s[PX] = {raw.s.x, raw.s.y, raw.s.z, raw.s.w};
+    const float r[PX] = {raw.r.x, raw.r.y, raw.r.z, raw.r.w};
+    RowZ z;
+    z.m = 0;
+#pragma unroll
+    for (int i = 0; i < PX; ++i) {
+        bool m = row_ok && ((colbits >> i) & 1u) && px_valid(s[i], a.src_nd_mode, a.src_nodata) &&
+                 px_valid(r[i], a.ref_nd_mode, a.ref_nodata);
+        if constexpr (MODEL == 1) {
+            // gain-blk-offset: the mask is re-derived from the NORMALISED float64 source (kernel_model.py:292-298)
+            const double sd = __dadd_rn(__dmul_rn((double)s[i], n0), n1);
+            m = m && !(sd != sd);
+        }
+        z.s[i] = m ? s[i] : 0.f;
+        z.r[i] = m ? r[i] : 0.f;
+        z.m |= (m ? 1u : 0u) << (8 * i);
+    }
+    return z;
+}
+
+// Running float64 column sums of one wave.
+template <int MODEL, bool R2>
+struct ColSums {
+    static constexpr bool GO = MODEL == 2, BLK = MODEL == 1;
+    static constexpr bool NEED_N = GO || R2, NEED_P = GO || R2, NEED_S2 = GO || R2, NEED_R2S = R2;
+    double S[PX], R[PX], P[PX], S2[PX], R2s[PX];
+    unsigned N;  // packed bytes
+
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int i = 0; i < PX; ++i) S[i] = R[i] = P[i] = S2[i] = R2s[i] = 0.0;
+        N = 0;
+    }
+
+    template <bool ADD>
+    __device__ __forceinline__ void update(const RowZ& z, double n0, double n1) {
+#pragma unroll
+        for (int i = 0; i < PX; ++i) {
+            const bool m = (z.m >> (8 * i)) & 1u;
+            const double dr = (double)z.r[i];
+            if constexpr (BLK) {
+                // normalised source in float64 (NumPy>=2 promotion of `src * np.float64`, kernel_model.py:295)
+                const double sd = m ? __dadd_rn(__dmul_rn((double)z.s[i], n0), n1) : 0.0;
+                S[i] = ADD ? __dadd_rn(S[i], sd) : __dsub_rn(S[i], sd);
+                if constexpr (NEED_P) {
+                    const double p = __dmul_rn(sd, dr);
+                    P[i] = ADD ? __dadd_rn(P[i], p) : __dsub_rn(P[i], p);
+                }
+                if constexpr (NEED_S2) {
+                    const double q = __dmul_rn(sd, sd);
+                    S2[i] = ADD ? __dadd_rn(S2[i], q) : __dsub_rn(S2[i], q);
+                }
+            } else {
+                const double ds = (double)z.s[i];
+                S[i] = ADD ? __dadd_rn(S[i], ds) : __dsub_rn(S[i], ds);
+                if constexpr (NEED_P) {
+                    const double p = (double)__fmul_rn(z.s[i], z.r[i]);  // product rounded to f32 first (:175,:334)
+                    P[i] = ADD ? __dadd_rn(P[i], p) : __dsub_rn(P[i], p);
+                }
+                if constexpr (NEED_S2) S2[i] = __fma_rn(ADD ? ds : -ds, ds, S2[i]);  // ds*ds exact in f64
+            }
+            R[i] = ADD ? __dadd_rn(R[i], dr) : __dsub_rn(R[i], dr);
+            if constexpr (NEED_R2S) R2s[i] = __fma_rn(ADD ? dr : -dr, dr, R2s[i]);
+        }
+        if constexpr (NEED_N) N = ADD ? N + z.m : N - z.m;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The fused kernel.  MODEL: 0 gain, 1 gain-blk-offset, 2 gain-offset.  R2: compute the R2 quantity set.
+// RW: compile-time kernel half-width, or -1 for the run-time path.
+template <int MODEL, bool R2, int RW>
+__global__ void __launch_bounds__(WAVE) fit_apply_kernel(const FitArgs a) {
+    using CS = ColSums<MODEL, R2>;
+    constexpr bool GO = MODEL == 2, BLK = MODEL == 1;
+    extern __shared__ float4 lds4[];
+
+    const int lane = threadIdx.x;
+    int unit = blockIdx.x;
+    if (a.xcd_remap) {
+        const int per_xcd = gridDim.x >> 3;
+        unit = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    }
+    if (unit >= a.total_units) return;
+    const int strip = unit % a.n_strips;
+    const int t0 = unit / a.n_strips;
+    const int seg = t0 % a.n_segs;
+    const int band = t0 / a.n_segs;
+
+    const int rh = a.rh, kh = 2 * rh + 1;
+    const int rw = RW >= 0 ? RW : a.rw;
+    const int ol = RW >= 0 ? (RW + PX - 1) / PX : a.overlap_lanes;
+    const int out_lanes = WAVE - 2 * ol;
+    const int x = (strip * out_lanes + lane - ol) * PX;
+    const int y0 = seg * a.seg_rows;
+    const int y1 = min(y0 + a.seg_rows, a.height);
+    const int W = a.width, H = a.height;
+
+    const float* __restrict__ sp = a.src + (long long)band * a.band_stride;
+    const float* __restrict__ rp = a.ref + (long long)band * a.band_stride;
+    const long long out_base = (long long)band * a.band_stride;
+
+    const bool lane_full = x >= 0 && x + PX <= W;
+    const bool lane_any = x + PX > 0 && x < W;
+    unsigned colbits = 0;
+#pragma unroll
+    for (int i = 0; i < PX; ++i) colbits |= (x + i >= 0 && x + i < W) ? (1u << i) : 0u;
+    const bool out_lane = lane >= ol && lane < WAVE - ol && lane_any;
+
+    double n0 = 0.0, n1 = 0.0;
+    if constexpr (BLK) {
+        n0 = a.norm[2 * band];
+        n1 = a.norm[2 * band + 1];
+    }
+
+    // wave-private LDS ring of kh processed rows: [slot][s|r][lane] float4 + [slot][lane] mask words
+    float4* ring_v = lds4;
+    unsigned* ring_m = reinterpret_cast<unsigned*>(lds4 + (size_t)kh * 2 * WAVE);
+    for (int sl = 0; sl < kh; ++sl) {
+        ring_v[(sl * 2 + 0) * WAVE + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+        ring_v[(sl * 2 + 1) * WAVE + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+        ring_m[sl * WAVE + lane] = 0u;
+    }
+
+    CS cs;
+    cs.clear();
+
+    const int t_first = y0 - rh, t_last = y1 - 1 + rh;
+    // two rows in flight ahead of the one being consumed
+    RowRaw q0 = load_row(sp, rp, a.stride, t_first, H, x, W, lane_full, lane_any);
+    RowRaw q1 = load_row(sp, rp, a.stride, t_first + 1 <= t_last ? t_first + 1 : -1, H, x, W, lane_full, lane_any);
+
+    unsigned nfail = 0;
+    int slot = 0;
+    int slot_c = kh - rh;  // slot of the centre row of the output produced at this iteration: (slot - rh) mod kh
+    if (slot_c >= kh) slot_c -= kh;
+    for (int t = t_first; t <= t_last; ++t) {
+        const RowRaw q2 = load_row(sp, rp, a.stride, t + 2 <= t_last ? t + 2 : -1, H, x, W, lane_full, lane_any);
+
+        const RowZ znew = process_row<MODEL>(q0, t >= 0 && t < H, colbits, a, n0, n1);
+        // leaving row (t - kh): read from the slot the entering row is about to overwrite
+        RowZ zold;
+        {
+            const float4 os = ring_v[(slot * 2 + 0) * WAVE + lane];
+            const float4 orr = ring_v[(slot * 2 + 1) * WAVE + lane];
+            zold.s[0] = os.x, zold.s[1] = os.y, zold.s[2] = os.z, zold.s[3] = os.w;
+            zold.r[0] = orr.x, zold.r[1] = orr.y, zold.r[2] = orr.z, zold.r[3] = orr.w;
+            zold.m = ring_m[slot * WAVE + lane];
+        }
+        ring_v[(slot * 2 + 0) * WAVE + lane] = make_float4(znew.s[0], znew.s[1], znew.s[2], znew.s[3]);
+        ring_v[(slot * 2 + 1) * WAVE + lane] = make_float4(znew.r[0], znew.r[1], znew.r[2], znew.r[3]);
+        ring_m[slot * WAVE + lane] = znew.m;
+
+        if (kh == 1) {  // wave-uniform: a 1-row window IS the entering row -- no running sum, exact by construction
+            cs.clear();
+            cs.template update<true>(znew, n0, n1);
+        } else {
+            cs.template update<true>(znew, n0, n1);
+            cs.template update<false>(zold, n0, n1);
+        }
+
+        const int y = t - rh;
+        if (y >= y0) {  // wave-uniform: the first 2*rh iterations only prime the running sums
+            // centre row of the window
+            const float4 cs4 = ring_v[(slot_c * 2 + 0) * WAVE + lane];
+            const float sc[PX] = {cs4.x, cs4.y, cs4.z, cs4.w};
+            const unsigned mc = ring_m[slot_c * WAVE + lane];
+
+            double HS[PX], HR[PX];
+            hsum_any<RW, double>(cs.S, HS, rw, ol, lane);
+            hsum_any<RW, double>(cs.R, HR, rw, ol, lane);
+            double HP[PX], HS2[PX], HR2[PX];
+            int HN[PX];
+            if constexpr (CS::NEED_P) hsum_any<RW, double>(cs.P, HP, rw, ol, lane);
+            if constexpr (CS::NEED_S2) hsum_any<RW, double>(cs.S2, HS2, rw, ol, lane);
+            if constexpr (CS::NEED_R2S) hsum_any<RW, double>(cs.R2s, HR2, rw, ol, lane);
+            if constexpr (CS::NEED_N) {
+                const int VN[PX] = {(int)(cs.N & 0xffu), (int)((cs.N >> 8) & 0xffu), (int)((cs.N >> 16) & 0xffu),
+                                    (int)(cs.N >> 24)};
+                hsum_any<RW, int>(VN, HN, rw, ol, lane);
+            }
+
+            float g[PX], o[PX], r2v[PX], c[PX];
+#pragma unroll
+            for (int i = 0; i < PX; ++i) {
+                const bool m = (mc >> (8 * i)) & 1u;
+                const float Rf = (float)HR[i];  // boxFilter output depth = input depth (float32)
+                float gi, oi, r2i = qnan();
+                [[maybe_unused]] float Nf = 0.f, Pf = 0.f;
+                [[maybe_unused]] double Nd = 0.0;
+                if constexpr (CS::NEED_N) {
+                    Nf = (float)HN[i];
+                    Nd = (double)Nf;
+                }
+                if constexpr (GO) {
+                    // kernel_model.py:338-351; src2_sum is float64 (sqrBoxFilter) so m_den and the division are f64
+                    const float Sf = (float)HS[i];
+                    Pf = (float)HP[i];
+                    const float num = __fsub_rn(__fmul_rn(Nf, Pf), __fmul_rn(Sf, Rf));
+                    const double den = __dsub_rn(__dmul_rn(Nd, HS2[i]), (double)__fmul_rn(Sf, Sf));
+                    gi = (float)__ddiv_rn((double)num, den);
+                    oi = __fdiv_rn(__fsub_rn(Rf, __fmul_rn(gi, Sf)), Nf);
+                    if constexpr (R2) {
+                        // kernel_model.py:179,189-195,203,212-213
+                        const double sstot = __dsub_rn(__dmul_rn(Nd, HR2[i]), (double)__fmul_rn(Rf, Rf));
+                        const double A = __dmul_rn((double)__fmul_rn(gi, gi), HS2[i]);
+                        const float B = __fmul_rn(__fmul_rn(2.f, __fmul_rn(gi, oi)), Sf);
+                        const float C = __fmul_rn(__fmul_rn(2.f, gi), Pf);
+                        const float D = __fmul_rn(__fmul_rn(2.f, oi), Rf);
+                        const float F = __fmul_rn(Nf, __fmul_rn(oi, oi));
+                        double ssres = __dadd_rn(A, (double)B);
+                        ssres = __dsub_rn(ssres, (double)C);
+                        ssres = __dsub_rn(ssres, (double)D);
+                        ssres = __dadd_rn(ssres, HR2[i]);
+                        ssres = __dadd_rn(ssres, (double)F);
+                        ssres = __dmul_rn(ssres, Nd);
+                        r2i = __fsub_rn(1.f, (float)__ddiv_rn(ssres, sstot));
+                    }
+                } else if constexpr (BLK) {
+                    // kernel_model.py:265 with a float64 src_sum: np.divide(f32, f64, out=f32)
+                    const float gp = (float)__ddiv_rn((double)Rf, HS[i]);
+                    if constexpr (R2) {
+                        // kernel_model.py:179,201,203,212-213 with float64 src2_sum / src_ref_sum / ref2_sum
+                        const double sstot = __dsub_rn(__dmul_rn(Nd, HR2[i]), (double)__fmul_rn(Rf, Rf));
+                        double ssres = __dmul_rn((double)__fmul_rn(gp, gp), HS2[i]);
+                        ssres = __dsub_rn(ssres, __dmul_rn((double)__fmul_rn(2.f, gp), HP[i]));
+                        ssres = __dadd_rn(ssres, HR2[i]);
+                        ssres = __dmul_rn(ssres, Nd);
+                        r2i = __fsub_rn(1.f, (float)__ddiv_rn(ssres, sstot));
+                    }
+                    // kernel_model.py:301-302
+                    oi = (float)__dmul_rn((double)gp, n1);
+                    gi = (float)__dmul_rn((double)gp, n0);
+                } else {
+                    // kernel_model.py:262-265
+                    const float Sf = (float)HS[i];
+                    gi = __fdiv_rn(Rf, Sf);
+                    oi = 0.f;
+                    if constexpr (R2) {
+                        Pf = (float)HP[i];
+                        const double sstot = __dsub_rn(__dmul_rn(Nd, HR2[i]), (double)__fmul_rn(Rf, Rf));
+                        double ssres = __dmul_rn((double)__fmul_rn(gi, gi), HS2[i]);
+                        ssres = __dsub_rn(ssres, (double)__fmul_rn(__fmul_rn(2.f, gi), Pf));
+                        ssres = __dadd_rn(ssres, HR2[i]);
+                        ssres = __dmul_rn(ssres, Nd);
+                        r2i = __fsub_rn(1.f, (float)__ddiv_rn(ssres, sstot));
+                    }
+                }
+                // every parameter write in the reference is `where=mask` into a NaN-filled array (:261,:345)
+                g[i] = m ? gi : qnan();
+                o[i] = m ? oi : qnan();
+                r2v[i] = m ? r2i : qnan();
+                // KernelModel.apply (:461): two float32 roundings
+                c[i] = __fadd_rn(__fmul_rn(g[i], sc[i]), o[i]);
+                if constexpr (GO && R2) {
+                    // kernel_model.py:363,370: valid pixels failing (r2 > thresh) & (gain > 0) need in-painting
+                    if (a.has_thresh && out_lane && m && !((r2v[i] > a.r2_thresh) && (g[i] > 0.f))) ++nfail;
+                }
+            }
+
+            if (out_lane) {
+                const long long off = out_base + (long long)y * a.stride + x;
+                if (lane_full) {
+                    if (a.corr) *reinterpret_cast<float4*>(a.corr + off) = make_float4(c[0], c[1], c[2], c[3]);
+                    if (a.gain) *reinterpret_cast<float4*>(a.gain + off) = make_float4(g[0], g[1], g[2], g[3]);
+                    if (a.offset) *reinterpret_cast<float4*>(a.offset + off) = make_float4(o[0], o[1], o[2], o[3]);
+                    if (R2 && a.r2) *reinterpret_cast<float4*>(a.r2 + off) = make_float4(r2v[0], r2v[1], r2v[2], r2v[3]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < PX; ++i) {
+                        if ((colbits >> i) & 1u) {
+                            if (a.corr) a.corr[off + i] = c[i];
+                            if (a.gain) a.gain[off + i] = g[i];
+                            if (a.offset) a.offset[off + i] = o[i];
+                            if (R2 && a.r2) a.r2[off + i] = r2v[i];
+                        }
+                    }
+                }
+            }
+        }
+
+        q0 = q1;
+        q1 = q2;
+        if (++slot == kh) slot = 0;
+        if (++slot_c == kh) slot_c = 0;
+    }
+
+    if constexpr (GO && R2) {
+        if (a.fail_count != nullptr && a.has_thresh) {
+#pragma unroll
+            for (int d = WAVE / 2; d > 0; d >>= 1) nfail += __shfl_xor(nfail, d);
+            if (lane == 0 && nfail) atomicAdd(a.fail_count + band, (unsigned long long)nfail);
+        }
+    }
+}
+
+size_t fit_lds_bytes(int kh) { return (size_t)kh * (2 * WAVE * sizeof(float4) + WAVE * sizeof(unsigned)); }
+
+template <int MODEL, bool R2, int RW>
+static hipError_t launch_one(const FitArgs& a, hipStream_t stream) {
+    const size_t lds = fit_lds_bytes(2 * a.rh + 1);
+    static bool attr_set = false;  // raise the dynamic-LDS cap once per instantiation (64 KiB default)
+    if (lds > 64 * 1024 && !attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fit_apply_kernel<MODEL, R2, RW>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    int grid = a.total_units;
+    if (a.xcd_remap) grid = (grid + 7) / 8 * 8;
+    hipLaunchKernelGGL((fit_apply_kernel<MODEL, R2, RW>), dim3(grid), dim3(WAVE), lds, stream, a);
+    return hipGetLastError();
+}
+
+template <int MODEL, bool R2>
+static hipError_t launch_rw(const FitArgs& a, hipStream_t stream) {
+    switch (a.rw) {
+        case 0: return launch_one<MODEL, R2, 0>(a, stream);
+        case 1: return launch_one<MODEL, R2, 1>(a, stream);
+        case 2: return launch_one<MODEL, R2, 2>(a, stream);
+        case 3: return launch_one<MODEL, R2, 3>(a, stream);
+        case 7: return launch_one<MODEL, R2, 7>(a, stream);
+        default: return launch_one<MODEL, R2, -1>(a, stream);
+    }
+}
+
+hipError_t launch_fit_apply(const FitArgs& a, int model, bool with_r2, hipStream_t stream) {
+    switch (model * 2 + (with_r2 ? 1 : 0)) {
+        case 0: return launch_rw<0, false>(a, stream);
+        case 1: return launch_rw<0, true>(a, stream);
+        case 2: return launch_rw<1, false>(a, stream);
+        case 3: return launch_rw<1, true>(a, stream);
+        case 4: return launch_rw<2, false>(a, stream);
+        case 5: return launch_rw<2, true>(a, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// KernelModel.apply alone (kernel_model.py:461): used after parameters were re-sampled / in-painted on another grid.
+__global__ void __launch_bounds__(256) apply_kernel(const float* __restrict__ src, const float* __restrict__ gain,
+                                                    const float* __restrict__ offset, float* __restrict__ out,
+                                                    int height, int width, long long stride) {
+    const int x = (blockIdx.x * blockDim.x + threadIdx.x) * PX;
+    if (x >= width) return;
+    for (int y = blockIdx.y; y < height; y += gridDim.y) {
+        const long long off = (long long)y * stride + x;
+        if (x + PX <= width) {
+            const float4 s = *reinterpret_cast<const float4*>(src + off);
+            const float4 g = *reinterpret_cast<const float4*>(gain + off);
+            const float4 o = *reinterpret_cast<const float4*>(offset + off);
+            float4 c;
+            c.x = __fadd_rn(__fmul_rn(g.x, s.x), o.x);
+            c.y = __fadd_rn(__fmul_rn(g.y, s.y), o.y);
+            c.z = __fadd_rn(__fmul_rn(g.z, s.z), o.z);
+            c.w = __fadd_rn(__fmul_rn(g.w, s.w), o.w);
+            *reinterpret_cast<float4*>(out + off) = c;
+        } else {
+            for (int i = 0; x + i < width; ++i) out[off + i] = __fadd_rn(__fmul_rn(gain[off + i], src[off + i]), offset[off + i]);
+        }
+    }
+}
+
+hipError_t launch_apply(const float* src, const float* gain, const float* offset, float* out, int height, int width,
+                        long long stride, hipStream_t stream) {
+    const int threads = 256;
+    const int gx = (width + threads * PX - 1) / (threads * PX);
+    const int gy = height < 4096 ? height : 4096;
+    hipLaunchKernelGGL(apply_kernel, dim3(gx, gy), dim3(threads), 0, stream, src, gain, offset, out, height, width,
+                       stride);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Synthetic workload, generated in place in HBM: counter-based hash RNG, so any tile of the
+// raster can be regenerated independently.  Test / bench data only.
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
+    z += 0x9e3779b97f4a7c15ull;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ float u01(unsigned long long h) { return (float)(h >> 40) * (1.0f / 16777216.0f); }
+
+__global__ void __launch_bounds__(256) synth_kernel(float* __restrict__ src, float* __restrict__ ref, int n_bands,
+                                                    int height, int width, long long stride, long long band_stride,
+                                                    unsigned long long seed, int nodata_variant) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int band = blockIdx.z;
+    if (x >= width) return;
+    for (int y = blockIdx.y; y < height; y += gridDim.y) {
+        const unsigned long long key = ((unsigned long long)band << 56) ^ ((unsigned long long)y << 28) ^ (unsigned long long)x;
+        const unsigned long long h0 = mix64(key ^ mix64(seed));
+        const unsigned long long h1 = mix64(h0), h2 = mix64(h1), h3 = mix64(h2);
+        const float s = 0.05f + 0.95f * u01(h0);
+        const float u1 = fmaxf(u01(h1), 5.9604645e-8f), u2 = u01(h2);
+        const float z = sqrtf(-2.0f * __logf(u1)) * __cosf(6.2831853f * u2);
+        const float g = 1.2f + 0.3f * __sinf((float)x / 97.f) * __cosf((float)y / 131.f);
+        const float o = 0.05f * (1.f + 0.5f * __sinf((float)y / 211.f));
+        float r = g * s + o + 0.01f * z;
+        float sv = s;
+        if (nodata_variant == 1) {
+            const bool frame = x < 3 || y < 3 || x >= width - 3 || y >= height - 3;
+            if (frame || (h3 & 0xffffu) < 66u) sv = qnan();            // ~0.1 %
+            if (frame || ((h3 >> 16) & 0xffffu) < 66u) r = qnan();
+        }
+        const long long off = (long long)band * band_stride + (long long)y * stride + x;
+        src[off] = sv;
+        ref[off] = r;
+    }
+}
+
+hipError_t launch_synth_fill(float* src, float* ref, int n_bands, int height, int width, long long stride,
+                             long long band_stride, unsigned long long seed, int nodata_variant, hipStream_t stream) {
+    const int threads = 256;
+    const int gy = height < 2048 ? height : 2048;
+    hipLaunchKernelGGL(synth_kernel, dim3((width + threads - 1) / threads, gy, n_bands), dim3(threads), 0, stream, src,
+                       ref, n_bands, height, width, stride, band_stride, seed, nodata_variant);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Self-test of the DPP wave shifts + the compile-time horizontal sums against a brute-force definition.
+template <int RW>
+__device__ int hsum_check(int lane) {
+    double V[PX], Hd[PX];
+    int Vi[PX], Hi[PX];
+#pragma unroll
+    for (int i = 0; i < PX; ++i) {
+        Vi[i] = (lane * PX + i) * 3 + 1;
+        V[i] = (double)Vi[i] + 0.5;
+    }
+    hsum<RW, double>(V, Hd);
+    hsum<RW, int>(Vi, Hi);
+    constexpr int OL = (RW + PX - 1) / PX;
+    int bad = 0;
+    if (lane >= OL && lane < WAVE - OL) {
+#pragma unroll
+        for (int i = 0; i < PX; ++i) {
+            const int c = lane * PX + i;
+            int ei = 0;
+            double ed = 0.0;
+            for (int d = -RW; d <= RW; ++d) {
+                ei += (c + d) * 3 + 1;
+                ed += (double)((c + d) * 3 + 1) + 0.5;
+            }
+            if (Hi[i] != ei || Hd[i] != ed) bad = 1;
+        }
+    }
+    return bad;
+}
+
+__global__ void selftest_kernel(int* result) {
+    const int lane = threadIdx.x;
+    int code = 0;
+    const int l = dpp_from_left(lane + 100), r = dpp_from_right(lane + 100);
+    if (l != (lane == 0 ? 0 : lane + 99)) code |= 1;
+    if (r != (lane == WAVE - 1 ? 0 : lane + 101)) code |= 2;
+    const double dl = dpp_from_left((double)lane + 0.25);
+    if (dl != (lane == 0 ? 0.0 : (double)(lane - 1) + 0.25)) code |= 4;
+    if (hsum_check<1>(lane)) code |= 8;
+    if (hsum_check<2>(lane)) code |= 16;
+    if (hsum_check<3>(lane)) code |= 32;
+    if (hsum_check<7>(lane)) code |= 64;
+    {   // run-time path
+        int Vi[PX], Hi[PX];
+#pragma unroll
+        for (int i = 0; i < PX; ++i) Vi[i] = (lane * PX + i) * 3 + 1;
+        for (int rw = 1; rw <= 9; ++rw) {
+            const int ol = (rw + PX - 1) / PX;
+            hsum_rt<int>(Vi, Hi, rw, ol, lane);
+            if (lane >= ol && lane < WAVE - ol) {
+                for (int i = 0; i < PX; ++i) {
+                    int e = 0;
+                    for (int d = -rw; d <= rw; ++d) e += (lane * PX + i + d) * 3 + 1;
+                    if (Hi[i] != e) code |= 128;
+                }
+            }
+        }
+    }
+    if (code) atomicOr(result, code);
+}
+
+hipError_t launch_selftest(int* result_dev, hipStream_t stream) {
+    hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(WAVE), 0, stream, result_dev);
+    return hipGetLastError();
+}
+
+}  // namespace hk

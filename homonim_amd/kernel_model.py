@@ -1,0 +1,202 @@
+"""
+Sliding-window kernel models on the MI355X: host-side mirror of the reference's operator interface for the hot path.
+
+Same class / method names, argument meaning and error behaviour as homonim/kernel_model.py (``KernelModel`` :35-463,
+``RefSpaceModel`` :466-503, ``SrcSpaceModel`` :506-535), but ``fit`` / ``apply`` hand the block to hand-written HIP
+kernels through the C ABI of include/homonim_hk.h (ctypes, ``homonim_amd/_hk.py``).  Nothing here computes pixels on
+the CPU and there is no fallback: without the built library or a gfx950 device the calls raise ``DeviceError``.
+
+Differences a caller can observe (all documented in DESIGN.md):
+
+* ``fit`` does NOT zero-fill / normalise the caller's ``src_ra`` / ``ref_ra`` in place (the reference does,
+  kernel_model.py:246-247,292-295,320-321; its own wrappers always pass temporaries or copies).
+* ``fit_apply`` is an extra, fused entry point for ``RasterFuse._process_block``'s fit->apply pair (fuse.py:305-307).
+* gain-offset with ``r2_inpaint_thresh`` set: the kernel evaluates the r2 mask (kernel_model.py:363); when no valid
+  pixel fails it the reference's GDAL ``fillnodata`` branch is the identity and results are identical; when some
+  fail, in-painting is required and currently raises ``NotImplementedError``.
+* ``RefSpaceModel`` / ``SrcSpaceModel`` accept same-grid pairs only (GDAL re-projection is section 8f row 1).
+"""
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+
+from homonim_amd import _hk, utils
+from homonim_amd.enums import Model, Resampling
+from homonim_amd.raster_array import RasterArray
+
+
+class KernelModel:
+    default_kernel_shape = (5, 5)
+    default_model = Model.gain_blk_offset
+
+    def __init__(self, model: Model = default_model, kernel_shape: Tuple[int, int] = default_kernel_shape,
+                 find_r2: bool = False, **kwargs):
+        """
+        model: correction model; kernel_shape: (height, width) of the sliding window, odd; find_r2: add an R2 band to
+        the parameters; kwargs: see ``create_config`` (unknown keys raise TypeError, as in the reference).
+        """
+        self._model = Model(model)
+        self._kernel_shape = utils.validate_kernel_shape(kernel_shape, model=self._model)
+        self._find_r2 = find_r2
+        config = self.create_config(**kwargs)
+        self._r2_inpaint_thresh: Optional[float] = config['r2_inpaint_thresh']
+        self._mask_partial: bool = config['mask_partial']
+        self._downsampling: Resampling = config['downsampling']
+        self._upsampling: Resampling = config['upsampling']
+        self._ctx = None  # GPU context, created on first use
+
+    # -- configuration (kernel_model.py:83-136) -----------------------------------------------------------------------
+    @property
+    def model(self) -> Model:
+        return self._model
+
+    @property
+    def kernel_shape(self) -> Tuple[int, int]:
+        return tuple(self._kernel_shape)
+
+    @property
+    def find_r2(self) -> bool:
+        return self._find_r2
+
+    @staticmethod
+    def create_config(r2_inpaint_thresh: Optional[float] = 0.25, mask_partial: bool = False,
+                      downsampling: Resampling = Resampling.average,
+                      upsampling: Resampling = Resampling.cubic_spline) -> Dict:
+        """ The model configuration dict accepted by ``__init__`` and ``RasterFuse.process`` (defaults = reference). """
+        return dict(r2_inpaint_thresh=r2_inpaint_thresh, mask_partial=mask_partial, downsampling=downsampling,
+                    upsampling=upsampling)
+
+    def _get_resampling(self, from_res: Tuple[float, float], to_res: Tuple[float, float]):
+        """ kernel_model.py:138-140 """
+        return self._downsampling if np.prod(np.abs(from_res)) <= np.prod(np.abs(to_res)) else self._upsampling
+
+    # -- device plumbing ----------------------------------------------------------------------------------------------
+    @property
+    def context(self) -> '_hk.Context':
+        if self._ctx is None:
+            self._ctx = _hk.default_context()
+        return self._ctx
+
+    @context.setter
+    def context(self, ctx: '_hk.Context'):
+        self._ctx = ctx
+
+    @property
+    def _emit_r2(self) -> bool:
+        # kernel_model.py:252 (gain models) / :325 (gain-offset)
+        return bool(self._find_r2 or (self._model == Model.gain_offset and self._r2_inpaint_thresh is not None))
+
+    def _desc(self, src_ra: RasterArray, ref_ra: RasterArray):
+        thresh = self._r2_inpaint_thresh if self._model == Model.gain_offset else None
+        return _hk.make_desc(self._model, self._kernel_shape, self._find_r2, thresh, src_ra.nodata, ref_ra.nodata)
+
+    @staticmethod
+    def _band(ra: RasterArray, what: str) -> np.ndarray:
+        arr = ra.array
+        if arr.ndim == 3:
+            if arr.shape[0] != 1:
+                raise ValueError(f'`{what}` must hold a single band')
+            arr = arr[0]
+        return arr
+
+    def _param_profile(self, src_ra: RasterArray, count: int) -> Dict:
+        profile = src_ra.profile.copy()
+        profile.update(count=count, nodata=RasterArray.default_nodata, dtype=RasterArray.default_dtype)
+        return profile
+
+    def _check_inpaint(self, n_fail: int):
+        if n_fail and self._model == Model.gain_offset and self._r2_inpaint_thresh is not None:
+            raise NotImplementedError(
+                f'{n_fail} valid pixel(s) fail the R2 > {self._r2_inpaint_thresh} & gain > 0 test and need in-painting '
+                '(GDAL fillnodata, homonim/kernel_model.py:361-371), which is not built yet: '
+                'pass r2_inpaint_thresh=None to fit without in-painting.'
+            )
+
+    # -- the hot path -------------------------------------------------------------------------------------------------
+    def fit(self, src_ra: RasterArray, ref_ra: RasterArray) -> RasterArray:
+        """
+        Fit sliding kernel models to a source / reference block pair on the same grid (kernel_model.py:411-440).
+        Returns the parameters: gains in band 0, offsets in band 1 and, when ``find_r2`` (or gain-offset with an
+        ``r2_inpaint_thresh``), R2 in band 2; NaN where either input is nodata.
+        """
+        if (ref_ra.transform != src_ra.transform) or (ref_ra.shape != src_ra.shape):
+            raise ValueError("'ref_ra' and 'src_ra' must have the same CRS, transform and shape")
+        count = 3 if self._emit_r2 else 2
+        params, _, _, n_fail = self.context.fit_apply(
+            self._desc(src_ra, ref_ra), self._band(src_ra, 'src_ra'), self._band(ref_ra, 'ref_ra'), count,
+            want_params=True, want_corr=False
+        )
+        self._check_inpaint(n_fail)
+        return RasterArray.from_profile(params, self._param_profile(src_ra, count))
+
+    def apply(self, src_ra: RasterArray, param_ra: RasterArray) -> RasterArray:
+        """ Corrected block = gain * source + offset (kernel_model.py:442-463). """
+        if (param_ra.transform != src_ra.transform) or (param_ra.shape != src_ra.shape):
+            raise ValueError("'param_ra' and 'src_ra' must have the same CRS, transform and shape")
+        corr = self.context.apply(self._band(src_ra, 'src_ra'), param_ra.array)
+        return RasterArray.from_profile(corr, param_ra.profile)
+
+    def fit_apply(self, src_ra: RasterArray, ref_ra: RasterArray,
+                  want_params: bool = False) -> Tuple[RasterArray, Optional[RasterArray]]:
+        """
+        ``apply(src_ra, fit(src_ra.copy(), ref_ra))`` in ONE pass over the data (window sums, solve, R2 test and
+        correction fused in a single kernel; each input byte is read once).  Returns (corr_ra, param_ra | None).
+        """
+        if (ref_ra.transform != src_ra.transform) or (ref_ra.shape != src_ra.shape):
+            raise ValueError("'ref_ra' and 'src_ra' must have the same CRS, transform and shape")
+        count = 3 if self._emit_r2 else 2
+        params, corr, _, n_fail = self.context.fit_apply(
+            self._desc(src_ra, ref_ra), self._band(src_ra, 'src_ra'), self._band(ref_ra, 'ref_ra'), count,
+            want_params=want_params, want_corr=True
+        )
+        self._check_inpaint(n_fail)
+        profile = self._param_profile(src_ra, count)
+        corr_ra = RasterArray.from_profile(corr, profile)
+        return corr_ra, (RasterArray.from_profile(params, profile) if want_params else None)
+
+    def block_norm(self, src_ra: RasterArray, ref_ra: RasterArray) -> np.ndarray:
+        """ The [gain, offset] block normalisation of gain-blk-offset (kernel_model.py:216-229), float64[2]. """
+        return self.context.block_norm(self._desc(src_ra, ref_ra), self._band(src_ra, 'src_ra'),
+                                       self._band(ref_ra, 'ref_ra'))
+
+
+def _same_grid(a: RasterArray, b: RasterArray) -> bool:
+    return a.transform == b.transform and a.shape == b.shape and a.crs == b.crs
+
+
+_REPROJECT_MSG = (
+    'source and reference blocks are on different grids: re-projection (GDAL warp, homonim/raster_array.py:526-578) '
+    'is outside the MI355X hot path built so far (SURVEY.md section 8f row 1)'
+)
+
+
+class RefSpaceModel(KernelModel):
+    """
+    Parameters estimated on the reference grid (kernel_model.py:466-503).  With source and reference on the same grid
+    the reference's ``average`` re-projection is the identity, which is the case handled here.
+    """
+
+    def fit(self, src_ra: RasterArray, ref_ra: RasterArray) -> RasterArray:
+        if not _same_grid(src_ra, ref_ra):
+            raise NotImplementedError(_REPROJECT_MSG)
+        return KernelModel.fit(self, src_ra, ref_ra)
+
+    def apply(self, src_ra: RasterArray, param_ra: RasterArray) -> RasterArray:
+        if not _same_grid(src_ra, param_ra):
+            raise NotImplementedError(_REPROJECT_MSG)
+        if self._mask_partial:
+            raise NotImplementedError('mask_partial (kernel_model.py:375-409) is not built yet (SURVEY.md 8f row 3)')
+        # the reference keeps only gain & offset and re-masks them with the source mask (:487,:500); on a shared grid
+        # the parameters are already nodata wherever the source is.
+        return KernelModel.apply(self, src_ra, param_ra)
+
+
+class SrcSpaceModel(KernelModel):
+    """ Parameters estimated on the source grid (kernel_model.py:506-535); same-grid pairs only, as above. """
+
+    def fit(self, src_ra: RasterArray, ref_ra: RasterArray) -> RasterArray:
+        if not _same_grid(src_ra, ref_ra):
+            raise NotImplementedError(_REPROJECT_MSG)
+        if self._mask_partial:
+            raise NotImplementedError('mask_partial (kernel_model.py:375-409) is not built yet (SURVEY.md 8f row 3)')
+        return KernelModel.fit(self, src_ra, ref_ra)

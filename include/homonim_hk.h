@@ -1,0 +1,162 @@
+/*
+ * homonim_hk.h -- C ABI of the MI355X-native homonim kernel-model hot path (libhomonim_hk.so).
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types.  Every entry point names the
+ * reference interface it replaces (paths relative to the reference repo leftfield-geospatial/homonim v0.4.3).
+ * The reference has no FFI of its own (it is pure Python on top of OpenCV/GDAL wheels); the binding a maintainer
+ * would add is a ctypes stub inside homonim/kernel_model.py -- shown in INTEGRATION.md and implemented in
+ * homonim_amd/_hk.py.
+ *
+ * Conventions
+ *   - All functions return 0 on success, a negative hk_status otherwise; hk_last_error() gives the text for the
+ *     calling thread.  Nothing aborts the process.
+ *   - Rasters are float32, row-major, one band per 2-D plane; `stride` is in ELEMENTS between rows.
+ *   - nodata is passed as (mode, value): HK_NODATA_NONE = RasterArray.nodata is None (all pixels valid),
+ *     HK_NODATA_NAN = nodata is NaN, HK_NODATA_VALUE = numeric nodata, compared with utils.nan_equals semantics
+ *     (homonim/utils.py:54-56; homonim/raster_array.py:298-308).
+ *   - kernel_shape is (kh, kw) = (rows, cols), both odd (homonim/utils.py:104-133).
+ *   - Thread safety: any number of host threads may call into one hk_ctx concurrently (the reference calls
+ *     fit/apply from a ThreadPoolExecutor on ONE shared model, homonim/fuse.py:396-401); each call checks a
+ *     stream + staging slot out of the context's pool.
+ */
+#ifndef HOMONIM_HK_H
+#define HOMONIM_HK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hk_ctx hk_ctx;
+
+typedef enum {
+    HK_OK = 0,
+    HK_ERR_ARG = -1,       /* bad argument (shape, kernel, null pointer ...) -> Python ValueError */
+    HK_ERR_HIP = -2,       /* HIP runtime error -> Python RuntimeError */
+    HK_ERR_NODEVICE = -3,  /* no usable GPU */
+    HK_ERR_UNSUPPORTED = -4,
+    HK_ERR_NOMEM = -5
+} hk_status;
+
+/* homonim/enums.py:22-41 (Model) */
+typedef enum { HK_MODEL_GAIN = 0, HK_MODEL_GAIN_BLK_OFFSET = 1, HK_MODEL_GAIN_OFFSET = 2 } hk_model;
+
+typedef enum { HK_NODATA_NONE = 0, HK_NODATA_NAN = 1, HK_NODATA_VALUE = 2 } hk_nodata_mode;
+
+/*
+ * Everything KernelModel.__init__ / create_config fix for the hot path (homonim/kernel_model.py:40-81,98-136)
+ * plus the per-call nodata of the two RasterArrays.
+ */
+typedef struct {
+    int32_t model;          /* hk_model */
+    int32_t kh, kw;         /* kernel_shape (rows, cols), odd */
+    int32_t find_r2;        /* KernelModel.find_r2: emit the R2 band (kernel_model.py:267-272,353-359) */
+    int32_t has_r2_thresh;  /* r2_inpaint_thresh is not None (gain-offset only; kernel_model.py:325,361) */
+    float r2_thresh;        /* r2_inpaint_thresh */
+    int32_t src_nodata_mode;
+    float src_nodata;
+    int32_t ref_nodata_mode;
+    float ref_nodata;
+} hk_fit_desc;
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * library / context
+ */
+const char* hk_backend_name(void);            /* "hip-gfx950" */
+const char* hk_last_error(void);              /* thread-local text of the last failure */
+int hk_device_count(int* count);
+/* One context per GPU: owns `n_streams` HIP streams, each with a pinned-host + device staging slot that grows on
+ * demand.  Replaces nothing in the reference (its "device" is the host CPU); mirrors the thread pool of
+ * homonim/fuse.py:396. */
+int hk_ctx_create(int device_id, int n_streams, hk_ctx** ctx);
+int hk_ctx_destroy(hk_ctx* ctx);
+int hk_ctx_sync(hk_ctx* ctx);                 /* hipDeviceSynchronize on the context's device */
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * host-pointer entry points (numpy arrays in, numpy arrays out): H2D -> kernels -> D2H on one pooled stream.
+ */
+
+/* KernelModel._fit_block_norm (homonim/kernel_model.py:216-229): norm[0] = std(ref[mask]) / std(src[mask]),
+ * norm[1] = percentile(ref[mask], 1) - percentile(src[mask], 1) * norm[0]; [0, 0] when no pixel is valid. */
+int hk_block_norm(hk_ctx* ctx, const hk_fit_desc* desc, const float* src, int64_t src_stride, const float* ref,
+                  int64_t ref_stride, int32_t height, int32_t width, double norm_out[2]);
+
+/* KernelModel.fit (homonim/kernel_model.py:411-440 -> _fit_gain :231-274, _fit_gain_blk_offset :276-303,
+ * _fit_gain_offset :305-373, _r2_array :142-214).
+ *   params_out : n_param_bands x height x width float32, band 0 gain, 1 offset, 2 R2 (iff n_param_bands == 3;
+ *                must equal 3 exactly when find_r2 || (model == gain-offset && has_r2_thresh)), NaN outside mask.
+ *   norm_in    : gain-blk-offset only: float64[2] block normalisation to use, or NULL to compute it (hk_block_norm).
+ *   norm_out   : optional float64[2], receives the normalisation actually used.
+ *   r2_fail_count : optional; gain-offset with has_r2_thresh: number of valid pixels failing
+ *                (r2 > thresh) & (gain > 0) (kernel_model.py:363).  When it is 0 the reference's in-paint branch is
+ *                the identity and params_out equals the reference's output; when > 0 the caller must in-paint
+ *                (params_out then holds the pre-in-paint parameters).
+ * Unlike the reference, src/ref are NOT modified (no in-place zero-fill, kernel_model.py:246-247,320-321). */
+int hk_fit(hk_ctx* ctx, const hk_fit_desc* desc, const float* src, int64_t src_stride, const float* ref,
+           int64_t ref_stride, int32_t height, int32_t width, const double* norm_in, float* params_out,
+           int32_t n_param_bands, double* norm_out, uint64_t* r2_fail_count);
+
+/* KernelModel.apply (homonim/kernel_model.py:442-463): out = params[0] * src + params[1] (two float32 roundings). */
+int hk_apply(hk_ctx* ctx, const float* src, int64_t src_stride, const float* params /* 2 x H x W */,
+             int32_t height, int32_t width, float* out);
+
+/* fit + apply of RasterFuse._process_block (homonim/fuse.py:305-307) fused in one pass: window sums, solve, R2 test
+ * and correction in a single kernel; parameters are materialised only if params_out != NULL. */
+int hk_fit_apply(hk_ctx* ctx, const hk_fit_desc* desc, const float* src, int64_t src_stride, const float* ref,
+                 int64_t ref_stride, int32_t height, int32_t width, const double* norm_in,
+                 float* params_out /* nullable */, int32_t n_param_bands, float* corr_out, double* norm_out,
+                 uint64_t* r2_fail_count);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * device-resident entry points (inputs already in HBM): what bench.py times and what the streaming tile pipeline
+ * is built from.  Buffers come from hk_dev_alloc; planes are height x stride float32 with stride % 4 == 0.
+ */
+int hk_dev_alloc(hk_ctx* ctx, size_t bytes, void** dptr);
+int hk_dev_free(hk_ctx* ctx, void* dptr);
+int hk_memcpy_h2d(hk_ctx* ctx, void* dst, const void* src, size_t bytes);
+int hk_memcpy_d2h(hk_ctx* ctx, void* dst, const void* src, size_t bytes);
+int hk_memset(hk_ctx* ctx, void* dst, int value, size_t bytes);
+
+typedef struct {
+    const float* src;      /* device, n_bands planes */
+    const float* ref;      /* device, n_bands planes */
+    float* gain;           /* device, nullable */
+    float* offset;         /* device, nullable */
+    float* r2;             /* device, nullable (written only when the R2 variant runs) */
+    float* corr;           /* device, nullable */
+    const double* norm;    /* device, n_bands x 2 float64 (gain-blk-offset), else NULL */
+    uint64_t* fail_count;  /* device, n_bands counters (must be zeroed by the caller), nullable */
+    int32_t n_bands;
+    int32_t height, width;
+    int64_t stride;        /* elements between rows, all planes */
+    int64_t band_stride;   /* elements between band planes, all arrays */
+    int32_t seg_rows;      /* rows per wave segment; 0 = library default */
+    int32_t stream;        /* index into the context's stream pool */
+} hk_dev_job;
+
+/* Launch the fused kernel over all bands of a device-resident job (asynchronous on stream `job->stream`). */
+int hk_fit_apply_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* job);
+/* Per-band block normalisation on device planes -> norm (device, n_bands x 2 float64); asynchronous. */
+int hk_block_norm_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* job, double* norm_dev);
+/* Fill device planes with the synthetic workload of SURVEY.md section 8(d) (src ~ U[0.05,1), ref = g*src+o+noise);
+ * nodata_variant 0: none, 1: 3-px NaN frame + 0.1 % NaN holes.  Test/bench data only. */
+int hk_synth_fill_dev(hk_ctx* ctx, float* src, float* ref, int32_t n_bands, int32_t height, int32_t width,
+                      int64_t stride, int64_t band_stride, uint64_t seed, int32_t nodata_variant, int32_t stream);
+
+/* HIP events on the pooled streams, so callers time exactly the stream the kernels run on. */
+typedef struct hk_event hk_event;
+int hk_event_create(hk_ctx* ctx, hk_event** ev);
+int hk_event_destroy(hk_ctx* ctx, hk_event* ev);
+int hk_event_record(hk_ctx* ctx, hk_event* ev, int32_t stream);
+int hk_event_elapsed_ms(hk_ctx* ctx, hk_event* start, hk_event* stop, float* ms); /* syncs on `stop` */
+int hk_stream_sync(hk_ctx* ctx, int32_t stream);
+
+/* Self-test of the cross-lane primitives the kernels rely on (DPP wave shifts); 0 = pass. */
+int hk_selftest(hk_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HOMONIM_HK_H */

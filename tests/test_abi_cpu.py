@@ -1,0 +1,151 @@
+"""
+CPU tests of the boundary: the C-ABI library builds, loads and exports every symbol include/homonim_hk.h declares
+(no compute calls -- there is no GPU here), the host-side classes validate like the reference, and the product never
+imports the oracle.
+"""
+import ctypes
+import os
+import re
+import warnings
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+from homonim_amd import (Affine, ConfigWarning, CRS, DeviceError, KernelModel, Model, RasterArray, RefSpaceModel,
+                         Resampling, SrcSpaceModel, _hk, utils)
+
+
+@pytest.fixture(scope='module')
+def lib():
+    from homonim_amd import build
+    build.build_hip(verbose=False)
+    return _hk.load_library()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    header = open(os.path.join(REPO, 'include', 'homonim_hk.h')).read()
+    declared = set(re.findall(r'\b(hk_[a-z0-9_]+)\s*\(', header))
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(lib, name), f'{name} declared in homonim_hk.h but not exported'
+    # and the ctypes table covers the header exactly
+    assert declared == set(_hk.SIGNATURES)
+
+
+def test_backend_name_and_struct_layout(lib):
+    assert lib.hk_backend_name() == b'hip-gfx950'
+    assert ctypes.sizeof(_hk.FitDesc) == 40  # 10 x 4-byte fields, matches hk_fit_desc
+    assert ctypes.sizeof(_hk.DevJob) == 8 * 8 + 3 * 4 + 4 + 2 * 8 + 2 * 4
+
+
+def test_no_gpu_fails_loudly(lib):
+    """ On a GPU-less host the context cannot be created: DeviceError, never a silent CPU path. """
+    if _hk.device_count() > 0:
+        pytest.skip('a GPU is present')
+    with pytest.raises(DeviceError):
+        _hk.Context(0)
+    ra = RasterArray(np.ones((8, 8), np.float32), CRS(), Affine.identity())
+    with pytest.raises(DeviceError):
+        KernelModel(Model.gain, (3, 3)).fit(ra, ra.copy())
+
+
+def test_product_never_imports_oracle():
+    for root, _, files in os.walk(os.path.join(REPO, 'homonim_amd')):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h', '.cpp')):
+                text = open(os.path.join(root, f)).read()
+                assert 'import oracle' not in text and 'from oracle' not in text and 'hk_oracle' not in text.replace(
+                    'build_oracle', '').replace('libhk_oracle', '').replace("'hk_oracle.c'", ''), f
+
+
+# -- reference tests/test_kernel_model.py:296-334 (error behaviour, config) -------------------------------------------
+@pytest.mark.parametrize('model, kernel_shape', [
+    (Model.gain, (0, 0)), (Model.gain_blk_offset, (0, 0)), (Model.gain_offset, (4, 5)), (Model.gain_offset, (1, 1)),
+])
+def test_kernel_shape_exception(model, kernel_shape):
+    with pytest.raises(ValueError):
+        RefSpaceModel(model=model, kernel_shape=kernel_shape)
+
+
+def test_small_gain_offset_kernel_warns():
+    with pytest.warns(ConfigWarning):
+        KernelModel(Model.gain_offset, (3, 3))
+
+
+def test_config():
+    config = dict(r2_inpaint_thresh=0.1, mask_partial=True, downsampling=Resampling.bilinear,
+                  upsampling=Resampling.nearest)
+    km = RefSpaceModel(Model.gain, (5, 5), find_r2=True, **config)
+    for key, val in config.items():
+        assert getattr(km, '_' + key) == val
+    assert KernelModel.create_config() == dict(r2_inpaint_thresh=0.25, mask_partial=False,
+                                               downsampling=Resampling.average, upsampling=Resampling.cubic_spline)
+    assert KernelModel.default_kernel_shape == (5, 5) and KernelModel.default_model == Model.gain_blk_offset
+    assert km.model == Model.gain and km.kernel_shape == (5, 5) and km.find_r2
+
+
+def test_config_exception():
+    with pytest.raises(TypeError):
+        RefSpaceModel(Model.gain, (5, 5), find_r2=True, unknown='value')
+
+
+def test_fit_apply_shape_mismatch_is_value_error():
+    a = RasterArray(np.ones((8, 8), np.float32), CRS(), Affine.identity())
+    b = RasterArray(np.ones((8, 9), np.float32), CRS(), Affine.identity())
+    c = RasterArray(np.ones((8, 8), np.float32), CRS(), Affine.translation(1, 0))
+    km = KernelModel(Model.gain, (3, 3))
+    for other in (b, c):
+        with pytest.raises(ValueError):
+            km.fit(a, other)
+        with pytest.raises(ValueError):
+            km.apply(a, other)
+
+
+def test_utils():
+    assert utils.overlap_for_kernel((5, 5)) == (3, 3) and utils.overlap_for_kernel((15, 15)) == (8, 8)
+    assert utils.overlap_for_kernel((1, 3)) == (1, 2)
+    assert utils.validate_kernel_shape((5, 7), Model.gain) == (5, 7)
+    assert utils.validate_threads(0) >= 1
+    with pytest.raises(ValueError):
+        utils.validate_threads(10**6)
+    assert utils.nan_equals(np.array([np.nan, 1., 2.]), np.nan).tolist() == [True, False, False]
+
+
+# -- RasterArray carrier (reference tests/test_raster_array.py semantics for the in-memory part) -----------------------
+def test_raster_array_mask_and_nodata():
+    arr = np.arange(12, dtype=np.float32).reshape(3, 4)
+    arr[0, 0] = np.nan
+    ra = RasterArray(arr.copy(), CRS(), Affine.identity())
+    assert ra.shape == (3, 4) and ra.count == 1 and ra.dtype == 'float32' and np.isnan(ra.nodata)
+    assert ra.mask.sum() == 11 and not ra.mask[0, 0]
+    ra.nodata = 5  # re-label the masked pixel
+    assert ra.array[0, 0] == 5 and ra.mask.sum() == 10  # the pixel that already equalled 5 is now masked too
+    ra.nodata = None
+    assert ra.mask.all()
+    ra2 = RasterArray(arr.copy(), CRS(), Affine.identity(), nodata=3)
+    m = ra2.mask.copy()
+    m[2, 2] = False
+    ra2.mask = m
+    assert ra2.array[2, 2] == 3 and ra2.mask.sum() == 10  # nan pixel is valid under numeric nodata
+    cp = ra2.copy()
+    cp.array[1, 1] = -1
+    assert ra2.array[1, 1] != -1
+    with pytest.raises(ValueError):
+        ra2.array = np.zeros((2, 2), np.float32)
+    with pytest.raises(ValueError):
+        RasterArray(np.zeros(3, np.float32), CRS(), Affine.identity())
+    with pytest.raises(TypeError):
+        RasterArray(arr, 'EPSG:3857', Affine.identity())
+    with pytest.raises(TypeError):
+        RasterArray(arr, CRS(), (1, 0, 0, 0, 1, 0))
+
+
+def test_raster_array_from_profile():
+    prof = dict(crs=CRS(), transform=Affine.identity(), nodata=float('nan'), count=3, width=4, height=2, dtype='float32')
+    ra = RasterArray.from_profile(None, prof)
+    assert ra.array.shape == (3, 2, 4) and np.isnan(ra.array).all() and ra.count == 3
+    assert ra.profile['count'] == 3 and ra.proj_profile['shape'] == (2, 4)
+    from homonim_amd.errors import ImageProfileError
+    with pytest.raises(ImageProfileError):
+        RasterArray.from_profile(None, dict(crs=CRS(), transform=Affine.identity()))

@@ -1,0 +1,275 @@
+"""
+GPU parity tests (run on the MI355X box: ``pytest -m gpu``).  Everything goes through the C ABI (ctypes ->
+libhomonim_hk.so -> HIP kernels); the oracle is only the checker.
+
+Bars (DESIGN.md "Numerics contract"):
+* gain / gain-offset parameters, R2 and corrected output: BIT-EXACT float32 against the reference goldens and the
+  numpy oracle, except that results which depend on the float64 sum of squares (whose 25..225-term float64 sum is
+  order dependent in its last bit) may differ in <= 1e-5 of the pixels by <= 2 ulp.  The stated acceptance tolerance of
+  the north star is 1e-5 relative; these tests hold the kernels to ~1e-7.
+* gain-blk-offset: same, given the same block normalisation; the normalisation itself (exact float64 statistics on
+  the GPU vs numpy's float32 pairwise ones) within 2e-6 relative.
+"""
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_CASES, assert_same_f32, case_id
+from homonim_amd import Affine, CRS, KernelModel, Model, RasterArray, RefSpaceModel, SrcSpaceModel, _hk
+from oracle import oracle_np as onp
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    c = _hk.default_context()
+    c.selftest()
+    return c
+
+
+def _ra(arr, nodata):
+    return RasterArray(arr, CRS(), Affine.identity(), nodata=nodata)
+
+
+def assert_close_ulp(actual, expected, what, max_ulp=2, max_frac=1e-5):
+    """ Bit-exact except for at most ``max_frac`` of the elements, which may be off by <= ``max_ulp`` float32 ulps. """
+    actual, expected = np.asarray(actual), np.asarray(expected)
+    assert actual.shape == expected.shape and actual.dtype == expected.dtype == np.float32, what
+    nan_a, nan_e = np.isnan(actual), np.isnan(expected)
+    assert (nan_a == nan_e).all(), f'{what}: NaN pattern differs at {np.argwhere(nan_a != nan_e)[:3].tolist()}'
+    ok = ~nan_e
+    diff = actual[ok] != expected[ok]
+    n_diff = int(diff.sum())
+    if n_diff:
+        a, e = actual[ok][diff], expected[ok][diff]
+        with np.errstate(all='ignore'):
+            ulps = np.abs(a.view(np.int32).astype(np.int64) - e.view(np.int32).astype(np.int64))
+        same_inf = np.isinf(a) & np.isinf(e) & (a == e)
+        worst = int(ulps[~same_inf].max()) if (~same_inf).any() else 0
+        frac = n_diff / max(1, int(ok.sum()))
+        assert worst <= max_ulp and frac <= max(max_frac, 2.0 / max(1, int(ok.sum()))), (
+            f'{what}: {n_diff} of {int(ok.sum())} valid elements differ (frac {frac:.2e}), worst {worst} ulp; '
+            f'e.g. {a[:3]} vs {e[:3]}'
+        )
+    return n_diff
+
+
+def _fit_via_abi(ctx, case_or_cfg, src, ref, norm_in=None, want_corr=True):
+    c = case_or_cfg
+    thresh = c['r2_inpaint_thresh'] if c['model'] == 'gain-offset' else None
+    desc = _hk.make_desc(c['model'], c['kernel_shape'], c['find_r2'], thresh, c['src_nodata'], c['ref_nodata'])
+    count = 3 if (c['find_r2'] or (c['model'] == 'gain-offset' and thresh is not None)) else 2
+    return ctx.fit_apply(desc, src, ref, count, want_params=True, want_corr=want_corr, norm_in=norm_in)
+
+
+def test_selftest(ctx):
+    ctx.selftest()
+
+
+@pytest.mark.parametrize('case', GOLDEN_CASES, ids=case_id)
+def test_goldens_through_c_abi(ctx, goldens, case):
+    """ Reference-generated golden vectors (oracle/gen_golden.py), fused fit+apply through the C ABI. """
+    src = goldens[f"in_{case['variant']}_src"]
+    ref = goldens[f"in_{case['variant']}_ref"]
+    exp_params, exp_corr = goldens[f"{case['name']}_params"], goldens[f"{case['name']}_corr"]
+    norm_in = goldens[f"{case['name']}_norm"] if case['model'] == 'gain-blk-offset' else None
+    src_before, ref_before = src.copy(), ref.copy()
+    params, corr, norm, n_fail = _fit_via_abi(ctx, case, src, ref, norm_in=norm_in)
+    np.testing.assert_array_equal(src, src_before)  # inputs are never modified
+    np.testing.assert_array_equal(ref, ref_before)
+    assert n_fail == 0
+    assert_close_ulp(params, exp_params, 'params')
+    assert_close_ulp(corr, exp_corr, 'corrected')
+    if norm_in is not None:
+        np.testing.assert_array_equal(norm, norm_in)
+
+
+@pytest.mark.parametrize('case', [c for c in GOLDEN_CASES if c['model'] == 'gain-blk-offset'], ids=case_id)
+def test_block_norm_vs_goldens(ctx, goldens, case):
+    src = goldens[f"in_{case['variant']}_src"]
+    ref = goldens[f"in_{case['variant']}_ref"]
+    exp = goldens[f"{case['name']}_norm"]
+    desc = _hk.make_desc(case['model'], case['kernel_shape'], False, None, case['src_nodata'], case['ref_nodata'])
+    norm = ctx.block_norm(desc, src, ref)
+    if (exp == 0).all():
+        assert (norm == 0).all()
+    else:
+        assert norm[0] == pytest.approx(exp[0], rel=2e-6)
+        assert norm[1] == pytest.approx(exp[1], rel=2e-6, abs=2e-6 * abs(exp[0]))
+
+
+@pytest.mark.parametrize('model, kernel_shape, find_r2, thresh', [
+    ('gain', (5, 5), False, None),
+    ('gain', (5, 5), True, None),
+    ('gain', (1, 1), True, None),
+    ('gain', (3, 3), False, None),
+    ('gain-offset', (5, 5), False, None),
+    ('gain-offset', (5, 5), True, 0.25),
+    ('gain-offset', (3, 3), True, None),
+    ('gain-offset', (5, 7), True, 0.25),
+    ('gain-offset', (7, 5), False, 0.25),
+    ('gain-offset', (9, 9), True, None),
+    ('gain-offset', (15, 15), True, 0.25),
+    ('gain-offset', (11, 13), True, None),
+    ('gain-blk-offset', (5, 5), False, None),
+    ('gain-blk-offset', (15, 15), True, None),
+    ('gain-blk-offset', (1, 1), False, None),
+])
+@pytest.mark.parametrize('shape, variant', [((300, 1003), 'frame+holes'), ((517, 640), 'none')])
+def test_multi_strip_multi_segment_vs_oracle(ctx, model, kernel_shape, find_r2, thresh, shape, variant):
+    """ Rasters spanning several 248-column strips and 128-row segments, ragged widths, every kernel path
+    (compile-time widths 0/1/2/3/7 and the run-time one) against the numpy oracle. """
+    import warnings
+    h, w = shape
+    src, ref = onp.synth_pair(h, w, seed=h + w, nodata_variant=variant)
+    nodata = np.nan if variant != 'none' else None
+    cfg = dict(model=model, kernel_shape=kernel_shape, find_r2=find_r2, r2_inpaint_thresh=thresh, src_nodata=nodata,
+               ref_nodata=nodata)
+    norm_in = None
+    if model == 'gain-blk-offset':
+        norm_in = onp.fit_block_norm(src, nodata, ref, nodata)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        exp_params, aux = onp.fit(model, src, nodata, ref, nodata, kernel_shape, find_r2, thresh, norm_model=norm_in)
+    exp_corr = onp.apply(src, exp_params)
+    params, corr, norm, n_fail = _fit_via_abi(ctx, cfg, src, ref, norm_in=norm_in)
+    assert_close_ulp(params, exp_params, 'params')
+    assert_close_ulp(corr, exp_corr, 'corrected')
+    if model == 'gain-offset' and thresh is not None:
+        assert n_fail == aux
+
+
+@pytest.mark.parametrize('shape', [(1, 1), (1, 7), (5, 1), (2, 3), (4, 250), (131, 5), (129, 249)])
+@pytest.mark.parametrize('model, kernel_shape', [('gain', (3, 3)), ('gain-offset', (5, 5)), ('gain-offset', (15, 15))])
+def test_tiny_and_ragged_shapes(ctx, shape, model, kernel_shape):
+    """ Rasters smaller than the kernel / one lane / one strip: windows are partial everywhere (zero border). """
+    rng = np.random.default_rng(shape[0] * 1000 + shape[1])
+    src = rng.uniform(0.1, 1, shape).astype(np.float32)
+    ref = (1.3 * src + 0.1 + rng.normal(0, 0.01, shape)).astype(np.float32)
+    cfg = dict(model=model, kernel_shape=kernel_shape, find_r2=True, r2_inpaint_thresh=None, src_nodata=np.nan,
+               ref_nodata=np.nan)
+    exp_params, _ = onp.fit(model, src, np.nan, ref, np.nan, kernel_shape, True, None)
+    params, corr, _, _ = _fit_via_abi(ctx, cfg, src, ref)
+    assert_close_ulp(params, exp_params, 'params', max_frac=1.0)  # tiny rasters: fraction is meaningless, ulps matter
+    assert_close_ulp(corr, onp.apply(src, exp_params), 'corrected', max_frac=1.0)
+
+
+def test_all_masked_block(ctx):
+    src = np.full((40, 300), np.nan, np.float32)
+    ref = np.ones((40, 300), np.float32)
+    for model in ('gain', 'gain-blk-offset', 'gain-offset'):
+        cfg = dict(model=model, kernel_shape=(5, 5), find_r2=True, r2_inpaint_thresh=0.25, src_nodata=np.nan,
+                   ref_nodata=np.nan)
+        params, corr, norm, n_fail = _fit_via_abi(ctx, cfg, src, ref)
+        assert np.isnan(params).all() and np.isnan(corr).all() and n_fail == 0
+        if model == 'gain-blk-offset':
+            assert (norm == 0).all()  # kernel_model.py:225-226
+
+
+def test_r2_fail_count_outlier(ctx):
+    """ reference tests/test_kernel_model.py:166-203: one -100 outlier makes R2 < 0.5 in its k x k neighbourhood. """
+    a = np.array(range(1, 201), dtype='float32').reshape(20, 10)
+    a[:, [0, -1]] = np.nan
+    a[[0, -1], :] = np.nan
+    src = np.kron(a, np.ones((2, 2), np.float32)).astype(np.float32)
+    ref = src.copy()
+    loc = (src.shape[0] // 2, src.shape[1] // 2)
+    ref[loc] = -100
+    for k in ((5, 5), (5, 7), (9, 9)):
+        cfg = dict(model='gain-offset', kernel_shape=k, find_r2=True, r2_inpaint_thresh=0.5, src_nodata=np.nan,
+                   ref_nodata=np.nan)
+        exp_params, exp_fail = onp.fit_gain_offset(src, np.nan, ref, np.nan, k, True, 0.5)
+        params, _, _, n_fail = _fit_via_abi(ctx, cfg, src, ref, want_corr=False)
+        assert n_fail == exp_fail and n_fail >= k[0] * k[1]
+        assert_close_ulp(params, exp_params, 'params', max_frac=1.0)
+        ul = (loc[0] - k[0] // 2, loc[1] - k[1] // 2)
+        low = np.zeros(src.shape, bool)
+        low[ul[0]:ul[0] + k[0], ul[1]:ul[1] + k[1]] = True
+        mask = ~np.isnan(src)
+        assert (params[2][low] < 0.5).all()
+        assert params[2][~low & mask] == pytest.approx(1, abs=1e-3)
+
+
+# -- through the reference-shaped Python classes -----------------------------------------------------------------------
+@pytest.mark.parametrize('model, kernel_shape', [
+    (Model.gain, (1, 1)), (Model.gain, (3, 3)), (Model.gain_blk_offset, (1, 1)), (Model.gain_blk_offset, (5, 5)),
+    (Model.gain_offset, (5, 5)),
+])
+@pytest.mark.parametrize('cls', [RefSpaceModel, SrcSpaceModel, KernelModel])
+def test_basic_fit_known_answer(ctx, cls, model, kernel_shape):
+    """ reference tests/test_kernel_model.py:32-81 on a shared grid: src == ref  =>  gain ~ 1, offset ~ 0. """
+    a = np.array(range(1, 201), dtype='float32').reshape(20, 10)
+    a[:, [0, -1]] = np.nan
+    a[[0, -1], :] = np.nan
+    src_ra, ref_ra = _ra(a.copy(), np.nan), _ra(a.copy(), np.nan)
+    km = cls(model, kernel_shape, mask_partial=False, r2_inpaint_thresh=0.25)
+    param_ra = km.fit(src_ra, ref_ra)
+    assert param_ra.shape == ref_ra.shape and param_ra.transform == ref_ra.transform
+    assert (ref_ra.mask == param_ra.mask).all()
+    assert param_ra.array[0, param_ra.mask] == pytest.approx(1, abs=1e-2)
+    assert param_ra.array[1, param_ra.mask] == pytest.approx(0, abs=1e-2)
+    np.testing.assert_array_equal(src_ra.array, a)  # not modified
+    # apply with gain = offset = 1 (tests/test_kernel_model.py:84-117)
+    ones = _ra(np.ones((2, *a.shape), np.float32), np.nan)
+    ones.mask = src_ra.mask
+    out_ra = km.apply(src_ra, ones)
+    assert (src_ra.mask == out_ra.mask).all()
+    assert out_ra.array[out_ra.mask] == pytest.approx(src_ra.array[out_ra.mask] + 1, abs=1e-2)
+
+
+@pytest.mark.parametrize('model', list(Model))
+@pytest.mark.parametrize('find_r2', [True, False])
+def test_find_r2_band(ctx, model, find_r2):
+    """ reference tests/test_kernel_model.py:120-140 """
+    src, ref = onp.synth_pair(64, 80, 3, 'frame+holes')
+    km = RefSpaceModel(model, (5, 5), find_r2=find_r2, r2_inpaint_thresh=None)
+    param_ra = km.fit(_ra(src, np.nan), _ra(ref, np.nan))
+    assert param_ra.count == (3 if find_r2 else 2)
+    if find_r2:
+        assert np.nanmax(param_ra.array[2]) <= 1
+
+
+def test_reference_param_tif_on_gpu(ctx):
+    """ The reference's own PARAM GeoTIFF (real homonim+OpenCV+GDAL output), reproduced by the HIP path. """
+    import os
+    from conftest import GOLDEN_DIR
+    g = np.load(os.path.join(GOLDEN_DIR, 'ref_param_tif.npz'))['params']
+    a = np.array(range(1, 201), dtype='float32').reshape(20, 10)
+    a[:, [0, -1]] = np.nan
+    a[[0, -1], :] = np.nan
+    km = RefSpaceModel(Model.gain_offset, (5, 5), find_r2=True, r2_inpaint_thresh=0.25)
+    param_ra = km.fit(_ra(a.copy(), np.nan), _ra(a.copy(), np.nan))
+    for pi in range(3):
+        assert_same_f32(param_ra.array[pi], g[pi * 3], f'param band {pi}')
+
+
+def test_fit_apply_fused_equals_two_calls(ctx):
+    src, ref = onp.synth_pair(200, 520, 11, 'frame+holes')
+    for model in Model:
+        km = KernelModel(model, (5, 5), find_r2=True, r2_inpaint_thresh=None)
+        src_ra, ref_ra = _ra(src.copy(), np.nan), _ra(ref.copy(), np.nan)
+        corr_ra, param_ra = km.fit_apply(src_ra, ref_ra, want_params=True)
+        param2 = km.fit(src_ra, ref_ra)
+        corr2 = km.apply(src_ra, param2)
+        assert_same_f32(param_ra.array, param2.array, 'params')
+        assert_same_f32(corr_ra.array, corr2.array, 'corrected')
+        corr3, none = km.fit_apply(src_ra, ref_ra)
+        assert none is None
+        assert_same_f32(corr3.array, corr2.array, 'corrected (no params)')
+
+
+def test_concurrent_callers_share_one_model(ctx):
+    """ homonim/fuse.py:396-401: many threads call fit/apply on ONE model object. """
+    from concurrent.futures import ThreadPoolExecutor
+    km = KernelModel(Model.gain_offset, (5, 5), r2_inpaint_thresh=None)
+    blocks = [onp.synth_pair(128 + 8 * i, 300 + 16 * i, 20 + i, 'frame+holes') for i in range(8)]
+
+    def work(b):
+        corr_ra, _ = km.fit_apply(_ra(b[0], np.nan), _ra(b[1], np.nan))
+        return corr_ra.array
+
+    with ThreadPoolExecutor(8) as ex:
+        got = list(ex.map(work, blocks))
+    for (src, ref), corr in zip(blocks, got):
+        exp, _ = onp.fit_gain_offset(src, np.nan, ref, np.nan, (5, 5), False, None)
+        assert_close_ulp(corr, onp.apply(src, exp), 'corrected')
