@@ -15,7 +15,9 @@ import numpy as np
 
 from homonim_amd.errors import DeviceError
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', 'libhomonim_hk.so')
+# HOMONIM_AMD_LIB overrides the library path (kernel-variant experiments); the default is the in-tree build.
+_LIB_PATH = os.environ.get('HOMONIM_AMD_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib',
+                                                               'libhomonim_hk.so')
 
 HK_OK, HK_ERR_ARG, HK_ERR_HIP, HK_ERR_NODEVICE, HK_ERR_UNSUPPORTED, HK_ERR_NOMEM = 0, -1, -2, -3, -4, -5
 MODEL_CODES = {'gain': 0, 'gain-blk-offset': 1, 'gain-offset': 2}

@@ -23,11 +23,12 @@ namespace hk {
 
 // ---------------------------------------------------------------------------------------------------------------------
 // cross-lane primitives
+// bound_ctrl:1 makes lanes without a source read 0, so no `old` operand has to be materialised per shift.
 __device__ __forceinline__ int dpp_from_left(int v) {  // value of lane-1; lane 0 receives 0
-    return __builtin_amdgcn_update_dpp(0, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+    return __builtin_amdgcn_update_dpp(0, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
 }
 __device__ __forceinline__ int dpp_from_right(int v) {  // value of lane+1; lane 63 receives 0
-    return __builtin_amdgcn_update_dpp(0, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+    return __builtin_amdgcn_update_dpp(0, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
 }
 __device__ __forceinline__ double dpp_from_left(double v) {
     int lo = dpp_from_left(__double2loint(v)), hi = dpp_from_left(__double2hiint(v));
@@ -163,9 +164,20 @@ __device__ __forceinline__ void hsum_any(const T (&V)[PX], T (&H)[PX], int rw, i
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool px_valid(float v, int mode, float nodata) {
-    // ~utils.nan_equals(v, nodata) (utils.py:54-56); mode 0: nodata is None -> always valid (raster_array.py:302-303)
-    return mode == 0 ? true : (mode == 1 ? !(v != v) : !(v == nodata));
+// ~utils.nan_equals(v, nodata) (utils.py:54-56) without branches: `cmp` is the numeric nodata (or NaN, which never
+// compares equal, for the None / NaN modes) and `nan_is_nodata` selects the isnan test (raster_array.py:298-308).
+struct NodataTest {
+    float cmp;
+    bool nan_is_nodata;
+};
+__device__ __forceinline__ NodataTest make_nodata_test(int mode, float nodata) {
+    NodataTest t;
+    t.cmp = mode == 2 ? nodata : __int_as_float(0x7fc00000);
+    t.nan_is_nodata = mode == 1;
+    return t;
+}
+__device__ __forceinline__ bool px_valid(float v, const NodataTest& t) {
+    return !((v == t.cmp) | (t.nan_is_nodata & (v != v)));
 }
 
 __device__ __forceinline__ float qnan() { return __int_as_float(0x7fc00000); }
@@ -174,27 +186,17 @@ struct RowRaw {
     float4 s, r;
 };
 
+// Rows are padded to a multiple of PX elements (stride % 4 == 0, checked on the host), so every lane whose first
+// column lies inside the raster moves a full 16 bytes; columns >= W inside that quad are masked by `colbits`.
 __device__ __forceinline__ RowRaw load_row(const float* __restrict__ sp, const float* __restrict__ rp, long long stride,
-                                           int row, int height, int x, int width, bool lane_full, bool lane_any) {
+                                           int row, int height, int x, bool lane_in) {
     RowRaw o;
     o.s = make_float4(0.f, 0.f, 0.f, 0.f);
     o.r = o.s;
-    if (row >= 0 && row < height) {  // wave-uniform
+    if (row >= 0 && row < height && lane_in) {
         const long long off = (long long)row * stride + x;
-        if (lane_full) {
-            o.s = *reinterpret_cast<const float4*>(sp + off);
-            o.r = *reinterpret_cast<const float4*>(rp + off);
-        } else if (lane_any) {
-            float s[PX], r[PX];
-#pragma unroll
-            for (int i = 0; i < PX; ++i) {
-                const bool in = x + i >= 0 && x + i < width;
-                s[i] = in ? sp[off + i] : 0.f;
-                r[i] = in ? rp[off + i] : 0.f;
-            }
-            o.s = make_float4(s[0], s[1], s[2], s[3]);
-            o.r = make_float4(r[0], r[1], r[2], r[3]);
-        }
+        o.s = *reinterpret_cast<const float4*>(sp + off);
+        o.r = *reinterpret_cast<const float4*>(rp + off);
     }
     return o;
 }
@@ -206,20 +208,19 @@ struct RowZ {
 };
 
 template <int MODEL>
-__device__ __forceinline__ RowZ process_row(const RowRaw& raw, bool row_ok, unsigned colbits, const FitArgs& a, double n0,
-                                            double n1) {
+__device__ __forceinline__ RowZ process_row(const RowRaw& raw, bool row_ok, unsigned colbits, const NodataTest& ts,
+                                            const NodataTest& tr, double n0, double n1) {
     const float s[PX] = {raw.s.x, raw.s.y, raw.s.z, raw.s.w};
     const float r[PX] = {raw.r.x, raw.r.y, raw.r.z, raw.r.w};
     RowZ z;
     z.m = 0;
 #pragma unroll
     for (int i = 0; i < PX; ++i) {
-        bool m = row_ok && ((colbits >> i) & 1u) && px_valid(s[i], a.src_nd_mode, a.src_nodata) &&
-                 px_valid(r[i], a.ref_nd_mode, a.ref_nodata);
+        bool m = row_ok & (bool)((colbits >> i) & 1u) & px_valid(s[i], ts) & px_valid(r[i], tr);
         if constexpr (MODEL == 1) {
             // gain-blk-offset: the mask is re-derived from the NORMALISED float64 source (kernel_model.py:292-298)
             const double sd = __dadd_rn(__dmul_rn((double)s[i], n0), n1);
-            m = m && !(sd != sd);
+            m = m & !(sd != sd);
         }
         z.s[i] = m ? s[i] : 0.f;
         z.r[i] = m ? r[i] : 0.f;
@@ -279,8 +280,11 @@ struct ColSums {
 // ---------------------------------------------------------------------------------------------------------------------
 // The fused kernel.  MODEL: 0 gain, 1 gain-blk-offset, 2 gain-offset.  R2: compute the R2 quantity set.
 // RW: compile-time kernel half-width, or -1 for the run-time path.
+#ifndef HK_FIT_MIN_WAVES
+#define HK_FIT_MIN_WAVES 3  // waves per SIMD the register allocator must leave room for (tuned on MI355X)
+#endif
 template <int MODEL, bool R2, int RW>
-__global__ void __launch_bounds__(WAVE) fit_apply_kernel(const FitArgs a) {
+__global__ void __launch_bounds__(WAVE, HK_FIT_MIN_WAVES) fit_apply_kernel(const FitArgs a) {
     using CS = ColSums<MODEL, R2>;
     constexpr bool GO = MODEL == 2, BLK = MODEL == 1;
     extern __shared__ float4 lds4[];
@@ -310,12 +314,13 @@ __global__ void __launch_bounds__(WAVE) fit_apply_kernel(const FitArgs a) {
     const float* __restrict__ rp = a.ref + (long long)band * a.band_stride;
     const long long out_base = (long long)band * a.band_stride;
 
-    const bool lane_full = x >= 0 && x + PX <= W;
-    const bool lane_any = x + PX > 0 && x < W;
+    const bool lane_in = x >= 0 && x < W;
+    const NodataTest ts = make_nodata_test(a.src_nd_mode, a.src_nodata);
+    const NodataTest tr = make_nodata_test(a.ref_nd_mode, a.ref_nodata);
     unsigned colbits = 0;
 #pragma unroll
     for (int i = 0; i < PX; ++i) colbits |= (x + i >= 0 && x + i < W) ? (1u << i) : 0u;
-    const bool out_lane = lane >= ol && lane < WAVE - ol && lane_any;
+    const bool out_lane = lane >= ol && lane < WAVE - ol && lane_in;
 
     double n0 = 0.0, n1 = 0.0;
     if constexpr (BLK) {
@@ -337,17 +342,17 @@ __global__ void __launch_bounds__(WAVE) fit_apply_kernel(const FitArgs a) {
 
     const int t_first = y0 - rh, t_last = y1 - 1 + rh;
     // two rows in flight ahead of the one being consumed
-    RowRaw q0 = load_row(sp, rp, a.stride, t_first, H, x, W, lane_full, lane_any);
-    RowRaw q1 = load_row(sp, rp, a.stride, t_first + 1 <= t_last ? t_first + 1 : -1, H, x, W, lane_full, lane_any);
+    RowRaw q0 = load_row(sp, rp, a.stride, t_first, H, x, lane_in);
+    RowRaw q1 = load_row(sp, rp, a.stride, t_first + 1 <= t_last ? t_first + 1 : -1, H, x, lane_in);
 
     unsigned nfail = 0;
     int slot = 0;
     int slot_c = kh - rh;  // slot of the centre row of the output produced at this iteration: (slot - rh) mod kh
     if (slot_c >= kh) slot_c -= kh;
     for (int t = t_first; t <= t_last; ++t) {
-        const RowRaw q2 = load_row(sp, rp, a.stride, t + 2 <= t_last ? t + 2 : -1, H, x, W, lane_full, lane_any);
+        const RowRaw q2 = load_row(sp, rp, a.stride, t + 2 <= t_last ? t + 2 : -1, H, x, lane_in);
 
-        const RowZ znew = process_row<MODEL>(q0, t >= 0 && t < H, colbits, a, n0, n1);
+        const RowZ znew = process_row<MODEL>(q0, t >= 0 && t < H, colbits, ts, tr, n0, n1);
         // leaving row (t - kh): read from the slot the entering row is about to overwrite
         RowZ zold;
         {
@@ -469,23 +474,12 @@ __global__ void __launch_bounds__(WAVE) fit_apply_kernel(const FitArgs a) {
             }
 
             if (out_lane) {
+                // stride % 4 == 0: a quad never crosses the row end, columns >= W land in the row padding
                 const long long off = out_base + (long long)y * a.stride + x;
-                if (lane_full) {
-                    if (a.corr) *reinterpret_cast<float4*>(a.corr + off) = make_float4(c[0], c[1], c[2], c[3]);
-                    if (a.gain) *reinterpret_cast<float4*>(a.gain + off) = make_float4(g[0], g[1], g[2], g[3]);
-                    if (a.offset) *reinterpret_cast<float4*>(a.offset + off) = make_float4(o[0], o[1], o[2], o[3]);
-                    if (R2 && a.r2) *reinterpret_cast<float4*>(a.r2 + off) = make_float4(r2v[0], r2v[1], r2v[2], r2v[3]);
-                } else {
-#pragma unroll
-                    for (int i = 0; i < PX; ++i) {
-                        if ((colbits >> i) & 1u) {
-                            if (a.corr) a.corr[off + i] = c[i];
-                            if (a.gain) a.gain[off + i] = g[i];
-                            if (a.offset) a.offset[off + i] = o[i];
-                            if (R2 && a.r2) a.r2[off + i] = r2v[i];
-                        }
-                    }
-                }
+                if (a.corr) *reinterpret_cast<float4*>(a.corr + off) = make_float4(c[0], c[1], c[2], c[3]);
+                if (a.gain) *reinterpret_cast<float4*>(a.gain + off) = make_float4(g[0], g[1], g[2], g[3]);
+                if (a.offset) *reinterpret_cast<float4*>(a.offset + off) = make_float4(o[0], o[1], o[2], o[3]);
+                if (R2 && a.r2) *reinterpret_cast<float4*>(a.r2 + off) = make_float4(r2v[0], r2v[1], r2v[2], r2v[3]);
             }
         }
 
