@@ -115,18 +115,9 @@ def parity_spot_check(ctx, args, bufs, stride, band_stride, thresh):
 
 def main():
     args = parse_args()
-    rank = int(os.environ.get('RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    from homonim_amd import _hk, dist
+    rank, world, local_rank = dist.init()  # torch.distributed (nccl = RCCL) only when WORLD_SIZE > 1
     n_gpus = args.gpus
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
-
-    from homonim_amd import _hk
     ctx = _hk.Context(local_rank, n_streams=2)
     ctx.selftest()
 
@@ -161,9 +152,7 @@ def main():
             ctx.block_norm_dev(desc, job, bufs['norm'])  # the block statistics are part of the fit
         ctx.fit_apply_dev(desc, job)
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
+    barrier = dist.barrier
 
     for _ in range(args.warmup):
         step()
@@ -182,11 +171,7 @@ def main():
     elapsed = time.perf_counter() - t0
 
     launch_ms = [ctx.event_elapsed_ms(events[i], events[i + 1]) for i in range(args.steps)]
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f'cuda:{local_rank}')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = dist.max_over_ranks(elapsed)
 
     fail = np.zeros(B, np.uint64)
     ctx.d2h(fail, bufs['fail'])
@@ -238,8 +223,7 @@ def main():
     for name in ('src', 'ref', 'corr', 'fail', 'norm'):
         ctx.dev_free(bufs[name])
     ctx.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    dist.finalize()
 
 
 if __name__ == '__main__':

@@ -1,0 +1,69 @@
+"""
+Multi-process plumbing for one-process-per-GPU runs (``python -m torch.distributed.run ... bench.py``).
+
+The hot path has NO data-path collective: (band x block) work items are independent, every rank
+works on its own shard and the only exchanges are a barrier and scalar reductions for timing / bookkeeping.  Those go
+through ``torch.distributed`` -- backend "nccl" (= RCCL over xGMI on ROCm) when this rank has a GPU, "gloo" otherwise
+(CPU tests).  torch is imported lazily and only when WORLD_SIZE > 1.
+"""
+import os
+from typing import Optional, Tuple
+
+_state = dict(initialised=False, world=1, rank=0, local_rank=0, backend=None)
+
+
+def env_ranks() -> Tuple[int, int, int]:
+    """ (rank, world_size, local_rank) from the torchrun environment (1-process defaults). """
+    return (int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1')),
+            int(os.environ.get('LOCAL_RANK', '0')))
+
+
+def init(backend: Optional[str] = None) -> Tuple[int, int, int]:
+    """ Join the process group named by the environment; a no-op for single-process runs. """
+    rank, world, local_rank = env_ranks()
+    _state.update(world=world, rank=rank, local_rank=local_rank)
+    if world > 1 and not _state['initialised']:
+        import torch
+        import torch.distributed as dist
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if backend == 'nccl':
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend=backend)
+        _state.update(initialised=True, backend=backend)
+    return rank, world, local_rank
+
+
+def _reduce(value: float, op_name: str) -> float:
+    if not _state['initialised']:
+        return float(value)
+    import torch
+    import torch.distributed as dist
+    device = f"cuda:{_state['local_rank']}" if _state['backend'] == 'nccl' else 'cpu'
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=getattr(dist.ReduceOp, op_name))
+    return float(t.item())
+
+
+def barrier():
+    if _state['initialised']:
+        import torch.distributed as dist
+        dist.barrier()
+
+
+def max_over_ranks(value: float) -> float:
+    return _reduce(value, 'MAX')
+
+
+def sum_over_ranks(value: float) -> float:
+    return _reduce(value, 'SUM')
+
+
+def finalize():
+    if _state['initialised']:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+        _state['initialised'] = False

@@ -116,7 +116,8 @@ def _make_rasterio():
             return hash(self.name)
 
     class Window(namedtuple('Window', 'col_off row_off width height')):
-        pass
+        def toranges(self):
+            return ((self.row_off, self.row_off + self.height), (self.col_off, self.col_off + self.width))
 
     class _Placeholder:
         pass
@@ -257,8 +258,69 @@ CASES += [
 ]
 
 
+class _FakeDataset:
+    """ North-up dataset with unit pixels at the origin: just enough of rasterio.DatasetReader for block_pairs(). """
+    closed = False
+
+    def __init__(self, height, width, res=(1., 1.)):
+        self.height, self.width, self.res = height, width, res
+        self.shape = (height, width)
+
+    def window_bounds(self, win):
+        rx, ry = self.res
+        return (win.col_off * rx, -(win.row_off + win.height) * ry, (win.col_off + win.width) * rx, -win.row_off * ry)
+
+    def window(self, left, bottom, right, top):
+        rx, ry = self.res
+        Window = sys.modules['rasterio.windows'].Window
+        return Window(left / rx, -top / ry, (right - left) / rx, (top - bottom) / ry)
+
+
+def gen_block_goldens():
+    """ The reference's own block partition (raster_pair.py:227-269,342-428) on same-grid rasters -> JSON table. """
+    import warnings
+    spec = importlib.util.spec_from_file_location('homonim.raster_pair', os.path.join(REF_ROOT, 'homonim', 'raster_pair.py'))
+    rp = importlib.util.module_from_spec(spec)
+    sys.modules['homonim.raster_pair'] = rp
+    spec.loader.exec_module(rp)
+    Window = sys.modules['rasterio.windows'].Window
+    ProcCrs = sys.modules['homonim.enums'].ProcCrs
+    table = []
+    cases = [  # (height, width, n_bands, kernel_shape, max_block_mem MB)
+        (16384, 16384, 4, (5, 5), 100), (16384, 16384, 8, (15, 15), 100), (8192, 8192, 4, (5, 5), 100),
+        (4096, 4096, 4, (5, 5), 100), (1421, 805, 3, (5, 5), 1), (1000, 3000, 2, (3, 7), 2), (777, 333, 1, (9, 9), 0.5),
+        (2048, 2048, 1, (1, 1), 4), (100, 100, 2, (5, 5), float('inf')),
+    ]
+    for (h, w, nb, k, mem) in cases:
+        for proc in (ProcCrs.ref, ProcCrs.src):
+            rdr = object.__new__(rp.RasterPairReader)
+            rdr._src_im, rdr._ref_im = _FakeDataset(h, w), _FakeDataset(h, w)
+            rdr._src_bands = tuple(range(1, nb + 1))
+            rdr._ref_bands = tuple(range(1, nb + 1))
+            rdr._src_win = rdr._ref_win = Window(0, 0, w, h)
+            rdr._proc_crs = proc
+            rdr._src_filename = rdr._ref_filename = 'fake.tif'
+            overlap = sys.modules['homonim.utils'].overlap_for_kernel(k)
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                block_shape = rdr._auto_block_shape(max_block_mem=mem)
+                bps = list(rdr.block_pairs(overlap=overlap, max_block_mem=mem))
+            wins = [[bp.band_i, *[int(v) for v in bp.src_in_block], *[int(v) for v in bp.src_out_block],
+                     *[int(v) for v in bp.ref_in_block], *[int(v) for v in bp.ref_out_block], bool(bp.outer)] for bp in bps]
+            table.append(dict(height=h, width=w, n_bands=nb, kernel_shape=list(k), overlap=[int(o) for o in overlap],
+                              max_block_mem=(None if mem == float('inf') else mem), proc_crs=proc.value,
+                              block_shape=[int(b) for b in block_shape], n_blocks=len(wins),
+                              # [band_i, src_in(col_off,row_off,w,h), src_out(...), ref_in(...), ref_out(...), outer]
+                              block_pairs=wins if len(wins) <= 70 else wins[:35] + wins[-35:]))
+    with open(os.path.join(GOLDEN_DIR, 'block_pairs.json'), 'w') as f:
+        json.dump(dict(note='reference raster_pair.py block partition on same-grid rasters; for > 70 blocks only the '
+                            'first and last 35 are stored', cases=table), f)
+    print(f'block goldens: {len(table)} cases')
+
+
 def main():
     mods = load_reference()
+    gen_block_goldens()
     os.makedirs(GOLDEN_DIR, exist_ok=True)
     h, w = 36, 52
     manifest = dict(

@@ -1,0 +1,130 @@
+"""
+CPU tests of the block scheduler: the partition rule against tables produced by the reference's own
+raster_pair.py (tests/golden/block_pairs.json, oracle/gen_golden.py), sharding, and the N>1 rank path under gloo.
+"""
+import json
+import os
+import subprocess
+import sys
+import warnings
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_DIR, REPO
+from homonim_amd import fuse, utils
+from homonim_amd.errors import BlockSizeError
+
+
+def _golden_blocks():
+    with open(os.path.join(GOLDEN_DIR, 'block_pairs.json')) as f:
+        return json.load(f)['cases']
+
+
+@pytest.mark.parametrize('case', _golden_blocks(), ids=lambda c: f"{c['height']}x{c['width']}x{c['n_bands']}-k{c['kernel_shape']}-m{c['max_block_mem']}-{c['proc_crs']}")
+def test_block_partition_matches_reference(case):
+    mem = float('inf') if case['max_block_mem'] is None else case['max_block_mem']
+    shape = (case['height'], case['width'])
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        assert list(fuse.auto_block_shape(shape, mem)) == case['block_shape']
+        overlap = utils.overlap_for_kernel(case['kernel_shape'])
+        assert list(overlap) == case['overlap']
+        bps = list(fuse.block_pairs(shape, case['n_bands'], overlap, mem))
+    assert len(bps) == case['n_blocks']
+    rows = [[bp.band_i, *bp.src_in_block, *bp.src_out_block, *bp.ref_in_block, *bp.ref_out_block, bp.outer] for bp in bps]
+    exp = case['block_pairs']
+    if len(rows) > 70:
+        rows = rows[:35] + rows[-35:]
+    assert rows == exp
+    # out-blocks tile each band exactly once
+    cover = np.zeros((case['n_bands'], *shape), np.uint8) if case['height'] * case['width'] <= 4096 * 4096 else None
+    if cover is not None:
+        for bp in bps:
+            rs, cs = bp.src_out_block.toslices()
+            cover[bp.band_i][rs, cs] += 1
+        assert (cover == 1).all()
+
+
+def test_baseline_sizes_appendix_b():
+    """ 16384^2 at max_block_mem=100 -> 4096^2 blocks, 16 per band; in-block rows with k=5. """
+    assert fuse.auto_block_shape((16384, 16384), 100) == (4096, 4096)
+    assert fuse.auto_block_shape((8192, 8192), 100) == (4096, 4096)
+    bps = list(fuse.block_pairs((16384, 16384), 1, (3, 3), 100))
+    assert len(bps) == 16
+    rows = sorted({(bp.src_in_block.row_off, bp.src_in_block.row_off + bp.src_in_block.height) for bp in bps})
+    assert rows == [(0, 4099), (4093, 8195), (8189, 12291), (12285, 16384)]
+
+
+def test_block_size_errors():
+    with pytest.raises(BlockSizeError):
+        fuse.auto_block_shape((100, 100), 1e-9)
+    with pytest.raises(BlockSizeError), warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        list(fuse.block_pairs((64, 64), 1, (16, 16), 64 * 8 * 4 / 2**20))
+
+
+def test_shard_is_a_partition():
+    items = list(range(37))
+    for n in (1, 2, 3, 8):
+        parts = [fuse.shard(items, i, n) for i in range(n)]
+        assert sorted(sum(parts, [])) == items
+        assert max(map(len, parts)) - min(map(len, parts)) <= 1
+    with pytest.raises(ValueError):
+        fuse.shard(items, 2, 2)
+
+
+def test_config_factories():
+    assert fuse.RasterFuse.create_block_config()['max_block_mem'] == 100
+    assert fuse.RasterFuse.create_block_config(threads=1)['threads'] == 1
+    prof = fuse.RasterFuse.create_out_profile()
+    assert prof['driver'] == 'GTiff' and prof['dtype'] == 'float32' and np.isnan(prof['nodata'])
+    assert prof['creation_options']['compress'] == 'deflate'
+    assert fuse.RasterFuse.create_model_config()['r2_inpaint_thresh'] == 0.25
+    with pytest.raises(TypeError):
+        fuse.RasterFuse.create_block_config(bogus=1)
+
+
+def test_convert_dtype_round_clip_nodata():
+    """ reference tests/test_raster_array.py:297-358 semantics: round, clip, nan -> nodata. """
+    a = np.array([[-5.4, 0.5, 1.5, 2.5], [254.6, 300., np.nan, 7.49]], np.float32)
+    out = fuse.convert_dtype(a, 'uint8', 0)
+    assert out.dtype == np.uint8
+    assert out.tolist() == [[0, 0, 2, 2], [255, 255, 0, 7]]
+    out16 = fuse.convert_dtype(a, 'int16', -9999)
+    assert out16.tolist() == [[-5, 0, 2, 2], [255, 300, -9999, 7]]
+
+
+_WORKER = r'''
+import os, sys, json
+sys.path.insert(0, {repo!r})
+from homonim_amd import dist, fuse, utils
+rank, world, local_rank = dist.init()          # gloo on a GPU-less host
+blocks = list(fuse.block_pairs((3000, 2000), 3, utils.overlap_for_kernel((5, 5)), 4))
+mine = fuse.shard(blocks, rank, world)
+px = sum(b.src_out_block.width * b.src_out_block.height for b in mine)
+dist.barrier()
+total = dist.sum_over_ranks(px)
+slowest = dist.max_over_ranks(float(rank + 1))
+n_blocks = dist.sum_over_ranks(len(mine))
+if rank == 0:
+    print(json.dumps(dict(world=world, total=total, slowest=slowest, n_blocks=n_blocks, all_blocks=len(blocks))))
+dist.finalize()
+'''
+
+
+@pytest.mark.timeout(180)
+def test_rank_sharding_gloo_world2(tmp_path):
+    """ The N>1 path of bench.py / RasterFuse: every rank takes a disjoint shard, scalar reductions over gloo. """
+    script = tmp_path / 'worker.py'
+    script.write_text(_WORKER.format(repo=REPO))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='1')
+    res = subprocess.run(
+        [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+         '--master-port', '29617', str(script)], capture_output=True, text=True, env=env, timeout=170
+    )
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = [l for l in res.stdout.splitlines() if l.startswith('{')][-1]
+    out = json.loads(line)
+    assert out['world'] == 2 and out['total'] == 3000 * 2000 * 3 and out['slowest'] == 2.0
+    assert out['n_blocks'] == out['all_blocks']

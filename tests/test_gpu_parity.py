@@ -273,3 +273,97 @@ def test_concurrent_callers_share_one_model(ctx):
     for (src, ref), corr in zip(blocks, got):
         exp, _ = onp.fit_gain_offset(src, np.nan, ref, np.nan, (5, 5), False, None)
         assert_close_ulp(corr, onp.apply(src, exp), 'corrected')
+
+
+# -- RasterFuse.process block loop (homonim/fuse.py:321-408) ------------------------------------------------------------
+def _oracle_process(src, ref, nodata, model, kernel_shape, max_block_mem, want_params, thresh):
+    """ The reference's block loop restated with the oracle per block: read in-block, fit, apply, crop to out-block. """
+    import warnings
+    from homonim_amd import fuse, utils
+    nb, h, w = src.shape
+    find_r2 = want_params
+    with_r2 = find_r2 or (model == 'gain-offset' and thresh is not None)
+    corr = np.full(src.shape, np.nan, np.float32)
+    params = np.full(((3 if with_r2 else 2) * nb, h, w), np.nan, np.float32)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        bps = list(fuse.block_pairs((h, w), nb, utils.overlap_for_kernel(kernel_shape), max_block_mem))
+    for bp in bps:
+        rs, cs = bp.src_in_block.toslices()
+        s, r = src[bp.band_i][rs, cs], ref[bp.band_i][rs, cs]
+        p, _ = onp.fit(model, s, nodata, r, nodata, kernel_shape, find_r2, thresh)
+        c = onp.apply(s, p)
+        crop = fuse.RasterFuse._crop(bp)
+        ors, ocs = bp.src_out_block.toslices()
+        corr[bp.band_i][ors, ocs] = c[crop]
+        for pi in range(p.shape[0]):
+            params[pi * nb + bp.band_i][ors, ocs] = p[pi][crop]
+    return corr, params, len(bps)
+
+
+@pytest.mark.parametrize('model, kernel_shape, thresh', [
+    ('gain-blk-offset', (5, 5), 0.25), ('gain-offset', (5, 5), 0.25), ('gain', (3, 3), None),
+    ('gain-blk-offset', (15, 15), None),
+])
+@pytest.mark.parametrize('threads', [1, 4])
+def test_raster_fuse_process_multi_block(ctx, model, kernel_shape, thresh, threads):
+    import warnings
+    from homonim_amd.fuse import RasterFuse
+    nb, h, w = 3, 700, 900
+    pairs = [onp.synth_pair(h, w, 40 + b, 'frame+holes') for b in range(nb)]
+    src = np.stack([p[0] for p in pairs])
+    ref = np.stack([p[1] for p in pairs])
+    mem = 0.5  # MB -> several blocks per band
+    exp_corr, exp_params, n_blocks = _oracle_process(src, ref, np.nan, model, kernel_shape, mem, True, thresh)
+    assert n_blocks >= 3 * 4
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        with RasterFuse(src, ref) as rf:
+            corr, params = rf.process(None, model, kernel_shape, param_filename=True,
+                                      model_config=dict(r2_inpaint_thresh=thresh),
+                                      block_config=dict(threads=threads, max_block_mem=mem))
+    if model == 'gain-blk-offset':
+        # block statistics: float64 on the GPU vs numpy float32 pairwise -> ~5e-7 relative in every parameter
+        ok = ~np.isnan(exp_corr)
+        assert (np.isnan(corr) == np.isnan(exp_corr)).all()
+        assert np.max(np.abs(corr[ok] - exp_corr[ok]) / np.maximum(np.abs(exp_corr[ok]), 1e-6)) < 1e-5
+        okp = ~np.isnan(exp_params[:2 * nb])
+        assert np.max(np.abs(params[:2 * nb][okp] - exp_params[:2 * nb][okp]) /
+                      np.maximum(np.abs(exp_params[:2 * nb][okp]), 1e-3)) < 1e-5
+    else:
+        assert_close_ulp(corr, exp_corr, 'corrected')
+        assert_close_ulp(params, exp_params, 'params')
+        # gain / gain-offset are partition invariant: the block loop equals one whole-image fit (SURVEY.md 8e)
+        for b in range(nb):
+            whole, _ = onp.fit(model, src[b], np.nan, ref[b], np.nan, kernel_shape, True, thresh)
+            assert_close_ulp(corr[b], onp.apply(src[b], whole), 'corrected vs whole-image fit')
+
+
+def test_raster_fuse_shards_are_disjoint_and_complete(ctx):
+    """ rank sharding of process(): the union of two ranks' outputs is the single-rank result. """
+    from homonim_amd.fuse import RasterFuse
+    src, ref = onp.synth_pair(600, 500, 77, 'frame+holes')
+    kw = dict(model='gain-offset', kernel_shape=(5, 5), model_config=dict(r2_inpaint_thresh=None),
+              block_config=dict(threads=2, max_block_mem=0.25))
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        full, _ = RasterFuse(src, ref).process(**kw)
+        parts = [RasterFuse(src, ref).process(device_config=dict(rank=r, world_size=2), **kw)[0] for r in range(2)]
+    filled = [~np.isnan(p) for p in parts]
+    assert not (filled[0] & filled[1]).any()
+    merged = np.where(filled[0], parts[0], parts[1])
+    assert_same_f32(merged, full, 'merged shards')
+
+
+def test_raster_fuse_uint8_output(ctx):
+    from homonim_amd.fuse import RasterFuse
+    rng = np.random.default_rng(5)
+    src = np.round(rng.uniform(1, 255, (2, 300, 400))).astype(np.float32)
+    ref = np.round(0.8 * src + 20 + rng.normal(0, 3, src.shape)).astype(np.float32)
+    src[:, :4], src[:, :, -4:] = 0, 0
+    corr, _ = RasterFuse(src, ref, src_nodata=0, ref_nodata=None).process(
+        model='gain-blk-offset', kernel_shape=(5, 5), out_profile=dict(dtype='uint8', nodata=0))
+    assert corr.dtype == np.uint8 and (corr[:, :4] == 0).all() and (corr[:, :, -4:] == 0).all()
+    valid = src != 0
+    assert abs(float(corr[valid].astype(np.float64).mean()) - float(ref[valid].mean())) < 3
