@@ -113,6 +113,21 @@ def parity_spot_check(ctx, args, bufs, stride, band_stride, thresh):
                 nan_pattern_equal=nan_ok, passed=bool(nan_ok and rel <= 1e-5))
 
 
+def measured_traffic(args):
+    """ HBM bytes per launch from the committed rocprofv3 PMC summary (collected in separate --pmc passes, FETCH_SIZE
+    corrected x2 for gfx950) when it was taken at exactly this configuration; None otherwise. """
+    try:
+        with open(os.path.join(REPO, 'profiles', 'pmc_summary.json')) as f:
+            pmc = json.load(f)
+        c = pmc['config']
+        if (c['model'], c['kernel'], c['size'], c['bands'], c['nodata']) == (args.model, args.kernel, args.size,
+                                                                           args.bands, args.nodata):
+            return float(pmc['hbm_traffic_bytes'])
+    except Exception:
+        pass
+    return None
+
+
 def main():
     args = parse_args()
     from homonim_amd import _hk, dist
@@ -209,7 +224,7 @@ def main():
             },
             'roofline': {
                 'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                'frac': round(achieved / HBM_PEAK_GBPS, 4), 'traffic': None,
+                'frac': round(achieved / HBM_PEAK_GBPS, 4), 'traffic': measured_traffic(args),
                 'kernel': 'hk::fit_apply_kernel', 'avg_launch_ms': round(avg_ms, 4),
                 'algorithmic_bytes_per_launch': ALGO_BYTES_PER_PX * px_bands,
             },
