@@ -39,6 +39,7 @@ def parse_args():
     p.add_argument('--kernel', type=int, default=5)
     p.add_argument('--seg-rows', type=int, default=0)
     p.add_argument('--nodata', type=int, default=0, help='0: no nodata, 1: NaN frame + 0.1%% holes')
+    p.add_argument('--no-thresh', action='store_true', help='gain-offset without r2_inpaint_thresh (no R2 work)')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-parity', action='store_true')
     p.add_argument('--cpu-sample', type=int, default=0, help='CPU baseline sample size (square); 0 = auto')
@@ -142,7 +143,7 @@ def main():
     stride = (W + 63) // 64 * 64
     band_stride = stride * H
     plane_bytes = 4 * band_stride * B
-    thresh = 0.25 if args.model == 'gain-offset' else None
+    thresh = 0.25 if (args.model == 'gain-offset' and not args.no_thresh) else None
     desc = _hk.make_desc(args.model, (k, k), False, thresh, np.nan if args.nodata else None,
                          np.nan if args.nodata else None)
 

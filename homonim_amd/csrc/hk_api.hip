@@ -6,9 +6,12 @@
 // thread-local error string; any number of host threads may use one context (homonim/fuse.py:396-401).
 #include <hip/hip_runtime.h>
 
+#include <cfloat>
+#include <cmath>
 #include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -121,6 +124,29 @@ int validate_desc(const hk_fit_desc* d) {
     return HK_OK;
 }
 
+// The reference decides `(1 - f32(f64(ssres / sstot))) > thresh` (kernel_model.py:212-213,363).  Returns a float64 factor
+// c such that, for sstot > 0, `ssres < c * sstot` PROVES that decision true: c sits 2^-40 (relative) below the
+// float32 rounding boundary of the largest quotient that still passes, which swallows the 2^-53 errors of the float64
+// division and of the comparison product.  -inf = nothing can be certified (threshold >= 1 or NaN).
+double r2_pass_scale(float thresh) {
+    if (!(thresh < 1.0f)) return -INFINITY;
+    // largest float q with (1.0f - q) > thresh: the predicate is monotone non-increasing in q
+    auto key = [](float f) { uint32_t u; memcpy(&u, &f, 4); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); };
+    auto unkey = [](uint32_t k) { uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k; float f; memcpy(&f, &u, 4); return f; };
+    uint32_t lo = key(-FLT_MAX), hi = key(FLT_MAX);  // pred(lo) is true for every thresh < 1
+    auto pred = [&](uint32_t k) { volatile float d = 1.0f - unkey(k); return d > thresh; };
+    if (!pred(lo)) return -INFINITY;
+    while (lo < hi) {
+        const uint32_t mid = lo + (hi - lo + 1) / 2;
+        if (pred(mid)) lo = mid; else hi = mid - 1;
+    }
+    const float q = unkey(lo);
+    const float qn = nextafterf(q, INFINITY);
+    const double boundary = std::isinf(qn) ? (double)q : 0.5 * ((double)q + (double)qn);
+    if (!(boundary > 0.0)) return -INFINITY;
+    return boundary * (1.0 - 0x1p-40);
+}
+
 void fill_args(hk::FitArgs& a, const hk_fit_desc* d, int xcd_remap) {
     a.rh = d->kh / 2;
     a.rw = d->kw / 2;
@@ -131,6 +157,8 @@ void fill_args(hk::FitArgs& a, const hk_fit_desc* d, int xcd_remap) {
     a.ref_nodata = d->ref_nodata;
     a.has_thresh = (d->model == HK_MODEL_GAIN_OFFSET) ? d->has_r2_thresh : 0;
     a.r2_thresh = d->r2_thresh;
+    a.r2_pass_scale = a.has_thresh ? r2_pass_scale(d->r2_thresh) : -INFINITY;
+    a.force_general = getenv("HK_FORCE_GENERAL") ? atoi(getenv("HK_FORCE_GENERAL")) : 0;
     a.xcd_remap = xcd_remap;
 }
 

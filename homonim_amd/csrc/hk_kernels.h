@@ -31,6 +31,8 @@ struct FitArgs {
     float src_nodata, ref_nodata;
     int has_thresh;
     float r2_thresh;
+    double r2_pass_scale;   // certified-pass factor of the division-free r2-mask test (hk_api.hip: r2_pass_scale())
+    int force_general;      // 1: never take the dense (nodata None) specialisation (testing)
     int xcd_remap;          // 1: blockIdx -> unit remap that keeps neighbouring units on one XCD
 };
 

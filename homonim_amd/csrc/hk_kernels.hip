@@ -207,13 +207,24 @@ struct RowZ {
     unsigned m;  // byte i = mask of pixel i (0/1)
 };
 
-template <int MODEL>
-__device__ __forceinline__ RowZ process_row(const RowRaw& raw, bool row_ok, unsigned colbits, const NodataTest& ts,
-                                            const NodataTest& tr, double n0, double n1) {
+// DENSE: both rasters have nodata None (raster_array.py:302-303: every pixel valid), so validity is purely geometric:
+// rows / lanes outside the raster were loaded as zeros, only the tail of a ragged last quad needs zeroing.
+template <int MODEL, bool DENSE>
+__device__ __forceinline__ RowZ process_row(const RowRaw& raw, bool row_ok, unsigned colbits, bool ragged,
+                                            const NodataTest& ts, const NodataTest& tr, double n0, double n1) {
     const float s[PX] = {raw.s.x, raw.s.y, raw.s.z, raw.s.w};
     const float r[PX] = {raw.r.x, raw.r.y, raw.r.z, raw.r.w};
     RowZ z;
     z.m = 0;
+    if constexpr (DENSE) {
+#pragma unroll
+        for (int i = 0; i < PX; ++i) {
+            const bool in = !ragged | (bool)((colbits >> i) & 1u);
+            z.s[i] = in ? s[i] : 0.f;
+            z.r[i] = in ? r[i] : 0.f;
+        }
+        return z;
+    }
 #pragma unroll
     for (int i = 0; i < PX; ++i) {
         bool m = row_ok & (bool)((colbits >> i) & 1u) & px_valid(s[i], ts) & px_valid(r[i], tr);
@@ -230,10 +241,10 @@ __device__ __forceinline__ RowZ process_row(const RowRaw& raw, bool row_ok, unsi
 }
 
 // Running float64 column sums of one wave.
-template <int MODEL, bool R2>
+template <int MODEL, bool R2, bool DENSE>
 struct ColSums {
     static constexpr bool GO = MODEL == 2, BLK = MODEL == 1;
-    static constexpr bool NEED_N = GO || R2, NEED_P = GO || R2, NEED_S2 = GO || R2, NEED_R2S = R2;
+    static constexpr bool NEED_N = (GO || R2) && !DENSE, NEED_P = GO || R2, NEED_S2 = GO || R2, NEED_R2S = R2;
     double S[PX], R[PX], P[PX], S2[PX], R2s[PX];
     unsigned N;  // packed bytes
 
@@ -247,7 +258,7 @@ struct ColSums {
     __device__ __forceinline__ void update(const RowZ& z, double n0, double n1) {
 #pragma unroll
         for (int i = 0; i < PX; ++i) {
-            const bool m = (z.m >> (8 * i)) & 1u;
+            const bool m = DENSE ? true : (bool)((z.m >> (8 * i)) & 1u);
             const double dr = (double)z.r[i];
             if constexpr (BLK) {
                 // normalised source in float64 (NumPy>=2 promotion of `src * np.float64`, kernel_model.py:295)
@@ -279,14 +290,16 @@ struct ColSums {
 
 // ---------------------------------------------------------------------------------------------------------------------
 // The fused kernel.  MODEL: 0 gain, 1 gain-blk-offset, 2 gain-offset.  R2: compute the R2 quantity set.
-// RW: compile-time kernel half-width, or -1 for the run-time path.
+// RW: compile-time kernel half-width, or -1 for the run-time path.  DENSE: both inputs have nodata None.
 #ifndef HK_FIT_MIN_WAVES
 #define HK_FIT_MIN_WAVES 3  // waves per SIMD the register allocator must leave room for (tuned on MI355X)
 #endif
-template <int MODEL, bool R2, int RW>
+template <int MODEL, bool R2, int RW, bool DENSE>
 __global__ void __launch_bounds__(WAVE, HK_FIT_MIN_WAVES) fit_apply_kernel(const FitArgs a) {
-    using CS = ColSums<MODEL, R2>;
+    using CS = ColSums<MODEL, R2, DENSE>;
     constexpr bool GO = MODEL == 2, BLK = MODEL == 1;
+    constexpr bool USE_N = GO || R2;
+    static_assert(!(DENSE && BLK), "gain-blk-offset re-derives its mask from the normalised source");
     extern __shared__ float4 lds4[];
 
     const int lane = threadIdx.x;
@@ -315,12 +328,24 @@ __global__ void __launch_bounds__(WAVE, HK_FIT_MIN_WAVES) fit_apply_kernel(const
     const long long out_base = (long long)band * a.band_stride;
 
     const bool lane_in = x >= 0 && x < W;
+    const bool ragged = (W & (PX - 1)) != 0;
     const NodataTest ts = make_nodata_test(a.src_nd_mode, a.src_nodata);
     const NodataTest tr = make_nodata_test(a.ref_nd_mode, a.ref_nodata);
     unsigned colbits = 0;
 #pragma unroll
     for (int i = 0; i < PX; ++i) colbits |= (x + i >= 0 && x + i < W) ? (1u << i) : 0u;
     const bool out_lane = lane >= ol && lane < WAVE - ol && lane_in;
+
+    // DENSE: the window count is geometric -- (rows of the window inside the raster) x (columns inside the raster)
+    [[maybe_unused]] float ncolf[PX];
+    if constexpr (DENSE) {
+#pragma unroll
+        for (int i = 0; i < PX; ++i) {
+            const int c = x + i;
+            const int n = min(c + rw, W - 1) - max(c - rw, 0) + 1;
+            ncolf[i] = (float)(n > 0 ? n : 1);
+        }
+    }
 
     double n0 = 0.0, n1 = 0.0;
     if constexpr (BLK) {
@@ -334,7 +359,7 @@ __global__ void __launch_bounds__(WAVE, HK_FIT_MIN_WAVES) fit_apply_kernel(const
     for (int sl = 0; sl < kh; ++sl) {
         ring_v[(sl * 2 + 0) * WAVE + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
         ring_v[(sl * 2 + 1) * WAVE + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
-        ring_m[sl * WAVE + lane] = 0u;
+        if constexpr (!DENSE) ring_m[sl * WAVE + lane] = 0u;
     }
 
     CS cs;
@@ -345,6 +370,14 @@ __global__ void __launch_bounds__(WAVE, HK_FIT_MIN_WAVES) fit_apply_kernel(const
     RowRaw q0 = load_row(sp, rp, a.stride, t_first, H, x, lane_in);
     RowRaw q1 = load_row(sp, rp, a.stride, t_first + 1 <= t_last ? t_first + 1 : -1, H, x, lane_in);
 
+    // r2-mask bookkeeping (gain-offset with a threshold, kernel_model.py:363): R2 values are only materialised when
+    // asked for; otherwise pixels are first put through a division-free CERTIFIED test
+    //     sstot > 0  &&  ssres < pass_scale * sstot  &&  gain > 0     ==>   (r2 > thresh) & (gain > 0)
+    // (pass_scale sits 2^-40 below the rounding boundary of the reference's `1 - f32(ssres/sstot) > thresh`, hk_api.hip)
+    // and the exact IEEE evaluation runs for the whole wave-row as soon as any pixel is not certified.
+    const bool want_r2_values = R2 && a.r2 != nullptr;
+    const bool count_fails = GO && R2 && a.has_thresh;
+
     unsigned nfail = 0;
     int slot = 0;
     int slot_c = kh - rh;  // slot of the centre row of the output produced at this iteration: (slot - rh) mod kh
@@ -352,7 +385,7 @@ __global__ void __launch_bounds__(WAVE, HK_FIT_MIN_WAVES) fit_apply_kernel(const
     for (int t = t_first; t <= t_last; ++t) {
         const RowRaw q2 = load_row(sp, rp, a.stride, t + 2 <= t_last ? t + 2 : -1, H, x, lane_in);
 
-        const RowZ znew = process_row<MODEL>(q0, t >= 0 && t < H, colbits, ts, tr, n0, n1);
+        const RowZ znew = process_row<MODEL, DENSE>(q0, t >= 0 && t < H, colbits, ragged, ts, tr, n0, n1);
         // leaving row (t - kh): read from the slot the entering row is about to overwrite
         RowZ zold;
         {
@@ -360,11 +393,11 @@ __global__ void __launch_bounds__(WAVE, HK_FIT_MIN_WAVES) fit_apply_kernel(const
             const float4 orr = ring_v[(slot * 2 + 1) * WAVE + lane];
             zold.s[0] = os.x, zold.s[1] = os.y, zold.s[2] = os.z, zold.s[3] = os.w;
             zold.r[0] = orr.x, zold.r[1] = orr.y, zold.r[2] = orr.z, zold.r[3] = orr.w;
-            zold.m = ring_m[slot * WAVE + lane];
+            zold.m = DENSE ? 0u : ring_m[slot * WAVE + lane];
         }
         ring_v[(slot * 2 + 0) * WAVE + lane] = make_float4(znew.s[0], znew.s[1], znew.s[2], znew.s[3]);
         ring_v[(slot * 2 + 1) * WAVE + lane] = make_float4(znew.r[0], znew.r[1], znew.r[2], znew.r[3]);
-        ring_m[slot * WAVE + lane] = znew.m;
+        if constexpr (!DENSE) ring_m[slot * WAVE + lane] = znew.m;
 
         if (kh == 1) {  // wave-uniform: a 1-row window IS the entering row -- no running sum, exact by construction
             cs.clear();
@@ -379,98 +412,129 @@ __global__ void __launch_bounds__(WAVE, HK_FIT_MIN_WAVES) fit_apply_kernel(const
             // centre row of the window
             const float4 cs4 = ring_v[(slot_c * 2 + 0) * WAVE + lane];
             const float sc[PX] = {cs4.x, cs4.y, cs4.z, cs4.w};
-            const unsigned mc = ring_m[slot_c * WAVE + lane];
+            const unsigned mc = DENSE ? (colbits * 0x00204081u) & 0x01010101u  // bit i -> byte i
+                                      : ring_m[slot_c * WAVE + lane];
 
             double HS[PX], HR[PX];
             hsum_any<RW, double>(cs.S, HS, rw, ol, lane);
             hsum_any<RW, double>(cs.R, HR, rw, ol, lane);
             double HP[PX], HS2[PX], HR2[PX];
-            int HN[PX];
+            float Nf[PX];
             if constexpr (CS::NEED_P) hsum_any<RW, double>(cs.P, HP, rw, ol, lane);
             if constexpr (CS::NEED_S2) hsum_any<RW, double>(cs.S2, HS2, rw, ol, lane);
             if constexpr (CS::NEED_R2S) hsum_any<RW, double>(cs.R2s, HR2, rw, ol, lane);
-            if constexpr (CS::NEED_N) {
-                const int VN[PX] = {(int)(cs.N & 0xffu), (int)((cs.N >> 8) & 0xffu), (int)((cs.N >> 16) & 0xffu),
-                                    (int)(cs.N >> 24)};
-                hsum_any<RW, int>(VN, HN, rw, ol, lane);
+            if constexpr (USE_N) {
+                if constexpr (DENSE) {
+                    const float nrows = (float)(min(y + rh, H - 1) - max(y - rh, 0) + 1);
+#pragma unroll
+                    for (int i = 0; i < PX; ++i) Nf[i] = nrows * ncolf[i];  // exact small integers
+                } else {
+                    const int VN[PX] = {(int)(cs.N & 0xffu), (int)((cs.N >> 8) & 0xffu), (int)((cs.N >> 16) & 0xffu),
+                                        (int)(cs.N >> 24)};
+                    int HN[PX];
+                    hsum_any<RW, int>(VN, HN, rw, ol, lane);
+#pragma unroll
+                    for (int i = 0; i < PX; ++i) Nf[i] = (float)HN[i];
+                }
             }
 
+            // ---- stage A: gains and offsets -------------------------------------------------------------------------
             float g[PX], o[PX], r2v[PX], c[PX];
+            [[maybe_unused]] float Rf[PX], Sf[PX], Pf[PX], gp[PX];
+            [[maybe_unused]] double Nd[PX];
 #pragma unroll
             for (int i = 0; i < PX; ++i) {
-                const bool m = (mc >> (8 * i)) & 1u;
-                const float Rf = (float)HR[i];  // boxFilter output depth = input depth (float32)
-                float gi, oi, r2i = qnan();
-                [[maybe_unused]] float Nf = 0.f, Pf = 0.f;
-                [[maybe_unused]] double Nd = 0.0;
-                if constexpr (CS::NEED_N) {
-                    Nf = (float)HN[i];
-                    Nd = (double)Nf;
-                }
+                Rf[i] = (float)HR[i];  // boxFilter output depth = input depth (float32)
+                if constexpr (USE_N) Nd[i] = (double)Nf[i];
                 if constexpr (GO) {
                     // kernel_model.py:338-351; src2_sum is float64 (sqrBoxFilter) so m_den and the division are f64
-                    const float Sf = (float)HS[i];
-                    Pf = (float)HP[i];
-                    const float num = __fsub_rn(__fmul_rn(Nf, Pf), __fmul_rn(Sf, Rf));
-                    const double den = __dsub_rn(__dmul_rn(Nd, HS2[i]), (double)__fmul_rn(Sf, Sf));
-                    gi = (float)__ddiv_rn((double)num, den);
-                    oi = __fdiv_rn(__fsub_rn(Rf, __fmul_rn(gi, Sf)), Nf);
-                    if constexpr (R2) {
-                        // kernel_model.py:179,189-195,203,212-213
-                        const double sstot = __dsub_rn(__dmul_rn(Nd, HR2[i]), (double)__fmul_rn(Rf, Rf));
-                        const double A = __dmul_rn((double)__fmul_rn(gi, gi), HS2[i]);
-                        const float B = __fmul_rn(__fmul_rn(2.f, __fmul_rn(gi, oi)), Sf);
-                        const float C = __fmul_rn(__fmul_rn(2.f, gi), Pf);
-                        const float D = __fmul_rn(__fmul_rn(2.f, oi), Rf);
-                        const float F = __fmul_rn(Nf, __fmul_rn(oi, oi));
-                        double ssres = __dadd_rn(A, (double)B);
-                        ssres = __dsub_rn(ssres, (double)C);
-                        ssres = __dsub_rn(ssres, (double)D);
-                        ssres = __dadd_rn(ssres, HR2[i]);
-                        ssres = __dadd_rn(ssres, (double)F);
-                        ssres = __dmul_rn(ssres, Nd);
-                        r2i = __fsub_rn(1.f, (float)__ddiv_rn(ssres, sstot));
-                    }
+                    Sf[i] = (float)HS[i];
+                    Pf[i] = (float)HP[i];
+                    const float num = __fsub_rn(__fmul_rn(Nf[i], Pf[i]), __fmul_rn(Sf[i], Rf[i]));
+                    const double den = __dsub_rn(__dmul_rn(Nd[i], HS2[i]), (double)__fmul_rn(Sf[i], Sf[i]));
+                    g[i] = (float)__ddiv_rn((double)num, den);
+                    o[i] = __fdiv_rn(__fsub_rn(Rf[i], __fmul_rn(g[i], Sf[i])), Nf[i]);
                 } else if constexpr (BLK) {
-                    // kernel_model.py:265 with a float64 src_sum: np.divide(f32, f64, out=f32)
-                    const float gp = (float)__ddiv_rn((double)Rf, HS[i]);
-                    if constexpr (R2) {
-                        // kernel_model.py:179,201,203,212-213 with float64 src2_sum / src_ref_sum / ref2_sum
-                        const double sstot = __dsub_rn(__dmul_rn(Nd, HR2[i]), (double)__fmul_rn(Rf, Rf));
-                        double ssres = __dmul_rn((double)__fmul_rn(gp, gp), HS2[i]);
-                        ssres = __dsub_rn(ssres, __dmul_rn((double)__fmul_rn(2.f, gp), HP[i]));
-                        ssres = __dadd_rn(ssres, HR2[i]);
-                        ssres = __dmul_rn(ssres, Nd);
-                        r2i = __fsub_rn(1.f, (float)__ddiv_rn(ssres, sstot));
-                    }
-                    // kernel_model.py:301-302
-                    oi = (float)__dmul_rn((double)gp, n1);
-                    gi = (float)__dmul_rn((double)gp, n0);
+                    // kernel_model.py:265 with a float64 src_sum: np.divide(f32, f64, out=f32); then :301-302
+                    gp[i] = (float)__ddiv_rn((double)Rf[i], HS[i]);
+                    o[i] = (float)__dmul_rn((double)gp[i], n1);
+                    g[i] = (float)__dmul_rn((double)gp[i], n0);
                 } else {
                     // kernel_model.py:262-265
-                    const float Sf = (float)HS[i];
-                    gi = __fdiv_rn(Rf, Sf);
-                    oi = 0.f;
-                    if constexpr (R2) {
-                        Pf = (float)HP[i];
-                        const double sstot = __dsub_rn(__dmul_rn(Nd, HR2[i]), (double)__fmul_rn(Rf, Rf));
-                        double ssres = __dmul_rn((double)__fmul_rn(gi, gi), HS2[i]);
-                        ssres = __dsub_rn(ssres, (double)__fmul_rn(__fmul_rn(2.f, gi), Pf));
-                        ssres = __dadd_rn(ssres, HR2[i]);
-                        ssres = __dmul_rn(ssres, Nd);
-                        r2i = __fsub_rn(1.f, (float)__ddiv_rn(ssres, sstot));
+                    Sf[i] = (float)HS[i];
+                    if constexpr (R2) Pf[i] = (float)HP[i];
+                    g[i] = __fdiv_rn(Rf[i], Sf[i]);
+                    o[i] = 0.f;
+                }
+                r2v[i] = qnan();
+            }
+
+            // ---- stage B: R2 (kernel_model.py:179,189-195|201,203,212-213) ---------------------------------------------
+            if constexpr (R2) {
+                if (want_r2_values || count_fails) {  // wave-uniform
+                    double sstot[PX], ssres[PX];
+#pragma unroll
+                    for (int i = 0; i < PX; ++i) {
+                        sstot[i] = __dsub_rn(__dmul_rn(Nd[i], HR2[i]), (double)__fmul_rn(Rf[i], Rf[i]));
+                        double q;
+                        if constexpr (GO) {
+                            const double A = __dmul_rn((double)__fmul_rn(g[i], g[i]), HS2[i]);
+                            const float B = __fmul_rn(__fmul_rn(2.f, __fmul_rn(g[i], o[i])), Sf[i]);
+                            const float C = __fmul_rn(__fmul_rn(2.f, g[i]), Pf[i]);
+                            const float D = __fmul_rn(__fmul_rn(2.f, o[i]), Rf[i]);
+                            const float F = __fmul_rn(Nf[i], __fmul_rn(o[i], o[i]));
+                            q = __dadd_rn(A, (double)B);
+                            q = __dsub_rn(q, (double)C);
+                            q = __dsub_rn(q, (double)D);
+                            q = __dadd_rn(q, HR2[i]);
+                            q = __dadd_rn(q, (double)F);
+                        } else if constexpr (BLK) {
+                            // float64 src2_sum / src_ref_sum (the normalised source is float64)
+                            q = __dmul_rn((double)__fmul_rn(gp[i], gp[i]), HS2[i]);
+                            q = __dsub_rn(q, __dmul_rn((double)__fmul_rn(2.f, gp[i]), HP[i]));
+                            q = __dadd_rn(q, HR2[i]);
+                        } else {
+                            q = __dmul_rn((double)__fmul_rn(g[i], g[i]), HS2[i]);
+                            q = __dsub_rn(q, (double)__fmul_rn(__fmul_rn(2.f, g[i]), Pf[i]));
+                            q = __dadd_rn(q, HR2[i]);
+                        }
+                        ssres[i] = __dmul_rn(q, Nd[i]);
+                    }
+                    bool exact = want_r2_values;
+                    if (!exact) {
+                        bool uncertain = false;
+#pragma unroll
+                        for (int i = 0; i < PX; ++i) {
+                            const bool m = (mc >> (8 * i)) & 1u;
+                            const bool sure = (sstot[i] > 0.0) & (ssres[i] < __dmul_rn(a.r2_pass_scale, sstot[i])) & (g[i] > 0.f);
+                            uncertain |= out_lane & m & !sure;
+                        }
+                        exact = __any(uncertain);
+                    }
+                    if (exact) {
+#pragma unroll
+                        for (int i = 0; i < PX; ++i) {
+                            r2v[i] = __fsub_rn(1.f, (float)__ddiv_rn(ssres[i], sstot[i]));
+                            if constexpr (GO) {
+                                const bool m = (mc >> (8 * i)) & 1u;
+                                // valid pixels failing (r2 > thresh) & (gain > 0) need in-painting (:363,:370)
+                                if (count_fails && out_lane && m && !((r2v[i] > a.r2_thresh) && (g[i] > 0.f))) ++nfail;
+                            }
+                        }
                     }
                 }
-                // every parameter write in the reference is `where=mask` into a NaN-filled array (:261,:345)
-                g[i] = m ? gi : qnan();
-                o[i] = m ? oi : qnan();
-                r2v[i] = m ? r2i : qnan();
-                // KernelModel.apply (:461): two float32 roundings
-                c[i] = __fadd_rn(__fmul_rn(g[i], sc[i]), o[i]);
-                if constexpr (GO && R2) {
-                    // kernel_model.py:363,370: valid pixels failing (r2 > thresh) & (gain > 0) need in-painting
-                    if (a.has_thresh && out_lane && m && !((r2v[i] > a.r2_thresh) && (g[i] > 0.f))) ++nfail;
+            }
+
+            // ---- stage C: where=mask (every parameter write goes into a NaN-filled array, :261,:345) and apply (:461) ----
+#pragma unroll
+            for (int i = 0; i < PX; ++i) {
+                if constexpr (!DENSE) {
+                    const bool m = (mc >> (8 * i)) & 1u;
+                    g[i] = m ? g[i] : qnan();
+                    o[i] = m ? o[i] : qnan();
+                    r2v[i] = m ? r2v[i] : qnan();
                 }
+                c[i] = __fadd_rn(__fmul_rn(g[i], sc[i]), o[i]);  // two float32 roundings
             }
 
             if (out_lane) {
@@ -500,42 +564,51 @@ __global__ void __launch_bounds__(WAVE, HK_FIT_MIN_WAVES) fit_apply_kernel(const
 
 size_t fit_lds_bytes(int kh) { return (size_t)kh * (2 * WAVE * sizeof(float4) + WAVE * sizeof(unsigned)); }
 
-template <int MODEL, bool R2, int RW>
+template <int MODEL, bool R2, int RW, bool DENSE>
 static hipError_t launch_one(const FitArgs& a, hipStream_t stream) {
     const size_t lds = fit_lds_bytes(2 * a.rh + 1);
     static bool attr_set = false;  // raise the dynamic-LDS cap once per instantiation (64 KiB default)
     if (lds > 64 * 1024 && !attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fit_apply_kernel<MODEL, R2, RW>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fit_apply_kernel<MODEL, R2, RW, DENSE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     int grid = a.total_units;
     if (a.xcd_remap) grid = (grid + 7) / 8 * 8;
-    hipLaunchKernelGGL((fit_apply_kernel<MODEL, R2, RW>), dim3(grid), dim3(WAVE), lds, stream, a);
+    hipLaunchKernelGGL((fit_apply_kernel<MODEL, R2, RW, DENSE>), dim3(grid), dim3(WAVE), lds, stream, a);
     return hipGetLastError();
 }
 
-template <int MODEL, bool R2>
+template <int MODEL, bool R2, bool DENSE>
 static hipError_t launch_rw(const FitArgs& a, hipStream_t stream) {
     switch (a.rw) {
-        case 0: return launch_one<MODEL, R2, 0>(a, stream);
-        case 1: return launch_one<MODEL, R2, 1>(a, stream);
-        case 2: return launch_one<MODEL, R2, 2>(a, stream);
-        case 3: return launch_one<MODEL, R2, 3>(a, stream);
-        case 7: return launch_one<MODEL, R2, 7>(a, stream);
-        default: return launch_one<MODEL, R2, -1>(a, stream);
+        case 0: return launch_one<MODEL, R2, 0, DENSE>(a, stream);
+        case 1: return launch_one<MODEL, R2, 1, DENSE>(a, stream);
+        case 2: return launch_one<MODEL, R2, 2, DENSE>(a, stream);
+        case 3: return launch_one<MODEL, R2, 3, DENSE>(a, stream);
+        case 7: return launch_one<MODEL, R2, 7, DENSE>(a, stream);
+        default: return launch_one<MODEL, R2, -1, DENSE>(a, stream);
     }
+}
+
+template <int MODEL, bool R2>
+static hipError_t launch_dense(const FitArgs& a, hipStream_t stream) {
+    // nodata None on both rasters (and not gain-blk-offset, whose mask depends on the normalised values)
+    if constexpr (MODEL != 1) {
+        if (a.src_nd_mode == 0 && a.ref_nd_mode == 0 && !a.force_general) return launch_rw<MODEL, R2, true>(a, stream);
+    }
+    return launch_rw<MODEL, R2, false>(a, stream);
 }
 
 hipError_t launch_fit_apply(const FitArgs& a, int model, bool with_r2, hipStream_t stream) {
     switch (model * 2 + (with_r2 ? 1 : 0)) {
-        case 0: return launch_rw<0, false>(a, stream);
-        case 1: return launch_rw<0, true>(a, stream);
-        case 2: return launch_rw<1, false>(a, stream);
-        case 3: return launch_rw<1, true>(a, stream);
-        case 4: return launch_rw<2, false>(a, stream);
-        case 5: return launch_rw<2, true>(a, stream);
+        case 0: return launch_dense<0, false>(a, stream);
+        case 1: return launch_dense<0, true>(a, stream);
+        case 2: return launch_dense<1, false>(a, stream);
+        case 3: return launch_dense<1, true>(a, stream);
+        case 4: return launch_dense<2, false>(a, stream);
+        case 5: return launch_dense<2, true>(a, stream);
     }
     return hipErrorInvalidValue;
 }

@@ -367,3 +367,68 @@ def test_raster_fuse_uint8_output(ctx):
     assert corr.dtype == np.uint8 and (corr[:, :4] == 0).all() and (corr[:, :, -4:] == 0).all()
     valid = src != 0
     assert abs(float(corr[valid].astype(np.float64).mean()) - float(ref[valid].mean())) < 3
+
+
+# -- specialisations: dense (nodata None) kernels and the division-free certified r2-mask test --------------------------
+@pytest.mark.parametrize('model, kernel_shape, find_r2, thresh', [
+    ('gain', (5, 5), True, None), ('gain-offset', (5, 5), True, 0.25), ('gain-offset', (3, 7), False, None),
+    ('gain-offset', (15, 15), True, 0.25), ('gain-offset', (9, 9), True, 0.25),
+])
+@pytest.mark.parametrize('shape', [(260, 1003), (131, 250), (64, 1024)])
+def test_dense_path_equals_general_path(ctx, model, kernel_shape, find_r2, thresh, shape, monkeypatch):
+    """ nodata None on both rasters selects the DENSE kernels (geometric window count, no mask ring); results must be
+    bit-identical to the general kernels and to the oracle -- ragged widths included. """
+    import warnings
+    src, ref = onp.synth_pair(*shape, seed=shape[1], nodata_variant='none')
+    cfg = dict(model=model, kernel_shape=kernel_shape, find_r2=find_r2, r2_inpaint_thresh=thresh, src_nodata=None,
+               ref_nodata=None)
+    monkeypatch.setenv('HK_FORCE_GENERAL', '1')
+    p_gen, c_gen, _, f_gen = _fit_via_abi(ctx, cfg, src, ref)
+    monkeypatch.setenv('HK_FORCE_GENERAL', '0')
+    p_den, c_den, _, f_den = _fit_via_abi(ctx, cfg, src, ref)
+    assert_same_f32(p_den, p_gen, 'params dense vs general')
+    assert_same_f32(c_den, c_gen, 'corrected dense vs general')
+    assert f_den == f_gen
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        exp, _ = onp.fit(model, src, None, ref, None, kernel_shape, find_r2, thresh)
+    assert_close_ulp(p_den, exp, 'params')
+
+
+def _fused_no_params(ctx, src, ref, nodata, k, thresh):
+    desc = _hk.make_desc('gain-offset', k, False, thresh, nodata, nodata)
+    _, corr, _, n_fail = ctx.fit_apply(desc, src, ref, 3, want_params=False, want_corr=True)
+    return corr, n_fail
+
+
+@pytest.mark.parametrize('thresh', [0.25, 0.5, 0.0, -1.0, float('-inf'), 0.9, 0.999, 0.9999999, 1.0, 2.0])
+@pytest.mark.parametrize('nodata, variant', [(np.nan, 'frame+holes'), (None, 'none')])
+def test_certified_r2_test_counts_exactly(ctx, thresh, nodata, variant):
+    """ Fused mode without parameter output: the r2-mask decision goes through the division-free certified test with
+    an exact fallback; the failure count must equal the oracle's for every threshold, incl. ones in the thick of the
+    R2 distribution and degenerate ones (>= 1: everything fails; -inf: everything passes). """
+    src, ref = onp.synth_pair(300, 760, seed=21, nodata_variant=variant)
+    rng = np.random.default_rng(3)
+    ref = (ref + rng.normal(0, 0.08, ref.shape).astype(np.float32)).astype(np.float32)  # R2 spread ~0.85..0.99
+    ref[100:104, 200:204] = -5.0                                                         # a low-R2 / odd-gain patch
+    exp_params, exp_fail = onp.fit_gain_offset(src, nodata, ref, nodata, (5, 5), False, thresh)
+    corr, n_fail = _fused_no_params(ctx, src, ref, nodata, (5, 5), thresh)
+    assert n_fail == exp_fail
+    if thresh in (1.0, 2.0):
+        assert n_fail == int((~np.isnan(exp_params[0])).sum())
+    assert_close_ulp(corr, onp.apply(src, exp_params), 'corrected')
+
+
+def test_certified_r2_test_degenerate_windows(ctx):
+    """ flat reference (sstot == 0), single-valid-pixel windows, negative gains: never certified, always exact. """
+    rng = np.random.default_rng(8)
+    src = rng.uniform(0.1, 1, (96, 300)).astype(np.float32)
+    ref = np.full_like(src, 0.5)                       # sstot = 0 -> r2 = nan / -inf: all fail
+    ref[:, 150:] = (-0.7 * src[:, 150:] + 1).astype(np.float32)   # perfect fit, negative gain: fail on gain > 0
+    src[40:60, 20:40] = np.nan
+    src[50, 30] = 0.3                                  # an isolated valid pixel: N = 1 windows
+    for thresh in (0.25, -10.0):
+        exp_params, exp_fail = onp.fit_gain_offset(src, np.nan, ref, np.nan, (5, 5), False, thresh)
+        corr, n_fail = _fused_no_params(ctx, src, ref, np.nan, (5, 5), thresh)
+        assert n_fail == exp_fail and n_fail > 0
+        assert_close_ulp(corr, onp.apply(src, exp_params), 'corrected', max_frac=1e-3)
