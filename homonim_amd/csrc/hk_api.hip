@@ -195,7 +195,7 @@ int run_host(hk_ctx* ctx, const hk_fit_desc* desc, const float* src, int64_t src
     const bool want_norm = blk || norm_only;
     const size_t n_planes = 2 + (norm_only ? 0 : ((params_out ? (size_t)n_param_bands : 0) + (corr_out ? 1 : 0)));
     const size_t aux_off = n_planes * plane;
-    const size_t ws_bytes = want_norm ? hk::norm_workspace_bytes(1) : 0;
+    const size_t ws_bytes = want_norm ? hk::norm_workspace_bytes(1, height, width) : 0;
     const size_t total = aux_off + 256 + ws_bytes;
 
     SlotLease lease(ctx);
@@ -463,7 +463,7 @@ int hk_block_norm_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* jo
     Slot& sl = ctx->slots[job->stream];
     {
         std::lock_guard<std::mutex> lk(ctx->mu);  // the slab doubles as workspace of this stream
-        rc = ensure_dev(sl, hk::norm_workspace_bytes(job->n_bands));
+        rc = ensure_dev(sl, hk::norm_workspace_bytes(job->n_bands, job->height, job->width));
     }
     if (rc) return rc;
     hk::NormArgs na;

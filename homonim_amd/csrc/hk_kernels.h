@@ -57,7 +57,7 @@ struct NormArgs {
     float src_nodata, ref_nodata;
 };
 // workspace: see norm_workspace_bytes(); norm_out: n_bands x 2 float64 on device.
-size_t norm_workspace_bytes(int n_bands);
+size_t norm_workspace_bytes(int n_bands, int height, int width);
 hipError_t launch_block_norm(const NormArgs& a, void* workspace, double* norm_out, hipStream_t stream);
 
 hipError_t launch_synth_fill(float* src, float* ref, int n_bands, int height, int width, long long stride,

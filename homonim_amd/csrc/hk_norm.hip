@@ -5,38 +5,64 @@
 //     norm[0] = np.std(ref[mask]) / np.std(src[mask])
 //     norm[1] = np.percentile(ref[mask], 1) - np.percentile(src[mask], 1) * norm[0]
 // np.std = population std; np.percentile(., 1) = linear interpolation between the order statistics at
-// floor(0.01 (n-1)) and the next one.  Here: exact float64 two-pass mean / variance (deterministic block partials,
-// fixed reduction order) and an EXACT order-statistic select: 3-level radix histograms (11 + 11 + 10 bits of the
-// order-preserving uint32 image of the float) -- no sort, no candidate buffer, 3 streaming passes, HBM-bound.
-// numpy runs the same statistics in float32 pairwise arithmetic; the two agree to ~5e-7 relative.
+// floor(0.01 (n-1)) and the next one.
+//
+// Here the moments are float64 (deterministic per-wave partials reduced in a fixed order) and the order statistics
+// are EXACT.  numpy runs the same statistics in float32 pairwise arithmetic; the two agree to ~5e-7 relative.
+//
+// ONE streaming pass over src+ref (8 B per pixel, HBM-bound) instead of a sort:
+//   1. sample:  a 4096-pixel strided sample per band is sorted in one workgroup; it yields the shift of the moment
+//               sums and, per raster, two pivots that bracket the 1st percentile (+-4 sigma of the sample quantile);
+//   2. pass:    every wave streams its rows: count, shifted first/second moments, number of values below the low
+//               pivot, and the ~1 % of values between the pivots compacted through a wave-private LDS stage into a
+//               small HBM buffer (one global atomic per 512 values);
+//   3. select:  the two ranks are resolved inside the compacted buffer by a 3-level radix select (11+11+10 bits of the
+//               order-preserving uint32 image of the float) -- integer histograms only, so the result is deterministic.
+// If the pivots miss (or the buffer overflows) a device-side flag routes the band through the same radix select over
+// the full rasters (three more passes); those kernels are always launched and exit immediately otherwise.
 #include "hk_kernels.h"
 
 namespace hk {
 
-constexpr int NORM_BLOCKS = 512;  // partial-reduction blocks per band
 constexpr int NORM_THREADS = 256;
 constexpr int L1_BITS = 11, L2_BITS = 11, L3_BITS = 10;
 constexpr int L1_BINS = 1 << L1_BITS, L2_BINS = 1 << L2_BITS, L3_BINS = 1 << L3_BITS;
+constexpr int SAMPLE_N = 4096;     // sample size per band (sorted in LDS by one workgroup)
+constexpr int PASS_WAVES = 2048;   // waves per band in the streaming pass (also the number of partials)
+constexpr int STAGE_N = 512;       // wave-private LDS staging slots per raster
+constexpr int FB_BLOCKS = 512;     // workgroups per band of the fallback passes
 
 struct Sel {
-    unsigned prefix;           // key bits fixed so far (right-aligned)
-    unsigned long long rank;   // rank still to resolve inside that prefix
+    unsigned prefix;          // key bits fixed so far (right-aligned)
+    unsigned long long rank;  // rank still to resolve inside that prefix
 };
 
 struct NormWS {  // one per band
-    unsigned long long pn[NORM_BLOCKS];
-    double ps[NORM_BLOCKS], pr[NORM_BLOCKS];
-    double pvs[NORM_BLOCKS], pvr[NORM_BLOCKS];
-    unsigned hist1[2][L1_BINS];       // [src|ref]
-    unsigned hist2[2][2][L2_BINS];    // [src|ref][rank k0|k1]
-    unsigned hist3[2][2][L3_BINS];
+    // sample stage
+    float lo[2], hi[2];  // [src|ref] pivots: values in [lo, hi] are compacted
+    double shift[2];
+    // streaming pass
+    unsigned long long pn[PASS_WAVES], pbelow[2][PASS_WAVES];
+    double p1[2][PASS_WAVES], p2[2][PASS_WAVES];
+    unsigned mid_count[2];
+    // statistics
     unsigned long long n;
-    double mean_s, mean_r, var_s, var_r, frac;
-    Sel sel[2][2];
+    double mean[2], var[2], frac;
+    unsigned long long k[2];  // the two ranks (k0, k0+1 clipped)
+    int fallback, done;
+    // radix select state (shared by the compacted-buffer select and the fallback)
+    Sel sel[2][2];  // [src|ref][rank k0|k1]
     float val[2][2];
+    unsigned hist1[2][2][L1_BINS], hist2[2][2][L2_BINS], hist3[2][2][L3_BINS];
 };
 
-size_t norm_workspace_bytes(int n_bands) { return sizeof(NormWS) * (size_t)n_bands; }
+static size_t mid_capacity(long long n_px) { return (size_t)(n_px / 25 + 8192); }  // 4 % of the block + slack
+static size_t align256(size_t b) { return (b + 255) / 256 * 256; }
+
+size_t norm_workspace_bytes(int n_bands, int height, int width) {
+    return align256(sizeof(NormWS) * (size_t)n_bands) +
+           (size_t)n_bands * 2 * align256(mid_capacity((long long)height * width) * sizeof(float));
+}
 
 __device__ __forceinline__ unsigned f2key(float f) {  // order-preserving float -> uint32
     const unsigned u = __float_as_uint(f);
@@ -50,115 +76,286 @@ __device__ __forceinline__ bool nvalid(float v, int mode, float nodata) {
     return mode == 0 ? true : (mode == 1 ? !(v != v) : !(v == nodata));
 }
 
-// Deterministic block reduction (fixed tree) of a double / u64 through LDS.
-template <typename T>
-__device__ __forceinline__ T block_reduce(T v, T* sh) {
-    const int t = threadIdx.x;
-    sh[t] = v;
-    __syncthreads();
-    for (int d = NORM_THREADS / 2; d > 0; d >>= 1) {
-        if (t < d) sh[t] = sh[t] + sh[t + d];
-        __syncthreads();
-    }
-    const T r = sh[0];
-    __syncthreads();
-    return r;
-}
-
-// PASS: 0 = count/sum + level-1 histograms; 1 = squared deviations + level-2; 2 = level-3.
-template <int PASS>
-__global__ void __launch_bounds__(NORM_THREADS) norm_pass_kernel(const NormArgs a, NormWS* __restrict__ ws_all) {
-    constexpr int NH = PASS == 0 ? 2 * L1_BINS : (PASS == 1 ? 4 * L2_BINS : 4 * L3_BINS);
-    __shared__ unsigned hist[NH];
-    __shared__ double shd[NORM_THREADS];
-    __shared__ unsigned long long shn[NORM_THREADS];
-    const int band = blockIdx.y;
+// ---------------------------------------------------------------------------------------------------------------------
+// 1. sample
+__global__ void __launch_bounds__(1024) norm_sample_kernel(const NormArgs a, NormWS* __restrict__ ws_all) {
+    __shared__ float samp[2][SAMPLE_N];
+    __shared__ unsigned cnt;
+    __shared__ double red[1024];
+    const int band = blockIdx.x, t = threadIdx.x;
     NormWS& ws = ws_all[band];
-    if (PASS > 0 && ws.n == 0) return;
-    for (int i = threadIdx.x; i < NH; i += NORM_THREADS) hist[i] = 0;
-    __syncthreads();
-
     const float* __restrict__ sp = a.src + (long long)band * a.band_stride;
     const float* __restrict__ rp = a.ref + (long long)band * a.band_stride;
-    double mean_s = 0.0, mean_r = 0.0;
-    unsigned pfx[2][2] = {{0, 0}, {0, 0}};
-    if (PASS >= 1) {
-        mean_s = ws.mean_s;
-        mean_r = ws.mean_r;
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int k = 0; k < 2; ++k) pfx[q][k] = ws.sel[q][k].prefix;
-    }
-
-    unsigned long long n = 0;
-    double acc_s = 0.0, acc_r = 0.0;
-    const int wq = (a.width + PX - 1) / PX;
-    for (int y = blockIdx.x; y < a.height; y += gridDim.x) {
-        const long long row = (long long)y * a.stride;
-        for (int xq = threadIdx.x; xq < wq; xq += NORM_THREADS) {
-            const int x = xq * PX;
-            float s[PX], r[PX];
-            if (x + PX <= a.width) {
-                const float4 s4 = *reinterpret_cast<const float4*>(sp + row + x);
-                const float4 r4 = *reinterpret_cast<const float4*>(rp + row + x);
-                s[0] = s4.x, s[1] = s4.y, s[2] = s4.z, s[3] = s4.w;
-                r[0] = r4.x, r[1] = r4.y, r[2] = r4.z, r[3] = r4.w;
-            } else {
-#pragma unroll
-                for (int i = 0; i < PX; ++i) {
-                    const bool in = x + i < a.width;
-                    s[i] = in ? sp[row + x + i] : 0.f;
-                    r[i] = in ? rp[row + x + i] : 0.f;
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < PX; ++i) {
-                const bool m = x + i < a.width && nvalid(s[i], a.src_nd_mode, a.src_nodata) &&
-                               nvalid(r[i], a.ref_nd_mode, a.ref_nodata);
-                if (!m) continue;
-                const unsigned ks = f2key(s[i]), kr = f2key(r[i]);
-                if (PASS == 0) {
-                    ++n;
-                    acc_s += (double)s[i];
-                    acc_r += (double)r[i];
-                    atomicAdd(&hist[ks >> (32 - L1_BITS)], 1u);
-                    atomicAdd(&hist[L1_BINS + (kr >> (32 - L1_BITS))], 1u);
-                } else if (PASS == 1) {
-                    const double ds = (double)s[i] - mean_s, dr = (double)r[i] - mean_r;
-                    acc_s += ds * ds;
-                    acc_r += dr * dr;
-#pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        if ((ks >> (32 - L1_BITS)) == pfx[0][k])
-                            atomicAdd(&hist[(0 * 2 + k) * L2_BINS + ((ks >> L3_BITS) & (L2_BINS - 1))], 1u);
-                        if ((kr >> (32 - L1_BITS)) == pfx[1][k])
-                            atomicAdd(&hist[(1 * 2 + k) * L2_BINS + ((kr >> L3_BITS) & (L2_BINS - 1))], 1u);
-                    }
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        if ((ks >> L3_BITS) == pfx[0][k]) atomicAdd(&hist[(0 * 2 + k) * L3_BINS + (ks & (L3_BINS - 1))], 1u);
-                        if ((kr >> L3_BITS) == pfx[1][k]) atomicAdd(&hist[(1 * 2 + k) * L3_BINS + (kr & (L3_BINS - 1))], 1u);
-                    }
-                }
+    if (t == 0) cnt = 0;
+    for (int i = t; i < SAMPLE_N; i += 1024) samp[0][i] = samp[1][i] = __int_as_float(0x7f800000);  // +inf padding
+    __syncthreads();
+    const long long total = (long long)a.height * a.width;
+    const long long step = total / SAMPLE_N > 0 ? total / SAMPLE_N : 1;
+    double sum_s = 0.0, sum_r = 0.0;
+    for (int j = t; j < SAMPLE_N; j += 1024) {
+        // stratified sample: one pseudo-random pixel per stratum of `step` pixels (a plain stride aliases with the row
+        // length -- e.g. every sample in one column of a nodata frame)
+        unsigned long long hsh = ((unsigned long long)j + 0x9e3779b97f4a7c15ull) * 0xbf58476d1ce4e5b9ull;
+        hsh = (hsh ^ (hsh >> 29)) * 0x94d049bb133111ebull;
+        hsh ^= hsh >> 32;
+        const long long p = (long long)j * step + (long long)(hsh % (unsigned long long)step);
+        if (p < total) {
+            const int y = (int)(p / a.width), x = (int)(p % a.width);
+            const float s = sp[(long long)y * a.stride + x], r = rp[(long long)y * a.stride + x];
+            if (nvalid(s, a.src_nd_mode, a.src_nodata) && nvalid(r, a.ref_nd_mode, a.ref_nodata)) {
+                const unsigned i = atomicAdd(&cnt, 1u);
+                samp[0][i] = s;
+                samp[1][i] = r;
+                sum_s += (double)s;
+                sum_r += (double)r;
             }
         }
     }
     __syncthreads();
-    unsigned* gh = PASS == 0 ? &ws.hist1[0][0] : (PASS == 1 ? &ws.hist2[0][0][0] : &ws.hist3[0][0][0]);
-    for (int i = threadIdx.x; i < NH; i += NORM_THREADS)
-        if (hist[i]) atomicAdd(gh + i, hist[i]);  // integer atomics: order-independent result
-    if (PASS <= 1) {
-        const double rs = block_reduce<double>(acc_s, shd);
-        const double rr = block_reduce<double>(acc_r, shd);
-        if (PASS == 0) {
-            const unsigned long long rn = block_reduce<unsigned long long>(n, shn);
-            if (threadIdx.x == 0) ws.pn[blockIdx.x] = rn, ws.ps[blockIdx.x] = rs, ws.pr[blockIdx.x] = rr;
-        } else if (threadIdx.x == 0) {
-            ws.pvs[blockIdx.x] = rs, ws.pvr[blockIdx.x] = rr;
+    const unsigned m = cnt;
+    // bitonic sort of both sample arrays (ascending; +inf padding sinks to the end)
+    for (int k = 2; k <= SAMPLE_N; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = t; i < SAMPLE_N; i += 1024) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const bool up = (i & k) == 0;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const float x0 = samp[q][i], x1 = samp[q][l];
+                        if ((x0 > x1) == up) {
+                            samp[q][i] = x1;
+                            samp[q][l] = x0;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
         }
     }
+    // shift of the moment sums = sample mean (any value works; a close one kills the cancellation)
+    for (int q = 0; q < 2; ++q) {
+        red[t] = q == 0 ? sum_s : sum_r;
+        __syncthreads();
+        for (int d = 512; d > 0; d >>= 1) {
+            if (t < d) red[t] += red[t + d];
+            __syncthreads();
+        }
+        if (t == 0) {
+            const double mean = m ? red[0] / (double)m : 0.0;
+            ws.shift[q] = (mean == mean && fabs(mean) < 1e300) ? mean : 0.0;
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        // sample ranks bracketing the 1st percentile by +-4 sigma of the binomial sample quantile (+ margin)
+        const double c = 0.01 * (double)m, sd = sqrt(c > 0.0 ? c : 0.0);
+        const long long ia = (long long)floor(c - 4.0 * sd) - 2, ib = (long long)ceil(c + 4.0 * sd) + 3;
+        for (int q = 0; q < 2; ++q) {
+            ws.lo[q] = (m == 0 || ia <= 0) ? __int_as_float(0xff800000) : samp[q][ia];
+            ws.hi[q] = (m == 0 || ib >= (long long)m - 1) ? __int_as_float(0x7f800000) : samp[q][ib];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 2. streaming pass: one wave per workgroup, wave-private LDS staging of the compacted values
+__device__ __forceinline__ double wave_sum(double v) {  // fixed butterfly order -> deterministic
+#pragma unroll
+    for (int d = WAVE / 2; d > 0; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
+#pragma unroll
+    for (int d = WAVE / 2; d > 0; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+
+__global__ void __launch_bounds__(WAVE) norm_stream_kernel(const NormArgs a, NormWS* __restrict__ ws_all,
+                                                            float* __restrict__ mid_all, size_t mid_cap) {
+    __shared__ float stage[2][STAGE_N];
+    const int band = blockIdx.y, wave = blockIdx.x, lane = threadIdx.x;
+    NormWS& ws = ws_all[band];
+    const float* __restrict__ sp = a.src + (long long)band * a.band_stride;
+    const float* __restrict__ rp = a.ref + (long long)band * a.band_stride;
+    float* mid[2] = {mid_all + ((size_t)band * 2 + 0) * mid_cap, mid_all + ((size_t)band * 2 + 1) * mid_cap};
+    const float lo[2] = {ws.lo[0], ws.lo[1]}, hi[2] = {ws.hi[0], ws.hi[1]};
+    const double shift[2] = {ws.shift[0], ws.shift[1]};
+    const unsigned long long lane_lt = (1ull << lane) - 1ull;
+
+    unsigned long long n = 0, below[2] = {0, 0};
+    double m1[2] = {0.0, 0.0}, m2[2] = {0.0, 0.0};
+    int fill[2] = {0, 0};  // wave-uniform
+
+    auto flush = [&](int q) {
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(&ws.mid_count[q], (unsigned)fill[q]);
+        base = __shfl(base, 0);
+        for (int j = lane; j < fill[q]; j += WAVE)
+            if ((size_t)base + j < mid_cap) mid[q][(size_t)base + j] = stage[q][j];
+        fill[q] = 0;
+    };
+
+    const int wq = (a.width + PX - 1) / PX;
+    for (int y = wave; y < a.height; y += gridDim.x) {
+        const long long row = (long long)y * a.stride;
+        for (int xq0 = 0; xq0 < wq; xq0 += WAVE) {  // wave-uniform trip count: the ballots below need all lanes
+            const int xq = xq0 + lane;
+            const int x = xq * PX;
+            float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f), r4 = s4;
+            if (xq < wq) {  // rows are padded to a multiple of PX elements
+                s4 = *reinterpret_cast<const float4*>(sp + row + x);
+                r4 = *reinterpret_cast<const float4*>(rp + row + x);
+            }
+            const float s[PX] = {s4.x, s4.y, s4.z, s4.w}, r[PX] = {r4.x, r4.y, r4.z, r4.w};
+#pragma unroll
+            for (int i = 0; i < PX; ++i) {
+                const bool m = xq < wq && x + i < a.width && nvalid(s[i], a.src_nd_mode, a.src_nodata) &&
+                               nvalid(r[i], a.ref_nd_mode, a.ref_nodata);
+                const float v[2] = {s[i], r[i]};
+                if (m) {
+                    ++n;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const double d = (double)v[q] - shift[q];
+                        m1[q] += d;
+                        m2[q] += d * d;
+                        below[q] += v[q] < lo[q] ? 1u : 0u;
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const bool in = m && v[q] >= lo[q] && v[q] <= hi[q];
+                    const unsigned long long bal = __ballot(in);
+                    if (bal) {  // wave-uniform
+                        const int c = __popcll(bal);
+                        if (fill[q] + c > STAGE_N) flush(q);
+                        if (in) stage[q][fill[q] + __popcll(bal & lane_lt)] = v[q];
+                        fill[q] += c;
+                    }
+                }
+            }
+        }
+    }
+    flush(0);
+    flush(1);
+    n = wave_sum(n);
+    for (int q = 0; q < 2; ++q) {
+        m1[q] = wave_sum(m1[q]);
+        m2[q] = wave_sum(m2[q]);
+        below[q] = wave_sum(below[q]);
+    }
+    if (lane == 0) {
+        ws.pn[wave] = n;
+        for (int q = 0; q < 2; ++q) ws.p1[q][wave] = m1[q], ws.p2[q][wave] = m2[q], ws.pbelow[q][wave] = below[q];
+    }
+}
+
+// statistics + ranks + decision whether the compacted buffers bracket both ranks
+__global__ void norm_stats_kernel(NormWS* __restrict__ ws_all, double* __restrict__ norm_out, size_t mid_cap) {
+    NormWS& ws = ws_all[blockIdx.x];
+    if (threadIdx.x != 0) return;
+    unsigned long long n = 0, below[2] = {0, 0};
+    double m1[2] = {0.0, 0.0}, m2[2] = {0.0, 0.0};
+    for (int i = 0; i < PASS_WAVES; ++i) {
+        n += ws.pn[i];
+        for (int q = 0; q < 2; ++q) m1[q] += ws.p1[q][i], m2[q] += ws.p2[q][i], below[q] += ws.pbelow[q][i];
+    }
+    ws.n = n;
+    if (n == 0) {  // kernel_model.py:223-226
+        norm_out[2 * blockIdx.x] = 0.0;
+        norm_out[2 * blockIdx.x + 1] = 0.0;
+        ws.done = 1;
+        return;
+    }
+    for (int q = 0; q < 2; ++q) {
+        const double d = m1[q] / (double)n;
+        ws.mean[q] = ws.shift[q] + d;
+        const double v = m2[q] / (double)n - d * d;
+        ws.var[q] = v > 0.0 ? v : 0.0;
+    }
+    const double vi = 0.01 * (double)(n - 1);
+    const unsigned long long k0 = (unsigned long long)floor(vi);
+    ws.frac = vi - (double)k0;
+    ws.k[0] = k0;
+    ws.k[1] = k0 + 1 < n ? k0 + 1 : n - 1;
+    int fb = 0;
+    for (int q = 0; q < 2; ++q) {
+        const unsigned long long nm = ws.mid_count[q];
+        if (nm > mid_cap || ws.k[0] < below[q] || ws.k[1] >= below[q] + nm) fb = 1;
+        ws.sel[q][0].rank = ws.k[0] - below[q];
+        ws.sel[q][1].rank = ws.k[1] - below[q];
+        ws.sel[q][0].prefix = ws.sel[q][1].prefix = 0;
+    }
+    if (fb)
+        for (int q = 0; q < 2; ++q) ws.sel[q][0].rank = ws.k[0], ws.sel[q][1].rank = ws.k[1];
+    ws.fallback = fb;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 3. radix select: histogram of the next key digit of every value whose higher digits match the rank's prefix
+__device__ __forceinline__ void hist_add(unsigned* hist, int level, unsigned key, const unsigned (&pfx)[2]) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        if (level == 0) {
+            atomicAdd(&hist[k * L1_BINS + (key >> (32 - L1_BITS))], 1u);
+        } else if (level == 1) {
+            if ((key >> (32 - L1_BITS)) == pfx[k]) atomicAdd(&hist[k * L2_BINS + ((key >> L3_BITS) & (L2_BINS - 1))], 1u);
+        } else {
+            if ((key >> L3_BITS) == pfx[k]) atomicAdd(&hist[k * L3_BINS + (key & (L3_BINS - 1))], 1u);
+        }
+    }
+}
+
+// LEVEL 0..2 over the compacted buffers (grid: x = workgroups, y = band * 2 + raster)
+template <int LEVEL>
+__global__ void __launch_bounds__(NORM_THREADS) norm_mid_hist_kernel(NormWS* __restrict__ ws_all,
+                                                                       const float* __restrict__ mid_all, size_t mid_cap) {
+    constexpr int NB = LEVEL == 0 ? L1_BINS : (LEVEL == 1 ? L2_BINS : L3_BINS);
+    __shared__ unsigned hist[2 * NB];
+    const int band = blockIdx.y >> 1, q = blockIdx.y & 1;
+    NormWS& ws = ws_all[band];
+    if (ws.done || ws.fallback) return;
+    for (int i = threadIdx.x; i < 2 * NB; i += NORM_THREADS) hist[i] = 0;
+    __syncthreads();
+    const float* __restrict__ buf = mid_all + ((size_t)band * 2 + q) * mid_cap;
+    const unsigned cnt = ws.mid_count[q];
+    const unsigned pfx[2] = {ws.sel[q][0].prefix, ws.sel[q][1].prefix};
+    for (unsigned i = blockIdx.x * NORM_THREADS + threadIdx.x; i < cnt; i += gridDim.x * NORM_THREADS)
+        hist_add(hist, LEVEL, f2key(buf[i]), pfx);
+    __syncthreads();
+    unsigned* gh = LEVEL == 0 ? &ws.hist1[q][0][0] : (LEVEL == 1 ? &ws.hist2[q][0][0] : &ws.hist3[q][0][0]);
+    for (int i = threadIdx.x; i < 2 * NB; i += NORM_THREADS)
+        if (hist[i]) atomicAdd(gh + i, hist[i]);  // integer atomics: order-independent result
+}
+
+// Fallback: the same select over the full rasters (only bands whose pivots missed); PASS 1 also redoes nothing else.
+template <int LEVEL>
+__global__ void __launch_bounds__(NORM_THREADS) norm_full_hist_kernel(const NormArgs a, NormWS* __restrict__ ws_all) {
+    constexpr int NB = LEVEL == 0 ? L1_BINS : (LEVEL == 1 ? L2_BINS : L3_BINS);
+    __shared__ unsigned hist[4 * NB];
+    const int band = blockIdx.y;
+    NormWS& ws = ws_all[band];
+    if (ws.done || !ws.fallback) return;
+    for (int i = threadIdx.x; i < 4 * NB; i += NORM_THREADS) hist[i] = 0;
+    __syncthreads();
+    const float* __restrict__ sp = a.src + (long long)band * a.band_stride;
+    const float* __restrict__ rp = a.ref + (long long)band * a.band_stride;
+    const unsigned pfs[2] = {ws.sel[0][0].prefix, ws.sel[0][1].prefix}, pfr[2] = {ws.sel[1][0].prefix, ws.sel[1][1].prefix};
+    for (int y = blockIdx.x; y < a.height; y += gridDim.x) {
+        const long long row = (long long)y * a.stride;
+        for (int x = threadIdx.x; x < a.width; x += NORM_THREADS) {
+            const float s = sp[row + x], r = rp[row + x];
+            if (nvalid(s, a.src_nd_mode, a.src_nodata) && nvalid(r, a.ref_nd_mode, a.ref_nodata)) {
+                hist_add(hist, LEVEL, f2key(s), pfs);
+                hist_add(hist + 2 * NB, LEVEL, f2key(r), pfr);
+            }
+        }
+    }
+    __syncthreads();
+    unsigned* gh = LEVEL == 0 ? &ws.hist1[0][0][0] : (LEVEL == 1 ? &ws.hist2[0][0][0] : &ws.hist3[0][0][0]);
+    for (int i = threadIdx.x; i < 4 * NB; i += NORM_THREADS)
+        if (hist[i]) atomicAdd(gh + i, hist[i]);
 }
 
 // Find the bin holding rank `rank` in hist[0..nbins): returns bin, and the rank inside it.
@@ -188,60 +385,31 @@ __device__ void select_bin(const unsigned* __restrict__ h, int nbins, unsigned l
     __syncthreads();
 }
 
-// STAGE 0: after pass 0 (n, means, ranks, level-1 select); 1: after pass 1 (variances, level-2 select);
-// 2: after pass 2 (level-3 select -> order statistics -> norm).
-template <int STAGE>
-__global__ void __launch_bounds__(NORM_THREADS) norm_finalize_kernel(NormWS* __restrict__ ws_all, double* __restrict__ norm_out) {
+// After each histogram level (of either path): fix the next digit of the four (raster, rank) keys; after the last level
+// the keys are the exact order statistics -> norm.
+template <int LEVEL>
+__global__ void __launch_bounds__(NORM_THREADS) norm_select_kernel(NormWS* __restrict__ ws_all, double* __restrict__ norm_out) {
     __shared__ unsigned long long sh[NORM_THREADS];
     __shared__ unsigned bin;
     __shared__ unsigned long long rk;
     NormWS& ws = ws_all[blockIdx.x];
-    if (STAGE == 0) {
-        if (threadIdx.x == 0) {
-            unsigned long long n = 0;
-            double ss = 0.0, sr = 0.0;
-            for (int i = 0; i < NORM_BLOCKS; ++i) n += ws.pn[i], ss += ws.ps[i], sr += ws.pr[i];
-            ws.n = n;
-            if (n > 0) {
-                ws.mean_s = ss / (double)n;
-                ws.mean_r = sr / (double)n;
-                const double v = 0.01 * (double)(n - 1);
-                const unsigned long long k0 = (unsigned long long)floor(v);
-                ws.frac = v - (double)k0;
-                ws.sel[0][0].rank = ws.sel[1][0].rank = k0;
-                ws.sel[0][1].rank = ws.sel[1][1].rank = (k0 + 1 < n) ? k0 + 1 : n - 1;
-            } else {
-                norm_out[2 * blockIdx.x] = 0.0;  // kernel_model.py:223-226
-                norm_out[2 * blockIdx.x + 1] = 0.0;
-            }
-        }
-        __syncthreads();
-        if (ws.n == 0) return;
-    } else if (ws.n == 0) {
-        return;
-    }
-    if (STAGE == 1 && threadIdx.x == 0) {
-        double vs = 0.0, vr = 0.0;
-        for (int i = 0; i < NORM_BLOCKS; ++i) vs += ws.pvs[i], vr += ws.pvr[i];
-        ws.var_s = vs / (double)ws.n;
-        ws.var_r = vr / (double)ws.n;
-    }
+    if (ws.done) return;
     for (int q = 0; q < 2; ++q) {
         for (int k = 0; k < 2; ++k) {
-            const unsigned* h = STAGE == 0 ? ws.hist1[q] : (STAGE == 1 ? ws.hist2[q][k] : ws.hist3[q][k]);
-            const int nb = STAGE == 0 ? L1_BINS : (STAGE == 1 ? L2_BINS : L3_BINS);
+            const unsigned* h = LEVEL == 0 ? ws.hist1[q][k] : (LEVEL == 1 ? ws.hist2[q][k] : ws.hist3[q][k]);
+            const int nb = LEVEL == 0 ? L1_BINS : (LEVEL == 1 ? L2_BINS : L3_BINS);
             select_bin(h, nb, ws.sel[q][k].rank, &bin, &rk, sh);
             if (threadIdx.x == 0) {
-                const int bits = STAGE == 0 ? 0 : (STAGE == 1 ? L2_BITS : L3_BITS);
-                ws.sel[q][k].prefix = (STAGE == 0) ? bin : ((ws.sel[q][k].prefix << bits) | bin);
+                const int bits = LEVEL == 0 ? 0 : (LEVEL == 1 ? L2_BITS : L3_BITS);
+                ws.sel[q][k].prefix = (LEVEL == 0) ? bin : ((ws.sel[q][k].prefix << bits) | bin);
                 ws.sel[q][k].rank = rk;
-                if (STAGE == 2) ws.val[q][k] = key2f(ws.sel[q][k].prefix);
+                if (LEVEL == 2) ws.val[q][k] = key2f(ws.sel[q][k].prefix);
             }
             __syncthreads();
         }
     }
-    if (STAGE == 2 && threadIdx.x == 0) {
-        const double n0 = sqrt(ws.var_r) / sqrt(ws.var_s);
+    if (LEVEL == 2 && threadIdx.x == 0) {
+        const double n0 = sqrt(ws.var[1]) / sqrt(ws.var[0]);
         double pct[2];
         for (int q = 0; q < 2; ++q) {
             // numpy _lerp (lib/_function_base_impl.py): a + (b-a)*t, and b - (b-a)*(1-t) where t >= 0.5
@@ -256,15 +424,25 @@ __global__ void __launch_bounds__(NORM_THREADS) norm_finalize_kernel(NormWS* __r
 
 hipError_t launch_block_norm(const NormArgs& a, void* workspace, double* norm_out, hipStream_t stream) {
     NormWS* ws = reinterpret_cast<NormWS*>(workspace);
+    const size_t cap = mid_capacity((long long)a.height * a.width);
+    const size_t cap_al = align256(cap * sizeof(float)) / sizeof(float);
+    float* mid = reinterpret_cast<float*>(static_cast<char*>(workspace) + align256(sizeof(NormWS) * (size_t)a.n_bands));
     hipError_t e = hipMemsetAsync(ws, 0, sizeof(NormWS) * (size_t)a.n_bands, stream);
     if (e != hipSuccess) return e;
-    const dim3 grid(NORM_BLOCKS, a.n_bands), block(NORM_THREADS);
-    hipLaunchKernelGGL(norm_pass_kernel<0>, grid, block, 0, stream, a, ws);
-    hipLaunchKernelGGL(norm_finalize_kernel<0>, dim3(a.n_bands), block, 0, stream, ws, norm_out);
-    hipLaunchKernelGGL(norm_pass_kernel<1>, grid, block, 0, stream, a, ws);
-    hipLaunchKernelGGL(norm_finalize_kernel<1>, dim3(a.n_bands), block, 0, stream, ws, norm_out);
-    hipLaunchKernelGGL(norm_pass_kernel<2>, grid, block, 0, stream, a, ws);
-    hipLaunchKernelGGL(norm_finalize_kernel<2>, dim3(a.n_bands), block, 0, stream, ws, norm_out);
+    const dim3 bands(a.n_bands), block(NORM_THREADS);
+    hipLaunchKernelGGL(norm_sample_kernel, bands, dim3(1024), 0, stream, a, ws);
+    hipLaunchKernelGGL(norm_stream_kernel, dim3(PASS_WAVES, a.n_bands), dim3(WAVE), 0, stream, a, ws, mid, cap_al);
+    hipLaunchKernelGGL(norm_stats_kernel, bands, dim3(64), 0, stream, ws, norm_out, cap_al);
+    const dim3 gmid(64, a.n_bands * 2), gfull(FB_BLOCKS, a.n_bands);
+    hipLaunchKernelGGL(norm_mid_hist_kernel<0>, gmid, block, 0, stream, ws, mid, cap_al);
+    hipLaunchKernelGGL(norm_full_hist_kernel<0>, gfull, block, 0, stream, a, ws);
+    hipLaunchKernelGGL(norm_select_kernel<0>, bands, block, 0, stream, ws, norm_out);
+    hipLaunchKernelGGL(norm_mid_hist_kernel<1>, gmid, block, 0, stream, ws, mid, cap_al);
+    hipLaunchKernelGGL(norm_full_hist_kernel<1>, gfull, block, 0, stream, a, ws);
+    hipLaunchKernelGGL(norm_select_kernel<1>, bands, block, 0, stream, ws, norm_out);
+    hipLaunchKernelGGL(norm_mid_hist_kernel<2>, gmid, block, 0, stream, ws, mid, cap_al);
+    hipLaunchKernelGGL(norm_full_hist_kernel<2>, gfull, block, 0, stream, a, ws);
+    hipLaunchKernelGGL(norm_select_kernel<2>, bands, block, 0, stream, ws, norm_out);
     return hipGetLastError();
 }
 

@@ -432,3 +432,23 @@ def test_certified_r2_test_degenerate_windows(ctx):
         corr, n_fail = _fused_no_params(ctx, src, ref, np.nan, (5, 5), thresh)
         assert n_fail == exp_fail and n_fail > 0
         assert_close_ulp(corr, onp.apply(src, exp_params), 'corrected', max_frac=1e-3)
+
+
+def test_block_norm_heavy_ties_take_the_fallback_select(ctx):
+    """ Few distinct values: the [lo, hi] pivot window holds a third of the block, overflows the compaction buffer and
+    routes the band through the full-raster radix select; the order statistics must still be exact. """
+    rng = np.random.default_rng(12)
+    src = rng.integers(1, 4, (400, 600)).astype(np.float32)          # values 1, 2, 3
+    ref = (2 * src + rng.integers(0, 2, src.shape)).astype(np.float32)
+    src[:5] = 0
+    desc = _hk.make_desc('gain-blk-offset', (5, 5), False, None, 0., None)
+    norm = ctx.block_norm(desc, src, ref)
+    exp = onp.fit_block_norm(src, 0., ref, None)
+    assert norm[0] == pytest.approx(exp[0], rel=2e-6)
+    assert norm[1] == pytest.approx(exp[1], rel=2e-6, abs=1e-6)
+    # large block, clean data: the one-pass path; both must agree with numpy
+    src2, ref2 = onp.synth_pair(1500, 2000, 5, 'frame+holes')
+    desc2 = _hk.make_desc('gain-blk-offset', (5, 5), False, None, np.nan, np.nan)
+    n2 = ctx.block_norm(desc2, src2, ref2)
+    e2 = onp.fit_block_norm(src2, np.nan, ref2, np.nan)
+    assert n2[0] == pytest.approx(e2[0], rel=2e-6) and n2[1] == pytest.approx(e2[1], rel=2e-6, abs=1e-6)
