@@ -58,6 +58,10 @@ SIGNATURES = {
     'hk_apply': (C.c_int, [C.c_void_p, _f32p, C.c_int64, _f32p, C.c_int32, C.c_int32, _f32p]),
     'hk_fit_apply': (C.c_int, [C.c_void_p, _P(FitDesc), _f32p, C.c_int64, _f32p, C.c_int64, C.c_int32, C.c_int32,
                                _f64p, _f32p, C.c_int32, _f32p, _f64p, _u64p]),
+    'hk_host_alloc': (C.c_int, [C.c_void_p, C.c_size_t, _P(C.c_void_p)]),
+    'hk_host_free': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'hk_host_register': (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    'hk_host_unregister': (C.c_int, [C.c_void_p, C.c_void_p]),
     'hk_dev_alloc': (C.c_int, [C.c_void_p, C.c_size_t, _P(C.c_void_p)]),
     'hk_dev_free': (C.c_int, [C.c_void_p, C.c_void_p]),
     'hk_memcpy_h2d': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
@@ -190,14 +194,21 @@ class Context:
         return norm
 
     def fit_apply(self, desc: FitDesc, src: np.ndarray, ref: np.ndarray, n_param_bands: int, want_params: bool,
-                  want_corr: bool, norm_in: Optional[np.ndarray] = None):
-        """ -> (params | None, corr | None, norm, r2_fail_count) """
+                  want_corr: bool, norm_in: Optional[np.ndarray] = None, out_params: Optional[np.ndarray] = None,
+                  out_corr: Optional[np.ndarray] = None):
+        """ -> (params | None, corr | None, norm, r2_fail_count).  ``out_params`` / ``out_corr`` let the caller supply
+        (e.g. pinned) float32 C-contiguous output arrays. """
         src, ref = _as_f32_2d(src, 'src'), _as_f32_2d(ref, 'ref')
         if src.shape != ref.shape:
             raise ValueError("'ref_ra' and 'src_ra' must have the same CRS, transform and shape")
         h, w = src.shape
-        params = np.empty((n_param_bands, h, w), np.float32) if want_params else None
-        corr = np.empty((h, w), np.float32) if want_corr else None
+        params = corr = None
+        if want_params:
+            params = out_params if out_params is not None else np.empty((n_param_bands, h, w), np.float32)
+            assert params.shape == (n_param_bands, h, w) and params.dtype == np.float32 and params.flags['C_CONTIGUOUS']
+        if want_corr:
+            corr = out_corr if out_corr is not None else np.empty((h, w), np.float32)
+            assert corr.shape == (h, w) and corr.dtype == np.float32 and corr.flags['C_CONTIGUOUS']
         norm = np.zeros(2, np.float64)
         fail = C.c_uint64(0)
         nin = None
@@ -220,6 +231,35 @@ class Context:
         _check(self._lib.hk_apply(self._h, _ptr(src), src.strides[0] // 4, _ptr(params), src.shape[0], src.shape[1],
                                   _ptr(out)))
         return out
+
+    # -- pinned host memory (async H2D / D2H) ----------------------------------------------------------------------------
+    def pinned_empty(self, shape, dtype=np.float32) -> np.ndarray:
+        """ A numpy array in page-locked host memory: copies to / from it overlap with kernels of other calls.  The
+        memory is released when the array (and every view of it) is garbage collected. """
+        dtype = np.dtype(dtype)
+        nbytes = int(np.prod(shape)) * dtype.itemsize
+        p = C.c_void_p()
+        _check(self._lib.hk_host_alloc(self._h, max(nbytes, 1), C.byref(p)))
+        lib, handle, addr = self._lib, self._h, p.value
+
+        class _Owner:
+            def __del__(self_inner):
+                try:
+                    lib.hk_host_free(handle, C.c_void_p(addr))
+                except Exception:
+                    pass
+
+        buf = (C.c_byte * max(nbytes, 1)).from_address(addr)
+        buf._owner = _Owner()
+        return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def pin(self, arr: np.ndarray):
+        """ Page-lock an existing C-contiguous array in place (hipHostRegister); undo with ``unpin``. """
+        assert arr.flags['C_CONTIGUOUS']
+        _check(self._lib.hk_host_register(self._h, arr.ctypes.data_as(C.c_void_p), arr.nbytes))
+
+    def unpin(self, arr: np.ndarray):
+        _check(self._lib.hk_host_unregister(self._h, arr.ctypes.data_as(C.c_void_p)))
 
     # -- device-resident helpers (bench / streaming) ------------------------------------------------------------------
     def dev_alloc(self, nbytes: int) -> int:

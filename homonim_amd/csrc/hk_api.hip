@@ -388,6 +388,32 @@ int hk_apply(hk_ctx* ctx, const float* src, int64_t src_stride, const float* par
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+int hk_host_alloc(hk_ctx* ctx, size_t bytes, void** hptr) {
+    if (!ctx || !hptr) return fail(HK_ERR_ARG, "NULL argument");
+    HK_HIP(hipSetDevice(ctx->device));
+    if (hipHostMalloc(hptr, bytes, hipHostMallocDefault) != hipSuccess)
+        return fail(HK_ERR_NOMEM, "hipHostMalloc(%zu) failed", bytes);
+    return HK_OK;
+}
+int hk_host_free(hk_ctx* ctx, void* hptr) {
+    if (!ctx) return fail(HK_ERR_ARG, "ctx is NULL");
+    HK_HIP(hipSetDevice(ctx->device));
+    HK_HIP(hipHostFree(hptr));
+    return HK_OK;
+}
+int hk_host_register(hk_ctx* ctx, void* hptr, size_t bytes) {
+    if (!ctx || !hptr) return fail(HK_ERR_ARG, "NULL argument");
+    HK_HIP(hipSetDevice(ctx->device));
+    HK_HIP(hipHostRegister(hptr, bytes, hipHostRegisterDefault));
+    return HK_OK;
+}
+int hk_host_unregister(hk_ctx* ctx, void* hptr) {
+    if (!ctx || !hptr) return fail(HK_ERR_ARG, "NULL argument");
+    HK_HIP(hipSetDevice(ctx->device));
+    HK_HIP(hipHostUnregister(hptr));
+    return HK_OK;
+}
+
 int hk_dev_alloc(hk_ctx* ctx, size_t bytes, void** dptr) {
     if (!ctx || !dptr) return fail(HK_ERR_ARG, "NULL argument");
     HK_HIP(hipSetDevice(ctx->device));

@@ -109,6 +109,15 @@ int hk_fit_apply(hk_ctx* ctx, const hk_fit_desc* desc, const float* src, int64_t
                  float* params_out /* nullable */, int32_t n_param_bands, float* corr_out, double* norm_out,
                  uint64_t* r2_fail_count);
 
+/* Page-lock caller memory so the host-pointer entry points above become truly asynchronous: with pinned src/ref/output
+ * arrays the H2D copy, the kernel and the D2H copy of different calls (different host threads, different pooled streams)
+ * overlap; with pageable memory HIP stages every copy synchronously.  The reference has no counterpart (its blocks are
+ * numpy arrays read by rasterio, homonim/raster_pair.py:331-340). */
+int hk_host_alloc(hk_ctx* ctx, size_t bytes, void** hptr);   /* pinned allocation */
+int hk_host_free(hk_ctx* ctx, void* hptr);
+int hk_host_register(hk_ctx* ctx, void* hptr, size_t bytes); /* pin existing memory in place */
+int hk_host_unregister(hk_ctx* ctx, void* hptr);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * device-resident entry points (inputs already in HBM): what bench.py times and what the streaming tile pipeline
  * is built from.  Buffers come from hk_dev_alloc; planes are height x stride float32 with stride % 4 == 0.

@@ -452,3 +452,20 @@ def test_block_norm_heavy_ties_take_the_fallback_select(ctx):
     n2 = ctx.block_norm(desc2, src2, ref2)
     e2 = onp.fit_block_norm(src2, np.nan, ref2, np.nan)
     assert n2[0] == pytest.approx(e2[0], rel=2e-6) and n2[1] == pytest.approx(e2[1], rel=2e-6, abs=1e-6)
+
+
+def test_pinned_arrays_and_caller_outputs(ctx):
+    """ Pinned (page-locked) inputs/outputs through the host-pointer path give the same bytes as pageable ones. """
+    src, ref = onp.synth_pair(333, 517, 9, 'frame+holes')
+    ps, pr, po = ctx.pinned_empty(src.shape), ctx.pinned_empty(ref.shape), ctx.pinned_empty(src.shape)
+    ps[:], pr[:] = src, ref
+    desc = _hk.make_desc('gain-offset', (5, 5), False, 0.25, np.nan, np.nan)
+    _, c_page, _, _ = ctx.fit_apply(desc, src, ref, 3, want_params=False, want_corr=True)
+    _, c_pin, _, _ = ctx.fit_apply(desc, ps, pr, 3, want_params=False, want_corr=True, out_corr=po)
+    assert c_pin is po
+    assert_same_f32(np.array(c_pin), c_page, 'pinned vs pageable')
+    arr = np.ascontiguousarray(src)
+    ctx.pin(arr)
+    _, c_reg, _, _ = ctx.fit_apply(desc, arr, ref, 3, want_params=False, want_corr=True)
+    ctx.unpin(arr)
+    assert_same_f32(c_reg, c_page, 'registered vs pageable')

@@ -1,0 +1,75 @@
+"""
+End-to-end (PCIe-inclusive) throughput of the host-pointer path: BASELINE.json configs[4]-style mosaic of independent
+4096 x 4096 band-tiles living in (pinned) host memory, one tile per call, T host threads sharing one context whose
+pooled streams overlap H2D / kernel / D2H of different tiles.  NOT the headline number (bench.py, HBM-resident).
+
+    python tools/bench_streamed.py [--tiles 64] [--bands 4] [--threads 8] [--streams 8] [--pageable]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from homonim_amd import _hk  # noqa: E402
+
+
+def main():
+    p = argparse.ArgumentParser()
+    p.add_argument('--tiles', type=int, default=64)
+    p.add_argument('--bands', type=int, default=4)
+    p.add_argument('--size', type=int, default=4096)
+    p.add_argument('--threads', type=int, default=8)
+    p.add_argument('--streams', type=int, default=8)
+    p.add_argument('--distinct', type=int, default=8, help='distinct host tile buffers (re-used round-robin)')
+    p.add_argument('--model', default='gain-offset')
+    p.add_argument('--kernel', type=int, default=5)
+    p.add_argument('--pageable', action='store_true', help='plain numpy arrays instead of pinned ones')
+    args = p.parse_args()
+
+    ctx = _hk.Context(int(os.environ.get('LOCAL_RANK', '0')), n_streams=args.streams)
+    n = args.size
+    alloc = (lambda shape: np.empty(shape, np.float32)) if args.pageable else ctx.pinned_empty
+    rng = np.random.default_rng(0)
+    srcs, refs = [], []
+    for i in range(args.distinct):
+        s, r = alloc((n, n)), alloc((n, n))
+        s[:] = rng.uniform(0.05, 1.0, (n, n)).astype(np.float32)
+        r[:] = (1.2 * s + 0.05 + rng.normal(0, 0.01, (n, n))).astype(np.float32)
+        srcs.append(s)
+        refs.append(r)
+    outs = [alloc((n, n)) for _ in range(args.threads)]
+    thresh = 0.25 if args.model == 'gain-offset' else None
+    desc = _hk.make_desc(args.model, (args.kernel, args.kernel), False, thresh, None, None)
+    n_param = 3 if thresh is not None else 2
+    work = list(range(args.tiles * args.bands))
+
+    def worker(tid):
+        fails = 0
+        for w in work[tid::args.threads]:
+            i = w % args.distinct
+            _, _, _, f = ctx.fit_apply(desc, srcs[i], refs[i], n_param, want_params=False, want_corr=True,
+                                       out_corr=outs[tid])
+            fails += f
+        return fails
+
+    with ThreadPoolExecutor(args.threads) as ex:
+        list(ex.map(worker, range(args.threads)))  # warm-up: grows the per-stream device slabs
+        t0 = time.perf_counter()
+        fails = sum(ex.map(worker, range(args.threads)))
+        dt = time.perf_counter() - t0
+    px = len(work) * n * n
+    print(json.dumps(dict(
+        metric='Mpixels*bands/s fit+apply end-to-end incl. PCIe (host-resident tiles)', value=round(px / dt / 1e6, 1),
+        seconds=round(dt, 3), tiles=args.tiles, bands=args.bands, tile=n, threads=args.threads, streams=args.streams,
+        pinned=not args.pageable, model=args.model, kernel=args.kernel, r2_mask_failures=int(fails),
+        pcie_gbps_in=round(px * 8 / dt / 1e9, 1), pcie_gbps_out=round(px * 4 / dt / 1e9, 1))))
+    ctx.close()
+
+
+if __name__ == '__main__':
+    main()
