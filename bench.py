@@ -56,7 +56,7 @@ def cpu_baseline(model, k, sample):
     except Exception:
         have_c = False
     if sample <= 0:
-        sample = 4096 if have_c else 1536
+        sample = (8192 if (os.cpu_count() or 1) >= 32 else 4096) if have_c else 1536
     src, ref = onp.synth_pair(sample, sample, seed=0)
     thresh = 0.25 if model == 'gain-offset' else None
     if have_c:
@@ -67,7 +67,7 @@ def cpu_baseline(model, k, sample):
         while True:
             oracle_c.fit_apply(model, src, np.nan, ref, np.nan, (k, k), False, thresh, n_threads=cores)
             reps += 1
-            if time.perf_counter() - t0 > 8.0 or reps >= 20:
+            if time.perf_counter() - t0 > 10.0 or reps >= 40:
                 break
         dt = (time.perf_counter() - t0) / reps
         impl = f'C oracle (oracle/hk_oracle.c, OpenMP {cores} threads)'

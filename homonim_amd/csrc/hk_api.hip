@@ -118,7 +118,6 @@ int validate_desc(const hk_fit_desc* d) {
         return fail(HK_ERR_ARG, "`kernel_shape` area should contain at least 2 elements for the gain-offset model.");
     if (d->kh > 255) return fail(HK_ERR_UNSUPPORTED, "kernel height %d > 255 not supported", d->kh);
     if (hk::overlap_lanes_for(d->kw / 2) > 24) return fail(HK_ERR_UNSUPPORTED, "kernel width %d too large", d->kw);
-    if (hk::fit_lds_bytes(d->kh) > 160 * 1024) return fail(HK_ERR_UNSUPPORTED, "kernel height %d exceeds the LDS ring", d->kh);
     for (int m : {d->src_nodata_mode, d->ref_nodata_mode})
         if (m < 0 || m > 2) return fail(HK_ERR_ARG, "bad nodata mode %d", m);
     return HK_OK;
@@ -159,12 +158,17 @@ void fill_args(hk::FitArgs& a, const hk_fit_desc* d, int xcd_remap) {
     a.r2_thresh = d->r2_thresh;
     a.r2_pass_scale = a.has_thresh ? r2_pass_scale(d->r2_thresh) : -INFINITY;
     a.force_general = getenv("HK_FORCE_GENERAL") ? atoi(getenv("HK_FORCE_GENERAL")) : 0;
+    // LDS row ring only while it leaves room for >= 11 waves per CU (kh <= 5); taller kernels re-load rows (hk_kernels.hip)
+    a.use_ring = d->kh <= 5 && d->kw <= 7;
+    if (const char* e = getenv("HK_USE_RING")) a.use_ring = atoi(e) != 0 && d->kh <= 63 && d->kw <= 7;
     a.xcd_remap = xcd_remap;
 }
 
 void fill_grid(hk::FitArgs& a, int seg_rows) {
     const int out_w = (hk::WAVE - 2 * a.overlap_lanes) * hk::PX;
-    a.seg_rows = seg_rows > 0 ? seg_rows : DEFAULT_SEG_ROWS;
+    const int kh = 2 * a.rh + 1;
+    // rows per wave segment: the 2*rh priming rows are redundant work, so taller kernels get longer segments
+    a.seg_rows = seg_rows > 0 ? seg_rows : (kh <= 5 ? 64 : (kh <= 9 ? 128 : 256));
     if (a.seg_rows > a.height) a.seg_rows = a.height;
     a.n_strips = (a.width + out_w - 1) / out_w;
     a.n_segs = (a.height + a.seg_rows - 1) / a.seg_rows;

@@ -294,7 +294,8 @@ struct ColSums {
 #ifndef HK_FIT_MIN_WAVES
 #define HK_FIT_MIN_WAVES 3  // waves per SIMD the register allocator must leave room for (tuned on MI355X)
 #endif
-template <int MODEL, bool R2, int RW, bool DENSE>
+// RING: leaving/centre rows from the wave-private LDS ring (short kernels) or re-loaded from global memory.
+template <int MODEL, bool R2, int RW, bool DENSE, bool RING>
 __global__ void __launch_bounds__(WAVE, HK_FIT_MIN_WAVES) fit_apply_kernel(const FitArgs a) {
     using CS = ColSums<MODEL, R2, DENSE>;
     constexpr bool GO = MODEL == 2, BLK = MODEL == 1;
@@ -353,14 +354,26 @@ __global__ void __launch_bounds__(WAVE, HK_FIT_MIN_WAVES) fit_apply_kernel(const
         n1 = a.norm[2 * band + 1];
     }
 
-    // wave-private LDS ring of kh processed rows: [slot][s|r][lane] float4 + [slot][lane] mask words
+    // Leaving / centre rows of the window come either from a wave-private LDS ring of kh processed rows
+    // ([slot][s|r][lane] float4 + [slot][lane] mask words; 36 B per lane-row) or, for tall kernels whose ring would
+    // crush occupancy (a.use_ring == 0), are simply loaded again from global memory (L2 / Infinity-Cache hits).
+    constexpr bool ring = RING;
+    const int ring_rows = ring ? kh : 0;
     float4* ring_v = lds4;
-    unsigned* ring_m = reinterpret_cast<unsigned*>(lds4 + (size_t)kh * 2 * WAVE);
-    for (int sl = 0; sl < kh; ++sl) {
+    unsigned* ring_m = reinterpret_cast<unsigned*>(lds4 + (size_t)ring_rows * 2 * WAVE);
+    for (int sl = 0; sl < ring_rows; ++sl) {
         ring_v[(sl * 2 + 0) * WAVE + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
         ring_v[(sl * 2 + 1) * WAVE + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
         if constexpr (!DENSE) ring_m[sl * WAVE + lane] = 0u;
     }
+
+    // 1/N table for the offset division (kernel_model.py:351: float32 `t / mask_sum`).  For a float32 t and an integer
+    // N < 2^8 the quotient t/N is never closer than 2^-33 (relative) to a float32 rounding midpoint, while
+    // f64(t) * RN64(1/N) is within 2^-52 of it -- so rounding that product to float32 IS the IEEE float32 division.
+    double* inv_lut = reinterpret_cast<double*>(ring_m + (size_t)ring_rows * WAVE);
+    const bool use_lut = GO && kh * (2 * rw + 1) <= 255;
+    if (use_lut)
+        for (int n = lane; n < 256; n += WAVE) inv_lut[n] = 1.0 / (double)n;
 
     CS cs;
     cs.clear();
@@ -385,19 +398,30 @@ __global__ void __launch_bounds__(WAVE, HK_FIT_MIN_WAVES) fit_apply_kernel(const
     for (int t = t_first; t <= t_last; ++t) {
         const RowRaw q2 = load_row(sp, rp, a.stride, t + 2 <= t_last ? t + 2 : -1, H, x, lane_in);
 
+        // reload mode: issue the loads of the leaving row (t - kh; a zero row if it was never added) and of the centre
+        // row (t - rh) now, consume them after the entering row has been folded in
+        RowRaw qo, qc;
+        const int t_old = t - kh, y_c = t - rh;
+        if (!ring) {
+            qo = load_row(sp, rp, a.stride, t_old >= t_first ? t_old : -1, H, x, lane_in);
+            qc = load_row(sp, rp, a.stride, y_c >= y0 ? y_c : -1, H, x, lane_in);
+        }
+
         const RowZ znew = process_row<MODEL, DENSE>(q0, t >= 0 && t < H, colbits, ragged, ts, tr, n0, n1);
-        // leaving row (t - kh): read from the slot the entering row is about to overwrite
         RowZ zold;
-        {
+        if (ring) {
+            // leaving row (t - kh): read from the slot the entering row is about to overwrite
             const float4 os = ring_v[(slot * 2 + 0) * WAVE + lane];
             const float4 orr = ring_v[(slot * 2 + 1) * WAVE + lane];
             zold.s[0] = os.x, zold.s[1] = os.y, zold.s[2] = os.z, zold.s[3] = os.w;
             zold.r[0] = orr.x, zold.r[1] = orr.y, zold.r[2] = orr.z, zold.r[3] = orr.w;
             zold.m = DENSE ? 0u : ring_m[slot * WAVE + lane];
+            ring_v[(slot * 2 + 0) * WAVE + lane] = make_float4(znew.s[0], znew.s[1], znew.s[2], znew.s[3]);
+            ring_v[(slot * 2 + 1) * WAVE + lane] = make_float4(znew.r[0], znew.r[1], znew.r[2], znew.r[3]);
+            if constexpr (!DENSE) ring_m[slot * WAVE + lane] = znew.m;
+        } else {
+            zold = process_row<MODEL, DENSE>(qo, t_old >= t_first && t_old >= 0 && t_old < H, colbits, ragged, ts, tr, n0, n1);
         }
-        ring_v[(slot * 2 + 0) * WAVE + lane] = make_float4(znew.s[0], znew.s[1], znew.s[2], znew.s[3]);
-        ring_v[(slot * 2 + 1) * WAVE + lane] = make_float4(znew.r[0], znew.r[1], znew.r[2], znew.r[3]);
-        if constexpr (!DENSE) ring_m[slot * WAVE + lane] = znew.m;
 
         if (kh == 1) {  // wave-uniform: a 1-row window IS the entering row -- no running sum, exact by construction
             cs.clear();
@@ -410,10 +434,19 @@ __global__ void __launch_bounds__(WAVE, HK_FIT_MIN_WAVES) fit_apply_kernel(const
         const int y = t - rh;
         if (y >= y0) {  // wave-uniform: the first 2*rh iterations only prime the running sums
             // centre row of the window
-            const float4 cs4 = ring_v[(slot_c * 2 + 0) * WAVE + lane];
-            const float sc[PX] = {cs4.x, cs4.y, cs4.z, cs4.w};
-            const unsigned mc = DENSE ? (colbits * 0x00204081u) & 0x01010101u  // bit i -> byte i
-                                      : ring_m[slot_c * WAVE + lane];
+            float sc[PX];
+            unsigned mc;
+            if (ring) {
+                const float4 cs4 = ring_v[(slot_c * 2 + 0) * WAVE + lane];
+                sc[0] = cs4.x, sc[1] = cs4.y, sc[2] = cs4.z, sc[3] = cs4.w;
+                mc = DENSE ? 0u : ring_m[slot_c * WAVE + lane];
+            } else {
+                const RowZ zc = process_row<MODEL, DENSE>(qc, true, colbits, ragged, ts, tr, n0, n1);
+#pragma unroll
+                for (int i = 0; i < PX; ++i) sc[i] = zc.s[i];
+                mc = zc.m;
+            }
+            if constexpr (DENSE) mc = (colbits * 0x00204081u) & 0x01010101u;  // bit i -> byte i
 
             double HS[PX], HR[PX];
             hsum_any<RW, double>(cs.S, HS, rw, ol, lane);
@@ -453,7 +486,8 @@ __global__ void __launch_bounds__(WAVE, HK_FIT_MIN_WAVES) fit_apply_kernel(const
                     const float num = __fsub_rn(__fmul_rn(Nf[i], Pf[i]), __fmul_rn(Sf[i], Rf[i]));
                     const double den = __dsub_rn(__dmul_rn(Nd[i], HS2[i]), (double)__fmul_rn(Sf[i], Sf[i]));
                     g[i] = (float)__ddiv_rn((double)num, den);
-                    o[i] = __fdiv_rn(__fsub_rn(Rf[i], __fmul_rn(g[i], Sf[i])), Nf[i]);
+                    const float tn = __fsub_rn(Rf[i], __fmul_rn(g[i], Sf[i]));
+                    o[i] = use_lut ? (float)__dmul_rn((double)tn, inv_lut[(int)Nf[i]]) : __fdiv_rn(tn, Nf[i]);
                 } else if constexpr (BLK) {
                     // kernel_model.py:265 with a float64 src_sum: np.divide(f32, f64, out=f32); then :301-302
                     gp[i] = (float)__ddiv_rn((double)Rf[i], HS[i]);
@@ -562,33 +596,48 @@ __global__ void __launch_bounds__(WAVE, HK_FIT_MIN_WAVES) fit_apply_kernel(const
     }
 }
 
-size_t fit_lds_bytes(int kh) { return (size_t)kh * (2 * WAVE * sizeof(float4) + WAVE * sizeof(unsigned)); }
+// LDS bytes of one wave: [row ring + mask words of kh rows, only in ring mode] + the 256-entry float64 1/N table
+size_t fit_lds_bytes(int kh, bool use_ring) {
+    return (use_ring ? (size_t)kh * (2 * WAVE * sizeof(float4) + WAVE * sizeof(unsigned)) : 0) + 256 * sizeof(double);
+}
 
-template <int MODEL, bool R2, int RW, bool DENSE>
+template <int MODEL, bool R2, int RW, bool DENSE, bool RING>
 static hipError_t launch_one(const FitArgs& a, hipStream_t stream) {
-    const size_t lds = fit_lds_bytes(2 * a.rh + 1);
+    const size_t lds = fit_lds_bytes(2 * a.rh + 1, RING);
     static bool attr_set = false;  // raise the dynamic-LDS cap once per instantiation (64 KiB default)
     if (lds > 64 * 1024 && !attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fit_apply_kernel<MODEL, R2, RW, DENSE>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fit_apply_kernel<MODEL, R2, RW, DENSE, RING>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     int grid = a.total_units;
     if (a.xcd_remap) grid = (grid + 7) / 8 * 8;
-    hipLaunchKernelGGL((fit_apply_kernel<MODEL, R2, RW, DENSE>), dim3(grid), dim3(WAVE), lds, stream, a);
+    hipLaunchKernelGGL((fit_apply_kernel<MODEL, R2, RW, DENSE, RING>), dim3(grid), dim3(WAVE), lds, stream, a);
     return hipGetLastError();
 }
 
 template <int MODEL, bool R2, bool DENSE>
 static hipError_t launch_rw(const FitArgs& a, hipStream_t stream) {
+    if (a.use_ring) {  // LDS-ring kernels exist for the short, narrow shapes only (hk_api.hip picks use_ring)
+        switch (a.rw) {
+            case 0: return launch_one<MODEL, R2, 0, DENSE, true>(a, stream);
+            case 1: return launch_one<MODEL, R2, 1, DENSE, true>(a, stream);
+            case 2: return launch_one<MODEL, R2, 2, DENSE, true>(a, stream);
+            case 3: return launch_one<MODEL, R2, 3, DENSE, true>(a, stream);
+            default: break;
+        }
+    }
     switch (a.rw) {
-        case 0: return launch_one<MODEL, R2, 0, DENSE>(a, stream);
-        case 1: return launch_one<MODEL, R2, 1, DENSE>(a, stream);
-        case 2: return launch_one<MODEL, R2, 2, DENSE>(a, stream);
-        case 3: return launch_one<MODEL, R2, 3, DENSE>(a, stream);
-        case 7: return launch_one<MODEL, R2, 7, DENSE>(a, stream);
-        default: return launch_one<MODEL, R2, -1, DENSE>(a, stream);
+        case 0: return launch_one<MODEL, R2, 0, DENSE, false>(a, stream);
+        case 1: return launch_one<MODEL, R2, 1, DENSE, false>(a, stream);
+        case 2: return launch_one<MODEL, R2, 2, DENSE, false>(a, stream);
+        case 3: return launch_one<MODEL, R2, 3, DENSE, false>(a, stream);
+        case 4: return launch_one<MODEL, R2, 4, DENSE, false>(a, stream);
+        case 5: return launch_one<MODEL, R2, 5, DENSE, false>(a, stream);
+        case 6: return launch_one<MODEL, R2, 6, DENSE, false>(a, stream);
+        case 7: return launch_one<MODEL, R2, 7, DENSE, false>(a, stream);
+        default: return launch_one<MODEL, R2, -1, DENSE, false>(a, stream);
     }
 }
 

@@ -469,3 +469,30 @@ def test_pinned_arrays_and_caller_outputs(ctx):
     _, c_reg, _, _ = ctx.fit_apply(desc, arr, ref, 3, want_params=False, want_corr=True)
     ctx.unpin(arr)
     assert_same_f32(c_reg, c_page, 'registered vs pageable')
+
+
+@pytest.mark.parametrize('model, kernel_shape, find_r2, thresh, nodata', [
+    ('gain-offset', (5, 5), True, 0.25, np.nan), ('gain-offset', (15, 15), True, 0.25, np.nan),
+    ('gain-offset', (9, 3), False, None, None), ('gain-blk-offset', (15, 15), True, None, np.nan),
+    ('gain', (1, 5), True, None, np.nan), ('gain-offset', (31, 31), False, None, np.nan),
+])
+def test_lds_ring_and_reload_modes_agree(ctx, model, kernel_shape, find_r2, thresh, nodata, monkeypatch):
+    """ The leaving/centre rows come from the LDS ring (short kernels) or are re-loaded from global memory (tall
+    kernels); both modes must give the same bytes, whichever the default for the shape is. """
+    import warnings
+    src, ref = onp.synth_pair(300, 520, seed=kernel_shape[0], nodata_variant='frame+holes' if nodata is not None else 'none')
+    cfg = dict(model=model, kernel_shape=kernel_shape, find_r2=find_r2, r2_inpaint_thresh=thresh, src_nodata=nodata,
+               ref_nodata=nodata)
+    norm_in = onp.fit_block_norm(src, nodata, ref, nodata) if model == 'gain-blk-offset' else None
+    out = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('HK_USE_RING', mode)
+        out[mode] = _fit_via_abi(ctx, cfg, src, ref, norm_in=norm_in)
+    monkeypatch.delenv('HK_USE_RING')
+    assert_same_f32(out['1'][0], out['0'][0], 'params ring vs reload')
+    assert_same_f32(out['1'][1], out['0'][1], 'corrected ring vs reload')
+    assert out['1'][3] == out['0'][3]
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        exp, _ = onp.fit(model, src, nodata, ref, nodata, kernel_shape, find_r2, thresh, norm_model=norm_in)
+    assert_close_ulp(out['0'][0], exp, 'params')
