@@ -225,9 +225,19 @@ __device__ __forceinline__ RowZ process_row(const RowRaw& raw, bool row_ok, unsi
         }
         return z;
     }
+    bool ok[PX];
+    if (ts.nan_is_nodata & tr.nan_is_nodata) {
+        // wave-uniform: the RasterArray default (nodata = nan on both rasters): valid <=> neither value is NaN
+        // <=> the pair compares ordered -- one v_cmp_o_f32 instead of four compares
+#pragma unroll
+        for (int i = 0; i < PX; ++i) ok[i] = !__builtin_isunordered(s[i], r[i]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < PX; ++i) ok[i] = px_valid(s[i], ts) & px_valid(r[i], tr);
+    }
 #pragma unroll
     for (int i = 0; i < PX; ++i) {
-        bool m = row_ok & (bool)((colbits >> i) & 1u) & px_valid(s[i], ts) & px_valid(r[i], tr);
+        bool m = row_ok & (bool)((colbits >> i) & 1u) & ok[i];
         if constexpr (MODEL == 1) {
             // gain-blk-offset: the mask is re-derived from the NORMALISED float64 source (kernel_model.py:292-298)
             const double sd = __dadd_rn(__dmul_rn((double)s[i], n0), n1);
@@ -559,25 +569,31 @@ __global__ void __launch_bounds__(WAVE, HK_FIT_MIN_WAVES) fit_apply_kernel(const
                 }
             }
 
-            // ---- stage C: where=mask (every parameter write goes into a NaN-filled array, :261,:345) and apply (:461) ----
+            // ---- stage C: apply (:461) and where=mask (every parameter write goes into a NaN-filled array, :261,:345) ----
+            // A masked pixel has NaN parameters, hence a NaN corrected value: select once per stored plane.
 #pragma unroll
             for (int i = 0; i < PX; ++i) {
-                if constexpr (!DENSE) {
-                    const bool m = (mc >> (8 * i)) & 1u;
-                    g[i] = m ? g[i] : qnan();
-                    o[i] = m ? o[i] : qnan();
-                    r2v[i] = m ? r2v[i] : qnan();
-                }
                 c[i] = __fadd_rn(__fmul_rn(g[i], sc[i]), o[i]);  // two float32 roundings
+                if constexpr (!DENSE) c[i] = ((mc >> (8 * i)) & 1u) ? c[i] : qnan();
             }
+            auto masked4 = [&](const float (&v)[PX]) {
+                float4 r4 = make_float4(v[0], v[1], v[2], v[3]);
+                if constexpr (!DENSE) {
+                    r4.x = (mc & 0x00000001u) ? r4.x : qnan();
+                    r4.y = (mc & 0x00000100u) ? r4.y : qnan();
+                    r4.z = (mc & 0x00010000u) ? r4.z : qnan();
+                    r4.w = (mc & 0x01000000u) ? r4.w : qnan();
+                }
+                return r4;
+            };
 
             if (out_lane) {
                 // stride % 4 == 0: a quad never crosses the row end, columns >= W land in the row padding
                 const long long off = out_base + (long long)y * a.stride + x;
                 if (a.corr) *reinterpret_cast<float4*>(a.corr + off) = make_float4(c[0], c[1], c[2], c[3]);
-                if (a.gain) *reinterpret_cast<float4*>(a.gain + off) = make_float4(g[0], g[1], g[2], g[3]);
-                if (a.offset) *reinterpret_cast<float4*>(a.offset + off) = make_float4(o[0], o[1], o[2], o[3]);
-                if (R2 && a.r2) *reinterpret_cast<float4*>(a.r2 + off) = make_float4(r2v[0], r2v[1], r2v[2], r2v[3]);
+                if (a.gain) *reinterpret_cast<float4*>(a.gain + off) = masked4(g);
+                if (a.offset) *reinterpret_cast<float4*>(a.offset + off) = masked4(o);
+                if (R2 && a.r2) *reinterpret_cast<float4*>(a.r2 + off) = masked4(r2v);
             }
         }
 
