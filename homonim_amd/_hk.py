@@ -32,6 +32,15 @@ class FitDesc(C.Structure):
     ]  # yapf: disable
 
 
+class IoDesc(C.Structure):
+    _fields_ = [('src_dtype', C.c_int32), ('ref_dtype', C.c_int32), ('out_dtype', C.c_int32),
+                ('out_has_nodata', C.c_int32), ('out_nodata', C.c_double)]
+
+
+# numpy dtype name -> hk_dtype
+DTYPE_CODES = {'float32': 0, 'uint8': 1, 'uint16': 2, 'int16': 3, 'uint32': 4, 'int32': 5, 'float64': 6}
+
+
 class DevJob(C.Structure):
     _fields_ = [
         ('src', C.c_void_p), ('ref', C.c_void_p), ('gain', C.c_void_p), ('offset', C.c_void_p), ('r2', C.c_void_p),
@@ -58,6 +67,8 @@ SIGNATURES = {
     'hk_apply': (C.c_int, [C.c_void_p, _f32p, C.c_int64, _f32p, C.c_int32, C.c_int32, _f32p]),
     'hk_fit_apply': (C.c_int, [C.c_void_p, _P(FitDesc), _f32p, C.c_int64, _f32p, C.c_int64, C.c_int32, C.c_int32,
                                _f64p, _f32p, C.c_int32, _f32p, _f64p, _u64p]),
+    'hk_fit_apply_io': (C.c_int, [C.c_void_p, _P(FitDesc), _P(IoDesc), C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                  C.c_int32, C.c_int32, _f64p, _f32p, C.c_int32, C.c_void_p, _f64p, _u64p]),
     'hk_host_alloc': (C.c_int, [C.c_void_p, C.c_size_t, _P(C.c_void_p)]),
     'hk_host_free': (C.c_int, [C.c_void_p, C.c_void_p]),
     'hk_host_register': (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
@@ -145,6 +156,18 @@ def _as_f32_2d(a: np.ndarray, name: str) -> np.ndarray:
     return a
 
 
+def _as_2d_native(a: np.ndarray, name: str) -> np.ndarray:
+    """ 2-D raster in one of the dtypes the device converts itself (DTYPE_CODES); rows may be strided. """
+    if a.ndim != 2:
+        raise ValueError(f'`{name}` must be 2-D')
+    if a.dtype.name not in DTYPE_CODES:
+        a = a.astype(np.float32)
+    it = a.dtype.itemsize
+    if a.strides[1] != it or a.strides[0] % it != 0 or a.strides[0] < a.shape[1] * it:
+        a = np.ascontiguousarray(a)
+    return a
+
+
 def _ptr(a: np.ndarray, typ=_f32p):
     return a.ctypes.data_as(typ)
 
@@ -195,31 +218,44 @@ class Context:
 
     def fit_apply(self, desc: FitDesc, src: np.ndarray, ref: np.ndarray, n_param_bands: int, want_params: bool,
                   want_corr: bool, norm_in: Optional[np.ndarray] = None, out_params: Optional[np.ndarray] = None,
-                  out_corr: Optional[np.ndarray] = None):
-        """ -> (params | None, corr | None, norm, r2_fail_count).  ``out_params`` / ``out_corr`` let the caller supply
-        (e.g. pinned) float32 C-contiguous output arrays. """
-        src, ref = _as_f32_2d(src, 'src'), _as_f32_2d(ref, 'ref')
+                  out_corr: Optional[np.ndarray] = None, out_dtype: str = 'float32', out_nodata: Optional[float] = None):
+        """
+        -> (params | None, corr | None, norm, r2_fail_count).
+
+        ``src`` / ``ref`` may be float32 or any dtype of DTYPE_CODES (converted on the device as rasterio would on
+        read); ``out_dtype`` / ``out_nodata`` convert the corrected block on the device as the reference does on write
+        (round half-to-even, clip, masked pixels -> ``out_nodata``).  ``out_params`` / ``out_corr`` let the caller
+        supply (e.g. pinned) C-contiguous output arrays.
+        """
+        src, ref = _as_2d_native(src, 'src'), _as_2d_native(ref, 'ref')
         if src.shape != ref.shape:
             raise ValueError("'ref_ra' and 'src_ra' must have the same CRS, transform and shape")
         h, w = src.shape
+        out_dtype = np.dtype(out_dtype)
+        if out_dtype.name not in DTYPE_CODES:
+            raise ValueError(f'unsupported output dtype {out_dtype}')
+        keep_nan = out_nodata is None or (isinstance(out_nodata, float) and math.isnan(out_nodata))
         params = corr = None
         if want_params:
             params = out_params if out_params is not None else np.empty((n_param_bands, h, w), np.float32)
             assert params.shape == (n_param_bands, h, w) and params.dtype == np.float32 and params.flags['C_CONTIGUOUS']
         if want_corr:
-            corr = out_corr if out_corr is not None else np.empty((h, w), np.float32)
-            assert corr.shape == (h, w) and corr.dtype == np.float32 and corr.flags['C_CONTIGUOUS']
+            corr = out_corr if out_corr is not None else np.empty((h, w), out_dtype)
+            assert corr.shape == (h, w) and corr.dtype == out_dtype and corr.flags['C_CONTIGUOUS']
         norm = np.zeros(2, np.float64)
         fail = C.c_uint64(0)
         nin = None
         if norm_in is not None:
             nin = np.ascontiguousarray(norm_in, dtype=np.float64)
-        args = (self._h, C.byref(desc), _ptr(src), src.strides[0] // 4, _ptr(ref), ref.strides[0] // 4, h, w,
-                _ptr(nin, _f64p) if nin is not None else None, _ptr(params) if want_params else None, n_param_bands)
-        if want_corr:
-            _check(self._lib.hk_fit_apply(*args, _ptr(corr), _ptr(norm, _f64p), C.byref(fail)))
-        else:
-            _check(self._lib.hk_fit(*args, _ptr(norm, _f64p), C.byref(fail)))
+        io = IoDesc(DTYPE_CODES[src.dtype.name], DTYPE_CODES[ref.dtype.name], DTYPE_CODES[out_dtype.name],
+                    0 if (keep_nan and out_dtype.kind == 'f') or out_nodata is None else 1,
+                    0.0 if out_nodata is None or keep_nan else float(out_nodata))
+        vp = C.c_void_p
+        _check(self._lib.hk_fit_apply_io(
+            self._h, C.byref(desc), C.byref(io), src.ctypes.data_as(vp), src.strides[0] // src.dtype.itemsize,
+            ref.ctypes.data_as(vp), ref.strides[0] // ref.dtype.itemsize, h, w,
+            _ptr(nin, _f64p) if nin is not None else None, _ptr(params) if want_params else None, n_param_bands,
+            corr.ctypes.data_as(vp) if want_corr else None, _ptr(norm, _f64p), C.byref(fail)))
         return params, corr, norm, int(fail.value)
 
     def apply(self, src: np.ndarray, params: np.ndarray) -> np.ndarray:

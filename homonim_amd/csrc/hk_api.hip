@@ -175,16 +175,20 @@ void fill_grid(hk::FitArgs& a, int seg_rows) {
     a.total_units = a.n_strips * a.n_segs * a.n_bands;
 }
 
-// The whole host-pointer path: stage in, (norm), fused kernel, stage out.  `corr_out`/`params_out` nullable.
-int run_host(hk_ctx* ctx, const hk_fit_desc* desc, const float* src, int64_t src_stride, const float* ref,
-             int64_t ref_stride, int32_t height, int32_t width, const double* norm_in, float* params_out,
-             int32_t n_param_bands, float* corr_out, double* norm_out, uint64_t* r2_fail_count, bool norm_only) {
+// The whole host-pointer path: stage in (+ typed -> float32), (norm), fused kernel, (float32 -> typed) stage out.
+// `corr_out` / `params_out` nullable; `io` nullable (float32 everywhere).
+int run_host(hk_ctx* ctx, const hk_fit_desc* desc, const hk_io_desc* io, const void* src, int64_t src_stride,
+             const void* ref, int64_t ref_stride, int32_t height, int32_t width, const double* norm_in, float* params_out,
+             int32_t n_param_bands, void* corr_out, double* norm_out, uint64_t* r2_fail_count, bool norm_only) {
     if (!ctx) return fail(HK_ERR_ARG, "ctx is NULL");
     int rc = validate_desc(desc);
     if (rc) return rc;
     if (!src || !ref) return fail(HK_ERR_ARG, "src/ref is NULL");
     if (height < 1 || width < 1) return fail(HK_ERR_ARG, "empty raster %d x %d", height, width);
     if (src_stride < width || ref_stride < width) return fail(HK_ERR_ARG, "row stride smaller than width");
+    const int sdt = io ? io->src_dtype : 0, rdt = io ? io->ref_dtype : 0, odt = io ? io->out_dtype : 0;
+    if (!hk::dtype_size(sdt) || !hk::dtype_size(rdt) || !hk::dtype_size(odt)) return fail(HK_ERR_ARG, "unknown dtype");
+    const bool out_cast = io && (odt != 0 || io->out_has_nodata);
     const bool r2 = needs_r2(desc);
     if (!norm_only) {
         if (params_out && n_param_bands != (r2 ? 3 : 2))
@@ -197,37 +201,53 @@ int run_host(hk_ctx* ctx, const hk_fit_desc* desc, const float* src, int64_t src
     const size_t plane = (size_t)stride * height * sizeof(float);
     const bool blk = desc->model == HK_MODEL_GAIN_BLK_OFFSET;
     const bool want_norm = blk || norm_only;
-    const size_t n_planes = 2 + (norm_only ? 0 : ((params_out ? (size_t)n_param_bands : 0) + (corr_out ? 1 : 0)));
-    const size_t aux_off = n_planes * plane;
-    const size_t ws_bytes = want_norm ? hk::norm_workspace_bytes(1, height, width) : 0;
-    const size_t total = aux_off + 256 + ws_bytes;
+
+    // bump allocation inside the stream's device slab (everything 256-byte aligned)
+    size_t total = 0;
+    auto take = [&](size_t bytes) { const size_t off = total; total += (bytes + 255) / 256 * 256; return off; };
+    const size_t o_src = take(plane), o_ref = take(plane);
+    size_t o_gain = 0, o_off = 0, o_r2 = 0, o_corr = 0, o_raw_s = 0, o_raw_r = 0, o_raw_o = 0;
+    if (!norm_only) {
+        if (params_out) {
+            o_gain = take(plane), o_off = take(plane);
+            if (n_param_bands == 3) o_r2 = take(plane);
+        }
+        if (corr_out) o_corr = take(plane);
+        if (corr_out && out_cast) o_raw_o = take((size_t)stride * height * hk::dtype_size(odt));
+    }
+    if (sdt) o_raw_s = take((size_t)stride * height * hk::dtype_size(sdt));
+    if (rdt) o_raw_r = take((size_t)stride * height * hk::dtype_size(rdt));
+    const size_t o_aux = take(256);
+    const size_t o_ws = want_norm ? take(hk::norm_workspace_bytes(1, height, width)) : 0;
 
     SlotLease lease(ctx);
     Slot& sl = lease.slot();
     rc = ensure_dev(sl, total);
     if (rc) return rc;
     char* base = static_cast<char*>(sl.dev);
-    float* d_src = reinterpret_cast<float*>(base);
-    float* d_ref = reinterpret_cast<float*>(base + plane);
-    size_t next = 2;
-    float *d_gain = nullptr, *d_off = nullptr, *d_r2 = nullptr, *d_corr = nullptr;
-    if (!norm_only) {
-        if (params_out) {
-            d_gain = reinterpret_cast<float*>(base + (next++) * plane);
-            d_off = reinterpret_cast<float*>(base + (next++) * plane);
-            if (n_param_bands == 3) d_r2 = reinterpret_cast<float*>(base + (next++) * plane);
-        }
-        if (corr_out) d_corr = reinterpret_cast<float*>(base + (next++) * plane);
-    }
-    double* d_norm = reinterpret_cast<double*>(base + aux_off);               // 2 doubles
-    unsigned long long* d_fail = reinterpret_cast<unsigned long long*>(base + aux_off + 64);
-    void* d_ws = base + aux_off + 256;
+    float* d_src = reinterpret_cast<float*>(base + o_src);
+    float* d_ref = reinterpret_cast<float*>(base + o_ref);
+    float* d_gain = (!norm_only && params_out) ? reinterpret_cast<float*>(base + o_gain) : nullptr;
+    float* d_off = (!norm_only && params_out) ? reinterpret_cast<float*>(base + o_off) : nullptr;
+    float* d_r2 = (!norm_only && params_out && n_param_bands == 3) ? reinterpret_cast<float*>(base + o_r2) : nullptr;
+    float* d_corr = (!norm_only && corr_out) ? reinterpret_cast<float*>(base + o_corr) : nullptr;
+    double* d_norm = reinterpret_cast<double*>(base + o_aux);  // 2 doubles
+    unsigned long long* d_fail = reinterpret_cast<unsigned long long*>(base + o_aux + 64);
+    void* d_ws = base + o_ws;
 
-    const size_t wbytes = (size_t)width * sizeof(float);
-    HK_HIP(hipMemcpy2DAsync(d_src, stride * sizeof(float), src, src_stride * sizeof(float), wbytes, height,
-                            hipMemcpyHostToDevice, sl.stream));
-    HK_HIP(hipMemcpy2DAsync(d_ref, stride * sizeof(float), ref, ref_stride * sizeof(float), wbytes, height,
-                            hipMemcpyHostToDevice, sl.stream));
+    // stage in: float32 planes directly, other dtypes through a raw plane + on-device conversion
+    auto stage_in = [&](const void* host, int64_t hstride, int dt, float* dplane, size_t o_raw) -> int {
+        const size_t es = hk::dtype_size(dt);
+        void* dst = dt ? static_cast<void*>(base + o_raw) : static_cast<void*>(dplane);
+        HK_HIP(hipMemcpy2DAsync(dst, stride * es, host, hstride * es, (size_t)width * es, height, hipMemcpyHostToDevice,
+                                sl.stream));
+        if (dt) HK_HIP(hk::launch_cast_in(dt, dst, stride, dplane, stride, height, width, sl.stream));
+        return HK_OK;
+    };
+    rc = stage_in(src, src_stride, sdt, d_src, o_raw_s);
+    if (rc) return rc;
+    rc = stage_in(ref, ref_stride, rdt, d_ref, o_raw_r);
+    if (rc) return rc;
     HK_HIP(hipMemsetAsync(d_fail, 0, sizeof(unsigned long long), sl.stream));
 
     if (want_norm) {
@@ -255,14 +275,25 @@ int run_host(hk_ctx* ctx, const hk_fit_desc* desc, const float* src, int64_t src
         fill_grid(a, 0);
         HK_HIP(hk::launch_fit_apply(a, desc->model, r2, sl.stream));
 
-        float* outs[4] = {d_gain, d_off, d_r2, nullptr};
+        const size_t wbytes = (size_t)width * sizeof(float);
+        float* outs[3] = {d_gain, d_off, d_r2};
         if (params_out)
             for (int b = 0; b < n_param_bands; ++b)
                 HK_HIP(hipMemcpy2DAsync(params_out + (size_t)b * height * width, wbytes, outs[b], stride * sizeof(float),
                                         wbytes, height, hipMemcpyDeviceToHost, sl.stream));
-        if (corr_out)
-            HK_HIP(hipMemcpy2DAsync(corr_out, wbytes, d_corr, stride * sizeof(float), wbytes, height,
-                                    hipMemcpyDeviceToHost, sl.stream));
+        if (corr_out) {
+            if (out_cast) {
+                const size_t es = hk::dtype_size(odt);
+                void* d_raw = base + o_raw_o;
+                HK_HIP(hk::launch_cast_out(odt, d_corr, stride, d_raw, stride, height, width, io->out_has_nodata,
+                                           io->out_nodata, sl.stream));
+                HK_HIP(hipMemcpy2DAsync(corr_out, (size_t)width * es, d_raw, stride * es, (size_t)width * es, height,
+                                        hipMemcpyDeviceToHost, sl.stream));
+            } else {
+                HK_HIP(hipMemcpy2DAsync(corr_out, wbytes, d_corr, stride * sizeof(float), wbytes, height,
+                                        hipMemcpyDeviceToHost, sl.stream));
+            }
+        }
         if (r2_fail_count)
             HK_HIP(hipMemcpyAsync(r2_fail_count, d_fail, sizeof(uint64_t), hipMemcpyDeviceToHost, sl.stream));
     }
@@ -342,23 +373,30 @@ int hk_ctx_sync(hk_ctx* ctx) {
 int hk_block_norm(hk_ctx* ctx, const hk_fit_desc* desc, const float* src, int64_t src_stride, const float* ref,
                   int64_t ref_stride, int32_t height, int32_t width, double norm_out[2]) {
     if (!norm_out) return fail(HK_ERR_ARG, "norm_out is NULL");
-    return run_host(ctx, desc, src, src_stride, ref, ref_stride, height, width, nullptr, nullptr, 0, nullptr, norm_out,
-                    nullptr, true);
+    return run_host(ctx, desc, nullptr, src, src_stride, ref, ref_stride, height, width, nullptr, nullptr, 0, nullptr,
+                    norm_out, nullptr, true);
 }
 
 int hk_fit(hk_ctx* ctx, const hk_fit_desc* desc, const float* src, int64_t src_stride, const float* ref,
            int64_t ref_stride, int32_t height, int32_t width, const double* norm_in, float* params_out,
            int32_t n_param_bands, double* norm_out, uint64_t* r2_fail_count) {
     if (!params_out) return fail(HK_ERR_ARG, "params_out is NULL");
-    return run_host(ctx, desc, src, src_stride, ref, ref_stride, height, width, norm_in, params_out, n_param_bands,
-                    nullptr, norm_out, r2_fail_count, false);
+    return run_host(ctx, desc, nullptr, src, src_stride, ref, ref_stride, height, width, norm_in, params_out,
+                    n_param_bands, nullptr, norm_out, r2_fail_count, false);
 }
 
 int hk_fit_apply(hk_ctx* ctx, const hk_fit_desc* desc, const float* src, int64_t src_stride, const float* ref,
                  int64_t ref_stride, int32_t height, int32_t width, const double* norm_in, float* params_out,
                  int32_t n_param_bands, float* corr_out, double* norm_out, uint64_t* r2_fail_count) {
     if (!corr_out) return fail(HK_ERR_ARG, "corr_out is NULL");
-    return run_host(ctx, desc, src, src_stride, ref, ref_stride, height, width, norm_in, params_out, n_param_bands,
+    return run_host(ctx, desc, nullptr, src, src_stride, ref, ref_stride, height, width, norm_in, params_out,
+                    n_param_bands, corr_out, norm_out, r2_fail_count, false);
+}
+
+int hk_fit_apply_io(hk_ctx* ctx, const hk_fit_desc* desc, const hk_io_desc* io, const void* src, int64_t src_stride,
+                    const void* ref, int64_t ref_stride, int32_t height, int32_t width, const double* norm_in,
+                    float* params_out, int32_t n_param_bands, void* corr_out, double* norm_out, uint64_t* r2_fail_count) {
+    return run_host(ctx, desc, io, src, src_stride, ref, ref_stride, height, width, norm_in, params_out, n_param_bands,
                     corr_out, norm_out, r2_fail_count, false);
 }
 

@@ -64,6 +64,13 @@ hipError_t launch_block_norm(const NormArgs& a, void* workspace, double* norm_ou
 hipError_t launch_synth_fill(float* src, float* ref, int n_bands, int height, int width, long long stride,
                              long long band_stride, unsigned long long seed, int nodata_variant, hipStream_t stream);
 
+// Typed IO (hk_convert.hip).  dtype codes = hk_dtype of include/homonim_hk.h: 0 f32, 1 u8, 2 u16, 3 i16, 4 u32, 5 i32, 6 f64.
+hipError_t launch_cast_in(int dtype, const void* in, long long in_stride, float* out, long long out_stride, int height,
+                          int width, hipStream_t stream);
+hipError_t launch_cast_out(int dtype, const float* in, long long in_stride, void* out, long long out_stride, int height,
+                           int width, int has_nodata, double nodata, hipStream_t stream);
+inline int dtype_size(int dtype) { const int sz[7] = {4, 1, 2, 2, 4, 4, 8}; return dtype >= 0 && dtype < 7 ? sz[dtype] : 0; }
+
 // returns 0 on pass; writes a diagnostic code otherwise
 hipError_t launch_selftest(int* result_dev, hipStream_t stream);
 

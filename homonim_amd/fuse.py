@@ -198,10 +198,12 @@ class RasterFuse:
         c0 = bp.src_out_block.col_off - bp.src_in_block.col_off
         return slice(r0, r0 + bp.src_out_block.height), slice(c0, c0 + bp.src_out_block.width)
 
-    def _process_block(self, bp: BlockPair, model: KernelModel, corr: np.ndarray, params: Optional[np.ndarray]):
-        """ read -> fused fit+apply on the GPU -> write (homonim/fuse.py:295-319) """
+    def _process_block(self, bp: BlockPair, model: KernelModel, corr: np.ndarray, params: Optional[np.ndarray],
+                       out_nodata: Optional[float]):
+        """ read -> fused fit+apply (+ output dtype conversion) on the GPU -> write (homonim/fuse.py:295-319) """
         src_ra, ref_ra = self._read(bp)
-        corr_ra, param_ra = model.fit_apply(src_ra, ref_ra, want_params=params is not None)
+        corr_ra, param_ra = model.fit_apply(src_ra, ref_ra, want_params=params is not None, out_dtype=corr.dtype.name,
+                                            out_nodata=out_nodata)
         crop = self._crop(bp)
         rs, cs = bp.src_out_block.toslices()
         corr[bp.band_i][rs, cs] = corr_ra.array[crop]
@@ -247,8 +249,11 @@ class RasterFuse:
 
         n_src = self._src.shape[0]
         nodata = out_profile['nodata']
-        fill = np.nan if nodata is None else nodata
-        corr = np.full((n_src, *self.shape), fill, dtype=np.float32)
+        out_dtype = np.dtype(out_profile['dtype'])
+        if out_dtype.name not in _hk.DTYPE_CODES:
+            raise ValueError(f"unsupported output dtype '{out_profile['dtype']}'")
+        fill = (np.nan if out_dtype.kind == 'f' else 0) if nodata is None else nodata
+        corr = np.full((n_src, *self.shape), fill, dtype=out_dtype)
         n_param = 3 if models[0]._emit_r2 else 2
         params = np.full((n_param * n_src, *self.shape), np.nan, dtype=np.float32) if want_params else None
 
@@ -257,12 +262,12 @@ class RasterFuse:
         try:
             if block_config['threads'] == 1 and len(models) == 1:
                 for bp in blocks:
-                    self._process_block(bp, models[0], corr, params)
+                    self._process_block(bp, models[0], corr, params, nodata)
             else:
                 workers = max(block_config['threads'], len(models))
                 with ThreadPoolExecutor(max_workers=workers) as ex:
                     futures = [
-                        ex.submit(self._process_block, bp, models[i % len(models)], corr, params)
+                        ex.submit(self._process_block, bp, models[i % len(models)], corr, params, nodata)
                         for i, bp in enumerate(blocks)
                     ]
                     for f in as_completed(futures):
@@ -271,8 +276,6 @@ class RasterFuse:
             for m in models:
                 m.context.close()
 
-        if out_profile['dtype'] != 'float32' or not (nodata is None or (isinstance(nodata, float) and math.isnan(nodata))):
-            corr = convert_dtype(corr, out_profile['dtype'], nodata)
         if isinstance(corr_filename, (str, os.PathLike)):
             np.save(corr_filename, corr)
         if want_params and isinstance(param_filename, (str, os.PathLike)):
@@ -282,8 +285,9 @@ class RasterFuse:
 
 def convert_dtype(array: np.ndarray, dtype: str, nodata: Optional[float]) -> np.ndarray:
     """
-    Corrected float32 -> output dtype as ``RasterArray._convert_array_dtype`` does it (homonim/raster_array.py:353-387):
-    round half-to-even and clip for integer types, NaN (the internal nodata) -> ``nodata``.
+    Host-side statement of ``RasterArray._convert_array_dtype`` (homonim/raster_array.py:353-387): round half-to-even and
+    clip for integer types, NaN (the internal nodata) -> ``nodata``.  ``RasterFuse.process`` does this conversion on the
+    device (hk_convert.hip); this helper documents the semantics and serves host-side callers.
     """
     invalid = np.isnan(array)
     out = array

@@ -136,22 +136,27 @@ class KernelModel:
         corr = self.context.apply(self._band(src_ra, 'src_ra'), param_ra.array)
         return RasterArray.from_profile(corr, param_ra.profile)
 
-    def fit_apply(self, src_ra: RasterArray, ref_ra: RasterArray,
-                  want_params: bool = False) -> Tuple[RasterArray, Optional[RasterArray]]:
+    def fit_apply(self, src_ra: RasterArray, ref_ra: RasterArray, want_params: bool = False,
+                  out_dtype: str = RasterArray.default_dtype,
+                  out_nodata: Optional[float] = RasterArray.default_nodata) -> Tuple[RasterArray, Optional[RasterArray]]:
         """
         ``apply(src_ra, fit(src_ra.copy(), ref_ra))`` in ONE pass over the data (window sums, solve, R2 test and
         correction fused in a single kernel; each input byte is read once).  Returns (corr_ra, param_ra | None).
+
+        ``out_dtype`` / ``out_nodata`` convert the corrected block on the device the way the reference converts it when
+        writing (raster_array.py:353-387); integer ``src_ra`` / ``ref_ra`` arrays are converted to float32 on the device.
         """
         if (ref_ra.transform != src_ra.transform) or (ref_ra.shape != src_ra.shape):
             raise ValueError("'ref_ra' and 'src_ra' must have the same CRS, transform and shape")
         count = 3 if self._emit_r2 else 2
         params, corr, _, n_fail = self.context.fit_apply(
             self._desc(src_ra, ref_ra), self._band(src_ra, 'src_ra'), self._band(ref_ra, 'ref_ra'), count,
-            want_params=want_params, want_corr=True
+            want_params=want_params, want_corr=True, out_dtype=out_dtype, out_nodata=out_nodata
         )
         self._check_inpaint(n_fail)
         profile = self._param_profile(src_ra, count)
-        corr_ra = RasterArray.from_profile(corr, profile)
+        corr_profile = dict(profile, nodata=out_nodata, dtype=str(out_dtype))
+        corr_ra = RasterArray.from_profile(corr, corr_profile)
         return corr_ra, (RasterArray.from_profile(params, profile) if want_params else None)
 
     def block_norm(self, src_ra: RasterArray, ref_ra: RasterArray) -> np.ndarray:

@@ -109,6 +109,25 @@ int hk_fit_apply(hk_ctx* ctx, const hk_fit_desc* desc, const float* src, int64_t
                  float* params_out /* nullable */, int32_t n_param_bands, float* corr_out, double* norm_out,
                  uint64_t* r2_fail_count);
 
+/* Typed rasters either side of the path: integer / float64 inputs are converted to float32 on the device exactly as
+ * RasterArray.from_rio_dataset reads them (homonim/raster_array.py:178-188), the corrected block is converted to the
+ * output dtype as RasterArray._convert_array_dtype does for to_rio_dataset (homonim/raster_array.py:353-387: round
+ * half-to-even, clip, masked pixels -> out_nodata).  PCIe then carries 1-2 B per pixel instead of 4. */
+typedef enum { HK_DTYPE_F32 = 0, HK_DTYPE_U8 = 1, HK_DTYPE_U16 = 2, HK_DTYPE_I16 = 3, HK_DTYPE_U32 = 4, HK_DTYPE_I32 = 5,
+               HK_DTYPE_F64 = 6 } hk_dtype;
+typedef struct {
+    int32_t src_dtype, ref_dtype;  /* hk_dtype of the src / ref host arrays */
+    int32_t out_dtype;             /* hk_dtype of corr_out */
+    int32_t out_has_nodata;        /* 0: masked pixels keep NaN (float outputs) / become 0 (integer outputs) */
+    double out_nodata;
+} hk_io_desc;
+/* hk_fit_apply with typed src / ref / corr_out (strides in ELEMENTS of the respective dtype); io == NULL means float32
+ * everywhere.  params_out stays float32. */
+int hk_fit_apply_io(hk_ctx* ctx, const hk_fit_desc* desc, const hk_io_desc* io, const void* src, int64_t src_stride,
+                    const void* ref, int64_t ref_stride, int32_t height, int32_t width, const double* norm_in,
+                    float* params_out /* nullable */, int32_t n_param_bands, void* corr_out /* nullable */,
+                    double* norm_out, uint64_t* r2_fail_count);
+
 /* Page-lock caller memory so the host-pointer entry points above become truly asynchronous: with pinned src/ref/output
  * arrays the H2D copy, the kernel and the D2H copy of different calls (different host threads, different pooled streams)
  * overlap; with pageable memory HIP stages every copy synchronously.  The reference has no counterpart (its blocks are

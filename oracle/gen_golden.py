@@ -318,9 +318,33 @@ def gen_block_goldens():
     print(f'block goldens: {len(table)} cases')
 
 
+def gen_convert_goldens(mods):
+    """ RasterArray._convert_array_dtype (raster_array.py:353-387) of the REFERENCE on a float32 block with NaN nodata. """
+    rio = sys.modules['rasterio']
+    RasterArray = mods['raster_array'].RasterArray
+    rng = np.random.default_rng(99)
+    a = rng.uniform(-40, 300, (24, 40)).astype(np.float32)
+    a[0, :8] = [-0.5, 0.5, 1.5, 2.5, 254.5, 255.5, -1e9, 1e9]
+    a[1, :8] = [65534.5, 65535.5, 70000, -32768.5, -32769, 32767.5, 3e9, -3e9]
+    a[2, :6] = [4294967295., 4294967040., 2147483520., -2147483648., 16777217., 0.49999997]
+    a[rng.random(a.shape) < 0.1] = np.nan
+    out = dict(input=a)
+    crs, tf = sys.modules['rasterio.crs'].CRS(), rio.Affine(1., 0., 0., 0., -1., 0.)
+    for dtype, nodata in (('uint8', 0), ('uint8', 255), ('uint16', 0), ('int16', -9999), ('int32', -2147483648),
+                          ('uint32', 0), ('float32', -9999.0), ('float32', float('nan')), ('float64', -1.5)):
+        ra = RasterArray(a.copy(), crs, tf, nodata=float('nan'))
+        with np.errstate(all='ignore'):
+            res = ra._convert_array_dtype(dtype, nodata=nodata)
+        key = f"{dtype}_{'nan' if (isinstance(nodata, float) and np.isnan(nodata)) else nodata}"
+        out[key] = res
+    np.savez_compressed(os.path.join(GOLDEN_DIR, 'convert_dtype.npz'), **out)
+    print('convert goldens:', [k for k in out if k != 'input'])
+
+
 def main():
     mods = load_reference()
     gen_block_goldens()
+    gen_convert_goldens(mods)
     os.makedirs(GOLDEN_DIR, exist_ok=True)
     h, w = 36, 52
     manifest = dict(

@@ -128,3 +128,19 @@ def test_rank_sharding_gloo_world2(tmp_path):
     out = json.loads(line)
     assert out['world'] == 2 and out['total'] == 3000 * 2000 * 3 and out['slowest'] == 2.0
     assert out['n_blocks'] == out['all_blocks']
+
+
+def test_convert_dtype_matches_reference_goldens():
+    """ host-side statement of RasterArray._convert_array_dtype vs outputs of the reference's own code
+    (tests/golden/convert_dtype.npz, oracle/gen_golden.py). """
+    g = np.load(os.path.join(GOLDEN_DIR, 'convert_dtype.npz'))
+    a = g['input']
+    for key in g.files:
+        if key == 'input':
+            continue
+        dtype, nd = key.rsplit('_', 1)
+        nodata = float('nan') if nd == 'nan' else float(nd)
+        out = fuse.convert_dtype(a.copy(), dtype, nodata)
+        exp = g[key]
+        assert out.dtype == exp.dtype, key
+        np.testing.assert_array_equal(out, exp, err_msg=key)

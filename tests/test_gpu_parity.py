@@ -496,3 +496,69 @@ def test_lds_ring_and_reload_modes_agree(ctx, model, kernel_shape, find_r2, thre
         warnings.simplefilter('ignore')
         exp, _ = onp.fit(model, src, nodata, ref, nodata, kernel_shape, find_r2, thresh, norm_model=norm_in)
     assert_close_ulp(out['0'][0], exp, 'params')
+
+
+# -- typed rasters either side of the path (raster_array.py:178-188 read, :353-387 write) -------------------------------
+@pytest.mark.parametrize('dtype', ['uint8', 'uint16', 'int16', 'int32', 'uint32', 'float64'])
+def test_integer_inputs_equal_float32_inputs(ctx, dtype):
+    """ Integer / float64 rasters are converted to float32 on the device exactly as rasterio does on read. """
+    rng = np.random.default_rng(31)
+    hi = {'uint8': 255, 'uint16': 4000, 'int16': 3000, 'int32': 100000, 'uint32': 100000, 'float64': 1000}[dtype]
+    src = rng.integers(1, hi, (300, 517)).astype(dtype)
+    ref = (0.8 * src.astype(np.float64) + 20 + rng.normal(0, 3, src.shape))
+    ref = np.round(ref).clip(1, None).astype(dtype) if dtype != 'float64' else ref
+    if dtype != 'float64':
+        src[:3], src[:, -2:] = 0, 0   # nodata 0 frame
+    src_nd = 0 if dtype != 'float64' else None
+    for model, k in (('gain-blk-offset', (5, 5)), ('gain-offset', (5, 5))):
+        desc = _hk.make_desc(model, k, True, None, src_nd, None)
+        p_t, c_t, n_t, _ = ctx.fit_apply(desc, src, ref, 3, True, True)
+        p_f, c_f, n_f, _ = ctx.fit_apply(desc, src.astype(np.float32), ref.astype(np.float32), 3, True, True)
+        assert_same_f32(p_t, p_f, f'{model} params typed vs float32')
+        assert_same_f32(c_t, c_f, f'{model} corrected typed vs float32')
+        np.testing.assert_array_equal(n_t, n_f)
+    # strided (windowed) integer views are taken as they are
+    big = np.zeros((400, 700), dtype)
+    big[50:350, 100:617] = src
+    desc = _hk.make_desc('gain-offset', (5, 5), False, None, src_nd, None)
+    _, c_v, _, _ = ctx.fit_apply(desc, big[50:350, 100:617], ref, 2, False, True)
+    _, c_c, _, _ = ctx.fit_apply(desc, src, ref, 2, False, True)
+    assert_same_f32(c_v, c_c, 'strided view vs contiguous')
+
+
+def test_output_dtype_conversion_matches_reference(ctx):
+    """ The corrected block converted on the device == the reference's own RasterArray._convert_array_dtype
+    (tests/golden/convert_dtype.npz).  gain 1x1 with ref == src reproduces the input exactly (gain 1, offset 0). """
+    import os
+    from conftest import GOLDEN_DIR
+    g = np.load(os.path.join(GOLDEN_DIR, 'convert_dtype.npz'))
+    a = g['input']
+    desc = _hk.make_desc('gain', (1, 1), False, None, np.nan, np.nan)
+    _, ident, _, _ = ctx.fit_apply(desc, a, a.copy(), 2, False, True)
+    assert_same_f32(ident, a, 'identity correction')
+    for key in g.files:
+        if key == 'input':
+            continue
+        dtype, nd = key.rsplit('_', 1)
+        nodata = float('nan') if nd == 'nan' else float(nd)
+        _, out, _, _ = ctx.fit_apply(desc, a, a.copy(), 2, False, True, out_dtype=dtype, out_nodata=nodata)
+        exp = g[key]
+        assert out.dtype == exp.dtype, key
+        np.testing.assert_array_equal(out, exp, err_msg=key)
+
+
+def test_raster_fuse_byte_in_byte_out(ctx):
+    """ uint8 rasters in, uint8 corrected raster out -- all conversions on the device; equals the float32 route. """
+    from homonim_amd.fuse import RasterFuse, convert_dtype
+    rng = np.random.default_rng(6)
+    src = rng.integers(1, 255, (2, 500, 640)).astype(np.uint8)
+    ref = np.clip(np.round(0.8 * src + 20 + rng.normal(0, 3, src.shape)), 0, 255).astype(np.uint8)
+    src[:, :4], src[:, :, -4:] = 0, 0
+    kw = dict(model='gain-blk-offset', kernel_shape=(5, 5), block_config=dict(threads=2, max_block_mem=0.5))
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        c8, _ = RasterFuse(src, ref, src_nodata=0, ref_nodata=None).process(out_profile=dict(dtype='uint8', nodata=0), **kw)
+        cf, _ = RasterFuse(src.astype(np.float32), ref.astype(np.float32), src_nodata=0, ref_nodata=None).process(**kw)
+    assert c8.dtype == np.uint8
+    np.testing.assert_array_equal(c8, convert_dtype(cf, 'uint8', 0))

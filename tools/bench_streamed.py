@@ -29,17 +29,23 @@ def main():
     p.add_argument('--model', default='gain-offset')
     p.add_argument('--kernel', type=int, default=5)
     p.add_argument('--pageable', action='store_true', help='plain numpy arrays instead of pinned ones')
+    p.add_argument('--dtype', default='float32', help='host raster dtype in and out (float32 | uint8 | uint16 | int16)')
     args = p.parse_args()
 
     ctx = _hk.Context(int(os.environ.get('LOCAL_RANK', '0')), n_streams=args.streams)
     n = args.size
-    alloc = (lambda shape: np.empty(shape, np.float32)) if args.pageable else ctx.pinned_empty
+    dt = np.dtype(args.dtype)
+    alloc = (lambda shape: np.empty(shape, dt)) if args.pageable else (lambda shape: ctx.pinned_empty(shape, dt))
     rng = np.random.default_rng(0)
     srcs, refs = [], []
     for i in range(args.distinct):
         s, r = alloc((n, n)), alloc((n, n))
-        s[:] = rng.uniform(0.05, 1.0, (n, n)).astype(np.float32)
-        r[:] = (1.2 * s + 0.05 + rng.normal(0, 0.01, (n, n))).astype(np.float32)
+        if dt.kind == 'f':
+            s[:] = rng.uniform(0.05, 1.0, (n, n)).astype(dt)
+            r[:] = (1.2 * s + 0.05 + rng.normal(0, 0.01, (n, n))).astype(dt)
+        else:
+            s[:] = rng.integers(10, 200, (n, n)).astype(dt)
+            r[:] = np.clip(np.round(1.2 * s + 5 + rng.normal(0, 2, (n, n))), 0, 255).astype(dt)
         srcs.append(s)
         refs.append(r)
     outs = [alloc((n, n)) for _ in range(args.threads)]
@@ -53,7 +59,7 @@ def main():
         for w in work[tid::args.threads]:
             i = w % args.distinct
             _, _, _, f = ctx.fit_apply(desc, srcs[i], refs[i], n_param, want_params=False, want_corr=True,
-                                       out_corr=outs[tid])
+                                       out_corr=outs[tid], out_dtype=dt.name, out_nodata=None if dt.kind == 'f' else 0)
             fails += f
         return fails
 
@@ -61,13 +67,14 @@ def main():
         list(ex.map(worker, range(args.threads)))  # warm-up: grows the per-stream device slabs
         t0 = time.perf_counter()
         fails = sum(ex.map(worker, range(args.threads)))
-        dt = time.perf_counter() - t0
+        dt_s = time.perf_counter() - t0
     px = len(work) * n * n
     print(json.dumps(dict(
-        metric='Mpixels*bands/s fit+apply end-to-end incl. PCIe (host-resident tiles)', value=round(px / dt / 1e6, 1),
-        seconds=round(dt, 3), tiles=args.tiles, bands=args.bands, tile=n, threads=args.threads, streams=args.streams,
+        metric='Mpixels*bands/s fit+apply end-to-end incl. PCIe (host-resident tiles)', value=round(px / dt_s / 1e6, 1),
+        seconds=round(dt_s, 3), tiles=args.tiles, bands=args.bands, tile=n, threads=args.threads, streams=args.streams,
         pinned=not args.pageable, model=args.model, kernel=args.kernel, r2_mask_failures=int(fails),
-        pcie_gbps_in=round(px * 8 / dt / 1e9, 1), pcie_gbps_out=round(px * 4 / dt / 1e9, 1))))
+        dtype=dt.name, pcie_gbps_in=round(px * 2 * dt.itemsize / dt_s / 1e9, 1),
+        pcie_gbps_out=round(px * dt.itemsize / dt_s / 1e9, 1))))
     ctx.close()
 
 
