@@ -67,6 +67,8 @@ SIGNATURES = {
     'hk_apply': (C.c_int, [C.c_void_p, _f32p, C.c_int64, _f32p, C.c_int32, C.c_int32, _f32p]),
     'hk_fit_apply': (C.c_int, [C.c_void_p, _P(FitDesc), _f32p, C.c_int64, _f32p, C.c_int64, C.c_int32, C.c_int32,
                                _f64p, _f32p, C.c_int32, _f32p, _f64p, _u64p]),
+    'hk_partial_mask': (C.c_int, [C.c_void_p, _f32p, C.c_int64, C.c_int32, C.c_float, _f32p, C.c_int32, _f32p, C.c_int64,
+                                  C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f32p, _f32p, _P(C.c_uint8)]),
     'hk_fit_apply_io': (C.c_int, [C.c_void_p, _P(FitDesc), _P(IoDesc), C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                   C.c_int32, C.c_int32, _f64p, _f32p, C.c_int32, C.c_void_p, _f64p, _u64p]),
     'hk_host_alloc': (C.c_int, [C.c_void_p, C.c_size_t, _P(C.c_void_p)]),
@@ -267,6 +269,27 @@ class Context:
         _check(self._lib.hk_apply(self._h, _ptr(src), src.strides[0] // 4, _ptr(params), src.shape[0], src.shape[1],
                                   _ptr(out)))
         return out
+
+    def partial_mask(self, in_arr: np.ndarray, in_nodata, params: np.ndarray, kernel_shape, src: Optional[np.ndarray] = None,
+                     want_params: bool = False, want_corr: bool = False, want_mask: bool = False):
+        """ mask_partial on a shared grid (hk_partial_mask) -> (masked params | None, corrected | None, mask | None). """
+        in_arr = _as_f32_2d(in_arr, 'in')
+        params = np.ascontiguousarray(params, dtype=np.float32)
+        if params.ndim != 3 or params.shape[-2:] != in_arr.shape:
+            raise ValueError("'param_ra' and 'src_ra' must have the same CRS, transform and shape")
+        h, w = in_arr.shape
+        if src is not None:
+            src = _as_f32_2d(src, 'src')
+        mode, val = nodata_code(in_nodata)
+        p_out = np.empty_like(params) if want_params else None
+        c_out = np.empty((h, w), np.float32) if want_corr else None
+        m_out = np.empty((h, w), np.uint8) if want_mask else None
+        _check(self._lib.hk_partial_mask(
+            self._h, _ptr(in_arr), in_arr.strides[0] // 4, mode, val, _ptr(params), params.shape[0],
+            _ptr(src) if src is not None else None, (src.strides[0] // 4) if src is not None else 0, h, w,
+            int(kernel_shape[0]), int(kernel_shape[1]), _ptr(p_out) if want_params else None,
+            _ptr(c_out) if want_corr else None, m_out.ctypes.data_as(_P(C.c_uint8)) if want_mask else None))
+        return p_out, c_out, m_out
 
     # -- pinned host memory (async H2D / D2H) ----------------------------------------------------------------------------
     def pinned_empty(self, shape, dtype=np.float32) -> np.ndarray:

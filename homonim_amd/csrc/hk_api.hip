@@ -429,6 +429,55 @@ int hk_apply(hk_ctx* ctx, const float* src, int64_t src_stride, const float* par
     return HK_OK;
 }
 
+int hk_partial_mask(hk_ctx* ctx, const float* in, int64_t in_stride, int32_t in_nodata_mode, float in_nodata,
+                    const float* params, int32_t n_param_bands, const float* src, int64_t src_stride, int32_t height,
+                    int32_t width, int32_t kh, int32_t kw, float* params_out, float* corr_out, uint8_t* mask_out) {
+    if (!ctx) return fail(HK_ERR_ARG, "ctx is NULL");
+    if (!in || !params) return fail(HK_ERR_ARG, "NULL pointer argument");
+    if (height < 1 || width < 1) return fail(HK_ERR_ARG, "empty raster %d x %d", height, width);
+    if (n_param_bands < 2 || n_param_bands > 3) return fail(HK_ERR_ARG, "params must have 2 or 3 bands");
+    if (kh < 1 || kw < 1 || !(kh & 1) || !(kw & 1)) return fail(HK_ERR_ARG, "`kernel_shape` must be odd in both dimensions.");
+    if ((kh + 2) * (kw + 2) > 65535) return fail(HK_ERR_UNSUPPORTED, "kernel too large for mask_partial");
+    if (corr_out && !src) return fail(HK_ERR_ARG, "corr_out needs src");
+    if (in_stride < width || (src && src_stride < width)) return fail(HK_ERR_ARG, "row stride smaller than width");
+    HK_HIP(hipSetDevice(ctx->device));
+    const int64_t stride = (width + ROW_ALIGN - 1) / ROW_ALIGN * ROW_ALIGN;
+    const size_t plane = (size_t)stride * height * sizeof(float);
+    size_t total = 0;
+    auto take = [&](size_t bytes) { const size_t off = total; total += (bytes + 255) / 256 * 256; return off; };
+    const size_t o_in = take(plane), o_par = take(plane * n_param_bands), o_src = src ? take(plane) : 0;
+    const size_t o_pout = params_out ? take(plane * n_param_bands) : 0, o_corr = corr_out ? take(plane) : 0;
+    const size_t o_mask = mask_out ? take((size_t)stride * height) : 0, o_cnt = take((size_t)stride * height * 2);
+    SlotLease lease(ctx);
+    Slot& sl = lease.slot();
+    int rc = ensure_dev(sl, total);
+    if (rc) return rc;
+    char* base = static_cast<char*>(sl.dev);
+    float* d_in = reinterpret_cast<float*>(base + o_in);
+    float* d_par = reinterpret_cast<float*>(base + o_par);
+    float* d_src = src ? reinterpret_cast<float*>(base + o_src) : nullptr;
+    float* d_pout = params_out ? reinterpret_cast<float*>(base + o_pout) : nullptr;
+    float* d_corr = corr_out ? reinterpret_cast<float*>(base + o_corr) : nullptr;
+    unsigned char* d_mask = mask_out ? reinterpret_cast<unsigned char*>(base + o_mask) : nullptr;
+    const size_t wb = (size_t)width * 4, sb = (size_t)stride * 4;
+    HK_HIP(hipMemcpy2DAsync(d_in, sb, in, in_stride * 4, wb, height, hipMemcpyHostToDevice, sl.stream));
+    for (int b = 0; b < n_param_bands; ++b)
+        HK_HIP(hipMemcpy2DAsync(d_par + (size_t)b * stride * height, sb, params + (size_t)b * height * width, wb, wb, height,
+                                hipMemcpyHostToDevice, sl.stream));
+    if (src) HK_HIP(hipMemcpy2DAsync(d_src, sb, src, src_stride * 4, wb, height, hipMemcpyHostToDevice, sl.stream));
+    HK_HIP(hk::launch_partial_mask(d_in, in_nodata_mode, in_nodata, d_par, n_param_bands, stride * height, d_src, height,
+                                   width, stride, kh, kw, reinterpret_cast<unsigned short*>(base + o_cnt), d_pout, d_corr,
+                                   d_mask, sl.stream));
+    if (params_out)
+        for (int b = 0; b < n_param_bands; ++b)
+            HK_HIP(hipMemcpy2DAsync(params_out + (size_t)b * height * width, wb, d_pout + (size_t)b * stride * height, sb,
+                                    wb, height, hipMemcpyDeviceToHost, sl.stream));
+    if (corr_out) HK_HIP(hipMemcpy2DAsync(corr_out, wb, d_corr, sb, wb, height, hipMemcpyDeviceToHost, sl.stream));
+    if (mask_out) HK_HIP(hipMemcpy2DAsync(mask_out, width, d_mask, stride, width, height, hipMemcpyDeviceToHost, sl.stream));
+    HK_HIP(hipStreamSynchronize(sl.stream));
+    return HK_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 int hk_host_alloc(hk_ctx* ctx, size_t bytes, void** hptr) {
     if (!ctx || !hptr) return fail(HK_ERR_ARG, "NULL argument");

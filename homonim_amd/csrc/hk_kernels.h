@@ -71,6 +71,13 @@ hipError_t launch_cast_out(int dtype, const float* in, long long in_stride, void
                            int width, int has_nodata, double nodata, hipStream_t stream);
 inline int dtype_size(int dtype) { const int sz[7] = {4, 1, 2, 2, 4, 4, 8}; return dtype >= 0 && dtype < 7 ? sz[dtype] : 0; }
 
+// mask_partial on a shared grid (hk_mask.hip): full-coverage mask from valid(in) & params, eroded by (kh+2) x (kw+2);
+// writes masked parameters and/or the corrected block and/or the uint8 mask.  rowcnt_ws: height x stride uint16.
+hipError_t launch_partial_mask(const float* in, int nd_mode, float nodata, const float* params, int n_bands,
+                               long long band_stride, const float* src, int height, int width, long long stride, int kh,
+                               int kw, unsigned short* rowcnt_ws, float* params_out, float* corr_out,
+                               unsigned char* mask_out, hipStream_t stream);
+
 // returns 0 on pass; writes a diagnostic code otherwise
 hipError_t launch_selftest(int* result_dev, hipStream_t stream);
 

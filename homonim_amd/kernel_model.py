@@ -14,7 +14,8 @@ Differences a caller can observe (all documented in DESIGN.md):
 * gain-offset with ``r2_inpaint_thresh`` set: the kernel evaluates the r2 mask (kernel_model.py:363); when no valid
   pixel fails it the reference's GDAL ``fillnodata`` branch is the identity and results are identical; when some
   fail, in-painting is required and currently raises ``NotImplementedError``.
-* ``RefSpaceModel`` / ``SrcSpaceModel`` accept same-grid pairs only (GDAL re-projection is section 8f row 1).
+* ``RefSpaceModel`` / ``SrcSpaceModel`` accept same-grid pairs only (GDAL re-projection is section 8f row 1);
+  ``mask_partial`` (kernel_model.py:375-409) is evaluated on the device for that case.
 """
 from typing import Dict, Optional, Tuple
 
@@ -190,7 +191,12 @@ class RefSpaceModel(KernelModel):
         if not _same_grid(src_ra, param_ra):
             raise NotImplementedError(_REPROJECT_MSG)
         if self._mask_partial:
-            raise NotImplementedError('mask_partial (kernel_model.py:375-409) is not built yet (SURVEY.md 8f row 3)')
+            # full-coverage mask of the source mask & parameters, eroded by (kh+2) x (kw+2), then apply (:493-503)
+            _, corr, _ = self.context.partial_mask(
+                self._band(src_ra, 'src_ra'), src_ra.nodata, param_ra.array[:2], self._kernel_shape,
+                src=self._band(src_ra, 'src_ra'), want_corr=True
+            )
+            return RasterArray.from_profile(corr, param_ra.profile)
         # the reference keeps only gain & offset and re-masks them with the source mask (:487,:500); on a shared grid
         # the parameters are already nodata wherever the source is.
         return KernelModel.apply(self, src_ra, param_ra)
@@ -202,6 +208,11 @@ class SrcSpaceModel(KernelModel):
     def fit(self, src_ra: RasterArray, ref_ra: RasterArray) -> RasterArray:
         if not _same_grid(src_ra, ref_ra):
             raise NotImplementedError(_REPROJECT_MSG)
+        param_ra = KernelModel.fit(self, src_ra, ref_ra)
         if self._mask_partial:
-            raise NotImplementedError('mask_partial (kernel_model.py:375-409) is not built yet (SURVEY.md 8f row 3)')
-        return KernelModel.fit(self, src_ra, ref_ra)
+            # full-coverage mask of the reference mask & gain/offset, eroded by (kh+2) x (kw+2), on all bands (:526-531)
+            masked, _, _ = self.context.partial_mask(
+                self._band(ref_ra, 'ref_ra'), ref_ra.nodata, param_ra.array, self._kernel_shape, want_params=True
+            )
+            param_ra = RasterArray.from_profile(masked, param_ra.profile)
+        return param_ra

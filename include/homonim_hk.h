@@ -109,6 +109,17 @@ int hk_fit_apply(hk_ctx* ctx, const hk_fit_desc* desc, const float* src, int64_t
                  float* params_out /* nullable */, int32_t n_param_bands, float* corr_out, double* norm_out,
                  uint64_t* r2_fail_count);
 
+/* `mask_partial` on a shared grid: KernelModel._full_coverage_mask (homonim/kernel_model.py:375-409) -- the mask of
+ * pixels that are valid in `in` (nodata as given) and have parameters, eroded by a (kh+2) x (kw+2) rectangle with a
+ * zero border -- followed by what the reference does with it:
+ *   RefSpaceModel.apply (:493-503): in = the source block, corr_out = gain * src + offset with parameters outside the
+ *                                   mask set to NaN (pass src = in);
+ *   SrcSpaceModel.fit   (:526-531): in = the reference block, params_out = all n_param_bands masked.
+ * params: n_param_bands x H x W float32 (band 0 gain, 1 offset); params_out / corr_out / mask_out (uint8) nullable. */
+int hk_partial_mask(hk_ctx* ctx, const float* in, int64_t in_stride, int32_t in_nodata_mode, float in_nodata,
+                    const float* params, int32_t n_param_bands, const float* src, int64_t src_stride, int32_t height,
+                    int32_t width, int32_t kh, int32_t kw, float* params_out, float* corr_out, uint8_t* mask_out);
+
 /* Typed rasters either side of the path: integer / float64 inputs are converted to float32 on the device exactly as
  * RasterArray.from_rio_dataset reads them (homonim/raster_array.py:178-188), the corrected block is converted to the
  * output dtype as RasterArray._convert_array_dtype does for to_rio_dataset (homonim/raster_array.py:353-387: round

@@ -154,7 +154,22 @@ def _make_rasterio():
         'windows', Window=Window, WindowMethodsMixin=type('WindowMethodsMixin', (), {}),
         transform=lambda window, transform: transform
     )
-    _sub('warp', reproject=None, Resampling=Resampling)
+    def reproject(source, destination=None, src_crs=None, src_transform=None, src_nodata=None, dst_crs=None,
+                  dst_transform=None, dst_nodata=None, num_threads=1, resampling=None, **kw):
+        # GDAL warp stand-in for IDENTICAL grids only: average / nearest re-sampling onto the same grid is the identity
+        # (source nodata -> destination nodata).  Anything else is outside what these goldens may depend on.
+        assert dst_transform is None or tuple(dst_transform) == tuple(src_transform), 'stand-in reproject: grids differ'
+        assert destination.shape[-2:] == source.shape[-2:], 'stand-in reproject: shapes differ'
+        assert resampling in (Resampling.average, Resampling.nearest), resampling
+        src = np.asarray(source)
+        out = src.astype(destination.dtype)
+        if src_nodata is not None and dst_nodata is not None:
+            bad = np.isnan(src) if (isinstance(src_nodata, float) and np.isnan(src_nodata)) else (src == src_nodata)
+            out[bad] = dst_nodata
+        destination[...] = out
+        return destination, src_transform
+
+    _sub('warp', reproject=reproject, Resampling=Resampling)
     _sub('errors', NotGeoreferencedWarning=type('NotGeoreferencedWarning', (UserWarning, ), {}))
     _sub('vrt', WarpedVRT=_Placeholder)
     _sub('io', DatasetWriter=_Placeholder)
@@ -341,9 +356,43 @@ def gen_convert_goldens(mods):
     print('convert goldens:', [k for k in out if k != 'input'])
 
 
+def gen_mask_partial_goldens(mods):
+    """ RefSpaceModel.apply / SrcSpaceModel.fit with mask_partial=True on a SHARED grid (kernel_model.py:375-409,
+    484-503, 516-535), run through the reference's own classes. """
+    import warnings
+    km, ra_mod, rio = mods['kernel_model'], mods['raster_array'], sys.modules['rasterio']
+    # re-bind the freshly installed stand-in (raster_array imported `reproject` by name)
+    ra_mod.reproject = sys.modules['rasterio.warp'].reproject
+    RasterArray = ra_mod.RasterArray
+    crs, tf = sys.modules['rasterio.crs'].CRS(), rio.Affine(1., 0., 0., 0., -1., 0.)
+    src, snd, ref, rnd = make_inputs(40, 56, 3, 'nan_frame_holes')
+    out = dict(src=src, ref=ref)
+    cases = []
+    for model, k in (('gain-blk-offset', (1, 1)), ('gain-blk-offset', (3, 3)), ('gain-blk-offset', (3, 5)),
+                     ('gain-blk-offset', (5, 5)), ('gain-offset', (5, 5)), ('gain', (7, 3))):
+        for space in ('ref', 'src'):
+            cls = km.RefSpaceModel if space == 'ref' else km.SrcSpaceModel
+            with warnings.catch_warnings(), np.errstate(all='ignore'):
+                warnings.simplefilter('ignore')
+                m = cls(model, k, find_r2=True, mask_partial=True, r2_inpaint_thresh=None)
+                src_ra = RasterArray(src.copy(), crs, tf, nodata=snd)
+                ref_ra = RasterArray(ref.copy(), crs, tf, nodata=rnd)
+                param_ra = m.fit(src_ra, ref_ra)
+                corr_ra = m.apply(RasterArray(src.copy(), crs, tf, nodata=snd), param_ra)
+            name = f'{space}_{model}_{k[0]}x{k[1]}'
+            out[name + '_params'] = param_ra.array
+            out[name + '_corr'] = corr_ra.array
+            cases.append(dict(name=name, space=space, model=model, kernel_shape=list(k)))
+    np.savez_compressed(os.path.join(GOLDEN_DIR, 'mask_partial.npz'), **out)
+    with open(os.path.join(GOLDEN_DIR, 'mask_partial.json'), 'w') as f:
+        json.dump(cases, f)
+    print(f'mask_partial goldens: {len(cases)} cases')
+
+
 def main():
     mods = load_reference()
     gen_block_goldens()
+    gen_mask_partial_goldens(mods)
     gen_convert_goldens(mods)
     os.makedirs(GOLDEN_DIR, exist_ok=True)
     h, w = 36, 52

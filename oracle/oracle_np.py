@@ -246,6 +246,17 @@ def fit_gain_offset(
     return param, n_fail
 
 
+def full_coverage_mask(in_mask: np.ndarray, params: np.ndarray, kernel_shape) -> np.ndarray:
+    """
+    kernel_model.py:375-409 on a shared grid (the two re-projections are identities there): in_mask & param mask
+    (any of the gain / offset bands not nodata), eroded by a (kh+2) x (kw+2) rectangle with a zero border.
+    """
+    mask = in_mask.astype(bool) & np.any(~np.isnan(params[:2]), axis=0)  # :399-401
+    kh, kw = int(kernel_shape[0]) + 2, int(kernel_shape[1]) + 2          # :407
+    cnt = box_sum(mask.astype(F32), (kh, kw))                             # erosion by a full rectangle == full count
+    return cnt == kh * kw
+
+
 def apply(src, param) -> np.ndarray:
     """ kernel_model.py:461 -- two float32 roundings, no FMA. """
     with np.errstate(all='ignore'):

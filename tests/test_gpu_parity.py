@@ -562,3 +562,54 @@ def test_raster_fuse_byte_in_byte_out(ctx):
         cf, _ = RasterFuse(src.astype(np.float32), ref.astype(np.float32), src_nodata=0, ref_nodata=None).process(**kw)
     assert c8.dtype == np.uint8
     np.testing.assert_array_equal(c8, convert_dtype(cf, 'uint8', 0))
+
+
+# -- mask_partial on a shared grid (kernel_model.py:375-409) ------------------------------------------------------------
+def _mask_partial_cases():
+    import json, os
+    from conftest import GOLDEN_DIR
+    with open(os.path.join(GOLDEN_DIR, 'mask_partial.json')) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize('case', _mask_partial_cases(), ids=lambda c: c['name'])
+def test_mask_partial_matches_reference(ctx, case):
+    """ RefSpaceModel.apply / SrcSpaceModel.fit with mask_partial=True vs outputs of the reference's own classes. """
+    import os, warnings
+    from conftest import GOLDEN_DIR
+    g = np.load(os.path.join(GOLDEN_DIR, 'mask_partial.npz'))
+    src, ref = g['src'], g['ref']
+    cls = RefSpaceModel if case['space'] == 'ref' else SrcSpaceModel
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        km = cls(case['model'], tuple(case['kernel_shape']), find_r2=True, mask_partial=True, r2_inpaint_thresh=None)
+    param_ra = km.fit(_ra(src.copy(), np.nan), _ra(ref.copy(), np.nan))
+    corr_ra = km.apply(_ra(src.copy(), np.nan), param_ra)
+    if case['model'] == 'gain-blk-offset':  # block statistics: float64 on the GPU vs numpy float32 pairwise
+        exp_p, exp_c = g[case['name'] + '_params'], g[case['name'] + '_corr']
+        assert (np.isnan(param_ra.array) == np.isnan(exp_p)).all() and (np.isnan(corr_ra.array) == np.isnan(exp_c)).all()
+        ok = ~np.isnan(exp_c)
+        assert np.max(np.abs(corr_ra.array[ok] - exp_c[ok]) / np.maximum(np.abs(exp_c[ok]), 1e-6)) < 1e-5
+    else:
+        assert_close_ulp(param_ra.array, g[case['name'] + '_params'], 'params', max_frac=1.0)
+        assert_close_ulp(corr_ra.array, g[case['name'] + '_corr'], 'corrected', max_frac=1.0)
+
+
+@pytest.mark.parametrize('kernel_shape', [(1, 1), (3, 3), (3, 5), (5, 5)])
+def test_mask_partial_erosion_properties(ctx, kernel_shape):
+    """ reference tests/test_kernel_model.py:206-273: the output mask is the source mask eroded by (k + 2). """
+    a = np.array(range(1, 201), dtype='float32').reshape(20, 10)
+    a[:, [0, -1]] = np.nan
+    a[[0, -1], :] = np.nan
+    src = np.kron(a, np.ones((2, 2), np.float32)).astype(np.float32)
+    km = RefSpaceModel(Model.gain_blk_offset, kernel_shape, mask_partial=True)
+    ones = _ra(np.ones((2, *src.shape), np.float32), np.nan)
+    ones.mask = ~np.isnan(src)
+    out_ra = km.apply(_ra(src, np.nan), ones)
+    src_mask = ~np.isnan(src)
+    assert src_mask.sum() > out_ra.mask.sum() and src_mask[out_ra.mask].all()
+    exp = onp.full_coverage_mask(src_mask, ones.array, kernel_shape)
+    assert (exp == out_ra.mask).all()
+    assert out_ra.array[out_ra.mask] == pytest.approx(src[out_ra.mask] + 1, abs=1e-2)
+    _, _, m = ctx.partial_mask(src, np.nan, ones.array, kernel_shape, want_mask=True)
+    assert (m.astype(bool) == exp).all()

@@ -81,3 +81,32 @@ def test_reference_param_tif():
         for pi, pname in enumerate(('gain', 'offset', 'r2')):
             assert_same_f32(params[pi], g[pi * 3 + band_i], f'{pname} (file band {pi * 3 + band_i + 1})')
     assert params[0, 16, 4] == np.float32(1.0000079) and params[0, 16, 4] != 1  # the deviation is real
+
+
+def _mask_partial_cases():
+    import json
+    with open(os.path.join(GOLDEN_DIR, 'mask_partial.json')) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize('case', _mask_partial_cases(), ids=lambda c: c['name'])
+def test_oracle_full_coverage_mask_matches_reference(case):
+    """ mask_partial on a shared grid: oracle restatement of _full_coverage_mask vs the reference's own
+    RefSpaceModel.apply / SrcSpaceModel.fit outputs (tests/golden/mask_partial.npz). """
+    g = np.load(os.path.join(GOLDEN_DIR, 'mask_partial.npz'))
+    src, ref = g['src'], g['ref']
+    k = tuple(case['kernel_shape'])
+    norm = onp.fit_block_norm(src, np.nan, ref, np.nan) if case['model'] == 'gain-blk-offset' else None
+    params, _ = onp.fit(case['model'], src, np.nan, ref, np.nan, k, True, None, norm_model=norm)
+    if case['space'] == 'ref':
+        # RefSpaceModel: fit unmasked, apply with parameters masked by the eroded source-mask & param-mask
+        assert_same_f32(params, g[case['name'] + '_params'], 'params')
+        cover = onp.full_coverage_mask(~np.isnan(src), params, k)
+        masked = np.where(cover, params[:2], np.float32(np.nan))
+        assert_same_f32(onp.apply(src, masked), g[case['name'] + '_corr'], 'corrected')
+    else:
+        # SrcSpaceModel: all parameter bands masked by the eroded reference-mask & param-mask at fit time
+        cover = onp.full_coverage_mask(~np.isnan(ref), params, k)
+        masked = np.where(cover, params, np.float32(np.nan))
+        assert_same_f32(masked, g[case['name'] + '_params'], 'params')
+        assert_same_f32(onp.apply(src, masked), g[case['name'] + '_corr'], 'corrected')
