@@ -386,6 +386,19 @@ def default_context() -> Context:
     return _default_ctx
 
 
+_ctx_cache = {}
+
+
+def get_context(device: int, n_streams: int = 4) -> Context:
+    """ Process-wide cached context per (device, n_streams): creating one costs stream + slab allocations. """
+    with _default_lock:
+        key = (int(device), int(n_streams))
+        ctx = _ctx_cache.get(key)
+        if ctx is None or ctx.handle is None:
+            ctx = _ctx_cache[key] = Context(*key)
+    return ctx
+
+
 def device_count() -> int:
     n = C.c_int(0)
     load_library().hk_device_count(C.byref(n))

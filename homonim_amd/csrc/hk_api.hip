@@ -41,8 +41,12 @@ int fail(int code, const char* fmt, ...) {
 
 struct Slot {
     hipStream_t stream = nullptr;
-    void* dev = nullptr;
+    void* dev = nullptr;      // staging slab of the host-pointer calls (owned by whoever holds the lease)
     size_t dev_bytes = 0;
+    void* norm_ws = nullptr;  // workspace of hk_block_norm_dev on this stream (never shared with `dev`)
+    size_t norm_ws_bytes = 0;
+    void* aux = nullptr;      // on-demand planes + tables of the in-painting branch
+    size_t aux_bytes = 0;
     bool busy = false;
 };
 
@@ -275,6 +279,39 @@ int run_host(hk_ctx* ctx, const hk_fit_desc* desc, const hk_io_desc* io, const v
         fill_grid(a, 0);
         HK_HIP(hk::launch_fit_apply(a, desc->model, r2, sl.stream));
 
+        if (a.has_thresh) {
+            // kernel_model.py:361-371: when valid pixels fail (r2 > thresh) & (gain > 0), in-paint their offsets from the
+            // passing ones and recompute their gains.  Needs the count on the host (one extra stream sync per call).
+            unsigned long long n_fail = 0;
+            HK_HIP(hipMemcpyAsync(&n_fail, d_fail, sizeof(n_fail), hipMemcpyDeviceToHost, sl.stream));
+            HK_HIP(hipStreamSynchronize(sl.stream));
+            if (n_fail > 0) {
+                const size_t need = 4 * plane + hk::inpaint_workspace_bytes(height, stride);
+                if (sl.aux_bytes < need) {
+                    if (sl.aux) HK_HIP(hipFree(sl.aux));
+                    sl.aux = nullptr, sl.aux_bytes = 0;
+                    if (hipMalloc(&sl.aux, need) != hipSuccess) return fail(HK_ERR_NOMEM, "hipMalloc(%zu) failed", need);
+                    sl.aux_bytes = need;
+                }
+                char* aux = static_cast<char*>(sl.aux);
+                float* filled = reinterpret_cast<float*>(aux);
+                float *pg = d_gain, *po = d_off, *pr = d_r2;
+                if (!pg) {  // parameters were not materialised by the first pass: run it again into scratch planes
+                    pg = reinterpret_cast<float*>(aux + plane), po = reinterpret_cast<float*>(aux + 2 * plane);
+                    pr = reinterpret_cast<float*>(aux + 3 * plane);
+                    hk::FitArgs b = a;
+                    b.gain = pg, b.offset = po, b.r2 = pr, b.corr = nullptr, b.fail_count = nullptr;
+                    HK_HIP(hk::launch_fit_apply(b, desc->model, r2, sl.stream));
+                }
+                HK_HIP(hk::launch_inpaint_offsets(po, pg, pr, desc->r2_thresh, stride, height, width, aux + 4 * plane,
+                                                  filled, sl.stream));
+                hk::FitArgs c = a;
+                c.offset_in = filled;
+                c.fail_count = nullptr;  // already counted
+                HK_HIP(hk::launch_fit_apply(c, desc->model, r2, sl.stream));
+            }
+        }
+
         const size_t wbytes = (size_t)width * sizeof(float);
         float* outs[3] = {d_gain, d_off, d_r2};
         if (params_out)
@@ -357,6 +394,8 @@ int hk_ctx_destroy(hk_ctx* ctx) {
     for (auto& s : ctx->slots) {
         if (s.stream) hipStreamSynchronize(s.stream);
         if (s.dev) hipFree(s.dev);
+        if (s.norm_ws) hipFree(s.norm_ws);
+        if (s.aux) hipFree(s.aux);
         if (s.stream) hipStreamDestroy(s.stream);
     }
     delete ctx;
@@ -578,17 +617,27 @@ int hk_block_norm_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* jo
     if (!norm_dev) return fail(HK_ERR_ARG, "norm_dev is NULL");
     HK_HIP(hipSetDevice(ctx->device));
     Slot& sl = ctx->slots[job->stream];
+    const size_t need = hk::norm_workspace_bytes(job->n_bands, job->height, job->width);
     {
-        std::lock_guard<std::mutex> lk(ctx->mu);  // the slab doubles as workspace of this stream
-        rc = ensure_dev(sl, hk::norm_workspace_bytes(job->n_bands, job->height, job->width));
+        // device-resident jobs on one stream are issued by one caller at a time (stream order); the lock only protects
+        // the (re)allocation against other streams' callers touching the context
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        if (sl.norm_ws_bytes < need) {
+            if (sl.norm_ws) {
+                HK_HIP(hipStreamSynchronize(sl.stream));
+                HK_HIP(hipFree(sl.norm_ws));
+                sl.norm_ws = nullptr, sl.norm_ws_bytes = 0;
+            }
+            if (hipMalloc(&sl.norm_ws, need) != hipSuccess) return fail(HK_ERR_NOMEM, "hipMalloc(%zu) failed", need);
+            sl.norm_ws_bytes = need;
+        }
     }
-    if (rc) return rc;
     hk::NormArgs na;
     na.src = job->src, na.ref = job->ref, na.height = job->height, na.width = job->width, na.stride = job->stride;
     na.band_stride = job->band_stride, na.n_bands = job->n_bands;
     na.src_nd_mode = desc->src_nodata_mode, na.ref_nd_mode = desc->ref_nodata_mode;
     na.src_nodata = desc->src_nodata, na.ref_nodata = desc->ref_nodata;
-    HK_HIP(hk::launch_block_norm(na, sl.dev, norm_dev, sl.stream));
+    HK_HIP(hk::launch_block_norm(na, sl.norm_ws, norm_dev, sl.stream));
     return HK_OK;
 }
 

@@ -17,6 +17,7 @@ struct FitArgs {
     float* r2;
     float* corr;
     const double* norm;              // n_bands x 2 (gain-blk-offset)
+    const float* offset_in;          // second (in-paint) pass of gain-offset: in-painted offsets, else NULL
     unsigned long long* fail_count;  // n_bands
     int height, width;
     long long stride;       // elements between rows
@@ -77,6 +78,12 @@ hipError_t launch_partial_mask(const float* in, int nd_mode, float nodata, const
                                long long band_stride, const float* src, int height, int width, long long stride, int kh,
                                int kw, unsigned short* rowcnt_ws, float* params_out, float* corr_out,
                                unsigned char* mask_out, hipStream_t stream);
+
+// In-painting of the offset band (hk_inpaint.hip; GDALFillNodata restated): sources are pixels with r2 > thresh and
+// gain > 0, everything else is a target.  workspace: inpaint_workspace_bytes(); filled: height x stride float32.
+size_t inpaint_workspace_bytes(int height, long long stride);
+hipError_t launch_inpaint_offsets(const float* offset, const float* gain, const float* r2, float thresh, long long stride,
+                                  int height, int width, void* workspace, float* filled, hipStream_t stream);
 
 // returns 0 on pass; writes a diagnostic code otherwise
 hipError_t launch_selftest(int* result_dev, hipStream_t stream);

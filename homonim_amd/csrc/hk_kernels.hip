@@ -398,7 +398,10 @@ __global__ void __launch_bounds__(WAVE, HK_FIT_MIN_WAVES) fit_apply_kernel(const
     //     sstot > 0  &&  ssres < pass_scale * sstot  &&  gain > 0     ==>   (r2 > thresh) & (gain > 0)
     // (pass_scale sits 2^-40 below the rounding boundary of the reference's `1 - f32(ssres/sstot) > thresh`, hk_api.hip)
     // and the exact IEEE evaluation runs for the whole wave-row as soon as any pixel is not certified.
-    const bool want_r2_values = R2 && a.r2 != nullptr;
+    // Second pass after in-painting (kernel_model.py:366-371): pixels failing the r2 mask take their offset from the
+    // in-painted plane and get their gain recomputed as (ref_sum - mask_sum * offset) / src_sum (float32).
+    const bool inpaint_pass = GO && R2 && a.offset_in != nullptr;
+    const bool want_r2_values = R2 && (a.r2 != nullptr || inpaint_pass);
     const bool count_fails = GO && R2 && a.has_thresh;
 
     unsigned nfail = 0;
@@ -562,7 +565,13 @@ __global__ void __launch_bounds__(WAVE, HK_FIT_MIN_WAVES) fit_apply_kernel(const
                             if constexpr (GO) {
                                 const bool m = (mc >> (8 * i)) & 1u;
                                 // valid pixels failing (r2 > thresh) & (gain > 0) need in-painting (:363,:370)
-                                if (count_fails && out_lane && m && !((r2v[i] > a.r2_thresh) && (g[i] > 0.f))) ++nfail;
+                                const bool failing = count_fails && m && !((r2v[i] > a.r2_thresh) && (g[i] > 0.f));
+                                if (failing && out_lane) ++nfail;
+                                if (failing && inpaint_pass && out_lane) {
+                                    const float oin = a.offset_in[out_base + (long long)y * a.stride + x + i];
+                                    o[i] = oin;
+                                    g[i] = __fdiv_rn(__fsub_rn(Rf[i], __fmul_rn(Nf[i], oin)), Sf[i]);
+                                }
                             }
                         }
                     }
@@ -620,12 +629,10 @@ size_t fit_lds_bytes(int kh, bool use_ring) {
 template <int MODEL, bool R2, int RW, bool DENSE, bool RING>
 static hipError_t launch_one(const FitArgs& a, hipStream_t stream) {
     const size_t lds = fit_lds_bytes(2 * a.rh + 1, RING);
-    static bool attr_set = false;  // raise the dynamic-LDS cap once per instantiation (64 KiB default)
-    if (lds > 64 * 1024 && !attr_set) {
+    if (lds > 64 * 1024) {  // forced LDS ring on a tall kernel (testing): raise the 64 KiB dynamic-LDS default
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fit_apply_kernel<MODEL, R2, RW, DENSE, RING>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     int grid = a.total_units;
     if (a.xcd_remap) grid = (grid + 7) / 8 * 8;

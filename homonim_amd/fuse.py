@@ -244,7 +244,7 @@ class RasterFuse:
         models = []
         for dev in devices:
             m = model_cls(model_type, kernel_shape, find_r2=want_params, **model_config)
-            m.context = _hk.Context(dev, n_streams=device_config['streams'])
+            m.context = _hk.get_context(dev, device_config['streams'])  # cached per process
             models.append(m)
 
         n_src = self._src.shape[0]
@@ -259,22 +259,18 @@ class RasterFuse:
 
         blocks = list(self.block_pairs(overlap=overlap, max_block_mem=block_config['max_block_mem']))
         blocks = shard(blocks, device_config['rank'], device_config['world_size'])
-        try:
-            if block_config['threads'] == 1 and len(models) == 1:
-                for bp in blocks:
-                    self._process_block(bp, models[0], corr, params, nodata)
-            else:
-                workers = max(block_config['threads'], len(models))
-                with ThreadPoolExecutor(max_workers=workers) as ex:
-                    futures = [
-                        ex.submit(self._process_block, bp, models[i % len(models)], corr, params, nodata)
-                        for i, bp in enumerate(blocks)
-                    ]
-                    for f in as_completed(futures):
-                        f.result()  # re-raise worker exceptions (fuse.py:404-408)
-        finally:
-            for m in models:
-                m.context.close()
+        if block_config['threads'] == 1 and len(models) == 1:
+            for bp in blocks:
+                self._process_block(bp, models[0], corr, params, nodata)
+        else:
+            workers = max(block_config['threads'], len(models))
+            with ThreadPoolExecutor(max_workers=workers) as ex:
+                futures = [
+                    ex.submit(self._process_block, bp, models[i % len(models)], corr, params, nodata)
+                    for i, bp in enumerate(blocks)
+                ]
+                for f in as_completed(futures):
+                    f.result()  # re-raise worker exceptions (fuse.py:404-408)
 
         if isinstance(corr_filename, (str, os.PathLike)):
             np.save(corr_filename, corr)

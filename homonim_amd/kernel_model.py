@@ -13,7 +13,8 @@ Differences a caller can observe (all documented in DESIGN.md):
 * ``fit_apply`` is an extra, fused entry point for ``RasterFuse._process_block``'s fit->apply pair (fuse.py:305-307).
 * gain-offset with ``r2_inpaint_thresh`` set: the kernel evaluates the r2 mask (kernel_model.py:363); when no valid
   pixel fails it the reference's GDAL ``fillnodata`` branch is the identity and results are identical; when some
-  fail, in-painting is required and currently raises ``NotImplementedError``.
+  fail, the offsets are in-painted on the device by a restatement of GDAL's published fill algorithm (parity with
+  GDAL itself unpinned, hk_inpaint.hip) and the gains of the failing pixels are recomputed as in :370-371.
 * ``RefSpaceModel`` / ``SrcSpaceModel`` accept same-grid pairs only (GDAL re-projection is section 8f row 1);
   ``mask_partial`` (kernel_model.py:375-409) is evaluated on the device for that case.
 """
@@ -105,14 +106,6 @@ class KernelModel:
         profile.update(count=count, nodata=RasterArray.default_nodata, dtype=RasterArray.default_dtype)
         return profile
 
-    def _check_inpaint(self, n_fail: int):
-        if n_fail and self._model == Model.gain_offset and self._r2_inpaint_thresh is not None:
-            raise NotImplementedError(
-                f'{n_fail} valid pixel(s) fail the R2 > {self._r2_inpaint_thresh} & gain > 0 test and need in-painting '
-                '(GDAL fillnodata, homonim/kernel_model.py:361-371), which is not built yet: '
-                'pass r2_inpaint_thresh=None to fit without in-painting.'
-            )
-
     # -- the hot path -------------------------------------------------------------------------------------------------
     def fit(self, src_ra: RasterArray, ref_ra: RasterArray) -> RasterArray:
         """
@@ -127,7 +120,6 @@ class KernelModel:
             self._desc(src_ra, ref_ra), self._band(src_ra, 'src_ra'), self._band(ref_ra, 'ref_ra'), count,
             want_params=True, want_corr=False
         )
-        self._check_inpaint(n_fail)
         return RasterArray.from_profile(params, self._param_profile(src_ra, count))
 
     def apply(self, src_ra: RasterArray, param_ra: RasterArray) -> RasterArray:
@@ -154,7 +146,6 @@ class KernelModel:
             self._desc(src_ra, ref_ra), self._band(src_ra, 'src_ra'), self._band(ref_ra, 'ref_ra'), count,
             want_params=want_params, want_corr=True, out_dtype=out_dtype, out_nodata=out_nodata
         )
-        self._check_inpaint(n_fail)
         profile = self._param_profile(src_ra, count)
         corr_profile = dict(profile, nodata=out_nodata, dtype=str(out_dtype))
         corr_ra = RasterArray.from_profile(corr, corr_profile)

@@ -18,6 +18,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <limits.h>
 #include <string.h>
 #ifdef _OPENMP
 #include <omp.h>
@@ -121,6 +122,23 @@ int hk_oracle_fit_apply(int model, int kh, int kw, int find_r2, int has_thresh, 
     const size_t plane = (size_t)H * W;
     uint64_t fails = 0;
     int err = 0;
+    /* in-paint branch (kernel_model.py:361-371) needs the parameters and three of the window sums afterwards */
+    const int may_inpaint = model == MODEL_GAIN_OFFSET && has_thresh;
+    float* own_params = NULL;
+    float *keepS = NULL, *keepR = NULL, *keepN = NULL;
+    if (may_inpaint) {
+        if (!params_out) {
+            own_params = (float*)malloc(sizeof(float) * 3 * plane);
+            if (!own_params) return -1;
+            params_out = own_params;
+        }
+        keepS = (float*)malloc(sizeof(float) * plane), keepR = (float*)malloc(sizeof(float) * plane);
+        keepN = (float*)malloc(sizeof(float) * plane);
+        if (!keepS || !keepR || !keepN) {
+            free(own_params), free(keepS), free(keepR), free(keepN);
+            return -1;
+        }
+    }
 #ifdef _OPENMP
     if (n_threads < 1) n_threads = omp_get_max_threads();
 #else
@@ -183,6 +201,9 @@ int hk_oracle_fit_apply(int model, int kh, int kw, int find_r2, int has_thresh, 
                         if (model == MODEL_GAIN_OFFSET) {
                             /* kernel_model.py:338-351 */
                             const float Sf = (float)acc[Q_S * W + x], Pf = (float)acc[Q_P * W + x];
+                            if (may_inpaint) {
+                                keepS[(size_t)y * W + x] = Sf, keepR[(size_t)y * W + x] = Rf, keepN[(size_t)y * W + x] = Nf;
+                            }
                             const float num = (float)(Nf * Pf) - (float)(Sf * Rf);
                             const double den = (Nd * S2) - (double)(float)(Sf * Sf);
                             g = (float)((double)num / den);
@@ -248,8 +269,116 @@ int hk_oracle_fit_apply(int model, int kh, int kw, int find_r2, int has_thresh, 
         free(sring);
         free(acc);
     }
+    if (!err && may_inpaint && fails > 0) {
+        /* kernel_model.py:363-371 */
+        unsigned char* r2_mask = (unsigned char*)malloc(plane);
+        if (!r2_mask) err = 1;
+        else {
+            float *pg = params_out, *po = params_out + plane, *pr = params_out + 2 * plane;
+            for (size_t i = 0; i < plane; ++i) r2_mask[i] = (pr[i] > thresh) && (pg[i] > 0.f); /* NaN outside mask -> 0 */
+            float* filled = (float*)malloc(sizeof(float) * plane);
+            if (!filled) err = 1;
+            else {
+                memcpy(filled, po, sizeof(float) * plane);
+                if (hk_oracle_fill_nodata(filled, r2_mask, H, W, 100.0)) err = 1;
+                /* param_ra.mask = mask (:367): masked pixels back to NaN; redo = ~r2_mask & mask (:370) */
+                for (size_t i = 0; i < plane && !err; ++i) {
+                    const int valid = px_valid(src[i], snd_mode, snd) && px_valid(ref[i], rnd_mode, rnd);
+                    if (!valid) continue; /* parameters already NaN there */
+                    po[i] = filled[i];
+                    if (!r2_mask[i]) pg[i] = (float)((float)(keepR[i] - (float)(keepN[i] * po[i])) / keepS[i]); /* :371 */
+                    if (corr_out) corr_out[i] = (float)((float)(pg[i] * src[i]) + po[i]);
+                }
+                free(filled);
+            }
+            free(r2_mask);
+        }
+    }
+    free(own_params), free(keepS), free(keepR), free(keepN);
     if (fail_count) *fail_count = fails;
     return err ? -1 : 0;
+}
+
+/*
+ * rasterio.fill.fillnodata(image, mask, max_search_distance, smoothing_iterations=0) == GDALFillNodata
+ * (kernel_model.py:366).  GDAL is not in /root/reference: its published algorithm (gdal/alg/rasterfill.cpp) is restated
+ * exactly as in oracle_np.fill_nodata -- PARITY WITH GDAL UNPINNED.  image is updated in place.
+ */
+static void quad_check(double* qd, double* qv, int tx, int64_t ty, int ox, int oy, float tv) {
+    if (ty == INT64_MAX) return;
+    const double dx = (double)tx - (double)ox, dy = (double)ty - (double)oy;
+    const double d2 = dx * dx + dy * dy;
+    if (d2 < (*qd) * (*qd)) {
+        *qd = sqrt(d2);
+        *qv = (double)tv;
+    }
+}
+
+int hk_oracle_fill_nodata(float* image, const unsigned char* mask, int H, int W, double max_search_distance) {
+    const size_t n = (size_t)H * W;
+    const int md = (int)floor(max_search_distance);
+    int64_t* top_y = (int64_t*)malloc(sizeof(int64_t) * n);
+    int64_t* bot_y = (int64_t*)malloc(sizeof(int64_t) * n);
+    float* top_v = (float*)malloc(sizeof(float) * n);
+    float* bot_v = (float*)malloc(sizeof(float) * n);
+    float* out = (float*)malloc(sizeof(float) * n);
+    if (!top_y || !bot_y || !top_v || !bot_v || !out) {
+        free(top_y), free(bot_y), free(top_v), free(bot_v), free(out);
+        return -1;
+    }
+#pragma omp parallel for
+    for (int x = 0; x < W; ++x) {
+        int64_t last_y = INT64_MAX;
+        float last_v = 0.f;
+        for (int y = 0; y < H; ++y) { /* nearest source at or above */
+            const size_t i = (size_t)y * W + x;
+            if (mask[i]) last_y = y, last_v = image[i];
+            else if (last_y != INT64_MAX && y > md + last_y) last_y = INT64_MAX;
+            top_y[i] = last_y, top_v[i] = last_v;
+        }
+        last_y = INT64_MAX, last_v = 0.f;
+        for (int y = H - 1; y >= 0; --y) { /* nearest source strictly below */
+            const size_t i = (size_t)y * W + x;
+            bot_y[i] = last_y, bot_v[i] = last_v;
+            if (mask[i]) last_y = y, last_v = image[i];
+            else if (last_y != INT64_MAX && last_y - y > md) last_y = INT64_MAX;
+        }
+    }
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int y = 0; y < H; ++y) {
+        for (int x = 0; x < W; ++x) {
+            const size_t i = (size_t)y * W + x;
+            out[i] = image[i];
+            if (mask[i]) continue;
+            double qd[4], qv[4] = {0, 0, 0, 0};
+            for (int q = 0; q < 4; ++q) qd[q] = max_search_distance + 1.0;
+            int this_max = md;
+            for (int step = 0; step <= this_max; ++step) {
+                const int lx = x - step > 0 ? x - step : 0, rx = x + step < W - 1 ? x + step : W - 1;
+                const size_t il = (size_t)y * W + lx, ir = (size_t)y * W + rx;
+                quad_check(&qd[0], &qv[0], lx, top_y[il], x, y, top_v[il]);
+                quad_check(&qd[1], &qv[1], lx, bot_y[il], x, y, bot_v[il]);
+                if (step == 0) continue;
+                quad_check(&qd[2], &qv[2], rx, top_y[ir], x, y, top_v[ir]);
+                quad_check(&qd[3], &qv[3], rx, bot_y[ir], x, y, bot_v[ir]);
+                if ((step & 3) == 0) this_max = (int)floor(fmax(fmax(qd[0], qd[1]), fmax(qd[2], qd[3])));
+            }
+            double wsum = 0.0, vsum = 0.0;
+            int has = 0;
+            for (int q = 0; q < 4; ++q) {
+                if (qd[q] <= max_search_distance) {
+                    const double wgt = 1.0 / qd[q];
+                    has = wgt != 0.0;
+                    wsum += wgt;
+                    vsum += qv[q] * wgt;
+                }
+            }
+            if (has) out[i] = (float)(vsum / wsum);
+        }
+    }
+    memcpy(image, out, sizeof(float) * n);
+    free(top_y), free(bot_y), free(top_v), free(bot_v), free(out);
+    return 0;
 }
 
 /* KernelModel.apply alone (kernel_model.py:461) */

@@ -31,6 +31,8 @@ def _load():
         lib.hk_oracle_block_norm.argtypes = [_f32p, C.c_int, C.c_float, _f32p, C.c_int, C.c_float, C.c_int, C.c_int, _f64p]
         lib.hk_oracle_apply.restype = None
         lib.hk_oracle_apply.argtypes = [_f32p, _f32p, C.c_int, C.c_int, _f32p]
+        lib.hk_oracle_fill_nodata.restype = C.c_int
+        lib.hk_oracle_fill_nodata.argtypes = [_f32p, C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_double]
         lib.hk_oracle_max_threads.restype = C.c_int
         _lib = lib
     return _lib
@@ -61,9 +63,20 @@ def fit_block_norm(src, src_nodata, ref, ref_nodata) -> np.ndarray:
     return norm
 
 
+def fill_nodata(image: np.ndarray, mask: np.ndarray, max_search_distance: float = 100.0) -> np.ndarray:
+    """ C twin of oracle_np.fill_nodata (restated GDALFillNodata; parity with GDAL unpinned). """
+    out = np.array(image, dtype=np.float32, copy=True, order='C')
+    m = np.ascontiguousarray(mask, dtype=np.uint8)
+    rc = _load().hk_oracle_fill_nodata(out.ctypes.data_as(_f32p), m.ctypes.data_as(C.POINTER(C.c_ubyte)), out.shape[0],
+                                       out.shape[1], float(max_search_distance))
+    assert rc == 0
+    return out
+
+
 def fit_apply(model, src, src_nodata, ref, ref_nodata, kernel_shape=(5, 5), find_r2=False, r2_inpaint_thresh=0.25,
               norm_model=None, want_params=True, want_corr=True, n_threads=0):
-    """ -> (params | None, corr | None, n_fail).  gain-blk-offset needs ``norm_model`` (float64[2]). """
+    """ -> (params | None, corr | None, n_fail).  gain-blk-offset needs ``norm_model`` (float64[2]).  gain-offset with
+    a threshold runs the whole reference branch incl. in-painting when n_fail > 0 (kernel_model.py:361-371). """
     src = np.ascontiguousarray(src, np.float32)
     ref = np.ascontiguousarray(ref, np.float32)
     h, w = src.shape

@@ -198,15 +198,88 @@ def fit_gain_blk_offset(
     return param, norm_model
 
 
+def fill_nodata(image: np.ndarray, mask: np.ndarray, max_search_distance: float = 100.0) -> np.ndarray:
+    """
+    rasterio.fill.fillnodata(image, mask, max_search_distance=100, smoothing_iterations=0) == GDALFillNodata, which the
+    reference calls at kernel_model.py:366.  GDAL is NOT in /root/reference (rasterio>=1.1, un-pinned, pyproject.toml:7)
+    and not installed here: its published algorithm (gdal/alg/rasterfill.cpp) is restated, PARITY WITH GDAL UNPINNED.
+    Pixels with mask == 0 are interpolated from pixels with mask != 0: per target, the nearest source in each of four
+    quadrants (found through per-column nearest-above / nearest-below tables while stepping outwards one column at a
+    time), inverse-distance weighted.  Plain loops -- small inputs only.
+    """
+    h, w = image.shape
+    src = mask.astype(bool)
+    md = int(np.floor(max_search_distance))
+    none = np.iinfo(np.int64).max
+    top_y = np.full((h, w), none, np.int64)
+    top_v = np.zeros((h, w), np.float32)
+    bot_y = np.full((h, w), none, np.int64)
+    bot_v = np.zeros((h, w), np.float32)
+    for x in range(w):
+        last_y, last_v = none, np.float32(0)
+        for y in range(h):                      # top-down: nearest source at or above
+            if src[y, x]:
+                last_y, last_v = y, image[y, x]
+            elif last_y != none and y > md + last_y:
+                last_y = none
+            top_y[y, x], top_v[y, x] = last_y, last_v
+        last_y, last_v = none, np.float32(0)
+        for y in range(h - 1, -1, -1):          # bottom-up: nearest source strictly below
+            bot_y[y, x], bot_v[y, x] = last_y, last_v
+            if src[y, x]:
+                last_y, last_v = y, image[y, x]
+            elif last_y != none and last_y - y > md:
+                last_y = none
+    out = image.copy()
+    for y in range(h):
+        for x in range(w):
+            if src[y, x]:
+                continue
+            qd = [max_search_distance + 1.0] * 4
+            qv = [0.0] * 4
+
+            def check(q, tx, ty, tv):
+                if ty == none:
+                    return
+                d2 = float(tx - x) ** 2 + float(ty - y) ** 2
+                if d2 < qd[q] * qd[q]:
+                    qd[q] = float(np.sqrt(d2))
+                    qv[q] = float(tv)
+
+            this_max = md
+            step = 0
+            while step <= this_max:
+                lx, rx = max(0, x - step), min(w - 1, x + step)
+                check(0, lx, top_y[y, lx], top_v[y, lx])
+                check(1, lx, bot_y[y, lx], bot_v[y, lx])
+                if step > 0:
+                    check(2, rx, top_y[y, rx], top_v[y, rx])
+                    check(3, rx, bot_y[y, rx], bot_v[y, rx])
+                    if step & 3 == 0:
+                        this_max = int(np.floor(max(qd)))
+                step += 1
+            wsum = vsum = 0.0
+            has = False
+            for q in range(4):
+                if qd[q] <= max_search_distance:
+                    wgt = 1.0 / qd[q]
+                    has = wgt != 0
+                    wsum += wgt
+                    vsum += qv[q] * wgt
+            if has:
+                out[y, x] = np.float32(vsum / wsum)
+    return out
+
+
 def fit_gain_offset(
     src, src_nodata, ref, ref_nodata, kernel_shape=(5, 5), find_r2=False, r2_inpaint_thresh: Optional[float] = 0.25
 ) -> Tuple[np.ndarray, int]:
     """
     Model.gain_offset: kernel_model.py:305-373.
-    Returns (params, n_fail) where n_fail is the number of valid pixels failing the r2 mask test (:363).  The GDAL
-    ``fillnodata`` in-painting itself (:366) lives outside /root/reference and is NOT restated: when n_fail == 0 it
-    is the identity on valid pixels and the branch below reproduces the reference exactly; when n_fail > 0 the
-    params are returned as they stand BEFORE in-painting (callers must treat that case separately).
+    Returns (params, n_fail) where n_fail is the number of valid pixels failing the r2 mask test (:363).  When
+    n_fail == 0 GDAL's ``fillnodata`` (:366) is the identity on valid pixels and the result is pinned by the reference
+    goldens; when n_fail > 0 the in-painting runs through ``fill_nodata`` above, a restatement of GDAL's published
+    algorithm whose parity with GDAL itself is unpinned (no GDAL here).
     """
     src_array = np.array(src, dtype=F32, copy=True)
     ref_array = np.array(ref, dtype=F32, copy=True)
@@ -243,6 +316,11 @@ def fit_gain_offset(
                 # ~mask here); ``param_ra.mask = mask`` (:367) then resets every band at ~mask to nan.
                 param[:, ~mask] = np.nan
                 # :370-371 is a no-op (its where-mask ``~r2_mask & mask`` is empty)
+            else:
+                param[1] = fill_nodata(param[1], r2_mask)  # :366
+                param[:, ~mask] = np.nan  # :367
+                redo = ~r2_mask & mask  # :370
+                np.divide(ref_sum - mask_sum * param[1], src_sum, out=param[0], where=redo)  # :371
     return param, n_fail
 
 

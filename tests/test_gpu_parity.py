@@ -27,6 +27,15 @@ def ctx():
     return c
 
 
+@pytest.fixture(scope='module')
+def oc():
+    """ the C oracle (bit-identical to oracle_np, tests/test_oracle_c.py) for inputs too large for Python loops """
+    from homonim_amd import build
+    build.build_oracle(verbose=False)
+    from oracle import oracle_c
+    return oracle_c
+
+
 def _ra(arr, nodata):
     return RasterArray(arr, CRS(), Affine.identity(), nodata=nodata)
 
@@ -403,7 +412,7 @@ def _fused_no_params(ctx, src, ref, nodata, k, thresh):
 
 @pytest.mark.parametrize('thresh', [0.25, 0.5, 0.0, -1.0, float('-inf'), 0.9, 0.999, 0.9999999, 1.0, 2.0])
 @pytest.mark.parametrize('nodata, variant', [(np.nan, 'frame+holes'), (None, 'none')])
-def test_certified_r2_test_counts_exactly(ctx, thresh, nodata, variant):
+def test_certified_r2_test_counts_exactly(ctx, oc, thresh, nodata, variant):
     """ Fused mode without parameter output: the r2-mask decision goes through the division-free certified test with
     an exact fallback; the failure count must equal the oracle's for every threshold, incl. ones in the thick of the
     R2 distribution and degenerate ones (>= 1: everything fails; -inf: everything passes). """
@@ -411,15 +420,17 @@ def test_certified_r2_test_counts_exactly(ctx, thresh, nodata, variant):
     rng = np.random.default_rng(3)
     ref = (ref + rng.normal(0, 0.08, ref.shape).astype(np.float32)).astype(np.float32)  # R2 spread ~0.85..0.99
     ref[100:104, 200:204] = -5.0                                                         # a low-R2 / odd-gain patch
-    exp_params, exp_fail = onp.fit_gain_offset(src, nodata, ref, nodata, (5, 5), False, thresh)
+    # expected: the whole reference branch incl. in-painting of the failing pixels (C oracle == numpy oracle, bit for bit)
+    exp_params, exp_corr, exp_fail = oc.fit_apply('gain-offset', src, nodata, ref, nodata, (5, 5), False, thresh)
     corr, n_fail = _fused_no_params(ctx, src, ref, nodata, (5, 5), thresh)
     assert n_fail == exp_fail
     if thresh in (1.0, 2.0):
-        assert n_fail == int((~np.isnan(exp_params[0])).sum())
-    assert_close_ulp(corr, onp.apply(src, exp_params), 'corrected')
+        valid = ~np.isnan(src) & ~np.isnan(ref)
+        assert n_fail == int(valid.sum())
+    assert_close_ulp(corr, exp_corr, 'corrected', max_frac=1e-4)
 
 
-def test_certified_r2_test_degenerate_windows(ctx):
+def test_certified_r2_test_degenerate_windows(ctx, oc):
     """ flat reference (sstot == 0), single-valid-pixel windows, negative gains: never certified, always exact. """
     rng = np.random.default_rng(8)
     src = rng.uniform(0.1, 1, (96, 300)).astype(np.float32)
@@ -428,10 +439,10 @@ def test_certified_r2_test_degenerate_windows(ctx):
     src[40:60, 20:40] = np.nan
     src[50, 30] = 0.3                                  # an isolated valid pixel: N = 1 windows
     for thresh in (0.25, -10.0):
-        exp_params, exp_fail = onp.fit_gain_offset(src, np.nan, ref, np.nan, (5, 5), False, thresh)
+        _, exp_corr, exp_fail = oc.fit_apply('gain-offset', src, np.nan, ref, np.nan, (5, 5), False, thresh)
         corr, n_fail = _fused_no_params(ctx, src, ref, np.nan, (5, 5), thresh)
         assert n_fail == exp_fail and n_fail > 0
-        assert_close_ulp(corr, onp.apply(src, exp_params), 'corrected', max_frac=1e-3)
+        assert_close_ulp(corr, exp_corr, 'corrected', max_frac=1e-3)
 
 
 def test_block_norm_heavy_ties_take_the_fallback_select(ctx):
@@ -613,3 +624,70 @@ def test_mask_partial_erosion_properties(ctx, kernel_shape):
     assert out_ra.array[out_ra.mask] == pytest.approx(src[out_ra.mask] + 1, abs=1e-2)
     _, _, m = ctx.partial_mask(src, np.nan, ones.array, kernel_shape, want_mask=True)
     assert (m.astype(bool) == exp).all()
+
+
+# -- R2 in-painting (kernel_model.py:361-371) ----------------------------------------------------------------------------
+@pytest.mark.parametrize('kernel_shape', [(5, 5), (5, 7), (9, 9)])
+def test_r2_inpainting_reference_test(ctx, kernel_shape):
+    """ reference tests/test_kernel_model.py:166-203: one -100 outlier; in-painting brings the offsets back to ~0 and
+    lowers the gain variance; R2 is ~1 outside the outlier's k x k neighbourhood and < 0.5 inside. """
+    import warnings
+    a = np.array(range(1, 201), dtype='float32').reshape(20, 10)
+    a[:, [0, -1]] = np.nan
+    a[[0, -1], :] = np.nan
+    src = np.kron(a, np.ones((2, 2), np.float32)).astype(np.float32)
+    src[:, [0, 1, -2, -1]] = np.nan
+    src[[0, 1, -2, -1], :] = np.nan
+    ref = src.copy()
+    loc = (src.shape[0] // 2, src.shape[1] // 2)
+    ul = (loc[0] - kernel_shape[0] // 2, loc[1] - kernel_shape[1] // 2)
+    low = np.zeros(src.shape, bool)
+    low[ul[0]:ul[0] + kernel_shape[0], ul[1]:ul[1] + kernel_shape[1]] = True
+    ref[loc] = -100
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        no_inpaint = RefSpaceModel(Model.gain_offset, kernel_shape, r2_inpaint_thresh=-np.inf, mask_partial=False)
+        inpaint = RefSpaceModel(Model.gain_offset, kernel_shape, r2_inpaint_thresh=0.5, mask_partial=False)
+    p0 = no_inpaint.fit(_ra(src.copy(), np.nan), _ra(ref.copy(), np.nan))
+    p1 = inpaint.fit(_ra(src.copy(), np.nan), _ra(ref.copy(), np.nan))
+    mask = ~np.isnan(src)
+    for p in (p0, p1):
+        assert p.array[2, ~low & mask] == pytest.approx(1, abs=1e-3)
+        assert (p.array[2, low] < .5).all()
+        assert (p.mask == mask).all()
+    assert p0.array[1, p0.mask] != pytest.approx(0, abs=1e-1)
+    assert p1.array[1, p1.mask] == pytest.approx(0, abs=1e-1)
+    assert p1.array[0, p1.mask].var() < p0.array[0, p0.mask].var()
+
+
+@pytest.mark.parametrize('want_params', [True, False])
+def test_r2_inpainting_vs_oracle(ctx, want_params):
+    """ In-painted parameters and corrected block against the oracle's restatement of the same GDAL algorithm, with
+    failing regions of several shapes (isolated pixels, a patch, a stripe that crosses the nodata frame). """
+    src, ref = onp.synth_pair(90, 140, 17, 'frame+holes')
+    ref = ref.copy()
+    ref[40:46, 60:70] = -3.0
+    ref[20, 30] = 9.0
+    ref[70:72, :] = np.float32(0.5)          # flat stripe: sstot ~ 0 -> fails
+    exp_params, exp_fail = onp.fit_gain_offset(src, np.nan, ref, np.nan, (5, 5), False, 0.25)
+    assert exp_fail > 100
+    desc = _hk.make_desc('gain-offset', (5, 5), False, 0.25, np.nan, np.nan)
+    params, corr, _, n_fail = ctx.fit_apply(desc, src, ref, 3, want_params=want_params, want_corr=True)
+    assert n_fail == exp_fail
+    if want_params:
+        assert_close_ulp(params, exp_params, 'in-painted params', max_frac=1e-3)
+    assert_close_ulp(corr, onp.apply(src, exp_params), 'corrected after in-painting', max_frac=1e-3)
+
+
+def test_fill_nodata_known_answers():
+    """ the restated GDAL fill on hand-checkable cases (oracle only; the GPU version is compared with it above). """
+    img = np.zeros((5, 7), np.float32)
+    msk = np.zeros((5, 7), bool)
+    img[2, 1], img[2, 5] = 10, 20
+    msk[2, 1] = msk[2, 5] = True
+    out = onp.fill_nodata(img, msk)
+    assert out[2, 3] == pytest.approx(15)                         # equidistant
+    assert out[2, 2] == pytest.approx((10 / 1 + 20 / 3) / (1 / 1 + 1 / 3))
+    assert out[2, 1] == 10 and out[2, 5] == 20                    # sources untouched
+    far = onp.fill_nodata(np.pad(img, ((0, 0), (0, 300))), np.pad(msk, ((0, 0), (0, 300))))
+    assert far[2, 5 + 150] == 0                                   # nothing within 100 px: left as it was

@@ -66,3 +66,24 @@ def test_oracle_c_block_norm_close_to_numpy(oc):
         assert n_c[1] == pytest.approx(n_np[1], rel=2e-6, abs=2e-6)
     allnan = np.full((8, 8), np.nan, np.float32)
     assert (oc.fit_block_norm(allnan, np.nan, allnan, np.nan) == 0).all()
+
+
+def test_oracle_c_inpaint_branch_equals_oracle_np(oc):
+    """ gain-offset with failing pixels: the in-paint branch (restated GDAL fill + gain recomputation,
+    kernel_model.py:361-371) of the C oracle against the numpy one, bit for bit. """
+    src, ref = onp.synth_pair(60, 90, 17, 'frame+holes')
+    ref = ref.copy()
+    ref[20:26, 30:40] = -3
+    ref[10, 12] = 9
+    ref[45:47, :] = 0.5
+    exp, n_np = onp.fit_gain_offset(src, np.nan, ref, np.nan, (5, 5), False, 0.25)
+    params, corr, n_c = oc.fit_apply('gain-offset', src, np.nan, ref, np.nan, (5, 5), False, 0.25)
+    assert n_c == n_np > 100
+    assert_same_f32(params, exp, 'in-painted params')
+    assert_same_f32(corr, onp.apply(src, exp), 'corrected')
+    _, corr_only, _ = oc.fit_apply('gain-offset', src, np.nan, ref, np.nan, (5, 5), False, 0.25, want_params=False)
+    assert_same_f32(corr_only, corr, 'corrected without parameter output')
+    rng = np.random.default_rng(0)
+    img = rng.normal(size=(50, 70)).astype(np.float32)
+    msk = rng.random((50, 70)) < 0.05
+    assert_same_f32(oc.fill_nodata(img, msk), onp.fill_nodata(img, msk), 'fill_nodata')
