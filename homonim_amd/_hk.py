@@ -67,6 +67,8 @@ SIGNATURES = {
     'hk_apply': (C.c_int, [C.c_void_p, _f32p, C.c_int64, _f32p, C.c_int32, C.c_int32, _f32p]),
     'hk_fit_apply': (C.c_int, [C.c_void_p, _P(FitDesc), _f32p, C.c_int64, _f32p, C.c_int64, C.c_int32, C.c_int32,
                                _f64p, _f32p, C.c_int32, _f32p, _f64p, _u64p]),
+    'hk_reproject': (C.c_int, [C.c_void_p, _f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_double, C.c_double,
+                               C.c_double, C.c_double, C.c_int32, _f32p, C.c_int32, C.c_int32, C.c_float]),
     'hk_partial_mask': (C.c_int, [C.c_void_p, _f32p, C.c_int64, C.c_int32, C.c_float, _f32p, C.c_int32, _f32p, C.c_int64,
                                   C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f32p, _f32p, _P(C.c_uint8)]),
     'hk_fit_apply_io': (C.c_int, [C.c_void_p, _P(FitDesc), _P(IoDesc), C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
@@ -270,9 +272,25 @@ class Context:
                                   _ptr(out)))
         return out
 
+    def reproject(self, src: np.ndarray, src_nodata, mapping, dst_shape, resampling: int, dst_fill: float) -> np.ndarray:
+        """ hk_reproject: (bands, h, w) or (h, w) float32 -> same rank on the destination grid. """
+        arr = np.ascontiguousarray(src, dtype=np.float32)
+        squeeze = arr.ndim == 2
+        if squeeze:
+            arr = arr[None]
+        nb, sh, sw = arr.shape
+        dh, dw = int(dst_shape[0]), int(dst_shape[1])
+        out = np.empty((nb, dh, dw), np.float32)
+        mode, val = nodata_code(src_nodata)
+        kx, ox, ky, oy = [float(v) for v in mapping]
+        _check(self._lib.hk_reproject(self._h, _ptr(arr), nb, sh, sw, mode, val, kx, ox, ky, oy, int(resampling),
+                                      _ptr(out), dh, dw, float(dst_fill)))
+        return out[0] if squeeze else out
+
     def partial_mask(self, in_arr: np.ndarray, in_nodata, params: np.ndarray, kernel_shape, src: Optional[np.ndarray] = None,
-                     want_params: bool = False, want_corr: bool = False, want_mask: bool = False):
-        """ mask_partial on a shared grid (hk_partial_mask) -> (masked params | None, corrected | None, mask | None). """
+                     want_params: bool = False, want_corr: bool = False, want_mask: bool = False, coverage: bool = False):
+        """ mask_partial on a shared grid (hk_partial_mask) -> (masked params | None, corrected | None, mask | None).
+        ``coverage``: ``in_arr`` is a coverage fraction (a mask re-projected with `average`), valid where >= 1. """
         in_arr = _as_f32_2d(in_arr, 'in')
         params = np.ascontiguousarray(params, dtype=np.float32)
         if params.ndim != 3 or params.shape[-2:] != in_arr.shape:
@@ -280,7 +298,7 @@ class Context:
         h, w = in_arr.shape
         if src is not None:
             src = _as_f32_2d(src, 'src')
-        mode, val = nodata_code(in_nodata)
+        mode, val = (3, 0.0) if coverage else nodata_code(in_nodata)
         p_out = np.empty_like(params) if want_params else None
         c_out = np.empty((h, w), np.float32) if want_corr else None
         m_out = np.empty((h, w), np.uint8) if want_mask else None

@@ -468,6 +468,37 @@ int hk_apply(hk_ctx* ctx, const float* src, int64_t src_stride, const float* par
     return HK_OK;
 }
 
+int hk_reproject(hk_ctx* ctx, const float* src, int32_t n_bands, int32_t src_height, int32_t src_width,
+                 int32_t src_nodata_mode, float src_nodata, double kx, double ox, double ky, double oy, int32_t resampling,
+                 float* dst, int32_t dst_height, int32_t dst_width, float dst_fill) {
+    if (!ctx) return fail(HK_ERR_ARG, "ctx is NULL");
+    if (!src || !dst) return fail(HK_ERR_ARG, "NULL pointer argument");
+    if (n_bands < 1 || src_height < 1 || src_width < 1 || dst_height < 1 || dst_width < 1)
+        return fail(HK_ERR_ARG, "empty raster");
+    if (!(kx > 0.0) || !(ky > 0.0)) return fail(HK_ERR_UNSUPPORTED, "flipped or degenerate grid mapping");
+    if (resampling != 0 && resampling != 1 && resampling != 3 && resampling != 5)
+        return fail(HK_ERR_UNSUPPORTED, "resampling %d is not built (nearest, bilinear, cubic_spline, average are)", resampling);
+    if ((resampling == 1 || resampling == 3) && (kx > 1.0 + 1e-9 || ky > 1.0 + 1e-9))
+        return fail(HK_ERR_UNSUPPORTED, "bilinear / cubic_spline down-sampling (stretched kernel) is not built");
+    if (dst_height > 65535) return fail(HK_ERR_UNSUPPORTED, "destination taller than 65535 rows");
+    HK_HIP(hipSetDevice(ctx->device));
+    const size_t sbytes = (size_t)n_bands * src_height * src_width * 4, dbytes = (size_t)n_bands * dst_height * dst_width * 4;
+    const size_t o_dst = (sbytes + 255) / 256 * 256;
+    SlotLease lease(ctx);
+    Slot& sl = lease.slot();
+    int rc = ensure_dev(sl, o_dst + dbytes);
+    if (rc) return rc;
+    float* d_src = static_cast<float*>(sl.dev);
+    float* d_dst = reinterpret_cast<float*>(static_cast<char*>(sl.dev) + o_dst);
+    HK_HIP(hipMemcpyAsync(d_src, src, sbytes, hipMemcpyHostToDevice, sl.stream));
+    HK_HIP(hk::launch_resample(resampling, d_src, src_width, (long long)src_height * src_width, src_height, src_width,
+                               n_bands, src_nodata_mode, src_nodata, kx, ox, ky, oy, d_dst, dst_width,
+                               (long long)dst_height * dst_width, dst_height, dst_width, dst_fill, sl.stream));
+    HK_HIP(hipMemcpyAsync(dst, d_dst, dbytes, hipMemcpyDeviceToHost, sl.stream));
+    HK_HIP(hipStreamSynchronize(sl.stream));
+    return HK_OK;
+}
+
 int hk_partial_mask(hk_ctx* ctx, const float* in, int64_t in_stride, int32_t in_nodata_mode, float in_nodata,
                     const float* params, int32_t n_param_bands, const float* src, int64_t src_stride, int32_t height,
                     int32_t width, int32_t kh, int32_t kw, float* params_out, float* corr_out, uint8_t* mask_out) {

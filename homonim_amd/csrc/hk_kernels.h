@@ -85,6 +85,12 @@ size_t inpaint_workspace_bytes(int height, long long stride);
 hipError_t launch_inpaint_offsets(const float* offset, const float* gain, const float* r2, float thresh, long long stride,
                                   int height, int width, void* workspace, float* filled, hipStream_t stream);
 
+// Re-sampling between axis-aligned grids (hk_resample.hip).  mode = rasterio.enums.Resampling value (0, 1, 3, 5).
+hipError_t launch_resample(int mode, const float* src, long long src_stride, long long src_band_stride, int sh, int sw,
+                           int n_bands, int nd_mode, float nodata, double kx, double ox, double ky, double oy, float* dst,
+                           long long dst_stride, long long dst_band_stride, int dh, int dw, float dst_fill,
+                           hipStream_t stream);
+
 // returns 0 on pass; writes a diagnostic code otherwise
 hipError_t launch_selftest(int* result_dev, hipStream_t stream);
 

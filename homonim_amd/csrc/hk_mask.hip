@@ -24,7 +24,8 @@ __global__ void __launch_bounds__(256) mask_rows_kernel(const float* __restrict_
             const int xx = x + dx;
             if (xx < 0 || xx >= width) continue;  // zero border
             const float v = in[row + xx], g = gain[row + xx], o = offset[row + xx];
-            const bool valid = nd_mode == 0 ? true : (nd_mode == 1 ? !(v != v) : !(v == nodata));
+            // mode 3: `in` is the source mask re-projected with `average` -- fully covered pixels only (:399)
+            const bool valid = nd_mode == 3 ? (v >= 1.f) : (nd_mode == 0 ? true : (nd_mode == 1 ? !(v != v) : !(v == nodata)));
             c += (valid && (!(g != g) || !(o != o))) ? 1 : 0;
         }
         rowcnt[row + x] = (unsigned short)c;

@@ -1,0 +1,137 @@
+// hk_resample.hip -- re-sampling between same-CRS, north-up, axis-aligned grids: RasterArray.reproject
+// (homonim/raster_array.py:526-578 -> rasterio.warp.reproject -> GDAL warp) as RefSpaceModel / SrcSpaceModel use it
+// (homonim/kernel_model.py:397,480,491,497,520).
+//
+// GDAL is not part of /root/reference and not installed here: its published warp kernels (gdal/alg/gdalwarpkernel.cpp)
+// are RESTATED, parity with GDAL itself unpinned; the arithmetic below is, operation for operation, the one of
+// oracle/oracle_np.py::reproject, which the tests hold it to bit for bit.
+//   mapping : src_col = kx * dst_col + ox, src_row = ky * dst_row + oy on continuous coordinates (integers = pixel edges)
+//   0 nearest      : source pixel containing the destination centre (floor(x + 1e-10))
+//   5 average      : weighted mean of the valid source pixels under the destination pixel's footprint
+//   1 bilinear / 3 cubic_spline : centre pixel must be valid; separable 2 / 4-tap (cubic B-spline) kernel, invalid or
+//                    outside taps skipped, renormalised by the accumulated weight; up-sampling only
+// One thread per destination pixel (gather); float64 accumulation, float32 result.
+#include "hk_kernels.h"
+
+namespace hk {
+
+struct ResampleArgs {
+    const float* src;
+    float* dst;
+    long long src_stride, src_band_stride, dst_stride, dst_band_stride;
+    int sh, sw, dh, dw;
+    int nd_mode;
+    float nodata;
+    float dst_fill;  // value of destination pixels that receive nothing
+    double kx, ox, ky, oy;
+};
+
+__device__ __forceinline__ bool rs_valid(float v, int mode, float nodata) {
+    return mode == 0 ? true : (mode == 1 ? !(v != v) : !(v == nodata));
+}
+
+__device__ __forceinline__ void bspline4(double d, double (&w)[4]) {
+    const double a = 1.0 - d, b = 2.0 - d, c = 3.0 - d;
+    w[0] = a * a * a / 6.0;
+    w[1] = (b * b * b - 4.0 * (a * a * a)) / 6.0;
+    w[2] = (c * c * c - 4.0 * (b * b * b) + 6.0 * (a * a * a)) / 6.0;
+    w[3] = d * d * d / 6.0;
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256) resample_kernel(const ResampleArgs a) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j >= a.dw) return;
+    const float* __restrict__ sp = a.src + (long long)blockIdx.z * a.src_band_stride;
+    float* __restrict__ dp = a.dst + (long long)blockIdx.z * a.dst_band_stride;
+    double result = 0.0;
+    bool got = false;
+    if constexpr (MODE == 0) {
+        const long long cx = (long long)floor(a.kx * ((double)j + 0.5) + a.ox + 1e-10);
+        const long long cy = (long long)floor(a.ky * ((double)i + 0.5) + a.oy + 1e-10);
+        if (cx >= 0 && cx < a.sw && cy >= 0 && cy < a.sh) {
+            const float v = sp[cy * a.src_stride + cx];
+            if (rs_valid(v, a.nd_mode, a.nodata)) result = (double)v, got = true;
+        }
+    } else if constexpr (MODE == 5) {
+        const double y0 = fmax(a.ky * (double)i + a.oy, 0.0), y1 = fmin(a.ky * (double)(i + 1) + a.oy, (double)a.sh);
+        const double x0 = fmax(a.kx * (double)j + a.ox, 0.0), x1 = fmin(a.kx * (double)(j + 1) + a.ox, (double)a.sw);
+        int iy0 = (int)floor(y0 + 1e-10), iy1 = (int)ceil(y1 - 1e-10);
+        int ix0 = (int)floor(x0 + 1e-10), ix1 = (int)ceil(x1 - 1e-10);
+        if (iy0 == iy1 && iy1 < a.sh) ++iy1;
+        if (ix0 == ix1 && ix1 < a.sw) ++ix1;
+        if (iy1 > iy0 && iy0 >= 0 && ix1 > ix0 && ix0 >= 0) {
+            double tot = 0.0, wsum = 0.0;
+            for (int yy = iy0; yy < iy1; ++yy) {
+                double wy = 1.0;
+                if (iy0 + 1 != iy1) wy = yy == iy0 ? 1.0 - (y0 - (double)iy0) : (yy == iy1 - 1 ? 1.0 - ((double)iy1 - y1) : 1.0);
+                for (int xx = ix0; xx < ix1; ++xx) {
+                    const float v = sp[(long long)yy * a.src_stride + xx];
+                    if (!rs_valid(v, a.nd_mode, a.nodata)) continue;
+                    double wx = 1.0;
+                    if (ix0 + 1 != ix1) wx = xx == ix0 ? 1.0 - (x0 - (double)ix0) : (xx == ix1 - 1 ? 1.0 - ((double)ix1 - x1) : 1.0);
+                    const double wgt = wx * wy;
+                    tot += (double)v * wgt;
+                    wsum += wgt;
+                }
+            }
+            if (wsum > 0.0) result = tot / wsum, got = true;
+        }
+    } else {
+        constexpr int NT = MODE == 1 ? 2 : 4, T0 = MODE == 1 ? 0 : -1;
+        const double sy = a.ky * ((double)i + 0.5) + a.oy, sx = a.kx * ((double)j + 0.5) + a.ox;
+        const long long cy = (long long)floor(sy + 1e-10), cx = (long long)floor(sx + 1e-10);
+        if (cx >= 0 && cx < a.sw && cy >= 0 && cy < a.sh && rs_valid(sp[cy * a.src_stride + cx], a.nd_mode, a.nodata)) {
+            const int iy = (int)floor(sy - 0.5), ix = (int)floor(sx - 0.5);
+            const double dy = sy - 0.5 - (double)iy, dx = sx - 0.5 - (double)ix;
+            double wys[4], wxs[4];
+            if constexpr (MODE == 1) {
+                wys[0] = 1.0 - dy, wys[1] = dy, wxs[0] = 1.0 - dx, wxs[1] = dx;
+            } else {
+                bspline4(dy, wys);
+                bspline4(dx, wxs);
+            }
+            double acc = 0.0, wacc = 0.0;
+            for (int tj = 0; tj < NT; ++tj) {
+                const int yy = iy + T0 + tj;
+                if (yy < 0 || yy >= a.sh) continue;
+                for (int ti = 0; ti < NT; ++ti) {
+                    const int xx = ix + T0 + ti;
+                    if (xx < 0 || xx >= a.sw) continue;
+                    const float v = sp[(long long)yy * a.src_stride + xx];
+                    if (!rs_valid(v, a.nd_mode, a.nodata)) continue;
+                    const double wgt = wxs[ti] * wys[tj];
+                    acc += (double)v * wgt;
+                    wacc += wgt;
+                }
+            }
+            if (!(wacc < 1e-6)) {
+                result = (wacc < 0.99999 || wacc > 1.00001) ? acc / wacc : acc;
+                got = true;
+            }
+        }
+    }
+    dp[(long long)i * a.dst_stride + j] = got ? (float)result : a.dst_fill;
+}
+
+hipError_t launch_resample(int mode, const float* src, long long src_stride, long long src_band_stride, int sh, int sw,
+                           int n_bands, int nd_mode, float nodata, double kx, double ox, double ky, double oy, float* dst,
+                           long long dst_stride, long long dst_band_stride, int dh, int dw, float dst_fill,
+                           hipStream_t stream) {
+    ResampleArgs a;
+    a.src = src, a.dst = dst, a.src_stride = src_stride, a.src_band_stride = src_band_stride, a.dst_stride = dst_stride;
+    a.dst_band_stride = dst_band_stride, a.sh = sh, a.sw = sw, a.dh = dh, a.dw = dw, a.nd_mode = nd_mode, a.nodata = nodata;
+    a.dst_fill = dst_fill, a.kx = kx, a.ox = ox, a.ky = ky, a.oy = oy;
+    const dim3 grid((dw + 255) / 256, dh, n_bands), block(256);
+    switch (mode) {
+        case 0: hipLaunchKernelGGL(resample_kernel<0>, grid, block, 0, stream, a); break;
+        case 1: hipLaunchKernelGGL(resample_kernel<1>, grid, block, 0, stream, a); break;
+        case 3: hipLaunchKernelGGL(resample_kernel<3>, grid, block, 0, stream, a); break;
+        case 5: hipLaunchKernelGGL(resample_kernel<5>, grid, block, 0, stream, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace hk

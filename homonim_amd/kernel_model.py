@@ -15,8 +15,9 @@ Differences a caller can observe (all documented in DESIGN.md):
   pixel fails it the reference's GDAL ``fillnodata`` branch is the identity and results are identical; when some
   fail, the offsets are in-painted on the device by a restatement of GDAL's published fill algorithm (parity with
   GDAL itself unpinned, hk_inpaint.hip) and the gains of the failing pixels are recomputed as in :370-371.
-* ``RefSpaceModel`` / ``SrcSpaceModel`` accept same-grid pairs only (GDAL re-projection is section 8f row 1);
-  ``mask_partial`` (kernel_model.py:375-409) is evaluated on the device for that case.
+* ``RefSpaceModel`` / ``SrcSpaceModel`` re-sample between same-CRS, north-up, axis-aligned grids on the device
+  (nearest / bilinear / cubic_spline up-sampling / average: a restatement of GDAL's warp kernels, parity with GDAL
+  unpinned); other CRSs, rotations or re-sampling methods raise ``NotImplementedError``.
 """
 from typing import Dict, Optional, Tuple
 
@@ -161,49 +162,77 @@ def _same_grid(a: RasterArray, b: RasterArray) -> bool:
     return a.transform == b.transform and a.shape == b.shape and a.crs == b.crs
 
 
-_REPROJECT_MSG = (
-    'source and reference blocks are on different grids: re-projection (GDAL warp, homonim/raster_array.py:526-578) '
-    'is outside the MI355X hot path built so far (SURVEY.md section 8f row 1)'
-)
+def _full_coverage_mask(model: KernelModel, in_mask_ra: RasterArray, param_ra: RasterArray) -> np.ndarray:
+    """
+    kernel_model.py:375-409: the mask of parameter-grid pixels fully covered by the input mask (re-projected with
+    `average`, >= 1), having parameters, and whose (kh+2) x (kw+2) neighbourhood is all of that kind (erosion with a zero
+    border).  Returns a bool array on the parameter grid; evaluated on the device.
+    """
+    cover_ra = in_mask_ra.reproject(**param_ra.proj_profile, nodata=None, resampling=Resampling.average,
+                                    context=model.context)
+    _, _, mask = model.context.partial_mask(cover_ra.array, None, param_ra.array[:2], model.kernel_shape, want_mask=True,
+                                            coverage=True)
+    return mask.astype(bool)
 
 
 class RefSpaceModel(KernelModel):
     """
-    Parameters estimated on the reference grid (kernel_model.py:466-503).  With source and reference on the same grid
-    the reference's ``average`` re-projection is the identity, which is the case handled here.
+    Parameters estimated on the reference grid (kernel_model.py:466-503): the source block is re-sampled to the
+    reference grid for ``fit`` and the parameters are re-sampled back to the source grid for ``apply``.  Re-sampling
+    runs on the GPU for same-CRS, axis-aligned grids (hk_resample.hip: a restatement of GDAL's warp kernels).
     """
 
     def fit(self, src_ra: RasterArray, ref_ra: RasterArray) -> RasterArray:
-        if not _same_grid(src_ra, ref_ra):
-            raise NotImplementedError(_REPROJECT_MSG)
+        if not _same_grid(src_ra, ref_ra):  # identical grids: the reference's `average` re-sampling is the identity
+            resampling = self._get_resampling(src_ra.res, ref_ra.res)
+            src_ra = src_ra.reproject(**ref_ra.proj_profile, resampling=resampling, context=self.context)  # :480
         return KernelModel.fit(self, src_ra, ref_ra)
 
     def apply(self, src_ra: RasterArray, param_ra: RasterArray) -> RasterArray:
-        if not _same_grid(src_ra, param_ra):
-            raise NotImplementedError(_REPROJECT_MSG)
+        if _same_grid(src_ra, param_ra):
+            if self._mask_partial:
+                # full-coverage mask of the source mask & parameters, eroded by (kh+2) x (kw+2), then apply (:493-503)
+                _, corr, _ = self.context.partial_mask(
+                    self._band(src_ra, 'src_ra'), src_ra.nodata, param_ra.array[:2], self._kernel_shape,
+                    src=self._band(src_ra, 'src_ra'), want_corr=True
+                )
+                return RasterArray.from_profile(corr, param_ra.profile)
+            # the reference keeps only gain & offset and re-masks them with the source mask (:487,:500); on a shared
+            # grid the parameters are already nodata wherever the source is.
+            return KernelModel.apply(self, src_ra, param_ra)
+
+        _param_ra = RasterArray.from_profile(param_ra.array[:2], param_ra.profile)  # :487
+        resampling = self._get_resampling(param_ra.res, src_ra.res)
+        param_us_ra = _param_ra.reproject(**src_ra.proj_profile, resampling=resampling, context=self.context)  # :491
         if self._mask_partial:
-            # full-coverage mask of the source mask & parameters, eroded by (kh+2) x (kw+2), then apply (:493-503)
-            _, corr, _ = self.context.partial_mask(
-                self._band(src_ra, 'src_ra'), src_ra.nodata, param_ra.array[:2], self._kernel_shape,
-                src=self._band(src_ra, 'src_ra'), want_corr=True
-            )
-            return RasterArray.from_profile(corr, param_ra.profile)
-        # the reference keeps only gain & offset and re-masks them with the source mask (:487,:500); on a shared grid
-        # the parameters are already nodata wherever the source is.
-        return KernelModel.apply(self, src_ra, param_ra)
+            mask = _full_coverage_mask(self, src_ra.mask_ra, _param_ra)  # :495
+            mask_ra = RasterArray(mask.astype('float32'), _param_ra.crs, _param_ra.transform, nodata=None)
+            mask_us_ra = mask_ra.reproject(**src_ra.proj_profile, nodata=0, resampling=Resampling.nearest,
+                                           context=self.context)  # :497
+            param_us_ra.mask = mask_us_ra.array.astype('bool', copy=False)  # :498
+        else:
+            param_us_ra.mask = src_ra.mask  # :500
+        return KernelModel.apply(self, src_ra, param_us_ra)
 
 
 class SrcSpaceModel(KernelModel):
-    """ Parameters estimated on the source grid (kernel_model.py:506-535); same-grid pairs only, as above. """
+    """ Parameters estimated on the source grid (kernel_model.py:506-535): the reference block is re-sampled to it. """
 
     def fit(self, src_ra: RasterArray, ref_ra: RasterArray) -> RasterArray:
+        ref_us_ra = ref_ra
         if not _same_grid(src_ra, ref_ra):
-            raise NotImplementedError(_REPROJECT_MSG)
-        param_ra = KernelModel.fit(self, src_ra, ref_ra)
+            resampling = self._get_resampling(ref_ra.res, src_ra.res)
+            ref_us_ra = ref_ra.reproject(**src_ra.proj_profile, resampling=resampling, context=self.context)  # :520
+        param_ra = KernelModel.fit(self, src_ra, ref_us_ra)
         if self._mask_partial:
             # full-coverage mask of the reference mask & gain/offset, eroded by (kh+2) x (kw+2), on all bands (:526-531)
-            masked, _, _ = self.context.partial_mask(
-                self._band(ref_ra, 'ref_ra'), ref_ra.nodata, param_ra.array, self._kernel_shape, want_params=True
-            )
-            param_ra = RasterArray.from_profile(masked, param_ra.profile)
+            if _same_grid(src_ra, ref_ra):
+                masked, _, _ = self.context.partial_mask(
+                    self._band(ref_ra, 'ref_ra'), ref_ra.nodata, param_ra.array, self._kernel_shape, want_params=True
+                )
+                param_ra = RasterArray.from_profile(masked, param_ra.profile)
+            else:
+                param_ra.mask = _full_coverage_mask(self, ref_ra.mask_ra, param_ra)
+        elif not _same_grid(src_ra, ref_ra):
+            param_ra.mask = src_ra.mask  # :533 (a no-op on a shared grid)
         return param_ra

@@ -10,14 +10,17 @@ properties :223-351, ``profile``/``proj_profile`` :281-296, ``copy`` :389-391):
 * ``nodata = None`` means "every pixel valid"; changing a numeric/NaN nodata re-labels the currently masked pixels;
 * multi-band arrays are band-major and a pixel is valid if it is valid in ANY band.
 
-The GDAL-backed members of the reference class (dataset IO, ``reproject``) are outside this package.
+``reproject`` (raster_array.py:526-578) runs on the GPU for same-CRS, north-up, axis-aligned grids with the nearest /
+bilinear / cubic_spline / average kernels -- a restatement of GDAL's warp kernels, see hk_resample.hip.  Dataset IO
+stays outside this package (GDAL).
 """
 from typing import Dict, Optional, Tuple
 
 import numpy as np
 
+from homonim_amd.enums import Resampling
 from homonim_amd.errors import ImageProfileError
-from homonim_amd.geo import Affine, CRS, Window, _is_affine, _is_crs, window_transform
+from homonim_amd.geo import Affine, CRS, Window, _is_affine, _is_crs, grid_mapping, window_transform
 from homonim_amd.utils import nan_equals
 
 _PROFILE_GEO_KEYS = ('crs', 'transform', 'nodata')
@@ -157,3 +160,30 @@ class RasterArray:
         if relabel or value is None or self._nodata is None:
             self._nodata = value
             self._mask = None
+
+    # -- re-sampling --------------------------------------------------------------------------------------------------
+    def reproject(self, crs=None, transform=None, shape: Optional[Tuple[int, int]] = None,
+                  nodata: Optional[float] = default_nodata, dtype: str = default_dtype,
+                  resampling: Resampling = Resampling.lanczos, context=None) -> 'RasterArray':
+        """
+        Re-sample onto another grid of the same CRS (raster_array.py:526-578).  ``transform`` needs ``shape``; the default
+        is this array's own grid.  Returns a float32 RasterArray with ``nodata`` where nothing valid contributes
+        (0 when ``nodata`` is None, as GDAL leaves the zero-initialised destination).
+        """
+        if transform is not None and shape is None:
+            raise ValueError('If `transform` is specified, `shape` is required')
+        if isinstance(resampling, str):
+            resampling = Resampling[resampling]
+        crs = crs or self._crs
+        if crs != self._crs:
+            raise NotImplementedError('re-projection between different CRSs is not built (GDAL warp)')
+        transform = transform or self._transform
+        shape = tuple(shape or self.shape)
+        if np.dtype(dtype or self.dtype) != np.float32:
+            raise NotImplementedError('re-projection yields float32 only')
+        from homonim_amd import _hk  # deferred: the carrier itself needs no GPU
+        ctx = context or _hk.default_context()
+        fill = 0.0 if nodata is None else float(nodata)
+        out = ctx.reproject(self._array, self._nodata, grid_mapping(self._transform, transform), shape, int(resampling),
+                            fill)
+        return RasterArray(out, crs, transform, nodata=nodata)

@@ -109,13 +109,26 @@ int hk_fit_apply(hk_ctx* ctx, const hk_fit_desc* desc, const float* src, int64_t
                  float* params_out /* nullable */, int32_t n_param_bands, float* corr_out, double* norm_out,
                  uint64_t* r2_fail_count);
 
+/* RasterArray.reproject (homonim/raster_array.py:526-578 -> GDAL warp) between two grids of the SAME CRS that are north-up
+ * and axis-aligned, as RefSpaceModel / SrcSpaceModel call it (homonim/kernel_model.py:397,480,491,497,520).
+ *   mapping   : src_col = kx * dst_col + ox, src_row = ky * dst_row + oy on continuous pixel coordinates whose integers
+ *               are pixel edges (kx, ky > 0);
+ *   resampling: rasterio.enums.Resampling value -- 0 nearest, 1 bilinear, 3 cubic_spline (both up-sampling only),
+ *               5 average;
+ *   src       : n_bands x src_h x src_w float32 with the given nodata; dst: n_bands x dst_h x dst_w float32, pixels that
+ *               receive nothing are set to dst_fill (the destination nodata; 0 when that is None). */
+int hk_reproject(hk_ctx* ctx, const float* src, int32_t n_bands, int32_t src_height, int32_t src_width,
+                 int32_t src_nodata_mode, float src_nodata, double kx, double ox, double ky, double oy, int32_t resampling,
+                 float* dst, int32_t dst_height, int32_t dst_width, float dst_fill);
+
 /* `mask_partial` on a shared grid: KernelModel._full_coverage_mask (homonim/kernel_model.py:375-409) -- the mask of
  * pixels that are valid in `in` (nodata as given) and have parameters, eroded by a (kh+2) x (kw+2) rectangle with a
  * zero border -- followed by what the reference does with it:
  *   RefSpaceModel.apply (:493-503): in = the source block, corr_out = gain * src + offset with parameters outside the
  *                                   mask set to NaN (pass src = in);
  *   SrcSpaceModel.fit   (:526-531): in = the reference block, params_out = all n_param_bands masked.
- * params: n_param_bands x H x W float32 (band 0 gain, 1 offset); params_out / corr_out / mask_out (uint8) nullable. */
+ * params: n_param_bands x H x W float32 (band 0 gain, 1 offset); params_out / corr_out / mask_out (uint8) nullable.
+ * in_nodata_mode 3 = `in` is a coverage fraction (the mask re-projected with `average`): valid where in >= 1 (:399). */
 int hk_partial_mask(hk_ctx* ctx, const float* in, int64_t in_stride, int32_t in_nodata_mode, float in_nodata,
                     const float* params, int32_t n_param_bands, const float* src, int64_t src_stride, int32_t height,
                     int32_t width, int32_t kh, int32_t kw, float* params_out, float* corr_out, uint8_t* mask_out);

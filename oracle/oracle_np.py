@@ -354,6 +354,141 @@ def fit(model: str, src, src_nodata, ref, ref_nodata, kernel_shape=(5, 5), find_
 
 
 # ----------------------------------------------------------------------------------------------------------------------
+# Re-sampling around the path: RasterArray.reproject (raster_array.py:526-578) -> rasterio.warp.reproject -> GDAL warp.
+# GDAL is NOT in /root/reference (rasterio>=1.1, un-pinned, pyproject.toml:7) and not installed here: the published warp
+# kernels (gdal/alg/gdalwarpkernel.cpp) are restated for the only geometry the block pipeline produces -- same CRS,
+# north-up axis-aligned grids -- PARITY WITH GDAL UNPINNED.  Anchors: the reference tests' known answers for the aligned
+# 2:1 pair (tests/test_kernel_model.py:32-117) and resampling invariants (tests/test_oracle_golden.py).
+#
+#   mapping  : (kx, ox, ky, oy) with src_col = kx * dst_col + ox, src_row = ky * dst_row + oy on continuous pixel
+#              coordinates whose integers are pixel EDGES (pixel i covers [i, i+1)).
+#   nearest  : GWKNearest -- the source pixel containing the destination pixel centre (floor(x + 1e-10)).
+#   average  : GWKAverageOrMode -- weighted mean of the valid source pixels overlapping the destination pixel's footprint,
+#              weight = fractional overlap per axis; nodata when no valid pixel.
+#   bilinear / cubic_spline : GWKResample -- the source pixel under the destination centre must be valid; separable
+#              2 / 4-tap kernel (cubic B-spline) around it, taps outside the raster or invalid are skipped and the sum is
+#              renormalised by the accumulated weight (nodata below 1e-6).  Up-sampling only (kernel not stretched).
+RESAMPLING_CODES = {'nearest': 0, 'bilinear': 1, 'cubic_spline': 3, 'average': 5}
+
+
+def grid_mapping(src_transform, dst_transform):
+    """ (kx, ox, ky, oy) between two axis-aligned affine transforms (a, b, c, d, e, f), b = d = 0. """
+    sa, sb, sc, sd, se, sf = [float(v) for v in src_transform[:6]]
+    da, db, dc, dd, de, df = [float(v) for v in dst_transform[:6]]
+    if sb or sd or db or dd:
+        raise NotImplementedError('rotated / sheared grids')
+    return da / sa, (dc - sc) / sa, de / se, (df - sf) / se
+
+
+def _bspline_weights(delta):
+    """ cubic B-spline weights of taps -1, 0, 1, 2 at fractional offset delta (GWKBSpline). """
+    d = np.float64(delta)
+    a, b, c = 1.0 - d, 2.0 - d, 3.0 - d  # cubes as explicit products so that every implementation rounds alike
+    w0 = a * a * a / 6.0
+    w1 = (b * b * b - 4.0 * (a * a * a)) / 6.0
+    w2 = (c * c * c - 4.0 * (b * b * b) + 6.0 * (a * a * a)) / 6.0
+    w3 = d * d * d / 6.0
+    return (w0, w1, w2, w3)
+
+
+def reproject(src: np.ndarray, src_nodata, mapping, dst_shape, dst_nodata=np.nan, resampling='average',
+              dtype=np.float32) -> np.ndarray:
+    """ One band (2-D) through the restated GDAL warp kernels; see the block comment above. """
+    kx, ox, ky, oy = mapping
+    if kx <= 0 or ky <= 0:
+        raise NotImplementedError('flipped grids')
+    sh, sw = src.shape
+    dh, dw = dst_shape
+    valid = mask_of(src, src_nodata)
+    srcd = src.astype(np.float64)
+    fill = 0 if dst_nodata is None else dst_nodata
+    out = np.full((dh, dw), fill, dtype=np.float64)
+    got = np.zeros((dh, dw), bool)
+
+    if resampling == 'nearest':
+        cx = np.floor(kx * (np.arange(dw) + 0.5) + ox + 1e-10).astype(np.int64)
+        cy = np.floor(ky * (np.arange(dh) + 0.5) + oy + 1e-10).astype(np.int64)
+        inx, iny = (cx >= 0) & (cx < sw), (cy >= 0) & (cy < sh)
+        yy, xx = np.meshgrid(np.clip(cy, 0, sh - 1), np.clip(cx, 0, sw - 1), indexing='ij')
+        ok = iny[:, None] & inx[None, :] & valid[yy, xx]
+        out[ok] = srcd[yy, xx][ok]
+        got = ok
+    elif resampling == 'average':
+        for i in range(dh):
+            y0, y1 = max(ky * i + oy, 0.0), min(ky * (i + 1) + oy, float(sh))
+            iy0, iy1 = int(np.floor(y0 + 1e-10)), int(np.ceil(y1 - 1e-10))
+            if iy0 == iy1 and iy1 < sh:
+                iy1 += 1
+            if iy1 <= iy0 or iy0 < 0:
+                continue
+            wy = np.ones(iy1 - iy0)
+            if iy0 + 1 != iy1:
+                wy[0] = 1 - (y0 - iy0)
+                wy[-1] = 1 - (iy1 - y1)
+            for j in range(dw):
+                x0, x1 = max(kx * j + ox, 0.0), min(kx * (j + 1) + ox, float(sw))
+                ix0, ix1 = int(np.floor(x0 + 1e-10)), int(np.ceil(x1 - 1e-10))
+                if ix0 == ix1 and ix1 < sw:
+                    ix1 += 1
+                if ix1 <= ix0 or ix0 < 0:
+                    continue
+                wx = np.ones(ix1 - ix0)
+                if ix0 + 1 != ix1:
+                    wx[0] = 1 - (x0 - ix0)
+                    wx[-1] = 1 - (ix1 - x1)
+                tot = wsum = 0.0
+                for a in range(iy0, iy1):      # row-major accumulation order, as GDAL
+                    for b in range(ix0, ix1):
+                        if valid[a, b]:
+                            wgt = wx[b - ix0] * wy[a - iy0]
+                            tot += srcd[a, b] * wgt
+                            wsum += wgt
+                if wsum > 0:
+                    out[i, j] = tot / wsum
+                    got[i, j] = True
+    elif resampling in ('bilinear', 'cubic_spline'):
+        if kx > 1 + 1e-9 or ky > 1 + 1e-9:
+            raise NotImplementedError(f'{resampling} down-sampling (stretched kernel)')
+        taps = (0, 1) if resampling == 'bilinear' else (-1, 0, 1, 2)
+        for i in range(dh):
+            sy = ky * (i + 0.5) + oy
+            cy = int(np.floor(sy + 1e-10))
+            iy = int(np.floor(sy - 0.5))
+            dy = sy - 0.5 - iy
+            wys = (1 - dy, dy) if resampling == 'bilinear' else _bspline_weights(dy)
+            for j in range(dw):
+                sx = kx * (j + 0.5) + ox
+                cx = int(np.floor(sx + 1e-10))
+                if cx < 0 or cx >= sw or cy < 0 or cy >= sh or not valid[cy, cx]:
+                    continue   # the source pixel under the destination centre must be valid
+                ix = int(np.floor(sx - 0.5))
+                dx = sx - 0.5 - ix
+                wxs = (1 - dx, dx) if resampling == 'bilinear' else _bspline_weights(dx)
+                acc = wacc = 0.0
+                for tj, wyv in zip(taps, wys):
+                    a = iy + tj
+                    if a < 0 or a >= sh:
+                        continue
+                    for ti, wxv in zip(taps, wxs):
+                        b = ix + ti
+                        if b < 0 or b >= sw or not valid[a, b]:
+                            continue
+                        wgt = float(wxv) * float(wyv)
+                        acc += srcd[a, b] * wgt
+                        wacc += wgt
+                if wacc < 1e-6:
+                    continue
+                out[i, j] = acc / wacc if (wacc < 0.99999 or wacc > 1.00001) else acc
+                got[i, j] = True
+    else:
+        raise NotImplementedError(resampling)
+    res = out.astype(dtype)
+    if dst_nodata is not None:
+        res[~got] = dst_nodata
+    return res
+
+
+# ----------------------------------------------------------------------------------------------------------------------
 # synthetic workload generator (SURVEY.md section 8d) -- shared by golden generation, tests and the CPU-baseline sample
 def synth_pair(h: int, w: int, seed: int = 0, nodata_variant: str = 'none', dn_like: bool = False):
     """

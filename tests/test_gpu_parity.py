@@ -691,3 +691,118 @@ def test_fill_nodata_known_answers():
     assert out[2, 1] == 10 and out[2, 5] == 20                    # sources untouched
     far = onp.fill_nodata(np.pad(img, ((0, 0), (0, 300))), np.pad(msk, ((0, 0), (0, 300))))
     assert far[2, 5 + 150] == 0                                   # nothing within 100 px: left as it was
+
+
+# -- re-sampling around the path (raster_array.py:526-578; kernel_model.py:466-535) --------------------------------------
+def _ref_arrays():
+    """ reference tests/conftest.py:74-140: 100 cm gradient with a 1-px NaN frame, its 2x up-sampled 50 cm version with a
+    2-px frame, and their north-up transforms (origin (5, -5)). """
+    a100 = np.array(range(1, 201), dtype='float32').reshape(20, 10)
+    a100[:, [0, -1]] = np.nan
+    a100[[0, -1], :] = np.nan
+    a50 = np.kron(a100, np.ones((2, 2))).astype(np.float32)
+    a50[:, [0, 1, -2, -1]] = np.nan
+    a50[[0, 1, -2, -1], :] = np.nan
+    t100 = Affine(1, 0, 0, 0, -1, 0) * Affine.translation(5, 5)
+    t50 = t100 * Affine.scale(0.5)
+    return RasterArray(a100, CRS(), t100), RasterArray(a50, CRS(), t50)
+
+
+@pytest.mark.parametrize('resampling, mapping, dst_shape', [
+    ('average', (2., 0., 2., 0.), (75, 120)), ('average', (2.2, 0.3, 1.9, -0.4), (70, 100)),
+    ('average', (10., 3., 10., 1.), (15, 24)), ('average', (.5, 0., .5, 0.), (300, 480)),
+    ('cubic_spline', (.5, 0., .5, 0.), (300, 480)), ('cubic_spline', (.45, -.5, .45, -.5), (340, 540)),
+    ('bilinear', (.45, -.5, .45, -.5), (340, 540)), ('nearest', (.5, 0., .5, 0.), (300, 480)),
+    ('nearest', (2.2, 0.3, 1.9, -0.4), (70, 100)), ('average', (1., 0., 1., 0.), (150, 240)),
+])
+@pytest.mark.parametrize('nodata', [np.nan, None, 0.])
+def test_device_resamplers_equal_oracle(ctx, resampling, mapping, dst_shape, nodata):
+    """ hk_reproject vs the oracle's restatement of the same GDAL kernels: bit-exact float32, NaN pattern included. """
+    src, _ = onp.synth_pair(150, 240, 13, 'frame+holes' if nodata is not None else 'none')
+    if nodata == 0.:
+        src = np.nan_to_num(src, nan=0.)
+    code = onp.RESAMPLING_CODES[resampling]
+    got = ctx.reproject(src, nodata, mapping, dst_shape, code, np.nan)
+    exp = onp.reproject(src, nodata, mapping, dst_shape, dst_nodata=np.nan, resampling=resampling)
+    assert_same_f32(got, exp, f'{resampling} {mapping}')
+
+
+@pytest.mark.parametrize('model, kernel_shape', [
+    (Model.gain, (1, 1)), (Model.gain, (3, 3)), (Model.gain_blk_offset, (1, 1)), (Model.gain_blk_offset, (5, 5)),
+    (Model.gain_offset, (5, 5)),
+])
+def test_ref_and_src_space_fit_different_grids(ctx, model, kernel_shape):
+    """ reference tests/test_kernel_model.py:32-81: src = 2x up-sampled ref  =>  gain ~ 1, offset ~ 0 in both spaces. """
+    ra100, ra50 = _ref_arrays()
+    km = RefSpaceModel(model, kernel_shape, mask_partial=False, r2_inpaint_thresh=0.25)
+    param_ra = km.fit(ra50, ra100.copy())
+    assert param_ra.shape == ra100.shape and param_ra.transform == ra100.transform
+    assert (ra100.mask == param_ra.mask).all()
+    assert param_ra.array[0, param_ra.mask] == pytest.approx(1, abs=1e-2)
+    assert param_ra.array[1, param_ra.mask] == pytest.approx(0, abs=1e-2)
+    km = SrcSpaceModel(model, kernel_shape, mask_partial=False, r2_inpaint_thresh=0.25)
+    param_ra = km.fit(ra100, ra50)
+    assert param_ra.shape == ra100.shape and param_ra.transform == ra100.transform
+    assert (ra100.mask == param_ra.mask).all()
+    assert param_ra.array[0, param_ra.mask] == pytest.approx(1, abs=1e-2)
+    assert param_ra.array[1, param_ra.mask] == pytest.approx(0, abs=1e-2)
+
+
+def test_ref_space_apply_different_grids(ctx):
+    """ reference tests/test_kernel_model.py:84-117: parameters == 1 on the 100 cm grid applied to the 50 cm source. """
+    ra100, ra50 = _ref_arrays()
+    km = RefSpaceModel(Model.gain_blk_offset, (5, 5), mask_partial=False)
+    param_ra = ra100.copy()
+    pmask = param_ra.mask
+    param_ra.array = np.ones((2, *param_ra.shape), dtype='float32')
+    param_ra.mask = pmask
+    out_ra = km.apply(ra50, param_ra)
+    assert out_ra.transform == ra50.transform and out_ra.shape == ra50.shape
+    assert (ra50.mask == out_ra.mask).all()
+    assert out_ra.array[out_ra.mask] == pytest.approx(ra50.array[out_ra.mask] + 1, abs=1e-2)
+
+
+@pytest.mark.parametrize('kernel_shape, mask_partial', [((1, 1), False), ((1, 1), True), ((3, 3), True), ((3, 5), True),
+                                                        ((5, 5), True)])
+def test_ref_and_src_masking_different_grids(ctx, kernel_shape, mask_partial):
+    """ reference tests/test_kernel_model.py:206-273: mask_partial across grids -- the output mask equals the source mask
+    averaged to the parameter grid (>= 1), eroded by (k + 2), brought back with nearest. """
+    ra100, ra50 = _ref_arrays()
+    km = RefSpaceModel(Model.gain_blk_offset, kernel_shape, mask_partial=mask_partial)
+    param_ra = ra100.copy()
+    pmask = param_ra.mask
+    param_ra.array = np.ones((2, *param_ra.shape), dtype='float32')
+    param_ra.mask = pmask
+    out_ra = km.apply(ra50.copy(), param_ra)
+    if not mask_partial:
+        assert (ra50.mask == out_ra.mask).all()
+    else:
+        assert ra50.mask.sum() > out_ra.mask.sum() and ra50.mask[out_ra.mask].all()
+        cover = onp.reproject(ra50.mask.astype(np.float32), None, (2., 0., 2., 0.), ra100.shape, dst_nodata=None,
+                              resampling='average')
+        exp = onp.full_coverage_mask(cover >= 1, param_ra.array, kernel_shape)
+        exp_us = onp.reproject(exp.astype(np.float32), None, (.5, 0., .5, 0.), ra50.shape, dst_nodata=0,
+                               resampling='nearest').astype(bool)
+        assert (exp_us == out_ra.mask).all()
+    # src space: parameters on the 100 cm source grid, reference at 50 cm
+    km = SrcSpaceModel(Model.gain_blk_offset, kernel_shape, mask_partial=mask_partial)
+    p = km.fit(ra100, ra50)
+    if not mask_partial:
+        assert (ra100.mask == p.mask).all()
+    else:
+        assert ra100.mask.sum() > p.mask.sum() and ra100.mask[p.mask].all()
+        exp = onp.full_coverage_mask(ra100.mask, np.where(ra100.mask, 1, np.nan)[None].repeat(2, 0), kernel_shape)
+        assert (exp == p.mask).all()
+
+
+def test_force_proc_crs(ctx):
+    """ reference tests/test_kernel_model.py:276-293: the 'wrong' space still gives corrected ~ source. """
+    ra100, ra50 = _ref_arrays()
+    km = RefSpaceModel(Model.gain_blk_offset, (5, 5), mask_partial=False)
+    p = km.fit(ra100, ra50.copy())       # low-res source, high-res reference, fitted on the reference grid
+    out = km.apply(ra100, p)
+    assert ra100.array[ra100.mask] == pytest.approx(out.array[out.mask], abs=2)
+    km = SrcSpaceModel(Model.gain_blk_offset, (5, 5), mask_partial=False)
+    p = km.fit(ra50, ra100)
+    out = km.apply(ra50, p)
+    assert ra50.array[ra50.mask] == pytest.approx(out.array[out.mask], abs=2)

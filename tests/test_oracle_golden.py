@@ -110,3 +110,44 @@ def test_oracle_full_coverage_mask_matches_reference(case):
         masked = np.where(cover, params, np.float32(np.nan))
         assert_same_f32(masked, g[case['name'] + '_params'], 'params')
         assert_same_f32(onp.apply(src, masked), g[case['name'] + '_corr'], 'corrected')
+
+
+# -- restated GDAL warp kernels (parity with GDAL unpinned): invariants every implementation of them must satisfy ---------
+def test_reproject_oracle_invariants():
+    a = np.array(range(1, 201), dtype='float32').reshape(20, 10)
+    a[:, [0, -1]] = np.nan
+    a[[0, -1], :] = np.nan
+    k = np.kron(a, np.ones((2, 2))).astype(np.float32)
+    a50 = k.copy()
+    a50[:, [0, 1, -2, -1]] = np.nan
+    a50[[0, 1, -2, -1], :] = np.nan
+    # reference conftest arrays (tests/conftest.py:74-89): average 50 cm -> 100 cm gives back the 100 cm array exactly
+    down = onp.reproject(a50, np.nan, (2., 0., 2., 0.), (20, 10), resampling='average')
+    assert_same_f32(down, a, 'average 2:1')
+    # nearest 1:2 replicates pixels; the identity mapping is the identity for every kernel
+    assert_same_f32(onp.reproject(a, np.nan, (.5, 0., .5, 0.), (40, 20), resampling='nearest'), k, 'nearest 1:2')
+    for rs in ('nearest', 'average', 'bilinear', 'cubic_spline'):
+        ident = onp.reproject(a, np.nan, (1., 0., 1., 0.), (20, 10), resampling=rs)
+        if rs == 'cubic_spline':   # the B-spline smooths: identity only for the mask and for linear ramps
+            assert (np.isnan(ident) == np.isnan(a)).all()
+            assert ident[5:15, 3:7] == pytest.approx(a[5:15, 3:7], abs=1e-4)
+        else:
+            assert_same_f32(ident, a, f'{rs} identity')
+    # partition of unity: constants are preserved wherever anything valid contributes, for odd scales and offsets
+    c = np.full((9, 11), 3.25, np.float32)
+    c[4, 5] = np.nan
+    for rs, m in (('cubic_spline', (.37, .2, .41, .1)), ('bilinear', (.5, .25, .5, .25)), ('average', (2.3, .2, 1.7, .1)),
+                  ('average', (.6, 0., .6, 0.))):
+        shape = (int(9 / m[2]), int(11 / m[0]))
+        out = onp.reproject(c, np.nan, m, shape, resampling=rs)
+        # (GDAL skips the renormalisation while the weight sum is within 1 +- 1e-5, hence 1e-4 and not 1e-7)
+        assert np.nanmax(np.abs(out - 3.25)) < 1e-4 and (~np.isnan(out)).sum() > 0.5 * out.size, rs
+    # average is mean preserving on aligned integer ratios; nodata=None destinations are 0 where empty
+    rng = np.random.default_rng(0)
+    r = rng.uniform(0, 1, (12, 18)).astype(np.float32)
+    avg = onp.reproject(r, None, (3., 0., 3., 0.), (4, 6), resampling='average')
+    assert avg == pytest.approx(r.reshape(4, 3, 6, 3).mean(axis=(1, 3)), rel=1e-6)
+    off = onp.reproject(r, None, (1., 30., 1., 0.), (12, 18), dst_nodata=None, resampling='nearest')
+    assert (off == 0).all()
+    with pytest.raises(NotImplementedError):
+        onp.reproject(r, None, (2., 0., 2., 0.), (6, 9), resampling='cubic_spline')
