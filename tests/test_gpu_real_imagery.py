@@ -1,0 +1,64 @@
+"""
+BASELINE.json configs[0] in miniature, on the GPU: a crop of the reference's own test rasters (NGI 5 m aerial RGB, uint8,
+nodata 0, vs Sentinel-2 10 m; grids offset by a fraction of a pixel -- tests/golden/real_imagery_crop.npz,
+oracle/extract_real_imagery.py) through the full RefSpaceModel / SrcSpaceModel pipeline: average down-sampling, kernel
+model fit, cubic-spline up-sampling of the parameters (or of the reference), apply.
+
+GDAL is not available, so the acceptance bar is the reference's own integration criterion
+(tests/integration.py:79-83): the corrected image agrees better with the reference than the source did -- r2 up,
+RMSE and rRMSE down, per band -- plus the mask rules of :85-103.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_DIR
+from homonim_amd import Affine, CRS, Model, RasterArray, RefSpaceModel, Resampling, SrcSpaceModel
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def pair():
+    g = np.load(os.path.join(GOLDEN_DIR, 'real_imagery_crop.npz'))
+    src_tf, ref_tf = Affine(*g['src_transform']), Affine(*g['ref_transform'])
+    return g['src'], src_tf, float(g['src_nodata']), g['ref'], ref_tf
+
+
+def _compare(img_ra: RasterArray, ref_ra: RasterArray):
+    """ RasterCompare in a nutshell (homonim/compare.py:232-256,142-186): bring the finer image to the reference grid
+    with `average`, then r2 / RMSE / rRMSE over the jointly valid pixels. """
+    ds = img_ra.reproject(**ref_ra.proj_profile, resampling=Resampling.average)
+    m = ds.mask & ref_ra.mask
+    x, y = ds.array[m].astype(np.float64), ref_ra.array[m].astype(np.float64)
+    r2 = np.corrcoef(x, y)[0, 1] ** 2
+    rmse = np.sqrt(np.mean((x - y) ** 2))
+    return dict(r2=r2, rmse=rmse, rrmse=rmse / y.mean(), n=int(m.sum()))
+
+
+@pytest.mark.parametrize('cls, model, kernel_shape, mask_partial', [
+    (RefSpaceModel, Model.gain_blk_offset, (5, 5), False),
+    (RefSpaceModel, Model.gain, (1, 1), False),
+    (RefSpaceModel, Model.gain_offset, (15, 15), False),
+    (RefSpaceModel, Model.gain_blk_offset, (5, 5), True),
+    (SrcSpaceModel, Model.gain_blk_offset, (31, 31), False),
+])
+def test_correction_improves_agreement_with_reference(pair, cls, model, kernel_shape, mask_partial):
+    src, src_tf, src_nodata, ref, ref_tf = pair
+    crs = CRS('EPSG:32735')
+    km = cls(model, kernel_shape, mask_partial=mask_partial)
+    for band in range(src.shape[0]):
+        src_ra = RasterArray(src[band].astype(np.float32), crs, src_tf, nodata=src_nodata)
+        ref_ra = RasterArray(ref[band].astype(np.float32), crs, ref_tf, nodata=None)
+        param_ra = km.fit(src_ra, ref_ra)
+        corr_ra = km.apply(src_ra, param_ra)
+        assert corr_ra.shape == src_ra.shape and corr_ra.transform == src_ra.transform
+        before, after = _compare(src_ra, ref_ra), _compare(corr_ra, ref_ra)
+        assert after['r2'] > before['r2'], (band, before, after)
+        assert after['rmse'] < before['rmse'], (band, before, after)
+        assert after['rrmse'] < before['rrmse'], (band, before, after)
+        if not mask_partial:
+            assert (corr_ra.mask == src_ra.mask).all()
+        else:
+            assert 0 < corr_ra.mask.sum() < src_ra.mask.sum() and src_ra.mask[corr_ra.mask].all()
