@@ -94,6 +94,119 @@ def block_pairs(shape: Tuple[int, int], n_bands: int, overlap: Tuple[int, int] =
                 yield BlockPair(band_i, win_in, win_in, win_out, win_out, outer)
 
 
+class Grid(NamedTuple):
+    """ A north-up raster grid: geo-transform + size (what the block partition needs of a rasterio dataset). """
+    transform: Affine
+    height: int
+    width: int
+
+    @property
+    def res(self) -> Tuple[float, float]:
+        return abs(self.transform.a), abs(self.transform.e)
+
+    def window_bounds(self, win: Window) -> Tuple[float, float, float, float]:
+        """ (left, bottom, right, top) of a pixel window. """
+        t = self.transform
+        return (t.c + win.col_off * t.a, t.f + (win.row_off + win.height) * t.e, t.c + (win.col_off + win.width) * t.a,
+                t.f + win.row_off * t.e)
+
+    @property
+    def bounds(self) -> Tuple[float, float, float, float]:
+        return self.window_bounds(Window(0, 0, self.width, self.height))
+
+    def window(self, left: float, bottom: float, right: float, top: float) -> Window:
+        """ The (fractional) pixel window of a bounding box. """
+        t = self.transform
+        return Window((left - t.c) / t.a, (top - t.f) / t.e, (right - left) / t.a, (bottom - top) / t.e)
+
+
+def expand_window_to_grid(win: Window, expand_pixels: Tuple[int, int] = (0, 0)) -> Window:
+    """ The smallest whole-pixel window containing ``win`` grown by ``expand_pixels`` (rows, cols)
+    (homonim/utils.py:59-81). """
+    col_off = math.floor(win.col_off - expand_pixels[1])
+    row_off = math.floor(win.row_off - expand_pixels[0])
+    col_frac = (win.col_off - expand_pixels[1]) - col_off
+    row_frac = (win.row_off - expand_pixels[0]) - row_off
+    width = math.ceil(win.width + 2 * expand_pixels[1] + col_frac)
+    height = math.ceil(win.height + 2 * expand_pixels[0] + row_frac)
+    return Window(int(col_off), int(row_off), int(width), int(height))
+
+
+def round_window_to_grid(win: Window) -> Window:
+    """ ``win`` with its edges rounded (half to even) to whole pixels (homonim/utils.py:84-101). """
+    r0, r1 = round(win.row_off), round(win.row_off + win.height)
+    c0, c1 = round(win.col_off), round(win.col_off + win.width)
+    return Window(int(c0), int(r0), int(c1 - c0), int(r1 - r0))
+
+
+def pair_windows(src: Grid, ref: Grid) -> Tuple[Window, Window]:
+    """ (src_win, ref_win): the reference window covering the source, and the (possibly boundless) source window covering
+    that -- so that blocks re-project between the two grids without losing data (homonim/raster_pair.py:289-291). """
+    ref_win = expand_window_to_grid(ref.window(*src.bounds))
+    src_win = expand_window_to_grid(src.window(*ref.window_bounds(ref_win)))
+    return src_win, ref_win
+
+
+def resolve_proc_crs(src: Grid, ref: Grid, proc_crs: ProcCrs = ProcCrs.auto) -> ProcCrs:
+    """ auto -> the grid with the larger pixels (homonim/raster_pair.py:193-224). """
+    src_smaller = src.res[0] * src.res[1] <= ref.res[0] * ref.res[1]
+    proc_crs = ProcCrs(proc_crs)
+    if proc_crs == ProcCrs.auto:
+        return ProcCrs.ref if src_smaller else ProcCrs.src
+    if (proc_crs == ProcCrs.src and src_smaller) or (proc_crs == ProcCrs.ref and not src_smaller):
+        import warnings
+        rec = ProcCrs.ref if src_smaller else ProcCrs.src
+        warnings.warn(f'proc_crs={rec} is recommended for these pixel sizes.', category=ConfigWarning)
+    return proc_crs
+
+
+def block_pairs_multires(src: Grid, ref: Grid, proc_crs: ProcCrs, n_bands: int, overlap: Tuple[int, int] = (0, 0),
+                         max_block_mem: float = math.inf) -> Iterator[BlockPair]:
+    """
+    The reference's block partition for a source / reference pair on DIFFERENT grids of one CRS
+    (homonim/raster_pair.py:227-269,342-428): blocks are cut on the processing grid, then mapped to whole-pixel windows
+    of the other grid (in-blocks expanded, out-blocks rounded).  Source in-blocks may reach beyond the image (boundless).
+    """
+    src_win, ref_win = pair_windows(src, ref)
+    proc_is_ref = ProcCrs(proc_crs) == ProcCrs.ref
+    proc, other = (ref, src) if proc_is_ref else (src, ref)
+    proc_win = ref_win if proc_is_ref else src_win
+    src_area, ref_area = src.res[0] * src.res[1], ref.res[0] * ref.res[1]
+    if proc_is_ref:
+        mem_scale = src_area / ref_area if ref_area > src_area else 1.
+    else:
+        mem_scale = 1. if ref_area > src_area else ref_area / src_area
+    mem = math.inf if (max_block_mem is None or max_block_mem <= 0) else max_block_mem * mem_scale
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore', ConfigWarning)  # the small-block warning is re-issued below in source pixels
+        blk_r, blk_c = auto_block_shape((proc_win.height, proc_win.width), mem)
+    if (blk_r / mem_scale < 256 or blk_c / mem_scale < 256) and (blk_r < proc_win.height or blk_c < proc_win.width):
+        warnings.warn(f'The auto block shape is small: {(blk_r, blk_c)}.  Increase `max_block_mem` to improve '
+                      'processing times.', category=ConfigWarning)
+    ov_r, ov_c = int(overlap[0]), int(overlap[1])
+    if blk_r <= ov_r or blk_c <= ov_c:
+        raise BlockSizeError('The auto block shape is smaller than the overlap.  Increase `max_block_mem`.')
+    p_r0, p_c0 = proc_win.row_off, proc_win.col_off
+    p_r1, p_c1 = p_r0 + proc_win.height, p_c0 + proc_win.width
+    for band_i in range(n_bands):
+        for r in range(p_r0 - ov_r, p_r1 - ov_r, blk_r):
+            for c in range(p_c0 - ov_c, p_c1 - ov_c, blk_c):
+                in_r0, in_c0 = max(r, p_r0), max(c, p_c0)
+                in_r1, in_c1 = min(r + blk_r + 2 * ov_r, p_r1), min(c + blk_c + 2 * ov_c, p_c1)
+                out_r0, out_c0 = max(r + ov_r, p_r0), max(c + ov_c, p_c0)
+                out_r1, out_c1 = min(r + blk_r + ov_r, p_r1), min(c + blk_c + ov_c, p_c1)
+                outer = in_r0 <= p_r0 or in_c0 <= p_c0 or in_r1 >= p_r1 or in_c1 >= p_c1
+                proc_in = Window(in_c0, in_r0, in_c1 - in_c0, in_r1 - in_r0)
+                proc_out = Window(out_c0, out_r0, out_c1 - out_c0, out_r1 - out_r0)
+                other_in = expand_window_to_grid(other.window(*proc.window_bounds(proc_in)))
+                other_out = round_window_to_grid(other.window(*proc.window_bounds(proc_out)))
+                if proc_is_ref:
+                    yield BlockPair(band_i, other_in, proc_in, other_out, proc_out, outer)
+                else:
+                    yield BlockPair(band_i, proc_in, other_in, proc_out, other_out, outer)
+
+
 def shard(items: Sequence, index: int, count: int) -> List:
     """ The work items of shard ``index`` of ``count`` (round-robin): shards are disjoint and cover ``items``. """
     if count < 1 or not (0 <= index < count):
@@ -113,11 +226,17 @@ class RasterFuse:
 
     def __init__(self, src: Union[np.ndarray, RasterArray], ref: Union[np.ndarray, RasterArray],
                  src_nodata: Optional[float] = float('nan'), ref_nodata: Optional[float] = float('nan'),
-                 proc_crs: ProcCrs = ProcCrs.auto, crs: Optional[CRS] = None, transform: Optional[Affine] = None):
+                 proc_crs: ProcCrs = ProcCrs.auto, crs: Optional[CRS] = None, transform: Optional[Affine] = None,
+                 ref_transform: Optional[Affine] = None):
+        """
+        ``transform`` / ``ref_transform``: geo-transforms of the source / reference rasters (same CRS, north-up).  When
+        they (or the shapes) differ, blocks are cut on the processing grid and re-sampled on the device as the
+        reference does through GDAL (RefSpaceModel / SrcSpaceModel); the reference must cover the source.
+        """
         if isinstance(src, RasterArray):
             src, src_nodata, crs, transform = src.array, src.nodata, src.crs, src.transform
         if isinstance(ref, RasterArray):
-            ref, ref_nodata = ref.array, ref.nodata
+            ref, ref_nodata, ref_transform = ref.array, ref.nodata, ref.transform
         src = np.asarray(src)
         ref = np.asarray(ref)
         if src.ndim == 2:
@@ -126,16 +245,24 @@ class RasterFuse:
             ref = ref[None]
         if src.ndim != 3 or ref.ndim != 3:
             raise ValueError('`src` and `ref` must be 2-D or 3-D (bands first) arrays')
-        if src.shape[-2:] != ref.shape[-2:]:
-            raise NotImplementedError('source and reference must share a grid (re-projection: SURVEY.md section 8f)')
         if ref.shape[0] < src.shape[0]:
             raise ValueError('`ref` has fewer bands than `src`')
         self._src, self._ref = src, ref
         self._src_nodata, self._ref_nodata = src_nodata, ref_nodata
         self._crs = crs or CRS()
         self._transform = transform or Affine.identity()
-        # equal resolutions: auto resolves to the reference grid (homonim/raster_pair.py:193-224)
-        self._proc_crs = ProcCrs.ref if ProcCrs(proc_crs) == ProcCrs.auto else ProcCrs(proc_crs)
+        self._ref_transform = ref_transform or self._transform
+        self._src_grid = Grid(self._transform, *src.shape[-2:])
+        self._ref_grid = Grid(self._ref_transform, *ref.shape[-2:])
+        self._same_grid = self._src_grid == self._ref_grid
+        if not self._same_grid:
+            l, b, r, t = self._src_grid.bounds
+            rl, rb, rr, rt = self._ref_grid.bounds
+            if l < rl or r > rr or b < rb or t > rt:  # homonim/raster_pair.py:93-94
+                from homonim_amd.errors import ImageContentError
+                raise ImageContentError('Reference extent does not cover source image')
+        # auto resolves to the grid with the larger pixels, the reference grid on ties (homonim/raster_pair.py:193-224)
+        self._proc_crs = resolve_proc_crs(self._src_grid, self._ref_grid, proc_crs)
         self._closed = False
         self._write_lock = threading.Lock()
 
@@ -181,7 +308,59 @@ class RasterFuse:
                     world_size=int(world_size))
 
     def block_pairs(self, overlap: Tuple[int, int] = (0, 0), max_block_mem: float = math.inf) -> Iterable[BlockPair]:
-        return block_pairs(self.shape, self._src.shape[0], overlap, max_block_mem)
+        if self._same_grid:
+            return block_pairs(self.shape, self._src.shape[0], overlap, max_block_mem)
+        return block_pairs_multires(self._src_grid, self._ref_grid, self._proc_crs, self._src.shape[0], overlap,
+                                    max_block_mem)
+
+    @staticmethod
+    def _read_boundless(band: np.ndarray, nodata: Optional[float], win: Window) -> Tuple[np.ndarray, Optional[float]]:
+        """ A window of a band that may reach beyond it, filled with nodata outside (RasterArray.from_rio_dataset,
+        homonim/raster_array.py:172-188: NaN when the raster has no nodata value). """
+        h, w = band.shape
+        r0, c0 = max(win.row_off, 0), max(win.col_off, 0)
+        r1, c1 = min(win.row_off + win.height, h), min(win.col_off + win.width, w)
+        inside = r0 == win.row_off and c0 == win.col_off and r1 == win.row_off + win.height and c1 == win.col_off + win.width
+        if inside:
+            return band[r0:r1, c0:c1], nodata
+        fill = float('nan') if nodata is None else nodata
+        dtype = np.float32 if (nodata is None or (isinstance(fill, float) and math.isnan(fill))) else band.dtype
+        out = np.full((win.height, win.width), fill, dtype=dtype)
+        if r1 > r0 and c1 > c0:
+            out[r0 - win.row_off:r1 - win.row_off, c0 - win.col_off:c1 - win.col_off] = band[r0:r1, c0:c1]
+        return out, fill
+
+    def _process_block_multires(self, bp: BlockPair, model: KernelModel, corr: np.ndarray, params: Optional[np.ndarray],
+                                out_nodata: Optional[float]):
+        """ read (boundless) -> fit on the processing grid -> apply on the source grid -> write the out-block
+        (homonim/fuse.py:295-319 with RefSpaceModel / SrcSpaceModel doing the re-sampling on the device) """
+        s_arr, s_nd = self._read_boundless(self._src[bp.band_i], self._src_nodata, bp.src_in_block)
+        r_arr, r_nd = self._read_boundless(self._ref[bp.band_i], self._ref_nodata, bp.ref_in_block)
+        src_tf = self._transform * Affine.translation(bp.src_in_block.col_off, bp.src_in_block.row_off)
+        ref_tf = self._ref_transform * Affine.translation(bp.ref_in_block.col_off, bp.ref_in_block.row_off)
+        src_ra = RasterArray(np.ascontiguousarray(s_arr, dtype=np.float32), self._crs, src_tf, nodata=s_nd)
+        ref_ra = RasterArray(np.ascontiguousarray(r_arr, dtype=np.float32), self._crs, ref_tf, nodata=r_nd)
+        param_ra = model.fit(src_ra, ref_ra)
+        corr_ra = model.apply(src_ra, param_ra)
+
+        def put(dst_plane, block_arr, in_win, out_win):
+            h, w = dst_plane.shape
+            r0, c0 = max(out_win.row_off, 0), max(out_win.col_off, 0)
+            r1, c1 = min(out_win.row_off + out_win.height, h), min(out_win.col_off + out_win.width, w)
+            if r1 > r0 and c1 > c0:
+                dst_plane[r0:r1, c0:c1] = block_arr[r0 - in_win.row_off:r1 - in_win.row_off,
+                                                    c0 - in_win.col_off:c1 - in_win.col_off]
+
+        block = corr_ra.array
+        if corr.dtype != np.float32 or not (out_nodata is None or (isinstance(out_nodata, float) and math.isnan(out_nodata))):
+            block = convert_dtype(block, corr.dtype.name, out_nodata)
+        put(corr[bp.band_i], block, bp.src_in_block, bp.src_out_block)
+        if params is not None:
+            n_src = self._src.shape[0]
+            p_in, p_out = (bp.ref_in_block, bp.ref_out_block) if self._proc_crs == ProcCrs.ref else \
+                (bp.src_in_block, bp.src_out_block)
+            for pi in range(param_ra.count):
+                put(params[pi * n_src + bp.band_i], param_ra.array[pi], p_in, p_out)
 
     # -- the block loop -----------------------------------------------------------------------------------------------
     def _read(self, bp: BlockPair) -> Tuple[RasterArray, RasterArray]:
@@ -255,18 +434,21 @@ class RasterFuse:
         fill = (np.nan if out_dtype.kind == 'f' else 0) if nodata is None else nodata
         corr = np.full((n_src, *self.shape), fill, dtype=out_dtype)
         n_param = 3 if models[0]._emit_r2 else 2
-        params = np.full((n_param * n_src, *self.shape), np.nan, dtype=np.float32) if want_params else None
+        # parameters live on the processing grid (homonim/fuse.py:254-293): the reference's when proc_crs == ref
+        param_shape = self._ref.shape[-2:] if (self._proc_crs == ProcCrs.ref and not self._same_grid) else self.shape
+        params = np.full((n_param * n_src, *param_shape), np.nan, dtype=np.float32) if want_params else None
+        process_block = self._process_block if self._same_grid else self._process_block_multires
 
         blocks = list(self.block_pairs(overlap=overlap, max_block_mem=block_config['max_block_mem']))
         blocks = shard(blocks, device_config['rank'], device_config['world_size'])
         if block_config['threads'] == 1 and len(models) == 1:
             for bp in blocks:
-                self._process_block(bp, models[0], corr, params, nodata)
+                process_block(bp, models[0], corr, params, nodata)
         else:
             workers = max(block_config['threads'], len(models))
             with ThreadPoolExecutor(max_workers=workers) as ex:
                 futures = [
-                    ex.submit(self._process_block, bp, models[i % len(models)], corr, params, nodata)
+                    ex.submit(process_block, bp, models[i % len(models)], corr, params, nodata)
                     for i, bp in enumerate(blocks)
                 ]
                 for f in as_completed(futures):

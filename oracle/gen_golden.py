@@ -274,21 +274,28 @@ CASES += [
 
 
 class _FakeDataset:
-    """ North-up dataset with unit pixels at the origin: just enough of rasterio.DatasetReader for block_pairs(). """
+    """ North-up dataset (pixel size `res`, upper-left corner `origin`): just enough of rasterio.DatasetReader for
+    RasterPairReader.open()'s window set-up and block_pairs(). """
     closed = False
 
-    def __init__(self, height, width, res=(1., 1.)):
-        self.height, self.width, self.res = height, width, res
+    def __init__(self, height, width, res=(1., 1.), origin=(0., 0.)):
+        self.height, self.width, self.res, self.origin = height, width, res, origin
         self.shape = (height, width)
 
+    @property
+    def bounds(self):
+        Window = sys.modules['rasterio.windows'].Window
+        return self.window_bounds(Window(0, 0, self.width, self.height))
+
     def window_bounds(self, win):
-        rx, ry = self.res
-        return (win.col_off * rx, -(win.row_off + win.height) * ry, (win.col_off + win.width) * rx, -win.row_off * ry)
+        (rx, ry), (x0, y0) = self.res, self.origin
+        return (x0 + win.col_off * rx, y0 - (win.row_off + win.height) * ry, x0 + (win.col_off + win.width) * rx,
+                y0 - win.row_off * ry)
 
     def window(self, left, bottom, right, top):
-        rx, ry = self.res
+        (rx, ry), (x0, y0) = self.res, self.origin
         Window = sys.modules['rasterio.windows'].Window
-        return Window(left / rx, -top / ry, (right - left) / rx, (top - bottom) / ry)
+        return Window((left - x0) / rx, (y0 - top) / ry, (right - left) / rx, (top - bottom) / ry)
 
 
 def gen_block_goldens():
@@ -331,6 +338,43 @@ def gen_block_goldens():
         json.dump(dict(note='reference raster_pair.py block partition on same-grid rasters; for > 70 blocks only the '
                             'first and last 35 are stored', cases=table), f)
     print(f'block goldens: {len(table)} cases')
+
+    # pairs of different resolution / origin: RasterPairReader.open()'s windows (raster_pair.py:289-291) + block_pairs
+    utils = sys.modules['homonim.utils']
+    table = []
+    multi = [  # (src h, w, res, origin), (ref h, w, res, origin), bands, kernel, max_block_mem
+        ((1421, 805, 5., (-57129.449, -3723906.806)), (1361, 797, 10., (-60370., -3722700.)), 3, (5, 5), 1),
+        ((560, 560, 5., (-56519.449, -3726056.806)), (289, 289, 10., (-56560., -3726010.)), 3, (5, 5), 0.25),
+        ((400, 600, 0.5, (5., -5.)), (200, 300, 1., (5., -5.)), 2, (3, 3), 0.1),
+        ((300, 500, 30., (1000., 9000.)), (900, 1500, 10., (1000., 9000.)), 1, (5, 5), 0.5),
+        ((333, 517, 2., (11.3, 77.7)), (120, 200, 7., (-13., 101.)), 2, (7, 3), 0.2),
+    ]
+    for (sh, sw, sr, so), (rh, rw, rr, ro), nb, k, mem in multi:
+        for proc in (ProcCrs.ref, ProcCrs.src):
+            rdr = object.__new__(rp.RasterPairReader)
+            rdr._src_im, rdr._ref_im = _FakeDataset(sh, sw, (sr, sr), so), _FakeDataset(rh, rw, (rr, rr), ro)
+            rdr._src_bands = rdr._ref_bands = tuple(range(1, nb + 1))
+            rdr._ref_win = utils.expand_window_to_grid(rdr._ref_im.window(*rdr._src_im.bounds))
+            rdr._src_win = utils.expand_window_to_grid(rdr._src_im.window(*rdr._ref_im.window_bounds(rdr._ref_win)))
+            rdr._proc_crs = proc
+            rdr._src_filename = rdr._ref_filename = 'fake.tif'
+            overlap = utils.overlap_for_kernel(k)
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                block_shape = rdr._auto_block_shape(max_block_mem=mem)
+                bps = list(rdr.block_pairs(overlap=overlap, max_block_mem=mem))
+            wins = [[bp.band_i, *[int(v) for v in bp.src_in_block], *[int(v) for v in bp.src_out_block],
+                     *[int(v) for v in bp.ref_in_block], *[int(v) for v in bp.ref_out_block], bool(bp.outer)] for bp in bps]
+            table.append(dict(src=dict(height=sh, width=sw, res=sr, origin=list(so)),
+                              ref=dict(height=rh, width=rw, res=rr, origin=list(ro)), n_bands=nb, kernel_shape=list(k),
+                              overlap=[int(o) for o in overlap], max_block_mem=mem, proc_crs=proc.value,
+                              src_win=[int(v) for v in rdr._src_win], ref_win=[int(v) for v in rdr._ref_win],
+                              block_shape=[int(b) for b in block_shape], n_blocks=len(wins),
+                              block_pairs=wins if len(wins) <= 60 else wins[:30] + wins[-30:]))
+    with open(os.path.join(GOLDEN_DIR, 'block_pairs_multires.json'), 'w') as f:
+        json.dump(dict(note='reference raster_pair.py windows + block partition for source / reference pairs of different '
+                            'resolution and origin (north-up, same CRS); > 60 blocks: first and last 30', cases=table), f)
+    print(f'multi-resolution block goldens: {len(table)} cases')
 
 
 def gen_convert_goldens(mods):

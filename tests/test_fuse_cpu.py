@@ -144,3 +144,35 @@ def test_convert_dtype_matches_reference_goldens():
         exp = g[key]
         assert out.dtype == exp.dtype, key
         np.testing.assert_array_equal(out, exp, err_msg=key)
+
+
+def _golden_multires():
+    with open(os.path.join(GOLDEN_DIR, 'block_pairs_multires.json')) as f:
+        return json.load(f)['cases']
+
+
+@pytest.mark.parametrize('case', _golden_multires(), ids=lambda c: f"src{c['src']['res']}-ref{c['ref']['res']}-{c['proc_crs']}-k{c['kernel_shape']}")
+def test_multires_block_partition_matches_reference(case):
+    """ Windows + blocks for source / reference pairs of different resolution and origin vs tables from the reference's
+    own RasterPairReader (tests/golden/block_pairs_multires.json). """
+    from homonim_amd.geo import Affine
+    mk = lambda g: fuse.Grid(Affine(g['res'], 0., g['origin'][0], 0., -g['res'], g['origin'][1]), g['height'], g['width'])
+    src, ref = mk(case['src']), mk(case['ref'])
+    src_win, ref_win = fuse.pair_windows(src, ref)
+    assert list(src_win) == case['src_win'] and list(ref_win) == case['ref_win']
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        bps = list(fuse.block_pairs_multires(src, ref, case['proc_crs'], case['n_bands'], case['overlap'],
+                                             case['max_block_mem']))
+    assert len(bps) == case['n_blocks']
+    rows = [[bp.band_i, *bp.src_in_block, *bp.src_out_block, *bp.ref_in_block, *bp.ref_out_block, bp.outer] for bp in bps]
+    if len(rows) > 60:
+        rows = rows[:30] + rows[-30:]
+    assert rows == case['block_pairs']
+
+
+def test_window_helpers():
+    from homonim_amd.geo import Window
+    assert fuse.expand_window_to_grid(Window(1.2, 3.7, 4.1, 2.0)) == Window(1, 3, 5, 3)
+    assert fuse.expand_window_to_grid(Window(-0.5, 2.0, 3.0, 3.0), (1, 2)) == Window(-3, 1, 8, 5)
+    assert fuse.round_window_to_grid(Window(1.5, 2.5, 3.0, 3.0)) == Window(2, 2, 2, 4)   # half to even, like np.round

@@ -62,3 +62,46 @@ def test_correction_improves_agreement_with_reference(pair, cls, model, kernel_s
             assert (corr_ra.mask == src_ra.mask).all()
         else:
             assert 0 < corr_ra.mask.sum() < src_ra.mask.sum() and src_ra.mask[corr_ra.mask].all()
+
+
+@pytest.mark.parametrize('model, kernel_shape, proc_crs, threads', [
+    ('gain-blk-offset', (5, 5), 'auto', 4), ('gain', (3, 3), 'ref', 1), ('gain-offset', (5, 5), 'src', 4),
+])
+def test_raster_fuse_process_across_resolutions(pair, model, kernel_shape, proc_crs, threads):
+    """ RasterFuse.process on the 5 m / 10 m pair: the reference's block partition across the two grids, re-sampling
+    and kernel models on the device per block; integration criteria per band + the mask rule. """
+    import warnings
+    from homonim_amd.fuse import RasterFuse
+    src, src_tf, src_nodata, ref, ref_tf = pair
+    crs = CRS('EPSG:32735')
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        rf = RasterFuse(src, ref, src_nodata=src_nodata, ref_nodata=None, proc_crs=proc_crs, crs=crs, transform=src_tf,
+                        ref_transform=ref_tf)
+        corr, params = rf.process(None, model, kernel_shape, param_filename=True,
+                                  block_config=dict(threads=threads, max_block_mem=0.3))
+        n_blocks = len(list(rf.block_pairs(utils_overlap(kernel_shape), 0.3)))
+    assert n_blocks >= 3 * 4 and corr.shape == src.shape and corr.dtype == np.float32
+    assert params.shape[0] == (3 if model == 'gain-offset' else 3) * src.shape[0]
+    for band in range(src.shape[0]):
+        src_ra = RasterArray(src[band].astype(np.float32), crs, src_tf, nodata=src_nodata)
+        ref_ra = RasterArray(ref[band].astype(np.float32), crs, ref_tf, nodata=None)
+        corr_ra = RasterArray(corr[band], crs, src_tf)
+        before, after = _compare(src_ra, ref_ra), _compare(corr_ra, ref_ra)
+        assert after['r2'] > before['r2'] and after['rmse'] < before['rmse'] and after['rrmse'] < before['rrmse']
+        assert (corr_ra.mask == src_ra.mask).all()
+    if model == 'gain':
+        # gain is block-partition invariant on one grid; across grids the reference's overlap of ceil(k/2) processing
+        # pixels leaves the cubic-spline support at block seams / image edges slightly different from a whole-image pass
+        # (inherent to its design), so the bulk of the pixels -- not all -- agree with one whole-image RefSpaceModel pass
+        km = RefSpaceModel(Model.gain, kernel_shape)
+        src_ra = RasterArray(src[0].astype(np.float32), crs, src_tf, nodata=src_nodata)
+        ref_ra = RasterArray(ref[0].astype(np.float32), crs, ref_tf, nodata=None)
+        whole = km.apply(src_ra, km.fit(src_ra, ref_ra)).array
+        ok = ~np.isnan(whole) & ~np.isnan(corr[0])
+        assert np.percentile(np.abs(whole[ok] - corr[0][ok]), 85) < 1e-3
+
+
+def utils_overlap(kernel_shape):
+    from homonim_amd import utils
+    return utils.overlap_for_kernel(kernel_shape)
