@@ -37,6 +37,11 @@ class IoDesc(C.Structure):
                 ('out_has_nodata', C.c_int32), ('out_nodata', C.c_double)]
 
 
+class SpaceDesc(C.Structure):
+    _fields_ = [('down', C.c_double * 4), ('up', C.c_double * 4), ('down_resampling', C.c_int32),
+                ('up_resampling', C.c_int32), ('mask_partial', C.c_int32)]
+
+
 # numpy dtype name -> hk_dtype
 DTYPE_CODES = {'float32': 0, 'uint8': 1, 'uint16': 2, 'int16': 3, 'uint32': 4, 'int32': 5, 'float64': 6}
 
@@ -67,6 +72,9 @@ SIGNATURES = {
     'hk_apply': (C.c_int, [C.c_void_p, _f32p, C.c_int64, _f32p, C.c_int32, C.c_int32, _f32p]),
     'hk_fit_apply': (C.c_int, [C.c_void_p, _P(FitDesc), _f32p, C.c_int64, _f32p, C.c_int64, C.c_int32, C.c_int32,
                                _f64p, _f32p, C.c_int32, _f32p, _f64p, _u64p]),
+    'hk_refspace_fit_apply': (C.c_int, [C.c_void_p, _P(FitDesc), _P(IoDesc), _P(SpaceDesc), C.c_void_p, C.c_int64, C.c_int32,
+                                        C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, _f32p, C.c_int32,
+                                        C.c_void_p, _u64p]),
     'hk_reproject': (C.c_int, [C.c_void_p, _f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_double, C.c_double,
                                C.c_double, C.c_double, C.c_int32, _f32p, C.c_int32, C.c_int32, C.c_float]),
     'hk_partial_mask': (C.c_int, [C.c_void_p, _f32p, C.c_int64, C.c_int32, C.c_float, _f32p, C.c_int32, _f32p, C.c_int64,
@@ -271,6 +279,31 @@ class Context:
         _check(self._lib.hk_apply(self._h, _ptr(src), src.strides[0] // 4, _ptr(params), src.shape[0], src.shape[1],
                                   _ptr(out)))
         return out
+
+    def refspace_fit_apply(self, desc: FitDesc, src: np.ndarray, ref: np.ndarray, down, up, down_resampling: int,
+                           up_resampling: int, mask_partial: bool, n_param_bands: int, want_params: bool,
+                           out_dtype: str = 'float32', out_nodata: Optional[float] = None):
+        """ hk_refspace_fit_apply: RefSpaceModel.fit + apply of one block pair on different grids, all on the device.
+        -> (params on the reference grid | None, corrected on the source grid, r2_fail_count) """
+        src, ref = _as_2d_native(src, 'src'), _as_2d_native(ref, 'ref')
+        out_dtype = np.dtype(out_dtype)
+        keep_nan = out_nodata is None or (isinstance(out_nodata, float) and math.isnan(out_nodata))
+        io = IoDesc(DTYPE_CODES[src.dtype.name], DTYPE_CODES[ref.dtype.name], DTYPE_CODES[out_dtype.name],
+                    0 if (keep_nan and out_dtype.kind == 'f') or out_nodata is None else 1,
+                    0.0 if out_nodata is None or keep_nan else float(out_nodata))
+        sp = SpaceDesc()
+        for i in range(4):
+            sp.down[i], sp.up[i] = float(down[i]), float(up[i])
+        sp.down_resampling, sp.up_resampling, sp.mask_partial = int(down_resampling), int(up_resampling), int(mask_partial)
+        params = np.empty((n_param_bands, *ref.shape), np.float32) if want_params else None
+        corr = np.empty(src.shape, out_dtype)
+        fail = C.c_uint64(0)
+        vp = C.c_void_p
+        _check(self._lib.hk_refspace_fit_apply(
+            self._h, C.byref(desc), C.byref(io), C.byref(sp), src.ctypes.data_as(vp), src.strides[0] // src.dtype.itemsize,
+            src.shape[0], src.shape[1], ref.ctypes.data_as(vp), ref.strides[0] // ref.dtype.itemsize, ref.shape[0],
+            ref.shape[1], _ptr(params) if want_params else None, n_param_bands, corr.ctypes.data_as(vp), C.byref(fail)))
+        return params, corr, int(fail.value)
 
     def reproject(self, src: np.ndarray, src_nodata, mapping, dst_shape, resampling: int, dst_fill: float) -> np.ndarray:
         """ hk_reproject: (bands, h, w) or (h, w) float32 -> same rank on the destination grid. """

@@ -179,6 +179,73 @@ void fill_grid(hk::FitArgs& a, int seg_rows) {
     a.total_units = a.n_strips * a.n_segs * a.n_bands;
 }
 
+// Device-side KernelModel.fit (+ apply when d_corr) of one float32 block already in HBM: block statistics for
+// gain-blk-offset (or the caller's norm), the fused kernel, and the in-painting branch of gain-offset
+// (kernel_model.py:361-371) when valid pixels fail the r2 mask.  d_gain / d_off / d_r2 / d_corr are nullable planes.
+int fit_on_device(hk_ctx* ctx, Slot& sl, const hk_fit_desc* desc, const double* norm_in, float* d_src, float* d_ref,
+                  int32_t height, int32_t width, int64_t stride, float* d_gain, float* d_off, float* d_r2, float* d_corr,
+                  double* d_norm, unsigned long long* d_fail, void* d_norm_ws) {
+    const bool blk = desc->model == HK_MODEL_GAIN_BLK_OFFSET;
+    const bool r2 = needs_r2(desc);
+    const size_t plane = (size_t)stride * height * sizeof(float);
+    HK_HIP(hipMemsetAsync(d_fail, 0, sizeof(unsigned long long), sl.stream));
+    if (blk) {
+        if (norm_in) {
+            HK_HIP(hipMemcpyAsync(d_norm, norm_in, 2 * sizeof(double), hipMemcpyHostToDevice, sl.stream));
+        } else {
+            hk::NormArgs na;
+            na.src = d_src, na.ref = d_ref, na.height = height, na.width = width, na.stride = stride;
+            na.band_stride = 0, na.n_bands = 1;
+            na.src_nd_mode = desc->src_nodata_mode, na.ref_nd_mode = desc->ref_nodata_mode;
+            na.src_nodata = desc->src_nodata, na.ref_nodata = desc->ref_nodata;
+            HK_HIP(hk::launch_block_norm(na, d_norm_ws, d_norm, sl.stream));
+        }
+    }
+    hk::FitArgs a;
+    memset(&a, 0, sizeof(a));
+    a.src = d_src, a.ref = d_ref, a.gain = d_gain, a.offset = d_off, a.r2 = d_r2, a.corr = d_corr;
+    a.norm = blk ? d_norm : nullptr;
+    a.fail_count = d_fail;
+    a.height = height, a.width = width, a.stride = stride, a.band_stride = 0, a.n_bands = 1;
+    fill_args(a, desc, ctx->xcd_remap);
+    fill_grid(a, 0);
+    HK_HIP(hk::launch_fit_apply(a, desc->model, r2, sl.stream));
+
+    if (a.has_thresh) {
+        // kernel_model.py:361-371: when valid pixels fail (r2 > thresh) & (gain > 0), in-paint their offsets from the
+        // passing ones and recompute their gains.  Needs the count on the host (one extra stream sync per call).
+        unsigned long long n_fail = 0;
+        HK_HIP(hipMemcpyAsync(&n_fail, d_fail, sizeof(n_fail), hipMemcpyDeviceToHost, sl.stream));
+        HK_HIP(hipStreamSynchronize(sl.stream));
+        if (n_fail > 0) {
+            const size_t need = 4 * plane + hk::inpaint_workspace_bytes(height, stride);
+            if (sl.aux_bytes < need) {
+                if (sl.aux) HK_HIP(hipFree(sl.aux));
+                sl.aux = nullptr, sl.aux_bytes = 0;
+                if (hipMalloc(&sl.aux, need) != hipSuccess) return fail(HK_ERR_NOMEM, "hipMalloc(%zu) failed", need);
+                sl.aux_bytes = need;
+            }
+            char* aux = static_cast<char*>(sl.aux);
+            float* filled = reinterpret_cast<float*>(aux);
+            float *pg = d_gain, *po = d_off, *pr = d_r2;
+            if (!pg) {  // parameters were not materialised by the first pass: run it again into scratch planes
+                pg = reinterpret_cast<float*>(aux + plane), po = reinterpret_cast<float*>(aux + 2 * plane);
+                pr = reinterpret_cast<float*>(aux + 3 * plane);
+                hk::FitArgs b = a;
+                b.gain = pg, b.offset = po, b.r2 = pr, b.corr = nullptr, b.fail_count = nullptr;
+                HK_HIP(hk::launch_fit_apply(b, desc->model, r2, sl.stream));
+            }
+            HK_HIP(hk::launch_inpaint_offsets(po, pg, pr, desc->r2_thresh, stride, height, width, aux + 4 * plane, filled,
+                                              sl.stream));
+            hk::FitArgs c = a;
+            c.offset_in = filled;
+            c.fail_count = nullptr;  // already counted
+            HK_HIP(hk::launch_fit_apply(c, desc->model, r2, sl.stream));
+        }
+    }
+    return HK_OK;
+}
+
 // The whole host-pointer path: stage in (+ typed -> float32), (norm), fused kernel, (float32 -> typed) stage out.
 // `corr_out` / `params_out` nullable; `io` nullable (float32 everywhere).
 int run_host(hk_ctx* ctx, const hk_fit_desc* desc, const hk_io_desc* io, const void* src, int64_t src_stride,
@@ -252,65 +319,19 @@ int run_host(hk_ctx* ctx, const hk_fit_desc* desc, const hk_io_desc* io, const v
     if (rc) return rc;
     rc = stage_in(ref, ref_stride, rdt, d_ref, o_raw_r);
     if (rc) return rc;
-    HK_HIP(hipMemsetAsync(d_fail, 0, sizeof(unsigned long long), sl.stream));
-
-    if (want_norm) {
-        if (norm_in && !norm_only) {
-            HK_HIP(hipMemcpyAsync(d_norm, norm_in, 2 * sizeof(double), hipMemcpyHostToDevice, sl.stream));
-        } else {
-            hk::NormArgs na;
-            na.src = d_src, na.ref = d_ref, na.height = height, na.width = width, na.stride = stride;
-            na.band_stride = 0, na.n_bands = 1;
-            na.src_nd_mode = desc->src_nodata_mode, na.ref_nd_mode = desc->ref_nodata_mode;
-            na.src_nodata = desc->src_nodata, na.ref_nodata = desc->ref_nodata;
-            HK_HIP(hk::launch_block_norm(na, d_ws, d_norm, sl.stream));
-        }
+    if (norm_only) {
+        hk::NormArgs na;
+        na.src = d_src, na.ref = d_ref, na.height = height, na.width = width, na.stride = stride;
+        na.band_stride = 0, na.n_bands = 1;
+        na.src_nd_mode = desc->src_nodata_mode, na.ref_nd_mode = desc->ref_nodata_mode;
+        na.src_nodata = desc->src_nodata, na.ref_nodata = desc->ref_nodata;
+        HK_HIP(hk::launch_block_norm(na, d_ws, d_norm, sl.stream));
         if (norm_out) HK_HIP(hipMemcpyAsync(norm_out, d_norm, 2 * sizeof(double), hipMemcpyDeviceToHost, sl.stream));
-    }
-
-    if (!norm_only) {
-        hk::FitArgs a;
-        memset(&a, 0, sizeof(a));
-        a.src = d_src, a.ref = d_ref, a.gain = d_gain, a.offset = d_off, a.r2 = d_r2, a.corr = d_corr;
-        a.norm = blk ? d_norm : nullptr;
-        a.fail_count = d_fail;
-        a.height = height, a.width = width, a.stride = stride, a.band_stride = 0, a.n_bands = 1;
-        fill_args(a, desc, ctx->xcd_remap);
-        fill_grid(a, 0);
-        HK_HIP(hk::launch_fit_apply(a, desc->model, r2, sl.stream));
-
-        if (a.has_thresh) {
-            // kernel_model.py:361-371: when valid pixels fail (r2 > thresh) & (gain > 0), in-paint their offsets from the
-            // passing ones and recompute their gains.  Needs the count on the host (one extra stream sync per call).
-            unsigned long long n_fail = 0;
-            HK_HIP(hipMemcpyAsync(&n_fail, d_fail, sizeof(n_fail), hipMemcpyDeviceToHost, sl.stream));
-            HK_HIP(hipStreamSynchronize(sl.stream));
-            if (n_fail > 0) {
-                const size_t need = 4 * plane + hk::inpaint_workspace_bytes(height, stride);
-                if (sl.aux_bytes < need) {
-                    if (sl.aux) HK_HIP(hipFree(sl.aux));
-                    sl.aux = nullptr, sl.aux_bytes = 0;
-                    if (hipMalloc(&sl.aux, need) != hipSuccess) return fail(HK_ERR_NOMEM, "hipMalloc(%zu) failed", need);
-                    sl.aux_bytes = need;
-                }
-                char* aux = static_cast<char*>(sl.aux);
-                float* filled = reinterpret_cast<float*>(aux);
-                float *pg = d_gain, *po = d_off, *pr = d_r2;
-                if (!pg) {  // parameters were not materialised by the first pass: run it again into scratch planes
-                    pg = reinterpret_cast<float*>(aux + plane), po = reinterpret_cast<float*>(aux + 2 * plane);
-                    pr = reinterpret_cast<float*>(aux + 3 * plane);
-                    hk::FitArgs b = a;
-                    b.gain = pg, b.offset = po, b.r2 = pr, b.corr = nullptr, b.fail_count = nullptr;
-                    HK_HIP(hk::launch_fit_apply(b, desc->model, r2, sl.stream));
-                }
-                HK_HIP(hk::launch_inpaint_offsets(po, pg, pr, desc->r2_thresh, stride, height, width, aux + 4 * plane,
-                                                  filled, sl.stream));
-                hk::FitArgs c = a;
-                c.offset_in = filled;
-                c.fail_count = nullptr;  // already counted
-                HK_HIP(hk::launch_fit_apply(c, desc->model, r2, sl.stream));
-            }
-        }
+    } else {
+        rc = fit_on_device(ctx, sl, desc, norm_in, d_src, d_ref, height, width, stride, d_gain, d_off, d_r2, d_corr, d_norm,
+                           d_fail, d_ws);
+        if (rc) return rc;
+        if (norm_out && blk) HK_HIP(hipMemcpyAsync(norm_out, d_norm, 2 * sizeof(double), hipMemcpyDeviceToHost, sl.stream));
 
         const size_t wbytes = (size_t)width * sizeof(float);
         float* outs[3] = {d_gain, d_off, d_r2};
@@ -464,6 +485,136 @@ int hk_apply(hk_ctx* ctx, const float* src, int64_t src_stride, const float* par
                             hipMemcpyHostToDevice, sl.stream));
     HK_HIP(hk::launch_apply(d_src, d_gain, d_off, d_out, height, width, stride, sl.stream));
     HK_HIP(hipMemcpy2DAsync(out, wbytes, d_out, stride * 4, wbytes, height, hipMemcpyDeviceToHost, sl.stream));
+    HK_HIP(hipStreamSynchronize(sl.stream));
+    return HK_OK;
+}
+
+int hk_refspace_fit_apply(hk_ctx* ctx, const hk_fit_desc* desc, const hk_io_desc* io, const hk_space_desc* space,
+                          const void* src, int64_t src_stride, int32_t src_height, int32_t src_width, const void* ref,
+                          int64_t ref_stride, int32_t ref_height, int32_t ref_width, float* params_out,
+                          int32_t n_param_bands, void* corr_out, uint64_t* r2_fail_count) {
+    if (!ctx) return fail(HK_ERR_ARG, "ctx is NULL");
+    int rc = validate_desc(desc);
+    if (rc) return rc;
+    if (!space || !src || !ref || !corr_out) return fail(HK_ERR_ARG, "NULL pointer argument");
+    if (src_height < 1 || src_width < 1 || ref_height < 1 || ref_width < 1) return fail(HK_ERR_ARG, "empty raster");
+    if (src_stride < src_width || ref_stride < ref_width) return fail(HK_ERR_ARG, "row stride smaller than width");
+    for (int m : {space->down_resampling, space->up_resampling})
+        if (m != 0 && m != 1 && m != 3 && m != 5) return fail(HK_ERR_UNSUPPORTED, "resampling %d is not built", m);
+    auto stretched = [](int m, const double* k) { return (m == 1 || m == 3) && (k[0] > 1.0 + 1e-9 || k[2] > 1.0 + 1e-9); };
+    if (stretched(space->down_resampling, space->down) || stretched(space->up_resampling, space->up))
+        return fail(HK_ERR_UNSUPPORTED, "bilinear / cubic_spline down-sampling (stretched kernel) is not built");
+    if (!(space->down[0] > 0 && space->down[2] > 0 && space->up[0] > 0 && space->up[2] > 0))
+        return fail(HK_ERR_UNSUPPORTED, "flipped or degenerate grid mapping");
+    if (src_height > 65535 || ref_height > 65535) return fail(HK_ERR_UNSUPPORTED, "block taller than 65535 rows");
+    const int sdt = io ? io->src_dtype : 0, rdt = io ? io->ref_dtype : 0, odt = io ? io->out_dtype : 0;
+    if (!hk::dtype_size(sdt) || !hk::dtype_size(rdt) || !hk::dtype_size(odt)) return fail(HK_ERR_ARG, "unknown dtype");
+    const bool out_cast = io && (odt != 0 || io->out_has_nodata);
+    const bool r2 = needs_r2(desc);
+    if (params_out && n_param_bands != (r2 ? 3 : 2))
+        return fail(HK_ERR_ARG, "n_param_bands must be %d for this model configuration", r2 ? 3 : 2);
+    HK_HIP(hipSetDevice(ctx->device));
+
+    const int64_t ss = (src_width + ROW_ALIGN - 1) / ROW_ALIGN * ROW_ALIGN;  // source-grid row stride
+    const int64_t rs = (ref_width + ROW_ALIGN - 1) / ROW_ALIGN * ROW_ALIGN;  // reference-grid row stride
+    const size_t splane = (size_t)ss * src_height * 4, rplane = (size_t)rs * ref_height * 4;
+    size_t total = 0;
+    auto take = [&](size_t bytes) { const size_t off = total; total += (bytes + 255) / 256 * 256; return off; };
+    const size_t o_src = take(splane), o_ref = take(rplane), o_ds = take(rplane);
+    const size_t o_gain = take(rplane), o_off = take(rplane), o_r2 = r2 ? take(rplane) : 0;
+    const size_t o_gus = take(splane), o_ous = take(splane), o_corr = take(splane);
+    const size_t o_vs = space->mask_partial ? take(splane) : 0, o_cov = space->mask_partial ? take(rplane) : 0;
+    const size_t o_mk = space->mask_partial ? take((size_t)rs * ref_height) : 0;
+    const size_t o_mkf = space->mask_partial ? take(rplane) : 0, o_keep = space->mask_partial ? take(splane) : 0;
+    const size_t o_cnt = space->mask_partial ? take((size_t)rs * ref_height * 2) : 0;
+    const size_t o_raw_s = sdt ? take((size_t)ss * src_height * hk::dtype_size(sdt)) : 0;
+    const size_t o_raw_r = rdt ? take((size_t)rs * ref_height * hk::dtype_size(rdt)) : 0;
+    const size_t o_raw_o = out_cast ? take((size_t)ss * src_height * hk::dtype_size(odt)) : 0;
+    const size_t o_aux = take(256);
+    const bool blk = desc->model == HK_MODEL_GAIN_BLK_OFFSET;
+    const size_t o_ws = blk ? take(hk::norm_workspace_bytes(1, ref_height, ref_width)) : 0;
+
+    SlotLease lease(ctx);
+    Slot& sl = lease.slot();
+    rc = ensure_dev(sl, total);
+    if (rc) return rc;
+    char* base = static_cast<char*>(sl.dev);
+    auto F = [&](size_t off) { return reinterpret_cast<float*>(base + off); };
+    float *d_src = F(o_src), *d_ref = F(o_ref), *d_ds = F(o_ds), *d_gain = F(o_gain), *d_off = F(o_off);
+    float *d_r2 = r2 ? F(o_r2) : nullptr, *d_gus = F(o_gus), *d_ous = F(o_ous), *d_corr = F(o_corr);
+    double* d_norm = reinterpret_cast<double*>(base + o_aux);
+    unsigned long long* d_fail = reinterpret_cast<unsigned long long*>(base + o_aux + 64);
+    const float nan = std::nanf("");
+
+    auto stage_in = [&](const void* host, int64_t hstride, int dt, float* dplane, size_t o_raw, int64_t dstride, int h,
+                        int w) -> int {
+        const size_t es = hk::dtype_size(dt);
+        void* dst = dt ? static_cast<void*>(base + o_raw) : static_cast<void*>(dplane);
+        HK_HIP(hipMemcpy2DAsync(dst, dstride * es, host, hstride * es, (size_t)w * es, h, hipMemcpyHostToDevice, sl.stream));
+        if (dt) HK_HIP(hk::launch_cast_in(dt, dst, dstride, dplane, dstride, h, w, sl.stream));
+        return HK_OK;
+    };
+    if ((rc = stage_in(src, src_stride, sdt, d_src, o_raw_s, ss, src_height, src_width))) return rc;
+    if ((rc = stage_in(ref, ref_stride, rdt, d_ref, o_raw_r, rs, ref_height, ref_width))) return rc;
+
+    // RefSpaceModel.fit (:476-482): source -> reference grid (nodata nan), then the base-class fit there
+    HK_HIP(hk::launch_resample(space->down_resampling, d_src, ss, 0, src_height, src_width, 1, desc->src_nodata_mode,
+                               desc->src_nodata, space->down[0], space->down[1], space->down[2], space->down[3], d_ds, rs, 0,
+                               ref_height, ref_width, nan, sl.stream));
+    hk_fit_desc fd = *desc;
+    fd.src_nodata_mode = HK_NODATA_NAN, fd.src_nodata = nan;
+    rc = fit_on_device(ctx, sl, &fd, nullptr, d_ds, d_ref, ref_height, ref_width, rs, d_gain, d_off, d_r2, nullptr, d_norm,
+                       d_fail, base + o_ws);
+    if (rc) return rc;
+
+    // RefSpaceModel.apply (:484-503): gain / offset -> source grid, re-mask, apply
+    for (int b = 0; b < 2; ++b)
+        HK_HIP(hk::launch_resample(space->up_resampling, b ? d_off : d_gain, rs, 0, ref_height, ref_width, 1, HK_NODATA_NAN,
+                                   nan, space->up[0], space->up[1], space->up[2], space->up[3], b ? d_ous : d_gus, ss, 0,
+                                   src_height, src_width, nan, sl.stream));
+    const float* d_keep = nullptr;
+    if (space->mask_partial) {
+        // _full_coverage_mask (:375-409): source mask --average--> reference grid (>= 1) & parameter mask, eroded by
+        // (kh+2) x (kw+2); back to the source grid with `nearest` (nodata 0)
+        HK_HIP(hk::launch_valid_plane(d_src, ss, desc->src_nodata_mode, desc->src_nodata, F(o_vs), ss, src_height,
+                                      src_width, sl.stream));
+        HK_HIP(hk::launch_resample(5, F(o_vs), ss, 0, src_height, src_width, 1, HK_NODATA_NONE, 0.f, space->down[0],
+                                   space->down[1], space->down[2], space->down[3], F(o_cov), rs, 0, ref_height, ref_width,
+                                   0.f, sl.stream));
+        // parameters sit in consecutive planes only by construction of the bump allocator above (gain, offset)
+        if (o_off != o_gain + ((rplane + 255) / 256 * 256)) return fail(HK_ERR_HIP, "internal: parameter planes not adjacent");
+        unsigned char* d_mk = reinterpret_cast<unsigned char*>(base + o_mk);
+        HK_HIP(hk::launch_partial_mask(F(o_cov), 3, 0.f, d_gain, 2, (long long)((rplane + 255) / 256 * 256 / 4), nullptr,
+                                       ref_height, ref_width, rs, desc->kh, desc->kw,
+                                       reinterpret_cast<unsigned short*>(base + o_cnt), nullptr, nullptr, d_mk, sl.stream));
+        HK_HIP(hk::launch_cast_in(1, d_mk, rs, F(o_mkf), rs, ref_height, ref_width, sl.stream));
+        HK_HIP(hk::launch_resample(0, F(o_mkf), rs, 0, ref_height, ref_width, 1, HK_NODATA_NONE, 0.f, space->up[0],
+                                   space->up[1], space->up[2], space->up[3], F(o_keep), ss, 0, src_height, src_width, 0.f,
+                                   sl.stream));
+        d_keep = F(o_keep);
+    }
+    HK_HIP(hk::launch_apply_space(d_src, ss, desc->src_nodata_mode, desc->src_nodata, d_gus, d_ous, ss, d_keep, d_corr, ss,
+                                  src_height, src_width, sl.stream));
+
+    if (params_out) {
+        float* outs[3] = {d_gain, d_off, d_r2};
+        const size_t wb = (size_t)ref_width * 4;
+        for (int b = 0; b < n_param_bands; ++b)
+            HK_HIP(hipMemcpy2DAsync(params_out + (size_t)b * ref_height * ref_width, wb, outs[b], rs * 4, wb, ref_height,
+                                    hipMemcpyDeviceToHost, sl.stream));
+    }
+    if (out_cast) {
+        const size_t es = hk::dtype_size(odt);
+        void* d_raw = base + o_raw_o;
+        HK_HIP(hk::launch_cast_out(odt, d_corr, ss, d_raw, ss, src_height, src_width, io->out_has_nodata, io->out_nodata,
+                                   sl.stream));
+        HK_HIP(hipMemcpy2DAsync(corr_out, (size_t)src_width * es, d_raw, ss * es, (size_t)src_width * es, src_height,
+                                hipMemcpyDeviceToHost, sl.stream));
+    } else {
+        HK_HIP(hipMemcpy2DAsync(corr_out, (size_t)src_width * 4, d_corr, ss * 4, (size_t)src_width * 4, src_height,
+                                hipMemcpyDeviceToHost, sl.stream));
+    }
+    if (r2_fail_count) HK_HIP(hipMemcpyAsync(r2_fail_count, d_fail, sizeof(uint64_t), hipMemcpyDeviceToHost, sl.stream));
     HK_HIP(hipStreamSynchronize(sl.stream));
     return HK_OK;
 }

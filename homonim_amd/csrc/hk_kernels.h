@@ -91,6 +91,12 @@ hipError_t launch_resample(int mode, const float* src, long long src_stride, lon
                            long long dst_stride, long long dst_band_stride, int dh, int dw, float dst_fill,
                            hipStream_t stream);
 
+hipError_t launch_valid_plane(const float* in, long long in_stride, int nd_mode, float nodata, float* out,
+                              long long out_stride, int height, int width, hipStream_t stream);
+hipError_t launch_apply_space(const float* src, long long src_stride, int nd_mode, float nodata, const float* gain,
+                              const float* offset, long long par_stride, const float* keep, float* out,
+                              long long out_stride, int height, int width, hipStream_t stream);
+
 // returns 0 on pass; writes a diagnostic code otherwise
 hipError_t launch_selftest(int* result_dev, hipStream_t stream);
 

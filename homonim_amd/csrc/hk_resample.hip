@@ -115,6 +115,51 @@ __global__ void __launch_bounds__(256) resample_kernel(const ResampleArgs a) {
     dp[(long long)i * a.dst_stride + j] = got ? (float)result : a.dst_fill;
 }
 
+// valid(src) as a float32 0/1 plane: RasterArray.mask_ra (raster_array.py:320-327) before it is re-projected
+__global__ void __launch_bounds__(256) valid_plane_kernel(const float* __restrict__ in, long long in_stride, int nd_mode,
+                                                          float nodata, float* __restrict__ out, long long out_stride,
+                                                          int height, int width) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= width) return;
+    for (int y = blockIdx.y; y < height; y += gridDim.y)
+        out[(long long)y * out_stride + x] = rs_valid(in[(long long)y * in_stride + x], nd_mode, nodata) ? 1.f : 0.f;
+}
+
+// RefSpaceModel.apply after the parameters were brought to the source grid (kernel_model.py:493-503): parameters are
+// masked with the (nearest re-projected) full-coverage mask, or with the source mask, then gain * src + offset.
+__global__ void __launch_bounds__(256) apply_space_kernel(const float* __restrict__ src, long long src_stride, int nd_mode,
+                                                          float nodata, const float* __restrict__ gain,
+                                                          const float* __restrict__ offset, long long par_stride,
+                                                          const float* __restrict__ keep, float* __restrict__ out,
+                                                          long long out_stride, int height, int width) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= width) return;
+    const float nan = __int_as_float(0x7fc00000);
+    for (int y = blockIdx.y; y < height; y += gridDim.y) {
+        const float s = src[(long long)y * src_stride + x];
+        const long long pi = (long long)y * par_stride + x;
+        // param_us_ra.mask = mask_us (bool of the nearest-resampled mask, :498) or src_ra.mask (:500)
+        const bool on = keep ? keep[pi] != 0.f : rs_valid(s, nd_mode, nodata);
+        const float g = on ? gain[pi] : nan, o = on ? offset[pi] : nan;
+        out[(long long)y * out_stride + x] = __fadd_rn(__fmul_rn(g, s), o);
+    }
+}
+
+hipError_t launch_valid_plane(const float* in, long long in_stride, int nd_mode, float nodata, float* out,
+                              long long out_stride, int height, int width, hipStream_t stream) {
+    hipLaunchKernelGGL(valid_plane_kernel, dim3((width + 255) / 256, height < 1024 ? height : 1024), dim3(256), 0, stream,
+                       in, in_stride, nd_mode, nodata, out, out_stride, height, width);
+    return hipGetLastError();
+}
+
+hipError_t launch_apply_space(const float* src, long long src_stride, int nd_mode, float nodata, const float* gain,
+                              const float* offset, long long par_stride, const float* keep, float* out,
+                              long long out_stride, int height, int width, hipStream_t stream) {
+    hipLaunchKernelGGL(apply_space_kernel, dim3((width + 255) / 256, height < 1024 ? height : 1024), dim3(256), 0, stream,
+                       src, src_stride, nd_mode, nodata, gain, offset, par_stride, keep, out, out_stride, height, width);
+    return hipGetLastError();
+}
+
 hipError_t launch_resample(int mode, const float* src, long long src_stride, long long src_band_stride, int sh, int sw,
                            int n_bands, int nd_mode, float nodata, double kx, double ox, double ky, double oy, float* dst,
                            long long dst_stride, long long dst_band_stride, int dh, int dw, float dst_fill,

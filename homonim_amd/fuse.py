@@ -338,10 +338,17 @@ class RasterFuse:
         r_arr, r_nd = self._read_boundless(self._ref[bp.band_i], self._ref_nodata, bp.ref_in_block)
         src_tf = self._transform * Affine.translation(bp.src_in_block.col_off, bp.src_in_block.row_off)
         ref_tf = self._ref_transform * Affine.translation(bp.ref_in_block.col_off, bp.ref_in_block.row_off)
-        src_ra = RasterArray(np.ascontiguousarray(s_arr, dtype=np.float32), self._crs, src_tf, nodata=s_nd)
-        ref_ra = RasterArray(np.ascontiguousarray(r_arr, dtype=np.float32), self._crs, ref_tf, nodata=r_nd)
-        param_ra = model.fit(src_ra, ref_ra)
-        corr_ra = model.apply(src_ra, param_ra)
+        fused = isinstance(model, RefSpaceModel)  # one upload / download per block, everything else stays in HBM
+        if fused:
+            src_ra = RasterArray(s_arr, self._crs, src_tf, nodata=s_nd)
+            ref_ra = RasterArray(r_arr, self._crs, ref_tf, nodata=r_nd)
+            corr_ra, param_ra = model.fit_apply(src_ra, ref_ra, want_params=params is not None, out_dtype=corr.dtype.name,
+                                                out_nodata=out_nodata)
+        else:
+            src_ra = RasterArray(np.ascontiguousarray(s_arr, dtype=np.float32), self._crs, src_tf, nodata=s_nd)
+            ref_ra = RasterArray(np.ascontiguousarray(r_arr, dtype=np.float32), self._crs, ref_tf, nodata=r_nd)
+            param_ra = model.fit(src_ra, ref_ra)
+            corr_ra = model.apply(src_ra, param_ra)
 
         def put(dst_plane, block_arr, in_win, out_win):
             h, w = dst_plane.shape
@@ -352,7 +359,8 @@ class RasterFuse:
                                                     c0 - in_win.col_off:c1 - in_win.col_off]
 
         block = corr_ra.array
-        if corr.dtype != np.float32 or not (out_nodata is None or (isinstance(out_nodata, float) and math.isnan(out_nodata))):
+        if not fused and (corr.dtype != np.float32 or
+                          not (out_nodata is None or (isinstance(out_nodata, float) and math.isnan(out_nodata)))):
             block = convert_dtype(block, corr.dtype.name, out_nodata)
         put(corr[bp.band_i], block, bp.src_in_block, bp.src_out_block)
         if params is not None:

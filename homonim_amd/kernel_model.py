@@ -215,6 +215,30 @@ class RefSpaceModel(KernelModel):
         return KernelModel.apply(self, src_ra, param_us_ra)
 
 
+    def fit_apply(self, src_ra: RasterArray, ref_ra: RasterArray, want_params: bool = False,
+                  out_dtype: str = RasterArray.default_dtype,
+                  out_nodata: Optional[float] = RasterArray.default_nodata) -> Tuple[RasterArray, Optional[RasterArray]]:
+        """ ``apply(src_ra, fit(src_ra, ref_ra))`` with everything between the two blocks kept in HBM
+        (hk_refspace_fit_apply): one upload of source + reference, one download of the corrected block. """
+        if _same_grid(src_ra, ref_ra) and not self._mask_partial:
+            return KernelModel.fit_apply(self, src_ra, ref_ra, want_params, out_dtype, out_nodata)
+        from homonim_amd.geo import grid_mapping
+        if src_ra.crs != ref_ra.crs:
+            raise NotImplementedError('re-projection between different CRSs is not built (GDAL warp)')
+        down = self._get_resampling(src_ra.res, ref_ra.res)
+        up = self._get_resampling(ref_ra.res, src_ra.res)
+        count = 3 if self._emit_r2 else 2
+        params, corr, _ = self.context.refspace_fit_apply(
+            self._desc(src_ra, ref_ra), self._band(src_ra, 'src_ra'), self._band(ref_ra, 'ref_ra'),
+            grid_mapping(src_ra.transform, ref_ra.transform), grid_mapping(ref_ra.transform, src_ra.transform), int(down),
+            int(up), self._mask_partial, count, want_params, out_dtype=out_dtype, out_nodata=out_nodata
+        )
+        corr_profile = dict(self._param_profile(src_ra, 1), nodata=out_nodata, dtype=str(out_dtype))
+        corr_ra = RasterArray.from_profile(corr, corr_profile)
+        param_ra = RasterArray.from_profile(params, self._param_profile(ref_ra, count)) if want_params else None
+        return corr_ra, param_ra
+
+
 class SrcSpaceModel(KernelModel):
     """ Parameters estimated on the source grid (kernel_model.py:506-535): the reference block is re-sampled to it. """
 

@@ -152,6 +152,26 @@ int hk_fit_apply_io(hk_ctx* ctx, const hk_fit_desc* desc, const hk_io_desc* io, 
                     float* params_out /* nullable */, int32_t n_param_bands, void* corr_out /* nullable */,
                     double* norm_out, uint64_t* r2_fail_count);
 
+/* RefSpaceModel.fit + RefSpaceModel.apply (homonim/kernel_model.py:476-503) of one block pair on DIFFERENT grids of one
+ * CRS, entirely on the device -- source and reference blocks in, corrected block (source grid) out:
+ *   source --down_resampling--> reference grid; KernelModel.fit there (incl. block statistics / in-painting);
+ *   gain, offset --up_resampling--> source grid; re-masked with the source mask, or (mask_partial) with the full-coverage
+ *   mask of kernel_model.py:375-409 brought back with `nearest`; KernelModel.apply.
+ * down = mapping source <- reference grid (src_col = down[0] * ref_col + down[1], src_row = down[2] * ref_row + down[3]),
+ * up = mapping reference <- source grid; both as hk_reproject defines them.  params_out (nullable): n_param_bands planes on
+ * the REFERENCE grid.  io (nullable) types src / ref / corr_out as in hk_fit_apply_io. */
+typedef struct {
+    double down[4];
+    double up[4];
+    int32_t down_resampling;  /* rasterio.enums.Resampling value, KernelModel._get_resampling(src.res, ref.res) */
+    int32_t up_resampling;    /* KernelModel._get_resampling(param.res, src.res) */
+    int32_t mask_partial;
+} hk_space_desc;
+int hk_refspace_fit_apply(hk_ctx* ctx, const hk_fit_desc* desc, const hk_io_desc* io, const hk_space_desc* space,
+                          const void* src, int64_t src_stride, int32_t src_height, int32_t src_width, const void* ref,
+                          int64_t ref_stride, int32_t ref_height, int32_t ref_width, float* params_out,
+                          int32_t n_param_bands, void* corr_out, uint64_t* r2_fail_count);
+
 /* Page-lock caller memory so the host-pointer entry points above become truly asynchronous: with pinned src/ref/output
  * arrays the H2D copy, the kernel and the D2H copy of different calls (different host threads, different pooled streams)
  * overlap; with pageable memory HIP stages every copy synchronously.  The reference has no counterpart (its blocks are

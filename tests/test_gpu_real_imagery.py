@@ -105,3 +105,32 @@ def test_raster_fuse_process_across_resolutions(pair, model, kernel_shape, proc_
 def utils_overlap(kernel_shape):
     from homonim_amd import utils
     return utils.overlap_for_kernel(kernel_shape)
+
+
+@pytest.mark.parametrize('model, kernel_shape, mask_partial', [
+    (Model.gain_blk_offset, (5, 5), False), (Model.gain_offset, (5, 5), False), (Model.gain, (3, 3), True),
+    (Model.gain_offset, (15, 15), True),
+])
+def test_fused_refspace_pipeline_equals_step_by_step(pair, model, kernel_shape, mask_partial):
+    """ hk_refspace_fit_apply keeps the re-sampled source, the parameters and the masks in HBM; it must reproduce the
+    step-by-step RefSpaceModel.fit -> apply (four host round trips) bit for bit -- float32 and uint8 in / out. """
+    import warnings
+    from homonim_amd.fuse import convert_dtype
+    src, src_tf, src_nodata, ref, ref_tf = pair
+    crs = CRS('EPSG:32735')
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        km = RefSpaceModel(model, kernel_shape, find_r2=True, mask_partial=mask_partial)
+    src_ra = RasterArray(src[1].astype(np.float32), crs, src_tf, nodata=src_nodata)
+    ref_ra = RasterArray(ref[1].astype(np.float32), crs, ref_tf, nodata=None)
+    param_ra = km.fit(src_ra, ref_ra)
+    corr_ra = km.apply(src_ra, param_ra)
+    f_corr, f_param = km.fit_apply(src_ra, ref_ra, want_params=True)
+    same = lambda a, b: bool(((a == b) | (np.isnan(a) & np.isnan(b))).all())
+    assert same(f_param.array, param_ra.array) and f_param.transform == ref_ra.transform
+    assert same(f_corr.array, corr_ra.array) and f_corr.transform == src_ra.transform
+    # typed: uint8 rasters in, uint8 corrected block out, converted on the device
+    b_corr, _ = km.fit_apply(RasterArray(src[1], crs, src_tf, nodata=src_nodata), RasterArray(ref[1], crs, ref_tf, nodata=None),
+                             out_dtype='uint8', out_nodata=0)
+    assert b_corr.array.dtype == np.uint8
+    np.testing.assert_array_equal(b_corr.array, convert_dtype(corr_ra.array, 'uint8', 0))
