@@ -282,7 +282,8 @@ class Context:
 
     def refspace_fit_apply(self, desc: FitDesc, src: np.ndarray, ref: np.ndarray, down, up, down_resampling: int,
                            up_resampling: int, mask_partial: bool, n_param_bands: int, want_params: bool,
-                           out_dtype: str = 'float32', out_nodata: Optional[float] = None):
+                           out_dtype: str = 'float32', out_nodata: Optional[float] = None,
+                           out_corr: Optional[np.ndarray] = None):
         """ hk_refspace_fit_apply: RefSpaceModel.fit + apply of one block pair on different grids, all on the device.
         -> (params on the reference grid | None, corrected on the source grid, r2_fail_count) """
         src, ref = _as_2d_native(src, 'src'), _as_2d_native(ref, 'ref')
@@ -296,7 +297,8 @@ class Context:
             sp.down[i], sp.up[i] = float(down[i]), float(up[i])
         sp.down_resampling, sp.up_resampling, sp.mask_partial = int(down_resampling), int(up_resampling), int(mask_partial)
         params = np.empty((n_param_bands, *ref.shape), np.float32) if want_params else None
-        corr = np.empty(src.shape, out_dtype)
+        corr = out_corr if out_corr is not None else np.empty(src.shape, out_dtype)
+        assert corr.shape == src.shape and corr.dtype == out_dtype and corr.flags['C_CONTIGUOUS']
         fail = C.c_uint64(0)
         vp = C.c_void_p
         _check(self._lib.hk_refspace_fit_apply(

@@ -29,6 +29,7 @@ def main():
     p.add_argument('--model', default='gain-offset')
     p.add_argument('--kernel', type=int, default=5)
     p.add_argument('--pageable', action='store_true', help='plain numpy arrays instead of pinned ones')
+    p.add_argument('--refspace', type=int, default=0, help='N > 0: reference tiles N x coarser than the source tiles; fused RefSpaceModel pipeline')
     p.add_argument('--dtype', default='float32', help='host raster dtype in and out (float32 | uint8 | uint16 | int16)')
     args = p.parse_args()
 
@@ -49,6 +50,16 @@ def main():
         srcs.append(s)
         refs.append(r)
     outs = [alloc((n, n)) for _ in range(args.threads)]
+    if args.refspace:
+        f = args.refspace
+        m = n // f
+        coarse = []
+        for r in refs:   # block-average the full-resolution reference to the coarse grid
+            c = alloc((m, m))
+            c[:] = r[:m * f, :m * f].reshape(m, f, m, f).astype(np.float64).mean(axis=(1, 3)).round().astype(dt) \
+                if dt.kind != 'f' else r[:m * f, :m * f].reshape(m, f, m, f).mean(axis=(1, 3)).astype(dt)
+            coarse.append(c)
+        refs = coarse
     thresh = 0.25 if args.model == 'gain-offset' else None
     desc = _hk.make_desc(args.model, (args.kernel, args.kernel), False, thresh, None, None)
     n_param = 3 if thresh is not None else 2
@@ -58,8 +69,14 @@ def main():
         fails = 0
         for w in work[tid::args.threads]:
             i = w % args.distinct
-            _, _, _, f = ctx.fit_apply(desc, srcs[i], refs[i], n_param, want_params=False, want_corr=True,
-                                       out_corr=outs[tid], out_dtype=dt.name, out_nodata=None if dt.kind == 'f' else 0)
+            if args.refspace:
+                k = float(args.refspace)
+                _, _, f = ctx.refspace_fit_apply(desc, srcs[i], refs[i], (k, 0., k, 0.), (1 / k, 0., 1 / k, 0.), 5, 3,
+                                                 False, n_param, False, out_dtype=dt.name,
+                                                 out_nodata=None if dt.kind == 'f' else 0, out_corr=outs[tid])
+            else:
+                _, _, _, f = ctx.fit_apply(desc, srcs[i], refs[i], n_param, want_params=False, want_corr=True,
+                                           out_corr=outs[tid], out_dtype=dt.name, out_nodata=None if dt.kind == 'f' else 0)
             fails += f
         return fails
 
@@ -73,7 +90,7 @@ def main():
         metric='Mpixels*bands/s fit+apply end-to-end incl. PCIe (host-resident tiles)', value=round(px / dt_s / 1e6, 1),
         seconds=round(dt_s, 3), tiles=args.tiles, bands=args.bands, tile=n, threads=args.threads, streams=args.streams,
         pinned=not args.pageable, model=args.model, kernel=args.kernel, r2_mask_failures=int(fails),
-        dtype=dt.name, pcie_gbps_in=round(px * 2 * dt.itemsize / dt_s / 1e9, 1),
+        refspace=args.refspace, dtype=dt.name, pcie_gbps_in=round(px * 2 * dt.itemsize / dt_s / 1e9, 1),
         pcie_gbps_out=round(px * dt.itemsize / dt_s / 1e9, 1))))
     ctx.close()
 
