@@ -163,8 +163,15 @@ void fill_args(hk::FitArgs& a, const hk_fit_desc* d, int xcd_remap) {
     a.r2_pass_scale = a.has_thresh ? r2_pass_scale(d->r2_thresh) : -INFINITY;
     a.force_general = getenv("HK_FORCE_GENERAL") ? atoi(getenv("HK_FORCE_GENERAL")) : 0;
     // LDS row ring only while it leaves room for >= 11 waves per CU (kh <= 5); taller kernels re-load rows (hk_kernels.hip)
-    a.use_ring = d->kh <= 5 && d->kw <= 7;
-    if (const char* e = getenv("HK_USE_RING")) a.use_ring = atoi(e) != 0 && d->kh <= 63 && d->kw <= 7;
+    // ring mode (hk_kernels.hip): full LDS ring while it leaves room for >= 11 waves per CU (kh <= 5), centre-only ring up
+    // to kh = 17 (<= 12.5 KB per wave), everything re-loaded beyond
+    a.use_ring = (d->kh <= 5 && d->kw <= 7) ? 1 : (d->kh <= 17 ? 2 : 0);
+    if (const char* e = getenv("HK_USE_RING")) {  // testing hook
+        const int m = atoi(e);
+        if (m == 1 && d->kh <= 63 && d->kw <= 7) a.use_ring = 1;
+        if (m == 2 && d->kh <= 127) a.use_ring = 2;
+        if (m == 0) a.use_ring = 0;
+    }
     a.xcd_remap = xcd_remap;
 }
 

@@ -34,14 +34,14 @@ struct FitArgs {
     float r2_thresh;
     double r2_pass_scale;   // certified-pass factor of the division-free r2-mask test (hk_api.hip: r2_pass_scale())
     int force_general;      // 1: never take the dense (nodata None) specialisation (testing)
-    int use_ring;           // 1: leaving/centre rows from the LDS ring (short kernels); 0: re-loaded from global memory
+    int use_ring;           // ring mode of fit_apply_kernel: 1 full LDS ring, 2 centre ring + re-loaded leaving row, 0 re-load both
     int xcd_remap;          // 1: blockIdx -> unit remap that keeps neighbouring units on one XCD
 };
 
 // model: 0 gain, 1 gain-blk-offset, 2 gain-offset.  with_r2: compute the R2 quantity set.
 hipError_t launch_fit_apply(const FitArgs& a, int model, bool with_r2, hipStream_t stream);
 // LDS bytes one wave needs (row ring of kh rows when use_ring, plus the 1/N table).
-size_t fit_lds_bytes(int kh, bool use_ring);
+size_t fit_lds_bytes(int kh, int ring_mode);
 // lanes per side that overlap with the neighbouring strip for kernel half-width rw
 inline int overlap_lanes_for(int rw) { return (rw + PX - 1) / PX; }
 

@@ -71,12 +71,57 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
+// value held by the lane `dist` lanes away (dist > 0: to the left) through the LDS crossbar; lanes without a source read
+// an unspecified lane -- only ever used where those lanes are overlap lanes whose results are discarded
+template <typename T>
+__device__ __forceinline__ T bperm_from(T v, int src_lane);
+template <>
+__device__ __forceinline__ int bperm_from<int>(int v, int src_lane) {
+    return __builtin_amdgcn_ds_bpermute((src_lane & (WAVE - 1)) << 2, v);
+}
+template <>
+__device__ __forceinline__ double bperm_from<double>(double v, int src_lane) {
+    const int a = (src_lane & (WAVE - 1)) << 2;
+    return __hiloint2double(__builtin_amdgcn_ds_bpermute(a, __double2hiint(v)), __builtin_amdgcn_ds_bpermute(a, __double2loint(v)));
+}
+
+__host__ __device__ constexpr bool need_left_at(int rw, int j, int len) {
+    for (int i = 0; i < PX; ++i)
+        if (left_len(rw, i, j) == len) return true;
+    return false;
+}
+__host__ __device__ constexpr bool need_right_at(int rw, int j, int len) {
+    for (int i = 0; i < PX; ++i)
+        if (right_len(rw, i, j) == len) return true;
+    return false;
+}
+// true when all four outputs take the WHOLE of the lane j to the left and to the right
+__host__ __device__ constexpr bool lane_full_for_all(int rw, int j) {
+    for (int i = 0; i < PX; ++i)
+        if (left_len(rw, i, j) != PX || right_len(rw, i, j) != PX) return false;
+    return true;
+}
+
+// Has output i already received a non-common term before (j, side) in the order j = 1.., left then right?
+__host__ __device__ constexpr bool specific_before(int rw, int i, int j, bool right_side, bool own_full) {
+    if (!own_full) return true;  // H[i] starts from the lane's own partial sum
+    for (int jj = 1; jj <= j; ++jj) {
+        if (lane_full_for_all(rw, jj)) continue;
+        const bool l = left_len(rw, i, jj) > 0, r = right_len(rw, i, jj) > 0;
+        if (jj < j ? (l || r) : (right_side && l)) return true;
+    }
+    return false;
+}
+
 // Horizontal window sums of half-width RW over the wave's 256 columns: lane holds V[0..3] (its 4 columns), receives
 // H[i] = sum of columns [i-RW, i+RW].  Everything below is resolved at compile time into straight-line code:
-// per lane 6 adds for the prefix/suffix partial sums, then per neighbour distance the needed DPP moves + adds
-// (RW = 2: 4 shifted values, 9 adds per 4 pixels).
+//   * per lane 5 adds for the prefix / suffix partial sums of its own columns;
+//   * neighbours at distance 1 arrive through DPP wave shifts (VALU), neighbours farther away through ds_bpermute (LDS
+//     crossbar, one instruction per dword whatever the distance);
+//   * lanes that lie wholly inside all four windows are summed once into a common term.
+// RW = 2: 4 shifted values (8 DPP moves) + 9 adds per 4 pixels; RW = 7: 2 DPP-shifted + 6 permuted values + 13 adds.
 template <int RW, typename T>
-__device__ __forceinline__ void hsum(const T (&V)[PX], T (&H)[PX]) {
+__device__ __forceinline__ void hsum(const T (&V)[PX], T (&H)[PX], int lane) {
     if constexpr (RW == 0) {
 #pragma unroll
         for (int i = 0; i < PX; ++i) H[i] = V[i];
@@ -90,35 +135,58 @@ __device__ __forceinline__ void hsum(const T (&V)[PX], T (&H)[PX]) {
         suf[2] = V[2] + V[3];
         suf[3] = V[1] + suf[2];
         pre[4] = suf[4] = pre[2] + suf[2];
+        constexpr bool OWN_FULL = RW >= PX - 1;  // every output's window holds the lane's own four columns
+        T common = pre[PX];
         static_for<0, PX>([&](auto I) {
             constexpr int i = decltype(I)::value, lo = i - RW, hi = i + RW;
-            if constexpr (lo <= 0 && hi >= PX - 1)
-                H[i] = pre[PX];
-            else if constexpr (lo <= 0)
-                H[i] = pre[hi + 1];
-            else
-                H[i] = suf[PX - lo];
+            if constexpr (!OWN_FULL) {
+                if constexpr (lo <= 0 && hi >= PX - 1)
+                    H[i] = pre[PX];
+                else if constexpr (lo <= 0)
+                    H[i] = pre[hi + 1];
+                else
+                    H[i] = suf[PX - lo];
+            }
         });
-        T ls[PX + 1], rp[PX + 1];
-#pragma unroll
-        for (int k = 1; k <= PX; ++k) {
-            ls[k] = suf[k];
-            rp[k] = pre[k];
-        }
         static_for<1, OL + 1>([&](auto J) {
             constexpr int j = decltype(J)::value;
+            T ls[PX + 1], rp[PX + 1];
             static_for<1, PX + 1>([&](auto K) {
                 constexpr int k = decltype(K)::value;
-                if constexpr (need_left_from(RW, j, k, OL)) ls[k] = dpp_from_left(ls[k]);
-                if constexpr (need_right_from(RW, j, k, OL)) rp[k] = dpp_from_right(rp[k]);
+                if constexpr (need_left_at(RW, j, k)) {
+                    if constexpr (j == 1) ls[k] = dpp_from_left(suf[k]);
+                    else ls[k] = bperm_from<T>(suf[k], lane - j);
+                }
+                if constexpr (need_right_at(RW, j, k)) {
+                    if constexpr (j == 1) rp[k] = dpp_from_right(pre[k]);
+                    else rp[k] = bperm_from<T>(pre[k], lane + j);
+                }
             });
+            if constexpr (OWN_FULL && lane_full_for_all(RW, j)) {
+                common = common + ls[PX];
+                common = common + rp[PX];
+            } else {
+                static_for<0, PX>([&](auto I) {
+                    constexpr int i = decltype(I)::value;
+                    constexpr int ll = left_len(RW, i, j), rl = right_len(RW, i, j);
+                    if constexpr (ll > 0) {
+                        if constexpr (specific_before(RW, i, j, false, OWN_FULL)) H[i] = H[i] + ls[ll];
+                        else H[i] = ls[ll];
+                    }
+                    if constexpr (rl > 0) {
+                        if constexpr (specific_before(RW, i, j, true, OWN_FULL)) H[i] = H[i] + rp[rl];
+                        else H[i] = rp[rl];
+                    }
+                });
+            }
+        });
+        if constexpr (OWN_FULL) {
             static_for<0, PX>([&](auto I) {
                 constexpr int i = decltype(I)::value;
-                constexpr int ll = left_len(RW, i, j), rl = right_len(RW, i, j);
-                if constexpr (ll > 0) H[i] = H[i] + ls[ll];
-                if constexpr (rl > 0) H[i] = H[i] + rp[rl];
+                if constexpr (specific_before(RW, i, OL + 1, false, true)) H[i] = common + H[i];
+                else H[i] = common;
             });
-        });
+        }
     }
 }
 
@@ -158,7 +226,7 @@ __device__ __forceinline__ void hsum_rt(const T (&V)[PX], T (&H)[PX], int rw, in
 template <int RW, typename T>
 __device__ __forceinline__ void hsum_any(const T (&V)[PX], T (&H)[PX], int rw, int ol, int lane) {
     if constexpr (RW >= 0)
-        hsum<RW, T>(V, H);
+        hsum<RW, T>(V, H, lane);
     else
         hsum_rt<T>(V, H, rw, ol, lane);
 }
@@ -304,8 +372,13 @@ struct ColSums {
 #ifndef HK_FIT_MIN_WAVES
 #define HK_FIT_MIN_WAVES 3  // waves per SIMD the register allocator must leave room for (tuned on MI355X)
 #endif
-// RING: leaving/centre rows from the wave-private LDS ring (short kernels) or re-loaded from global memory.
-template <int MODEL, bool R2, int RW, bool DENSE, bool RING>
+// RING: where the leaving row (t - kh) and the window's centre row (t - rh) come from:
+//   1  both from a wave-private LDS ring of kh processed rows (short kernels, kh <= 5);
+//   2  centre row from an LDS ring of rh + 1 rows holding only `s` + mask (20 B per lane-row), leaving row re-loaded from
+//      global memory -- tall kernels: a full ring would cut occupancy to one wave per SIMD, re-loading BOTH rows makes
+//      three streams that all miss L2 and the kernel fabric-bound;
+//   0  both re-loaded (very tall kernels whose centre ring would not fit either).
+template <int MODEL, bool R2, int RW, bool DENSE, int RING>
 __global__ void __launch_bounds__(WAVE, HK_FIT_MIN_WAVES) fit_apply_kernel(const FitArgs a) {
     using CS = ColSums<MODEL, R2, DENSE>;
     constexpr bool GO = MODEL == 2, BLK = MODEL == 1;
@@ -364,16 +437,18 @@ __global__ void __launch_bounds__(WAVE, HK_FIT_MIN_WAVES) fit_apply_kernel(const
         n1 = a.norm[2 * band + 1];
     }
 
-    // Leaving / centre rows of the window come either from a wave-private LDS ring of kh processed rows
-    // ([slot][s|r][lane] float4 + [slot][lane] mask words; 36 B per lane-row) or, for tall kernels whose ring would
-    // crush occupancy (a.use_ring == 0), are simply loaded again from global memory (L2 / Infinity-Cache hits).
-    constexpr bool ring = RING;
-    const int ring_rows = ring ? kh : 0;
-    float4* ring_v = lds4;
-    unsigned* ring_m = reinterpret_cast<unsigned*>(lds4 + (size_t)ring_rows * 2 * WAVE);
+    constexpr bool ring = RING == 1;         // full ring: leaving + centre rows
+    constexpr bool cring = RING == 2;        // centre-only ring
+    const int ring_rows = ring ? kh : (cring ? rh + 1 : 0);
+    float4* ring_v = lds4;  // RING 1: [slot][s|r][lane]; RING 2: [slot][lane] (s only)
+    unsigned* ring_m = reinterpret_cast<unsigned*>(lds4 + (size_t)ring_rows * (ring ? 2 : 1) * WAVE);
     for (int sl = 0; sl < ring_rows; ++sl) {
-        ring_v[(sl * 2 + 0) * WAVE + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
-        ring_v[(sl * 2 + 1) * WAVE + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (ring) {
+            ring_v[(sl * 2 + 0) * WAVE + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+            ring_v[(sl * 2 + 1) * WAVE + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+            ring_v[sl * WAVE + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         if constexpr (!DENSE) ring_m[sl * WAVE + lane] = 0u;
     }
 
@@ -406,23 +481,22 @@ __global__ void __launch_bounds__(WAVE, HK_FIT_MIN_WAVES) fit_apply_kernel(const
 
     unsigned nfail = 0;
     int slot = 0;
+    int slot2 = 0;  // RING 2: write slot of the centre ring
     int slot_c = kh - rh;  // slot of the centre row of the output produced at this iteration: (slot - rh) mod kh
     if (slot_c >= kh) slot_c -= kh;
     for (int t = t_first; t <= t_last; ++t) {
         const RowRaw q2 = load_row(sp, rp, a.stride, t + 2 <= t_last ? t + 2 : -1, H, x, lane_in);
 
-        // reload mode: issue the loads of the leaving row (t - kh; a zero row if it was never added) and of the centre
-        // row (t - rh) now, consume them after the entering row has been folded in
+        // rows that do not come from LDS: issue their loads now, consume them after the entering row has been folded in
+        // (the leaving row t - kh is a zero row if it was never added; the centre row is t - rh)
         RowRaw qo, qc;
         const int t_old = t - kh, y_c = t - rh;
-        if (!ring) {
-            qo = load_row(sp, rp, a.stride, t_old >= t_first ? t_old : -1, H, x, lane_in);
-            qc = load_row(sp, rp, a.stride, y_c >= y0 ? y_c : -1, H, x, lane_in);
-        }
+        if constexpr (!ring) qo = load_row(sp, rp, a.stride, t_old >= t_first ? t_old : -1, H, x, lane_in);
+        if constexpr (RING == 0) qc = load_row(sp, rp, a.stride, y_c >= y0 ? y_c : -1, H, x, lane_in);
 
         const RowZ znew = process_row<MODEL, DENSE>(q0, t >= 0 && t < H, colbits, ragged, ts, tr, n0, n1);
         RowZ zold;
-        if (ring) {
+        if constexpr (ring) {
             // leaving row (t - kh): read from the slot the entering row is about to overwrite
             const float4 os = ring_v[(slot * 2 + 0) * WAVE + lane];
             const float4 orr = ring_v[(slot * 2 + 1) * WAVE + lane];
@@ -434,6 +508,10 @@ __global__ void __launch_bounds__(WAVE, HK_FIT_MIN_WAVES) fit_apply_kernel(const
             if constexpr (!DENSE) ring_m[slot * WAVE + lane] = znew.m;
         } else {
             zold = process_row<MODEL, DENSE>(qo, t_old >= t_first && t_old >= 0 && t_old < H, colbits, ragged, ts, tr, n0, n1);
+            if constexpr (cring) {  // slot2 cycles over rh + 1 rows: the entering row replaces the centre row of rh + 1 ago
+                ring_v[slot2 * WAVE + lane] = make_float4(znew.s[0], znew.s[1], znew.s[2], znew.s[3]);
+                if constexpr (!DENSE) ring_m[slot2 * WAVE + lane] = znew.m;
+            }
         }
 
         if (kh == 1) {  // wave-uniform: a 1-row window IS the entering row -- no running sum, exact by construction
@@ -449,10 +527,13 @@ __global__ void __launch_bounds__(WAVE, HK_FIT_MIN_WAVES) fit_apply_kernel(const
             // centre row of the window
             float sc[PX];
             unsigned mc;
-            if (ring) {
-                const float4 cs4 = ring_v[(slot_c * 2 + 0) * WAVE + lane];
+            if constexpr (ring || cring) {
+                // RING 1: slot_c = (slot - rh) mod kh; RING 2: the slot after the one just written = (slot2 + 1) mod (rh + 1)
+                int cs_slot = slot_c;
+                if constexpr (cring) cs_slot = slot2 + 1 == rh + 1 ? 0 : slot2 + 1;
+                const float4 cs4 = ring ? ring_v[(cs_slot * 2 + 0) * WAVE + lane] : ring_v[cs_slot * WAVE + lane];
                 sc[0] = cs4.x, sc[1] = cs4.y, sc[2] = cs4.z, sc[3] = cs4.w;
-                mc = DENSE ? 0u : ring_m[slot_c * WAVE + lane];
+                mc = DENSE ? 0u : ring_m[cs_slot * WAVE + lane];
             } else {
                 const RowZ zc = process_row<MODEL, DENSE>(qc, true, colbits, ragged, ts, tr, n0, n1);
 #pragma unroll
@@ -610,6 +691,7 @@ __global__ void __launch_bounds__(WAVE, HK_FIT_MIN_WAVES) fit_apply_kernel(const
         q1 = q2;
         if (++slot == kh) slot = 0;
         if (++slot_c == kh) slot_c = 0;
+        if (++slot2 == rh + 1) slot2 = 0;
     }
 
     if constexpr (GO && R2) {
@@ -621,12 +703,15 @@ __global__ void __launch_bounds__(WAVE, HK_FIT_MIN_WAVES) fit_apply_kernel(const
     }
 }
 
-// LDS bytes of one wave: [row ring + mask words of kh rows, only in ring mode] + the 256-entry float64 1/N table
-size_t fit_lds_bytes(int kh, bool use_ring) {
-    return (use_ring ? (size_t)kh * (2 * WAVE * sizeof(float4) + WAVE * sizeof(unsigned)) : 0) + 256 * sizeof(double);
+// LDS bytes of one wave: the row ring of the mode (see fit_apply_kernel) + the 256-entry float64 1/N table
+size_t fit_lds_bytes(int kh, int ring_mode) {
+    size_t ring = 0;
+    if (ring_mode == 1) ring = (size_t)kh * (2 * WAVE * sizeof(float4) + WAVE * sizeof(unsigned));
+    if (ring_mode == 2) ring = (size_t)(kh / 2 + 1) * (WAVE * sizeof(float4) + WAVE * sizeof(unsigned));
+    return ring + 256 * sizeof(double);
 }
 
-template <int MODEL, bool R2, int RW, bool DENSE, bool RING>
+template <int MODEL, bool R2, int RW, bool DENSE, int RING>
 static hipError_t launch_one(const FitArgs& a, hipStream_t stream) {
     const size_t lds = fit_lds_bytes(2 * a.rh + 1, RING);
     if (lds > 64 * 1024) {  // forced LDS ring on a tall kernel (testing): raise the 64 KiB dynamic-LDS default
@@ -642,25 +727,28 @@ static hipError_t launch_one(const FitArgs& a, hipStream_t stream) {
 
 template <int MODEL, bool R2, bool DENSE>
 static hipError_t launch_rw(const FitArgs& a, hipStream_t stream) {
-    if (a.use_ring) {  // LDS-ring kernels exist for the short, narrow shapes only (hk_api.hip picks use_ring)
+    // a.use_ring (hk_api.hip): 1 full LDS ring (short, narrow kernels only), 2 centre ring + re-loaded leaving row,
+    // 0 everything re-loaded (very tall kernels; run-time width path only, to bound the number of instantiations)
+    if (a.use_ring == 1) {
         switch (a.rw) {
-            case 0: return launch_one<MODEL, R2, 0, DENSE, true>(a, stream);
-            case 1: return launch_one<MODEL, R2, 1, DENSE, true>(a, stream);
-            case 2: return launch_one<MODEL, R2, 2, DENSE, true>(a, stream);
-            case 3: return launch_one<MODEL, R2, 3, DENSE, true>(a, stream);
+            case 0: return launch_one<MODEL, R2, 0, DENSE, 1>(a, stream);
+            case 1: return launch_one<MODEL, R2, 1, DENSE, 1>(a, stream);
+            case 2: return launch_one<MODEL, R2, 2, DENSE, 1>(a, stream);
+            case 3: return launch_one<MODEL, R2, 3, DENSE, 1>(a, stream);
             default: break;
         }
     }
+    if (a.use_ring == 0) return launch_one<MODEL, R2, -1, DENSE, 0>(a, stream);
     switch (a.rw) {
-        case 0: return launch_one<MODEL, R2, 0, DENSE, false>(a, stream);
-        case 1: return launch_one<MODEL, R2, 1, DENSE, false>(a, stream);
-        case 2: return launch_one<MODEL, R2, 2, DENSE, false>(a, stream);
-        case 3: return launch_one<MODEL, R2, 3, DENSE, false>(a, stream);
-        case 4: return launch_one<MODEL, R2, 4, DENSE, false>(a, stream);
-        case 5: return launch_one<MODEL, R2, 5, DENSE, false>(a, stream);
-        case 6: return launch_one<MODEL, R2, 6, DENSE, false>(a, stream);
-        case 7: return launch_one<MODEL, R2, 7, DENSE, false>(a, stream);
-        default: return launch_one<MODEL, R2, -1, DENSE, false>(a, stream);
+        case 0: return launch_one<MODEL, R2, 0, DENSE, 2>(a, stream);
+        case 1: return launch_one<MODEL, R2, 1, DENSE, 2>(a, stream);
+        case 2: return launch_one<MODEL, R2, 2, DENSE, 2>(a, stream);
+        case 3: return launch_one<MODEL, R2, 3, DENSE, 2>(a, stream);
+        case 4: return launch_one<MODEL, R2, 4, DENSE, 2>(a, stream);
+        case 5: return launch_one<MODEL, R2, 5, DENSE, 2>(a, stream);
+        case 6: return launch_one<MODEL, R2, 6, DENSE, 2>(a, stream);
+        case 7: return launch_one<MODEL, R2, 7, DENSE, 2>(a, stream);
+        default: return launch_one<MODEL, R2, -1, DENSE, 2>(a, stream);
     }
 }
 
@@ -779,8 +867,8 @@ __device__ int hsum_check(int lane) {
         Vi[i] = (lane * PX + i) * 3 + 1;
         V[i] = (double)Vi[i] + 0.5;
     }
-    hsum<RW, double>(V, Hd);
-    hsum<RW, int>(Vi, Hi);
+    hsum<RW, double>(V, Hd, lane);
+    hsum<RW, int>(Vi, Hi, lane);
     constexpr int OL = (RW + PX - 1) / PX;
     int bad = 0;
     if (lane >= OL && lane < WAVE - OL) {
@@ -811,6 +899,7 @@ __global__ void selftest_kernel(int* result) {
     if (hsum_check<2>(lane)) code |= 16;
     if (hsum_check<3>(lane)) code |= 32;
     if (hsum_check<7>(lane)) code |= 64;
+    if (hsum_check<4>(lane) || hsum_check<5>(lane) || hsum_check<6>(lane)) code |= 256;
     {   // run-time path
         int Vi[PX], Hi[PX];
 #pragma unroll

@@ -488,21 +488,23 @@ def test_pinned_arrays_and_caller_outputs(ctx):
     ('gain', (1, 5), True, None, np.nan), ('gain-offset', (31, 31), False, None, np.nan),
 ])
 def test_lds_ring_and_reload_modes_agree(ctx, model, kernel_shape, find_r2, thresh, nodata, monkeypatch):
-    """ The leaving/centre rows come from the LDS ring (short kernels) or are re-loaded from global memory (tall
-    kernels); both modes must give the same bytes, whichever the default for the shape is. """
+    """ The leaving / centre rows come from a full LDS ring (mode 1, short kernels), from a centre-only LDS ring plus a
+    re-loaded leaving row (mode 2, tall kernels) or are both re-loaded (mode 0); every mode must give the same bytes,
+    whichever the default for the shape is. """
     import warnings
     src, ref = onp.synth_pair(300, 520, seed=kernel_shape[0], nodata_variant='frame+holes' if nodata is not None else 'none')
     cfg = dict(model=model, kernel_shape=kernel_shape, find_r2=find_r2, r2_inpaint_thresh=thresh, src_nodata=nodata,
                ref_nodata=nodata)
     norm_in = onp.fit_block_norm(src, nodata, ref, nodata) if model == 'gain-blk-offset' else None
     out = {}
-    for mode in ('1', '0'):
+    for mode in ('1', '2', '0'):
         monkeypatch.setenv('HK_USE_RING', mode)
         out[mode] = _fit_via_abi(ctx, cfg, src, ref, norm_in=norm_in)
     monkeypatch.delenv('HK_USE_RING')
-    assert_same_f32(out['1'][0], out['0'][0], 'params ring vs reload')
-    assert_same_f32(out['1'][1], out['0'][1], 'corrected ring vs reload')
-    assert out['1'][3] == out['0'][3]
+    for mode in ('2', '0'):
+        assert_same_f32(out['1'][0], out[mode][0], f'params ring mode 1 vs {mode}')
+        assert_same_f32(out['1'][1], out[mode][1], f'corrected ring mode 1 vs {mode}')
+        assert out['1'][3] == out[mode][3]
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
         exp, _ = onp.fit(model, src, nodata, ref, nodata, kernel_shape, find_r2, thresh, norm_model=norm_in)
