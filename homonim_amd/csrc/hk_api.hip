@@ -150,6 +150,18 @@ double r2_pass_scale(float thresh) {
     return boundary * (1.0 - 0x1p-40);
 }
 
+// kappa >= 1 - c' with c' = c * (1 - 2^-50) (so that `ssres < c' * sstot` in real arithmetic implies the float64
+// comparison against fl(c * sstot)), clamped to >= 0 and rounded up to float32.  +inf = nothing can be certified.
+float r2_fail_scale(float thresh) {
+    const double c = r2_pass_scale(thresh);
+    if (!(c > 0.0)) return INFINITY;
+    double k = 1.0 - c * (1.0 - 0x1p-50);
+    if (k < 0.0) k = 0.0;
+    float kf = (float)k;
+    if ((double)kf < k + 0x1p-60) kf = nextafterf(kf, INFINITY);
+    return kf;
+}
+
 void fill_args(hk::FitArgs& a, const hk_fit_desc* d, int xcd_remap) {
     a.rh = d->kh / 2;
     a.rw = d->kw / 2;
@@ -160,7 +172,7 @@ void fill_args(hk::FitArgs& a, const hk_fit_desc* d, int xcd_remap) {
     a.ref_nodata = d->ref_nodata;
     a.has_thresh = (d->model == HK_MODEL_GAIN_OFFSET) ? d->has_r2_thresh : 0;
     a.r2_thresh = d->r2_thresh;
-    a.r2_pass_scale = a.has_thresh ? r2_pass_scale(d->r2_thresh) : -INFINITY;
+    a.r2_fail_scale = a.has_thresh ? r2_fail_scale(d->r2_thresh) : INFINITY;
     a.force_general = getenv("HK_FORCE_GENERAL") ? atoi(getenv("HK_FORCE_GENERAL")) : 0;
     // LDS row ring only while it leaves room for >= 11 waves per CU (kh <= 5); taller kernels re-load rows (hk_kernels.hip)
     // ring mode (hk_kernels.hip): full LDS ring while it leaves room for >= 11 waves per CU (kh <= 5), centre-only ring up

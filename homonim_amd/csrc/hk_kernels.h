@@ -32,7 +32,7 @@ struct FitArgs {
     float src_nodata, ref_nodata;
     int has_thresh;
     float r2_thresh;
-    double r2_pass_scale;   // certified-pass factor of the division-free r2-mask test (hk_api.hip: r2_pass_scale())
+    float r2_fail_scale;    // kappa of the division-free r2-mask certificate: 1 - r2_pass_scale(), rounded up (hk_api.hip)
     int force_general;      // 1: never take the dense (nodata None) specialisation (testing)
     int use_ring;           // ring mode of fit_apply_kernel: 1 full LDS ring, 2 centre ring + re-loaded leaving row, 0 re-load both
     int xcd_remap;          // 1: blockIdx -> unit remap that keeps neighbouring units on one XCD

@@ -465,8 +465,11 @@ __global__ void __launch_bounds__(WAVE, HK_FIT_MIN_WAVES) fit_apply_kernel(const
 
     const int t_first = y0 - rh, t_last = y1 - 1 + rh;
     // two rows in flight ahead of the one being consumed
+    // (one row for the wide variants: their horizontal stage needs the registers, a spill costs more than the latency)
+    constexpr int PF = (RW < 0 || RW >= 4) ? 1 : 2;
     RowRaw q0 = load_row(sp, rp, a.stride, t_first, H, x, lane_in);
-    RowRaw q1 = load_row(sp, rp, a.stride, t_first + 1 <= t_last ? t_first + 1 : -1, H, x, lane_in);
+    [[maybe_unused]] RowRaw q1;
+    if constexpr (PF == 2) q1 = load_row(sp, rp, a.stride, t_first + 1 <= t_last ? t_first + 1 : -1, H, x, lane_in);
 
     // r2-mask bookkeeping (gain-offset with a threshold, kernel_model.py:363): R2 values are only materialised when
     // asked for; otherwise pixels are first put through a division-free CERTIFIED test
@@ -478,6 +481,7 @@ __global__ void __launch_bounds__(WAVE, HK_FIT_MIN_WAVES) fit_apply_kernel(const
     const bool inpaint_pass = GO && R2 && a.offset_in != nullptr;
     const bool want_r2_values = R2 && (a.r2 != nullptr || inpaint_pass);
     const bool count_fails = GO && R2 && a.has_thresh;
+    const bool cert_ok = kh * (2 * rw + 1) <= 65535;  // window-count bound assumed by the certificate's constants
 
     unsigned nfail = 0;
     int slot = 0;
@@ -485,7 +489,7 @@ __global__ void __launch_bounds__(WAVE, HK_FIT_MIN_WAVES) fit_apply_kernel(const
     int slot_c = kh - rh;  // slot of the centre row of the output produced at this iteration: (slot - rh) mod kh
     if (slot_c >= kh) slot_c -= kh;
     for (int t = t_first; t <= t_last; ++t) {
-        const RowRaw q2 = load_row(sp, rp, a.stride, t + 2 <= t_last ? t + 2 : -1, H, x, lane_in);
+        const RowRaw q2 = load_row(sp, rp, a.stride, t + PF <= t_last ? t + PF : -1, H, x, lane_in);
 
         // rows that do not come from LDS: issue their loads now, consume them after the entering row has been folded in
         // (the leaving row t - kh is a zero row if it was never added; the centre row is t - rh)
@@ -568,17 +572,15 @@ __global__ void __launch_bounds__(WAVE, HK_FIT_MIN_WAVES) fit_apply_kernel(const
             // ---- stage A: gains and offsets -------------------------------------------------------------------------
             float g[PX], o[PX], r2v[PX], c[PX];
             [[maybe_unused]] float Rf[PX], Sf[PX], Pf[PX], gp[PX];
-            [[maybe_unused]] double Nd[PX];
 #pragma unroll
             for (int i = 0; i < PX; ++i) {
                 Rf[i] = (float)HR[i];  // boxFilter output depth = input depth (float32)
-                if constexpr (USE_N) Nd[i] = (double)Nf[i];
                 if constexpr (GO) {
                     // kernel_model.py:338-351; src2_sum is float64 (sqrBoxFilter) so m_den and the division are f64
                     Sf[i] = (float)HS[i];
                     Pf[i] = (float)HP[i];
                     const float num = __fsub_rn(__fmul_rn(Nf[i], Pf[i]), __fmul_rn(Sf[i], Rf[i]));
-                    const double den = __dsub_rn(__dmul_rn(Nd[i], HS2[i]), (double)__fmul_rn(Sf[i], Sf[i]));
+                    const double den = __dsub_rn(__dmul_rn((double)Nf[i], HS2[i]), (double)__fmul_rn(Sf[i], Sf[i]));
                     g[i] = (float)__ddiv_rn((double)num, den);
                     const float tn = __fsub_rn(Rf[i], __fmul_rn(g[i], Sf[i]));
                     o[i] = use_lut ? (float)__dmul_rn((double)tn, inv_lut[(int)Nf[i]]) : __fdiv_rn(tn, Nf[i]);
@@ -600,46 +602,66 @@ __global__ void __launch_bounds__(WAVE, HK_FIT_MIN_WAVES) fit_apply_kernel(const
             // ---- stage B: R2 (kernel_model.py:179,189-195|201,203,212-213) ---------------------------------------------
             if constexpr (R2) {
                 if (want_r2_values || count_fails) {  // wave-uniform
-                    double sstot[PX], ssres[PX];
-#pragma unroll
-                    for (int i = 0; i < PX; ++i) {
-                        sstot[i] = __dsub_rn(__dmul_rn(Nd[i], HR2[i]), (double)__fmul_rn(Rf[i], Rf[i]));
-                        double q;
-                        if constexpr (GO) {
-                            const double A = __dmul_rn((double)__fmul_rn(g[i], g[i]), HS2[i]);
-                            const float B = __fmul_rn(__fmul_rn(2.f, __fmul_rn(g[i], o[i])), Sf[i]);
-                            const float C = __fmul_rn(__fmul_rn(2.f, g[i]), Pf[i]);
-                            const float D = __fmul_rn(__fmul_rn(2.f, o[i]), Rf[i]);
-                            const float F = __fmul_rn(Nf[i], __fmul_rn(o[i], o[i]));
-                            q = __dadd_rn(A, (double)B);
-                            q = __dsub_rn(q, (double)C);
-                            q = __dsub_rn(q, (double)D);
-                            q = __dadd_rn(q, HR2[i]);
-                            q = __dadd_rn(q, (double)F);
-                        } else if constexpr (BLK) {
-                            // float64 src2_sum / src_ref_sum (the normalised source is float64)
-                            q = __dmul_rn((double)__fmul_rn(gp[i], gp[i]), HS2[i]);
-                            q = __dsub_rn(q, __dmul_rn((double)__fmul_rn(2.f, gp[i]), HP[i]));
-                            q = __dadd_rn(q, HR2[i]);
-                        } else {
-                            q = __dmul_rn((double)__fmul_rn(g[i], g[i]), HS2[i]);
-                            q = __dsub_rn(q, (double)__fmul_rn(__fmul_rn(2.f, g[i]), Pf[i]));
-                            q = __dadd_rn(q, HR2[i]);
-                        }
-                        ssres[i] = __dmul_rn(q, Nd[i]);
-                    }
                     bool exact = want_r2_values;
-                    if (!exact) {
-                        bool uncertain = false;
+                    if constexpr (GO) {
+                        if (!exact) {
+                            // Division-free CERTIFICATE of `(r2 > thresh) & (gain > 0)` from float32 quantities (proof:
+                            // DESIGN.md appendix A).  With T = g^2*S2 + R2 + N*o^2 the reference's float arithmetic obeys
+                            //   ssres_ref <= sstot_ref - g^2*den + 35*2^-24*N*T   and   |sstot_ref - sst| <= 4.1*2^-24*N*T,
+                            // so  g^2*den > kappa*sst + 2^-17*N*T  (kappa = 1 - r2_pass_scale, rounded up) proves
+                            // ssres_ref < r2_pass_scale * sstot_ref, which proves the reference's decision.
+                            bool uncertain = !cert_ok;
 #pragma unroll
-                        for (int i = 0; i < PX; ++i) {
-                            const bool m = (mc >> (8 * i)) & 1u;
-                            const bool sure = (sstot[i] > 0.0) & (ssres[i] < __dmul_rn(a.r2_pass_scale, sstot[i])) & (g[i] > 0.f);
-                            uncertain |= out_lane & m & !sure;
+                            for (int i = 0; i < PX; ++i) {
+                                const bool m = (mc >> (8 * i)) & 1u;
+                                const float gg = __fmul_rn(g[i], g[i]);
+                                const float S2f = (float)HS2[i], R2f = (float)HR2[i];
+                                const float sst = __fmaf_rn(Nf[i], R2f, -__fmul_rn(Rf[i], Rf[i]));
+                                const float T = __fmaf_rn(gg, S2f, __fmaf_rn(__fmul_rn(Nf[i], o[i]), o[i], R2f));
+                                const float NT = __fmul_rn(Nf[i], T);
+                                const float slack = __fmul_rn(0x1p-17f, NT);
+                                const float denf = __fmaf_rn(Nf[i], S2f, -__fmul_rn(Sf[i], Sf[i]));
+                                const float lhs = __fmul_rn(gg, denf);
+                                const float rhs = __fmaf_rn(a.r2_fail_scale, sst, slack);
+                                // magnitude windows (no underflow / overflow anywhere in the reference's expression):
+                                // 2^-20 < g < 2^20 (also the `gain > 0` half of the decision), 2^-40 < N*T < 2^60
+                                const bool g_in = (__float_as_uint(g[i]) - 0x35800000u) < (0x49800000u - 0x35800000u);
+                                const bool t_in = (__float_as_uint(NT) - 0x2b800000u) < (0x5d800000u - 0x2b800000u);
+                                const bool sure = (lhs > rhs) & (sst > slack) & g_in & t_in;
+                                uncertain |= out_lane & m & !sure;
+                            }
+                            exact = __any(uncertain);
                         }
-                        exact = __any(uncertain);
                     }
                     if (exact) {
+                        double sstot[PX], ssres[PX];
+#pragma unroll
+                        for (int i = 0; i < PX; ++i) {
+                            sstot[i] = __dsub_rn(__dmul_rn((double)Nf[i], HR2[i]), (double)__fmul_rn(Rf[i], Rf[i]));
+                            double q;
+                            if constexpr (GO) {
+                                const double A = __dmul_rn((double)__fmul_rn(g[i], g[i]), HS2[i]);
+                                const float B = __fmul_rn(__fmul_rn(2.f, __fmul_rn(g[i], o[i])), Sf[i]);
+                                const float C = __fmul_rn(__fmul_rn(2.f, g[i]), Pf[i]);
+                                const float D = __fmul_rn(__fmul_rn(2.f, o[i]), Rf[i]);
+                                const float F = __fmul_rn(Nf[i], __fmul_rn(o[i], o[i]));
+                                q = __dadd_rn(A, (double)B);
+                                q = __dsub_rn(q, (double)C);
+                                q = __dsub_rn(q, (double)D);
+                                q = __dadd_rn(q, HR2[i]);
+                                q = __dadd_rn(q, (double)F);
+                            } else if constexpr (BLK) {
+                                // float64 src2_sum / src_ref_sum (the normalised source is float64)
+                                q = __dmul_rn((double)__fmul_rn(gp[i], gp[i]), HS2[i]);
+                                q = __dsub_rn(q, __dmul_rn((double)__fmul_rn(2.f, gp[i]), HP[i]));
+                                q = __dadd_rn(q, HR2[i]);
+                            } else {
+                                q = __dmul_rn((double)__fmul_rn(g[i], g[i]), HS2[i]);
+                                q = __dsub_rn(q, (double)__fmul_rn(__fmul_rn(2.f, g[i]), Pf[i]));
+                                q = __dadd_rn(q, HR2[i]);
+                            }
+                            ssres[i] = __dmul_rn(q, (double)Nf[i]);
+                        }
 #pragma unroll
                         for (int i = 0; i < PX; ++i) {
                             r2v[i] = __fsub_rn(1.f, (float)__ddiv_rn(ssres[i], sstot[i]));
@@ -687,8 +709,12 @@ __global__ void __launch_bounds__(WAVE, HK_FIT_MIN_WAVES) fit_apply_kernel(const
             }
         }
 
-        q0 = q1;
-        q1 = q2;
+        if constexpr (PF == 2) {
+            q0 = q1;
+            q1 = q2;
+        } else {
+            q0 = q2;
+        }
         if (++slot == kh) slot = 0;
         if (++slot_c == kh) slot_c = 0;
         if (++slot2 == rh + 1) slot2 = 0;

@@ -445,6 +445,65 @@ def test_certified_r2_test_degenerate_windows(ctx, oc):
         assert_close_ulp(corr, exp_corr, 'corrected', max_frac=1e-3)
 
 
+def _adversarial_pair(kind, shape, seed):
+    """ Rasters whose windows sit where the r2-mask certificate is tight: tiny variance on a large mean (flat DN
+    imagery), R2 spread around the threshold, integer data, and magnitudes outside the certificate's windows. """
+    rng = np.random.default_rng(seed)
+    h, w = shape
+    yy, xx = np.mgrid[0:h, 0:w]
+    if kind == 'flat-dn':
+        sd = 10 ** (-2 + 3.5 * xx / w)                               # std 0.01 .. 30 on a mean of 5000
+        src = 5000 + sd * rng.normal(size=shape)
+        ref = 0.8 * src + 300 + sd * 10 ** (-1.5 + 2 * yy / h) * rng.normal(size=shape)
+    elif kind == 'marginal':
+        src = rng.normal(100, 10, shape)
+        ref = src + (3 + 40 * xx / w) * rng.normal(size=shape)       # R2 from ~0.9 down to ~0.05 across the columns
+    elif kind == 'integer':
+        src = rng.integers(0, 255, shape).astype(float)
+        ref = np.round(src * (0.5 + yy / h)) + rng.integers(0, 6, shape)
+    elif kind == 'tiny':
+        src = 1e-17 * rng.uniform(0.05, 1, shape)
+        ref = 1.2 * src + 1e-18 + 1e-19 * rng.normal(size=shape)
+    elif kind == 'huge':
+        src = 1e14 * rng.uniform(0.05, 1, shape)
+        ref = 1.2 * src + 1e13 + 1e12 * rng.normal(size=shape)
+    elif kind == 'small-gain':
+        src = 1e4 * rng.uniform(0.05, 1, shape)
+        ref = 10 ** (-8 + 7 * xx / w) * src + 1e-3 * rng.normal(size=shape)   # gains 1e-8 .. 0.1 (window edge 2^-20)
+    else:
+        raise ValueError(kind)
+    return src.astype(np.float32), ref.astype(np.float32)
+
+
+@pytest.mark.parametrize('kind', ['flat-dn', 'marginal', 'integer', 'tiny', 'huge', 'small-gain'])
+@pytest.mark.parametrize('kernel_shape, nodata', [((5, 5), None), ((5, 5), np.nan), ((3, 7), None), ((15, 15), np.nan)])
+def test_r2_certificate_on_adversarial_rasters(ctx, oc, kind, kernel_shape, nodata):
+    """ The float32 certificate of the r2 mask may never disagree with the reference's own
+    arithmetic: failure counts and corrected values equal the oracle's on data built to sit on its error bound. """
+    src, ref = _adversarial_pair(kind, (150, 700), seed=len(kind) + kernel_shape[1])
+    if nodata is not None:
+        src[60:64, 100:130] = np.nan
+        ref[10, ::37] = np.nan
+    n_valid = int((~np.isnan(src) & ~np.isnan(ref)).sum())
+    for thresh in (0.25, 0.0, 0.9):
+        # (1) the certificate against the kernel's own exact evaluation (parameter output switches the certificate
+        #     off): identical counts and corrected values, bit for bit
+        corr, n_fail = _fused_no_params(ctx, src, ref, nodata, kernel_shape, thresh)
+        desc = _hk.make_desc('gain-offset', kernel_shape, False, thresh, nodata, nodata)
+        _, corr_exact, _, n_fail_exact = ctx.fit_apply(desc, src, ref, 3, want_params=True, want_corr=True)
+        assert n_fail == n_fail_exact, (kind, thresh)
+        assert_same_f32(corr, corr_exact, 'corrected, certificate vs exact evaluation')
+        # (2) against the oracle.  On flat DN data the float64 sums of squares of a window are no longer exact and
+        #     sstot = N*sum(r^2) - sum(r)^2 cancels ~8 digits, so a few decisions near the threshold depend on the
+        #     summation order (oracle: OpenCV's order; kernel: column sums first) -- bounded, not bit-exact.
+        _, exp_corr, exp_fail = oc.fit_apply('gain-offset', src, nodata, ref, nodata, kernel_shape, False, thresh)
+        if kind in ('flat-dn', 'huge', 'tiny'):
+            assert abs(n_fail - exp_fail) <= 1e-3 * n_valid, (kind, thresh, n_fail, exp_fail)
+        else:
+            assert n_fail == exp_fail, (kind, thresh)
+            assert_close_ulp(corr, exp_corr, 'corrected', max_frac=1e-3)
+
+
 def test_block_norm_heavy_ties_take_the_fallback_select(ctx):
     """ Few distinct values: the [lo, hi] pivot window holds a third of the block, overflows the compaction buffer and
     routes the band through the full-raster radix select; the order statistics must still be exact. """

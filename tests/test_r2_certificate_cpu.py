@@ -1,0 +1,147 @@
+"""
+CPU test: numerical validation of the division-free r2-mask CERTIFICATE of the fused kernel (DESIGN.md appendix A;
+hk_kernels.hip stage B) on a numpy model of the same float32 expression.
+
+For millions of random windows -- incl. low-variance / large-mean, wildly scaled, marginal-R2 and integer data -- the
+reference's own arithmetic (kernel_model.py:338-351 gains/offsets, :179-195 R2, :363 mask; float64 sums of squares as
+cv2.sqrBoxFilter returns them) must say "passes" wherever the certificate says so.  The certificate may only err on the
+side of "not sure" (exact evaluation).  A slack constant 2^-24 instead of the proven 2^-17 does produce false
+certificates on this data, i.e. the data does probe the bound.
+"""
+import zlib
+
+import numpy as np
+import pytest
+
+F32, F64 = np.float32, np.float64
+
+
+def _fma32(a, b, c):
+    return (np.asarray(a, F64) * np.asarray(b, F64) + np.asarray(c, F64)).astype(F32)
+
+
+def reference_window_math(s, r):
+    """ s, r: (M, N) float32 windows, all pixels valid -> the reference's per-window quantities. """
+    n = s.shape[1]
+    nf, nd = F32(n), F64(n)
+    hs, hr = s.astype(F64).sum(1), r.astype(F64).sum(1)
+    hp = (s * r).astype(F32).astype(F64).sum(1)
+    hs2, hr2 = (s.astype(F64) ** 2).sum(1), (r.astype(F64) ** 2).sum(1)
+    sf, rf, pf = hs.astype(F32), hr.astype(F32), hp.astype(F32)
+    with np.errstate(all='ignore'):
+        num = ((nf * pf).astype(F32) - (sf * rf).astype(F32)).astype(F32)
+        den = nd * hs2 - (sf * sf).astype(F32).astype(F64)
+        g = (num.astype(F64) / den).astype(F32)
+        o = ((rf - (g * sf).astype(F32)).astype(F32) / nf).astype(F32)
+        sstot = nd * hr2 - (rf * rf).astype(F32).astype(F64)
+        q = (g * g).astype(F32).astype(F64) * hs2
+        q = q + ((F32(2) * (g * o).astype(F32)).astype(F32) * sf).astype(F32).astype(F64)
+        q = q - ((F32(2) * g).astype(F32) * pf).astype(F32).astype(F64)
+        q = q - ((F32(2) * o).astype(F32) * rf).astype(F32).astype(F64)
+        q = q + hr2
+        q = q + (nf * (o * o).astype(F32)).astype(F32).astype(F64)
+        r2 = (F32(1) - (q * nd / sstot).astype(F32)).astype(F32)
+    return dict(n=nf, g=g, o=o, sf=sf, rf=rf, hs2=hs2, hr2=hr2, r2=r2)
+
+
+def certificate(q, kappa, k2=F32(2.0 ** -17)):
+    """ The kernel's expression, operation for operation (hk_kernels.hip, stage B). """
+    g, o, nf, rf, sf = q['g'], q['o'], q['n'], q['rf'], q['sf']
+    with np.errstate(all='ignore'):
+        gg = (g * g).astype(F32)
+        s2f, r2f = q['hs2'].astype(F32), q['hr2'].astype(F32)
+        nfull = np.full_like(r2f, nf)
+        sst = _fma32(nfull, r2f, -(rf * rf).astype(F32))
+        t = _fma32(gg, s2f, _fma32((nf * o).astype(F32), o, r2f))
+        nt = (nf * t).astype(F32)
+        slack = (k2 * nt).astype(F32)
+        denf = _fma32(nfull, s2f, -(sf * sf).astype(F32))
+        lhs = (gg * denf).astype(F32)
+        rhs = _fma32(np.full_like(sst, kappa), sst, slack)
+        g_in = (g > F32(2.0 ** -20)) & (g < F32(2.0 ** 20))
+        t_in = (nt > F32(2.0 ** -40)) & (nt < F32(2.0 ** 60))
+        return (lhs > rhs) & (sst > slack) & g_in & t_in
+
+
+def kappa_for(thresh):
+    """ Mirror of hk_api.hip r2_pass_scale() / r2_fail_scale(). """
+    t = F32(thresh)
+    q = F32(1) - t
+    for _ in range(8):
+        q = np.nextafter(q, F32(np.inf))
+    while not (F32(1) - q > t):
+        q = np.nextafter(q, F32(-np.inf))
+    boundary = 0.5 * (float(q) + float(np.nextafter(q, F32(np.inf))))
+    c = boundary * (1 - 2.0 ** -40)
+    k = max(1 - c * (1 - 2.0 ** -50), 0.0)
+    kf = F32(k)
+    if float(kf) < k + 2.0 ** -60:
+        kf = np.nextafter(kf, F32(np.inf))
+    return kf
+
+
+def _windows(rng, m, n, kind):
+    if kind == 'synth':
+        s = rng.uniform(0.05, 1, (m, n))
+        r = 1.2 * s + 0.05 + rng.normal(0, 0.01, (m, n))
+    elif kind == 'lowvar':
+        mean = 10 ** rng.uniform(0, 4, (m, 1))
+        sd = mean * 10 ** rng.uniform(-5, -1, (m, 1))
+        s = mean + sd * rng.normal(size=(m, n))
+        r = ((0.5 + rng.random((m, 1))) * s + rng.normal(size=(m, n)) * sd * 10 ** rng.uniform(-3, 0.5, (m, 1))
+             + mean * rng.normal(size=(m, 1)))
+    elif kind == 'wild':
+        s = 10 ** rng.uniform(-8, 8, (m, 1)) * rng.normal(size=(m, n))
+        r = (10 ** rng.uniform(-6, 6, (m, 1)) * s * rng.normal(1, 0.1, (m, n))
+             + 10 ** rng.uniform(-8, 8, (m, 1)) * rng.normal(size=(m, n)))
+    elif kind == 'marginal':
+        s = rng.normal(100, 10, (m, n))
+        r = s + 10 ** rng.uniform(0.5, 1.6, (m, 1)) * rng.normal(size=(m, n))
+    elif kind == 'int':
+        s = rng.integers(0, 255, (m, n)).astype(float)
+        r = rng.integers(0, 4, (m, n)) + np.round(s * rng.uniform(0.3, 2, (m, 1)))
+    else:
+        raise ValueError(kind)
+    return s.astype(F32), r.astype(F32)
+
+
+@pytest.mark.parametrize('kind', ['synth', 'lowvar', 'wild', 'marginal', 'int'])
+@pytest.mark.parametrize('n', [2, 9, 25, 225])
+def test_certificate_never_contradicts_the_reference_arithmetic(kind, n):
+    rng = np.random.default_rng(zlib.crc32(f'{kind}{n}'.encode()))
+    s, r = _windows(rng, 120_000 if n < 100 else 30_000, n, kind)
+    q = reference_window_math(s, r)
+    n_cert = 0
+    for thresh in (0.0, 0.25, 0.5, 0.9, 0.999):
+        sure = certificate(q, kappa_for(thresh))
+        with np.errstate(all='ignore'):
+            passes = (q['r2'] > F32(thresh)) & (q['g'] > 0)
+        assert not (sure & ~passes).any()
+        n_cert += int(sure.sum())
+    if kind in ('synth', 'int') and n >= 9:
+        assert n_cert > 0.5 * 4 * len(s)   # and it is not vacuous: well-conditioned data is certified
+
+
+def test_the_data_probes_the_bound():
+    """ With the slack shrunk to 2^-24 (below the rounding errors of the reference expression) false certificates
+    appear on the low-variance windows; with the shipped 2^-17 (and even 2^-22) there are none. """
+    rng = np.random.default_rng(5)
+    s, r = _windows(rng, 400_000, 25, 'lowvar')
+    q = reference_window_math(s, r)
+    with np.errstate(all='ignore'):
+        passes = (q['r2'] > F32(0.25)) & (q['g'] > 0)
+    kappa = kappa_for(0.25)
+    assert (certificate(q, kappa, F32(2.0 ** -24)) & ~passes).sum() > 0
+    assert (certificate(q, kappa, F32(2.0 ** -22)) & ~passes).sum() == 0
+    assert (certificate(q, kappa) & ~passes).sum() == 0
+
+
+def test_nothing_is_certified_outside_the_magnitude_windows_or_for_impossible_thresholds():
+    rng = np.random.default_rng(6)
+    s, r = _windows(rng, 20_000, 25, 'synth')
+    for scale in (1e-18, 1e16):
+        q = reference_window_math((s * F32(scale)).astype(F32), (r * F32(scale)).astype(F32))
+        assert not certificate(q, kappa_for(0.25)).any()
+    q = reference_window_math(s, r)
+    assert not certificate(q, F32(np.inf)).any()          # thresh >= 1: r2_fail_scale() = +inf
+    assert not certificate(reference_window_math(s, (-r).astype(F32)), kappa_for(0.25)).any()   # negative gains
