@@ -254,18 +254,25 @@ struct RowRaw {
     float4 s, r;
 };
 
-// Rows are padded to a multiple of PX elements (stride % 4 == 0, checked on the host), so every lane whose first
-// column lies inside the raster moves a full 16 bytes; columns >= W inside that quad are masked by `colbits`.
+// Packed float32 arithmetic (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32: two IEEE operations per instruction).  With
+// -ffp-contract=off `a * b - c` stays a rounded product followed by a rounded subtraction, element-wise identical to
+// __fmul_rn / __fsub_rn; pk_fma is the fused single-rounding form (used by the r2-mask certificate only).
+typedef float f2 __attribute__((ext_vector_type(2)));
+#define HK_P2(a, j) (f2{(a)[2 * (j)], (a)[2 * (j) + 1]})
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+// Rows are padded to a multiple of PX elements (stride % 4 == 0, checked on the host), so every lane moves a full
+// 16 bytes.  The load is unconditional: the row is clamped into the raster (wave-uniform, so the row address is a
+// scalar base and the lane offset a 32-bit VGPR -> no per-row vector address arithmetic) and `xq` is a safe in-raster
+// quad for lanes outside it; whatever such a load returns is discarded by process_row (row_ok / colbits).
 __device__ __forceinline__ RowRaw load_row(const float* __restrict__ sp, const float* __restrict__ rp, long long stride,
-                                           int row, int height, int x, bool lane_in) {
+                                           int row, int height, unsigned xq) {
+    const int rc = min(max(row, 0), height - 1);
+    const float* __restrict__ ps = sp + (long long)rc * stride;
+    const float* __restrict__ pr = rp + (long long)rc * stride;
     RowRaw o;
-    o.s = make_float4(0.f, 0.f, 0.f, 0.f);
-    o.r = o.s;
-    if (row >= 0 && row < height && lane_in) {
-        const long long off = (long long)row * stride + x;
-        o.s = *reinterpret_cast<const float4*>(sp + off);
-        o.r = *reinterpret_cast<const float4*>(rp + off);
-    }
+    o.s = *reinterpret_cast<const float4*>(ps + xq);
+    o.r = *reinterpret_cast<const float4*>(pr + xq);
     return o;
 }
 
@@ -276,20 +283,26 @@ struct RowZ {
 };
 
 // DENSE: both rasters have nodata None (raster_array.py:302-303: every pixel valid), so validity is purely geometric:
-// rows / lanes outside the raster were loaded as zeros, only the tail of a ragged last quad needs zeroing.
+// only rows outside the raster / not yet added and the columns of the last strip beyond the raster need zeroing.
 template <int MODEL, bool DENSE>
-__device__ __forceinline__ RowZ process_row(const RowRaw& raw, bool row_ok, unsigned colbits, bool ragged,
+__device__ __forceinline__ RowZ process_row(const RowRaw& raw, bool row_ok, unsigned colbits, bool full_wave,
                                             const NodataTest& ts, const NodataTest& tr, double n0, double n1) {
     const float s[PX] = {raw.s.x, raw.s.y, raw.s.z, raw.s.w};
     const float r[PX] = {raw.r.x, raw.r.y, raw.r.z, raw.r.w};
     RowZ z;
     z.m = 0;
     if constexpr (DENSE) {
+        if (row_ok && full_wave) {  // wave-uniform: every column of every lane is inside the raster -> nothing to zero
 #pragma unroll
-        for (int i = 0; i < PX; ++i) {
-            const bool in = !ragged | (bool)((colbits >> i) & 1u);
-            z.s[i] = in ? s[i] : 0.f;
-            z.r[i] = in ? r[i] : 0.f;
+            for (int i = 0; i < PX; ++i) z.s[i] = s[i], z.r[i] = r[i];
+        } else {
+            const unsigned bits = row_ok ? colbits : 0u;
+#pragma unroll
+            for (int i = 0; i < PX; ++i) {
+                const bool in = (bits >> i) & 1u;
+                z.s[i] = in ? s[i] : 0.f;
+                z.r[i] = in ? r[i] : 0.f;
+            }
         }
         return z;
     }
@@ -334,6 +347,14 @@ struct ColSums {
 
     template <bool ADD>
     __device__ __forceinline__ void update(const RowZ& z, double n0, double n1) {
+        [[maybe_unused]] float sr[PX];  // src * ref rounded to float32 first (:175,:334), two pixels per instruction
+        if constexpr (!BLK && NEED_P) {
+#pragma unroll
+            for (int j = 0; j < PX / 2; ++j) {
+                const f2 pr = HK_P2(z.s, j) * HK_P2(z.r, j);
+                sr[2 * j] = pr.x, sr[2 * j + 1] = pr.y;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < PX; ++i) {
             const bool m = DENSE ? true : (bool)((z.m >> (8 * i)) & 1u);
@@ -354,7 +375,7 @@ struct ColSums {
                 const double ds = (double)z.s[i];
                 S[i] = ADD ? __dadd_rn(S[i], ds) : __dsub_rn(S[i], ds);
                 if constexpr (NEED_P) {
-                    const double p = (double)__fmul_rn(z.s[i], z.r[i]);  // product rounded to f32 first (:175,:334)
+                    const double p = (double)sr[i];
                     P[i] = ADD ? __dadd_rn(P[i], p) : __dsub_rn(P[i], p);
                 }
                 if constexpr (NEED_S2) S2[i] = __fma_rn(ADD ? ds : -ds, ds, S2[i]);  // ds*ds exact in f64
@@ -412,7 +433,8 @@ __global__ void __launch_bounds__(WAVE, HK_FIT_MIN_WAVES) fit_apply_kernel(const
     const long long out_base = (long long)band * a.band_stride;
 
     const bool lane_in = x >= 0 && x < W;
-    const bool ragged = (W & (PX - 1)) != 0;
+    const unsigned xq = lane_in ? (unsigned)x : 0u;                    // load offset: a safe quad for lanes outside
+    const bool full_wave = __all((int)(x >= 0 && x + PX <= W));        // no column of this strip needs zeroing
     const NodataTest ts = make_nodata_test(a.src_nd_mode, a.src_nodata);
     const NodataTest tr = make_nodata_test(a.ref_nd_mode, a.ref_nodata);
     unsigned colbits = 0;
@@ -464,12 +486,13 @@ __global__ void __launch_bounds__(WAVE, HK_FIT_MIN_WAVES) fit_apply_kernel(const
     cs.clear();
 
     const int t_first = y0 - rh, t_last = y1 - 1 + rh;
-    // two rows in flight ahead of the one being consumed
-    // (one row for the wide variants: their horizontal stage needs the registers, a spill costs more than the latency)
-    constexpr int PF = (RW < 0 || RW >= 4) ? 1 : 2;
-    RowRaw q0 = load_row(sp, rp, a.stride, t_first, H, x, lane_in);
+    // One row in flight: the next row's load is issued as soon as the current one has been consumed, so it lands in the
+    // same registers (no queue rotation).  A two-row queue was measured equal or slower (8 more VGPRs + 8 moves per row).
+    // The light `gain` kernel without R2 is HBM-bound and keeps a second row in flight (measured: 2.85 vs 3.02 ms).
+    constexpr bool PF2 = MODEL == 0 && !R2;
+    RowRaw q0 = load_row(sp, rp, a.stride, t_first, H, xq);
     [[maybe_unused]] RowRaw q1;
-    if constexpr (PF == 2) q1 = load_row(sp, rp, a.stride, t_first + 1 <= t_last ? t_first + 1 : -1, H, x, lane_in);
+    if constexpr (PF2) q1 = load_row(sp, rp, a.stride, min(t_first + 1, t_last), H, xq);
 
     // r2-mask bookkeeping (gain-offset with a threshold, kernel_model.py:363): R2 values are only materialised when
     // asked for; otherwise pixels are first put through a division-free CERTIFIED test
@@ -489,16 +512,21 @@ __global__ void __launch_bounds__(WAVE, HK_FIT_MIN_WAVES) fit_apply_kernel(const
     int slot_c = kh - rh;  // slot of the centre row of the output produced at this iteration: (slot - rh) mod kh
     if (slot_c >= kh) slot_c -= kh;
     for (int t = t_first; t <= t_last; ++t) {
-        const RowRaw q2 = load_row(sp, rp, a.stride, t + PF <= t_last ? t + PF : -1, H, x, lane_in);
 
         // rows that do not come from LDS: issue their loads now, consume them after the entering row has been folded in
         // (the leaving row t - kh is a zero row if it was never added; the centre row is t - rh)
         RowRaw qo, qc;
         const int t_old = t - kh, y_c = t - rh;
-        if constexpr (!ring) qo = load_row(sp, rp, a.stride, t_old >= t_first ? t_old : -1, H, x, lane_in);
-        if constexpr (RING == 0) qc = load_row(sp, rp, a.stride, y_c >= y0 ? y_c : -1, H, x, lane_in);
+        if constexpr (!ring) qo = load_row(sp, rp, a.stride, t_old, H, xq);
+        if constexpr (RING == 0) qc = load_row(sp, rp, a.stride, y_c, H, xq);
 
-        const RowZ znew = process_row<MODEL, DENSE>(q0, t >= 0 && t < H, colbits, ragged, ts, tr, n0, n1);
+        const RowZ znew = process_row<MODEL, DENSE>(q0, t >= 0 && t < H, colbits, full_wave, ts, tr, n0, n1);
+        if constexpr (PF2) {
+            q0 = q1;
+            q1 = load_row(sp, rp, a.stride, min(t + 2, t_last), H, xq);
+        } else {
+            q0 = load_row(sp, rp, a.stride, min(t + 1, t_last), H, xq);  // next row (see above)
+        }
         RowZ zold;
         if constexpr (ring) {
             // leaving row (t - kh): read from the slot the entering row is about to overwrite
@@ -511,7 +539,7 @@ __global__ void __launch_bounds__(WAVE, HK_FIT_MIN_WAVES) fit_apply_kernel(const
             ring_v[(slot * 2 + 1) * WAVE + lane] = make_float4(znew.r[0], znew.r[1], znew.r[2], znew.r[3]);
             if constexpr (!DENSE) ring_m[slot * WAVE + lane] = znew.m;
         } else {
-            zold = process_row<MODEL, DENSE>(qo, t_old >= t_first && t_old >= 0 && t_old < H, colbits, ragged, ts, tr, n0, n1);
+            zold = process_row<MODEL, DENSE>(qo, t_old >= t_first && t_old >= 0 && t_old < H, colbits, full_wave, ts, tr, n0, n1);
             if constexpr (cring) {  // slot2 cycles over rh + 1 rows: the entering row replaces the centre row of rh + 1 ago
                 ring_v[slot2 * WAVE + lane] = make_float4(znew.s[0], znew.s[1], znew.s[2], znew.s[3]);
                 if constexpr (!DENSE) ring_m[slot2 * WAVE + lane] = znew.m;
@@ -539,7 +567,7 @@ __global__ void __launch_bounds__(WAVE, HK_FIT_MIN_WAVES) fit_apply_kernel(const
                 sc[0] = cs4.x, sc[1] = cs4.y, sc[2] = cs4.z, sc[3] = cs4.w;
                 mc = DENSE ? 0u : ring_m[cs_slot * WAVE + lane];
             } else {
-                const RowZ zc = process_row<MODEL, DENSE>(qc, true, colbits, ragged, ts, tr, n0, n1);
+                const RowZ zc = process_row<MODEL, DENSE>(qc, true, colbits, full_wave, ts, tr, n0, n1);
 #pragma unroll
                 for (int i = 0; i < PX; ++i) sc[i] = zc.s[i];
                 mc = zc.m;
@@ -572,18 +600,40 @@ __global__ void __launch_bounds__(WAVE, HK_FIT_MIN_WAVES) fit_apply_kernel(const
             // ---- stage A: gains and offsets -------------------------------------------------------------------------
             float g[PX], o[PX], r2v[PX], c[PX];
             [[maybe_unused]] float Rf[PX], Sf[PX], Pf[PX], gp[PX];
+            if constexpr (GO) {
+                // kernel_model.py:338-351; src2_sum is float64 (sqrBoxFilter) so m_den and the division are f64.
+                // float32 steps run two pixels per instruction (packed), float64 steps per pixel.
+#pragma unroll
+                for (int j = 0; j < PX / 2; ++j) {
+                    const f2 Rf2 = {(float)HR[2 * j], (float)HR[2 * j + 1]};  // boxFilter output depth = input depth
+                    const f2 Sf2 = {(float)HS[2 * j], (float)HS[2 * j + 1]};
+                    const f2 Pf2 = {(float)HP[2 * j], (float)HP[2 * j + 1]};
+                    const f2 Nf2 = HK_P2(Nf, j);
+                    const f2 num2 = Nf2 * Pf2 - Sf2 * Rf2;
+                    const f2 SS2 = Sf2 * Sf2;
+                    f2 g2;
+                    g2.x = (float)__ddiv_rn((double)num2.x, __dsub_rn(__dmul_rn((double)Nf2.x, HS2[2 * j]), (double)SS2.x));
+                    g2.y = (float)__ddiv_rn((double)num2.y, __dsub_rn(__dmul_rn((double)Nf2.y, HS2[2 * j + 1]), (double)SS2.y));
+                    const f2 tn2 = Rf2 - g2 * Sf2;
+                    f2 o2;
+                    if (use_lut) {  // wave-uniform
+                        o2.x = (float)__dmul_rn((double)tn2.x, inv_lut[(int)Nf2.x]);
+                        o2.y = (float)__dmul_rn((double)tn2.y, inv_lut[(int)Nf2.y]);
+                    } else {
+                        o2.x = __fdiv_rn(tn2.x, Nf2.x);
+                        o2.y = __fdiv_rn(tn2.y, Nf2.y);
+                    }
+                    Rf[2 * j] = Rf2.x, Rf[2 * j + 1] = Rf2.y;
+                    Sf[2 * j] = Sf2.x, Sf[2 * j + 1] = Sf2.y;
+                    Pf[2 * j] = Pf2.x, Pf[2 * j + 1] = Pf2.y;
+                    g[2 * j] = g2.x, g[2 * j + 1] = g2.y;
+                    o[2 * j] = o2.x, o[2 * j + 1] = o2.y;
+                }
+            }
 #pragma unroll
             for (int i = 0; i < PX; ++i) {
-                Rf[i] = (float)HR[i];  // boxFilter output depth = input depth (float32)
+                if constexpr (!GO) Rf[i] = (float)HR[i];  // boxFilter output depth = input depth (float32)
                 if constexpr (GO) {
-                    // kernel_model.py:338-351; src2_sum is float64 (sqrBoxFilter) so m_den and the division are f64
-                    Sf[i] = (float)HS[i];
-                    Pf[i] = (float)HP[i];
-                    const float num = __fsub_rn(__fmul_rn(Nf[i], Pf[i]), __fmul_rn(Sf[i], Rf[i]));
-                    const double den = __dsub_rn(__dmul_rn((double)Nf[i], HS2[i]), (double)__fmul_rn(Sf[i], Sf[i]));
-                    g[i] = (float)__ddiv_rn((double)num, den);
-                    const float tn = __fsub_rn(Rf[i], __fmul_rn(g[i], Sf[i]));
-                    o[i] = use_lut ? (float)__dmul_rn((double)tn, inv_lut[(int)Nf[i]]) : __fdiv_rn(tn, Nf[i]);
                 } else if constexpr (BLK) {
                     // kernel_model.py:265 with a float64 src_sum: np.divide(f32, f64, out=f32); then :301-302
                     gp[i] = (float)__ddiv_rn((double)Rf[i], HS[i]);
@@ -612,23 +662,30 @@ __global__ void __launch_bounds__(WAVE, HK_FIT_MIN_WAVES) fit_apply_kernel(const
                             // ssres_ref < r2_pass_scale * sstot_ref, which proves the reference's decision.
                             bool uncertain = !cert_ok;
 #pragma unroll
-                            for (int i = 0; i < PX; ++i) {
-                                const bool m = (mc >> (8 * i)) & 1u;
-                                const float gg = __fmul_rn(g[i], g[i]);
-                                const float S2f = (float)HS2[i], R2f = (float)HR2[i];
-                                const float sst = __fmaf_rn(Nf[i], R2f, -__fmul_rn(Rf[i], Rf[i]));
-                                const float T = __fmaf_rn(gg, S2f, __fmaf_rn(__fmul_rn(Nf[i], o[i]), o[i], R2f));
-                                const float NT = __fmul_rn(Nf[i], T);
-                                const float slack = __fmul_rn(0x1p-17f, NT);
-                                const float denf = __fmaf_rn(Nf[i], S2f, -__fmul_rn(Sf[i], Sf[i]));
-                                const float lhs = __fmul_rn(gg, denf);
-                                const float rhs = __fmaf_rn(a.r2_fail_scale, sst, slack);
-                                // magnitude windows (no underflow / overflow anywhere in the reference's expression):
-                                // 2^-20 < g < 2^20 (also the `gain > 0` half of the decision), 2^-40 < N*T < 2^60
-                                const bool g_in = (__float_as_uint(g[i]) - 0x35800000u) < (0x49800000u - 0x35800000u);
-                                const bool t_in = (__float_as_uint(NT) - 0x2b800000u) < (0x5d800000u - 0x2b800000u);
-                                const bool sure = (lhs > rhs) & (sst > slack) & g_in & t_in;
-                                uncertain |= out_lane & m & !sure;
+                            for (int j = 0; j < PX / 2; ++j) {
+                                const f2 g2 = HK_P2(g, j), o2 = HK_P2(o, j), Nf2 = HK_P2(Nf, j);
+                                const f2 Rf2 = HK_P2(Rf, j), Sf2 = HK_P2(Sf, j);
+                                const f2 S2f = {(float)HS2[2 * j], (float)HS2[2 * j + 1]};
+                                const f2 R2f = {(float)HR2[2 * j], (float)HR2[2 * j + 1]};
+                                const f2 gg = g2 * g2;
+                                const f2 sst = pk_fma(Nf2, R2f, -(Rf2 * Rf2));
+                                const f2 T = pk_fma(gg, S2f, pk_fma(Nf2 * o2, o2, R2f));
+                                const f2 NT = Nf2 * T;
+                                const f2 slack = NT * 0x1p-17f;
+                                const f2 denf = pk_fma(Nf2, S2f, -(Sf2 * Sf2));
+                                const f2 lhs = gg * denf;
+                                const f2 rhs = pk_fma(f2{a.r2_fail_scale, a.r2_fail_scale}, sst, slack);
+#pragma unroll
+                                for (int e = 0; e < 2; ++e) {
+                                    const int i = 2 * j + e;
+                                    const bool m = (mc >> (8 * i)) & 1u;
+                                    // magnitude windows (no underflow / overflow anywhere in the reference's expression):
+                                    // 2^-20 < g < 2^20 (also the `gain > 0` half of the decision), 2^-40 < N*T < 2^60
+                                    const bool g_in = (__float_as_uint(g2[e]) - 0x35800000u) < (0x49800000u - 0x35800000u);
+                                    const bool t_in = (__float_as_uint(NT[e]) - 0x2b800000u) < (0x5d800000u - 0x2b800000u);
+                                    const bool sure = (lhs[e] > rhs[e]) & (sst[e] > slack[e]) & g_in & t_in;
+                                    uncertain |= out_lane & m & !sure;
+                                }
                             }
                             exact = __any(uncertain);
                         }
@@ -684,9 +741,13 @@ __global__ void __launch_bounds__(WAVE, HK_FIT_MIN_WAVES) fit_apply_kernel(const
             // ---- stage C: apply (:461) and where=mask (every parameter write goes into a NaN-filled array, :261,:345) ----
             // A masked pixel has NaN parameters, hence a NaN corrected value: select once per stored plane.
 #pragma unroll
-            for (int i = 0; i < PX; ++i) {
-                c[i] = __fadd_rn(__fmul_rn(g[i], sc[i]), o[i]);  // two float32 roundings
-                if constexpr (!DENSE) c[i] = ((mc >> (8 * i)) & 1u) ? c[i] : qnan();
+            for (int j = 0; j < PX / 2; ++j) {
+                const f2 c2 = HK_P2(g, j) * HK_P2(sc, j) + HK_P2(o, j);  // two float32 roundings
+                c[2 * j] = c2.x, c[2 * j + 1] = c2.y;
+            }
+            if constexpr (!DENSE) {
+#pragma unroll
+                for (int i = 0; i < PX; ++i) c[i] = ((mc >> (8 * i)) & 1u) ? c[i] : qnan();
             }
             auto masked4 = [&](const float (&v)[PX]) {
                 float4 r4 = make_float4(v[0], v[1], v[2], v[3]);
@@ -709,12 +770,6 @@ __global__ void __launch_bounds__(WAVE, HK_FIT_MIN_WAVES) fit_apply_kernel(const
             }
         }
 
-        if constexpr (PF == 2) {
-            q0 = q1;
-            q1 = q2;
-        } else {
-            q0 = q2;
-        }
         if (++slot == kh) slot = 0;
         if (++slot_c == kh) slot_c = 0;
         if (++slot2 == rh + 1) slot2 = 0;
