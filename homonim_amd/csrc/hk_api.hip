@@ -173,6 +173,9 @@ void fill_args(hk::FitArgs& a, const hk_fit_desc* d, int xcd_remap) {
     a.has_thresh = (d->model == HK_MODEL_GAIN_OFFSET) ? d->has_r2_thresh : 0;
     a.r2_thresh = d->r2_thresh;
     a.r2_fail_scale = a.has_thresh ? r2_fail_scale(d->r2_thresh) : INFINITY;
+    a.n_full = (float)(d->kh * d->kw);
+    a.nd_full = (double)(d->kh * d->kw);
+    a.inv_n_full = 1.0 / (double)(d->kh * d->kw);
     a.force_general = getenv("HK_FORCE_GENERAL") ? atoi(getenv("HK_FORCE_GENERAL")) : 0;
     // LDS row ring only while it leaves room for >= 11 waves per CU (kh <= 5); taller kernels re-load rows (hk_kernels.hip)
     // ring mode (hk_kernels.hip): full LDS ring while it leaves room for >= 11 waves per CU (kh <= 5), centre-only ring up

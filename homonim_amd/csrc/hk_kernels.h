@@ -33,6 +33,9 @@ struct FitArgs {
     int has_thresh;
     float r2_thresh;
     float r2_fail_scale;    // kappa of the division-free r2-mask certificate: 1 - r2_pass_scale(), rounded up (hk_api.hip)
+    float n_full;           // kh * kw: the window count of every pixel away from the raster's edges (dense kernels)
+    double nd_full;         // the same as float64
+    double inv_n_full;      // RN64(1 / (kh * kw)) -- the 1/N table entry (hk_kernels.hip)
     int force_general;      // 1: never take the dense (nodata None) specialisation (testing)
     int use_ring;           // ring mode of fit_apply_kernel: 1 full LDS ring, 2 centre ring + re-loaded leaving row, 0 re-load both
     int xcd_remap;          // 1: blockIdx -> unit remap that keeps neighbouring units on one XCD

@@ -506,6 +506,17 @@ __global__ void __launch_bounds__(WAVE, HK_FIT_MIN_WAVES) fit_apply_kernel(const
     const bool count_fails = GO && R2 && a.has_thresh;
     const bool cert_ok = kh * (2 * rw + 1) <= 65535;  // window-count bound assumed by the certificate's constants
 
+    // DENSE gain-offset: away from the raster's edges every stored pixel of a wave-row has N = kh * kw -- then N, its
+    // float64 image and RN64(1/N) are kernel arguments (SGPRs) instead of per-pixel conversions and table look-ups.
+    [[maybe_unused]] bool n_uniform = false;
+    [[maybe_unused]] bool n_uniform_cols = false;
+    if constexpr (DENSE && GO) {
+        bool full = true;
+#pragma unroll
+        for (int i = 0; i < PX; ++i) full &= ncolf[i] == (float)(2 * rw + 1);
+        n_uniform_cols = use_lut && __all((int)(!out_lane || full));
+    }
+
     unsigned nfail = 0;
     int slot = 0;
     int slot2 = 0;  // RING 2: write slot of the centre ring
@@ -584,9 +595,11 @@ __global__ void __launch_bounds__(WAVE, HK_FIT_MIN_WAVES) fit_apply_kernel(const
             if constexpr (CS::NEED_R2S) hsum_any<RW, double>(cs.R2s, HR2, rw, ol, lane);
             if constexpr (USE_N) {
                 if constexpr (DENSE) {
-                    const float nrows = (float)(min(y + rh, H - 1) - max(y - rh, 0) + 1);
+                    const int nrows_i = min(y + rh, H - 1) - max(y - rh, 0) + 1;
+                    n_uniform = n_uniform_cols && nrows_i == kh;  // wave-uniform: every stored pixel has the full window
+                    const float nrows = (float)nrows_i;
 #pragma unroll
-                    for (int i = 0; i < PX; ++i) Nf[i] = nrows * ncolf[i];  // exact small integers
+                    for (int i = 0; i < PX; ++i) Nf[i] = n_uniform ? a.n_full : nrows * ncolf[i];  // exact small integers
                 } else {
                     const int VN[PX] = {(int)(cs.N & 0xffu), (int)((cs.N >> 8) & 0xffu), (int)((cs.N >> 16) & 0xffu),
                                         (int)(cs.N >> 24)};
@@ -603,32 +616,41 @@ __global__ void __launch_bounds__(WAVE, HK_FIT_MIN_WAVES) fit_apply_kernel(const
             if constexpr (GO) {
                 // kernel_model.py:338-351; src2_sum is float64 (sqrBoxFilter) so m_den and the division are f64.
                 // float32 steps run two pixels per instruction (packed), float64 steps per pixel.
+                auto stage_a = [&](auto uniform_n) {
+                    constexpr bool UN = decltype(uniform_n)::value;
 #pragma unroll
-                for (int j = 0; j < PX / 2; ++j) {
-                    const f2 Rf2 = {(float)HR[2 * j], (float)HR[2 * j + 1]};  // boxFilter output depth = input depth
-                    const f2 Sf2 = {(float)HS[2 * j], (float)HS[2 * j + 1]};
-                    const f2 Pf2 = {(float)HP[2 * j], (float)HP[2 * j + 1]};
-                    const f2 Nf2 = HK_P2(Nf, j);
-                    const f2 num2 = Nf2 * Pf2 - Sf2 * Rf2;
-                    const f2 SS2 = Sf2 * Sf2;
-                    f2 g2;
-                    g2.x = (float)__ddiv_rn((double)num2.x, __dsub_rn(__dmul_rn((double)Nf2.x, HS2[2 * j]), (double)SS2.x));
-                    g2.y = (float)__ddiv_rn((double)num2.y, __dsub_rn(__dmul_rn((double)Nf2.y, HS2[2 * j + 1]), (double)SS2.y));
-                    const f2 tn2 = Rf2 - g2 * Sf2;
-                    f2 o2;
-                    if (use_lut) {  // wave-uniform
-                        o2.x = (float)__dmul_rn((double)tn2.x, inv_lut[(int)Nf2.x]);
-                        o2.y = (float)__dmul_rn((double)tn2.y, inv_lut[(int)Nf2.y]);
-                    } else {
-                        o2.x = __fdiv_rn(tn2.x, Nf2.x);
-                        o2.y = __fdiv_rn(tn2.y, Nf2.y);
+                    for (int j = 0; j < PX / 2; ++j) {
+                        const f2 Rf2 = {(float)HR[2 * j], (float)HR[2 * j + 1]};  // boxFilter output depth = input depth
+                        const f2 Sf2 = {(float)HS[2 * j], (float)HS[2 * j + 1]};
+                        const f2 Pf2 = {(float)HP[2 * j], (float)HP[2 * j + 1]};
+                        const f2 Nf2 = UN ? f2{a.n_full, a.n_full} : HK_P2(Nf, j);
+                        const double Ndx = UN ? a.nd_full : (double)Nf2.x, Ndy = UN ? a.nd_full : (double)Nf2.y;
+                        const f2 num2 = Nf2 * Pf2 - Sf2 * Rf2;
+                        const f2 SS2 = Sf2 * Sf2;
+                        f2 g2;
+                        g2.x = (float)__ddiv_rn((double)num2.x, __dsub_rn(__dmul_rn(Ndx, HS2[2 * j]), (double)SS2.x));
+                        g2.y = (float)__ddiv_rn((double)num2.y, __dsub_rn(__dmul_rn(Ndy, HS2[2 * j + 1]), (double)SS2.y));
+                        const f2 tn2 = Rf2 - g2 * Sf2;
+                        f2 o2;
+                        if constexpr (UN) {
+                            o2.x = (float)__dmul_rn((double)tn2.x, a.inv_n_full);
+                            o2.y = (float)__dmul_rn((double)tn2.y, a.inv_n_full);
+                        } else if (use_lut) {  // wave-uniform
+                            o2.x = (float)__dmul_rn((double)tn2.x, inv_lut[(int)Nf2.x]);
+                            o2.y = (float)__dmul_rn((double)tn2.y, inv_lut[(int)Nf2.y]);
+                        } else {
+                            o2.x = __fdiv_rn(tn2.x, Nf2.x);
+                            o2.y = __fdiv_rn(tn2.y, Nf2.y);
+                        }
+                        Rf[2 * j] = Rf2.x, Rf[2 * j + 1] = Rf2.y;
+                        Sf[2 * j] = Sf2.x, Sf[2 * j + 1] = Sf2.y;
+                        Pf[2 * j] = Pf2.x, Pf[2 * j + 1] = Pf2.y;
+                        g[2 * j] = g2.x, g[2 * j + 1] = g2.y;
+                        o[2 * j] = o2.x, o[2 * j + 1] = o2.y;
                     }
-                    Rf[2 * j] = Rf2.x, Rf[2 * j + 1] = Rf2.y;
-                    Sf[2 * j] = Sf2.x, Sf[2 * j + 1] = Sf2.y;
-                    Pf[2 * j] = Pf2.x, Pf[2 * j + 1] = Pf2.y;
-                    g[2 * j] = g2.x, g[2 * j + 1] = g2.y;
-                    o[2 * j] = o2.x, o[2 * j + 1] = o2.y;
-                }
+                };
+                if (DENSE && n_uniform) stage_a(std::true_type{});
+                else stage_a(std::false_type{});
             }
 #pragma unroll
             for (int i = 0; i < PX; ++i) {
