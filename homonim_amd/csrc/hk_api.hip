@@ -190,14 +190,41 @@ void fill_args(hk::FitArgs& a, const hk_fit_desc* d, int xcd_remap) {
     a.xcd_remap = xcd_remap;
 }
 
+static int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+// Units of one launch: (segment, band, strip), one wave each.  A wave re-reads 2*rh priming rows, so long segments waste
+// less; but the launch ends when its last wave does, so the final segments are short.  Large rasters therefore get
+// `big` rows per segment for most of the height and `tail` rows for the last ~1.25 "generations" of resident waves
+// (dispatched last, segment-major order); small rasters and an explicit `seg_rows` use one size.
 void fill_grid(hk::FitArgs& a, int seg_rows) {
     const int out_w = (hk::WAVE - 2 * a.overlap_lanes) * hk::PX;
     const int kh = 2 * a.rh + 1;
-    // rows per wave segment: the 2*rh priming rows are redundant work, so taller kernels get longer segments
-    a.seg_rows = seg_rows > 0 ? seg_rows : (kh <= 5 ? 64 : (kh <= 9 ? 128 : 256));
-    if (a.seg_rows > a.height) a.seg_rows = a.height;
     a.n_strips = (a.width + out_w - 1) / out_w;
+    const int uniform = seg_rows > 0 ? seg_rows : (kh <= 5 ? 64 : (kh <= 9 ? 128 : 256));
+    a.seg_rows = uniform < a.height ? uniform : a.height;
+    a.seg_rows_tail = a.seg_rows;
     a.n_segs = (a.height + a.seg_rows - 1) / a.seg_rows;
+    a.n_segs_big = a.n_segs;
+    const long long slots = (long long)env_int("HK_WAVE_SLOTS", 256 * 12);  // resident waves of the device (3 per SIMD)
+    const long long per_row_band = (long long)a.n_strips * a.n_bands;        // units per segment row
+    if (seg_rows <= 0 && per_row_band * a.n_segs >= 6 * slots) {
+        const int big = env_int("HK_SEG_BIG", 2 * uniform), tail = env_int("HK_SEG_TAIL", uniform / 2);
+        const double gens = env_int("HK_TAIL_GENS_X100", 125) / 100.0;
+        // image rows whose big-segment units make up `gens` generations of resident waves
+        long long tail_rows = (long long)(gens * (double)slots / (double)per_row_band * big);
+        tail_rows = (tail_rows + tail - 1) / tail * tail;
+        if (big > 0 && tail > 0 && tail_rows < a.height - big) {
+            const int n_big = (int)((a.height - tail_rows) / big);
+            const int rest = a.height - n_big * big;
+            a.seg_rows = big;
+            a.seg_rows_tail = tail;
+            a.n_segs_big = n_big;
+            a.n_segs = n_big + (rest + tail - 1) / tail;
+        }
+    }
     a.total_units = a.n_strips * a.n_segs * a.n_bands;
 }
 

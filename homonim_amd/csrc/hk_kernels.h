@@ -25,6 +25,8 @@ struct FitArgs {
     int n_bands;
     int seg_rows;           // output rows per unit
     int n_strips, n_segs;   // units per band = n_strips * n_segs
+    int seg_rows_tail;      // rows per unit of the last segments (launched last: they level the end of the launch)
+    int n_segs_big;         // segments of seg_rows rows; the remaining n_segs - n_segs_big have seg_rows_tail rows
     int total_units;
     int rh, rw;             // kernel radii (kh = 2*rh+1, kw = 2*rw+1)
     int overlap_lanes;      // lanes per side that only feed neighbours: ceil(rw / PX)

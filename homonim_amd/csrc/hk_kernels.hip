@@ -414,18 +414,20 @@ __global__ void __launch_bounds__(WAVE, HK_FIT_MIN_WAVES) fit_apply_kernel(const
         unit = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     }
     if (unit >= a.total_units) return;
+    // segment-major order: the short tail segments (hk_api.hip fill_grid) are dispatched last
     const int strip = unit % a.n_strips;
     const int t0 = unit / a.n_strips;
-    const int seg = t0 % a.n_segs;
-    const int band = t0 / a.n_segs;
+    const int band = t0 % a.n_bands;
+    const int seg = t0 / a.n_bands;
 
     const int rh = a.rh, kh = 2 * rh + 1;
     const int rw = RW >= 0 ? RW : a.rw;
     const int ol = RW >= 0 ? (RW + PX - 1) / PX : a.overlap_lanes;
     const int out_lanes = WAVE - 2 * ol;
     const int x = (strip * out_lanes + lane - ol) * PX;
-    const int y0 = seg * a.seg_rows;
-    const int y1 = min(y0 + a.seg_rows, a.height);
+    const bool big = seg < a.n_segs_big;
+    const int y0 = big ? seg * a.seg_rows : a.n_segs_big * a.seg_rows + (seg - a.n_segs_big) * a.seg_rows_tail;
+    const int y1 = min(y0 + (big ? a.seg_rows : a.seg_rows_tail), a.height);
     const int W = a.width, H = a.height;
 
     const float* __restrict__ sp = a.src + (long long)band * a.band_stride;
