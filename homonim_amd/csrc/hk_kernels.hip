@@ -280,6 +280,7 @@ __device__ __forceinline__ RowRaw load_row(const float* __restrict__ sp, const f
 struct RowZ {
     float s[PX], r[PX];
     unsigned m;  // byte i = mask of pixel i (0/1)
+    bool clean;  // wave-uniform: the row is inside the raster and every pixel of every lane of the strip is valid
 };
 
 // DENSE: both rasters have nodata None (raster_array.py:302-303: every pixel valid), so validity is purely geometric:
@@ -291,6 +292,7 @@ __device__ __forceinline__ RowZ process_row(const RowRaw& raw, bool row_ok, unsi
     const float r[PX] = {raw.r.x, raw.r.y, raw.r.z, raw.r.w};
     RowZ z;
     z.m = 0;
+    z.clean = false;
     if constexpr (DENSE) {
         if (row_ok && full_wave) {  // wave-uniform: every column of every lane is inside the raster -> nothing to zero
 #pragma unroll
@@ -315,6 +317,16 @@ __device__ __forceinline__ RowZ process_row(const RowRaw& raw, bool row_ok, unsi
     } else {
 #pragma unroll
         for (int i = 0; i < PX; ++i) ok[i] = px_valid(s[i], ts) & px_valid(r[i], tr);
+    }
+    if constexpr (MODEL != 1) {
+        // wave-uniform short cut: nothing to zero, nothing to pack (the usual state away from the edges of real mosaics)
+        if (row_ok && full_wave && __all((int)(ok[0] & ok[1] & ok[2] & ok[3]))) {
+#pragma unroll
+            for (int i = 0; i < PX; ++i) z.s[i] = s[i], z.r[i] = r[i];
+            z.m = 0x01010101u;
+            z.clean = true;
+            return z;
+        }
     }
 #pragma unroll
     for (int i = 0; i < PX; ++i) {
@@ -510,12 +522,19 @@ __global__ void __launch_bounds__(WAVE, HK_FIT_MIN_WAVES) fit_apply_kernel(const
 
     // DENSE gain-offset: away from the raster's edges every stored pixel of a wave-row has N = kh * kw -- then N, its
     // float64 image and RN64(1/N) are kernel arguments (SGPRs) instead of per-pixel conversions and table look-ups.
+    // General gain-offset kernels reach the same state through data: `last_dirty` is the latest entering row that was
+    // outside the raster or held an invalid pixel anywhere in the strip; while the whole window is newer than that,
+    // every window count is kh * kw and the packed-count horizontal sum is skipped as well.
     [[maybe_unused]] bool n_uniform = false;
     [[maybe_unused]] bool n_uniform_cols = false;
-    if constexpr (DENSE && GO) {
+    [[maybe_unused]] int last_dirty = t_first - 1;
+    if constexpr (GO && MODEL != 1) {
         bool full = true;
 #pragma unroll
-        for (int i = 0; i < PX; ++i) full &= ncolf[i] == (float)(2 * rw + 1);
+        for (int i = 0; i < PX; ++i) {
+            const int c = x + i;
+            full &= (c - rw >= 0) && (c + rw < W);
+        }
         n_uniform_cols = use_lut && __all((int)(!out_lane || full));
     }
 
@@ -539,6 +558,9 @@ __global__ void __launch_bounds__(WAVE, HK_FIT_MIN_WAVES) fit_apply_kernel(const
             q1 = load_row(sp, rp, a.stride, min(t + 2, t_last), H, xq);
         } else {
             q0 = load_row(sp, rp, a.stride, min(t + 1, t_last), H, xq);  // next row (see above)
+        if constexpr (GO && !DENSE) {
+            if (!znew.clean) last_dirty = t;  // wave-uniform
+        }
         }
         RowZ zold;
         if constexpr (ring) {
@@ -603,12 +625,18 @@ __global__ void __launch_bounds__(WAVE, HK_FIT_MIN_WAVES) fit_apply_kernel(const
 #pragma unroll
                     for (int i = 0; i < PX; ++i) Nf[i] = n_uniform ? a.n_full : nrows * ncolf[i];  // exact small integers
                 } else {
-                    const int VN[PX] = {(int)(cs.N & 0xffu), (int)((cs.N >> 8) & 0xffu), (int)((cs.N >> 16) & 0xffu),
-                                        (int)(cs.N >> 24)};
-                    int HN[PX];
-                    hsum_any<RW, int>(VN, HN, rw, ol, lane);
+                    if constexpr (GO) n_uniform = n_uniform_cols && last_dirty < t - kh + 1;  // wave-uniform
+                    if (GO && n_uniform) {
 #pragma unroll
-                    for (int i = 0; i < PX; ++i) Nf[i] = (float)HN[i];
+                        for (int i = 0; i < PX; ++i) Nf[i] = a.n_full;
+                    } else {
+                        const int VN[PX] = {(int)(cs.N & 0xffu), (int)((cs.N >> 8) & 0xffu), (int)((cs.N >> 16) & 0xffu),
+                                            (int)(cs.N >> 24)};
+                        int HN[PX];
+                        hsum_any<RW, int>(VN, HN, rw, ol, lane);
+#pragma unroll
+                        for (int i = 0; i < PX; ++i) Nf[i] = (float)HN[i];
+                    }
                 }
             }
 
@@ -651,7 +679,7 @@ __global__ void __launch_bounds__(WAVE, HK_FIT_MIN_WAVES) fit_apply_kernel(const
                         o[2 * j] = o2.x, o[2 * j + 1] = o2.y;
                     }
                 };
-                if (DENSE && n_uniform) stage_a(std::true_type{});
+                if (n_uniform) stage_a(std::true_type{});
                 else stage_a(std::false_type{});
             }
 #pragma unroll
@@ -941,10 +969,11 @@ __global__ void __launch_bounds__(256) synth_kernel(float* __restrict__ src, flo
         const float o = 0.05f * (1.f + 0.5f * __sinf((float)y / 211.f));
         float r = g * s + o + 0.01f * z;
         float sv = s;
-        if (nodata_variant == 1) {
+        if (nodata_variant != 0) {  // 1: NaN frame + 0.1 % holes, 2: NaN frame only
             const bool frame = x < 3 || y < 3 || x >= width - 3 || y >= height - 3;
-            if (frame || (h3 & 0xffffu) < 66u) sv = qnan();            // ~0.1 %
-            if (frame || ((h3 >> 16) & 0xffffu) < 66u) r = qnan();
+            const bool holes = nodata_variant == 1;
+            if (frame || (holes && (h3 & 0xffffu) < 66u)) sv = qnan();            // ~0.1 %
+            if (frame || (holes && ((h3 >> 16) & 0xffffu) < 66u)) r = qnan();
         }
         const long long off = (long long)band * band_stride + (long long)y * stride + x;
         src[off] = sv;
