@@ -2,6 +2,7 @@
 import csv
 import glob
 import json
+import os
 import sys
 
 tag = sys.argv[1]
@@ -10,7 +11,7 @@ for path in glob.glob(f'gpurun_out/pmc_{tag}_*/**/*counter_collection.csv', recu
     per = {}
     with open(path) as f:
         for row in csv.DictReader(f):
-            if 'fit_apply_kernel' not in row['Kernel_Name']:
+            if os.environ.get('HK_PMC_KERNEL', 'fit_apply_kernel') not in row['Kernel_Name']:
                 continue
             per.setdefault(row['Counter_Name'], {}).setdefault(row['Dispatch_Id'], 0.0)
             per[row['Counter_Name']][row['Dispatch_Id']] += float(row['Counter_Value'])
