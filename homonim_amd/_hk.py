@@ -91,6 +91,7 @@ SIGNATURES = {
     'hk_memcpy_d2h': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     'hk_memset': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t]),
     'hk_fit_apply_dev': (C.c_int, [C.c_void_p, _P(FitDesc), _P(DevJob)]),
+    'hk_inpaint_dev': (C.c_int, [C.c_void_p, _P(FitDesc), _P(DevJob), _P(C.c_uint64)]),
     'hk_block_norm_dev': (C.c_int, [C.c_void_p, _P(FitDesc), _P(DevJob), C.c_void_p]),
     'hk_synth_fill_dev': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64,
                                     C.c_int64, C.c_uint64, C.c_int32, C.c_int32]),
@@ -396,6 +397,12 @@ class Context:
 
     def fit_apply_dev(self, desc: FitDesc, job: DevJob):
         _check(self._lib.hk_fit_apply_dev(self._h, C.byref(desc), C.byref(job)))
+
+    def inpaint_dev(self, desc: FitDesc, job: DevJob) -> int:
+        """ In-paint the bands of a device-resident job whose r2 mask has failures; returns the failure count. """
+        n = C.c_uint64(0)
+        _check(self._lib.hk_inpaint_dev(self._h, C.byref(desc), C.byref(job), C.byref(n)))
+        return int(n.value)
 
     def block_norm_dev(self, desc: FitDesc, job: DevJob, norm_dptr: int):
         _check(self._lib.hk_block_norm_dev(self._h, C.byref(desc), C.byref(job), C.c_void_p(norm_dptr)))

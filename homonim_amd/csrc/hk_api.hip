@@ -228,6 +228,36 @@ void fill_grid(hk::FitArgs& a, int seg_rows) {
     a.total_units = a.n_strips * a.n_segs * a.n_bands;
 }
 
+// kernel_model.py:364-371 for ONE band whose first pass counted failing pixels: in-paint the offsets of the failing
+// pixels from the passing ones (restated GDALFillNodata) and run the fit again with `offset_in`, which recomputes their
+// gains and re-applies.  `a` is the first pass's argument block (n_bands == 1).
+static int inpaint_band(Slot& sl, const hk::FitArgs& a, const hk_fit_desc* desc, bool r2, size_t plane) {
+    const size_t need = 4 * plane + hk::inpaint_workspace_bytes(a.height, a.stride);
+    if (sl.aux_bytes < need) {
+        if (sl.aux) HK_HIP(hipFree(sl.aux));
+        sl.aux = nullptr, sl.aux_bytes = 0;
+        if (hipMalloc(&sl.aux, need) != hipSuccess) return fail(HK_ERR_NOMEM, "hipMalloc(%zu) failed", need);
+        sl.aux_bytes = need;
+    }
+    char* aux = static_cast<char*>(sl.aux);
+    float* filled = reinterpret_cast<float*>(aux);
+    float *pg = a.gain, *po = a.offset, *pr = a.r2;
+    if (!pg || !po || !pr) {  // parameters were not materialised by the first pass: run it again into scratch planes
+        pg = reinterpret_cast<float*>(aux + plane), po = reinterpret_cast<float*>(aux + 2 * plane);
+        pr = reinterpret_cast<float*>(aux + 3 * plane);
+        hk::FitArgs b = a;
+        b.gain = pg, b.offset = po, b.r2 = pr, b.corr = nullptr, b.fail_count = nullptr;
+        HK_HIP(hk::launch_fit_apply(b, desc->model, r2, sl.stream));
+    }
+    HK_HIP(hk::launch_inpaint_offsets(po, pg, pr, desc->r2_thresh, a.stride, a.height, a.width, aux + 4 * plane, filled,
+                                      sl.stream));
+    hk::FitArgs c = a;
+    c.offset_in = filled;
+    c.fail_count = nullptr;  // already counted
+    HK_HIP(hk::launch_fit_apply(c, desc->model, r2, sl.stream));
+    return HK_OK;
+}
+
 // Device-side KernelModel.fit (+ apply when d_corr) of one float32 block already in HBM: block statistics for
 // gain-blk-offset (or the caller's norm), the fused kernel, and the in-painting branch of gain-offset
 // (kernel_model.py:361-371) when valid pixels fail the r2 mask.  d_gain / d_off / d_r2 / d_corr are nullable planes.
@@ -267,29 +297,8 @@ int fit_on_device(hk_ctx* ctx, Slot& sl, const hk_fit_desc* desc, const double* 
         HK_HIP(hipMemcpyAsync(&n_fail, d_fail, sizeof(n_fail), hipMemcpyDeviceToHost, sl.stream));
         HK_HIP(hipStreamSynchronize(sl.stream));
         if (n_fail > 0) {
-            const size_t need = 4 * plane + hk::inpaint_workspace_bytes(height, stride);
-            if (sl.aux_bytes < need) {
-                if (sl.aux) HK_HIP(hipFree(sl.aux));
-                sl.aux = nullptr, sl.aux_bytes = 0;
-                if (hipMalloc(&sl.aux, need) != hipSuccess) return fail(HK_ERR_NOMEM, "hipMalloc(%zu) failed", need);
-                sl.aux_bytes = need;
-            }
-            char* aux = static_cast<char*>(sl.aux);
-            float* filled = reinterpret_cast<float*>(aux);
-            float *pg = d_gain, *po = d_off, *pr = d_r2;
-            if (!pg) {  // parameters were not materialised by the first pass: run it again into scratch planes
-                pg = reinterpret_cast<float*>(aux + plane), po = reinterpret_cast<float*>(aux + 2 * plane);
-                pr = reinterpret_cast<float*>(aux + 3 * plane);
-                hk::FitArgs b = a;
-                b.gain = pg, b.offset = po, b.r2 = pr, b.corr = nullptr, b.fail_count = nullptr;
-                HK_HIP(hk::launch_fit_apply(b, desc->model, r2, sl.stream));
-            }
-            HK_HIP(hk::launch_inpaint_offsets(po, pg, pr, desc->r2_thresh, stride, height, width, aux + 4 * plane, filled,
-                                              sl.stream));
-            hk::FitArgs c = a;
-            c.offset_in = filled;
-            c.fail_count = nullptr;  // already counted
-            HK_HIP(hk::launch_fit_apply(c, desc->model, r2, sl.stream));
+            const int rc = inpaint_band(sl, a, desc, r2, plane);
+            if (rc) return rc;
         }
     }
     return HK_OK;
@@ -837,6 +846,46 @@ int hk_fit_apply_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* job
     fill_args(a, desc, ctx->xcd_remap);
     fill_grid(a, job->seg_rows);
     HK_HIP(hk::launch_fit_apply(a, desc->model, needs_r2(desc), ctx->slots[job->stream].stream));
+    return HK_OK;
+}
+
+int hk_inpaint_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* job, uint64_t* n_fail_out) {
+    int rc = validate_desc(desc);
+    if (rc) return rc;
+    rc = check_job(ctx, job);
+    if (rc) return rc;
+    if (n_fail_out) *n_fail_out = 0;
+    if (desc->model != HK_MODEL_GAIN_OFFSET || !desc->has_r2_thresh) return HK_OK;  // nothing to in-paint
+    if (!job->fail_count) return fail(HK_ERR_ARG, "job->fail_count is NULL");
+    if (job->n_bands > 1024) return fail(HK_ERR_ARG, "too many bands");
+    HK_HIP(hipSetDevice(ctx->device));
+    Slot& sl = ctx->slots[job->stream];
+    std::vector<unsigned long long> counts((size_t)job->n_bands);
+    HK_HIP(hipMemcpyAsync(counts.data(), job->fail_count, counts.size() * sizeof(unsigned long long),
+                          hipMemcpyDeviceToHost, sl.stream));
+    HK_HIP(hipStreamSynchronize(sl.stream));
+    // the counters are consumed: the next hk_fit_apply_dev of this job starts from zero
+    HK_HIP(hipMemsetAsync(job->fail_count, 0, counts.size() * sizeof(unsigned long long), sl.stream));
+    const bool r2 = needs_r2(desc);
+    const size_t plane = (size_t)job->stride * job->height * sizeof(float);
+    unsigned long long total = 0;
+    for (int b = 0; b < job->n_bands; ++b) {
+        total += counts[b];
+        if (counts[b] == 0) continue;
+        const long long off = (long long)b * job->band_stride;
+        hk::FitArgs a;
+        memset(&a, 0, sizeof(a));
+        a.src = job->src + off, a.ref = job->ref + off;
+        a.gain = job->gain ? job->gain + off : nullptr, a.offset = job->offset ? job->offset + off : nullptr;
+        a.r2 = job->r2 ? job->r2 + off : nullptr, a.corr = job->corr ? job->corr + off : nullptr;
+        a.height = job->height, a.width = job->width, a.stride = job->stride, a.band_stride = 0, a.n_bands = 1;
+        fill_args(a, desc, ctx->xcd_remap);
+        fill_grid(a, job->seg_rows);
+        std::lock_guard<std::mutex> lk(ctx->mu);  // the slot's scratch may be (re)allocated
+        rc = inpaint_band(sl, a, desc, r2, plane);
+        if (rc) return rc;
+    }
+    if (n_fail_out) *n_fail_out = total;
     return HK_OK;
 }
 

@@ -208,8 +208,16 @@ typedef struct {
     int32_t stream;        /* index into the context's stream pool */
 } hk_dev_job;
 
-/* Launch the fused kernel over all bands of a device-resident job (asynchronous on stream `job->stream`). */
+/* Launch the fused kernel over all bands of a device-resident job (asynchronous on stream `job->stream`).  With an r2
+ * threshold the pixels failing the mask are only COUNTED (job->fail_count); follow with hk_inpaint_dev. */
 int hk_fit_apply_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* job);
+/* Second half of gain-offset with an r2 threshold on a device-resident job (kernel_model.py:361-371): waits for the
+ * stream, reads job->fail_count and, for every band with failing pixels, in-paints their offsets and re-runs the fit
+ * with them (recomputed gains, re-applied correction; parameter planes of the job are updated when present).  A no-op
+ * for the other models.  *n_fail_out (nullable) receives the number of failing pixels over all bands; the counters
+ * are then cleared (asynchronously), ready for the job's next hk_fit_apply_dev.  Returns after queueing the passes on
+ * `job->stream`. */
+int hk_inpaint_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* job, uint64_t* n_fail_out);
 /* Per-band block normalisation on device planes -> norm (device, n_bands x 2 float64); asynchronous. */
 int hk_block_norm_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* job, double* norm_dev);
 /* Fill device planes with the synthetic workload of SURVEY.md section 8(d) (src ~ U[0.05,1), ref = g*src+o+noise);

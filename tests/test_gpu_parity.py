@@ -740,6 +740,63 @@ def test_r2_inpainting_vs_oracle(ctx, want_params):
     assert_close_ulp(corr, onp.apply(src, exp_params), 'corrected after in-painting', max_frac=1e-3)
 
 
+@pytest.mark.parametrize('with_params', [False, True])
+def test_device_resident_job_with_inpainting(ctx, oc, with_params):
+    """ hk_fit_apply_dev + hk_inpaint_dev on a 3-band job resident in HBM: only the bands whose r2 mask has failures
+    are in-painted; every band equals the oracle's whole reference branch. """
+    h, w, nb = 96, 300, 3
+    stride = (w + 63) // 64 * 64
+    band_stride = stride * h
+    srcs, refs = [], []
+    for b in range(nb):
+        s_, r_ = onp.synth_pair(h, w, 40 + b, 'frame+holes')
+        r_ = r_.copy()
+        if b == 1:
+            r_[30:36, 100:112] = -3.0
+            r_[60, 200] = 9.0
+        srcs.append(s_), refs.append(r_)
+    pad = lambda planes: np.stack([np.pad(p, ((0, 0), (0, stride - w))) for p in planes]).astype(np.float32)  # noqa: E731
+    nbytes = 4 * band_stride * nb
+    names = ('src', 'ref', 'corr') + (('gain', 'offset', 'r2') if with_params else ())
+    d = {k: ctx.dev_alloc(nbytes) for k in names}
+    d['fail'] = ctx.dev_alloc(8 * nb)
+    try:
+        ctx.h2d(d['src'], pad(srcs)), ctx.h2d(d['ref'], pad(refs))
+        ctx.memset(d['fail'], 0, 8 * nb)
+        desc = _hk.make_desc('gain-offset', (5, 5), False, 0.25, np.nan, np.nan)
+        job = _hk.DevJob()
+        job.src, job.ref, job.corr, job.fail_count = d['src'], d['ref'], d['corr'], d['fail']
+        job.gain, job.offset, job.r2 = (d['gain'], d['offset'], d['r2']) if with_params else (None, None, None)
+        job.norm = None
+        job.n_bands, job.height, job.width, job.stride, job.band_stride = nb, h, w, stride, band_stride
+        job.seg_rows, job.stream = 0, 0
+        ctx.fit_apply_dev(desc, job)
+        ctx.stream_sync(0)
+        counts = np.zeros(nb, np.uint64)
+        ctx.d2h(counts, d['fail'])           # per-band counts of the first pass ...
+        n_fail = ctx.inpaint_dev(desc, job)  # ... which hk_inpaint_dev consumes and clears
+        ctx.stream_sync(0)
+        cleared = np.ones(nb, np.uint64)
+        ctx.d2h(cleared, d['fail'])
+        assert not cleared.any()
+        out = {k: np.empty((nb, h, stride), np.float32) for k in names if k not in ('src', 'ref')}
+        for k, arr in out.items():
+            ctx.d2h(arr, d[k])
+        exp_total = 0
+        for b in range(nb):
+            exp_params, exp_corr, exp_fail = oc.fit_apply('gain-offset', srcs[b], np.nan, refs[b], np.nan, (5, 5), False, 0.25)
+            exp_total += exp_fail
+            assert int(counts[b]) == exp_fail and (exp_fail > 0) == (b == 1)
+            assert_close_ulp(out['corr'][b, :, :w], exp_corr, f'band {b} corrected', max_frac=1e-3)
+            if with_params:
+                got = np.stack([out['gain'][b, :, :w], out['offset'][b, :, :w], out['r2'][b, :, :w]])
+                assert_close_ulp(got, exp_params, f'band {b} params', max_frac=1e-3)
+        assert n_fail == exp_total
+    finally:
+        for v in d.values():
+            ctx.dev_free(v)
+
+
 def test_fill_nodata_known_answers():
     """ the restated GDAL fill on hand-checkable cases (oracle only; the GPU version is compared with it above). """
     img = np.zeros((5, 7), np.float32)
