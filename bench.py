@@ -134,7 +134,7 @@ def main():
     from homonim_amd import _hk, dist
     rank, world, local_rank = dist.init()  # torch.distributed (nccl = RCCL) only when WORLD_SIZE > 1
     n_gpus = args.gpus
-    ctx = _hk.Context(local_rank, n_streams=2)
+    ctx = _hk.Context(local_rank % max(1, _hk.device_count()), n_streams=2)  # one GPU per rank on a full node
     ctx.selftest()
 
     H = W = args.size

@@ -26,7 +26,8 @@ def init(backend: Optional[str] = None) -> Tuple[int, int, int]:
         import torch
         import torch.distributed as dist
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+            # HOMONIM_AMD_DIST_BACKEND=gloo: several ranks sharing one GPU (smoke tests on a 1-GPU box)
+            backend = os.environ.get('HOMONIM_AMD_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if backend == 'nccl':
             torch.cuda.set_device(local_rank)
