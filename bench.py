@@ -38,7 +38,7 @@ def parse_args():
     p.add_argument('--model', default='gain-offset', choices=['gain', 'gain-blk-offset', 'gain-offset'])
     p.add_argument('--kernel', type=int, default=5)
     p.add_argument('--seg-rows', type=int, default=0)
-    p.add_argument('--nodata', type=int, default=0, help='0: no nodata, 1: NaN frame + 0.1%% holes, 2: NaN frame only')
+    p.add_argument('--nodata', type=int, default=0, help='0: no nodata, 1: NaN frame + 0.1%% holes, 2: NaN frame only, 3: no nodata, noisy reference (r2 failures)')
     p.add_argument('--no-thresh', action='store_true', help='gain-offset without r2_inpaint_thresh (no R2 work)')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-parity', action='store_true')
@@ -83,7 +83,7 @@ def cpu_baseline(model, k, sample):
                        f'fit+apply, {impl}, {dt:.3f} s per pass')
 
 
-def parity_spot_check(ctx, args, bufs, stride, band_stride, thresh):
+def parity_spot_check(ctx, args, bufs, stride, band_stride, thresh, n_fail=0):
     """ Not timed: download a window of band 0 and compare the GPU output with the numpy oracle. """
     from oracle import oracle_np as onp
     H = W = args.size
@@ -97,13 +97,16 @@ def parity_spot_check(ctx, args, bufs, stride, band_stride, thresh):
     for name in ('src', 'ref', 'corr'):
         ctx.d2h(rows, bufs[name] + 4 * (y0 * stride))
         win[name] = rows[:, x0:x0 + ww].copy()
-    nodata = np.nan if args.nodata else None
+    nodata = np.nan if args.nodata in (1, 2) else None
     norm = None
     if args.model == 'gain-blk-offset':
         norm = bufs['norm_host'][0]
     params, _ = onp.fit(args.model, win['src'], nodata, win['ref'], nodata, (k, k), False, thresh, norm_model=norm)
     exp = onp.apply(win['src'], params)
-    # windows of interior pixels see the same data as on the GPU; drop the r-px rim of the downloaded window
+    # windows of interior pixels see the same data as on the GPU; drop the r-px rim of the downloaded window (plus the
+    # 100-px search radius of the in-painting when pixels failed the r2 mask: it looks that far for passing neighbours)
+    if n_fail:
+        r += 101
     sl = (slice(r if y0 > 0 else 0, wh - r if y0 + wh < H else wh), slice(r if x0 > 0 else 0, ww - r if x0 + ww < W else ww))
     got, exp = win['corr'][sl], exp[sl]
     nan_ok = bool((np.isnan(got) == np.isnan(exp)).all())
@@ -144,8 +147,8 @@ def main():
     band_stride = stride * H
     plane_bytes = 4 * band_stride * B
     thresh = 0.25 if (args.model == 'gain-offset' and not args.no_thresh) else None
-    desc = _hk.make_desc(args.model, (k, k), False, thresh, np.nan if args.nodata else None,
-                         np.nan if args.nodata else None)
+    nd = np.nan if args.nodata in (1, 2) else None
+    desc = _hk.make_desc(args.model, (k, k), False, thresh, nd, nd)
 
     bufs = {name: ctx.dev_alloc(plane_bytes) for name in ('src', 'ref', 'corr')}
     bufs['fail'] = ctx.dev_alloc(8 * B)
@@ -211,7 +214,7 @@ def main():
                 nh = np.zeros((B, 2), np.float64)
                 ctx.d2h(nh, bufs['norm'])
                 bufs['norm_host'] = nh
-            parity = parity_spot_check(ctx, args, bufs, stride, band_stride, thresh)
+            parity = parity_spot_check(ctx, args, bufs, stride, band_stride, thresh, n_fail)
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args.model, k, args.cpu_sample)

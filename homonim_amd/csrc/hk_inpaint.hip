@@ -11,7 +11,7 @@
 //   * value = sum(v_q / d_q) / sum(1 / d_q) over the quadrants with d_q <= max_dist, in float64, cast to float32;
 //     targets without any source keep their value.  Filled pixels never act as sources.
 // GDAL runs this sequentially line by line; every target is independent given the column tables, so here it is one
-// thread per column for the scans and one thread per pixel for the search.
+// thread per (column, row chunk) for the scans and one thread per pixel for the search.
 #include "hk_kernels.h"
 
 namespace hk {
@@ -21,6 +21,10 @@ constexpr int NONE_Y = 0x7fffffff;
 // source = (r2 > thresh) & (gain > 0) & valid (kernel_model.py:363); valid <=> gain plane holds a parameter or NaN from
 // a degenerate window -- the validity itself travels as the non-NaN-ness of `valid_ref` (the corrected/gain planes are
 // NaN outside the mask by construction, but degenerate windows can be NaN inside it, so the mask is passed explicitly).
+// One thread per (column, chunk of SCAN_ROWS rows).  A source is only visible `max_dist` rows away, so a chunk's scan
+// starts `max_dist` rows before (top-down) / after (bottom-up) its first output row with an empty state and reproduces
+// the sequential scan exactly, while the grid has (height / SCAN_ROWS) times more threads than columns.
+constexpr int SCAN_ROWS = 128;
 __global__ void __launch_bounds__(256) inpaint_scan_kernel(const float* __restrict__ offset, const float* __restrict__ gain,
                                                            const float* __restrict__ r2, float thresh, long long stride,
                                                            int height, int width, int max_dist, int* __restrict__ top_y,
@@ -28,10 +32,11 @@ __global__ void __launch_bounds__(256) inpaint_scan_kernel(const float* __restri
                                                            float* __restrict__ bot_v) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= width) return;
+    const int y0 = blockIdx.y * SCAN_ROWS, y1 = min(y0 + SCAN_ROWS, height);
     // top-down: nearest source at or above each row
     int last_y = NONE_Y;
     float last_v = 0.f;
-    for (int y = 0; y < height; ++y) {
+    for (int y = max(0, y0 - max_dist); y < y1; ++y) {
         const long long i = (long long)y * stride + x;
         const bool srcpx = (r2[i] > thresh) && (gain[i] > 0.f);  // NaN parameters (masked pixels) compare false
         if (srcpx) {
@@ -40,16 +45,20 @@ __global__ void __launch_bounds__(256) inpaint_scan_kernel(const float* __restri
         } else if (last_y != NONE_Y && y > max_dist + last_y) {
             last_y = NONE_Y;
         }
-        top_y[i] = last_y;
-        top_v[i] = last_v;
+        if (y >= y0) {
+            top_y[i] = last_y;
+            top_v[i] = last_v;
+        }
     }
     // bottom-up: nearest source strictly below each row (the state left by the row underneath)
     last_y = NONE_Y;
     last_v = 0.f;
-    for (int y = height - 1; y >= 0; --y) {
+    for (int y = min(height - 1, y1 - 1 + max_dist + 1); y >= y0; --y) {
         const long long i = (long long)y * stride + x;
-        bot_y[i] = last_y;
-        bot_v[i] = last_v;
+        if (y < y1) {
+            bot_y[i] = last_y;
+            bot_v[i] = last_v;
+        }
         const bool srcpx = (r2[i] > thresh) && (gain[i] > 0.f);
         if (srcpx) {
             last_y = y;
@@ -121,7 +130,8 @@ hipError_t launch_inpaint_offsets(const float* offset, const float* gain, const 
     int* bot_y = reinterpret_cast<int*>(top_v + plane);
     float* bot_v = reinterpret_cast<float*>(bot_y + plane);
     const int max_dist = 100;  // rasterio.fill.fillnodata default max_search_distance (kernel_model.py:366)
-    hipLaunchKernelGGL(inpaint_scan_kernel, dim3((width + 255) / 256), dim3(256), 0, stream, offset, gain, r2, thresh,
+    hipLaunchKernelGGL(inpaint_scan_kernel, dim3((width + 255) / 256, (height + SCAN_ROWS - 1) / SCAN_ROWS), dim3(256), 0,
+                       stream, offset, gain, r2, thresh,
                        stride, height, width, max_dist, top_y, top_v, bot_y, bot_v);
     hipLaunchKernelGGL(inpaint_fill_kernel, dim3((width + 255) / 256, height), dim3(256), 0, stream, offset, gain, r2,
                        thresh, stride, height, width, max_dist, top_y, top_v, bot_y, bot_v, filled);
