@@ -580,7 +580,10 @@ int hk_refspace_fit_apply(hk_ctx* ctx, const hk_fit_desc* desc, const hk_io_desc
     auto take = [&](size_t bytes) { const size_t off = total; total += (bytes + 255) / 256 * 256; return off; };
     const size_t o_src = take(splane), o_ref = take(rplane), o_ds = take(rplane);
     const size_t o_gain = take(rplane), o_off = take(rplane), o_r2 = r2 ? take(rplane) : 0;
-    const size_t o_gus = take(splane), o_ous = take(splane), o_corr = take(splane);
+    // bilinear / cubic_spline parameters are up-sampled inside the apply kernel (no full-resolution parameter planes)
+    const bool fused_up = space->up_resampling == 1 || space->up_resampling == 3;
+    const size_t o_gus = fused_up ? 0 : take(splane), o_ous = fused_up ? 0 : take(splane), o_corr = take(splane);
+    const size_t o_rowtab = fused_up ? take(hk::upsample_apply_workspace_bytes(src_height)) : 0;
     const size_t o_vs = space->mask_partial ? take(splane) : 0, o_cov = space->mask_partial ? take(rplane) : 0;
     const size_t o_mk = space->mask_partial ? take((size_t)rs * ref_height) : 0;
     const size_t o_mkf = space->mask_partial ? take(rplane) : 0, o_keep = space->mask_partial ? take(splane) : 0;
@@ -626,10 +629,11 @@ int hk_refspace_fit_apply(hk_ctx* ctx, const hk_fit_desc* desc, const hk_io_desc
     if (rc) return rc;
 
     // RefSpaceModel.apply (:484-503): gain / offset -> source grid, re-mask, apply
-    for (int b = 0; b < 2; ++b)
-        HK_HIP(hk::launch_resample(space->up_resampling, b ? d_off : d_gain, rs, 0, ref_height, ref_width, 1, HK_NODATA_NAN,
-                                   nan, space->up[0], space->up[1], space->up[2], space->up[3], b ? d_ous : d_gus, ss, 0,
-                                   src_height, src_width, nan, sl.stream));
+    if (!fused_up)
+        for (int b = 0; b < 2; ++b)
+            HK_HIP(hk::launch_resample(space->up_resampling, b ? d_off : d_gain, rs, 0, ref_height, ref_width, 1,
+                                       HK_NODATA_NAN, nan, space->up[0], space->up[1], space->up[2], space->up[3],
+                                       b ? d_ous : d_gus, ss, 0, src_height, src_width, nan, sl.stream));
     const float* d_keep = nullptr;
     if (space->mask_partial) {
         // _full_coverage_mask (:375-409): source mask --average--> reference grid (>= 1) & parameter mask, eroded by
@@ -651,8 +655,14 @@ int hk_refspace_fit_apply(hk_ctx* ctx, const hk_fit_desc* desc, const hk_io_desc
                                    sl.stream));
         d_keep = F(o_keep);
     }
-    HK_HIP(hk::launch_apply_space(d_src, ss, desc->src_nodata_mode, desc->src_nodata, d_gus, d_ous, ss, d_keep, d_corr, ss,
-                                  src_height, src_width, sl.stream));
+    if (fused_up) {
+        HK_HIP(hk::launch_upsample_apply(space->up_resampling, d_src, ss, desc->src_nodata_mode, desc->src_nodata, d_gain,
+                                         d_off, rs, ref_height, ref_width, d_keep, ss, d_corr, ss, src_height, src_width,
+                                         space->up[0], space->up[1], space->up[2], space->up[3], base + o_rowtab, sl.stream));
+    } else {
+        HK_HIP(hk::launch_apply_space(d_src, ss, desc->src_nodata_mode, desc->src_nodata, d_gus, d_ous, ss, d_keep, d_corr,
+                                      ss, src_height, src_width, sl.stream));
+    }
 
     if (params_out) {
         float* outs[3] = {d_gain, d_off, d_r2};

@@ -96,6 +96,11 @@ hipError_t launch_resample(int mode, const float* src, long long src_stride, lon
                            long long dst_stride, long long dst_band_stride, int dh, int dw, float dst_fill,
                            hipStream_t stream);
 
+size_t upsample_apply_workspace_bytes(int height);
+hipError_t launch_upsample_apply(int mode, const float* src, long long src_stride, int nd_mode, float nodata,
+                                 const float* gain, const float* offset, long long par_stride, int ph, int pw,
+                                 const float* keep, long long keep_stride, float* out, long long out_stride, int height,
+                                 int width, double kx, double ox, double ky, double oy, void* workspace, hipStream_t stream);
 hipError_t launch_valid_plane(const float* in, long long in_stride, int nd_mode, float nodata, float* out,
                               long long out_stride, int height, int width, hipStream_t stream);
 hipError_t launch_apply_space(const float* src, long long src_stride, int nd_mode, float nodata, const float* gain,

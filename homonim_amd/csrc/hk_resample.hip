@@ -145,6 +145,131 @@ __global__ void __launch_bounds__(256) apply_space_kernel(const float* __restric
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// RefSpaceModel.apply fused (kernel_model.py:484-503): the up-sampled gain / offset never exist as full-resolution
+// planes.  Per destination pixel the bilinear / cubic-spline values of BOTH parameter planes are formed exactly as
+// resample_kernel<MODE> does (same weights, same tap order, same renormalisation rule), masked like apply_space_kernel and
+// applied.  The work that does not depend on the pixel is hoisted: the row geometry and weights come from a table made
+// by row_table_kernel (one entry per destination row), the column geometry and weights are computed once per thread,
+// which then walks down its column.
+constexpr int UP_ROWS = 16;  // destination rows per thread of upsample_apply_kernel (amortises the column weights)
+struct RowTab {
+    double w[4];
+    int iy;       // first tap row - T0
+    int centre;   // source row under the destination centre, or -1 when outside
+};
+
+template <int MODE>
+__global__ void __launch_bounds__(256) row_table_kernel(RowTab* __restrict__ tab, int dh, int sh, double ky, double oy) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= dh) return;
+    const double sy = ky * ((double)i + 0.5) + oy;
+    const long long cy = (long long)floor(sy + 1e-10);
+    RowTab t;
+    t.iy = (int)floor(sy - 0.5);
+    t.centre = (cy >= 0 && cy < sh) ? (int)cy : -1;
+    const double dy = sy - 0.5 - (double)t.iy;
+    if constexpr (MODE == 1) {
+        t.w[0] = 1.0 - dy, t.w[1] = dy, t.w[2] = t.w[3] = 0.0;
+    } else {
+        bspline4(dy, t.w);
+    }
+    tab[i] = t;
+}
+
+struct UpApplyArgs {
+    const float* src;     // full-resolution source (destination grid)
+    long long src_stride;
+    int nd_mode;
+    float nodata;
+    const float* gain;    // coarse parameter planes, NaN = nodata
+    const float* offset;
+    long long par_stride;
+    int ph, pw;
+    const float* keep;    // nullable full-resolution 0/1 plane (mask_partial)
+    long long keep_stride;
+    float* out;
+    long long out_stride;
+    int height, width;
+    double kx, ox;
+    const RowTab* rows;
+};
+
+template <int MODE>
+__global__ void __launch_bounds__(256) upsample_apply_kernel(const UpApplyArgs a) {
+    constexpr int NT = MODE == 1 ? 2 : 4, T0 = MODE == 1 ? 0 : -1;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= a.width) return;
+    const float nan = __int_as_float(0x7fc00000);
+    // column geometry and weights: once per thread
+    const double sx = a.kx * ((double)j + 0.5) + a.ox;
+    const long long cx = (long long)floor(sx + 1e-10);
+    const bool cx_ok = cx >= 0 && cx < a.pw;
+    const int ix = (int)floor(sx - 0.5);
+    const double dx = sx - 0.5 - (double)ix;
+    double wxs[4];
+    if constexpr (MODE == 1) {
+        wxs[0] = 1.0 - dx, wxs[1] = dx, wxs[2] = wxs[3] = 0.0;
+    } else {
+        bspline4(dx, wxs);
+    }
+    for (int i = blockIdx.y; i < a.height; i += gridDim.y) {
+        const RowTab t = a.rows[i];  // wave-uniform
+        const float s = a.src[(long long)i * a.src_stride + j];
+        const bool on = a.keep ? a.keep[(long long)i * a.keep_stride + j] != 0.f : rs_valid(s, a.nd_mode, a.nodata);
+        float par[2] = {nan, nan};
+        if (on && cx_ok && t.centre >= 0) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const float* __restrict__ pp = b ? a.offset : a.gain;
+                if (pp[(long long)t.centre * a.par_stride + cx] != pp[(long long)t.centre * a.par_stride + cx]) continue;  // NaN centre
+                double acc = 0.0, wacc = 0.0;
+#pragma unroll
+                for (int tj = 0; tj < NT; ++tj) {
+                    const int yy = t.iy + T0 + tj;
+                    if (yy < 0 || yy >= a.ph) continue;
+#pragma unroll
+                    for (int ti = 0; ti < NT; ++ti) {
+                        const int xx = ix + T0 + ti;
+                        if (xx < 0 || xx >= a.pw) continue;
+                        const float v = pp[(long long)yy * a.par_stride + xx];
+                        if (v != v) continue;
+                        const double wgt = wxs[ti] * t.w[tj];
+                        acc += (double)v * wgt;
+                        wacc += wgt;
+                    }
+                }
+                if (!(wacc < 1e-6)) par[b] = (float)((wacc < 0.99999 || wacc > 1.00001) ? acc / wacc : acc);
+            }
+        }
+        a.out[(long long)i * a.out_stride + j] = __fadd_rn(__fmul_rn(par[0], s), par[1]);
+    }
+}
+
+size_t upsample_apply_workspace_bytes(int height) { return (size_t)height * sizeof(RowTab); }
+
+// mode: 1 bilinear, 3 cubic_spline (anything else: hipErrorInvalidValue -- the caller keeps the unfused path)
+hipError_t launch_upsample_apply(int mode, const float* src, long long src_stride, int nd_mode, float nodata,
+                                 const float* gain, const float* offset, long long par_stride, int ph, int pw,
+                                 const float* keep, long long keep_stride, float* out, long long out_stride, int height,
+                                 int width, double kx, double ox, double ky, double oy, void* workspace, hipStream_t stream) {
+    if (mode != 1 && mode != 3) return hipErrorInvalidValue;
+    RowTab* tab = static_cast<RowTab*>(workspace);
+    UpApplyArgs a;
+    a.src = src, a.src_stride = src_stride, a.nd_mode = nd_mode, a.nodata = nodata, a.gain = gain, a.offset = offset;
+    a.par_stride = par_stride, a.ph = ph, a.pw = pw, a.keep = keep, a.keep_stride = keep_stride, a.out = out;
+    a.out_stride = out_stride, a.height = height, a.width = width, a.kx = kx, a.ox = ox, a.rows = tab;
+    const dim3 tgrid((height + 255) / 256), grid((width + 255) / 256, (height + UP_ROWS - 1) / UP_ROWS), block(256);
+    if (mode == 1) {
+        hipLaunchKernelGGL(row_table_kernel<1>, tgrid, block, 0, stream, tab, height, ph, ky, oy);
+        hipLaunchKernelGGL(upsample_apply_kernel<1>, grid, block, 0, stream, a);
+    } else {
+        hipLaunchKernelGGL(row_table_kernel<3>, tgrid, block, 0, stream, tab, height, ph, ky, oy);
+        hipLaunchKernelGGL(upsample_apply_kernel<3>, grid, block, 0, stream, a);
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_valid_plane(const float* in, long long in_stride, int nd_mode, float nodata, float* out,
                               long long out_stride, int height, int width, hipStream_t stream) {
     hipLaunchKernelGGL(valid_plane_kernel, dim3((width + 255) / 256, height < 1024 ? height : 1024), dim3(256), 0, stream,
