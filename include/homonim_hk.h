@@ -184,6 +184,9 @@ int hk_host_unregister(hk_ctx* ctx, void* hptr);
 /* ------------------------------------------------------------------------------------------------------------------
  * device-resident entry points (inputs already in HBM): what bench.py times and what the streaming tile pipeline
  * is built from.  Buffers come from hk_dev_alloc; planes are height x stride float32 with stride % 4 == 0.
+ * A job names its stream by index: jobs on one stream must be issued by one host thread at a time (stream order is the
+ * only ordering), and a context that serves device-resident jobs should not serve host-pointer calls (hk_fit, ...)
+ * concurrently -- those lease the same pooled streams and their scratch buffers.  Use a second context for that.
  */
 int hk_dev_alloc(hk_ctx* ctx, size_t bytes, void** dptr);
 int hk_dev_free(hk_ctx* ctx, void* dptr);
