@@ -613,12 +613,31 @@ __global__ void __launch_bounds__(WAVE, HK_FIT_MIN_WAVES) fit_apply_kernel(const
             }
             if constexpr (DENSE) mc = (colbits * 0x00204081u) & 0x01010101u;  // bit i -> byte i
 
+            // gain-offset only ever uses the float32 images of S, R, P (boxFilter output depth = input depth): convert each
+            // as soon as its horizontal sum exists and keep the scheduler from interleaving the five sums, so that at most
+            // one of those float64 quadruples is live beside S2 / R2 (12-16 VGPRs less at the pressure peak)
             double HS[PX], HR[PX];
+            [[maybe_unused]] float Sf0[PX], Rf0[PX], Pf0[PX];
             hsum_any<RW, double>(cs.S, HS, rw, ol, lane);
+            if constexpr (GO) {
+#pragma unroll
+                for (int i = 0; i < PX; ++i) Sf0[i] = (float)HS[i];
+                __builtin_amdgcn_sched_barrier(0);
+            }
             hsum_any<RW, double>(cs.R, HR, rw, ol, lane);
+            if constexpr (GO) {
+#pragma unroll
+                for (int i = 0; i < PX; ++i) Rf0[i] = (float)HR[i];
+                __builtin_amdgcn_sched_barrier(0);
+            }
             double HP[PX], HS2[PX], HR2[PX];
             float Nf[PX];
             if constexpr (CS::NEED_P) hsum_any<RW, double>(cs.P, HP, rw, ol, lane);
+            if constexpr (GO) {
+#pragma unroll
+                for (int i = 0; i < PX; ++i) Pf0[i] = (float)HP[i];
+                __builtin_amdgcn_sched_barrier(0);
+            }
             if constexpr (CS::NEED_S2) hsum_any<RW, double>(cs.S2, HS2, rw, ol, lane);
             if constexpr (CS::NEED_R2S) hsum_any<RW, double>(cs.R2s, HR2, rw, ol, lane);
             if constexpr (USE_N) {
@@ -644,190 +663,198 @@ __global__ void __launch_bounds__(WAVE, HK_FIT_MIN_WAVES) fit_apply_kernel(const
                 }
             }
 
-            // ---- stage A: gains and offsets -------------------------------------------------------------------------
-            float g[PX], o[PX], r2v[PX], c[PX];
-            [[maybe_unused]] float Rf[PX], Sf[PX], Pf[PX], gp[PX];
-            if constexpr (GO) {
-                // kernel_model.py:338-351; src2_sum is float64 (sqrBoxFilter) so m_den and the division are f64.
-                // float32 steps run two pixels per instruction (packed), float64 steps per pixel.
-                auto stage_a = [&](auto uniform_n) {
-                    constexpr bool UN = decltype(uniform_n)::value;
-#pragma unroll
-                    for (int j = 0; j < PX / 2; ++j) {
-                        const f2 Rf2 = {(float)HR[2 * j], (float)HR[2 * j + 1]};  // boxFilter output depth = input depth
-                        const f2 Sf2 = {(float)HS[2 * j], (float)HS[2 * j + 1]};
-                        const f2 Pf2 = {(float)HP[2 * j], (float)HP[2 * j + 1]};
-                        const f2 Nf2 = UN ? f2{a.n_full, a.n_full} : HK_P2(Nf, j);
-                        const double Ndx = UN ? a.nd_full : (double)Nf2.x, Ndy = UN ? a.nd_full : (double)Nf2.y;
-                        const f2 num2 = Nf2 * Pf2 - Sf2 * Rf2;
-                        const f2 SS2 = Sf2 * Sf2;
-                        f2 g2;
-                        g2.x = (float)__ddiv_rn((double)num2.x, __dsub_rn(__dmul_rn(Ndx, HS2[2 * j]), (double)SS2.x));
-                        g2.y = (float)__ddiv_rn((double)num2.y, __dsub_rn(__dmul_rn(Ndy, HS2[2 * j + 1]), (double)SS2.y));
-                        const f2 tn2 = Rf2 - g2 * Sf2;
-                        f2 o2;
-                        if constexpr (UN) {
-                            o2.x = (float)__dmul_rn((double)tn2.x, a.inv_n_full);
-                            o2.y = (float)__dmul_rn((double)tn2.y, a.inv_n_full);
-                        } else if (use_lut) {  // wave-uniform
-                            o2.x = (float)__dmul_rn((double)tn2.x, inv_lut[(int)Nf2.x]);
-                            o2.y = (float)__dmul_rn((double)tn2.y, inv_lut[(int)Nf2.y]);
-                        } else {
-                            o2.x = __fdiv_rn(tn2.x, Nf2.x);
-                            o2.y = __fdiv_rn(tn2.y, Nf2.y);
-                        }
-                        Rf[2 * j] = Rf2.x, Rf[2 * j + 1] = Rf2.y;
-                        Sf[2 * j] = Sf2.x, Sf[2 * j + 1] = Sf2.y;
-                        Pf[2 * j] = Pf2.x, Pf[2 * j + 1] = Pf2.y;
-                        g[2 * j] = g2.x, g[2 * j + 1] = g2.y;
-                        o[2 * j] = o2.x, o[2 * j + 1] = o2.y;
-                    }
-                };
-                if (n_uniform) stage_a(std::true_type{});
-                else stage_a(std::false_type{});
-            }
-#pragma unroll
-            for (int i = 0; i < PX; ++i) {
-                if constexpr (!GO) Rf[i] = (float)HR[i];  // boxFilter output depth = input depth (float32)
+            // The pointwise stages exist in two versions: UN = every stored pixel of this wave-row has the full, all-valid
+            // window (n_uniform): the window count, its float64 image and 1/N are scalars and the centre-row mask is all ones,
+            // so every mask select and bit test folds away.
+            auto pointwise = [&](auto uniform_n) {
+                constexpr bool UN = decltype(uniform_n)::value;
+                const unsigned mcu = UN ? 0x01010101u : mc;
+                // ---- stage A: gains and offsets -------------------------------------------------------------------------
+                float g[PX], o[PX], r2v[PX], c[PX];
+                [[maybe_unused]] float Rf[PX], Sf[PX], Pf[PX], gp[PX];
                 if constexpr (GO) {
-                } else if constexpr (BLK) {
-                    // kernel_model.py:265 with a float64 src_sum: np.divide(f32, f64, out=f32); then :301-302
-                    gp[i] = (float)__ddiv_rn((double)Rf[i], HS[i]);
-                    o[i] = (float)__dmul_rn((double)gp[i], n1);
-                    g[i] = (float)__dmul_rn((double)gp[i], n0);
-                } else {
-                    // kernel_model.py:262-265
-                    Sf[i] = (float)HS[i];
-                    if constexpr (R2) Pf[i] = (float)HP[i];
-                    g[i] = __fdiv_rn(Rf[i], Sf[i]);
-                    o[i] = 0.f;
-                }
-                r2v[i] = qnan();
-            }
-
-            // ---- stage B: R2 (kernel_model.py:179,189-195|201,203,212-213) ---------------------------------------------
-            if constexpr (R2) {
-                if (want_r2_values || count_fails) {  // wave-uniform
-                    bool exact = want_r2_values;
-                    if constexpr (GO) {
-                        if (!exact && cert_skip > 0) {  // the rows just above needed the exact evaluation: go straight to it
-                            exact = true;
-                            --cert_skip;
-                        }
-                        if (!exact) {
-                            // Division-free CERTIFICATE of `(r2 > thresh) & (gain > 0)` from float32 quantities (proof:
-                            // DESIGN.md appendix A).  With T = g^2*S2 + R2 + N*o^2 the reference's float arithmetic obeys
-                            //   ssres_ref <= sstot_ref - g^2*den + 35*2^-24*N*T   and   |sstot_ref - sst| <= 4.1*2^-24*N*T,
-                            // so  g^2*den > kappa*sst + 2^-17*N*T  (kappa = 1 - r2_pass_scale, rounded up) proves
-                            // ssres_ref < r2_pass_scale * sstot_ref, which proves the reference's decision.
-                            bool uncertain = !cert_ok;
-#pragma unroll
-                            for (int j = 0; j < PX / 2; ++j) {
-                                const f2 g2 = HK_P2(g, j), o2 = HK_P2(o, j), Nf2 = HK_P2(Nf, j);
-                                const f2 Rf2 = HK_P2(Rf, j), Sf2 = HK_P2(Sf, j);
-                                const f2 S2f = {(float)HS2[2 * j], (float)HS2[2 * j + 1]};
-                                const f2 R2f = {(float)HR2[2 * j], (float)HR2[2 * j + 1]};
-                                const f2 gg = g2 * g2;
-                                const f2 sst = pk_fma(Nf2, R2f, -(Rf2 * Rf2));
-                                const f2 T = pk_fma(gg, S2f, pk_fma(Nf2 * o2, o2, R2f));
-                                const f2 NT = Nf2 * T;
-                                const f2 slack = NT * 0x1p-17f;
-                                const f2 denf = pk_fma(Nf2, S2f, -(Sf2 * Sf2));
-                                const f2 lhs = gg * denf;
-                                const f2 rhs = pk_fma(f2{a.r2_fail_scale, a.r2_fail_scale}, sst, slack);
-#pragma unroll
-                                for (int e = 0; e < 2; ++e) {
-                                    const int i = 2 * j + e;
-                                    const bool m = (mc >> (8 * i)) & 1u;
-                                    // magnitude windows (no underflow / overflow anywhere in the reference's expression):
-                                    // 2^-20 < g < 2^20 (also the `gain > 0` half of the decision), 2^-40 < N*T < 2^60
-                                    const bool g_in = (__float_as_uint(g2[e]) - 0x35800000u) < (0x49800000u - 0x35800000u);
-                                    const bool t_in = (__float_as_uint(NT[e]) - 0x2b800000u) < (0x5d800000u - 0x2b800000u);
-                                    const bool sure = (lhs[e] > rhs[e]) & (sst[e] > slack[e]) & g_in & t_in;
-                                    uncertain |= out_lane & m & !sure;
-                                }
-                            }
-                            exact = __any(uncertain);
-                            if (exact) cert_skip = HK_CERT_SKIP;  // failing regions are coherent: skip the certificate for a few rows
-                        }
-                    }
-                    if (exact) {
-                        double sstot[PX], ssres[PX];
-#pragma unroll
-                        for (int i = 0; i < PX; ++i) {
-                            sstot[i] = __dsub_rn(__dmul_rn((double)Nf[i], HR2[i]), (double)__fmul_rn(Rf[i], Rf[i]));
-                            double q;
-                            if constexpr (GO) {
-                                const double A = __dmul_rn((double)__fmul_rn(g[i], g[i]), HS2[i]);
-                                const float B = __fmul_rn(__fmul_rn(2.f, __fmul_rn(g[i], o[i])), Sf[i]);
-                                const float C = __fmul_rn(__fmul_rn(2.f, g[i]), Pf[i]);
-                                const float D = __fmul_rn(__fmul_rn(2.f, o[i]), Rf[i]);
-                                const float F = __fmul_rn(Nf[i], __fmul_rn(o[i], o[i]));
-                                q = __dadd_rn(A, (double)B);
-                                q = __dsub_rn(q, (double)C);
-                                q = __dsub_rn(q, (double)D);
-                                q = __dadd_rn(q, HR2[i]);
-                                q = __dadd_rn(q, (double)F);
-                            } else if constexpr (BLK) {
-                                // float64 src2_sum / src_ref_sum (the normalised source is float64)
-                                q = __dmul_rn((double)__fmul_rn(gp[i], gp[i]), HS2[i]);
-                                q = __dsub_rn(q, __dmul_rn((double)__fmul_rn(2.f, gp[i]), HP[i]));
-                                q = __dadd_rn(q, HR2[i]);
+                    // kernel_model.py:338-351; src2_sum is float64 (sqrBoxFilter) so m_den and the division are f64.
+                    // float32 steps run two pixels per instruction (packed), float64 steps per pixel.
+                    {
+    #pragma unroll
+                        for (int j = 0; j < PX / 2; ++j) {
+                            const f2 Rf2 = HK_P2(Rf0, j), Sf2 = HK_P2(Sf0, j), Pf2 = HK_P2(Pf0, j);
+                            const f2 Nf2 = UN ? f2{a.n_full, a.n_full} : HK_P2(Nf, j);
+                            const double Ndx = UN ? a.nd_full : (double)Nf2.x, Ndy = UN ? a.nd_full : (double)Nf2.y;
+                            const f2 num2 = Nf2 * Pf2 - Sf2 * Rf2;
+                            const f2 SS2 = Sf2 * Sf2;
+                            f2 g2;
+                            g2.x = (float)__ddiv_rn((double)num2.x, __dsub_rn(__dmul_rn(Ndx, HS2[2 * j]), (double)SS2.x));
+                            g2.y = (float)__ddiv_rn((double)num2.y, __dsub_rn(__dmul_rn(Ndy, HS2[2 * j + 1]), (double)SS2.y));
+                            const f2 tn2 = Rf2 - g2 * Sf2;
+                            f2 o2;
+                            if constexpr (UN) {
+                                o2.x = (float)__dmul_rn((double)tn2.x, a.inv_n_full);
+                                o2.y = (float)__dmul_rn((double)tn2.y, a.inv_n_full);
+                            } else if (use_lut) {  // wave-uniform
+                                o2.x = (float)__dmul_rn((double)tn2.x, inv_lut[(int)Nf2.x]);
+                                o2.y = (float)__dmul_rn((double)tn2.y, inv_lut[(int)Nf2.y]);
                             } else {
-                                q = __dmul_rn((double)__fmul_rn(g[i], g[i]), HS2[i]);
-                                q = __dsub_rn(q, (double)__fmul_rn(__fmul_rn(2.f, g[i]), Pf[i]));
-                                q = __dadd_rn(q, HR2[i]);
+                                o2.x = __fdiv_rn(tn2.x, Nf2.x);
+                                o2.y = __fdiv_rn(tn2.y, Nf2.y);
                             }
-                            ssres[i] = __dmul_rn(q, (double)Nf[i]);
+                            Rf[2 * j] = Rf2.x, Rf[2 * j + 1] = Rf2.y;
+                            Sf[2 * j] = Sf2.x, Sf[2 * j + 1] = Sf2.y;
+                            Pf[2 * j] = Pf2.x, Pf[2 * j + 1] = Pf2.y;
+                            g[2 * j] = g2.x, g[2 * j + 1] = g2.y;
+                            o[2 * j] = o2.x, o[2 * j + 1] = o2.y;
                         }
-#pragma unroll
-                        for (int i = 0; i < PX; ++i) {
-                            r2v[i] = __fsub_rn(1.f, (float)__ddiv_rn(ssres[i], sstot[i]));
-                            if constexpr (GO) {
-                                const bool m = (mc >> (8 * i)) & 1u;
-                                // valid pixels failing (r2 > thresh) & (gain > 0) need in-painting (:363,:370)
-                                const bool failing = count_fails && m && !((r2v[i] > a.r2_thresh) && (g[i] > 0.f));
-                                if (failing && out_lane) ++nfail;
-                                if (failing && inpaint_pass && out_lane) {
-                                    const float oin = a.offset_in[out_base + (long long)y * a.stride + x + i];
-                                    o[i] = oin;
-                                    g[i] = __fdiv_rn(__fsub_rn(Rf[i], __fmul_rn(Nf[i], oin)), Sf[i]);
+                    }
+                }
+    #pragma unroll
+                for (int i = 0; i < PX; ++i) {
+                    if constexpr (!GO) Rf[i] = (float)HR[i];  // boxFilter output depth = input depth (float32)
+                    if constexpr (GO) {
+                    } else if constexpr (BLK) {
+                        // kernel_model.py:265 with a float64 src_sum: np.divide(f32, f64, out=f32); then :301-302
+                        gp[i] = (float)__ddiv_rn((double)Rf[i], HS[i]);
+                        o[i] = (float)__dmul_rn((double)gp[i], n1);
+                        g[i] = (float)__dmul_rn((double)gp[i], n0);
+                    } else {
+                        // kernel_model.py:262-265
+                        Sf[i] = (float)HS[i];
+                        if constexpr (R2) Pf[i] = (float)HP[i];
+                        g[i] = __fdiv_rn(Rf[i], Sf[i]);
+                        o[i] = 0.f;
+                    }
+                    r2v[i] = qnan();
+                }
+
+                // ---- stage B: R2 (kernel_model.py:179,189-195|201,203,212-213) ---------------------------------------------
+                if constexpr (R2) {
+                    if (want_r2_values || count_fails) {  // wave-uniform
+                        bool exact = want_r2_values;
+                        if constexpr (GO) {
+                            if (!exact && cert_skip > 0) {  // the rows just above needed the exact evaluation: go straight to it
+                                exact = true;
+                                --cert_skip;
+                            }
+                            if (!exact) {
+                                // Division-free CERTIFICATE of `(r2 > thresh) & (gain > 0)` from float32 quantities (proof:
+                                // DESIGN.md appendix A).  With T = g^2*S2 + R2 + N*o^2 the reference's float arithmetic obeys
+                                //   ssres_ref <= sstot_ref - g^2*den + 35*2^-24*N*T   and   |sstot_ref - sst| <= 4.1*2^-24*N*T,
+                                // so  g^2*den > kappa*sst + 2^-17*N*T  (kappa = 1 - r2_pass_scale, rounded up) proves
+                                // ssres_ref < r2_pass_scale * sstot_ref, which proves the reference's decision.
+                                bool uncertain = !cert_ok;
+    #pragma unroll
+                                for (int j = 0; j < PX / 2; ++j) {
+                                    const f2 g2 = HK_P2(g, j), o2 = HK_P2(o, j), Nf2 = HK_P2(Nf, j);
+                                    const f2 Rf2 = HK_P2(Rf, j), Sf2 = HK_P2(Sf, j);
+                                    const f2 S2f = {(float)HS2[2 * j], (float)HS2[2 * j + 1]};
+                                    const f2 R2f = {(float)HR2[2 * j], (float)HR2[2 * j + 1]};
+                                    const f2 gg = g2 * g2;
+                                    const f2 sst = pk_fma(Nf2, R2f, -(Rf2 * Rf2));
+                                    const f2 T = pk_fma(gg, S2f, pk_fma(Nf2 * o2, o2, R2f));
+                                    const f2 NT = Nf2 * T;
+                                    const f2 slack = NT * 0x1p-17f;
+                                    const f2 denf = pk_fma(Nf2, S2f, -(Sf2 * Sf2));
+                                    const f2 lhs = gg * denf;
+                                    const f2 rhs = pk_fma(f2{a.r2_fail_scale, a.r2_fail_scale}, sst, slack);
+    #pragma unroll
+                                    for (int e = 0; e < 2; ++e) {
+                                        const int i = 2 * j + e;
+                                        const bool m = (mcu >> (8 * i)) & 1u;
+                                        // magnitude windows (no underflow / overflow anywhere in the reference's expression):
+                                        // 2^-20 < g < 2^20 (also the `gain > 0` half of the decision), 2^-40 < N*T < 2^60
+                                        const bool g_in = (__float_as_uint(g2[e]) - 0x35800000u) < (0x49800000u - 0x35800000u);
+                                        const bool t_in = (__float_as_uint(NT[e]) - 0x2b800000u) < (0x5d800000u - 0x2b800000u);
+                                        const bool sure = (lhs[e] > rhs[e]) & (sst[e] > slack[e]) & g_in & t_in;
+                                        uncertain |= out_lane & m & !sure;
+                                    }
+                                }
+                                exact = __any(uncertain);
+                                if (exact) cert_skip = HK_CERT_SKIP;  // failing regions are coherent: skip the certificate for a few rows
+                            }
+                        }
+                        if (exact) {
+                            double sstot[PX], ssres[PX];
+    #pragma unroll
+                            for (int i = 0; i < PX; ++i) {
+                                sstot[i] = __dsub_rn(__dmul_rn((double)Nf[i], HR2[i]), (double)__fmul_rn(Rf[i], Rf[i]));
+                                double q;
+                                if constexpr (GO) {
+                                    const double A = __dmul_rn((double)__fmul_rn(g[i], g[i]), HS2[i]);
+                                    const float B = __fmul_rn(__fmul_rn(2.f, __fmul_rn(g[i], o[i])), Sf[i]);
+                                    const float C = __fmul_rn(__fmul_rn(2.f, g[i]), Pf[i]);
+                                    const float D = __fmul_rn(__fmul_rn(2.f, o[i]), Rf[i]);
+                                    const float F = __fmul_rn(Nf[i], __fmul_rn(o[i], o[i]));
+                                    q = __dadd_rn(A, (double)B);
+                                    q = __dsub_rn(q, (double)C);
+                                    q = __dsub_rn(q, (double)D);
+                                    q = __dadd_rn(q, HR2[i]);
+                                    q = __dadd_rn(q, (double)F);
+                                } else if constexpr (BLK) {
+                                    // float64 src2_sum / src_ref_sum (the normalised source is float64)
+                                    q = __dmul_rn((double)__fmul_rn(gp[i], gp[i]), HS2[i]);
+                                    q = __dsub_rn(q, __dmul_rn((double)__fmul_rn(2.f, gp[i]), HP[i]));
+                                    q = __dadd_rn(q, HR2[i]);
+                                } else {
+                                    q = __dmul_rn((double)__fmul_rn(g[i], g[i]), HS2[i]);
+                                    q = __dsub_rn(q, (double)__fmul_rn(__fmul_rn(2.f, g[i]), Pf[i]));
+                                    q = __dadd_rn(q, HR2[i]);
+                                }
+                                ssres[i] = __dmul_rn(q, (double)Nf[i]);
+                            }
+    #pragma unroll
+                            for (int i = 0; i < PX; ++i) {
+                                r2v[i] = __fsub_rn(1.f, (float)__ddiv_rn(ssres[i], sstot[i]));
+                                if constexpr (GO) {
+                                    const bool m = (mcu >> (8 * i)) & 1u;
+                                    // valid pixels failing (r2 > thresh) & (gain > 0) need in-painting (:363,:370)
+                                    const bool failing = count_fails && m && !((r2v[i] > a.r2_thresh) && (g[i] > 0.f));
+                                    if (failing && out_lane) ++nfail;
+                                    if (failing && inpaint_pass && out_lane) {
+                                        const float oin = a.offset_in[out_base + (long long)y * a.stride + x + i];
+                                        o[i] = oin;
+                                        g[i] = __fdiv_rn(__fsub_rn(Rf[i], __fmul_rn(Nf[i], oin)), Sf[i]);
+                                    }
                                 }
                             }
                         }
                     }
                 }
-            }
 
-            // ---- stage C: apply (:461) and where=mask (every parameter write goes into a NaN-filled array, :261,:345) ----
-            // A masked pixel has NaN parameters, hence a NaN corrected value: select once per stored plane.
-#pragma unroll
-            for (int j = 0; j < PX / 2; ++j) {
-                const f2 c2 = HK_P2(g, j) * HK_P2(sc, j) + HK_P2(o, j);  // two float32 roundings
-                c[2 * j] = c2.x, c[2 * j + 1] = c2.y;
-            }
-            if constexpr (!DENSE) {
-#pragma unroll
-                for (int i = 0; i < PX; ++i) c[i] = ((mc >> (8 * i)) & 1u) ? c[i] : qnan();
-            }
-            auto masked4 = [&](const float (&v)[PX]) {
-                float4 r4 = make_float4(v[0], v[1], v[2], v[3]);
-                if constexpr (!DENSE) {
-                    r4.x = (mc & 0x00000001u) ? r4.x : qnan();
-                    r4.y = (mc & 0x00000100u) ? r4.y : qnan();
-                    r4.z = (mc & 0x00010000u) ? r4.z : qnan();
-                    r4.w = (mc & 0x01000000u) ? r4.w : qnan();
+                // ---- stage C: apply (:461) and where=mask (every parameter write goes into a NaN-filled array, :261,:345) ----
+                // A masked pixel has NaN parameters, hence a NaN corrected value: select once per stored plane.
+    #pragma unroll
+                for (int j = 0; j < PX / 2; ++j) {
+                    const f2 c2 = HK_P2(g, j) * HK_P2(sc, j) + HK_P2(o, j);  // two float32 roundings
+                    c[2 * j] = c2.x, c[2 * j + 1] = c2.y;
                 }
-                return r4;
-            };
+                if constexpr (!DENSE) {
+    #pragma unroll
+                    for (int i = 0; i < PX; ++i) c[i] = ((mcu >> (8 * i)) & 1u) ? c[i] : qnan();
+                }
+                auto masked4 = [&](const float (&v)[PX]) {
+                    float4 r4 = make_float4(v[0], v[1], v[2], v[3]);
+                    if constexpr (!DENSE) {
+                        r4.x = (mcu & 0x00000001u) ? r4.x : qnan();
+                        r4.y = (mcu & 0x00000100u) ? r4.y : qnan();
+                        r4.z = (mcu & 0x00010000u) ? r4.z : qnan();
+                        r4.w = (mcu & 0x01000000u) ? r4.w : qnan();
+                    }
+                    return r4;
+                };
 
-            if (out_lane) {
-                // stride % 4 == 0: a quad never crosses the row end, columns >= W land in the row padding
-                const long long off = out_base + (long long)y * a.stride + x;
-                if (a.corr) *reinterpret_cast<float4*>(a.corr + off) = make_float4(c[0], c[1], c[2], c[3]);
-                if (a.gain) *reinterpret_cast<float4*>(a.gain + off) = masked4(g);
-                if (a.offset) *reinterpret_cast<float4*>(a.offset + off) = masked4(o);
-                if (R2 && a.r2) *reinterpret_cast<float4*>(a.r2 + off) = masked4(r2v);
+                if (out_lane) {
+                    // stride % 4 == 0: a quad never crosses the row end, columns >= W land in the row padding
+                    const long long off = out_base + (long long)y * a.stride + x;
+                    if (a.corr) *reinterpret_cast<float4*>(a.corr + off) = make_float4(c[0], c[1], c[2], c[3]);
+                    if (a.gain) *reinterpret_cast<float4*>(a.gain + off) = masked4(g);
+                    if (a.offset) *reinterpret_cast<float4*>(a.offset + off) = masked4(o);
+                    if (R2 && a.r2) *reinterpret_cast<float4*>(a.r2 + off) = masked4(r2v);
+                }
+            };
+            if constexpr (GO) {
+                if (n_uniform) pointwise(std::true_type{});
+                else pointwise(std::false_type{});
+            } else {
+                pointwise(std::false_type{});
             }
         }
 
@@ -845,17 +872,18 @@ __global__ void __launch_bounds__(WAVE, HK_FIT_MIN_WAVES) fit_apply_kernel(const
     }
 }
 
-// LDS bytes of one wave: the row ring of the mode (see fit_apply_kernel) + the 256-entry float64 1/N table
-size_t fit_lds_bytes(int kh, int ring_mode) {
+// LDS bytes of one wave: the row ring of the mode (see fit_apply_kernel) + the 256-entry float64 1/N table that only the
+// gain-offset model reads (the HBM-bound `gain` kernel gets one more resident wave per SIMD without it)
+size_t fit_lds_bytes(int kh, int ring_mode, bool with_lut) {
     size_t ring = 0;
     if (ring_mode == 1) ring = (size_t)kh * (2 * WAVE * sizeof(float4) + WAVE * sizeof(unsigned));
     if (ring_mode == 2) ring = (size_t)(kh / 2 + 1) * (WAVE * sizeof(float4) + WAVE * sizeof(unsigned));
-    return ring + 256 * sizeof(double);
+    return ring + (with_lut ? 256 * sizeof(double) : 0);
 }
 
 template <int MODEL, bool R2, int RW, bool DENSE, int RING>
 static hipError_t launch_one(const FitArgs& a, hipStream_t stream) {
-    const size_t lds = fit_lds_bytes(2 * a.rh + 1, RING);
+    const size_t lds = fit_lds_bytes(2 * a.rh + 1, RING, MODEL == 2);
     if (lds > 64 * 1024) {  // forced LDS ring on a tall kernel (testing): raise the 64 KiB dynamic-LDS default
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fit_apply_kernel<MODEL, R2, RW, DENSE, RING>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
