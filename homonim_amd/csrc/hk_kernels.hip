@@ -541,6 +541,11 @@ __global__ void __launch_bounds__(WAVE, HK_FIT_MIN_WAVES) fit_apply_kernel(const
         n_uniform_cols = use_lut && __all((int)(!out_lane || full));
     }
 
+    // RING 0 / 2: the re-loaded leaving row runs one iteration ahead where the registers allow it (not in the general
+    // gain-offset kernels, which would spill)
+    constexpr bool PF_OLD = !ring && (DENSE || MODEL != 2);
+    [[maybe_unused]] RowRaw qo_next;
+    if constexpr (PF_OLD) qo_next = load_row(sp, rp, a.stride, t_first - kh, H, xq);
     unsigned nfail = 0;
     [[maybe_unused]] int cert_skip = 0;  // wave-uniform: rows for which the r2-mask certificate is not attempted
     int slot = 0;
@@ -553,7 +558,13 @@ __global__ void __launch_bounds__(WAVE, HK_FIT_MIN_WAVES) fit_apply_kernel(const
         // (the leaving row t - kh is a zero row if it was never added; the centre row is t - rh)
         RowRaw qo, qc;
         const int t_old = t - kh, y_c = t - rh;
-        if constexpr (!ring) qo = load_row(sp, rp, a.stride, t_old, H, xq);
+        if constexpr (PF_OLD) {
+            // the leaving row is fetched one iteration ahead (it comes from L2 / the Infinity Cache): qo_next holds row t_old
+            qo = qo_next;
+            qo_next = load_row(sp, rp, a.stride, t_old + 1, H, xq);
+        } else if constexpr (!ring) {
+            qo = load_row(sp, rp, a.stride, t_old, H, xq);
+        }
         if constexpr (RING == 0) qc = load_row(sp, rp, a.stride, y_c, H, xq);
 
         const RowZ znew = process_row<MODEL, DENSE>(q0, t >= 0 && t < H, colbits, full_wave, ts, tr, n0, n1);
