@@ -268,10 +268,10 @@ __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elemen
 __device__ __forceinline__ RowRaw load_row(const float* __restrict__ sp, const float* __restrict__ rp, long long stride,
                                            int row, int height, unsigned xq) {
     const int rc = min(max(row, 0), height - 1);
-    const float* __restrict__ ps = sp + (long long)rc * stride;
-    const float* __restrict__ pr = rp + (long long)rc * stride;
+    const char* __restrict__ ps = reinterpret_cast<const char*>(sp + (long long)rc * stride);
+    const char* __restrict__ pr = reinterpret_cast<const char*>(rp + (long long)rc * stride);
     RowRaw o;
-    o.s = *reinterpret_cast<const float4*>(ps + xq);
+    o.s = *reinterpret_cast<const float4*>(ps + xq);  // xq: this lane's byte offset in the row (32-bit)
     o.r = *reinterpret_cast<const float4*>(pr + xq);
     return o;
 }
@@ -450,7 +450,8 @@ __global__ void __launch_bounds__(WAVE, HK_FIT_MIN_WAVES) fit_apply_kernel(const
     const long long out_base = (long long)band * a.band_stride;
 
     const bool lane_in = x >= 0 && x < W;
-    const unsigned xq = lane_in ? (unsigned)x : 0u;                    // load offset: a safe quad for lanes outside
+    const unsigned xq = lane_in ? (unsigned)x * 4u : 0u;               // load byte offset: a safe quad for lanes outside
+    const unsigned xbytes = (unsigned)(x > 0 ? x : 0) * 4u;            // store byte offset (only lanes inside ever store)
     const bool full_wave = __all((int)(x >= 0 && x + PX <= W));        // no column of this strip needs zeroing
     const NodataTest ts = make_nodata_test(a.src_nd_mode, a.src_nodata);
     const NodataTest tr = make_nodata_test(a.ref_nd_mode, a.ref_nodata);
@@ -854,11 +855,13 @@ __global__ void __launch_bounds__(WAVE, HK_FIT_MIN_WAVES) fit_apply_kernel(const
 
                 if (out_lane) {
                     // stride % 4 == 0: a quad never crosses the row end, columns >= W land in the row padding
-                    const long long off = out_base + (long long)y * a.stride + x;
-                    if (a.corr) *reinterpret_cast<float4*>(a.corr + off) = make_float4(c[0], c[1], c[2], c[3]);
-                    if (a.gain) *reinterpret_cast<float4*>(a.gain + off) = masked4(g);
-                    if (a.offset) *reinterpret_cast<float4*>(a.offset + off) = masked4(o);
-                    if (R2 && a.r2) *reinterpret_cast<float4*>(a.r2 + off) = masked4(r2v);
+                    // wave-uniform row offset (scalar) + this lane's 32-bit byte offset: no per-plane address registers
+                    const long long row_off = out_base + (long long)y * a.stride;
+                    auto at = [&](float* plane) { return reinterpret_cast<float4*>(reinterpret_cast<char*>(plane + row_off) + xbytes); };
+                    if (a.corr) *at(a.corr) = make_float4(c[0], c[1], c[2], c[3]);
+                    if (a.gain) *at(a.gain) = masked4(g);
+                    if (a.offset) *at(a.offset) = masked4(o);
+                    if (R2 && a.r2) *at(a.r2) = masked4(r2v);
                 }
             };
             if constexpr (GO) {
