@@ -405,6 +405,9 @@ struct ColSums {
 #ifndef HK_CERT_SKIP
 #define HK_CERT_SKIP 3  // rows for which the r2-mask certificate is not attempted after it failed (measured)
 #endif
+#ifndef HK_FIT_MIN_WAVES_WIDE
+#define HK_FIT_MIN_WAVES_WIDE 2  // the general gain-offset + R2 kernels of width >= 9 spill at 3 waves per SIMD
+#endif
 #ifndef HK_FIT_MIN_WAVES
 #define HK_FIT_MIN_WAVES 3  // waves per SIMD the register allocator must leave room for (tuned on MI355X)
 #endif
@@ -415,7 +418,8 @@ struct ColSums {
 //      three streams that all miss L2 and the kernel fabric-bound;
 //   0  both re-loaded (very tall kernels whose centre ring would not fit either).
 template <int MODEL, bool R2, int RW, bool DENSE, int RING>
-__global__ void __launch_bounds__(WAVE, HK_FIT_MIN_WAVES) fit_apply_kernel(const FitArgs a) {
+__global__ void __launch_bounds__(WAVE, (MODEL == 2 && R2 && !DENSE && (RW < 0 || RW >= 4)) ? HK_FIT_MIN_WAVES_WIDE : HK_FIT_MIN_WAVES)
+fit_apply_kernel(const FitArgs a) {
     using CS = ColSums<MODEL, R2, DENSE>;
     constexpr bool GO = MODEL == 2, BLK = MODEL == 1;
     constexpr bool USE_N = GO || R2;
