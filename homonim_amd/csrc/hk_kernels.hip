@@ -510,11 +510,18 @@ fit_apply_kernel(const FitArgs a) {
     const int t_first = y0 - rh, t_last = y1 - 1 + rh;
     // One row in flight: the next row's load is issued as soon as the current one has been consumed, so it lands in the
     // same registers (no queue rotation).  A two-row queue was measured equal or slower (8 more VGPRs + 8 moves per row).
-    // The light `gain` kernel without R2 is HBM-bound and keeps a second row in flight (measured: 2.85 vs 3.02 ms).
-    constexpr bool PF2 = MODEL == 0 && !R2;
+    // The light `gain` kernel without R2 is HBM-bound (VALU 37 % busy, ~3 waves per SIMD because of the LDS ring): it keeps
+    // HK_PF_GAIN rows in flight in a small register queue (moves are free there).
+#ifndef HK_PF_GAIN
+#define HK_PF_GAIN 2  // 4 and 6 rows measured the same (2.91-2.97 ms): the wait is on the LDS ring, not on HBM latency
+#endif
+    constexpr int PFD = (MODEL == 0 && !R2) ? HK_PF_GAIN : 1;
     RowRaw q0 = load_row(sp, rp, a.stride, t_first, H, xq);
-    [[maybe_unused]] RowRaw q1;
-    if constexpr (PF2) q1 = load_row(sp, rp, a.stride, min(t_first + 1, t_last), H, xq);
+    [[maybe_unused]] RowRaw qq[PFD > 1 ? PFD - 1 : 1];
+    if constexpr (PFD > 1) {
+#pragma unroll
+        for (int d = 1; d < PFD; ++d) qq[d - 1] = load_row(sp, rp, a.stride, min(t_first + d, t_last), H, xq);
+    }
 
     // r2-mask bookkeeping (gain-offset with a threshold, kernel_model.py:363): R2 values are only materialised when
     // asked for; otherwise pixels are first put through a division-free CERTIFIED test
@@ -573,14 +580,16 @@ fit_apply_kernel(const FitArgs a) {
         if constexpr (RING == 0) qc = load_row(sp, rp, a.stride, y_c, H, xq);
 
         const RowZ znew = process_row<MODEL, DENSE>(q0, t >= 0 && t < H, colbits, full_wave, ts, tr, n0, n1);
-        if constexpr (PF2) {
-            q0 = q1;
-            q1 = load_row(sp, rp, a.stride, min(t + 2, t_last), H, xq);
+        if constexpr (PFD > 1) {
+            q0 = qq[0];
+#pragma unroll
+            for (int d = 1; d < PFD - 1; ++d) qq[d - 1] = qq[d];
+            qq[PFD - 2] = load_row(sp, rp, a.stride, min(t + PFD, t_last), H, xq);
         } else {
             q0 = load_row(sp, rp, a.stride, min(t + 1, t_last), H, xq);  // next row (see above)
+        }
         if constexpr (GO && !DENSE) {
             if (!znew.clean) last_dirty = t;  // wave-uniform
-        }
         }
         RowZ zold;
         if constexpr (ring) {
