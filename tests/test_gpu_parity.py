@@ -570,6 +570,38 @@ def test_lds_ring_and_reload_modes_agree(ctx, model, kernel_shape, find_r2, thre
     assert_close_ulp(out['0'][0], exp, 'params')
 
 
+@pytest.mark.parametrize('model, kernel_shape, thresh, nodata', [
+    ('gain-offset', (5, 5), 0.25, None), ('gain-offset', (5, 5), 0.25, np.nan), ('gain-offset', (9, 9), 0.25, None),
+    ('gain', (3, 3), None, np.nan), ('gain-blk-offset', (5, 7), None, np.nan),
+])
+def test_two_segment_sizes_equal_one_size(ctx, model, kernel_shape, thresh, nodata, monkeypatch):
+    """ Large rasters are cut into long row segments followed by short ones (hk_api.hip fill_grid).  Forcing that
+    policy onto a small raster (HK_WAVE_SLOTS: pretend the device holds few waves) must give the bytes of the one-size
+    partition wherever the float64 window sums are exact, and the oracle's values. """
+    import warnings
+    src, ref = onp.synth_pair(700, 530, seed=5, nodata_variant='frame+holes' if nodata is not None else 'none')
+    src, ref = np.round(src * 4096) / 4096, np.round(ref * 4096) / 4096   # 12-bit values: every window sum is exact
+    src, ref = src.astype(np.float32), ref.astype(np.float32)
+    cfg = dict(model=model, kernel_shape=kernel_shape, find_r2=False, r2_inpaint_thresh=thresh, src_nodata=nodata,
+               ref_nodata=nodata)
+    norm_in = onp.fit_block_norm(src, nodata, ref, nodata) if model == 'gain-blk-offset' else None
+    one = _fit_via_abi(ctx, cfg, src, ref, norm_in=norm_in)
+    for big, tail in (('96', '16'), ('200', '8')):
+        monkeypatch.setenv('HK_WAVE_SLOTS', '4')
+        monkeypatch.setenv('HK_SEG_BIG', big)
+        monkeypatch.setenv('HK_SEG_TAIL', tail)
+        two = _fit_via_abi(ctx, cfg, src, ref, norm_in=norm_in)
+        for k in ('HK_WAVE_SLOTS', 'HK_SEG_BIG', 'HK_SEG_TAIL'):
+            monkeypatch.delenv(k)
+        assert_same_f32(one[0], two[0], f'params, segments {big}/{tail}')
+        assert_same_f32(one[1], two[1], f'corrected, segments {big}/{tail}')
+        assert one[3] == two[3]
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        exp, _ = onp.fit(model, src, nodata, ref, nodata, kernel_shape, False, thresh, norm_model=norm_in)
+    assert_close_ulp(one[0], exp, 'params')
+
+
 # -- typed rasters either side of the path (raster_array.py:178-188 read, :353-387 write) -------------------------------
 @pytest.mark.parametrize('dtype', ['uint8', 'uint16', 'int16', 'int32', 'uint32', 'float64'])
 def test_integer_inputs_equal_float32_inputs(ctx, dtype):
