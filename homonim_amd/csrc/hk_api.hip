@@ -6,6 +6,7 @@
 // thread-local error string; any number of host threads may use one context (homonim/fuse.py:396-401).
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cfloat>
 #include <cmath>
 #include <condition_variable>
@@ -61,6 +62,9 @@ struct hk_ctx {
     std::mutex mu;
     std::condition_variable cv;
     int xcd_remap = 0;
+    // the last gain-offset call with a threshold found pixels failing the r2 mask: real imagery usually does, block after
+    // block, so the next call materialises the parameters in its first pass instead of re-running it for the in-painting
+    std::atomic<int> expect_r2_failures{0};
 };
 
 struct hk_event {
@@ -231,13 +235,26 @@ void fill_grid(hk::FitArgs& a, int seg_rows) {
 // kernel_model.py:364-371 for ONE band whose first pass counted failing pixels: in-paint the offsets of the failing
 // pixels from the passing ones (restated GDALFillNodata) and run the fit again with `offset_in`, which recomputes their
 // gains and re-applies.  `a` is the first pass's argument block (n_bands == 1).
-static int inpaint_band(Slot& sl, const hk::FitArgs& a, const hk_fit_desc* desc, bool r2, size_t plane) {
-    const size_t need = 4 * plane + hk::inpaint_workspace_bytes(a.height, a.stride);
+// scratch of the in-painting branch: [filled | gain | offset | r2 | column tables]
+static int ensure_inpaint_scratch(Slot& sl, size_t plane, int height, long long stride) {
+    const size_t need = 4 * plane + hk::inpaint_workspace_bytes(height, stride);
     if (sl.aux_bytes < need) {
-        if (sl.aux) HK_HIP(hipFree(sl.aux));
+        if (sl.aux) {
+            HK_HIP(hipStreamSynchronize(sl.stream));
+            HK_HIP(hipFree(sl.aux));
+        }
         sl.aux = nullptr, sl.aux_bytes = 0;
         if (hipMalloc(&sl.aux, need) != hipSuccess) return fail(HK_ERR_NOMEM, "hipMalloc(%zu) failed", need);
         sl.aux_bytes = need;
+    }
+    return HK_OK;
+}
+
+static int inpaint_band(Slot& sl, const hk::FitArgs& a, const hk_fit_desc* desc, bool r2, size_t plane,
+                        bool params_are_scratch = false) {
+    {
+        const int rc = ensure_inpaint_scratch(sl, plane, a.height, a.stride);
+        if (rc) return rc;
     }
     char* aux = static_cast<char*>(sl.aux);
     float* filled = reinterpret_cast<float*>(aux);
@@ -254,6 +271,7 @@ static int inpaint_band(Slot& sl, const hk::FitArgs& a, const hk_fit_desc* desc,
     hk::FitArgs c = a;
     c.offset_in = filled;
     c.fail_count = nullptr;  // already counted
+    if (params_are_scratch) c.gain = c.offset = c.r2 = nullptr;  // nobody reads them after this
     HK_HIP(hk::launch_fit_apply(c, desc->model, r2, sl.stream));
     return HK_OK;
 }
@@ -288,6 +306,16 @@ int fit_on_device(hk_ctx* ctx, Slot& sl, const hk_fit_desc* desc, const double* 
     a.height = height, a.width = width, a.stride = stride, a.band_stride = 0, a.n_bands = 1;
     fill_args(a, desc, ctx->xcd_remap);
     fill_grid(a, 0);
+    bool scratch_params = false;
+    if (a.has_thresh && !d_gain && !d_off && !d_r2 && ctx->expect_r2_failures.load()) {
+        // parameters into the slot's scratch planes right away (layout of inpaint_band): no second "first pass"
+        int rc = ensure_inpaint_scratch(sl, plane, height, stride);
+        if (rc) return rc;
+        char* aux = static_cast<char*>(sl.aux);
+        a.gain = reinterpret_cast<float*>(aux + plane), a.offset = reinterpret_cast<float*>(aux + 2 * plane);
+        a.r2 = reinterpret_cast<float*>(aux + 3 * plane);
+        scratch_params = true;
+    }
     HK_HIP(hk::launch_fit_apply(a, desc->model, r2, sl.stream));
 
     if (a.has_thresh) {
@@ -296,8 +324,9 @@ int fit_on_device(hk_ctx* ctx, Slot& sl, const hk_fit_desc* desc, const double* 
         unsigned long long n_fail = 0;
         HK_HIP(hipMemcpyAsync(&n_fail, d_fail, sizeof(n_fail), hipMemcpyDeviceToHost, sl.stream));
         HK_HIP(hipStreamSynchronize(sl.stream));
+        ctx->expect_r2_failures.store(n_fail > 0 ? 1 : 0);
         if (n_fail > 0) {
-            const int rc = inpaint_band(sl, a, desc, r2, plane);
+            const int rc = inpaint_band(sl, a, desc, r2, plane, scratch_params);
             if (rc) return rc;
         }
     }

@@ -94,16 +94,41 @@ __global__ void __launch_bounds__(256) inpaint_fill_kernel(const float* __restri
     if (!srcpx) {
         double qd[4], qv[4] = {0.0, 0.0, 0.0, 0.0};
         for (int q = 0; q < 4; ++q) qd[q] = (double)max_dist + 1.0;
+        // Steps are taken in groups that end where GDAL re-derives its search bound (after steps 4, 8, 12, ...): the
+        // bound is constant inside a group, so all of the group's table look-ups (8 per step) are issued before the
+        // checks, which then run in the original order (ascending step; left quadrants before right ones).
         int this_max = max_dist;
-        for (int step = 0; step <= this_max; ++step) {
-            const int lx = max(0, x - step), rx = min(width - 1, x + step);
-            quad_check(qd[0], qv[0], lx, top_y[row + lx], x, y, top_v[row + lx]);  // top left (own column, own row incl.)
-            quad_check(qd[1], qv[1], lx, bot_y[row + lx], x, y, bot_v[row + lx]);  // bottom left
-            if (step == 0) continue;
-            quad_check(qd[2], qv[2], rx, top_y[row + rx], x, y, top_v[row + rx]);  // top right
-            quad_check(qd[3], qv[3], rx, bot_y[row + rx], x, y, bot_v[row + rx]);  // bottom right
-            if ((step & 3) == 0)  // no farther column can beat every quadrant's current distance
-                this_max = (int)floor(fmax(fmax(qd[0], qd[1]), fmax(qd[2], qd[3])));
+        int first = 0;
+        while (first <= this_max) {
+            const int last = min(this_max, first == 0 ? 4 : first + 3);
+            constexpr int G = 5;  // longest group (steps 0..4)
+            int ly[G][2], ry[G][2];
+            float lv[G][2], rv[G][2];
+#pragma unroll
+            for (int k = 0; k < G; ++k) {
+                const int step = first + k;
+                if (step <= last) {
+                    const long long li = row + max(0, x - step), ri = row + min(width - 1, x + step);
+                    ly[k][0] = top_y[li], lv[k][0] = top_v[li], ly[k][1] = bot_y[li], lv[k][1] = bot_v[li];
+                    ry[k][0] = top_y[ri], rv[k][0] = top_v[ri], ry[k][1] = bot_y[ri], rv[k][1] = bot_v[ri];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < G; ++k) {
+                const int step = first + k;
+                if (step <= last) {
+                    const int lx = max(0, x - step), rx = min(width - 1, x + step);
+                    quad_check(qd[0], qv[0], lx, ly[k][0], x, y, lv[k][0]);  // top left (own column, own row incl.)
+                    quad_check(qd[1], qv[1], lx, ly[k][1], x, y, lv[k][1]);  // bottom left
+                    if (step != 0) {
+                        quad_check(qd[2], qv[2], rx, ry[k][0], x, y, rv[k][0]);  // top right
+                        quad_check(qd[3], qv[3], rx, ry[k][1], x, y, rv[k][1]);  // bottom right
+                    }
+                }
+            }
+            // no farther column can beat every quadrant's current distance
+            if (last >= 4 && (last & 3) == 0) this_max = (int)floor(fmax(fmax(qd[0], qd[1]), fmax(qd[2], qd[3])));
+            first = last + 1;
         }
         double wsum = 0.0, vsum = 0.0;
         bool has = false;
