@@ -4,7 +4,7 @@
 // smoothing_iterations = 0).  GDAL is not part of /root/reference (rasterio>=1.1, un-pinned) and not installed here,
 // so its published algorithm (gdal/alg/rasterfill.cpp) is RESTATED -- parity with GDAL itself is unpinned:
 //   * two column scans give, for every pixel, the nearest source pixel (mask != 0) at-or-above it and strictly below
-//     it in its own column, carried at most `max_dist` rows;
+//     it in its own column, carried at most `max_dist` rows (kept here as uint16 row distances);
 //   * a target pixel (mask == 0) steps left and right one column at a time (0..max_dist) and keeps, per quadrant
 //     (top-left and bottom-left include the pixel's own column, the right quadrants do not), the closest source found
 //     through those column tables -- strict `<` on the squared distance, so the first one met wins ties;
@@ -17,100 +17,120 @@
 namespace hk {
 
 constexpr int NONE_Y = 0x7fffffff;
+constexpr unsigned short NONE_D = 0xffff;
 
-// source = (r2 > thresh) & (gain > 0) & valid (kernel_model.py:363); valid <=> gain plane holds a parameter or NaN from
-// a degenerate window -- the validity itself travels as the non-NaN-ness of `valid_ref` (the corrected/gain planes are
-// NaN outside the mask by construction, but degenerate windows can be NaN inside it, so the mask is passed explicitly).
-// One thread per (column, chunk of SCAN_ROWS rows).  A source is only visible `max_dist` rows away, so a chunk's scan
-// starts `max_dist` rows before (top-down) / after (bottom-up) its first output row with an empty state and reproduces
-// the sequential scan exactly, while the grid has (height / SCAN_ROWS) times more threads than columns.
-constexpr int SCAN_ROWS = 128;
-__global__ void __launch_bounds__(256) inpaint_scan_kernel(const float* __restrict__ offset, const float* __restrict__ gain,
-                                                           const float* __restrict__ r2, float thresh, long long stride,
-                                                           int height, int width, int max_dist, int* __restrict__ top_y,
-                                                           float* __restrict__ top_v, int* __restrict__ bot_y,
-                                                           float* __restrict__ bot_v) {
+// source = (r2 > thresh) & (gain > 0) & valid (kernel_model.py:363): one byte per pixel.  NaN parameters (masked pixels,
+// degenerate windows) compare false.
+__global__ void __launch_bounds__(256) inpaint_flag_kernel(const float* __restrict__ gain, const float* __restrict__ r2,
+                                                           float thresh, long long stride, int height, int width,
+                                                           unsigned char* __restrict__ flag) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= width) return;
+    for (int y = blockIdx.y; y < height; y += gridDim.y) {
+        const long long i = (long long)y * stride + x;
+        flag[i] = ((r2[i] > thresh) && (gain[i] > 0.f)) ? 1 : 0;
+    }
+}
+
+// Column tables as DISTANCES (uint16): rows up to the nearest source at-or-above (0..max_dist) and down to the nearest
+// source strictly below (1..max_dist + 1), NONE_D when there is none in reach; the search reads the source's value from
+// the offset plane itself.  One thread per (column, chunk of SCAN_ROWS rows): a source is only visible `max_dist` rows
+// away, so a chunk's scan starts `max_dist` rows before (top-down) / after (bottom-up) its first output row with an
+// empty state and reproduces the sequential scan exactly.
+constexpr int SCAN_ROWS = 256;
+__global__ void __launch_bounds__(256) inpaint_scan_kernel(const unsigned char* __restrict__ flag, long long stride, int height,
+                                                           int width, int max_dist, unsigned short* __restrict__ top_d,
+                                                           unsigned short* __restrict__ bot_d) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= width) return;
     const int y0 = blockIdx.y * SCAN_ROWS, y1 = min(y0 + SCAN_ROWS, height);
     // top-down: nearest source at or above each row
     int last_y = NONE_Y;
-    float last_v = 0.f;
     for (int y = max(0, y0 - max_dist); y < y1; ++y) {
         const long long i = (long long)y * stride + x;
-        const bool srcpx = (r2[i] > thresh) && (gain[i] > 0.f);  // NaN parameters (masked pixels) compare false
-        if (srcpx) {
+        if (flag[i]) {
             last_y = y;
-            last_v = offset[i];
         } else if (last_y != NONE_Y && y > max_dist + last_y) {
             last_y = NONE_Y;
         }
-        if (y >= y0) {
-            top_y[i] = last_y;
-            top_v[i] = last_v;
-        }
+        if (y >= y0) top_d[i] = last_y == NONE_Y ? NONE_D : (unsigned short)(y - last_y);
     }
     // bottom-up: nearest source strictly below each row (the state left by the row underneath)
     last_y = NONE_Y;
-    last_v = 0.f;
-    for (int y = min(height - 1, y1 - 1 + max_dist + 1); y >= y0; --y) {
+    for (int y = min(height - 1, y1 + max_dist); y >= y0; --y) {
         const long long i = (long long)y * stride + x;
-        if (y < y1) {
-            bot_y[i] = last_y;
-            bot_v[i] = last_v;
-        }
-        const bool srcpx = (r2[i] > thresh) && (gain[i] > 0.f);
-        if (srcpx) {
+        if (y < y1) bot_d[i] = last_y == NONE_Y ? NONE_D : (unsigned short)(last_y - y);
+        if (flag[i]) {
             last_y = y;
-            last_v = offset[i];
         } else if (last_y != NONE_Y && last_y - y > max_dist) {
             last_y = NONE_Y;
         }
     }
 }
 
-__device__ __forceinline__ void quad_check(double& qd, double& qv, int tx, int ty, int ox, int oy, float tv) {
-    if (ty == NONE_Y) return;
-    const double dx = (double)tx - (double)ox, dy = (double)ty - (double)oy;
-    const double d2 = dx * dx + dy * dy;
-    if (d2 < qd * qd) {
-        qd = sqrt(d2);
-        qv = (double)tv;
+// GDAL's QUAD_CHECK compares the squared distance of a candidate with the ROUNDED square of the current distance,
+//     if (d2 < qd * qd) { qd = sqrt(d2); ... }          (float64; d2 is an exact integer < 2^15)
+// so a candidate at the SAME squared distance n replaces the current source exactly when fl(fl(sqrt(n))^2) > n.  That is a
+// property of n alone: tie_kernel tabulates it as a bitmap (TIE_N bits), and the search itself runs on integers -- no
+// sqrt and no float64 in the loop, same decisions.
+constexpr int TIE_N = 2 * 102 * 102;  // > the largest squared distance the search can meet (100^2 + 101^2)
+constexpr int WTAB_N = 100 * 100 + 1;  // weights 1 / qd of the accepted distances (qd <= max_dist = 100)
+__global__ void __launch_bounds__(256) tie_kernel(unsigned* __restrict__ tie, double* __restrict__ wtab) {
+    const int word = blockIdx.x * blockDim.x + threadIdx.x;
+    // the inverse-distance weights GDAL forms as 1.0 / qd with qd = sqrt(n): a table instead of a sqrt and a division
+    // per quadrant and target
+    for (int n = word; n < WTAB_N; n += gridDim.x * blockDim.x) wtab[n] = n ? 1.0 / sqrt((double)n) : 0.0;
+    if (word * 32 >= TIE_N) return;
+    unsigned bits = 0;
+    for (int b = 0; b < 32; ++b) {
+        const double n = (double)(word * 32 + b);
+        const double q = sqrt(n);
+        if (__dmul_rn(q, q) > n) bits |= 1u << b;
     }
+    tie[word] = bits;
 }
 
-__global__ void __launch_bounds__(256) inpaint_fill_kernel(const float* __restrict__ offset, const float* __restrict__ gain,
-                                                           const float* __restrict__ r2, float thresh, long long stride,
-                                                           int height, int width, int max_dist, const int* __restrict__ top_y,
-                                                           const float* __restrict__ top_v, const int* __restrict__ bot_y,
-                                                           const float* __restrict__ bot_v, float* __restrict__ filled) {
+__device__ __forceinline__ void quad_check(int& qd2, int& qx, int& qy, int tx, int ty, int ox, int oy,
+                                           const unsigned* __restrict__ tie) {
+    if (ty == NONE_Y) return;
+    const int dx = tx - ox, dy = ty - oy;
+    const int d2 = dx * dx + dy * dy;
+    bool better = d2 < qd2;
+    if (d2 == qd2) better = (tie[d2 >> 5] >> (d2 & 31)) & 1u;  // rare
+    if (better) qd2 = d2, qx = tx, qy = ty;
+}
+
+__global__ void __launch_bounds__(256) inpaint_fill_kernel(const float* __restrict__ offset, const unsigned char* __restrict__ flag,
+                                                           long long stride, int height, int width, int max_dist,
+                                                           const unsigned short* __restrict__ top_d,
+                                                           const unsigned short* __restrict__ bot_d,
+                                                           const unsigned* __restrict__ tie,
+                                                           const double* __restrict__ wtab, float* __restrict__ filled) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
     if (x >= width) return;
     const long long row = (long long)y * stride;
     const long long i = row + x;
     float out = offset[i];
-    const bool srcpx = (r2[i] > thresh) && (gain[i] > 0.f);
-    if (!srcpx) {
-        double qd[4], qv[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int q = 0; q < 4; ++q) qd[q] = (double)max_dist + 1.0;
+    if (!flag[i]) {
+        const int none2 = (max_dist + 1) * (max_dist + 1);  // qd = max_dist + 1: "nothing found yet" (a perfect square: no tie)
+        int qd2[4] = {none2, none2, none2, none2};
+        int qx[4] = {0, 0, 0, 0}, qy[4] = {0, 0, 0, 0};
         // Steps are taken in groups that end where GDAL re-derives its search bound (after steps 4, 8, 12, ...): the
-        // bound is constant inside a group, so all of the group's table look-ups (8 per step) are issued before the
+        // bound is constant inside a group, so all of the group's table look-ups (4 per step) are issued before the
         // checks, which then run in the original order (ascending step; left quadrants before right ones).
         int this_max = max_dist;
         int first = 0;
         while (first <= this_max) {
             const int last = min(this_max, first == 0 ? 4 : first + 3);
             constexpr int G = 5;  // longest group (steps 0..4)
-            int ly[G][2], ry[G][2];
-            float lv[G][2], rv[G][2];
+            unsigned short lt[G], lb[G], rt[G], rb[G];
 #pragma unroll
             for (int k = 0; k < G; ++k) {
                 const int step = first + k;
                 if (step <= last) {
                     const long long li = row + max(0, x - step), ri = row + min(width - 1, x + step);
-                    ly[k][0] = top_y[li], lv[k][0] = top_v[li], ly[k][1] = bot_y[li], lv[k][1] = bot_v[li];
-                    ry[k][0] = top_y[ri], rv[k][0] = top_v[ri], ry[k][1] = bot_y[ri], rv[k][1] = bot_v[ri];
+                    lt[k] = top_d[li], lb[k] = bot_d[li], rt[k] = top_d[ri], rb[k] = bot_d[ri];
                 }
             }
 #pragma unroll
@@ -118,26 +138,27 @@ __global__ void __launch_bounds__(256) inpaint_fill_kernel(const float* __restri
                 const int step = first + k;
                 if (step <= last) {
                     const int lx = max(0, x - step), rx = min(width - 1, x + step);
-                    quad_check(qd[0], qv[0], lx, ly[k][0], x, y, lv[k][0]);  // top left (own column, own row incl.)
-                    quad_check(qd[1], qv[1], lx, ly[k][1], x, y, lv[k][1]);  // bottom left
+                    quad_check(qd2[0], qx[0], qy[0], lx, lt[k] == NONE_D ? NONE_Y : y - (int)lt[k], x, y, tie);  // top left
+                    quad_check(qd2[1], qx[1], qy[1], lx, lb[k] == NONE_D ? NONE_Y : y + (int)lb[k], x, y, tie);  // bottom left
                     if (step != 0) {
-                        quad_check(qd[2], qv[2], rx, ry[k][0], x, y, rv[k][0]);  // top right
-                        quad_check(qd[3], qv[3], rx, ry[k][1], x, y, rv[k][1]);  // bottom right
+                        quad_check(qd2[2], qx[2], qy[2], rx, rt[k] == NONE_D ? NONE_Y : y - (int)rt[k], x, y, tie);  // top right
+                        quad_check(qd2[3], qx[3], qy[3], rx, rb[k] == NONE_D ? NONE_Y : y + (int)rb[k], x, y, tie);  // bottom right
                     }
                 }
             }
-            // no farther column can beat every quadrant's current distance
-            if (last >= 4 && (last & 3) == 0) this_max = (int)floor(fmax(fmax(qd[0], qd[1]), fmax(qd[2], qd[3])));
+            // no farther column can beat every quadrant's current distance: floor(max qd) = floor(sqrt(max qd2))
+            if (last >= 4 && (last & 3) == 0)
+                this_max = (int)floor(sqrt((double)max(max(qd2[0], qd2[1]), max(qd2[2], qd2[3]))));
             first = last + 1;
         }
         double wsum = 0.0, vsum = 0.0;
         bool has = false;
         for (int q = 0; q < 4; ++q) {
-            if (qd[q] <= (double)max_dist) {
-                const double w = 1.0 / qd[q];
+            if (qd2[q] <= max_dist * max_dist) {  // qd <= max_dist
+                const double w = wtab[qd2[q]];
                 has = w != 0.0;
                 wsum += w;
-                vsum += qv[q] * w;
+                vsum += (double)offset[(long long)qy[q] * stride + qx[q]] * w;
             }
         }
         if (has) out = (float)(vsum / wsum);
@@ -145,21 +166,25 @@ __global__ void __launch_bounds__(256) inpaint_fill_kernel(const float* __restri
     filled[i] = out;
 }
 
-size_t inpaint_workspace_bytes(int height, long long stride) { return (size_t)height * stride * 16; }
+// workspace: two uint16 distance tables + source flags (1 byte per pixel) + the tie bitmap + the weight table
+size_t inpaint_workspace_bytes(int height, long long stride) { return (size_t)height * stride * 5 + 1024 + TIE_N / 8 + 256 + WTAB_N * 8 + 256; }
 
 hipError_t launch_inpaint_offsets(const float* offset, const float* gain, const float* r2, float thresh, long long stride,
                                   int height, int width, void* workspace, float* filled, hipStream_t stream) {
     const size_t plane = (size_t)height * stride;
-    int* top_y = static_cast<int*>(workspace);
-    float* top_v = reinterpret_cast<float*>(top_y + plane);
-    int* bot_y = reinterpret_cast<int*>(top_v + plane);
-    float* bot_v = reinterpret_cast<float*>(bot_y + plane);
+    unsigned short* top_d = static_cast<unsigned short*>(workspace);
+    unsigned short* bot_d = top_d + plane;
+    unsigned char* flag = reinterpret_cast<unsigned char*>(bot_d + plane);
+    unsigned* tie = reinterpret_cast<unsigned*>(flag + (plane + 255) / 256 * 256);
+    double* wtab = reinterpret_cast<double*>(tie + (TIE_N / 32 + 64) / 64 * 64);
+    hipLaunchKernelGGL(tie_kernel, dim3((TIE_N / 32 + 255) / 256), dim3(256), 0, stream, tie, wtab);
     const int max_dist = 100;  // rasterio.fill.fillnodata default max_search_distance (kernel_model.py:366)
+    hipLaunchKernelGGL(inpaint_flag_kernel, dim3((width + 255) / 256, height < 1024 ? height : 1024), dim3(256), 0, stream,
+                       gain, r2, thresh, stride, height, width, flag);
     hipLaunchKernelGGL(inpaint_scan_kernel, dim3((width + 255) / 256, (height + SCAN_ROWS - 1) / SCAN_ROWS), dim3(256), 0,
-                       stream, offset, gain, r2, thresh,
-                       stride, height, width, max_dist, top_y, top_v, bot_y, bot_v);
-    hipLaunchKernelGGL(inpaint_fill_kernel, dim3((width + 255) / 256, height), dim3(256), 0, stream, offset, gain, r2,
-                       thresh, stride, height, width, max_dist, top_y, top_v, bot_y, bot_v, filled);
+                       stream, flag, stride, height, width, max_dist, top_d, bot_d);
+    hipLaunchKernelGGL(inpaint_fill_kernel, dim3((width + 255) / 256, height), dim3(256), 0, stream, offset, flag, stride,
+                       height, width, max_dist, top_d, bot_d, tie, wtab, filled);
     return hipGetLastError();
 }
 
