@@ -154,6 +154,14 @@ double r2_pass_scale(float thresh) {
     return boundary * (1.0 - 0x1p-40);
 }
 
+// The mirror image: for sstot > 0, `ssres > c_hi * sstot` PROVES the decision false (c_hi sits 2^-40 above the same
+// rounding boundary).  +inf = failure is never certified (degenerate thresholds): the division decides.
+double r2_fail_above(float thresh) {
+    const double c = r2_pass_scale(thresh);
+    if (!(c > 0.0)) return INFINITY;
+    return c / (1.0 - 0x1p-40) * (1.0 + 0x1p-40);
+}
+
 // kappa >= 1 - c' with c' = c * (1 - 2^-50) (so that `ssres < c' * sstot` in real arithmetic implies the float64
 // comparison against fl(c * sstot)), clamped to >= 0 and rounded up to float32.  +inf = nothing can be certified.
 float r2_fail_scale(float thresh) {
@@ -177,6 +185,8 @@ void fill_args(hk::FitArgs& a, const hk_fit_desc* d, int xcd_remap) {
     a.has_thresh = (d->model == HK_MODEL_GAIN_OFFSET) ? d->has_r2_thresh : 0;
     a.r2_thresh = d->r2_thresh;
     a.r2_fail_scale = a.has_thresh ? r2_fail_scale(d->r2_thresh) : INFINITY;
+    a.r2_pass_below = a.has_thresh ? r2_pass_scale(d->r2_thresh) : -INFINITY;
+    a.r2_fail_above = a.has_thresh ? r2_fail_above(d->r2_thresh) : INFINITY;
     a.n_full = (float)(d->kh * d->kw);
     a.nd_full = (double)(d->kh * d->kw);
     a.inv_n_full = 1.0 / (double)(d->kh * d->kw);

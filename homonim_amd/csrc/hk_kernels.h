@@ -35,6 +35,8 @@ struct FitArgs {
     int has_thresh;
     float r2_thresh;
     float r2_fail_scale;    // kappa of the division-free r2-mask certificate: 1 - r2_pass_scale(), rounded up (hk_api.hip)
+    double r2_pass_below;   // exact evaluation without R2 output: ssres < r2_pass_below * sstot proves the r2 test true,
+    double r2_fail_above;   // ssres > r2_fail_above * sstot proves it false (sstot > 0); in between the division decides
     float n_full;           // kh * kw: the window count of every pixel away from the raster's edges (dense kernels)
     double nd_full;         // the same as float64
     double inv_n_full;      // RN64(1 / (kh * kw)) -- the 1/N table entry (hk_kernels.hip)

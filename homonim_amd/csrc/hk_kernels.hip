@@ -825,13 +825,36 @@ fit_apply_kernel(const FitArgs a) {
                                 }
                                 ssres[i] = __dmul_rn(q, (double)Nf[i]);
                             }
+                            // Without an R2 plane to write only the DECISION r2 > thresh is needed: ssres against the two
+                            // bounds that bracket the float32 rounding boundary of the reference's quotient (hk_api.hip) settles
+                            // it without the division; a pixel in the 2^-39-wide gap, or with sstot <= 0 / NaN, sends the
+                            // wave-row through the division.
+                            bool r2_ok[PX];
+                            bool divide = !GO || a.r2 != nullptr;
+                            if constexpr (GO) {
+                                if (!divide) {
+                                    bool unsure = false;
+#pragma unroll
+                                    for (int i = 0; i < PX; ++i) {
+                                        const bool pos = sstot[i] > 0.0;
+                                        const bool yes = pos & (ssres[i] < __dmul_rn(a.r2_pass_below, sstot[i]));
+                                        const bool no = pos & (ssres[i] > __dmul_rn(a.r2_fail_above, sstot[i]));
+                                        r2_ok[i] = yes;
+                                        unsure |= out_lane & (bool)((mcu >> (8 * i)) & 1u) & !(yes | no);
+                                    }
+                                    divide = __any(unsure);
+                                }
+                            }
     #pragma unroll
                             for (int i = 0; i < PX; ++i) {
-                                r2v[i] = __fsub_rn(1.f, (float)__ddiv_rn(ssres[i], sstot[i]));
+                                if (divide) {
+                                    r2v[i] = __fsub_rn(1.f, (float)__ddiv_rn(ssres[i], sstot[i]));
+                                    r2_ok[i] = r2v[i] > a.r2_thresh;
+                                }
                                 if constexpr (GO) {
                                     const bool m = (mcu >> (8 * i)) & 1u;
                                     // valid pixels failing (r2 > thresh) & (gain > 0) need in-painting (:363,:370)
-                                    const bool failing = count_fails && m && !((r2v[i] > a.r2_thresh) && (g[i] > 0.f));
+                                    const bool failing = count_fails && m && !(r2_ok[i] && (g[i] > 0.f));
                                     if (failing && out_lane) ++nfail;
                                     if (failing && inpaint_pass && out_lane) {
                                         const float oin = a.offset_in[out_base + (long long)y * a.stride + x + i];
