@@ -701,7 +701,7 @@ fit_apply_kernel(const FitArgs a) {
                     // kernel_model.py:338-351; src2_sum is float64 (sqrBoxFilter) so m_den and the division are f64.
                     // float32 steps run two pixels per instruction (packed), float64 steps per pixel.
                     {
-    #pragma unroll
+#pragma unroll
                         for (int j = 0; j < PX / 2; ++j) {
                             const f2 Rf2 = HK_P2(Rf0, j), Sf2 = HK_P2(Sf0, j), Pf2 = HK_P2(Pf0, j);
                             const f2 Nf2 = UN ? f2{a.n_full, a.n_full} : HK_P2(Nf, j);
@@ -731,7 +731,7 @@ fit_apply_kernel(const FitArgs a) {
                         }
                     }
                 }
-    #pragma unroll
+#pragma unroll
                 for (int i = 0; i < PX; ++i) {
                     if constexpr (!GO) Rf[i] = (float)HR[i];  // boxFilter output depth = input depth (float32)
                     if constexpr (GO) {
@@ -766,7 +766,7 @@ fit_apply_kernel(const FitArgs a) {
                                 // so  g^2*den > kappa*sst + 2^-17*N*T  (kappa = 1 - r2_pass_scale, rounded up) proves
                                 // ssres_ref < r2_pass_scale * sstot_ref, which proves the reference's decision.
                                 bool uncertain = !cert_ok;
-    #pragma unroll
+#pragma unroll
                                 for (int j = 0; j < PX / 2; ++j) {
                                     const f2 g2 = HK_P2(g, j), o2 = HK_P2(o, j), Nf2 = HK_P2(Nf, j);
                                     const f2 Rf2 = HK_P2(Rf, j), Sf2 = HK_P2(Sf, j);
@@ -780,7 +780,7 @@ fit_apply_kernel(const FitArgs a) {
                                     const f2 denf = pk_fma(Nf2, S2f, -(Sf2 * Sf2));
                                     const f2 lhs = gg * denf;
                                     const f2 rhs = pk_fma(f2{a.r2_fail_scale, a.r2_fail_scale}, sst, slack);
-    #pragma unroll
+#pragma unroll
                                     for (int e = 0; e < 2; ++e) {
                                         const int i = 2 * j + e;
                                         const bool m = (mcu >> (8 * i)) & 1u;
@@ -798,7 +798,7 @@ fit_apply_kernel(const FitArgs a) {
                         }
                         if (exact) {
                             double sstot[PX], ssres[PX];
-    #pragma unroll
+#pragma unroll
                             for (int i = 0; i < PX; ++i) {
                                 sstot[i] = __dsub_rn(__dmul_rn((double)Nf[i], HR2[i]), (double)__fmul_rn(Rf[i], Rf[i]));
                                 double q;
@@ -845,7 +845,7 @@ fit_apply_kernel(const FitArgs a) {
                                     divide = __any(unsure);
                                 }
                             }
-    #pragma unroll
+#pragma unroll
                             for (int i = 0; i < PX; ++i) {
                                 if (divide) {
                                     r2v[i] = __fsub_rn(1.f, (float)__ddiv_rn(ssres[i], sstot[i]));
@@ -869,13 +869,13 @@ fit_apply_kernel(const FitArgs a) {
 
                 // ---- stage C: apply (:461) and where=mask (every parameter write goes into a NaN-filled array, :261,:345) ----
                 // A masked pixel has NaN parameters, hence a NaN corrected value: select once per stored plane.
-    #pragma unroll
+#pragma unroll
                 for (int j = 0; j < PX / 2; ++j) {
                     const f2 c2 = HK_P2(g, j) * HK_P2(sc, j) + HK_P2(o, j);  // two float32 roundings
                     c[2 * j] = c2.x, c[2 * j + 1] = c2.y;
                 }
                 if constexpr (!DENSE) {
-    #pragma unroll
+#pragma unroll
                     for (int i = 0; i < PX; ++i) c[i] = ((mcu >> (8 * i)) & 1u) ? c[i] : qnan();
                 }
                 auto masked4 = [&](const float (&v)[PX]) {
