@@ -157,6 +157,8 @@ struct RowTab {
     double w[4];
     int iy;       // first tap row - T0
     int centre;   // source row under the destination centre, or -1 when outside
+    int yy[4];    // tap rows clamped into the plane (always loadable)
+    int all_in;   // every tap row lies inside the plane
 };
 
 template <int MODE>
@@ -173,6 +175,13 @@ __global__ void __launch_bounds__(256) row_table_kernel(RowTab* __restrict__ tab
         t.w[0] = 1.0 - dy, t.w[1] = dy, t.w[2] = t.w[3] = 0.0;
     } else {
         bspline4(dy, t.w);
+    }
+    constexpr int NT = MODE == 1 ? 2 : 4, T0 = MODE == 1 ? 0 : -1;
+    t.all_in = 1;
+    for (int tj = 0; tj < 4; ++tj) {
+        const int yy = t.iy + T0 + (tj < NT ? tj : NT - 1);
+        if (yy < 0 || yy >= sh) t.all_in = 0;
+        t.yy[tj] = min(max(yy, 0), sh - 1);
     }
     tab[i] = t;
 }
@@ -213,12 +222,56 @@ __global__ void __launch_bounds__(256) upsample_apply_kernel(const UpApplyArgs a
     } else {
         bspline4(dx, wxs);
     }
-    for (int i = blockIdx.y; i < a.height; i += gridDim.y) {
+    // clamped tap columns (always loadable) for the straight-line path below
+    int xxc[NT];
+    bool col_all_in = true;
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti) {
+        const int xx = ix + T0 + ti;
+        col_all_in &= xx >= 0 && xx < a.pw;
+        xxc[ti] = min(max(xx, 0), a.pw - 1);
+    }
+    // consecutive destination rows per block: neighbouring rows read the same parameter rows (L1 / L2 reuse)
+    const int i_end = min(a.height, ((int)blockIdx.y + 1) * UP_ROWS);
+    for (int i = blockIdx.y * UP_ROWS; i < i_end; ++i) {
         const RowTab t = a.rows[i];  // wave-uniform
         const float s = a.src[(long long)i * a.src_stride + j];
         const bool on = a.keep ? a.keep[(long long)i * a.keep_stride + j] != 0.f : rs_valid(s, a.nd_mode, a.nodata);
         float par[2] = {nan, nan};
-        if (on && cx_ok && t.centre >= 0) {
+        const bool need = on && cx_ok && t.centre >= 0;
+        // Straight-line path (the interior of the raster): every tap of every lane that needs a value is inside the plane
+        // and not NaN -> all 2 x NT x NT loads go out together, no per-tap control flow, and the sums run over the same
+        // taps in the same order as below (the weight sum does not depend on the plane).  Otherwise: the general path.
+        float tg[NT][NT], to[NT][NT];
+        float chk = 0.f;
+#pragma unroll
+        for (int tj = 0; tj < NT; ++tj) {
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti) {
+                const int off = t.yy[tj] * (int)a.par_stride + xxc[ti];
+                tg[tj][ti] = a.gain[off], to[tj][ti] = a.offset[off];
+                chk += tg[tj][ti] + to[tj][ti];  // NaN anywhere (or inf - inf) makes chk NaN
+            }
+        }
+        const bool straight = !need || (t.all_in && col_all_in && chk == chk);
+        if (__all((int)straight)) {
+            double wgt[NT][NT], wacc = 0.0, accg = 0.0, acco = 0.0;
+#pragma unroll
+            for (int tj = 0; tj < NT; ++tj) {
+#pragma unroll
+                for (int ti = 0; ti < NT; ++ti) {
+                    wgt[tj][ti] = wxs[ti] * t.w[tj];
+                    accg += (double)tg[tj][ti] * wgt[tj][ti];
+                    acco += (double)to[tj][ti] * wgt[tj][ti];
+                    wacc += wgt[tj][ti];
+                }
+            }
+            if (need && !(wacc < 1e-6)) {
+                const bool renorm = wacc < 0.99999 || wacc > 1.00001;
+                par[0] = (float)(renorm ? accg / wacc : accg);
+                par[1] = (float)(renorm ? acco / wacc : acco);
+            }
+        } else if (need) {
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
                 const float* __restrict__ pp = b ? a.offset : a.gain;
@@ -254,6 +307,7 @@ hipError_t launch_upsample_apply(int mode, const float* src, long long src_strid
                                  const float* keep, long long keep_stride, float* out, long long out_stride, int height,
                                  int width, double kx, double ox, double ky, double oy, void* workspace, hipStream_t stream) {
     if (mode != 1 && mode != 3) return hipErrorInvalidValue;
+    if ((long long)ph * par_stride >= 0x7fffffffLL) return hipErrorInvalidValue;  // 32-bit tap offsets
     RowTab* tab = static_cast<RowTab*>(workspace);
     UpApplyArgs a;
     a.src = src, a.src_stride = src_stride, a.nd_mode = nd_mode, a.nodata = nodata, a.gain = gain, a.offset = offset;
