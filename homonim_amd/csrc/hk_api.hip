@@ -620,7 +620,8 @@ int hk_refspace_fit_apply(hk_ctx* ctx, const hk_fit_desc* desc, const hk_io_desc
     const size_t o_src = take(splane), o_ref = take(rplane), o_ds = take(rplane);
     const size_t o_gain = take(rplane), o_off = take(rplane), o_r2 = r2 ? take(rplane) : 0;
     // bilinear / cubic_spline parameters are up-sampled inside the apply kernel (no full-resolution parameter planes)
-    const bool fused_up = space->up_resampling == 1 || space->up_resampling == 3;
+    const bool fused_up = (space->up_resampling == 1 || space->up_resampling == 3) && ref_width >= 4 &&
+                          (long long)ref_height * rs < 0x7fffffffLL;
     const size_t o_gus = fused_up ? 0 : take(splane), o_ous = fused_up ? 0 : take(splane), o_corr = take(splane);
     const size_t o_rowtab = fused_up ? take(hk::upsample_apply_workspace_bytes(src_height)) : 0;
     const size_t o_vs = space->mask_partial ? take(splane) : 0, o_cov = space->mask_partial ? take(rplane) : 0;

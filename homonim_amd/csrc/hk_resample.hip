@@ -222,15 +222,9 @@ __global__ void __launch_bounds__(256) upsample_apply_kernel(const UpApplyArgs a
     } else {
         bspline4(dx, wxs);
     }
-    // clamped tap columns (always loadable) for the straight-line path below
-    int xxc[NT];
-    bool col_all_in = true;
-#pragma unroll
-    for (int ti = 0; ti < NT; ++ti) {
-        const int xx = ix + T0 + ti;
-        col_all_in &= xx >= 0 && xx < a.pw;
-        xxc[ti] = min(max(xx, 0), a.pw - 1);
-    }
+    // first tap column, clamped so that NT consecutive columns are always loadable (straight-line path below)
+    const bool col_all_in = ix + T0 >= 0 && ix + T0 + NT <= a.pw;
+    const int xbase = min(max(ix + T0, 0), max(a.pw - NT, 0));
     // consecutive destination rows per block: neighbouring rows read the same parameter rows (L1 / L2 reuse)
     const int i_end = min(a.height, ((int)blockIdx.y + 1) * UP_ROWS);
     for (int i = blockIdx.y * UP_ROWS; i < i_end; ++i) {
@@ -246,12 +240,21 @@ __global__ void __launch_bounds__(256) upsample_apply_kernel(const UpApplyArgs a
         float chk = 0.f;
 #pragma unroll
         for (int tj = 0; tj < NT; ++tj) {
-#pragma unroll
-            for (int ti = 0; ti < NT; ++ti) {
-                const int off = t.yy[tj] * (int)a.par_stride + xxc[ti];
-                tg[tj][ti] = a.gain[off], to[tj][ti] = a.offset[off];
-                chk += tg[tj][ti] + to[tj][ti];  // NaN anywhere (or inf - inf) makes chk NaN
+            // the NT taps of a row are consecutive columns when they are all inside (the only case that uses them):
+            // one (possibly unaligned) NT-float load per row and plane from a base clamped into the plane
+            const int off = t.yy[tj] * (int)a.par_stride + xbase;
+            if constexpr (NT == 4) {
+                const float4 vg = *reinterpret_cast<const float4*>(a.gain + off);
+                const float4 vo = *reinterpret_cast<const float4*>(a.offset + off);
+                tg[tj][0] = vg.x, tg[tj][1] = vg.y, tg[tj][2] = vg.z, tg[tj][3] = vg.w;
+                to[tj][0] = vo.x, to[tj][1] = vo.y, to[tj][2] = vo.z, to[tj][3] = vo.w;
+            } else {
+                const float2 vg = *reinterpret_cast<const float2*>(a.gain + off);
+                const float2 vo = *reinterpret_cast<const float2*>(a.offset + off);
+                tg[tj][0] = vg.x, tg[tj][1] = vg.y, to[tj][0] = vo.x, to[tj][1] = vo.y;
             }
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti) chk += tg[tj][ti] + to[tj][ti];  // NaN anywhere (or inf - inf) makes chk NaN
         }
         const bool straight = !need || (t.all_in && col_all_in && chk == chk);
         if (__all((int)straight)) {
@@ -266,11 +269,12 @@ __global__ void __launch_bounds__(256) upsample_apply_kernel(const UpApplyArgs a
                     wacc += wgt[tj][ti];
                 }
             }
-            if (need && !(wacc < 1e-6)) {
-                const bool renorm = wacc < 0.99999 || wacc > 1.00001;
-                par[0] = (float)(renorm ? accg / wacc : accg);
-                par[1] = (float)(renorm ? acco / wacc : acco);
+            const bool renorm = wacc < 0.99999 || wacc > 1.00001;
+            if (__any((int)(need && renorm))) {  // wave-uniform: interior weights sum to 1 within the tolerance
+                accg = renorm ? accg / wacc : accg;
+                acco = renorm ? acco / wacc : acco;
             }
+            if (need && !(wacc < 1e-6)) par[0] = (float)accg, par[1] = (float)acco;
         } else if (need) {
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
@@ -308,6 +312,7 @@ hipError_t launch_upsample_apply(int mode, const float* src, long long src_strid
                                  int width, double kx, double ox, double ky, double oy, void* workspace, hipStream_t stream) {
     if (mode != 1 && mode != 3) return hipErrorInvalidValue;
     if ((long long)ph * par_stride >= 0x7fffffffLL) return hipErrorInvalidValue;  // 32-bit tap offsets
+    if (pw < 4) return hipErrorInvalidValue;                                       // row loads of 4 consecutive taps
     RowTab* tab = static_cast<RowTab*>(workspace);
     UpApplyArgs a;
     a.src = src, a.src_stride = src_stride, a.nd_mode = nd_mode, a.nodata = nodata, a.gain = gain, a.offset = offset;
