@@ -254,13 +254,17 @@ __global__ void __launch_bounds__(WAVE) norm_stream_kernel(const NormArgs a, Nor
 // statistics + ranks + decision whether the compacted buffers bracket both ranks
 __global__ void norm_stats_kernel(NormWS* __restrict__ ws_all, double* __restrict__ norm_out, size_t mid_cap) {
     NormWS& ws = ws_all[blockIdx.x];
-    if (threadIdx.x != 0) return;
+    // one wave: every lane sums its stride-64 subset of the per-wave partials in index order, then a fixed butterfly --
+    // deterministic, and 64x shorter than one thread walking all PASS_WAVES entries
     unsigned long long n = 0, below[2] = {0, 0};
     double m1[2] = {0.0, 0.0}, m2[2] = {0.0, 0.0};
-    for (int i = 0; i < PASS_WAVES; ++i) {
+    for (int i = threadIdx.x; i < PASS_WAVES; i += WAVE) {
         n += ws.pn[i];
         for (int q = 0; q < 2; ++q) m1[q] += ws.p1[q][i], m2[q] += ws.p2[q][i], below[q] += ws.pbelow[q][i];
     }
+    n = wave_sum(n);
+    for (int q = 0; q < 2; ++q) m1[q] = wave_sum(m1[q]), m2[q] = wave_sum(m2[q]), below[q] = wave_sum(below[q]);
+    if (threadIdx.x != 0) return;
     ws.n = n;
     if (n == 0) {  // kernel_model.py:223-226
         norm_out[2 * blockIdx.x] = 0.0;
