@@ -166,33 +166,60 @@ def main():
     job.n_bands, job.height, job.width, job.stride, job.band_stride = B, H, W, stride, band_stride
     job.seg_rows, job.stream = args.seg_rows, 0
 
-    def step():
+    # Two sets of failure counters + pinned host copies: the r2-mask check of step i (the reference's `if not all(mask)`,
+    # kernel_model.py:363-371) reads counters that were copied to the host behind launch i, AFTER launch i + 1 has been
+    # queued -- the stream never drains between steps, and the in-painting passes (if a band has failures; none on the
+    # clean synthetic workload) are queued behind launch i + 1 and recompute their band from src / ref.
+    fail_dev = [bufs['fail'], ctx.dev_alloc(8 * B)]
+    bufs['fail2'] = fail_dev[1]
+    ctx.memset(fail_dev[1], 0, 8 * B)
+    fail_host = [ctx.pinned_empty((B,), np.uint64) for _ in range(2)]
+    fail_ready = [ctx.event(), ctx.event()]
+
+    def launch(i):
+        job.fail_count = fail_dev[i % 2]
         if args.model == 'gain-blk-offset':
             ctx.block_norm_dev(desc, job, bufs['norm'])  # the block statistics are part of the fit
         ctx.fit_apply_dev(desc, job)
 
-    def finish_step():
-        """ gain-offset with a threshold: the reference checks the r2 mask and in-paints (kernel_model.py:363-371);
-        here that is one read of the per-band failure counters (a stream sync) + the in-painting passes if any. """
-        return ctx.inpaint_dev(desc, job) if thresh is not None else 0
+    def queue_check(i):
+        if thresh is not None:
+            job.fail_count = fail_dev[i % 2]
+            ctx.fail_counts_async(job, fail_host[i % 2], fail_ready[i % 2])
+
+    def finish(i):
+        """ the host side of step i's r2-mask check; returns the number of failing pixels """
+        if thresh is None:
+            return 0
+        ctx.event_sync(fail_ready[i % 2])
+        counts = fail_host[i % 2].copy()
+        return ctx.inpaint_dev_counts(desc, job, counts) if counts.any() else 0
+
+    def run(n_steps, events=None):
+        n_fail = 0
+        for i in range(n_steps):
+            if events:
+                ctx.event_record(events[i][0], 0)
+            launch(i)
+            if events:
+                ctx.event_record(events[i][1], 0)
+            queue_check(i)
+            if i > 0:
+                n_fail += finish(i - 1)
+        if n_steps:
+            n_fail += finish(n_steps - 1)
+        return n_fail
 
     barrier = dist.barrier
 
-    for _ in range(args.warmup):
-        step()
-        finish_step()
+    run(args.warmup)
     ctx.stream_sync(0)
 
     events = [(ctx.event(), ctx.event()) for _ in range(args.steps)]
-    n_fail = 0
     barrier()
     ctx.sync()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        ctx.event_record(events[i][0], 0)
-        step()
-        ctx.event_record(events[i][1], 0)
-        n_fail += finish_step()
+    n_fail = run(args.steps, events)
     ctx.sync()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -242,10 +269,10 @@ def main():
         }
         print(json.dumps(out), flush=True)
 
-    for pair in events:
+    for pair in events + [tuple(fail_ready)]:
         for e in pair:
             ctx.event_destroy(e)
-    for name in ('src', 'ref', 'corr', 'fail', 'norm'):
+    for name in ('src', 'ref', 'corr', 'fail', 'fail2', 'norm'):
         ctx.dev_free(bufs[name])
     ctx.close()
     dist.finalize()

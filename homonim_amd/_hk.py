@@ -92,6 +92,9 @@ SIGNATURES = {
     'hk_memset': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t]),
     'hk_fit_apply_dev': (C.c_int, [C.c_void_p, _P(FitDesc), _P(DevJob)]),
     'hk_inpaint_dev': (C.c_int, [C.c_void_p, _P(FitDesc), _P(DevJob), _P(C.c_uint64)]),
+    'hk_fail_counts_async': (C.c_int, [C.c_void_p, _P(DevJob), _P(C.c_uint64), C.c_void_p]),
+    'hk_inpaint_dev_counts': (C.c_int, [C.c_void_p, _P(FitDesc), _P(DevJob), _P(C.c_uint64), _P(C.c_uint64)]),
+    'hk_event_sync': (C.c_int, [C.c_void_p, C.c_void_p]),
     'hk_block_norm_dev': (C.c_int, [C.c_void_p, _P(FitDesc), _P(DevJob), C.c_void_p]),
     'hk_synth_fill_dev': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64,
                                     C.c_int64, C.c_uint64, C.c_int32, C.c_int32]),
@@ -397,6 +400,23 @@ class Context:
 
     def fit_apply_dev(self, desc: FitDesc, job: DevJob):
         _check(self._lib.hk_fit_apply_dev(self._h, C.byref(desc), C.byref(job)))
+
+    def fail_counts_async(self, job: DevJob, host_counts: np.ndarray, ready_event: int):
+        """ Queue the copy of the job's failure counters into a PINNED uint64 array, their clearing and `ready_event`. """
+        assert host_counts.dtype == np.uint64 and host_counts.flags['C_CONTIGUOUS']
+        _check(self._lib.hk_fail_counts_async(self._h, C.byref(job), host_counts.ctypes.data_as(_P(C.c_uint64)),
+                                              C.c_void_p(ready_event)))
+
+    def event_sync(self, ev: int):
+        _check(self._lib.hk_event_sync(self._h, C.c_void_p(ev)))
+
+    def inpaint_dev_counts(self, desc: FitDesc, job: DevJob, counts: np.ndarray) -> int:
+        """ In-paint the bands whose count (host array, from fail_counts_async) is non-zero; only queues work. """
+        n = C.c_uint64(0)
+        counts = np.ascontiguousarray(counts, np.uint64)
+        _check(self._lib.hk_inpaint_dev_counts(self._h, C.byref(desc), C.byref(job), counts.ctypes.data_as(_P(C.c_uint64)),
+                                               C.byref(n)))
+        return int(n.value)
 
     def inpaint_dev(self, desc: FitDesc, job: DevJob) -> int:
         """ In-paint the bands of a device-resident job whose r2 mask has failures; returns the failure count. """

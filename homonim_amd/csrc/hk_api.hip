@@ -899,23 +899,38 @@ int hk_fit_apply_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* job
     return HK_OK;
 }
 
-int hk_inpaint_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* job, uint64_t* n_fail_out) {
+int hk_fail_counts_async(hk_ctx* ctx, const hk_dev_job* job, uint64_t* host_counts, hk_event* ready) {
+    int rc = check_job(ctx, job);
+    if (rc) return rc;
+    if (!job->fail_count || !host_counts || !ready) return fail(HK_ERR_ARG, "NULL argument");
+    HK_HIP(hipSetDevice(ctx->device));
+    Slot& sl = ctx->slots[job->stream];
+    const size_t bytes = (size_t)job->n_bands * sizeof(unsigned long long);
+    HK_HIP(hipMemcpyAsync(host_counts, job->fail_count, bytes, hipMemcpyDeviceToHost, sl.stream));
+    // the counters are consumed: the next hk_fit_apply_dev into this buffer starts from zero
+    HK_HIP(hipMemsetAsync(job->fail_count, 0, bytes, sl.stream));
+    HK_HIP(hipEventRecord(ready->ev, sl.stream));
+    return HK_OK;
+}
+
+int hk_event_sync(hk_ctx* ctx, hk_event* ev) {
+    if (!ctx || !ev) return fail(HK_ERR_ARG, "NULL argument");
+    HK_HIP(hipSetDevice(ctx->device));
+    HK_HIP(hipEventSynchronize(ev->ev));
+    return HK_OK;
+}
+
+int hk_inpaint_dev_counts(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* job, const uint64_t* counts,
+                          uint64_t* n_fail_out) {
     int rc = validate_desc(desc);
     if (rc) return rc;
     rc = check_job(ctx, job);
     if (rc) return rc;
     if (n_fail_out) *n_fail_out = 0;
     if (desc->model != HK_MODEL_GAIN_OFFSET || !desc->has_r2_thresh) return HK_OK;  // nothing to in-paint
-    if (!job->fail_count) return fail(HK_ERR_ARG, "job->fail_count is NULL");
-    if (job->n_bands > 1024) return fail(HK_ERR_ARG, "too many bands");
+    if (!counts) return fail(HK_ERR_ARG, "counts is NULL");
     HK_HIP(hipSetDevice(ctx->device));
     Slot& sl = ctx->slots[job->stream];
-    std::vector<unsigned long long> counts((size_t)job->n_bands);
-    HK_HIP(hipMemcpyAsync(counts.data(), job->fail_count, counts.size() * sizeof(unsigned long long),
-                          hipMemcpyDeviceToHost, sl.stream));
-    HK_HIP(hipStreamSynchronize(sl.stream));
-    // the counters are consumed: the next hk_fit_apply_dev of this job starts from zero
-    HK_HIP(hipMemsetAsync(job->fail_count, 0, counts.size() * sizeof(unsigned long long), sl.stream));
     const bool r2 = needs_r2(desc);
     const size_t plane = (size_t)job->stride * job->height * sizeof(float);
     unsigned long long total = 0;
@@ -937,6 +952,25 @@ int hk_inpaint_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* job, 
     }
     if (n_fail_out) *n_fail_out = total;
     return HK_OK;
+}
+
+int hk_inpaint_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* job, uint64_t* n_fail_out) {
+    int rc = validate_desc(desc);
+    if (rc) return rc;
+    rc = check_job(ctx, job);
+    if (rc) return rc;
+    if (n_fail_out) *n_fail_out = 0;
+    if (desc->model != HK_MODEL_GAIN_OFFSET || !desc->has_r2_thresh) return HK_OK;  // nothing to in-paint
+    if (!job->fail_count) return fail(HK_ERR_ARG, "job->fail_count is NULL");
+    if (job->n_bands > 1024) return fail(HK_ERR_ARG, "too many bands");
+    HK_HIP(hipSetDevice(ctx->device));
+    Slot& sl = ctx->slots[job->stream];
+    std::vector<uint64_t> counts((size_t)job->n_bands);
+    HK_HIP(hipMemcpyAsync(counts.data(), job->fail_count, counts.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, sl.stream));
+    HK_HIP(hipStreamSynchronize(sl.stream));
+    // the counters are consumed: the next hk_fit_apply_dev of this job starts from zero
+    HK_HIP(hipMemsetAsync(job->fail_count, 0, counts.size() * sizeof(uint64_t), sl.stream));
+    return hk_inpaint_dev_counts(ctx, desc, job, counts.data(), n_fail_out);
 }
 
 int hk_block_norm_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* job, double* norm_dev) {

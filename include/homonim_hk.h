@@ -30,6 +30,7 @@ extern "C" {
 #endif
 
 typedef struct hk_ctx hk_ctx;
+typedef struct hk_event hk_event;   /* a point in a context stream (hk_event_*, bottom of this header) */
 
 typedef enum {
     HK_OK = 0,
@@ -221,6 +222,13 @@ int hk_fit_apply_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* job
  * are then cleared (asynchronously), ready for the job's next hk_fit_apply_dev.  Returns after queueing the passes on
  * `job->stream`. */
 int hk_inpaint_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* job, uint64_t* n_fail_out);
+/* The same in two halves, for pipelines that must not drain the stream after every launch: hk_fail_counts_async queues the
+ * copy of the job's counters into `host_counts` (n_bands values, pinned host memory: hk_host_alloc), their clearing and
+ * the recording of `ready`; after hk_event_sync(ready) the caller passes the counts to hk_inpaint_dev_counts, which only
+ * queues work.  Launch N + 1 (into a second counter buffer) may be queued before the counts of launch N are looked at. */
+int hk_fail_counts_async(hk_ctx* ctx, const hk_dev_job* job, uint64_t* host_counts, hk_event* ready);
+int hk_inpaint_dev_counts(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* job, const uint64_t* counts,
+                          uint64_t* n_fail_out);
 /* Per-band block normalisation on device planes -> norm (device, n_bands x 2 float64); asynchronous. */
 int hk_block_norm_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* job, double* norm_dev);
 /* Fill device planes with the synthetic workload of SURVEY.md section 8(d) (src ~ U[0.05,1), ref = g*src+o+noise);
@@ -229,10 +237,10 @@ int hk_synth_fill_dev(hk_ctx* ctx, float* src, float* ref, int32_t n_bands, int3
                       int64_t stride, int64_t band_stride, uint64_t seed, int32_t nodata_variant, int32_t stream);
 
 /* HIP events on the pooled streams, so callers time exactly the stream the kernels run on. */
-typedef struct hk_event hk_event;
 int hk_event_create(hk_ctx* ctx, hk_event** ev);
 int hk_event_destroy(hk_ctx* ctx, hk_event* ev);
 int hk_event_record(hk_ctx* ctx, hk_event* ev, int32_t stream);
+int hk_event_sync(hk_ctx* ctx, hk_event* ev);  /* blocks the calling thread until the event has happened */
 int hk_event_elapsed_ms(hk_ctx* ctx, hk_event* start, hk_event* stop, float* ms); /* syncs on `stop` */
 int hk_stream_sync(hk_ctx* ctx, int32_t stream);
 

@@ -772,8 +772,8 @@ def test_r2_inpainting_vs_oracle(ctx, want_params):
     assert_close_ulp(corr, onp.apply(src, exp_params), 'corrected after in-painting', max_frac=1e-3)
 
 
-@pytest.mark.parametrize('with_params', [False, True])
-def test_device_resident_job_with_inpainting(ctx, oc, with_params):
+@pytest.mark.parametrize('with_params, split_api', [(False, False), (True, False), (False, True)])
+def test_device_resident_job_with_inpainting(ctx, oc, with_params, split_api):
     """ hk_fit_apply_dev + hk_inpaint_dev on a 3-band job resident in HBM: only the bands whose r2 mask has failures
     are in-painted; every band equals the oracle's whole reference branch. """
     h, w, nb = 96, 300, 3
@@ -806,7 +806,16 @@ def test_device_resident_job_with_inpainting(ctx, oc, with_params):
         ctx.stream_sync(0)
         counts = np.zeros(nb, np.uint64)
         ctx.d2h(counts, d['fail'])           # per-band counts of the first pass ...
-        n_fail = ctx.inpaint_dev(desc, job)  # ... which hk_inpaint_dev consumes and clears
+        if split_api:                        # ... consumed and cleared by hk_fail_counts_async + hk_inpaint_dev_counts
+            host_counts = ctx.pinned_empty((nb,), np.uint64)
+            ready = ctx.event()
+            ctx.fail_counts_async(job, host_counts, ready)
+            ctx.event_sync(ready)
+            assert (host_counts == counts).all()
+            n_fail = ctx.inpaint_dev_counts(desc, job, host_counts.copy())
+            ctx.event_destroy(ready)
+        else:                                # ... or by hk_inpaint_dev in one blocking call
+            n_fail = ctx.inpaint_dev(desc, job)
         ctx.stream_sync(0)
         cleared = np.ones(nb, np.uint64)
         ctx.d2h(cleared, d['fail'])
