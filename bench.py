@@ -31,8 +31,8 @@ ALGO_BYTES_PER_PX = 12   # read src 4 + read ref 4 + write corrected 4 (SURVEY.m
 def parse_args():
     p = argparse.ArgumentParser()
     p.add_argument('--gpus', type=int, default=1)
-    p.add_argument('--steps', type=int, default=20)
-    p.add_argument('--warmup', type=int, default=3)
+    p.add_argument('--steps', type=int, default=50)
+    p.add_argument('--warmup', type=int, default=5)
     p.add_argument('--size', type=int, default=16384, help='raster height = width')
     p.add_argument('--bands', type=int, default=4)
     p.add_argument('--model', default='gain-offset', choices=['gain', 'gain-blk-offset', 'gain-offset'])
