@@ -558,6 +558,12 @@ fit_apply_kernel(const FitArgs a) {
     constexpr bool PF_OLD = !ring && (DENSE || MODEL != 2);
     [[maybe_unused]] RowRaw qo_next;
     if constexpr (PF_OLD) qo_next = load_row(sp, rp, a.stride, t_first - kh, H, xq);
+    // RING 1: the first leaving row is the zero row the ring was initialised with
+    constexpr bool RING_AHEAD = ring && MODEL == 0 && !R2;
+    [[maybe_unused]] RowZ zold_next;
+#pragma unroll
+    for (int i = 0; i < PX; ++i) zold_next.s[i] = zold_next.r[i] = 0.f;
+    zold_next.m = 0u, zold_next.clean = false;
     unsigned nfail = 0;
     [[maybe_unused]] int cert_skip = 0;  // wave-uniform: rows for which the r2-mask certificate is not attempted
     int slot = 0;
@@ -593,15 +599,29 @@ fit_apply_kernel(const FitArgs a) {
         }
         RowZ zold;
         if constexpr (ring) {
-            // leaving row (t - kh): read from the slot the entering row is about to overwrite
-            const float4 os = ring_v[(slot * 2 + 0) * WAVE + lane];
-            const float4 orr = ring_v[(slot * 2 + 1) * WAVE + lane];
-            zold.s[0] = os.x, zold.s[1] = os.y, zold.s[2] = os.z, zold.s[3] = os.w;
-            zold.r[0] = orr.x, zold.r[1] = orr.y, zold.r[2] = orr.z, zold.r[3] = orr.w;
-            zold.m = DENSE ? 0u : ring_m[slot * WAVE + lane];
+            // leaving row (t - kh) = the slot the entering row overwrites.  The HBM-bound `gain` kernel fetches it from LDS
+            // one iteration ahead (its latency leaves the loop-carried path: 3.06 -> 2.99 ms); the VALU-bound kernels do
+            // not gain from that and keep the registers.
+            if constexpr (RING_AHEAD) {
+                zold = zold_next;
+            } else {
+                const float4 os = ring_v[(slot * 2 + 0) * WAVE + lane];
+                const float4 orr = ring_v[(slot * 2 + 1) * WAVE + lane];
+                zold.s[0] = os.x, zold.s[1] = os.y, zold.s[2] = os.z, zold.s[3] = os.w;
+                zold.r[0] = orr.x, zold.r[1] = orr.y, zold.r[2] = orr.z, zold.r[3] = orr.w;
+                zold.m = DENSE ? 0u : ring_m[slot * WAVE + lane];
+            }
             ring_v[(slot * 2 + 0) * WAVE + lane] = make_float4(znew.s[0], znew.s[1], znew.s[2], znew.s[3]);
             ring_v[(slot * 2 + 1) * WAVE + lane] = make_float4(znew.r[0], znew.r[1], znew.r[2], znew.r[3]);
             if constexpr (!DENSE) ring_m[slot * WAVE + lane] = znew.m;
+            if constexpr (RING_AHEAD) {  // the row that leaves at the NEXT iteration sits in the next slot (kh == 1: this one)
+                const int sn = slot + 1 == kh ? 0 : slot + 1;
+                const float4 os = ring_v[(sn * 2 + 0) * WAVE + lane];
+                const float4 orr = ring_v[(sn * 2 + 1) * WAVE + lane];
+                zold_next.s[0] = os.x, zold_next.s[1] = os.y, zold_next.s[2] = os.z, zold_next.s[3] = os.w;
+                zold_next.r[0] = orr.x, zold_next.r[1] = orr.y, zold_next.r[2] = orr.z, zold_next.r[3] = orr.w;
+                zold_next.m = DENSE ? 0u : ring_m[sn * WAVE + lane];
+            }
         } else {
             zold = process_row<MODEL, DENSE>(qo, t_old >= t_first && t_old >= 0 && t_old < H, colbits, full_wave, ts, tr, n0, n1);
             if constexpr (cring) {  // slot2 cycles over rh + 1 rows: the entering row replaces the centre row of rh + 1 ago
