@@ -3,7 +3,7 @@ End-to-end (PCIe-inclusive) throughput of the host-pointer path: BASELINE.json c
 4096 x 4096 band-tiles living in (pinned) host memory, one tile per call, T host threads sharing one context whose
 pooled streams overlap H2D / kernel / D2H of different tiles.  NOT the headline number (bench.py, HBM-resident).
 
-    python tools/bench_streamed.py [--tiles 64] [--bands 4] [--threads 8] [--streams 8] [--pageable]
+    python tools/bench_streamed.py [--tiles 64] [--bands 4] [--threads 4] [--streams 4] [--pageable]
 """
 import argparse
 import json
@@ -23,8 +23,8 @@ def main():
     p.add_argument('--tiles', type=int, default=64)
     p.add_argument('--bands', type=int, default=4)
     p.add_argument('--size', type=int, default=4096)
-    p.add_argument('--threads', type=int, default=8)
-    p.add_argument('--streams', type=int, default=8)
+    p.add_argument('--threads', type=int, default=4)
+    p.add_argument('--streams', type=int, default=4)
     p.add_argument('--distinct', type=int, default=8, help='distinct host tile buffers (re-used round-robin)')
     p.add_argument('--model', default='gain-offset')
     p.add_argument('--kernel', type=int, default=5)
