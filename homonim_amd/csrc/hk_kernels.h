@@ -48,7 +48,7 @@ struct FitArgs {
 // model: 0 gain, 1 gain-blk-offset, 2 gain-offset.  with_r2: compute the R2 quantity set.
 hipError_t launch_fit_apply(const FitArgs& a, int model, bool with_r2, hipStream_t stream);
 // LDS bytes one wave needs (row ring of kh rows when use_ring, plus the 1/N table).
-size_t fit_lds_bytes(int kh, int ring_mode, bool with_lut);
+size_t fit_lds_bytes(int kh, int ring_mode, bool with_lut, bool with_mask);
 // lanes per side that overlap with the neighbouring strip for kernel half-width rw
 inline int overlap_lanes_for(int rw) { return (rw + PX - 1) / PX; }
 

@@ -499,7 +499,7 @@ fit_apply_kernel(const FitArgs a) {
     // 1/N table for the offset division (kernel_model.py:351: float32 `t / mask_sum`).  For a float32 t and an integer
     // N < 2^8 the quotient t/N is never closer than 2^-33 (relative) to a float32 rounding midpoint, while
     // f64(t) * RN64(1/N) is within 2^-52 of it -- so rounding that product to float32 IS the IEEE float32 division.
-    double* inv_lut = reinterpret_cast<double*>(ring_m + (size_t)ring_rows * WAVE);
+    double* inv_lut = reinterpret_cast<double*>(ring_m + (DENSE ? (size_t)0 : (size_t)ring_rows * WAVE));  // dense: no mask ring
     const bool use_lut = GO && kh * (2 * rw + 1) <= 255;
     if (use_lut)
         for (int n = lane; n < 256; n += WAVE) inv_lut[n] = 1.0 / (double)n;
@@ -944,16 +944,17 @@ fit_apply_kernel(const FitArgs a) {
 
 // LDS bytes of one wave: the row ring of the mode (see fit_apply_kernel) + the 256-entry float64 1/N table that only the
 // gain-offset model reads (the HBM-bound `gain` kernel gets one more resident wave per SIMD without it)
-size_t fit_lds_bytes(int kh, int ring_mode, bool with_lut) {
+size_t fit_lds_bytes(int kh, int ring_mode, bool with_lut, bool with_mask) {
+    const size_t mask = with_mask ? WAVE * sizeof(unsigned) : 0;
     size_t ring = 0;
-    if (ring_mode == 1) ring = (size_t)kh * (2 * WAVE * sizeof(float4) + WAVE * sizeof(unsigned));
-    if (ring_mode == 2) ring = (size_t)(kh / 2 + 1) * (WAVE * sizeof(float4) + WAVE * sizeof(unsigned));
+    if (ring_mode == 1) ring = (size_t)kh * (2 * WAVE * sizeof(float4) + mask);
+    if (ring_mode == 2) ring = (size_t)(kh / 2 + 1) * (WAVE * sizeof(float4) + mask);
     return ring + (with_lut ? 256 * sizeof(double) : 0);
 }
 
 template <int MODEL, bool R2, int RW, bool DENSE, int RING>
 static hipError_t launch_one(const FitArgs& a, hipStream_t stream) {
-    const size_t lds = fit_lds_bytes(2 * a.rh + 1, RING, MODEL == 2);
+    const size_t lds = fit_lds_bytes(2 * a.rh + 1, RING, MODEL == 2, !DENSE);
     if (lds > 64 * 1024) {  // forced LDS ring on a tall kernel (testing): raise the 64 KiB dynamic-LDS default
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fit_apply_kernel<MODEL, R2, RW, DENSE, RING>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
