@@ -38,7 +38,7 @@ def parse_args():
     p.add_argument('--model', default='gain-offset', choices=['gain', 'gain-blk-offset', 'gain-offset'])
     p.add_argument('--kernel', type=int, default=5)
     p.add_argument('--seg-rows', type=int, default=0)
-    p.add_argument('--nodata', type=int, default=0, help='0: no nodata, 1: NaN frame + 0.1%% holes, 2: NaN frame only, 3: no nodata, noisy reference (r2 failures)')
+    p.add_argument('--nodata', type=int, default=0, help='0: no nodata, 1: NaN frame + 0.1%% holes, 2: NaN frame only, 3 / 4: no nodata, noisy reference (35 %% / 85 %% of the pixels fail the r2 mask)')
     p.add_argument('--no-thresh', action='store_true', help='gain-offset without r2_inpaint_thresh (no R2 work)')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-parity', action='store_true')

@@ -119,20 +119,25 @@ __global__ void __launch_bounds__(256) inpaint_fill_kernel(const float* __restri
         // Steps are taken in groups that end where GDAL re-derives its search bound (after steps 4, 8, 12, ...): the
         // bound is constant inside a group, so all of the group's table look-ups (4 per step) are issued before the
         // checks, which then run in the original order (ascending step; left quadrants before right ones).
-        int this_max = max_dist;
-        int first = 0;
-        while (first <= this_max) {
-            const int last = min(this_max, first == 0 ? 4 : first + 3);
-            constexpr int G = 5;  // longest group (steps 0..4)
-            unsigned short lt[G], lb[G], rt[G], rb[G];
+        // The look-ups of the NEXT group are issued before the checks of the current one (their latency hides behind the
+        // checks; a group that turns out not to be needed costs four cached loads per step and nothing else).
+        constexpr int G = 5;  // longest group (steps 0..4)
+        unsigned short lt[G], lb[G], rt[G], rb[G], nlt[G], nlb[G], nrt[G], nrb[G];
+        auto fetch = [&](int first_step, unsigned short (&a)[G], unsigned short (&b)[G], unsigned short (&c)[G],
+                         unsigned short (&d)[G]) {
 #pragma unroll
             for (int k = 0; k < G; ++k) {
-                const int step = first + k;
-                if (step <= last) {
-                    const long long li = row + max(0, x - step), ri = row + min(width - 1, x + step);
-                    lt[k] = top_d[li], lb[k] = bot_d[li], rt[k] = top_d[ri], rb[k] = bot_d[ri];
-                }
+                const int step = first_step + k;  // steps beyond the bound are clamped into the row and never checked
+                const long long li = row + max(0, x - step), ri = row + min(width - 1, x + step);
+                a[k] = top_d[li], b[k] = bot_d[li], c[k] = top_d[ri], d[k] = bot_d[ri];
             }
+        };
+        int this_max = max_dist;
+        int first = 0;
+        fetch(0, lt, lb, rt, rb);
+        while (first <= this_max) {
+            const int last = min(this_max, first == 0 ? 4 : first + 3);
+            fetch(last + 1, nlt, nlb, nrt, nrb);
 #pragma unroll
             for (int k = 0; k < G; ++k) {
                 const int step = first + k;
@@ -150,6 +155,8 @@ __global__ void __launch_bounds__(256) inpaint_fill_kernel(const float* __restri
             if (last >= 4 && (last & 3) == 0)
                 this_max = (int)floor(sqrt((double)max(max(qd2[0], qd2[1]), max(qd2[2], qd2[3]))));
             first = last + 1;
+#pragma unroll
+            for (int k = 0; k < G; ++k) lt[k] = nlt[k], lb[k] = nlb[k], rt[k] = nrt[k], rb[k] = nrb[k];
         }
         double wsum = 0.0, vsum = 0.0;
         bool has = false;

@@ -1075,7 +1075,8 @@ __global__ void __launch_bounds__(256) synth_kernel(float* __restrict__ src, flo
         const float z = sqrtf(-2.0f * __logf(u1)) * __cosf(6.2831853f * u2);
         const float g = 1.2f + 0.3f * __sinf((float)x / 97.f) * __cosf((float)y / 131.f);
         const float o = 0.05f * (1.f + 0.5f * __sinf((float)y / 211.f));
-        float r = g * s + o + (nodata_variant == 3 ? 0.5f : 0.01f) * z;  // 3: noisy reference, R2 around the threshold
+        // 3: noisy reference, R2 around the threshold (35 % of the pixels fail 0.25); 4: very noisy (85 % fail, like real pairs)
+        float r = g * s + o + (nodata_variant == 3 ? 0.5f : (nodata_variant == 4 ? 1.5f : 0.01f)) * z;
         float sv = s;
         if (nodata_variant == 1 || nodata_variant == 2) {  // 1: NaN frame + 0.1 % holes, 2: NaN frame only
             const bool frame = x < 3 || y < 3 || x >= width - 3 || y >= height - 3;
