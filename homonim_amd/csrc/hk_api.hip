@@ -174,18 +174,6 @@ float r2_fail_scale(float thresh) {
     return kf;
 }
 
-// kappa_f <= 1 - c_hi' with c_hi' = r2_fail_above * (1 + 2^-50), rounded DOWN to float32; needs to be positive to be of
-// any use (the certificate compares against kappa_f * sstot - slack).  -inf = failure is never certified.
-float r2_fail_cert(float thresh) {
-    const double c = r2_fail_above(thresh);
-    if (!(c < INFINITY)) return -INFINITY;
-    const double k = 1.0 - c * (1.0 + 0x1p-50);
-    if (!(k > 0.0)) return -INFINITY;
-    float kf = (float)k;
-    if ((double)kf > k - 0x1p-60) kf = nextafterf(kf, -INFINITY);
-    return kf > 0.f ? kf : -INFINITY;
-}
-
 void fill_args(hk::FitArgs& a, const hk_fit_desc* d, int xcd_remap) {
     a.rh = d->kh / 2;
     a.rw = d->kw / 2;
@@ -197,7 +185,6 @@ void fill_args(hk::FitArgs& a, const hk_fit_desc* d, int xcd_remap) {
     a.has_thresh = (d->model == HK_MODEL_GAIN_OFFSET) ? d->has_r2_thresh : 0;
     a.r2_thresh = d->r2_thresh;
     a.r2_fail_scale = a.has_thresh ? r2_fail_scale(d->r2_thresh) : INFINITY;
-    a.r2_fail_cert = a.has_thresh ? r2_fail_cert(d->r2_thresh) : -INFINITY;
     a.r2_pass_below = a.has_thresh ? r2_pass_scale(d->r2_thresh) : -INFINITY;
     a.r2_fail_above = a.has_thresh ? r2_fail_above(d->r2_thresh) : INFINITY;
     a.n_full = (float)(d->kh * d->kw);

@@ -34,7 +34,6 @@ struct FitArgs {
     float src_nodata, ref_nodata;
     int has_thresh;
     float r2_thresh;
-    float r2_fail_cert;     // kappa_f of the mirror certificate (decision certainly false): 1 - r2_fail_above, rounded down; -inf = never
     float r2_fail_scale;    // kappa of the division-free r2-mask certificate: 1 - r2_pass_scale(), rounded up (hk_api.hip)
     double r2_pass_below;   // exact evaluation without R2 output: ssres < r2_pass_below * sstot proves the r2 test true,
     double r2_fail_above;   // ssres > r2_fail_above * sstot proves it false (sstot > 0); in between the division decides

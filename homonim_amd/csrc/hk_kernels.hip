@@ -531,7 +531,7 @@ fit_apply_kernel(const FitArgs a) {
     // Second pass after in-painting (kernel_model.py:366-371): pixels failing the r2 mask take their offset from the
     // in-painted plane and get their gain recomputed as (ref_sum - mask_sum * offset) / src_sum (float32).
     const bool inpaint_pass = GO && R2 && a.offset_in != nullptr;
-    const bool want_r2_values = R2 && a.r2 != nullptr;
+    const bool want_r2_values = R2 && (a.r2 != nullptr || inpaint_pass);
     const bool count_fails = GO && R2 && a.has_thresh;
     const bool cert_ok = kh * (2 * rw + 1) <= 65535;  // window-count bound assumed by the certificate's constants
 
@@ -771,7 +771,6 @@ fit_apply_kernel(const FitArgs a) {
                 }
 
                 // ---- stage B: R2 (kernel_model.py:179,189-195|201,203,212-213) ---------------------------------------------
-                [[maybe_unused]] bool failing_px[PX] = {false, false, false, false};  // valid pixels failing the r2 mask
                 if constexpr (R2) {
                     if (want_r2_values || count_fails) {  // wave-uniform
                         bool exact = want_r2_values;
@@ -786,9 +785,6 @@ fit_apply_kernel(const FitArgs a) {
                                 //   ssres_ref <= sstot_ref - g^2*den + 35*2^-24*N*T   and   |sstot_ref - sst| <= 4.1*2^-24*N*T,
                                 // so  g^2*den > kappa*sst + 2^-17*N*T  (kappa = 1 - r2_pass_scale, rounded up) proves
                                 // ssres_ref < r2_pass_scale * sstot_ref, which proves the reference's decision.
-                                // The mirror image (kappa_f = 1 - r2_fail_above, rounded down):  g^2*den < kappa_f*sst - 2^-17*N*T
-                                // proves ssres_ref > r2_fail_above * sstot_ref, i.e. the decision is FALSE; so is it when the
-                                // gain is not positive.  Only pixels in the slack around the threshold stay undecided.
                                 bool uncertain = !cert_ok;
 #pragma unroll
                                 for (int j = 0; j < PX / 2; ++j) {
@@ -804,7 +800,6 @@ fit_apply_kernel(const FitArgs a) {
                                     const f2 denf = pk_fma(Nf2, S2f, -(Sf2 * Sf2));
                                     const f2 lhs = gg * denf;
                                     const f2 rhs = pk_fma(f2{a.r2_fail_scale, a.r2_fail_scale}, sst, slack);
-                                    const f2 rhs_f = pk_fma(f2{a.r2_fail_cert, a.r2_fail_cert}, sst, -slack);
 #pragma unroll
                                     for (int e = 0; e < 2; ++e) {
                                         const int i = 2 * j + e;
@@ -813,16 +808,12 @@ fit_apply_kernel(const FitArgs a) {
                                         // 2^-20 < g < 2^20 (also the `gain > 0` half of the decision), 2^-40 < N*T < 2^60
                                         const bool g_in = (__float_as_uint(g2[e]) - 0x35800000u) < (0x49800000u - 0x35800000u);
                                         const bool t_in = (__float_as_uint(NT[e]) - 0x2b800000u) < (0x5d800000u - 0x2b800000u);
-                                        const bool sane = (sst[e] > slack[e]) & g_in & t_in;
-                                        const bool sure_pass = (lhs[e] > rhs[e]) & sane;
-                                        const bool sure_fail = !(g2[e] > 0.f) | ((lhs[e] < rhs_f[e]) & sane);
-                                        failing_px[i] = m & !sure_pass;
-                                        uncertain |= out_lane & m & !(sure_pass | sure_fail);
+                                        const bool sure = (lhs[e] > rhs[e]) & (sst[e] > slack[e]) & g_in & t_in;
+                                        uncertain |= out_lane & m & !sure;
                                     }
                                 }
                                 exact = __any(uncertain);
-                                // undecided pixels cluster (R2 near the threshold): skip the certificate for a few rows
-                                if (exact) cert_skip = HK_CERT_SKIP;
+                                if (exact) cert_skip = HK_CERT_SKIP;  // failing regions are coherent: skip the certificate for a few rows
                             }
                         }
                         if (exact) {
@@ -882,21 +873,14 @@ fit_apply_kernel(const FitArgs a) {
                                 }
                                 if constexpr (GO) {
                                     const bool m = (mcu >> (8 * i)) & 1u;
-                                    failing_px[i] = count_fails && m && !(r2_ok[i] && (g[i] > 0.f));
-                                }
-                            }
-                        }
-                        if constexpr (GO) {
-                            // valid pixels failing (r2 > thresh) & (gain > 0) need in-painting (:363,:370): counted in the first
-                            // pass; in the second one they take the in-painted offset and a recomputed gain (:371)
-#pragma unroll
-                            for (int i = 0; i < PX; ++i) {
-                                const bool failing = count_fails && failing_px[i] && out_lane;
-                                if (failing) ++nfail;
-                                if (failing && inpaint_pass) {
-                                    const float oin = a.offset_in[out_base + (long long)y * a.stride + x + i];
-                                    o[i] = oin;
-                                    g[i] = __fdiv_rn(__fsub_rn(Rf[i], __fmul_rn(Nf[i], oin)), Sf[i]);
+                                    // valid pixels failing (r2 > thresh) & (gain > 0) need in-painting (:363,:370)
+                                    const bool failing = count_fails && m && !(r2_ok[i] && (g[i] > 0.f));
+                                    if (failing && out_lane) ++nfail;
+                                    if (failing && inpaint_pass && out_lane) {
+                                        const float oin = a.offset_in[out_base + (long long)y * a.stride + x + i];
+                                        o[i] = oin;
+                                        g[i] = __fdiv_rn(__fsub_rn(Rf[i], __fmul_rn(Nf[i], oin)), Sf[i]);
+                                    }
                                 }
                             }
                         }

@@ -44,9 +44,8 @@ def reference_window_math(s, r):
     return dict(n=nf, g=g, o=o, sf=sf, rf=rf, hs2=hs2, hr2=hr2, r2=r2)
 
 
-def certificate(q, kappa, k2=F32(2.0 ** -17), kappa_fail=None):
-    """ The kernel's expression, operation for operation (hk_kernels.hip, stage B).  With ``kappa_fail`` also the mirror
-    certificate: -> (certainly passes, certainly fails). """
+def certificate(q, kappa, k2=F32(2.0 ** -17)):
+    """ The kernel's expression, operation for operation (hk_kernels.hip, stage B). """
     g, o, nf, rf, sf = q['g'], q['o'], q['n'], q['rf'], q['sf']
     with np.errstate(all='ignore'):
         gg = (g * g).astype(F32)
@@ -61,11 +60,7 @@ def certificate(q, kappa, k2=F32(2.0 ** -17), kappa_fail=None):
         rhs = _fma32(np.full_like(sst, kappa), sst, slack)
         g_in = (g > F32(2.0 ** -20)) & (g < F32(2.0 ** 20))
         t_in = (nt > F32(2.0 ** -40)) & (nt < F32(2.0 ** 60))
-        sane = (sst > slack) & g_in & t_in
-        if kappa_fail is None:
-            return (lhs > rhs) & sane
-        rhs_f = _fma32(np.full_like(sst, kappa_fail), sst, -slack)
-        return (lhs > rhs) & sane, ~(g > 0) | ((lhs < rhs_f) & sane)
+        return (lhs > rhs) & (sst > slack) & g_in & t_in
 
 
 def kappa_for(thresh):
@@ -83,25 +78,6 @@ def kappa_for(thresh):
     if float(kf) < k + 2.0 ** -60:
         kf = np.nextafter(kf, F32(np.inf))
     return kf
-
-
-def kappa_fail_for(thresh):
-    """ Mirror of hk_api.hip r2_fail_above() / r2_fail_cert(). """
-    t = F32(thresh)
-    q = F32(1) - t
-    for _ in range(8):
-        q = np.nextafter(q, F32(np.inf))
-    while not (F32(1) - q > t):
-        q = np.nextafter(q, F32(-np.inf))
-    boundary = 0.5 * (float(q) + float(np.nextafter(q, F32(np.inf))))
-    c_hi = boundary * (1 + 2.0 ** -40)
-    k = 1 - c_hi * (1 + 2.0 ** -50)
-    if not k > 0:
-        return F32(-np.inf)
-    kf = F32(k)
-    if float(kf) > k - 2.0 ** -60:
-        kf = np.nextafter(kf, F32(-np.inf))
-    return kf if kf > 0 else F32(-np.inf)
 
 
 def _windows(rng, m, n, kind):
@@ -144,26 +120,6 @@ def test_certificate_never_contradicts_the_reference_arithmetic(kind, n):
         n_cert += int(sure.sum())
     if kind in ('synth', 'int') and n >= 9:
         assert n_cert > 0.5 * 4 * len(s)   # and it is not vacuous: well-conditioned data is certified
-
-
-@pytest.mark.parametrize('kind', ['synth', 'lowvar', 'wild', 'marginal', 'int'])
-@pytest.mark.parametrize('n', [2, 9, 25, 225])
-def test_failure_certificate_never_contradicts_the_reference_arithmetic(kind, n):
-    """ The mirror certificate ("certainly fails") against the reference arithmetic, and the two certificates against
-    each other. """
-    rng = np.random.default_rng(zlib.crc32(f'fail{kind}{n}'.encode()))
-    s, r = _windows(rng, 120_000 if n < 100 else 30_000, n, kind)
-    q = reference_window_math(s, r)
-    n_fail_cert = 0
-    for thresh in (0.0, 0.25, 0.5, 0.9, 0.999):
-        sure_pass, sure_fail = certificate(q, kappa_for(thresh), kappa_fail=kappa_fail_for(thresh))
-        with np.errstate(all='ignore'):
-            passes = (q['r2'] > F32(thresh)) & (q['g'] > 0)
-        assert not (sure_fail & passes).any()
-        assert not (sure_pass & sure_fail).any()
-        n_fail_cert += int(sure_fail.sum())
-    if kind == 'marginal' and n >= 9:
-        assert n_fail_cert > 0.2 * 5 * len(s)   # not vacuous: most of the genuinely failing windows are certified
 
 
 def test_the_data_probes_the_bound():
