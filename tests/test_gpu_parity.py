@@ -148,6 +148,62 @@ def test_multi_strip_multi_segment_vs_oracle(ctx, model, kernel_shape, find_r2, 
         assert n_fail == aux
 
 
+@pytest.mark.parametrize('seed', range(120))
+def test_randomized_configurations_vs_oracle(ctx, oc, seed):
+    """ A seeded sweep over the configuration space (model, odd kernel shape up to 17 x 17, R2 output, threshold, the
+    three nodata kinds on either raster, raster shape from one pixel to a few strips / segments, fused vs parameter
+    output): every draw must reproduce the C oracle (= the reference's whole fit branch incl. in-painting). """
+    import warnings
+    rng = np.random.default_rng(1000 + seed)
+    model = ['gain', 'gain-blk-offset', 'gain-offset'][rng.integers(3)]
+    kshape = (int(rng.choice([1, 3, 5, 7, 9, 15, 17])), int(rng.choice([1, 3, 5, 7, 9, 13, 15])))
+    if model == 'gain-offset' and kshape[0] * kshape[1] < 2:
+        kshape = (3, 3)
+    find_r2 = bool(rng.integers(2))
+    thresh = [None, 0.25, 0.6][rng.integers(3)] if model == 'gain-offset' else None
+    h, w = int(rng.integers(1, 420)), int(rng.integers(1, 700))
+    src = rng.uniform(0.05, 1, (h, w)).astype(np.float32)
+    ref = ((0.6 + rng.random()) * src + 0.1 * rng.random() + rng.normal(0, 0.02 + 0.2 * rng.random(), (h, w))).astype(np.float32)
+    nodata = {}
+    for name, arr in (('src', src), ('ref', ref)):
+        kind = rng.integers(3)
+        holes = rng.random((h, w)) < [0.0, 0.002, 0.05][rng.integers(3)]
+        if kind == 0:
+            nodata[name] = None
+        elif kind == 1:
+            nodata[name] = np.nan
+            arr[holes] = np.nan
+        else:
+            nodata[name] = -1.0
+            arr[holes] = -1.0
+    norm_in = oc.fit_block_norm(src, nodata['src'], ref, nodata['ref']) if model == 'gain-blk-offset' else None
+    exp_params, exp_corr, exp_fail = oc.fit_apply(model, src, nodata['src'], ref, nodata['ref'], kshape, find_r2, thresh,
+                                                  norm_in)
+    cfg = dict(model=model, kernel_shape=kshape, find_r2=find_r2, r2_inpaint_thresh=thresh, src_nodata=nodata['src'],
+               ref_nodata=nodata['ref'])
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        params, corr, _, n_fail = _fit_via_abi(ctx, cfg, src, ref, norm_in=norm_in)
+        desc = _hk.make_desc(model, kshape, find_r2, thresh, nodata['src'], nodata['ref'])
+        _, corr_fused, _, n_fail_fused = ctx.fit_apply(desc, src, ref, exp_params.shape[0], want_params=False, want_corr=True,
+                                                       norm_in=norm_in)
+    what = f'{model} {kshape} r2={find_r2} thresh={thresh} {h}x{w} nodata={nodata}'
+    if exp_params.shape[0] == 3 and kshape[0] * kshape[1] < 9:
+        # R2 of a window of < 9 pixels is rounding noise wherever sstot = N*sum(r^2) - sum(r)^2 cancels (values like -1.8
+        # or 9.0 come out of the reference itself): the last bit of the float64 sums decides it (DESIGN.md section 2)
+        got_r2, exp_r2 = params[2], exp_params[2]
+        assert (np.isnan(got_r2) == np.isnan(exp_r2)).all(), what
+        ok = np.isfinite(exp_r2) & np.isfinite(got_r2)
+        assert (np.isinf(got_r2) == np.isinf(exp_r2)).all(), what
+        assert np.allclose(got_r2[ok], exp_r2[ok], rtol=1e-3, atol=1e-3), what
+        params, exp_params = params[:2], exp_params[:2]
+    assert_close_ulp(params, exp_params, 'params: ' + what, max_frac=2e-3)
+    assert_close_ulp(corr, exp_corr, 'corrected: ' + what, max_frac=2e-3)
+    assert_close_ulp(corr_fused, exp_corr, 'corrected (fused, no parameter output): ' + what, max_frac=2e-3)
+    if thresh is not None:
+        assert n_fail == exp_fail == n_fail_fused, what
+
+
 @pytest.mark.parametrize('shape', [(1, 1), (1, 7), (5, 1), (2, 3), (4, 250), (131, 5), (129, 249)])
 @pytest.mark.parametrize('model, kernel_shape', [('gain', (3, 3)), ('gain-offset', (5, 5)), ('gain-offset', (15, 15))])
 def test_tiny_and_ragged_shapes(ctx, shape, model, kernel_shape):
