@@ -65,6 +65,24 @@ struct hk_ctx {
     // the last gain-offset call with a threshold found pixels failing the r2 mask: real imagery usually does, block after
     // block, so the next call materialises the parameters in its first pass instead of re-running it for the in-painting
     std::atomic<int> expect_r2_failures{0};
+    // certificate-only build of the gain-offset kernel (hk_kernels.hip launch_one): tried first unless it recently had to
+    // be re-run; every re-run doubles the number of eligible launches that go straight to the full build (<= 1024)
+    std::atomic<int> cert_skip{0}, cert_penalty{1};
+
+    bool try_cert_only() {
+        if (cert_disabled) return false;
+        int s = cert_skip.load(std::memory_order_relaxed);
+        while (s > 0)
+            if (cert_skip.compare_exchange_weak(s, s - 1, std::memory_order_relaxed)) return false;
+        return true;
+    }
+    void cert_only_settled() { cert_penalty.store(1, std::memory_order_relaxed); }
+    void cert_only_retried() {
+        const int p = std::min(cert_penalty.load(std::memory_order_relaxed) * 2, 1024);
+        cert_penalty.store(p, std::memory_order_relaxed);
+        cert_skip.store(p, std::memory_order_relaxed);
+    }
+    bool cert_disabled = false;  // HK_CERT_ONLY=0 in the environment (A/B measurements)
 };
 
 struct hk_event {
@@ -260,6 +278,13 @@ static int ensure_inpaint_scratch(Slot& sl, size_t plane, int height, long long 
     return HK_OK;
 }
 
+// The certificate-only build applies to gain-offset with the r2 mask when no R2 plane is asked for and the failures are
+// counted (the counter carries the re-run bit).
+static_assert(HK_COUNT_RETRY == hk::FIT_RETRY_BIT, "public and kernel-side re-run bits differ");
+static bool cert_only_eligible(const hk::FitArgs& a, const hk_fit_desc* desc) {
+    return desc->model == HK_MODEL_GAIN_OFFSET && a.has_thresh && a.fail_count && !a.r2 && !a.offset_in;
+}
+
 static int inpaint_band(Slot& sl, const hk::FitArgs& a, const hk_fit_desc* desc, bool r2, size_t plane,
                         bool params_are_scratch = false) {
     {
@@ -326,6 +351,7 @@ int fit_on_device(hk_ctx* ctx, Slot& sl, const hk_fit_desc* desc, const double* 
         a.r2 = reinterpret_cast<float*>(aux + 3 * plane);
         scratch_params = true;
     }
+    a.cert_only = cert_only_eligible(a, desc) && !scratch_params && ctx->try_cert_only();
     HK_HIP(hk::launch_fit_apply(a, desc->model, r2, sl.stream));
 
     if (a.has_thresh) {
@@ -334,6 +360,18 @@ int fit_on_device(hk_ctx* ctx, Slot& sl, const hk_fit_desc* desc, const double* 
         unsigned long long n_fail = 0;
         HK_HIP(hipMemcpyAsync(&n_fail, d_fail, sizeof(n_fail), hipMemcpyDeviceToHost, sl.stream));
         HK_HIP(hipStreamSynchronize(sl.stream));
+        if (a.cert_only) {
+            if (n_fail & hk::FIT_RETRY_BIT) {  // the certificate left a wave-row open: the full build decides
+                ctx->cert_only_retried();
+                a.cert_only = 0;
+                HK_HIP(hipMemsetAsync(d_fail, 0, sizeof(unsigned long long), sl.stream));
+                HK_HIP(hk::launch_fit_apply(a, desc->model, r2, sl.stream));
+                HK_HIP(hipMemcpyAsync(&n_fail, d_fail, sizeof(n_fail), hipMemcpyDeviceToHost, sl.stream));
+                HK_HIP(hipStreamSynchronize(sl.stream));
+            } else {
+                ctx->cert_only_settled();
+            }
+        }
         ctx->expect_r2_failures.store(n_fail > 0 ? 1 : 0);
         if (n_fail > 0) {
             const int rc = inpaint_band(sl, a, desc, r2, plane, scratch_params);
@@ -495,6 +533,7 @@ int hk_ctx_create(int device_id, int n_streams, hk_ctx** out) {
     ctx->slots.resize(n_streams);
     const char* remap = getenv("HK_XCD_REMAP");
     ctx->xcd_remap = remap ? atoi(remap) : 0;
+    if (const char* e = getenv("HK_CERT_ONLY")) ctx->cert_disabled = atoi(e) == 0;
     for (auto& s : ctx->slots) {
         hipError_t e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
         if (e != hipSuccess) {
@@ -895,6 +934,9 @@ int hk_fit_apply_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* job
     a.n_bands = job->n_bands;
     fill_args(a, desc, ctx->xcd_remap);
     fill_grid(a, job->seg_rows);
+    // a band the certificate-only build cannot settle comes back with FIT_RETRY_BIT in its counter; hk_inpaint_dev /
+    // hk_inpaint_dev_counts run it again with the full build
+    a.cert_only = cert_only_eligible(a, desc) && !ctx->expect_r2_failures.load() && ctx->try_cert_only();
     HK_HIP(hk::launch_fit_apply(a, desc->model, needs_r2(desc), ctx->slots[job->stream].stream));
     return HK_OK;
 }
@@ -934,9 +976,10 @@ int hk_inpaint_dev_counts(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job
     const bool r2 = needs_r2(desc);
     const size_t plane = (size_t)job->stride * job->height * sizeof(float);
     unsigned long long total = 0;
+    bool retried = false;
     for (int b = 0; b < job->n_bands; ++b) {
-        total += counts[b];
-        if (counts[b] == 0) continue;
+        unsigned long long n_fail = counts[b];
+        if (n_fail == 0) continue;
         const long long off = (long long)b * job->band_stride;
         hk::FitArgs a;
         memset(&a, 0, sizeof(a));
@@ -947,9 +990,37 @@ int hk_inpaint_dev_counts(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job
         fill_args(a, desc, ctx->xcd_remap);
         fill_grid(a, job->seg_rows);
         std::lock_guard<std::mutex> lk(ctx->mu);  // the slot's scratch may be (re)allocated
-        rc = inpaint_band(sl, a, desc, r2, plane);
+        bool scratch_params = false;
+        if (n_fail & hk::FIT_RETRY_BIT) {
+            // the certificate-only build gave up on this band (hk_fit_apply_dev): run the full build, straight into the
+            // in-painting scratch planes when the caller keeps no parameters, and count again
+            if (!job->fail_count) return fail(HK_ERR_ARG, "a band needs its re-run but job->fail_count is NULL");
+            retried = true;
+            unsigned long long* d_fail = reinterpret_cast<unsigned long long*>(job->fail_count) + b;
+            if (!a.gain && !a.offset) {
+                rc = ensure_inpaint_scratch(sl, plane, a.height, a.stride);
+                if (rc) return rc;
+                char* aux = static_cast<char*>(sl.aux);
+                a.gain = reinterpret_cast<float*>(aux + plane), a.offset = reinterpret_cast<float*>(aux + 2 * plane);
+                a.r2 = reinterpret_cast<float*>(aux + 3 * plane);
+                scratch_params = true;
+            }
+            a.fail_count = d_fail;
+            HK_HIP(hipMemsetAsync(d_fail, 0, sizeof(unsigned long long), sl.stream));
+            HK_HIP(hk::launch_fit_apply(a, desc->model, r2, sl.stream));
+            HK_HIP(hipMemcpyAsync(&n_fail, d_fail, sizeof(n_fail), hipMemcpyDeviceToHost, sl.stream));
+            HK_HIP(hipMemsetAsync(d_fail, 0, sizeof(unsigned long long), sl.stream));
+            HK_HIP(hipStreamSynchronize(sl.stream));
+            a.fail_count = nullptr;
+        }
+        total += n_fail;
+        if (n_fail == 0) continue;
+        rc = inpaint_band(sl, a, desc, r2, plane, scratch_params);
         if (rc) return rc;
     }
+    if (retried) ctx->cert_only_retried();
+    else if (ctx->cert_skip.load(std::memory_order_relaxed) == 0) ctx->cert_only_settled();
+    ctx->expect_r2_failures.store(total > 0 ? 1 : 0);
     if (n_fail_out) *n_fail_out = total;
     return HK_OK;
 }

@@ -9,6 +9,10 @@ constexpr int PX = 4;      // pixels per lane per row (one 16-byte load)
 constexpr int WAVE = 64;   // gfx950 wavefront
 
 // Device-side argument block of the fused fit(+apply) kernel.  One wave = one (band, row-segment, column-strip) unit.
+// Set in a band's r2-failure counter by the certificate-only build: the count is void, run the band again with
+// cert_only = 0.  (Counts themselves are < 2^63.)
+constexpr unsigned long long FIT_RETRY_BIT = 1ull << 63;
+
 struct FitArgs {
     const float* src;
     const float* ref;
@@ -34,6 +38,8 @@ struct FitArgs {
     float src_nodata, ref_nodata;
     int has_thresh;
     float r2_thresh;
+    int cert_only;          // gain-offset + r2 mask, no R2 plane, fail_count set: run the certificate-only build, which
+                            // ORs FIT_RETRY_BIT into fail_count[band] when the band has to be re-run (launch_one)
     float r2_fail_scale;    // kappa of the division-free r2-mask certificate: 1 - r2_pass_scale(), rounded up (hk_api.hip)
     double r2_pass_below;   // exact evaluation without R2 output: ssres < r2_pass_below * sstot proves the r2 test true,
     double r2_fail_above;   // ssres > r2_fail_above * sstot proves it false (sstot > 0); in between the division decides

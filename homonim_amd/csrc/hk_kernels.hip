@@ -417,8 +417,9 @@ struct ColSums {
 //      global memory -- tall kernels: a full ring would cut occupancy to one wave per SIMD, re-loading BOTH rows makes
 //      three streams that all miss L2 and the kernel fabric-bound;
 //   0  both re-loaded (very tall kernels whose centre ring would not fit either).
-template <int MODEL, bool R2, int RW, bool DENSE, int RING>
-__global__ void __launch_bounds__(WAVE, (MODEL == 2 && R2 && !DENSE && (RW < 0 || RW >= 4)) ? HK_FIT_MIN_WAVES_WIDE : HK_FIT_MIN_WAVES)
+template <int MODEL, bool R2, int RW, bool DENSE, int RING, bool CERT_ONLY>
+__global__ void __launch_bounds__(WAVE, (CERT_ONLY && RW >= 0 && RW <= 3 && (DENSE || RW <= 1)) ? 4
+                                        : ((MODEL == 2 && R2 && !DENSE && (RW < 0 || RW >= 4)) ? HK_FIT_MIN_WAVES_WIDE : HK_FIT_MIN_WAVES))
 fit_apply_kernel(const FitArgs a) {
     using CS = ColSums<MODEL, R2, DENSE>;
     constexpr bool GO = MODEL == 2, BLK = MODEL == 1;
@@ -500,7 +501,10 @@ fit_apply_kernel(const FitArgs a) {
     // N < 2^8 the quotient t/N is never closer than 2^-33 (relative) to a float32 rounding midpoint, while
     // f64(t) * RN64(1/N) is within 2^-52 of it -- so rounding that product to float32 IS the IEEE float32 division.
     double* inv_lut = reinterpret_cast<double*>(ring_m + (DENSE ? (size_t)0 : (size_t)ring_rows * WAVE));  // dense: no mask ring
-    const bool use_lut = GO && kh * (2 * rw + 1) <= 255;
+    const bool lut_ok = GO && kh * (2 * rw + 1) <= 255;  // the product trick is proven for window counts < 2^8
+    // the certificate-only build keeps no table in LDS (10 KB per wave = 16 waves per CU): away from the edges N is a
+    // kernel argument anyway, elsewhere it divides (IEEE float32, identical result)
+    const bool use_lut = lut_ok && !CERT_ONLY;
     if (use_lut)
         for (int n = lane; n < 256; n += WAVE) inv_lut[n] = 1.0 / (double)n;
 
@@ -550,7 +554,7 @@ fit_apply_kernel(const FitArgs a) {
             const int c = x + i;
             full &= (c - rw >= 0) && (c + rw < W);
         }
-        n_uniform_cols = use_lut && __all((int)(!out_lane || full));
+        n_uniform_cols = lut_ok && __all((int)(!out_lane || full));
     }
 
     // RING 0 / 2: the re-loaded leaving row runs one iteration ahead where the registers allow it (not in the general
@@ -775,7 +779,7 @@ fit_apply_kernel(const FitArgs a) {
                     if (want_r2_values || count_fails) {  // wave-uniform
                         bool exact = want_r2_values;
                         if constexpr (GO) {
-                            if (!exact && cert_skip > 0) {  // the rows just above needed the exact evaluation: go straight to it
+                            if (!CERT_ONLY && !exact && cert_skip > 0) {  // the rows just above needed the exact evaluation: go straight to it
                                 exact = true;
                                 --cert_skip;
                             }
@@ -816,7 +820,16 @@ fit_apply_kernel(const FitArgs a) {
                                 if (exact) cert_skip = HK_CERT_SKIP;  // failing regions are coherent: skip the certificate for a few rows
                             }
                         }
-                        if (exact) {
+                        if constexpr (CERT_ONLY) {
+                            // this build holds no exact evaluation (which would cost the whole kernel a wave per SIMD): a
+                            // wave-row the certificate cannot settle invalidates the launch -- the host sees the flag and
+                            // runs the full build instead (hk_api.hip), remembering to start with it next time.  (Ending the
+                            // wave here also keeps the allocator at 128 VGPRs without spills; carrying on costs 16 spilled.)
+                            if (exact) {  // the launch is void from here on: flag it and stop working on this unit
+                                if (lane == 0) atomicOr(a.fail_count + band, FIT_RETRY_BIT);
+                                return;
+                            }
+                        } else if (exact) {
                             double sstot[PX], ssres[PX];
 #pragma unroll
                             for (int i = 0; i < PX; ++i) {
@@ -938,6 +951,7 @@ fit_apply_kernel(const FitArgs a) {
 #pragma unroll
             for (int d = WAVE / 2; d > 0; d >>= 1) nfail += __shfl_xor(nfail, d);
             if (lane == 0 && nfail) atomicAdd(a.fail_count + band, (unsigned long long)nfail);
+
         }
     }
 }
@@ -952,18 +966,32 @@ size_t fit_lds_bytes(int kh, int ring_mode, bool with_lut, bool with_mask) {
     return ring + (with_lut ? 256 * sizeof(double) : 0);
 }
 
-template <int MODEL, bool R2, int RW, bool DENSE, int RING>
-static hipError_t launch_one(const FitArgs& a, hipStream_t stream) {
-    const size_t lds = fit_lds_bytes(2 * a.rh + 1, RING, MODEL == 2, !DENSE);
+template <int MODEL, bool R2, int RW, bool DENSE, int RING, bool CERT_ONLY>
+static hipError_t launch_build(const FitArgs& a, hipStream_t stream) {
+    const size_t lds = fit_lds_bytes(2 * a.rh + 1, RING, MODEL == 2 && !CERT_ONLY, !DENSE);
     if (lds > 64 * 1024) {  // forced LDS ring on a tall kernel (testing): raise the 64 KiB dynamic-LDS default
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fit_apply_kernel<MODEL, R2, RW, DENSE, RING>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fit_apply_kernel<MODEL, R2, RW, DENSE, RING, CERT_ONLY>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
     }
     int grid = a.total_units;
     if (a.xcd_remap) grid = (grid + 7) / 8 * 8;
-    hipLaunchKernelGGL((fit_apply_kernel<MODEL, R2, RW, DENSE, RING>), dim3(grid), dim3(WAVE), lds, stream, a);
+    hipLaunchKernelGGL((fit_apply_kernel<MODEL, R2, RW, DENSE, RING, CERT_ONLY>), dim3(grid), dim3(WAVE), lds, stream, a);
     return hipGetLastError();
+}
+
+// gain-offset with the r2 mask exists in two builds.  The FULL one carries the reference's R2 expression inline for the
+// wave-rows the float32 certificate cannot settle (and for R2 output): 154 VGPRs, 3 waves per SIMD.  The CERTIFICATE-ONLY
+// one (a.cert_only, chosen by the host when no R2 plane is written and the previous launch had no failures) has nothing
+// but the certificate: 128 VGPRs and no LDS table = 4 waves per SIMD (-9 % on clean rasters); a wave-row it cannot settle
+// sets FIT_RETRY_BIT in the band's fail counter and the host re-runs the band with the full build.
+template <int MODEL, bool R2, int RW, bool DENSE, int RING>
+static hipError_t launch_one(const FitArgs& a, hipStream_t stream) {
+    if constexpr (MODEL == 2 && R2 && (RING == 1 || RING == 2) && RW >= 0) {
+        if (a.cert_only && a.has_thresh && a.fail_count && !a.r2 && !a.offset_in)
+            return launch_build<MODEL, R2, RW, DENSE, RING, true>(a, stream);
+    }
+    return launch_build<MODEL, R2, RW, DENSE, RING, false>(a, stream);
 }
 
 template <int MODEL, bool R2, bool DENSE>

@@ -225,7 +225,12 @@ int hk_inpaint_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* job, 
 /* The same in two halves, for pipelines that must not drain the stream after every launch: hk_fail_counts_async queues the
  * copy of the job's counters into `host_counts` (n_bands values, pinned host memory: hk_host_alloc), their clearing and
  * the recording of `ready`; after hk_event_sync(ready) the caller passes the counts to hk_inpaint_dev_counts, which only
- * queues work.  Launch N + 1 (into a second counter buffer) may be queued before the counts of launch N are looked at. */
+ * queues work.  Launch N + 1 (into a second counter buffer) may be queued before the counts of launch N are looked at.
+ * A raw counter with HK_COUNT_RETRY set is not a count: gain-offset jobs that keep no R2 plane are first run with a
+ * lighter kernel build that can only certify "no pixel fails", and the bit says it could not; hk_inpaint_dev /
+ * hk_inpaint_dev_counts then run that band again with the complete build (job->fail_count must still be the job's
+ * counter buffer) and report the true count in *n_fail_out.  Pass the counts on unchanged. */
+#define HK_COUNT_RETRY (1ull << 63)
 int hk_fail_counts_async(hk_ctx* ctx, const hk_dev_job* job, uint64_t* host_counts, hk_event* ready);
 int hk_inpaint_dev_counts(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* job, const uint64_t* counts,
                           uint64_t* n_fail_out);
