@@ -9,9 +9,11 @@ from homonim_amd.errors import ConfigWarning, DeviceError, HomonimError
 from homonim_amd.geo import Affine, CRS, Window
 from homonim_amd.kernel_model import KernelModel, RefSpaceModel, SrcSpaceModel
 from homonim_amd.raster_array import RasterArray
+from homonim_amd.fuse import RasterFuse
+from homonim_amd.compare import RasterCompare
 
 __version__ = '0.1.0'
 __all__ = [
     'Model', 'ProcCrs', 'Resampling', 'ConfigWarning', 'DeviceError', 'HomonimError', 'Affine', 'CRS', 'Window',
-    'KernelModel', 'RefSpaceModel', 'SrcSpaceModel', 'RasterArray',
+    'KernelModel', 'RefSpaceModel', 'SrcSpaceModel', 'RasterArray', 'RasterFuse', 'RasterCompare',
 ]

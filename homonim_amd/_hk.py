@@ -67,6 +67,8 @@ SIGNATURES = {
     'hk_ctx_destroy': (C.c_int, [C.c_void_p]),
     'hk_ctx_sync': (C.c_int, [C.c_void_p]),
     'hk_block_norm': (C.c_int, [C.c_void_p, _P(FitDesc), _f32p, C.c_int64, _f32p, C.c_int64, C.c_int32, C.c_int32, _f64p]),
+    'hk_compare_sums': (C.c_int, [C.c_void_p, _f32p, C.c_int64, C.c_int32, C.c_float, _f32p, C.c_int64, C.c_int32, C.c_float,
+                                  C.c_int32, C.c_int32, _f64p]),
     'hk_fit': (C.c_int, [C.c_void_p, _P(FitDesc), _f32p, C.c_int64, _f32p, C.c_int64, C.c_int32, C.c_int32, _f64p,
                          _f32p, C.c_int32, _f64p, _u64p]),
     'hk_apply': (C.c_int, [C.c_void_p, _f32p, C.c_int64, _f32p, C.c_int32, C.c_int32, _f32p]),
@@ -96,6 +98,7 @@ SIGNATURES = {
     'hk_inpaint_dev_counts': (C.c_int, [C.c_void_p, _P(FitDesc), _P(DevJob), _P(C.c_uint64), _P(C.c_uint64)]),
     'hk_event_sync': (C.c_int, [C.c_void_p, C.c_void_p]),
     'hk_block_norm_dev': (C.c_int, [C.c_void_p, _P(FitDesc), _P(DevJob), C.c_void_p]),
+    'hk_compare_sums_dev': (C.c_int, [C.c_void_p, _P(DevJob), C.c_int32, C.c_float, C.c_int32, C.c_float, C.c_void_p]),
     'hk_synth_fill_dev': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64,
                                     C.c_int64, C.c_uint64, C.c_int32, C.c_int32]),
     'hk_event_create': (C.c_int, [C.c_void_p, _P(C.c_void_p)]),
@@ -231,6 +234,18 @@ class Context:
         _check(self._lib.hk_block_norm(self._h, C.byref(desc), _ptr(src), src.strides[0] // 4, _ptr(ref),
                                        ref.strides[0] // 4, src.shape[0], src.shape[1], _ptr(norm, _f64p)))
         return norm
+
+    def compare_sums(self, src: np.ndarray, src_nodata, ref: np.ndarray, ref_nodata) -> np.ndarray:
+        """ float64[7] = [sum s, sum r, sum s^2, sum r^2, sum s*r, sum (r-s)^2, N] over the jointly valid pixels
+        (homonim/compare.py:243-255) """
+        src, ref = _as_f32_2d(src, 'src'), _as_f32_2d(ref, 'ref')
+        if src.shape != ref.shape:
+            raise ValueError('`src` and `ref` shapes differ')
+        sums = np.zeros(7, np.float64)
+        (sm, sv), (rm, rv) = nodata_code(src_nodata), nodata_code(ref_nodata)
+        _check(self._lib.hk_compare_sums(self._h, _ptr(src), src.strides[0] // 4, sm, sv, _ptr(ref), ref.strides[0] // 4,
+                                         rm, rv, src.shape[0], src.shape[1], _ptr(sums, _f64p)))
+        return sums
 
     def fit_apply(self, desc: FitDesc, src: np.ndarray, ref: np.ndarray, n_param_bands: int, want_params: bool,
                   want_corr: bool, norm_in: Optional[np.ndarray] = None, out_params: Optional[np.ndarray] = None,
@@ -426,6 +441,10 @@ class Context:
 
     def block_norm_dev(self, desc: FitDesc, job: DevJob, norm_dptr: int):
         _check(self._lib.hk_block_norm_dev(self._h, C.byref(desc), C.byref(job), C.c_void_p(norm_dptr)))
+
+    def compare_sums_dev(self, job: DevJob, src_nodata, ref_nodata, sums_dptr: int):
+        (sm, sv), (rm, rv) = nodata_code(src_nodata), nodata_code(ref_nodata)
+        _check(self._lib.hk_compare_sums_dev(self._h, C.byref(job), sm, sv, rm, rv, C.c_void_p(sums_dptr)))
 
     def synth_fill_dev(self, src_dptr, ref_dptr, n_bands, height, width, stride, band_stride, seed=0, nodata_variant=0,
                        stream=0):

@@ -15,7 +15,7 @@ REPO = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, 'csrc')
 LIB_DIR = os.path.join(PKG, 'lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libhomonim_hk.so')
-HIP_SOURCES = ['hk_kernels.hip', 'hk_norm.hip', 'hk_convert.hip', 'hk_mask.hip', 'hk_inpaint.hip', 'hk_resample.hip', 'hk_api.hip']
+HIP_SOURCES = ['hk_kernels.hip', 'hk_norm.hip', 'hk_convert.hip', 'hk_mask.hip', 'hk_inpaint.hip', 'hk_resample.hip', 'hk_compare.hip', 'hk_api.hip']
 # -ffp-contract=off: numpy never fuses a*b+c; the kernels must round exactly where the reference does.
 HIPCC_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wall', '-Wno-unused-function']
 

@@ -1044,6 +1044,85 @@ int hk_inpaint_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* job, 
     return hk_inpaint_dev_counts(ctx, desc, job, counts.data(), n_fail_out);
 }
 
+// Reduction workspace of the device-resident entry points on one stream (block statistics, comparison sums).
+static int ensure_stream_ws(hk_ctx* ctx, Slot& sl, size_t need) {
+    // device-resident jobs on one stream are issued by one caller at a time (stream order); the lock only protects
+    // the (re)allocation against other streams' callers touching the context
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (sl.norm_ws_bytes < need) {
+        if (sl.norm_ws) {
+            HK_HIP(hipStreamSynchronize(sl.stream));
+            HK_HIP(hipFree(sl.norm_ws));
+            sl.norm_ws = nullptr, sl.norm_ws_bytes = 0;
+        }
+        if (hipMalloc(&sl.norm_ws, need) != hipSuccess) return fail(HK_ERR_NOMEM, "hipMalloc(%zu) failed", need);
+        sl.norm_ws_bytes = need;
+    }
+    return HK_OK;
+}
+
+static int check_nodata_mode(int32_t mode) {
+    return (mode == HK_NODATA_NONE || mode == HK_NODATA_NAN || mode == HK_NODATA_VALUE)
+               ? HK_OK
+               : fail(HK_ERR_ARG, "bad nodata mode %d", mode);
+}
+
+int hk_compare_sums_dev(hk_ctx* ctx, const hk_dev_job* job, int32_t src_nodata_mode, float src_nodata,
+                        int32_t ref_nodata_mode, float ref_nodata, double* sums_dev) {
+    int rc = check_job(ctx, job);
+    if (rc) return rc;
+    if (!sums_dev) return fail(HK_ERR_ARG, "sums_dev is NULL");
+    if ((rc = check_nodata_mode(src_nodata_mode)) || (rc = check_nodata_mode(ref_nodata_mode))) return rc;
+    HK_HIP(hipSetDevice(ctx->device));
+    Slot& sl = ctx->slots[job->stream];
+    rc = ensure_stream_ws(ctx, sl, hk::compare_workspace_bytes(job->n_bands));
+    if (rc) return rc;
+    hk::CompareArgs ca;
+    memset(&ca, 0, sizeof(ca));
+    ca.src = job->src, ca.ref = job->ref, ca.height = job->height, ca.width = job->width;
+    ca.src_stride = ca.ref_stride = job->stride, ca.src_band_stride = ca.ref_band_stride = job->band_stride;
+    ca.n_bands = job->n_bands;
+    ca.src_nd_mode = src_nodata_mode, ca.ref_nd_mode = ref_nodata_mode, ca.src_nodata = src_nodata, ca.ref_nodata = ref_nodata;
+    HK_HIP(hk::launch_compare_sums(ca, sl.norm_ws, sums_dev, sl.stream));
+    return HK_OK;
+}
+
+int hk_compare_sums(hk_ctx* ctx, const float* src, int64_t src_stride, int32_t src_nodata_mode, float src_nodata,
+                    const float* ref, int64_t ref_stride, int32_t ref_nodata_mode, float ref_nodata, int32_t height,
+                    int32_t width, double sums_out[7]) {
+    if (!ctx) return fail(HK_ERR_ARG, "ctx is NULL");
+    if (!src || !ref || !sums_out) return fail(HK_ERR_ARG, "NULL pointer argument");
+    if (height < 1 || width < 1) return fail(HK_ERR_ARG, "empty raster %d x %d", height, width);
+    if (src_stride < width || ref_stride < width) return fail(HK_ERR_ARG, "row stride smaller than width");
+    int rc;
+    if ((rc = check_nodata_mode(src_nodata_mode)) || (rc = check_nodata_mode(ref_nodata_mode))) return rc;
+    HK_HIP(hipSetDevice(ctx->device));
+    const int64_t stride = (width + ROW_ALIGN - 1) / ROW_ALIGN * ROW_ALIGN;
+    const size_t plane = (size_t)stride * height * sizeof(float);
+    const size_t ws_bytes = hk::compare_workspace_bytes(1);
+    SlotLease lease(ctx);
+    Slot& sl = lease.slot();
+    rc = ensure_dev(sl, 2 * plane + ws_bytes + 256);
+    if (rc) return rc;
+    char* base = static_cast<char*>(sl.dev);
+    float* d_src = reinterpret_cast<float*>(base);
+    float* d_ref = reinterpret_cast<float*>(base + plane);
+    void* d_ws = base + 2 * plane;
+    double* d_sums = reinterpret_cast<double*>(base + 2 * plane + ws_bytes);
+    const size_t wbytes = (size_t)width * sizeof(float);
+    HK_HIP(hipMemcpy2DAsync(d_src, stride * 4, src, src_stride * 4, wbytes, height, hipMemcpyHostToDevice, sl.stream));
+    HK_HIP(hipMemcpy2DAsync(d_ref, stride * 4, ref, ref_stride * 4, wbytes, height, hipMemcpyHostToDevice, sl.stream));
+    hk::CompareArgs ca;
+    memset(&ca, 0, sizeof(ca));
+    ca.src = d_src, ca.ref = d_ref, ca.height = height, ca.width = width;
+    ca.src_stride = ca.ref_stride = stride, ca.src_band_stride = ca.ref_band_stride = 0, ca.n_bands = 1;
+    ca.src_nd_mode = src_nodata_mode, ca.ref_nd_mode = ref_nodata_mode, ca.src_nodata = src_nodata, ca.ref_nodata = ref_nodata;
+    HK_HIP(hk::launch_compare_sums(ca, d_ws, d_sums, sl.stream));
+    HK_HIP(hipMemcpyAsync(sums_out, d_sums, 7 * sizeof(double), hipMemcpyDeviceToHost, sl.stream));
+    HK_HIP(hipStreamSynchronize(sl.stream));
+    return HK_OK;
+}
+
 int hk_block_norm_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* job, double* norm_dev) {
     int rc = validate_desc(desc);
     if (rc) return rc;
@@ -1052,21 +1131,8 @@ int hk_block_norm_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* jo
     if (!norm_dev) return fail(HK_ERR_ARG, "norm_dev is NULL");
     HK_HIP(hipSetDevice(ctx->device));
     Slot& sl = ctx->slots[job->stream];
-    const size_t need = hk::norm_workspace_bytes(job->n_bands, job->height, job->width);
-    {
-        // device-resident jobs on one stream are issued by one caller at a time (stream order); the lock only protects
-        // the (re)allocation against other streams' callers touching the context
-        std::lock_guard<std::mutex> lk(ctx->mu);
-        if (sl.norm_ws_bytes < need) {
-            if (sl.norm_ws) {
-                HK_HIP(hipStreamSynchronize(sl.stream));
-                HK_HIP(hipFree(sl.norm_ws));
-                sl.norm_ws = nullptr, sl.norm_ws_bytes = 0;
-            }
-            if (hipMalloc(&sl.norm_ws, need) != hipSuccess) return fail(HK_ERR_NOMEM, "hipMalloc(%zu) failed", need);
-            sl.norm_ws_bytes = need;
-        }
-    }
+    rc = ensure_stream_ws(ctx, sl, hk::norm_workspace_bytes(job->n_bands, job->height, job->width));
+    if (rc) return rc;
     hk::NormArgs na;
     na.src = job->src, na.ref = job->ref, na.height = job->height, na.width = job->width, na.stride = job->stride;
     na.band_stride = job->band_stride, na.n_bands = job->n_bands;

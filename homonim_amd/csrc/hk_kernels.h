@@ -75,6 +75,22 @@ struct NormArgs {
 size_t norm_workspace_bytes(int n_bands, int height, int width);
 hipError_t launch_block_norm(const NormArgs& a, void* workspace, double* norm_out, hipStream_t stream);
 
+// Masked comparison sums of homonim/compare.py:243-255 (hk_compare.hip), per band:
+// sums_out[band * 7 + k] = [sum s, sum r, sum s^2, sum r^2, sum s*r, sum (r - s)^2, count] over jointly valid pixels.
+struct CompareArgs {
+    const float* src;
+    const float* ref;
+    int height, width;
+    long long src_stride, ref_stride;            // elements between rows
+    long long src_band_stride, ref_band_stride;  // elements between planes
+    int n_bands;
+    int src_nd_mode, ref_nd_mode;
+    float src_nodata, ref_nodata;
+    int vec_ok;                                  // set by the launcher: 16-byte row loads are legal
+};
+size_t compare_workspace_bytes(int n_bands);
+hipError_t launch_compare_sums(const CompareArgs& a, void* workspace, double* sums_out, hipStream_t stream);
+
 hipError_t launch_synth_fill(float* src, float* ref, int n_bands, int height, int width, long long stride,
                              long long band_stride, unsigned long long seed, int nodata_variant, hipStream_t stream);
 

@@ -84,6 +84,13 @@ int hk_ctx_sync(hk_ctx* ctx);                 /* hipDeviceSynchronize on the con
 int hk_block_norm(hk_ctx* ctx, const hk_fit_desc* desc, const float* src, int64_t src_stride, const float* ref,
                   int64_t ref_stride, int32_t height, int32_t width, double norm_out[2]);
 
+/* RasterCompare.process / get_block_sums (homonim/compare.py:243-255) for one band of two rasters on the same grid:
+ * sums_out = [ sum src, sum ref, sum src^2, sum ref^2, sum src*ref, sum (ref - src)^2, N ] over jointly valid pixels
+ * (see hk_compare_sums_dev for the arithmetic). */
+int hk_compare_sums(hk_ctx* ctx, const float* src, int64_t src_stride, int32_t src_nodata_mode, float src_nodata,
+                    const float* ref, int64_t ref_stride, int32_t ref_nodata_mode, float ref_nodata, int32_t height,
+                    int32_t width, double sums_out[7]);
+
 /* KernelModel.fit (homonim/kernel_model.py:411-440 -> _fit_gain :231-274, _fit_gain_blk_offset :276-303,
  * _fit_gain_offset :305-373, _r2_array :142-214).
  *   params_out : n_param_bands x height x width float32, band 0 gain, 1 offset, 2 R2 (iff n_param_bands == 3;
@@ -236,6 +243,14 @@ int hk_inpaint_dev_counts(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job
                           uint64_t* n_fail_out);
 /* Per-band block normalisation on device planes -> norm (device, n_bands x 2 float64); asynchronous. */
 int hk_block_norm_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* job, double* norm_dev);
+/* The masked sums of RasterCompare.process / get_block_sums (homonim/compare.py:243-255) on the job's src and ref planes
+ * (job->corr etc. are not used), per band into sums_dev (device, n_bands x 7 float64; asynchronous):
+ *   [ sum src, sum ref, sum src^2, sum ref^2, sum src*ref, sum (ref - src)^2, number of pixels ]
+ * over the pixels valid in both rasters.  Per-pixel terms are formed in float32 as numpy does on float32 arrays; they are
+ * accumulated in float64 in a fixed order (the reference's float32 pairwise sums differ from these by ~1e-7 relative).
+ * r2 / RMSE / rRMSE follow from them as in compare.py:142-160. */
+int hk_compare_sums_dev(hk_ctx* ctx, const hk_dev_job* job, int32_t src_nodata_mode, float src_nodata,
+                        int32_t ref_nodata_mode, float ref_nodata, double* sums_dev);
 /* Fill device planes with the synthetic workload of SURVEY.md section 8(d) (src ~ U[0.05,1), ref = g*src+o+noise);
  * nodata_variant 0: none, 1: 3-px NaN frame + 0.1 % NaN holes, 2: frame only, 3 / 4: none, noisy reference (35 % / 85 % r2-mask failures).  Test/bench data only. */
 int hk_synth_fill_dev(hk_ctx* ctx, float* src, float* ref, int32_t n_bands, int32_t height, int32_t width,

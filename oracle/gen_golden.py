@@ -433,9 +433,71 @@ def gen_mask_partial_goldens(mods):
     print(f'mask_partial goldens: {len(cases)} cases')
 
 
+def gen_compare_goldens(mods):
+    """ The reference's own RasterCompare.process (compare.py:212-278) on in-memory same-grid band stacks: the block
+    reader of RasterPairReader is replaced by array slicing (no GDAL), everything from get_block_sums to
+    _get_image_stats is the reference's code.  -> tests/golden/compare.npz (inputs + per-band r2 / RMSE / rRMSE / N). """
+    import warnings
+    for name in ('matched_pair', 'compare'):
+        spec = importlib.util.spec_from_file_location(f'homonim.{name}', os.path.join(REF_ROOT, 'homonim', f'{name}.py'))
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[f'homonim.{name}'] = mod
+        spec.loader.exec_module(mod)
+    cmp_mod, ra_mod, rio = sys.modules['homonim.compare'], mods['raster_array'], sys.modules['rasterio']
+    ra_mod.reproject = sys.modules['rasterio.warp'].reproject
+    Window = sys.modules['rasterio.windows'].Window
+    ProcCrs = sys.modules['homonim.enums'].ProcCrs
+    crs = sys.modules['rasterio.crs'].CRS()
+
+    class ArrayCompare(cmp_mod.RasterCompare):
+        def __init__(self, src, src_nodata, ref, ref_nodata, proc_crs):
+            nb, h, w = src.shape
+            self._src, self._ref, self._snd, self._rnd = src, ref, src_nodata, ref_nodata
+            self._src_im, self._ref_im = _FakeDataset(h, w), _FakeDataset(h, w)
+            self._src_im.descriptions = self._ref_im.descriptions = (None, ) * nb
+            self._src_bands = self._ref_bands = tuple(range(1, nb + 1))
+            self._src_win = self._ref_win = Window(0, 0, w, h)
+            self._proc_crs = proc_crs
+            self._src_filename = self._ref_filename = 'memory.tif'
+
+        def read(self, bp):
+            def cut(stack, nodata, win):
+                (r0, r1), (c0, c1) = win.toranges()
+                tf = rio.Affine(1., 0., float(c0), 0., -1., -float(r0))
+                return ra_mod.RasterArray(stack[bp.band_i, r0:r1, c0:c1].copy(), crs, tf, nodata=nodata)
+            return cut(self._src, self._snd, bp.src_in_block), cut(self._ref, self._rnd, bp.ref_in_block)
+
+    arrays, cases = {}, []
+    specs = [  # (name, h, w, bands, variant of make_inputs, proc_crs, max_block_mem MB)
+        ('nan_holes', 300, 420, 3, 'nan_frame_holes', ProcCrs.ref, 0.1),
+        ('no_nodata', 257, 511, 2, 'no_nodata', ProcCrs.src, 0.25),
+        ('numeric_nodata', 300, 420, 2, 'numeric_nodata', ProcCrs.ref, 512),
+    ]
+    for (name, h, w, nb, variant, proc, mem) in specs:
+        srcs, refs = [], []
+        for b in range(nb):
+            s_, snd, r_, rnd = make_inputs(h, w, 100 + 7 * b + len(cases), variant)
+            srcs.append(s_), refs.append(r_)
+        src, ref = np.stack(srcs), np.stack(refs)
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            stats = ArrayCompare(src, snd, ref, rnd, proc).process(threads=1, max_block_mem=mem)
+        arrays[f'{name}_src'], arrays[f'{name}_ref'] = src, ref
+        keys = list(stats.keys())
+        arrays[f'{name}_stats'] = np.array([[float(stats[k]['r2']), float(stats[k]['rmse']), float(stats[k]['rrmse']),
+                                             float(stats[k]['n'])] for k in keys], dtype=np.float64)
+        cases.append(dict(name=name, bands=keys, proc_crs=proc.value, max_block_mem=mem,
+                          src_nodata=(None if snd is None else ('nan' if np.isnan(snd) else float(snd))),
+                          ref_nodata=(None if rnd is None else ('nan' if np.isnan(rnd) else float(rnd)))))
+    arrays['cases_json'] = np.frombuffer(json.dumps(cases).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(GOLDEN_DIR, 'compare.npz'), **arrays)
+    print(f'compare goldens: {len(cases)} cases', {c['name']: arrays[c['name'] + '_stats'][-1].tolist() for c in cases})
+
+
 def main():
     mods = load_reference()
     gen_block_goldens()
+    gen_compare_goldens(mods)
     gen_mask_partial_goldens(mods)
     gen_convert_goldens(mods)
     os.makedirs(GOLDEN_DIR, exist_ok=True)

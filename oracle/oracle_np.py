@@ -24,6 +24,7 @@ What is restated, and from where
 * ``fit_gain_blk_offset``   <- kernel_model.py:276-303   (NumPy>=2 flavour: normalised source is float64)
 * ``fit_gain_offset``       <- kernel_model.py:305-373   (in-paint branch: bookkeeping only, see below)
 * ``apply``                 <- kernel_model.py:442-463
+* ``compare_sums``, ``compare_stats`` <- compare.py:243-255 (get_block_sums), :142-186 (_get_image_stats)
 
 Pinning
 -------
@@ -369,6 +370,48 @@ def fit(model: str, src, src_nodata, ref, ref_nodata, kernel_shape=(5, 5), find_
 #              2 / 4-tap kernel (cubic B-spline) around it, taps outside the raster or invalid are skipped and the sum is
 #              renormalised by the accumulated weight (nodata below 1e-6).  Up-sampling only (kernel not stretched).
 RESAMPLING_CODES = {'nearest': 0, 'bilinear': 1, 'cubic_spline': 3, 'average': 5}
+
+
+COMPARE_KEYS = ('src_sum', 'ref_sum', 'src2_sum', 'ref2_sum', 'src_ref_sum', 'res2_sum', 'mask_sum')
+
+
+def compare_sums(src, src_nodata, ref, ref_nodata) -> dict:
+    """ compare.py:243-255 for one block of two rasters on one grid: the seven masked sums, with the reference's dtypes
+    (float32 arrays -> numpy float32 pairwise sums; the count is an integer). """
+    src_array = np.array(src, dtype=np.float32, copy=True)
+    ref_array = np.array(ref, dtype=np.float32, copy=True)
+    mask = mask_of(ref_array, ref_nodata) & mask_of(src_array, src_nodata)
+    src_array[~mask] = 0
+    ref_array[~mask] = 0
+    return dict(
+        src_sum=src_array.sum(), ref_sum=ref_array.sum(), src2_sum=(src_array ** 2).sum(),
+        ref2_sum=(ref_array ** 2).sum(), src_ref_sum=(src_array * ref_array).sum(),
+        res2_sum=((ref_array - src_array) ** 2).sum(), mask_sum=mask.sum()
+    )
+
+
+def compare_band_stats(src_sum=0, ref_sum=0, src2_sum=0, ref2_sum=0, src_ref_sum=0, res2_sum=0, mask_sum=0) -> dict:
+    """ compare.py:145-163: Pearson r2, RMSE, rRMSE and N of one band from its accumulated sums. """
+    src_mean = src_sum / mask_sum
+    ref_mean = ref_sum / mask_sum
+    pcc_num = src_ref_sum - (mask_sum * src_mean * ref_mean)
+    pcc_den = np.sqrt(src2_sum - (mask_sum * (src_mean ** 2))) * np.sqrt(ref2_sum - (mask_sum * (ref_mean ** 2)))
+    pcc = pcc_num / pcc_den
+    rmse = np.sqrt(res2_sum / mask_sum)
+    rrmse = rmse / ref_mean
+    return dict(r2=pcc ** 2, rmse=rmse, rrmse=rrmse, n=int(mask_sum))
+
+
+def compare_stats(image_sums, band_names=None) -> dict:
+    """ compare.py:142-186: per-band statistics + their 'Mean' (integers stay integers). """
+    image_stats, sum_over_bands = {}, {}
+    for band_i, band_sum_dict in enumerate(image_sums):
+        band_stats = compare_band_stats(**band_sum_dict)
+        image_stats[band_names[band_i] if band_names else f'Ref. band {band_i + 1}'] = band_stats
+        sum_over_bands = {k: sum_over_bands.get(k, 0) + v for k, v in band_stats.items()}
+    image_stats['Mean'] = {k: int(v / len(image_sums)) if isinstance(v, int) else (v / len(image_sums))
+                           for k, v in sum_over_bands.items()}
+    return image_stats
 
 
 def grid_mapping(src_transform, dst_transform):

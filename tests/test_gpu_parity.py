@@ -10,6 +10,8 @@ Bars (DESIGN.md "Numerics contract"):
 * gain-blk-offset: same, given the same block normalisation; the normalisation itself (exact float64 statistics on
   the GPU vs numpy's float32 pairwise ones) within 2e-6 relative.
 """
+import warnings
+
 import numpy as np
 import pytest
 
@@ -985,6 +987,86 @@ def test_certificate_only_build_and_its_rerun_protocol(oc, monkeypatch):
         full.close(), fresh.close()
         if 'fresh2' in locals():
             fresh2.close()
+
+
+def _exact_compare_sums(src, src_nodata, ref, ref_nodata):
+    """ float64 sums of the reference's float32 per-pixel terms (compare.py:243-255) """
+    s, r = np.array(src, np.float32), np.array(ref, np.float32)
+    m = onp.mask_of(s, src_nodata) & onp.mask_of(r, ref_nodata)
+    s[~m], r[~m] = 0, 0
+    f = lambda a: float(a.astype(np.float64).sum())  # noqa: E731
+    return np.array([f(s), f(r), f(s * s), f(r * r), f(s * r), f((r - s) ** 2), float(m.sum())])
+
+
+@pytest.mark.parametrize('shape, variant, src_nodata, ref_nodata', [
+    ((300, 761), 'frame+holes', np.nan, np.nan), ((64, 64), 'none', None, None), ((1, 5), 'none', None, np.nan),
+    ((257, 3), 'frame+holes', np.nan, None), ((2100, 1030), 'frame+holes', np.nan, np.nan),
+])
+def test_compare_sums_equal_exact_float64_sums(ctx, shape, variant, src_nodata, ref_nodata):
+    """ hk_compare_sums against numpy: same float32 per-pixel terms, float64 accumulation (order-independent to 1e-13) """
+    src, ref = onp.synth_pair(*shape, seed=3, nodata_variant=variant)
+    got = ctx.compare_sums(src, src_nodata, ref, ref_nodata)
+    exp = _exact_compare_sums(src, src_nodata, ref, ref_nodata)
+    assert got[6] == exp[6]
+    assert np.allclose(got, exp, rtol=1e-12, atol=0)
+    # against the reference's float32 pairwise sums (oracle): equal to numpy's own summation error
+    ora = onp.compare_sums(src, src_nodata, ref, ref_nodata)
+    assert np.allclose(got, [float(ora[k]) for k in onp.COMPARE_KEYS], rtol=3e-6, atol=0)
+
+
+def test_compare_sums_numeric_nodata_strided_rows_and_empty(ctx):
+    rng = np.random.default_rng(8)
+    big = np.round(rng.uniform(0, 255, (120, 400))).astype(np.float32)
+    src = big[:, 3:330]                       # rows are strided, not 16-byte aligned
+    ref = (0.7 * src + 12).astype(np.float32)
+    got = ctx.compare_sums(src, 0., ref, None)
+    assert np.allclose(got, _exact_compare_sums(src, 0., ref, None), rtol=1e-12, atol=0)
+    assert got[6] == np.count_nonzero(src)
+    none = ctx.compare_sums(np.full((40, 50), np.nan, np.float32), np.nan, ref[:40, :50], None)
+    assert not none.any()                     # nothing valid: all seven sums are zero
+    with pytest.raises(ValueError):
+        ctx.compare_sums(src, None, ref[:, :-1], None)
+
+
+def test_compare_sums_on_device_resident_bands(ctx):
+    h, w, nb = 200, 333, 3
+    stride = (w + 63) // 64 * 64
+    planes = [onp.synth_pair(h, w, 60 + b, 'frame+holes') for b in range(nb)]
+    pad = lambda k: np.stack([np.pad(p[k], ((0, 0), (0, stride - w)), constant_values=np.nan) for p in planes])  # noqa: E731
+    d = {k: ctx.dev_alloc(4 * stride * h * nb) for k in ('src', 'ref')}
+    d['sums'] = ctx.dev_alloc(8 * 7 * nb)
+    try:
+        ctx.h2d(d['src'], pad(0).astype(np.float32)), ctx.h2d(d['ref'], pad(1).astype(np.float32))
+        job = _hk.DevJob()
+        job.src, job.ref = d['src'], d['ref']
+        job.corr = job.gain = job.offset = job.r2 = job.norm = job.fail_count = None
+        job.n_bands, job.height, job.width, job.stride, job.band_stride = nb, h, w, stride, stride * h
+        job.seg_rows, job.stream = 0, 0
+        ctx.compare_sums_dev(job, np.nan, np.nan, d['sums'])
+        ctx.stream_sync(0)
+        got = np.zeros((nb, 7), np.float64)
+        ctx.d2h(got, d['sums'])
+        for b in range(nb):
+            assert np.array_equal(got[b], ctx.compare_sums(planes[b][0], np.nan, planes[b][1], np.nan)), b
+    finally:
+        for v in d.values():
+            ctx.dev_free(v)
+
+
+def test_raster_compare_matches_reference_statistics():
+    """ RasterCompare.process against the statistics of the reference's own RasterCompare.process (compare.npz),
+    block partition and thread pool included. """
+    from homonim_amd.compare import RasterCompare
+    from test_compare_cpu import assert_stats_close, compare_cases, stats_rows
+    for case in compare_cases():
+        for threads in (1, 3):
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                with RasterCompare(case['src'], case['ref'], src_nodata=case['src_nodata'], ref_nodata=case['ref_nodata'],
+                                   proc_crs=case['proc_crs']) as cmp:
+                    stats = cmp.process(threads=threads, max_block_mem=case['max_block_mem'])
+            assert list(stats.keys()) == case['bands']
+            assert_stats_close(stats_rows(stats), case['stats'])
 
 
 def test_fill_nodata_known_answers():

@@ -102,6 +102,48 @@ def test_raster_fuse_process_across_resolutions(pair, model, kernel_shape, proc_
         assert np.percentile(np.abs(whole[ok] - corr[0][ok]), 85) < 1e-3
 
 
+@pytest.mark.parametrize('proc_crs, max_block_mem', [('ref', 512), ('ref', 0.3), ('src', 0.3)])
+def test_raster_compare_across_resolutions(pair, proc_crs, max_block_mem):
+    """ RasterCompare.process on the 5 m / 10 m pair (the reference's acceptance metric, compare.py:212-278): blocks
+    cut on the processing grid, the other raster re-sampled onto it on the device, masked sums on the device.  In one
+    block on the reference grid it must agree with the numpy statistics of `_compare`; block-wise the re-sampling supports
+    differ slightly at the seams (as in the reference), and on the source grid the reference is up-sampled instead. """
+    import warnings
+    from homonim_amd.compare import RasterCompare
+    src, src_tf, src_nodata, ref, ref_tf = pair
+    crs = CRS('EPSG:32735')
+    names = ['red', 'green', 'blue'][:src.shape[0]]
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        with RasterCompare(src.astype(np.float32), ref.astype(np.float32), src_nodata=src_nodata, ref_nodata=None,
+                           proc_crs=proc_crs, crs=crs, transform=src_tf, ref_transform=ref_tf, band_names=names) as cmp:
+            stats = cmp.process(threads=2, max_block_mem=max_block_mem)
+    assert list(stats.keys()) == names + ['Mean']
+    for band, name in enumerate(names):
+        src_ra = RasterArray(src[band].astype(np.float32), crs, src_tf, nodata=src_nodata)
+        ref_ra = RasterArray(ref[band].astype(np.float32), crs, ref_tf, nodata=None)
+        exp, got = _compare(src_ra, ref_ra), stats[name]
+        if proc_crs == 'ref' and max_block_mem == 512:
+            # `_compare` averages the whole source raster, whose clamped kernel support reaches one reference column
+            # beyond the source extent; the reference's boundless source window (nodata outside) does not
+            assert 0 <= exp['n'] - got['n'] <= ref.shape[-1]
+            for k in ('r2', 'rmse', 'rrmse'):
+                assert got[k] == pytest.approx(exp[k], rel=2e-3), (name, k)
+        else:
+            assert 0 < got['r2'] <= 1 and got['n'] > 0
+            if proc_crs == 'ref':
+                assert abs(got['n'] - exp['n']) <= 0.01 * exp['n']
+                for k in ('r2', 'rmse', 'rrmse'):
+                    assert got[k] == pytest.approx(exp[k], rel=0.05), (name, k)
+            else:
+                # on the (finer) source grid: ~4x the pixels, and the 5 m detail the up-sampled reference cannot
+                # explain lowers the correlation / raises the error somewhat
+                assert got['n'] > 3 * exp['n']
+                assert 0.8 * exp['r2'] < got['r2'] < exp['r2']
+                assert exp['rmse'] < got['rmse'] < 1.25 * exp['rmse']
+    assert stats['Mean']['r2'] == pytest.approx(np.mean([stats[n]['r2'] for n in names]), rel=1e-12)
+
+
 def utils_overlap(kernel_shape):
     from homonim_amd import utils
     return utils.overlap_for_kernel(kernel_shape)
