@@ -99,8 +99,9 @@ int hk_compare_sums(hk_ctx* ctx, const float* src, int64_t src_stride, int32_t s
  *   norm_out   : optional float64[2], receives the normalisation actually used.
  *   r2_fail_count : optional; gain-offset with has_r2_thresh: number of valid pixels failing
  *                (r2 > thresh) & (gain > 0) (kernel_model.py:363).  When it is 0 the reference's in-paint branch is
- *                the identity and params_out equals the reference's output; when > 0 the caller must in-paint
- *                (params_out then holds the pre-in-paint parameters).
+ *                the identity; when > 0 the offsets of those pixels have been in-painted from the passing ones and
+ *                their gains recomputed on the device (kernel_model.py:364-371; restated GDALFillNodata, hk_inpaint.hip)
+ *                before params_out is written.
  * Unlike the reference, src/ref are NOT modified (no in-place zero-fill, kernel_model.py:246-247,320-321). */
 int hk_fit(hk_ctx* ctx, const hk_fit_desc* desc, const float* src, int64_t src_stride, const float* ref,
            int64_t ref_stride, int32_t height, int32_t width, const double* norm_in, float* params_out,
