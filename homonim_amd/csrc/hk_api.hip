@@ -532,7 +532,9 @@ int hk_ctx_create(int device_id, int n_streams, hk_ctx** out) {
     ctx->device = device_id;
     ctx->slots.resize(n_streams);
     const char* remap = getenv("HK_XCD_REMAP");
-    ctx->xcd_remap = remap ? atoi(remap) : 0;
+    // runs of this many consecutive units (neighbouring strips) per XCD, 0 = plain round-robin (hk_kernels.hip); 16 measured
+    // best across models on MI355X (gain 5x5: -12 %, gain-offset without the r2 mask: -4 %, VALU-bound variants: -1 %)
+    ctx->xcd_remap = remap ? std::min(std::max(atoi(remap), 0), 256) : 16;
     if (const char* e = getenv("HK_CERT_ONLY")) ctx->cert_disabled = atoi(e) == 0;
     for (auto& s : ctx->slots) {
         hipError_t e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);

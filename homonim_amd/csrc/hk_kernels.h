@@ -48,7 +48,7 @@ struct FitArgs {
     double inv_n_full;      // RN64(1 / (kh * kw)) -- the 1/N table entry (hk_kernels.hip)
     int force_general;      // 1: never take the dense (nodata None) specialisation (testing)
     int use_ring;           // ring mode of fit_apply_kernel: 1 full LDS ring, 2 centre ring + re-loaded leaving row, 0 re-load both
-    int xcd_remap;          // 1: blockIdx -> unit remap that keeps neighbouring units on one XCD
+    int xcd_remap;          // G > 0: blockIdx -> unit remap handing each XCD runs of G consecutive units (0: round-robin)
 };
 
 // model: 0 gain, 1 gain-blk-offset, 2 gain-offset.  with_r2: compute the R2 quantity set.

@@ -430,8 +430,11 @@ fit_apply_kernel(const FitArgs a) {
     const int lane = threadIdx.x;
     int unit = blockIdx.x;
     if (a.xcd_remap) {
-        const int per_xcd = gridDim.x >> 3;
-        unit = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+        // workgroups go round-robin to the 8 XCDs (each with its own L2): hand every XCD runs of `xcd_remap` consecutive
+        // units, i.e. neighbouring strips of one segment, whose shared cache lines (strips start 16-byte-, not 128-byte-
+        // aligned, and overlap by two lanes) are then fetched from HBM once instead of once per strip
+        const int g = a.xcd_remap, slot = blockIdx.x >> 3;
+        unit = ((slot / g) * 8 + (blockIdx.x & 7)) * g + slot % g;
     }
     if (unit >= a.total_units) return;
     // segment-major order: the short tail segments (hk_api.hip fill_grid) are dispatched last
@@ -975,7 +978,7 @@ static hipError_t launch_build(const FitArgs& a, hipStream_t stream) {
         if (e != hipSuccess) return e;
     }
     int grid = a.total_units;
-    if (a.xcd_remap) grid = (grid + 7) / 8 * 8;
+    if (a.xcd_remap) grid = (grid + 8 * a.xcd_remap - 1) / (8 * a.xcd_remap) * (8 * a.xcd_remap);
     hipLaunchKernelGGL((fit_apply_kernel<MODEL, R2, RW, DENSE, RING, CERT_ONLY>), dim3(grid), dim3(WAVE), lds, stream, a);
     return hipGetLastError();
 }
@@ -983,7 +986,7 @@ static hipError_t launch_build(const FitArgs& a, hipStream_t stream) {
 // gain-offset with the r2 mask exists in two builds.  The FULL one carries the reference's R2 expression inline for the
 // wave-rows the float32 certificate cannot settle (and for R2 output): 154 VGPRs, 3 waves per SIMD.  The CERTIFICATE-ONLY
 // one (a.cert_only, chosen by the host when no R2 plane is written and the previous launch had no failures) has nothing
-// but the certificate: 128 VGPRs and no LDS table = 4 waves per SIMD (-9 % on clean rasters); a wave-row it cannot settle
+// but the certificate: 128 VGPRs and no LDS table = 4 waves per SIMD (-5 % on clean rasters); a wave-row it cannot settle
 // sets FIT_RETRY_BIT in the band's fail counter and the host re-runs the band with the full build.
 template <int MODEL, bool R2, int RW, bool DENSE, int RING>
 static hipError_t launch_one(const FitArgs& a, hipStream_t stream) {
