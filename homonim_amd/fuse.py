@@ -14,7 +14,8 @@ model.apply -> write`` on a thread pool (fuse.py:295-319,396-408).  This module 
 * blocks are independent: they shard round-robin over the GPUs of a node (one context per device inside one process)
   and/or over ranks (one process per GPU), with no data-path collective.
 
-GeoTIFF reading/writing, band matching and re-projection stay outside (GDAL IO).
+Rasters may also be given / written as GeoTIFF paths (homonim_amd/tiff.py: the classic-TIFF subset the reference's
+rasters use); band matching by wavelength and re-projection BETWEEN CRSs stay outside (GDAL).
 """
 import math
 import os
@@ -216,9 +217,10 @@ def shard(items: Sequence, index: int, count: int) -> List:
 
 class RasterFuse:
     """
-    Correct a source raster to surface reflectance by fusion with a reference raster on the same grid.
+    Correct a source raster to surface reflectance by fusion with a reference raster of the same CRS.
 
-    src, ref : float32 arrays (bands, height, width) or (height, width); ``RasterArray`` instances are accepted too.
+    src, ref : float32 arrays (bands, height, width) or (height, width), ``RasterArray`` instances, or GeoTIFF paths
+    (nodata, CRS and geo-transform then come from the files; bands are paired in file order).
     The other constructor arguments mirror homonim.RasterFuse / RasterPairReader where they make sense in memory.
     """
 
@@ -233,6 +235,19 @@ class RasterFuse:
         they (or the shapes) differ, blocks are cut on the processing grid and re-sampled on the device as the
         reference does through GDAL (RefSpaceModel / SrcSpaceModel); the reference must cover the source.
         """
+        self._src_filename = self._ref_filename = None
+        if isinstance(src, (str, os.PathLike)):  # a GeoTIFF, as homonim.RasterFuse(src_filename, ref_filename, ...)
+            from homonim_amd.tiff import read_tiff
+            self._src_filename = os.fspath(src)
+            tif = read_tiff(src)
+            src, src_nodata, crs, transform = tif.array, tif.nodata, tif.crs, tif.transform
+        if isinstance(ref, (str, os.PathLike)):
+            from homonim_amd.tiff import read_tiff
+            self._ref_filename = os.fspath(ref)
+            tif = read_tiff(ref)
+            if crs is not None and tif.crs != crs:
+                raise NotImplementedError('source and reference CRSs differ: re-projection between CRSs is not built (GDAL warp)')
+            ref, ref_nodata, ref_transform = tif.array, tif.nodata, tif.transform
         if isinstance(src, RasterArray):
             src, src_nodata, crs, transform = src.array, src.nodata, src.crs, src.transform
         if isinstance(ref, RasterArray):
@@ -407,9 +422,9 @@ class RasterFuse:
         """
         Same arguments as homonim.RasterFuse.process (fuse.py:321-332) plus ``device_config``.  Returns
         ``(corrected, params)``: float32 arrays (bands, H, W) and (n_param_bands * bands, H, W) or None.  When
-        ``corr_filename`` / ``param_filename`` are paths the arrays are also saved with ``numpy.save`` (GeoTIFF output
-        belongs to the GDAL side of the reference; ``build_ovw`` and ``out_profile['driver'|'creation_options']`` are
-        accepted and ignored).  With ``world_size > 1`` only this rank's blocks are filled in (others stay nodata).
+        ``corr_filename`` / ``param_filename`` are paths the arrays are also written there: ``.tif`` as a tiled DEFLATE
+        GeoTIFF with the reference's FUSE_* provenance tags (homonim_amd/tiff.py), anything else with ``numpy.save``
+        (``build_ovw`` and ``out_profile['driver'|'creation_options']`` are accepted and ignored).  With ``world_size > 1`` only this rank's blocks are filled in (others stay nodata).
         """
         if self._closed:
             raise IoError('The raster pair has been closed')
@@ -462,11 +477,27 @@ class RasterFuse:
                 for f in as_completed(futures):
                     f.result()  # re-raise worker exceptions (fuse.py:404-408)
 
-        if isinstance(corr_filename, (str, os.PathLike)):
-            np.save(corr_filename, corr)
-        if want_params and isinstance(param_filename, (str, os.PathLike)):
-            np.save(param_filename, params)
+        if isinstance(corr_filename, (str, os.PathLike)) or (want_params and isinstance(param_filename, (str, os.PathLike))):
+            # provenance tags of homonim/fuse.py:193-207
+            meta = dict(FUSE_SRC_FILE=os.path.basename(self._src_filename or 'memory'),
+                        FUSE_REF_FILE=os.path.basename(self._ref_filename or 'memory'), FUSE_PROC_CRS=self._proc_crs.name,
+                        FUSE_MODEL=model_type.name, FUSE_KERNEL_SHAPE=tuple(kernel_shape),
+                        **{f'FUSE_{k.upper()}': getattr(v, 'name', v) for k, v in model_config.items()})
+            if isinstance(corr_filename, (str, os.PathLike)):
+                self._save(corr_filename, corr, self._transform, nodata, meta)
+            if want_params and isinstance(param_filename, (str, os.PathLike)):
+                param_tf = self._ref_transform if (self._proc_crs == ProcCrs.ref and not self._same_grid) else self._transform
+                self._save(param_filename, params, param_tf, float('nan'), meta)
         return corr, params
+
+    def _save(self, filename, array: np.ndarray, transform: Affine, nodata, metadata: Dict):
+        """ ``.tif`` / ``.tiff``: tiled DEFLATE GeoTIFF like the reference's default output profile (no overviews);
+        anything else: ``numpy.save``. """
+        if os.fspath(filename).lower().endswith(('.tif', '.tiff')):
+            from homonim_amd.tiff import write_tiff
+            write_tiff(filename, array, transform, self._crs, nodata, {k: str(v) for k, v in metadata.items()})
+        else:
+            np.save(filename, array)
 
 
 def convert_dtype(array: np.ndarray, dtype: str, nodata: Optional[float]) -> np.ndarray:

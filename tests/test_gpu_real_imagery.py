@@ -144,6 +144,50 @@ def test_raster_compare_across_resolutions(pair, proc_crs, max_block_mem):
     assert stats['Mean']['r2'] == pytest.approx(np.mean([stats[n]['r2'] for n in names]), rel=1e-12)
 
 
+def test_geotiff_in_geotiff_out(pair, tmp_path):
+    """ The reference's file-level workflow (fuse.py:321-408, compare.py:212-278) on GeoTIFFs: RasterFuse(src.tif,
+    ref.tif).process(corr.tif, ..., param_filename=param.tif) equals the in-memory run, the outputs carry the
+    geo-referencing / nodata / FUSE_* tags, and RasterCompare on the files shows the improvement. """
+    import warnings
+    from homonim_amd.compare import RasterCompare
+    from homonim_amd.fuse import RasterFuse
+    from homonim_amd.tiff import read_tiff, write_tiff
+    src, src_tf, src_nodata, ref, ref_tf = pair
+    crs = CRS('EPSG:32735')
+    src_path, ref_path = tmp_path / 'src.tif', tmp_path / 'ref.tif'
+    corr_path, param_path = tmp_path / 'corr.tif', tmp_path / 'param.tif'
+    write_tiff(src_path, src, src_tf, crs, src_nodata, tile=256)
+    write_tiff(ref_path, ref, ref_tf, crs, None, tile=256)
+    kw = dict(model='gain-blk-offset', kernel_shape=(5, 5), out_profile=dict(dtype='uint8', nodata=0),
+              block_config=dict(threads=2, max_block_mem=0.3))
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        with RasterFuse(src_path, ref_path) as rf:
+            assert rf.proc_crs.name == 'ref'
+            corr, params = rf.process(corr_path, param_filename=param_path, **kw)
+        with RasterFuse(src, ref, src_nodata=src_nodata, ref_nodata=None, crs=crs, transform=src_tf, ref_transform=ref_tf) as rf:
+            corr_mem, params_mem = rf.process(None, param_filename=True, **kw)
+    assert corr.dtype == np.uint8 and np.array_equal(corr, corr_mem) and np.array_equal(params, params_mem, equal_nan=True)
+    out = read_tiff(corr_path)
+    assert np.array_equal(out.array, corr) and out.nodata == 0 and out.transform == src_tf and out.crs == crs
+    assert out.metadata['FUSE_MODEL'] == 'gain_blk_offset' and out.metadata['FUSE_PROC_CRS'] == 'ref'
+    assert out.metadata['FUSE_SRC_FILE'] == 'src.tif' and out.metadata['FUSE_KERNEL_SHAPE'] == '(5, 5)'
+    par = read_tiff(param_path)
+    assert par.array.dtype == np.float32 and par.array.shape == (3 * src.shape[0], *ref.shape[-2:])
+    assert np.array_equal(par.array, params, equal_nan=True) and np.isnan(par.nodata) and par.transform == ref_tf
+    with pytest.raises(FileExistsError):
+        with RasterFuse(src_path, ref_path) as rf:
+            rf.process(corr_path, **kw)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        with RasterCompare(src_path, ref_path) as cmp:
+            before = cmp.process(threads=1)
+        with RasterCompare(corr_path, ref_path) as cmp:
+            after = cmp.process(threads=1)
+    assert after['Mean']['r2'] > before['Mean']['r2'] and after['Mean']['rmse'] < before['Mean']['rmse']
+    assert after['Mean']['rrmse'] < before['Mean']['rrmse'] and after['Mean']['n'] == before['Mean']['n']
+
+
 def utils_overlap(kernel_shape):
     from homonim_amd import utils
     return utils.overlap_for_kernel(kernel_shape)
