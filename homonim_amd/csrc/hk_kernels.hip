@@ -573,6 +573,7 @@ fit_apply_kernel(const FitArgs a) {
     zold_next.m = 0u, zold_next.clean = false;
     unsigned nfail = 0;
     [[maybe_unused]] int cert_skip = 0;  // wave-uniform: rows for which the r2-mask certificate is not attempted
+    [[maybe_unused]] bool gave_up = false;  // wave-uniform, certificate-only build: this wave has asked for the re-run
     int slot = 0;
     int slot2 = 0;  // RING 2: write slot of the centre ring
     int slot_c = kh - rh;  // slot of the centre row of the output produced at this iteration: (slot - rh) mod kh
@@ -826,11 +827,16 @@ fit_apply_kernel(const FitArgs a) {
                         if constexpr (CERT_ONLY) {
                             // this build holds no exact evaluation (which would cost the whole kernel a wave per SIMD): a
                             // wave-row the certificate cannot settle invalidates the launch -- the host sees the flag and
-                            // runs the full build instead (hk_api.hip), remembering to start with it next time.  (Ending the
-                            // wave here also keeps the allocator at 128 VGPRs without spills; carrying on costs 16 spilled.)
-                            if (exact) {  // the launch is void from here on: flag it and stop working on this unit
-                                if (lane == 0) atomicOr(a.fail_count + band, FIT_RETRY_BIT);
-                                return;
+                            // runs the full build instead (hk_api.hip), remembering to start with it next time.  The wave says
+                            // so ONCE (an atomic per uncertain row from every wave, all on one address, made such a launch take
+                            // 50 ms) and carries on, its results void.  Ending the wave here instead (s_endpgm, or a flag handed
+                            // out of this lambda) would cut an aborted launch from 3.3 to 0.13 ms but costs the 128-VGPR
+                            // allocation two spilled registers = +1.5 % on every clean launch; aborted launches are rare
+                            // (the host backs off after each).
+                            if (exact) {
+                                if (!gave_up && lane == 0) atomicOr(a.fail_count + band, FIT_RETRY_BIT);
+                                gave_up = true;
+                                return;  // leaves this row's pointwise lambda (skipping its stage C also keeps the allocation spill-free)
                             }
                         } else if (exact) {
                             double sstot[PX], ssres[PX];
