@@ -505,11 +505,13 @@ fit_apply_kernel(const FitArgs a) {
     // f64(t) * RN64(1/N) is within 2^-52 of it -- so rounding that product to float32 IS the IEEE float32 division.
     double* inv_lut = reinterpret_cast<double*>(ring_m + (DENSE ? (size_t)0 : (size_t)ring_rows * WAVE));  // dense: no mask ring
     const bool lut_ok = GO && kh * (2 * rw + 1) <= 255;  // the product trick is proven for window counts < 2^8
-    // the certificate-only build keeps no table in LDS (10 KB per wave = 16 waves per CU): away from the edges N is a
-    // kernel argument anyway, elsewhere it divides (IEEE float32, identical result)
-    const bool use_lut = lut_ok && !CERT_ONLY;
+    // The table has fit_lut_entries() = kh * kw + 1 (rounded up to 32) entries: 256 B for 5x5.  The DENSE certificate-only
+    // build keeps none (its 10 KB ring gives exactly 16 waves per CU): away from the edges N is a kernel argument anyway,
+    // elsewhere it divides (IEEE float32, identical result).  With nodata almost every wave-row has a window with a hole,
+    // i.e. per-pixel N, and the mask ring has taken the sixteenth wave already: those builds keep the table.
+    const bool use_lut = lut_ok && !(CERT_ONLY && DENSE);
     if (use_lut)
-        for (int n = lane; n < 256; n += WAVE) inv_lut[n] = 1.0 / (double)n;
+        for (int n = lane; n < fit_lut_entries(kh, 2 * rw + 1); n += WAVE) inv_lut[n] = 1.0 / (double)n;
 
     CS cs;
     cs.clear();
@@ -965,19 +967,19 @@ fit_apply_kernel(const FitArgs a) {
     }
 }
 
-// LDS bytes of one wave: the row ring of the mode (see fit_apply_kernel) + the 256-entry float64 1/N table that only the
+// LDS bytes of one wave: the row ring of the mode (see fit_apply_kernel) + the float64 1/N table (fit_lut_entries) that only the
 // gain-offset model reads (the HBM-bound `gain` kernel gets one more resident wave per SIMD without it)
-size_t fit_lds_bytes(int kh, int ring_mode, bool with_lut, bool with_mask) {
+size_t fit_lds_bytes(int kh, int kw, int ring_mode, bool with_lut, bool with_mask) {
     const size_t mask = with_mask ? WAVE * sizeof(unsigned) : 0;
     size_t ring = 0;
     if (ring_mode == 1) ring = (size_t)kh * (2 * WAVE * sizeof(float4) + mask);
     if (ring_mode == 2) ring = (size_t)(kh / 2 + 1) * (WAVE * sizeof(float4) + mask);
-    return ring + (with_lut ? 256 * sizeof(double) : 0);
+    return ring + (with_lut ? fit_lut_entries(kh, kw) * sizeof(double) : 0);
 }
 
 template <int MODEL, bool R2, int RW, bool DENSE, int RING, bool CERT_ONLY>
 static hipError_t launch_build(const FitArgs& a, hipStream_t stream) {
-    const size_t lds = fit_lds_bytes(2 * a.rh + 1, RING, MODEL == 2 && !CERT_ONLY, !DENSE);
+    const size_t lds = fit_lds_bytes(2 * a.rh + 1, 2 * a.rw + 1, RING, MODEL == 2 && !(CERT_ONLY && DENSE), !DENSE);
     if (lds > 64 * 1024) {  // forced LDS ring on a tall kernel (testing): raise the 64 KiB dynamic-LDS default
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fit_apply_kernel<MODEL, R2, RW, DENSE, RING, CERT_ONLY>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
