@@ -31,6 +31,7 @@ constexpr int SAMPLE_N = 4096;     // sample size per band (sorted in LDS by one
 constexpr int PASS_WAVES = 2048;   // waves per band in the streaming pass (also the number of partials)
 constexpr int STAGE_N = 512;       // wave-private LDS staging slots per raster
 constexpr int FB_BLOCKS = 512;     // workgroups per band of the fallback passes
+constexpr int MID_BLOCKS = 256;    // workgroups per compacted buffer of the regular select passes
 
 struct Sel {
     unsigned prefix;          // key bits fixed so far (right-aligned)
@@ -325,8 +326,36 @@ __global__ void __launch_bounds__(NORM_THREADS) norm_mid_hist_kernel(NormWS* __r
     const float* __restrict__ buf = mid_all + ((size_t)band * 2 + q) * mid_cap;
     const unsigned cnt = ws.mid_count[q];
     const unsigned pfx[2] = {ws.sel[q][0].prefix, ws.sel[q][1].prefix};
-    for (unsigned i = blockIdx.x * NORM_THREADS + threadIdx.x; i < cnt; i += gridDim.x * NORM_THREADS)
-        hist_add(hist, LEVEL, f2key(buf[i]), pfx);
+    // 16-byte loads (the buffers are 256-byte aligned), MID_BLOCKS workgroups per buffer: the pass is bound by the loads in
+    // flight, not by the LDS atomics
+    const float4* __restrict__ buf4 = reinterpret_cast<const float4*>(buf);
+    const unsigned cnt4 = cnt >> 2;
+    for (unsigned i = blockIdx.x * NORM_THREADS + threadIdx.x; i < cnt4; i += gridDim.x * NORM_THREADS) {
+        const float4 v = buf4[i];
+        if (LEVEL == 0) {
+            // the compacted values lie between two pivots: nearly all share their top digit.  One LDS atomic per wave for the
+            // lanes whose four values all carry the first lane's digit, plain atomics for the (few) other lanes.
+            const unsigned bin[4] = {f2key(v.x) >> (32 - L1_BITS), f2key(v.y) >> (32 - L1_BITS), f2key(v.z) >> (32 - L1_BITS),
+                                     f2key(v.w) >> (32 - L1_BITS)};
+            const int lane = threadIdx.x & 63;
+            const unsigned b0 = __shfl(bin[0], __ffsll((unsigned long long)__ballot(1)) - 1);
+            const bool all4 = bin[0] == b0 && bin[1] == b0 && bin[2] == b0 && bin[3] == b0;
+            const unsigned long long full = __ballot(all4);
+            if (all4) {
+                if (lane == __ffsll(full) - 1) {
+                    atomicAdd(&hist[b0], 4u * (unsigned)__popcll(full));
+                    atomicAdd(&hist[L1_BINS + b0], 4u * (unsigned)__popcll(full));
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) atomicAdd(&hist[bin[j]], 1u), atomicAdd(&hist[L1_BINS + bin[j]], 1u);
+            }
+        } else {
+            hist_add(hist, LEVEL, f2key(v.x), pfx), hist_add(hist, LEVEL, f2key(v.y), pfx);
+            hist_add(hist, LEVEL, f2key(v.z), pfx), hist_add(hist, LEVEL, f2key(v.w), pfx);
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (cnt & 3u)) hist_add(hist, LEVEL, f2key(buf[(cnt & ~3u) + threadIdx.x]), pfx);
     __syncthreads();
     unsigned* gh = LEVEL == 0 ? &ws.hist1[q][0][0] : (LEVEL == 1 ? &ws.hist2[q][0][0] : &ws.hist3[q][0][0]);
     for (int i = threadIdx.x; i < 2 * NB; i += NORM_THREADS)
@@ -437,7 +466,7 @@ hipError_t launch_block_norm(const NormArgs& a, void* workspace, double* norm_ou
     hipLaunchKernelGGL(norm_sample_kernel, bands, dim3(1024), 0, stream, a, ws);
     hipLaunchKernelGGL(norm_stream_kernel, dim3(PASS_WAVES, a.n_bands), dim3(WAVE), 0, stream, a, ws, mid, cap_al);
     hipLaunchKernelGGL(norm_stats_kernel, bands, dim3(64), 0, stream, ws, norm_out, cap_al);
-    const dim3 gmid(64, a.n_bands * 2), gfull(FB_BLOCKS, a.n_bands);
+    const dim3 gmid(MID_BLOCKS, a.n_bands * 2), gfull(FB_BLOCKS, a.n_bands);
     hipLaunchKernelGGL(norm_mid_hist_kernel<0>, gmid, block, 0, stream, ws, mid, cap_al);
     hipLaunchKernelGGL(norm_full_hist_kernel<0>, gfull, block, 0, stream, a, ws);
     hipLaunchKernelGGL(norm_select_kernel<0>, bands, block, 0, stream, ws, norm_out);
