@@ -33,6 +33,18 @@ def test_library_exports_every_declared_symbol(lib):
     assert declared == set(_hk.SIGNATURES)
 
 
+def test_header_is_plain_c_and_a_c_program_can_drive_the_library(lib, tmp_path):
+    """ The boundary is a C ABI: include/homonim_hk.h compiles as strict C99 and a C program (tests/c/abi_consumer.c)
+    dlopens the library, checks struct layout and error behaviour -- and, without a GPU, that contexts are refused. """
+    import subprocess
+    exe = tmp_path / 'abi_consumer'
+    subprocess.run(['gcc', '-std=c99', '-pedantic', '-Wall', '-Werror', '-I', os.path.join(REPO, 'include'),
+                    os.path.join(REPO, 'tests', 'c', 'abi_consumer.c'), '-o', str(exe), '-ldl'], check=True)
+    run = subprocess.run([str(exe), _hk.lib_path()], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, (run.returncode, run.stdout, run.stderr)
+    assert 'abi_consumer: ok' in run.stdout
+
+
 def test_backend_name_and_struct_layout(lib):
     assert lib.hk_backend_name() == b'hip-gfx950'
     assert ctypes.sizeof(_hk.FitDesc) == 40  # 10 x 4-byte fields, matches hk_fit_desc

@@ -1069,6 +1069,19 @@ def test_raster_compare_matches_reference_statistics():
             assert_stats_close(stats_rows(stats), case['stats'])
 
 
+def test_c_program_drives_the_library_on_the_gpu(tmp_path):
+    """ tests/c/abi_consumer.c (plain C99, dlopen) with a GPU present: context, one compute call, known answer. """
+    import os
+    import subprocess
+    from conftest import REPO
+    exe = tmp_path / 'abi_consumer'
+    subprocess.run(['gcc', '-std=c99', '-pedantic', '-Wall', '-Werror', '-I', os.path.join(REPO, 'include'),
+                    os.path.join(REPO, 'tests', 'c', 'abi_consumer.c'), '-o', str(exe), '-ldl'], check=True)
+    run = subprocess.run([str(exe), _hk.lib_path()], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, (run.returncode, run.stdout, run.stderr)
+    assert 'ok (GPU present)' in run.stdout
+
+
 def test_fill_nodata_known_answers():
     """ the restated GDAL fill on hand-checkable cases (oracle only; the GPU version is compared with it above). """
     img = np.zeros((5, 7), np.float32)
