@@ -124,8 +124,8 @@ def measured_traffic(args):
         with open(os.path.join(REPO, 'profiles', 'pmc_summary.json')) as f:
             pmc = json.load(f)
         c = pmc['config']
-        if (c['model'], c['kernel'], c['size'], c['bands'], c['nodata']) == (args.model, args.kernel, args.size,
-                                                                           args.bands, args.nodata):
+        if (c['model'], c['kernel'], c['size'], c['bands'], c['nodata'], bool(c.get('no_thresh', False))) == (
+                args.model, args.kernel, args.size, args.bands, args.nodata, bool(args.no_thresh)):
             return float(pmc['hbm_traffic_bytes'])
     except Exception:
         pass

@@ -14,5 +14,5 @@ for g in "${groups[@]}"; do
   (cd /tmp && timeout 300 rocprofv3 --pmc $g --kernel-trace -d "$out" -o run --output-format csv -- python3 "$root/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-parity "$@" > "$out.log" 2>&1)
   i=$((i+1))
 done
-python3 "$root/tools/pmc_summarise.py" "$tag" > "$root/gpurun_out/pmc_${tag}_summary.json"
+python3 "$root/tools/pmc_summarise.py" "$tag" "$@" > "$root/gpurun_out/pmc_${tag}_summary.json"
 cat "$root/gpurun_out/pmc_${tag}_summary.json"

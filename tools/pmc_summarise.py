@@ -28,4 +28,21 @@ if 'SQ_ACTIVE_INST_VALU' in c and 'GRBM_GUI_ACTIVE' in c:
     out['valu_busy_fraction'] = c['SQ_ACTIVE_INST_VALU'] * 4 / (c['GRBM_GUI_ACTIVE'] / 8 * 1024)
     out['cycles_per_valu_inst'] = c['SQ_ACTIVE_INST_VALU'] * 4 / c['SQ_INSTS_VALU']
     out['valu_insts_per_wave'] = c['SQ_INSTS_VALU'] / c['SQ_WAVES']
+# the bench.py arguments the passes ran with (tools/pmc_collect.sh hands them on): bench.py reports `roofline.traffic`
+# from this file only at exactly this configuration
+import argparse
+ap = argparse.ArgumentParser()
+ap.add_argument('--size', type=int, default=16384), ap.add_argument('--bands', type=int, default=4)
+ap.add_argument('--model', default='gain-offset'), ap.add_argument('--kernel', type=int, default=5)
+ap.add_argument('--nodata', type=int, default=0), ap.add_argument('--no-thresh', action='store_true')
+cfg, _ = ap.parse_known_args(sys.argv[2:])
+out['config'] = dict(model=cfg.model, kernel=cfg.kernel, size=cfg.size, bands=cfg.bands, nodata=cfg.nodata,
+                     no_thresh=cfg.no_thresh)
+if 'hbm_read_bytes' in out and 'hbm_write_bytes' in out:
+    out['hbm_traffic_bytes'] = out['hbm_read_bytes'] + out['hbm_write_bytes']
+    out['algorithmic_bytes'] = 12 * cfg.size * cfg.size * cfg.bands
+    out['traffic_over_algorithmic'] = out['hbm_traffic_bytes'] / out['algorithmic_bytes']
+out['note'] = ('rocprofv3 --pmc passes (tools/pmc_collect.sh: separate runs, --kernel-trace only) of bench.py at this config; '
+               'per-launch means over the fit_apply_kernel dispatches; FETCH_SIZE (KiB) doubled per the gfx950 correction of '
+               'MI355X_MICROARCH.md; SQ_* are quad-cycles / wave-instructions')
 print(json.dumps(out, indent=1))
