@@ -20,7 +20,7 @@ import numpy as np
 
 from homonim_amd.enums import Resampling
 from homonim_amd.errors import ImageProfileError
-from homonim_amd.geo import Affine, CRS, Window, _is_affine, _is_crs, grid_mapping, window_transform
+from homonim_amd.geo import Window, _is_affine, _is_crs, grid_mapping, window_transform
 from homonim_amd.utils import nan_equals
 
 _PROFILE_GEO_KEYS = ('crs', 'transform', 'nodata')

@@ -6,14 +6,13 @@ imports the oracle.
 import ctypes
 import os
 import re
-import warnings
 
 import numpy as np
 import pytest
 
 from conftest import REPO
 from homonim_amd import (Affine, ConfigWarning, CRS, DeviceError, KernelModel, Model, RasterArray, RefSpaceModel,
-                         Resampling, SrcSpaceModel, _hk, utils)
+                         Resampling, _hk, utils)
 
 
 @pytest.fixture(scope='module')

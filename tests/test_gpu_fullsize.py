@@ -11,13 +11,11 @@ size-independent properties + oracle checks on windows.  Device-resident data, t
 * r2-mask bookkeeping: the failure counter equals the number of failing pixels the oracle finds in those windows' union
   when it is zero (clean data).
 """
-import os
 
 import numpy as np
 import pytest
 
 from homonim_amd import _hk
-from oracle import oracle_np as onp
 
 pytestmark = pytest.mark.gpu
 
