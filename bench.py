@@ -40,6 +40,7 @@ def parse_args():
     p.add_argument('--seg-rows', type=int, default=0)
     p.add_argument('--nodata', type=int, default=0, help='0: no nodata, 1: NaN frame + 0.1%% holes, 2: NaN frame only, 3 / 4: no nodata, noisy reference (35 %% / 85 %% of the pixels fail the r2 mask)')
     p.add_argument('--no-thresh', action='store_true', help='gain-offset without r2_inpaint_thresh (no R2 work)')
+    p.add_argument('--params', action='store_true', help='also materialise the gain / offset / R2 planes in the fused launch (find_r2=True; 24 B per pixel*band of HBM traffic, reported against the same 12 algorithmic bytes)')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-parity', action='store_true')
     p.add_argument('--cpu-sample', type=int, default=0, help='CPU baseline sample size (square); 0 = auto')
@@ -125,7 +126,7 @@ def measured_traffic(args):
             pmc = json.load(f)
         c = pmc['config']
         if (c['model'], c['kernel'], c['size'], c['bands'], c['nodata'], bool(c.get('no_thresh', False))) == (
-                args.model, args.kernel, args.size, args.bands, args.nodata, bool(args.no_thresh)):
+                args.model, args.kernel, args.size, args.bands, args.nodata, bool(args.no_thresh)) and not args.params:
             return float(pmc['hbm_traffic_bytes'])
     except Exception:
         pass
@@ -148,9 +149,9 @@ def main():
     plane_bytes = 4 * band_stride * B
     thresh = 0.25 if (args.model == 'gain-offset' and not args.no_thresh) else None
     nd = np.nan if args.nodata in (1, 2) else None
-    desc = _hk.make_desc(args.model, (k, k), False, thresh, nd, nd)
+    desc = _hk.make_desc(args.model, (k, k), bool(args.params), thresh, nd, nd)
 
-    bufs = {name: ctx.dev_alloc(plane_bytes) for name in ('src', 'ref', 'corr')}
+    bufs = {name: ctx.dev_alloc(plane_bytes) for name in ('src', 'ref', 'corr') + (('gain', 'offset', 'r2') if args.params else ())}
     bufs['fail'] = ctx.dev_alloc(8 * B)
     bufs['norm'] = ctx.dev_alloc(16 * B)
     ctx.memset(bufs['fail'], 0, 8 * B)
@@ -161,6 +162,8 @@ def main():
     job = _hk.DevJob()
     job.src, job.ref, job.corr = bufs['src'], bufs['ref'], bufs['corr']
     job.gain = job.offset = job.r2 = None
+    if args.params:
+        job.gain, job.offset, job.r2 = bufs['gain'], bufs['offset'], bufs['r2']
     job.fail_count = bufs['fail']
     job.norm = bufs['norm'] if args.model == 'gain-blk-offset' else None
     job.n_bands, job.height, job.width, job.stride, job.band_stride = B, H, W, stride, band_stride
@@ -254,7 +257,10 @@ def main():
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32 in/out, f64 window sums', 'data': 'synthetic',
             'config': {
                 'workload': f'synthetic float32 {B}-band {H}x{W} src/ref resident in HBM per GPU, Model.{args.model}, '
-                            f'kernel {k}x{k}, r2_inpaint_thresh {thresh}, fused fit+apply (BASELINE.json configs[2])',
+                            f'kernel {k}x{k}, r2_inpaint_thresh {thresh}, fused fit+apply'
+                            + (' + gain / offset / R2 planes written' if args.params else '')
+                            + (' (BASELINE.json configs[2])' if (args.model, k, H, B, args.nodata, args.no_thresh, args.params)
+                               == ('gain-offset', 5, 16384, 4, 0, False, False) else ''),
                 'bands': B, 'height': H, 'width': W, 'nodata_variant': args.nodata,
                 'parallelism': f'{world} rank(s) x 1 GPU, independent rasters, no collective',
                 'r2_mask_failures_per_step': n_fail,

@@ -20,3 +20,5 @@ run --kernel 15 --nodata 1
 run --model gain-blk-offset
 run --model gain-blk-offset --kernel 15 --bands 8
 run --nodata 3
+run --params
+run --model gain --params
