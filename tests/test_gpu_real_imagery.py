@@ -4,6 +4,9 @@ nodata 0, vs Sentinel-2 10 m; grids offset by a fraction of a pixel -- tests/gol
 oracle/extract_real_imagery.py) through the full RefSpaceModel / SrcSpaceModel pipeline: average down-sampling, kernel
 model fit, cubic-spline up-sampling of the parameters (or of the reference), apply.
 
+`test_reference_rasters_fuse_then_compare` runs the full-size pair itself, file to file (tests/golden/rasters: the two
+data files, read and written by homonim_amd/tiff.py), as the reference's integration test does.
+
 GDAL is not available, so the acceptance bar is the reference's own integration criterion
 (tests/integration.py:79-83): the corrected image agrees better with the reference than the source did -- r2 up,
 RMSE and rRMSE down, per band -- plus the mask rules of :85-103.
@@ -186,6 +189,66 @@ def test_geotiff_in_geotiff_out(pair, tmp_path):
             after = cmp.process(threads=1)
     assert after['Mean']['r2'] > before['Mean']['r2'] and after['Mean']['rmse'] < before['Mean']['rmse']
     assert after['Mean']['rrmse'] < before['Mean']['rrmse'] and after['Mean']['n'] == before['Mean']['n']
+
+
+RASTER_DIR = os.path.join(GOLDEN_DIR, 'rasters')  # two data files of the reference's own tests (tests/data)
+
+
+@pytest.mark.parametrize('model, kernel_shape, proc_crs, mask_partial, exp_proc_crs, out_dtype', [
+    ('gain-blk-offset', (5, 5), 'auto', False, 'ref', 'float32'),     # BASELINE.json configs[0]
+    ('gain-offset', (15, 15), 'auto', False, 'ref', 'float32'), ('gain-offset', (31, 31), 'src', False, 'src', 'float32'),
+    ('gain', (1, 1), 'auto', False, 'ref', 'float32'), ('gain-blk-offset', (5, 5), 'auto', True, 'ref', 'float32'),
+    ('gain-blk-offset', (5, 5), 'auto', False, 'ref', 'uint8'),
+])
+def test_reference_rasters_fuse_then_compare(tmp_path, model, kernel_shape, proc_crs, mask_partial, exp_proc_crs, out_dtype):
+    """ The reference's integration test (tests/integration.py:30-110) on its own rasters, file to file: the 5 m NGI
+    aerial tile ngi_rgb_byte_1.tif (3 x 1421 x 805 uint8, nodata 0, 256-px tiles) fused with sentinel2_b432_byte.tif
+    (10 m, RGB-interleaved strips, grid origin off by a fraction of a pixel), max_block_mem = 1 MB as there; the corrected
+    GeoTIFF must agree better with the reference than the source did in every band (r2 up, RMSE and rRMSE down), and
+    keep the source mask (or shrink it to one blob's worth of interior pixels with mask_partial). """
+    import warnings
+    from homonim_amd.compare import RasterCompare
+    from homonim_amd.fuse import RasterFuse
+    from homonim_amd.tiff import read_tiff
+    src_path = os.path.join(RASTER_DIR, 'ngi_rgb_byte_1.tif')
+    ref_path = os.path.join(RASTER_DIR, 'sentinel2_b432_byte.tif')
+    corr_path = tmp_path / 'corr.tif'
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        with RasterFuse(src_path, ref_path, proc_crs=proc_crs) as rf:
+            assert rf.proc_crs.name == exp_proc_crs and rf.shape == (1421, 805)
+            rf.process(corr_path, model, kernel_shape, model_config=dict(mask_partial=mask_partial),
+                       out_profile=dict(dtype='uint8', nodata=0) if out_dtype == 'uint8' else None,
+                       block_config=dict(threads=2, max_block_mem=1))
+        with RasterCompare(src_path, ref_path, proc_crs=proc_crs) as cmp:
+            src_res = cmp.process()
+        with RasterCompare(corr_path, ref_path, proc_crs=proc_crs) as cmp:
+            corr_res = cmp.process()
+    for band, src_dict in src_res.items():
+        corr_dict = corr_res[band]
+        assert corr_dict['r2'] > src_dict['r2'], (band, src_dict, corr_dict)
+        assert corr_dict['rmse'] < src_dict['rmse'], (band, src_dict, corr_dict)
+        assert corr_dict['rrmse'] < src_dict['rrmse'], (band, src_dict, corr_dict)
+    src, corr = read_tiff(src_path), read_tiff(corr_path)
+    assert corr.array.dtype.name == out_dtype and corr.array.shape == src.array.shape
+    assert corr.transform == src.transform and corr.crs == src.crs
+    src_mask = (src.array != 0).any(axis=0)                                             # dataset masks
+    if out_dtype == 'uint8':
+        # (the reference's default output is float32 / NaN; in a uint8 file with nodata 0 a valid pixel that is corrected to
+        # 0 in every band reads back as nodata -- in the reference too -- so the masks agree up to a handful of pixels)
+        assert corr.nodata == 0
+        corr_mask = (corr.array != 0).any(axis=0)
+        assert not (corr_mask & ~src_mask).any() and (src_mask & ~corr_mask).sum() <= 1e-4 * src_mask.sum()
+        assert 0 <= src_res['Mean']['n'] - corr_res['Mean']['n'] <= 1e-4 * src_res['Mean']['n']
+        return
+    assert np.isnan(corr.nodata)
+    corr_mask = (~np.isnan(corr.array)).any(axis=0)
+    if not mask_partial:
+        assert corr_res['Mean']['n'] == src_res['Mean']['n']
+        assert (corr_mask == src_mask).all()
+    else:
+        assert corr_res['Mean']['n'] < src_res['Mean']['n']
+        assert 0 < corr_mask.sum() < src_mask.sum() and src_mask[corr_mask].all()
 
 
 def utils_overlap(kernel_shape):
