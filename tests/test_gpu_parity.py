@@ -1082,6 +1082,45 @@ def test_c_program_drives_the_library_on_the_gpu(tmp_path):
     assert 'ok (GPU present)' in run.stdout
 
 
+def test_raster_compare_known_answers_across_grids():
+    """ The reference's RasterCompare API tests (tests/test_compare.py:30-148) on in-memory rasters: a source compared
+    with its own 2:1 block average is a perfect match (r2 = 1, RMSE = 0) on the reference grid; results do not depend on
+    the thread count, barely on the block size (1e-5), and the two processing grids agree to 1e-3. """
+    from homonim_amd.compare import RasterCompare
+    rng = np.random.default_rng(11)
+    h, w, nb = 192, 256, 2
+    yy, xx = np.mgrid[0:h, 0:w]
+    src = np.stack([(np.sin(xx / (9.0 + b)) * np.cos(yy / (7.0 + b)) + 2 + 0.05 * rng.standard_normal((h, w))) for b in range(nb)])
+    src = src.astype(np.float32)
+    src[:, :4], src[:, -4:], src[:, :, :4], src[:, :, -4:] = np.nan, np.nan, np.nan, np.nan   # even-aligned NaN frame
+    ref = src.reshape(nb, h // 2, 2, w // 2, 2).mean(axis=(2, 4), dtype=np.float64).astype(np.float32)
+    src_tf, ref_tf = Affine(0.5, 0., 10., 0., -0.5, 200.), Affine(1., 0., 10., 0., -1., 200.)
+    kw = dict(src_nodata=np.nan, ref_nodata=np.nan, transform=src_tf, ref_transform=ref_tf, band_names=['b1', 'b2'])
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        with RasterCompare(src, ref, proc_crs='ref', **kw) as cmp:
+            assert cmp.proc_crs.name == 'ref'
+            one = cmp.process(threads=1)
+            many = cmp.process(threads=4, max_block_mem=0.02)
+        with RasterCompare(src, ref, proc_crs='src', **kw) as cmp:
+            on_src = cmp.process(threads=2)
+    assert list(one.keys()) == ['b1', 'b2', 'Mean']
+    n_valid = int((~np.isnan(ref[0])).sum())
+    for band in ('b1', 'b2', 'Mean'):
+        assert one[band]['n'] == n_valid
+        assert one[band]['r2'] == pytest.approx(1, abs=1e-6) and one[band]['rmse'] == pytest.approx(0, abs=1e-6)
+        assert one[band]['rrmse'] == pytest.approx(0, abs=1e-6)
+        for k in ('r2', 'rmse', 'rrmse'):
+            assert many[band][k] == pytest.approx(one[band][k], rel=1e-5, abs=1e-6)
+        assert many[band]['n'] == one[band]['n']
+        assert on_src[band]['r2'] == pytest.approx(one[band]['r2'], rel=2e-2)    # up-sampled reference vs 0.5 m detail
+        assert on_src[band]['n'] > 3.5 * one[band]['n']
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        with RasterCompare(src, ref, proc_crs='ref', **kw) as cmp:
+            assert cmp.process(threads=3) == one                                 # block order, not completion order
+
+
 def test_fill_nodata_known_answers():
     """ the restated GDAL fill on hand-checkable cases (oracle only; the GPU version is compared with it above). """
     img = np.zeros((5, 7), np.float32)
