@@ -99,7 +99,7 @@ _WORKER = r'''
 import os, sys, json
 sys.path.insert(0, {repo!r})
 from homonim_amd import dist, fuse, utils
-rank, world, local_rank = dist.init()          # gloo on a GPU-less host
+rank, world, local_rank = dist.init()          # gloo (HOMONIM_AMD_DIST_BACKEND, set by the test)
 blocks = list(fuse.block_pairs((3000, 2000), 3, utils.overlap_for_kernel((5, 5)), 4))
 mine = fuse.shard(blocks, rank, world)
 px = sum(b.src_out_block.width * b.src_out_block.height for b in mine)
@@ -118,7 +118,8 @@ def test_rank_sharding_gloo_world2(tmp_path):
     """ The N>1 path of bench.py / RasterFuse: every rank takes a disjoint shard, scalar reductions over gloo. """
     script = tmp_path / 'worker.py'
     script.write_text(_WORKER.format(repo=REPO))
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='1')
+    # gloo explicitly: on a host WITH GPUs the default would be nccl, which needs one device per rank
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='1', HOMONIM_AMD_DIST_BACKEND='gloo')
     res = subprocess.run(
         [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
          '--master-port', '29617', str(script)], capture_output=True, text=True, env=env, timeout=170
