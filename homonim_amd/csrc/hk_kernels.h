@@ -60,7 +60,7 @@ __host__ __device__ inline int fit_lut_entries(int kh, int kw) {
     const int n = (kh * kw + 1 + 31) / 32 * 32;
     return n < 256 ? n : 256;
 }
-size_t fit_lds_bytes(int kh, int kw, int ring_mode, bool with_lut, bool with_mask);
+size_t fit_lds_bytes(int kh, int kw, int ring_mode, bool with_lut, bool with_mask, bool ahead);
 // lanes per side that overlap with the neighbouring strip for kernel half-width rw
 inline int overlap_lanes_for(int rw) { return (rw + PX - 1) / PX; }
 

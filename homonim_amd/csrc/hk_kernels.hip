@@ -487,7 +487,11 @@ fit_apply_kernel(const FitArgs a) {
 
     constexpr bool ring = RING == 1;         // full ring: leaving + centre rows
     constexpr bool cring = RING == 2;        // centre-only ring
-    const int ring_rows = ring ? kh : (cring ? rh + 1 : 0);
+    // The HBM-bound kernels without R2 (gain, gain-blk-offset) read the leaving row from LDS one iteration AHEAD (its
+    // latency leaves the loop-carried path), which also frees its slot before the entering row is written: their ring has
+    // kh - 1 rows (8 KB instead of 10 KB per wave at 5x5 = 20 instead of 16 waves per CU).
+    constexpr bool RING_AHEAD = ring && MODEL != 2 && !R2;
+    const int ring_rows = ring ? (RING_AHEAD ? (kh > 1 ? kh - 1 : 1) : kh) : (cring ? rh + 1 : 0);
     float4* ring_v = lds4;  // RING 1: [slot][s|r][lane]; RING 2: [slot][lane] (s only)
     unsigned* ring_m = reinterpret_cast<unsigned*>(lds4 + (size_t)ring_rows * (ring ? 2 : 1) * WAVE);
     for (int sl = 0; sl < ring_rows; ++sl) {
@@ -568,7 +572,6 @@ fit_apply_kernel(const FitArgs a) {
     [[maybe_unused]] RowRaw qo_next;
     if constexpr (PF_OLD) qo_next = load_row(sp, rp, a.stride, t_first - kh, H, xq);
     // RING 1: the first leaving row is the zero row the ring was initialised with
-    constexpr bool RING_AHEAD = ring && MODEL == 0 && !R2;
     [[maybe_unused]] RowZ zold_next;
 #pragma unroll
     for (int i = 0; i < PX; ++i) zold_next.s[i] = zold_next.r[i] = 0.f;
@@ -578,8 +581,9 @@ fit_apply_kernel(const FitArgs a) {
     [[maybe_unused]] bool gave_up = false;  // wave-uniform, certificate-only build: this wave has asked for the re-run
     int slot = 0;
     int slot2 = 0;  // RING 2: write slot of the centre ring
-    int slot_c = kh - rh;  // slot of the centre row of the output produced at this iteration: (slot - rh) mod kh
-    if (slot_c >= kh) slot_c -= kh;
+    const int ring_mod = ring ? ring_rows : kh;
+    int slot_c = ring_mod - rh;  // slot of the centre row of the output produced at this iteration: (slot - rh) mod ring_mod
+    if (slot_c >= ring_mod) slot_c -= ring_mod;
     for (int t = t_first; t <= t_last; ++t) {
 
         // rows that do not come from LDS: issue their loads now, consume them after the entering row has been folded in
@@ -609,11 +613,18 @@ fit_apply_kernel(const FitArgs a) {
         }
         RowZ zold;
         if constexpr (ring) {
-            // leaving row (t - kh) = the slot the entering row overwrites.  The HBM-bound `gain` kernel fetches it from LDS
-            // one iteration ahead (its latency leaves the loop-carried path: 3.06 -> 2.99 ms); the VALU-bound kernels do
+            // leaving row (t - kh) = the slot the entering row overwrites.  The HBM-bound kernels fetch it from LDS one
+            // iteration ahead (RING_AHEAD above; 3.06 -> 2.99 ms for `gain` by the latency alone); the VALU-bound kernels do
             // not gain from that and keep the registers.
             if constexpr (RING_AHEAD) {
+                // zold_next was read an iteration ago; now fetch the row that leaves at the NEXT iteration from the slot the
+                // entering row is about to take (LDS operations of a wave execute in order)
                 zold = zold_next;
+                const float4 os = ring_v[(slot * 2 + 0) * WAVE + lane];
+                const float4 orr = ring_v[(slot * 2 + 1) * WAVE + lane];
+                zold_next.s[0] = os.x, zold_next.s[1] = os.y, zold_next.s[2] = os.z, zold_next.s[3] = os.w;
+                zold_next.r[0] = orr.x, zold_next.r[1] = orr.y, zold_next.r[2] = orr.z, zold_next.r[3] = orr.w;
+                zold_next.m = DENSE ? 0u : ring_m[slot * WAVE + lane];
             } else {
                 const float4 os = ring_v[(slot * 2 + 0) * WAVE + lane];
                 const float4 orr = ring_v[(slot * 2 + 1) * WAVE + lane];
@@ -624,14 +635,6 @@ fit_apply_kernel(const FitArgs a) {
             ring_v[(slot * 2 + 0) * WAVE + lane] = make_float4(znew.s[0], znew.s[1], znew.s[2], znew.s[3]);
             ring_v[(slot * 2 + 1) * WAVE + lane] = make_float4(znew.r[0], znew.r[1], znew.r[2], znew.r[3]);
             if constexpr (!DENSE) ring_m[slot * WAVE + lane] = znew.m;
-            if constexpr (RING_AHEAD) {  // the row that leaves at the NEXT iteration sits in the next slot (kh == 1: this one)
-                const int sn = slot + 1 == kh ? 0 : slot + 1;
-                const float4 os = ring_v[(sn * 2 + 0) * WAVE + lane];
-                const float4 orr = ring_v[(sn * 2 + 1) * WAVE + lane];
-                zold_next.s[0] = os.x, zold_next.s[1] = os.y, zold_next.s[2] = os.z, zold_next.s[3] = os.w;
-                zold_next.r[0] = orr.x, zold_next.r[1] = orr.y, zold_next.r[2] = orr.z, zold_next.r[3] = orr.w;
-                zold_next.m = DENSE ? 0u : ring_m[sn * WAVE + lane];
-            }
         } else {
             zold = process_row<MODEL, DENSE>(qo, t_old >= t_first && t_old >= 0 && t_old < H, colbits, full_wave, ts, tr, n0, n1);
             if constexpr (cring) {  // slot2 cycles over rh + 1 rows: the entering row replaces the centre row of rh + 1 ago
@@ -952,8 +955,8 @@ fit_apply_kernel(const FitArgs a) {
             }
         }
 
-        if (++slot == kh) slot = 0;
-        if (++slot_c == kh) slot_c = 0;
+        if (++slot == ring_mod) slot = 0;
+        if (++slot_c == ring_mod) slot_c = 0;
         if (++slot2 == rh + 1) slot2 = 0;
     }
 
@@ -969,17 +972,18 @@ fit_apply_kernel(const FitArgs a) {
 
 // LDS bytes of one wave: the row ring of the mode (see fit_apply_kernel) + the float64 1/N table (fit_lut_entries) that only the
 // gain-offset model reads (the HBM-bound `gain` kernel gets one more resident wave per SIMD without it)
-size_t fit_lds_bytes(int kh, int kw, int ring_mode, bool with_lut, bool with_mask) {
+size_t fit_lds_bytes(int kh, int kw, int ring_mode, bool with_lut, bool with_mask, bool ahead) {
     const size_t mask = with_mask ? WAVE * sizeof(unsigned) : 0;
     size_t ring = 0;
-    if (ring_mode == 1) ring = (size_t)kh * (2 * WAVE * sizeof(float4) + mask);
+    if (ring_mode == 1) ring = (size_t)(ahead && kh > 1 ? kh - 1 : kh) * (2 * WAVE * sizeof(float4) + mask);
     if (ring_mode == 2) ring = (size_t)(kh / 2 + 1) * (WAVE * sizeof(float4) + mask);
     return ring + (with_lut ? fit_lut_entries(kh, kw) * sizeof(double) : 0);
 }
 
 template <int MODEL, bool R2, int RW, bool DENSE, int RING, bool CERT_ONLY>
 static hipError_t launch_build(const FitArgs& a, hipStream_t stream) {
-    const size_t lds = fit_lds_bytes(2 * a.rh + 1, 2 * a.rw + 1, RING, MODEL == 2 && !(CERT_ONLY && DENSE), !DENSE);
+    const size_t lds = fit_lds_bytes(2 * a.rh + 1, 2 * a.rw + 1, RING, MODEL == 2 && !(CERT_ONLY && DENSE), !DENSE,
+                                     RING == 1 && MODEL != 2 && !R2);
     if (lds > 64 * 1024) {  // forced LDS ring on a tall kernel (testing): raise the 64 KiB dynamic-LDS default
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fit_apply_kernel<MODEL, R2, RW, DENSE, RING, CERT_ONLY>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
