@@ -991,7 +991,7 @@ int hk_inpaint_dev_counts(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job
         a.height = job->height, a.width = job->width, a.stride = job->stride, a.band_stride = 0, a.n_bands = 1;
         fill_args(a, desc, ctx->xcd_remap);
         fill_grid(a, job->seg_rows);
-        std::lock_guard<std::mutex> lk(ctx->mu);  // the slot's scratch may be (re)allocated
+        std::unique_lock<std::mutex> lk(ctx->mu);  // the slot's scratch may be (re)allocated
         bool scratch_params = false;
         if (n_fail & hk::FIT_RETRY_BIT) {
             // the certificate-only build gave up on this band (hk_fit_apply_dev): run the full build, straight into the
@@ -1012,7 +1012,9 @@ int hk_inpaint_dev_counts(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job
             HK_HIP(hk::launch_fit_apply(a, desc->model, r2, sl.stream));
             HK_HIP(hipMemcpyAsync(&n_fail, d_fail, sizeof(n_fail), hipMemcpyDeviceToHost, sl.stream));
             HK_HIP(hipMemsetAsync(d_fail, 0, sizeof(unsigned long long), sl.stream));
+            lk.unlock();  // other streams' callers need not wait for this stream to drain
             HK_HIP(hipStreamSynchronize(sl.stream));
+            lk.lock();
             a.fail_count = nullptr;
         }
         total += n_fail;
