@@ -391,56 +391,56 @@ __global__ void __launch_bounds__(NORM_THREADS) norm_full_hist_kernel(const Norm
         if (hist[i]) atomicAdd(gh + i, hist[i]);
 }
 
-// Find the bin holding rank `rank` in hist[0..nbins): returns bin, and the rank inside it.
-__device__ void select_bin(const unsigned* __restrict__ h, int nbins, unsigned long long rank, unsigned* bin_out,
-                           unsigned long long* rank_out, unsigned long long* sh /* NORM_THREADS */) {
-    const int t = threadIdx.x;
-    const int per = nbins / NORM_THREADS;
+// Find the bin holding rank `rank` in hist[0..nbins) -- the first bin whose running count exceeds it (the last bin if
+// none does) -- and the rank inside that bin.  One wave: each lane sums a contiguous chunk, an inclusive scan over the
+// lanes finds the chunk, its lane walks the chunk.  The lane that found it returns true.
+__device__ __forceinline__ bool select_bin(const unsigned* __restrict__ h, int nbins, unsigned long long rank, unsigned* bin_out,
+                                           unsigned long long* rank_out) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int per = nbins / WAVE;
     unsigned long long local = 0;
-    for (int i = 0; i < per; ++i) local += h[t * per + i];
-    sh[t] = local;
-    __syncthreads();
-    if (t == 0) {
-        unsigned long long cum = 0;
-        int tt = 0;
-        for (; tt < NORM_THREADS - 1; ++tt) {
-            if (cum + sh[tt] > rank) break;
-            cum += sh[tt];
-        }
-        int b = tt * per;
-        for (int i = 0; i < per - 1; ++i, ++b) {
-            if (cum + h[b] > rank) break;
-            cum += h[b];
-        }
-        *bin_out = (unsigned)b;
-        *rank_out = rank - cum;
+    for (int i = 0; i < per; ++i) local += h[lane * per + i];
+    unsigned long long incl = local;
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        const unsigned long long v = __shfl_up(incl, d, WAVE);
+        if (lane >= d) incl += v;
     }
-    __syncthreads();
+    const unsigned long long hit = __ballot(incl > rank);
+    const int owner = hit ? __ffsll(hit) - 1 : WAVE - 1;
+    if (lane != owner) return false;
+    unsigned long long cum = incl - local;
+    int b = lane * per;
+    for (int i = 0; i < per - 1; ++i, ++b) {
+        if (cum + h[b] > rank) break;
+        cum += h[b];
+    }
+    *bin_out = (unsigned)b;
+    *rank_out = rank - cum;
+    return true;
 }
 
-// After each histogram level (of either path): fix the next digit of the four (raster, rank) keys; after the last level
-// the keys are the exact order statistics -> norm.
+// After each histogram level (of either path): fix the next digit of the four (raster, rank) keys -- one wave each; after
+// the last level the keys are the exact order statistics -> norm.
 template <int LEVEL>
 __global__ void __launch_bounds__(NORM_THREADS) norm_select_kernel(NormWS* __restrict__ ws_all, double* __restrict__ norm_out) {
-    __shared__ unsigned long long sh[NORM_THREADS];
-    __shared__ unsigned bin;
-    __shared__ unsigned long long rk;
+    static_assert(NORM_THREADS == 4 * WAVE, "one wave per (raster, rank)");
     NormWS& ws = ws_all[blockIdx.x];
     if (ws.done) return;
-    for (int q = 0; q < 2; ++q) {
-        for (int k = 0; k < 2; ++k) {
-            const unsigned* h = LEVEL == 0 ? ws.hist1[q][k] : (LEVEL == 1 ? ws.hist2[q][k] : ws.hist3[q][k]);
-            const int nb = LEVEL == 0 ? L1_BINS : (LEVEL == 1 ? L2_BINS : L3_BINS);
-            select_bin(h, nb, ws.sel[q][k].rank, &bin, &rk, sh);
-            if (threadIdx.x == 0) {
-                const int bits = LEVEL == 0 ? 0 : (LEVEL == 1 ? L2_BITS : L3_BITS);
-                ws.sel[q][k].prefix = (LEVEL == 0) ? bin : ((ws.sel[q][k].prefix << bits) | bin);
-                ws.sel[q][k].rank = rk;
-                if (LEVEL == 2) ws.val[q][k] = key2f(ws.sel[q][k].prefix);
-            }
-            __syncthreads();
+    {
+        const int q = threadIdx.x >> 7, k = (threadIdx.x >> 6) & 1;
+        const unsigned* h = LEVEL == 0 ? ws.hist1[q][k] : (LEVEL == 1 ? ws.hist2[q][k] : ws.hist3[q][k]);
+        const int nb = LEVEL == 0 ? L1_BINS : (LEVEL == 1 ? L2_BINS : L3_BINS);
+        unsigned bin;
+        unsigned long long rk;
+        if (select_bin(h, nb, ws.sel[q][k].rank, &bin, &rk)) {
+            const int bits = LEVEL == 0 ? 0 : (LEVEL == 1 ? L2_BITS : L3_BITS);
+            ws.sel[q][k].prefix = (LEVEL == 0) ? bin : ((ws.sel[q][k].prefix << bits) | bin);
+            ws.sel[q][k].rank = rk;
+            if (LEVEL == 2) ws.val[q][k] = key2f(ws.sel[q][k].prefix);
         }
     }
+    __syncthreads();
     if (LEVEL == 2 && threadIdx.x == 0) {
         const double n0 = sqrt(ws.var[1]) / sqrt(ws.var[0]);
         double pct[2];
