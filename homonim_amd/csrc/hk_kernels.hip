@@ -726,6 +726,9 @@ fit_apply_kernel(const FitArgs a) {
             // so every mask select and bit test folds away.
             auto pointwise = [&](auto uniform_n) {
                 constexpr bool UN = decltype(uniform_n)::value;
+                // the halo lanes only feed their neighbours' horizontal sums: masked out of the pointwise stages, they draw
+                // no power there (the kernel runs at the package's power cap; -0.6 %)
+                if (!out_lane) return;
                 const unsigned mcu = UN ? 0x01010101u : mc;
                 // ---- stage A: gains and offsets -------------------------------------------------------------------------
                 float g[PX], o[PX], r2v[PX], c[PX];
@@ -839,7 +842,7 @@ fit_apply_kernel(const FitArgs a) {
                             // allocation two spilled registers = +1.5 % on every clean launch; aborted launches are rare
                             // (the host backs off after each).
                             if (exact) {
-                                if (!gave_up && lane == 0) atomicOr(a.fail_count + band, FIT_RETRY_BIT);
+                                if (!gave_up && lane == ol) atomicOr(a.fail_count + band, FIT_RETRY_BIT);  // first output lane
                                 gave_up = true;
                                 return;  // leaves this row's pointwise lambda (skipping its stage C also keeps the allocation spill-free)
                             }
