@@ -261,6 +261,39 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #define HK_P2(a, j) (f2{(a)[2 * (j)], (a)[2 * (j) + 1]})
 __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
+// float32(RN64(n / d)) without the IEEE float64 division (13 VALU instructions, one of them v_rcp_f64 at quarter rate):
+//     y0 = v_rcp_f64(d)            relative error <= 2^-22 (documented 2^-23; 2^-24.4 measured, profiles/r02_ubench_valu.txt)
+//     y1 = y0 + y0 * (1 - d * y0)  one Newton step: <= 2^-44 + 2^-53
+//     q  = n * y1                  <= 2^-44 + 2^-52 relative = 513 float64 ulps of q at most
+// RN64(n / d) lies within 514 ulps of q, so both round to the same float32 unless one of its rounding boundaries (the
+// midpoints of neighbouring float32 values: low 29 mantissa bits == 0x10000000) lies within 514 ulps of q.  quot_guard()
+// maps q to a word that is < 2 * HK_DIV_GUARD + 1 exactly when q is that close (probability 2^-18 per pixel); such a
+// wave-row -- and one with a quotient outside the float32 normal range, which includes every zero / infinite / NaN
+// operand -- is solved again with the IEEE division, so results are identical by construction.
+#ifndef HK_DIV_GUARD
+#define HK_DIV_GUARD 1024u
+#endif
+__device__ __forceinline__ double fast_quot(double n, double d) {
+    double y = __builtin_amdgcn_rcp(d);
+    const double e = __fma_rn(-d, y, 1.0);
+    y = __fma_rn(y, e, y);
+    return __dmul_rn(n, y);
+}
+__device__ __forceinline__ unsigned quot_guard(double q) {
+    return ((unsigned)__double2loint(q) & 0x1fffffffu) - (0x10000000u - HK_DIV_GUARD);
+}
+// biased float64 exponent of q relative to that of 2^-126: <= 0x0fd00000 exactly for |q| in [2^-126, 2^128)
+__device__ __forceinline__ unsigned quot_range(double q) {
+    return ((unsigned)__double2hiint(q) & 0x7ff00000u) - 0x38100000u;
+}
+
+// Streaming stores: the output planes are written once and never read by this launch -- non-temporal stores keep them
+// from displacing the rows the neighbouring strips still share in L2 (strip-march pattern: -2 %, tools/ubench_strips.hip)
+typedef float hk_v4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store4_nt(float4* p, float4 v) {
+    __builtin_nontemporal_store(hk_v4{v.x, v.y, v.z, v.w}, reinterpret_cast<hk_v4*>(p));
+}
+
 // Rows are padded to a multiple of PX elements (stride % 4 == 0, checked on the host), so every lane moves a full
 // 16 bytes.  The load is unconditional: the row is clamped into the raster (wave-uniform, so the row address is a
 // scalar base and the lane offset a 32-bit VGPR -> no per-row vector address arithmetic) and `xq` is a safe in-raster
@@ -733,10 +766,22 @@ fit_apply_kernel(const FitArgs a) {
                 // ---- stage A: gains and offsets -------------------------------------------------------------------------
                 float g[PX], o[PX], r2v[PX], c[PX];
                 [[maybe_unused]] float Rf[PX], Sf[PX], Pf[PX], gp[PX];
+                // r2-mask decision of this wave-row (gain-offset with a threshold and no R2 plane to write): first through the
+                // float32 CERTIFICATE below, evaluated right behind each pixel pair's gain while its operands are in
+                // registers; the reference's own R2 expression (stage B) runs only if a pixel stays uncertain
+                [[maybe_unused]] bool try_cert = false, uncertain = false;
+                if constexpr (GO && R2) {
+                    if (count_fails && !want_r2_values) {  // wave-uniform
+                        if (!CERT_ONLY && cert_skip > 0) --cert_skip;  // the rows just above needed the exact evaluation: go straight to it
+                        else try_cert = true;
+                    }
+                }
                 if constexpr (GO) {
                     // kernel_model.py:338-351; src2_sum is float64 (sqrBoxFilter) so m_den and the division are f64.
                     // float32 steps run two pixels per instruction (packed), float64 steps per pixel.
                     {
+                        [[maybe_unused]] unsigned gwin = 0u, twin = 0u;  // largest distance of a pixel's g / N*T' from its window's low end
+                        uncertain = !cert_ok;
 #pragma unroll
                         for (int j = 0; j < PX / 2; ++j) {
                             const f2 Rf2 = HK_P2(Rf0, j), Sf2 = HK_P2(Sf0, j), Pf2 = HK_P2(Pf0, j);
@@ -744,10 +789,22 @@ fit_apply_kernel(const FitArgs a) {
                             const double Ndx = UN ? a.nd_full : (double)Nf2.x, Ndy = UN ? a.nd_full : (double)Nf2.y;
                             const f2 num2 = Nf2 * Pf2 - Sf2 * Rf2;
                             const f2 SS2 = Sf2 * Sf2;
-                            f2 g2;
-                            g2.x = (float)__ddiv_rn((double)num2.x, __dsub_rn(__dmul_rn(Ndx, HS2[2 * j]), (double)SS2.x));
-                            g2.y = (float)__ddiv_rn((double)num2.y, __dsub_rn(__dmul_rn(Ndy, HS2[2 * j + 1]), (double)SS2.y));
-                            const f2 tn2 = Rf2 - g2 * Sf2;
+                            const double denx = __dsub_rn(__dmul_rn(Ndx, HS2[2 * j]), (double)SS2.x);
+                            const double deny = __dsub_rn(__dmul_rn(Ndy, HS2[2 * j + 1]), (double)SS2.y);
+                            const double qx = fast_quot((double)num2.x, denx), qy = fast_quot((double)num2.y, deny);
+                            f2 g2 = {(float)qx, (float)qy};
+                            // a lane with a quotient too close to a float32 rounding boundary divides this pixel pair again,
+                            // the IEEE way, while the operands are still in registers.  The range test (zero / infinite /
+                            // NaN / denormal-float32 quotients) is left to the r2-mask certificate in the certificate-only
+                            // build, which refuses gains outside (2^-20, 2^20) and has no other consumer of them.
+                            bool again = min(quot_guard(qx), quot_guard(qy)) < 2u * HK_DIV_GUARD + 1u;
+                            if constexpr (!CERT_ONLY) again |= max(quot_range(qx), quot_range(qy)) > 0x0fd00000u;
+                            if (again) {
+                                g2.x = (float)__ddiv_rn((double)num2.x, denx);
+                                g2.y = (float)__ddiv_rn((double)num2.y, deny);
+                            }
+                            const f2 t2 = g2 * Sf2;
+                            const f2 tn2 = Rf2 - t2;
                             f2 o2;
                             if constexpr (UN) {
                                 o2.x = (float)__dmul_rn((double)tn2.x, a.inv_n_full);
@@ -759,13 +816,45 @@ fit_apply_kernel(const FitArgs a) {
                                 o2.x = __fdiv_rn(tn2.x, Nf2.x);
                                 o2.y = __fdiv_rn(tn2.y, Nf2.y);
                             }
-                            Rf[2 * j] = Rf2.x, Rf[2 * j + 1] = Rf2.y;
-                            Sf[2 * j] = Sf2.x, Sf[2 * j + 1] = Sf2.y;
-                            Pf[2 * j] = Pf2.x, Pf[2 * j + 1] = Pf2.y;
                             g[2 * j] = g2.x, g[2 * j + 1] = g2.y;
                             o[2 * j] = o2.x, o[2 * j + 1] = o2.y;
+                            if constexpr (R2) {
+                                if (try_cert) {  // wave-uniform
+                                    // Division-free CERTIFICATE of `(r2 > thresh) & (gain > 0)` from float32 quantities (proof:
+                                    // DESIGN.md appendix A).  With T = g^2*S2 + R2 + N*o^2 the reference's arithmetic obeys
+                                    //   ssres_ref <= sstot_ref - g^2*den + 23.5*2^-24*N*T,  |sstot_ref - sst| <= 4.1*2^-24*N*T,
+                                    // and g = fl32(fl64(num / den)) makes g^2*den = g*num*(1 + eps), |eps| <= 1.01*2^-24, so
+                                    //   fl32(g*num) > kappa*sst + 2^-17*N*T'   (kappa = 1 - r2_pass_scale, rounded up)
+                                    // proves ssres_ref < r2_pass_scale * sstot_ref, i.e. the reference's decision.  N*T' is
+                                    // N*T = g^2*den_x + (g*S)^2 + N*R2 + (N*o)^2 rebuilt from this pixel pair's float32
+                                    // operands: g*num + t^2 + N*R2 + tn^2 (t = g*S, tn = R - t), within 4*2^-24 of it.
+                                    const f2 R2f = {(float)HR2[2 * j], (float)HR2[2 * j + 1]};
+                                    const f2 lhs = g2 * num2;
+                                    const f2 sst = pk_fma(Nf2, R2f, -(Rf2 * Rf2));
+                                    const f2 NT = pk_fma(t2, t2, pk_fma(tn2, tn2, pk_fma(Nf2, R2f, lhs)));
+                                    const f2 slack = NT * 0x1p-17f;
+                                    const f2 rhs = pk_fma(f2{a.r2_fail_scale, a.r2_fail_scale}, sst, slack);
+#pragma unroll
+                                    for (int e = 0; e < 2; ++e) {
+                                        const bool m = (mcu >> (8 * (2 * j + e))) & 1u;
+                                        const bool sure = (lhs[e] > rhs[e]) & (sst[e] > slack[e]);
+                                        // magnitude windows (no underflow / overflow anywhere in the reference's expression):
+                                        // 2^-20 < g < 2^20 (also the `gain > 0` half of the decision), 2^-40 < N*T' < 2^60;
+                                        // a masked pixel's quantities are arbitrary and must not count
+                                        const unsigned gd = __float_as_uint(g2[e]) - 0x35800000u, td = __float_as_uint(NT[e]) - 0x2b800000u;
+                                        gwin = max(gwin, UN ? gd : (m ? gd : 0u));
+                                        twin = max(twin, UN ? td : (m ? td : 0u));
+                                        uncertain |= m & !sure;
+                                    }
+                                }
+                            }
+                        }
+                        if constexpr (R2) {
+                            if (try_cert) uncertain |= (gwin >= 0x49800000u - 0x35800000u) | (twin >= 0x5d800000u - 0x2b800000u);
                         }
                     }
+#pragma unroll
+                    for (int i = 0; i < PX; ++i) Rf[i] = Rf0[i], Sf[i] = Sf0[i], Pf[i] = Pf0[i];
                 }
 #pragma unroll
                 for (int i = 0; i < PX; ++i) {
@@ -789,45 +878,9 @@ fit_apply_kernel(const FitArgs a) {
                 // ---- stage B: R2 (kernel_model.py:179,189-195|201,203,212-213) ---------------------------------------------
                 if constexpr (R2) {
                     if (want_r2_values || count_fails) {  // wave-uniform
-                        bool exact = want_r2_values;
+                        bool exact = true;
                         if constexpr (GO) {
-                            if (!CERT_ONLY && !exact && cert_skip > 0) {  // the rows just above needed the exact evaluation: go straight to it
-                                exact = true;
-                                --cert_skip;
-                            }
-                            if (!exact) {
-                                // Division-free CERTIFICATE of `(r2 > thresh) & (gain > 0)` from float32 quantities (proof:
-                                // DESIGN.md appendix A).  With T = g^2*S2 + R2 + N*o^2 the reference's float arithmetic obeys
-                                //   ssres_ref <= sstot_ref - g^2*den + 35*2^-24*N*T   and   |sstot_ref - sst| <= 4.1*2^-24*N*T,
-                                // so  g^2*den > kappa*sst + 2^-17*N*T  (kappa = 1 - r2_pass_scale, rounded up) proves
-                                // ssres_ref < r2_pass_scale * sstot_ref, which proves the reference's decision.
-                                bool uncertain = !cert_ok;
-#pragma unroll
-                                for (int j = 0; j < PX / 2; ++j) {
-                                    const f2 g2 = HK_P2(g, j), o2 = HK_P2(o, j), Nf2 = HK_P2(Nf, j);
-                                    const f2 Rf2 = HK_P2(Rf, j), Sf2 = HK_P2(Sf, j);
-                                    const f2 S2f = {(float)HS2[2 * j], (float)HS2[2 * j + 1]};
-                                    const f2 R2f = {(float)HR2[2 * j], (float)HR2[2 * j + 1]};
-                                    const f2 gg = g2 * g2;
-                                    const f2 sst = pk_fma(Nf2, R2f, -(Rf2 * Rf2));
-                                    const f2 T = pk_fma(gg, S2f, pk_fma(Nf2 * o2, o2, R2f));
-                                    const f2 NT = Nf2 * T;
-                                    const f2 slack = NT * 0x1p-17f;
-                                    const f2 denf = pk_fma(Nf2, S2f, -(Sf2 * Sf2));
-                                    const f2 lhs = gg * denf;
-                                    const f2 rhs = pk_fma(f2{a.r2_fail_scale, a.r2_fail_scale}, sst, slack);
-#pragma unroll
-                                    for (int e = 0; e < 2; ++e) {
-                                        const int i = 2 * j + e;
-                                        const bool m = (mcu >> (8 * i)) & 1u;
-                                        // magnitude windows (no underflow / overflow anywhere in the reference's expression):
-                                        // 2^-20 < g < 2^20 (also the `gain > 0` half of the decision), 2^-40 < N*T < 2^60
-                                        const bool g_in = (__float_as_uint(g2[e]) - 0x35800000u) < (0x49800000u - 0x35800000u);
-                                        const bool t_in = (__float_as_uint(NT[e]) - 0x2b800000u) < (0x5d800000u - 0x2b800000u);
-                                        const bool sure = (lhs[e] > rhs[e]) & (sst[e] > slack[e]) & g_in & t_in;
-                                        uncertain |= out_lane & m & !sure;
-                                    }
-                                }
+                            if (try_cert) {
                                 exact = __any(uncertain);
                                 if (exact) cert_skip = HK_CERT_SKIP;  // failing regions are coherent: skip the certificate for a few rows
                             }
@@ -944,10 +997,10 @@ fit_apply_kernel(const FitArgs a) {
                     // wave-uniform row offset (scalar) + this lane's 32-bit byte offset: no per-plane address registers
                     const long long row_off = out_base + (long long)y * a.stride;
                     auto at = [&](float* plane) { return reinterpret_cast<float4*>(reinterpret_cast<char*>(plane + row_off) + xbytes); };
-                    if (a.corr) *at(a.corr) = make_float4(c[0], c[1], c[2], c[3]);
-                    if (a.gain) *at(a.gain) = masked4(g);
-                    if (a.offset) *at(a.offset) = masked4(o);
-                    if (R2 && a.r2) *at(a.r2) = masked4(r2v);
+                    if (a.corr) store4_nt(at(a.corr), make_float4(c[0], c[1], c[2], c[3]));
+                    if (a.gain) store4_nt(at(a.gain), masked4(g));
+                    if (a.offset) store4_nt(at(a.offset), masked4(o));
+                    if (R2 && a.r2) store4_nt(at(a.r2), masked4(r2v));
                 }
             };
             if constexpr (GO) {
@@ -1014,6 +1067,9 @@ static hipError_t launch_one(const FitArgs& a, hipStream_t stream) {
 
 template <int MODEL, bool R2, bool DENSE>
 static hipError_t launch_rw(const FitArgs& a, hipStream_t stream) {
+#ifdef HK_DEV_SUBSET  // development builds: only the 5x5 kernels with the full LDS ring (seconds instead of a minute)
+    return launch_one<MODEL, R2, 2, DENSE, 1>(a, stream);
+#else
     // a.use_ring (hk_api.hip): 1 full LDS ring (short, narrow kernels only), 2 centre ring + re-loaded leaving row,
     // 0 everything re-loaded (very tall kernels; run-time width path only, to bound the number of instantiations)
     if (a.use_ring == 1) {
@@ -1037,6 +1093,7 @@ static hipError_t launch_rw(const FitArgs& a, hipStream_t stream) {
         case 7: return launch_one<MODEL, R2, 7, DENSE, 2>(a, stream);
         default: return launch_one<MODEL, R2, -1, DENSE, 2>(a, stream);
     }
+#endif
 }
 
 template <int MODEL, bool R2>
