@@ -53,14 +53,8 @@ struct FitArgs {
 
 // model: 0 gain, 1 gain-blk-offset, 2 gain-offset.  with_r2: compute the R2 quantity set.
 hipError_t launch_fit_apply(const FitArgs& a, int model, bool with_r2, hipStream_t stream);
-// LDS bytes one wave needs (row ring of kh rows when use_ring, plus the 1/N table).
-// entries of the 1/N table of the gain-offset kernels: window counts 0 .. kh * kw, padded to a multiple of 32; 256 at most
-// (larger windows do not use the table)
-__host__ __device__ inline int fit_lut_entries(int kh, int kw) {
-    const int n = (kh * kw + 1 + 31) / 32 * 32;
-    return n < 256 ? n : 256;
-}
-size_t fit_lds_bytes(int kh, int kw, int ring_mode, bool with_lut, bool with_mask, bool ahead);
+// LDS bytes one wave needs (its row ring; hk_kernels.hip)
+size_t fit_lds_bytes(int kh, int ring_mode, bool ahead);
 // lanes per side that overlap with the neighbouring strip for kernel half-width rw
 inline int overlap_lanes_for(int rw) { return (rw + PX - 1) / PX; }
 

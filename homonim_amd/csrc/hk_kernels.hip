@@ -294,6 +294,24 @@ __device__ __forceinline__ void store4_nt(float4* p, float4 v) {
     __builtin_nontemporal_store(hk_v4{v.x, v.y, v.z, v.w}, reinterpret_cast<hk_v4*>(p));
 }
 
+// RN64(1 / n) for window counts 0 .. 255 (entry 0 is never used for a stored pixel).  For a float32 t and an integer
+// n < 2^8 the quotient t / n is never closer than 2^-33 (relative) to a float32 rounding midpoint, while
+// f64(t) * RN64(1/n) is within 2^-52 of it -- so rounding that product to float32 IS the IEEE float32 division
+// (kernel_model.py:351: float32 `t / mask_sum`).  Only wave-rows with a hole or a raster edge in their windows read it
+// (elsewhere 1/N is a kernel argument), so it lives in global memory (2 KB, cache-resident) and costs no LDS.
+struct InvTable {
+    double v[256];
+    constexpr InvTable() : v() {
+        v[0] = 0.0;
+        for (int n = 1; n < 256; ++n) v[n] = 1.0 / (double)n;
+    }
+};
+__device__ const InvTable HK_INV_N = InvTable();
+
+// Invalid pixels are kept in the LDS row ring as this NaN payload in the SOURCE plane (the reference plane holds their
+// zero fill): no separate mask plane, i.e. the general kernels need exactly the LDS of the nodata=None ones.
+constexpr unsigned RING_SENTINEL = 0x7fc0deadu;
+
 // Rows are padded to a multiple of PX elements (stride % 4 == 0, checked on the host), so every lane moves a full
 // 16 bytes.  The load is unconditional: the row is clamped into the raster (wave-uniform, so the row address is a
 // scalar base and the lane offset a 32-bit VGPR -> no per-row vector address arithmetic) and `xq` is a safe in-raster
@@ -451,7 +469,7 @@ struct ColSums {
 //      three streams that all miss L2 and the kernel fabric-bound;
 //   0  both re-loaded (very tall kernels whose centre ring would not fit either).
 template <int MODEL, bool R2, int RW, bool DENSE, int RING, bool CERT_ONLY>
-__global__ void __launch_bounds__(WAVE, (CERT_ONLY && RW >= 0 && RW <= 3 && (DENSE || RW <= 1)) ? 4
+__global__ void __launch_bounds__(WAVE, (CERT_ONLY && RW >= 0 && RW <= 3) ? 4
                                         : ((MODEL == 2 && R2 && !DENSE && (RW < 0 || RW >= 4)) ? HK_FIT_MIN_WAVES_WIDE : HK_FIT_MIN_WAVES))
 fit_apply_kernel(const FitArgs a) {
     using CS = ColSums<MODEL, R2, DENSE>;
@@ -526,29 +544,55 @@ fit_apply_kernel(const FitArgs a) {
     constexpr bool RING_AHEAD = ring && MODEL != 2 && !R2;
     const int ring_rows = ring ? (RING_AHEAD ? (kh > 1 ? kh - 1 : 1) : kh) : (cring ? rh + 1 : 0);
     float4* ring_v = lds4;  // RING 1: [slot][s|r][lane]; RING 2: [slot][lane] (s only)
-    unsigned* ring_m = reinterpret_cast<unsigned*>(lds4 + (size_t)ring_rows * (ring ? 2 : 1) * WAVE);
+    // slots start as rows that were never added: zero contribution, no valid pixel
+    const float ring_init = DENSE ? 0.f : __uint_as_float(RING_SENTINEL);
     for (int sl = 0; sl < ring_rows; ++sl) {
         if constexpr (ring) {
-            ring_v[(sl * 2 + 0) * WAVE + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+            ring_v[(sl * 2 + 0) * WAVE + lane] = make_float4(ring_init, ring_init, ring_init, ring_init);
             ring_v[(sl * 2 + 1) * WAVE + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
         } else {
-            ring_v[sl * WAVE + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+            ring_v[sl * WAVE + lane] = make_float4(ring_init, ring_init, ring_init, ring_init);
         }
-        if constexpr (!DENSE) ring_m[sl * WAVE + lane] = 0u;
     }
+    // wave-uniform: bit k = the row in ring slot k is `clean` (inside the raster, every pixel of the strip valid) and is
+    // stored as it was loaded; the other rows carry RING_SENTINEL in place of their invalid source pixels
+    [[maybe_unused]] unsigned long long ring_clean = 0ull;
+    auto ring_encode = [&](const RowZ& z) {
+        float4 v = make_float4(z.s[0], z.s[1], z.s[2], z.s[3]);
+        if constexpr (!DENSE) {
+            if (!z.clean) {
+                const float sent = __uint_as_float(RING_SENTINEL);
+                v.x = (z.m & 0x00000001u) ? v.x : sent;
+                v.y = (z.m & 0x00000100u) ? v.y : sent;
+                v.z = (z.m & 0x00010000u) ? v.z : sent;
+                v.w = (z.m & 0x01000000u) ? v.w : sent;
+            }
+        }
+        return v;
+    };
+    // source values + validity bytes of a ring row (zero fill restored)
+    auto ring_decode = [&](const float4& v, bool clean, float (&sv)[PX], unsigned& m) {
+        sv[0] = v.x, sv[1] = v.y, sv[2] = v.z, sv[3] = v.w;
+        m = 0x01010101u;
+        if constexpr (DENSE) {
+            m = 0u;
+        } else {
+            if (!clean) {
+                m = 0u;
+#pragma unroll
+                for (int i = 0; i < PX; ++i) {
+                    const bool ok = __float_as_uint(sv[i]) != RING_SENTINEL;
+                    sv[i] = ok ? sv[i] : 0.f;
+                    m |= (ok ? 1u : 0u) << (8 * i);
+                }
+            }
+        }
+    };
 
-    // 1/N table for the offset division (kernel_model.py:351: float32 `t / mask_sum`).  For a float32 t and an integer
-    // N < 2^8 the quotient t/N is never closer than 2^-33 (relative) to a float32 rounding midpoint, while
-    // f64(t) * RN64(1/N) is within 2^-52 of it -- so rounding that product to float32 IS the IEEE float32 division.
-    double* inv_lut = reinterpret_cast<double*>(ring_m + (DENSE ? (size_t)0 : (size_t)ring_rows * WAVE));  // dense: no mask ring
-    const bool lut_ok = GO && kh * (2 * rw + 1) <= 255;  // the product trick is proven for window counts < 2^8
-    // The table has fit_lut_entries() = kh * kw + 1 (rounded up to 32) entries: 256 B for 5x5.  The DENSE certificate-only
-    // build keeps none (its 10 KB ring gives exactly 16 waves per CU): away from the edges N is a kernel argument anyway,
-    // elsewhere it divides (IEEE float32, identical result).  With nodata almost every wave-row has a window with a hole,
-    // i.e. per-pixel N, and the mask ring has taken the sixteenth wave already: those builds keep the table.
-    const bool use_lut = lut_ok && !(CERT_ONLY && DENSE);
-    if (use_lut)
-        for (int n = lane; n < fit_lut_entries(kh, 2 * rw + 1); n += WAVE) inv_lut[n] = 1.0 / (double)n;
+    // 1/N for the offset division (see HK_INV_N): proven for window counts < 2^8
+    const bool lut_ok = GO && kh * (2 * rw + 1) <= 255;
+    const bool use_lut = lut_ok;
+    const double* __restrict__ inv_lut = HK_INV_N.v;
 
     CS cs;
     cs.clear();
@@ -649,30 +693,29 @@ fit_apply_kernel(const FitArgs a) {
             // leaving row (t - kh) = the slot the entering row overwrites.  The HBM-bound kernels fetch it from LDS one
             // iteration ahead (RING_AHEAD above; 3.06 -> 2.99 ms for `gain` by the latency alone); the VALU-bound kernels do
             // not gain from that and keep the registers.
+            const bool slot_clean = (ring_clean >> slot) & 1ull;
             if constexpr (RING_AHEAD) {
                 // zold_next was read an iteration ago; now fetch the row that leaves at the NEXT iteration from the slot the
                 // entering row is about to take (LDS operations of a wave execute in order)
                 zold = zold_next;
                 const float4 os = ring_v[(slot * 2 + 0) * WAVE + lane];
                 const float4 orr = ring_v[(slot * 2 + 1) * WAVE + lane];
-                zold_next.s[0] = os.x, zold_next.s[1] = os.y, zold_next.s[2] = os.z, zold_next.s[3] = os.w;
+                ring_decode(os, slot_clean, zold_next.s, zold_next.m);
                 zold_next.r[0] = orr.x, zold_next.r[1] = orr.y, zold_next.r[2] = orr.z, zold_next.r[3] = orr.w;
-                zold_next.m = DENSE ? 0u : ring_m[slot * WAVE + lane];
             } else {
                 const float4 os = ring_v[(slot * 2 + 0) * WAVE + lane];
                 const float4 orr = ring_v[(slot * 2 + 1) * WAVE + lane];
-                zold.s[0] = os.x, zold.s[1] = os.y, zold.s[2] = os.z, zold.s[3] = os.w;
+                ring_decode(os, slot_clean, zold.s, zold.m);
                 zold.r[0] = orr.x, zold.r[1] = orr.y, zold.r[2] = orr.z, zold.r[3] = orr.w;
-                zold.m = DENSE ? 0u : ring_m[slot * WAVE + lane];
             }
-            ring_v[(slot * 2 + 0) * WAVE + lane] = make_float4(znew.s[0], znew.s[1], znew.s[2], znew.s[3]);
+            ring_v[(slot * 2 + 0) * WAVE + lane] = ring_encode(znew);
             ring_v[(slot * 2 + 1) * WAVE + lane] = make_float4(znew.r[0], znew.r[1], znew.r[2], znew.r[3]);
-            if constexpr (!DENSE) ring_m[slot * WAVE + lane] = znew.m;
+            if constexpr (!DENSE) ring_clean = (ring_clean & ~(1ull << slot)) | ((unsigned long long)znew.clean << slot);
         } else {
             zold = process_row<MODEL, DENSE>(qo, t_old >= t_first && t_old >= 0 && t_old < H, colbits, full_wave, ts, tr, n0, n1);
             if constexpr (cring) {  // slot2 cycles over rh + 1 rows: the entering row replaces the centre row of rh + 1 ago
-                ring_v[slot2 * WAVE + lane] = make_float4(znew.s[0], znew.s[1], znew.s[2], znew.s[3]);
-                if constexpr (!DENSE) ring_m[slot2 * WAVE + lane] = znew.m;
+                ring_v[slot2 * WAVE + lane] = ring_encode(znew);
+                if constexpr (!DENSE) ring_clean = (ring_clean & ~(1ull << slot2)) | ((unsigned long long)znew.clean << slot2);
             }
         }
 
@@ -694,8 +737,7 @@ fit_apply_kernel(const FitArgs a) {
                 int cs_slot = slot_c;
                 if constexpr (cring) cs_slot = slot2 + 1 == rh + 1 ? 0 : slot2 + 1;
                 const float4 cs4 = ring ? ring_v[(cs_slot * 2 + 0) * WAVE + lane] : ring_v[cs_slot * WAVE + lane];
-                sc[0] = cs4.x, sc[1] = cs4.y, sc[2] = cs4.z, sc[3] = cs4.w;
-                mc = DENSE ? 0u : ring_m[cs_slot * WAVE + lane];
+                ring_decode(cs4, (ring_clean >> cs_slot) & 1ull, sc, mc);
             } else {
                 const RowZ zc = process_row<MODEL, DENSE>(qc, true, colbits, full_wave, ts, tr, n0, n1);
 #pragma unroll
@@ -1026,20 +1068,18 @@ fit_apply_kernel(const FitArgs a) {
     }
 }
 
-// LDS bytes of one wave: the row ring of the mode (see fit_apply_kernel) + the float64 1/N table (fit_lut_entries) that only the
-// gain-offset model reads (the HBM-bound `gain` kernel gets one more resident wave per SIMD without it)
-size_t fit_lds_bytes(int kh, int kw, int ring_mode, bool with_lut, bool with_mask, bool ahead) {
-    const size_t mask = with_mask ? WAVE * sizeof(unsigned) : 0;
-    size_t ring = 0;
-    if (ring_mode == 1) ring = (size_t)(ahead && kh > 1 ? kh - 1 : kh) * (2 * WAVE * sizeof(float4) + mask);
-    if (ring_mode == 2) ring = (size_t)(kh / 2 + 1) * (WAVE * sizeof(float4) + mask);
-    return ring + (with_lut ? fit_lut_entries(kh, kw) * sizeof(double) : 0);
+// LDS bytes of one wave: the row ring of the mode (see fit_apply_kernel).  Validity travels inside the source plane
+// (RING_SENTINEL) and the 1/N table sits in global memory, so every build of a kernel shape needs the same amount: 10 KB at
+// 5x5 = 16 waves per CU (8 KB = 20 waves for the kernels that read the leaving row one iteration ahead).
+size_t fit_lds_bytes(int kh, int ring_mode, bool ahead) {
+    if (ring_mode == 1) return (size_t)(ahead && kh > 1 ? kh - 1 : kh) * 2 * WAVE * sizeof(float4);
+    if (ring_mode == 2) return (size_t)(kh / 2 + 1) * WAVE * sizeof(float4);
+    return 0;
 }
 
 template <int MODEL, bool R2, int RW, bool DENSE, int RING, bool CERT_ONLY>
 static hipError_t launch_build(const FitArgs& a, hipStream_t stream) {
-    const size_t lds = fit_lds_bytes(2 * a.rh + 1, 2 * a.rw + 1, RING, MODEL == 2 && !(CERT_ONLY && DENSE), !DENSE,
-                                     RING == 1 && MODEL != 2 && !R2);
+    const size_t lds = fit_lds_bytes(2 * a.rh + 1, RING, RING == 1 && MODEL != 2 && !R2);
     if (lds > 64 * 1024) {  // forced LDS ring on a tall kernel (testing): raise the 64 KiB dynamic-LDS default
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fit_apply_kernel<MODEL, R2, RW, DENSE, RING, CERT_ONLY>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
