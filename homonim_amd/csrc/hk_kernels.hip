@@ -268,8 +268,9 @@ __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elemen
 // RN64(n / d) lies within 514 ulps of q, so both round to the same float32 unless one of its rounding boundaries (the
 // midpoints of neighbouring float32 values: low 29 mantissa bits == 0x10000000) lies within 514 ulps of q.  quot_guard()
 // maps q to a word that is < 2 * HK_DIV_GUARD + 1 exactly when q is that close (probability 2^-18 per pixel); such a
-// wave-row -- and one with a quotient outside the float32 normal range, which includes every zero / infinite / NaN
-// operand -- is solved again with the IEEE division, so results are identical by construction.
+// pixel pair -- and one with a quotient outside the float32 normal range (every infinite / NaN / zero-denominator case;
+// an exactly zero quotient is exempt, it is exact) -- is divided again the IEEE way, so results are identical by
+// construction.
 #ifndef HK_DIV_GUARD
 #define HK_DIV_GUARD 1024u
 #endif
@@ -282,9 +283,11 @@ __device__ __forceinline__ double fast_quot(double n, double d) {
 __device__ __forceinline__ unsigned quot_guard(double q) {
     return ((unsigned)__double2loint(q) & 0x1fffffffu) - (0x10000000u - HK_DIV_GUARD);
 }
-// biased float64 exponent of q relative to that of 2^-126: <= 0x0fd00000 exactly for |q| in [2^-126, 2^128)
+// biased float64 exponent of q relative to that of 2^-126: <= 0x0fd00000 exactly for |q| in [2^-126, 2^128), and 0 for a
+// zero / float64-denormal q (num == 0 or an underflowing quotient: the IEEE quotient rounds to the same signed float32 zero)
 __device__ __forceinline__ unsigned quot_range(double q) {
-    return ((unsigned)__double2hiint(q) & 0x7ff00000u) - 0x38100000u;
+    const unsigned e = (unsigned)__double2hiint(q) & 0x7ff00000u;
+    return e ? e - 0x38100000u : 0u;
 }
 
 // Streaming stores: the output planes are written once and never read by this launch -- non-temporal stores keep them
@@ -330,13 +333,14 @@ __device__ __forceinline__ RowRaw load_row(const float* __restrict__ sp, const f
 // A processed row as it sits in the LDS ring: zero-filled source/reference + one validity byte per pixel.
 struct RowZ {
     float s[PX], r[PX];
+    float e[PX];  // general kernels: source values as the LDS ring keeps them (RING_SENTINEL in place of invalid pixels)
     unsigned m;  // byte i = mask of pixel i (0/1)
     bool clean;  // wave-uniform: the row is inside the raster and every pixel of every lane of the strip is valid
 };
 
 // DENSE: both rasters have nodata None (raster_array.py:302-303: every pixel valid), so validity is purely geometric:
 // only rows outside the raster / not yet added and the columns of the last strip beyond the raster need zeroing.
-template <int MODEL, bool DENSE>
+template <int MODEL, bool DENSE, bool PERPX = false>
 __device__ __forceinline__ RowZ process_row(const RowRaw& raw, bool row_ok, unsigned colbits, bool full_wave,
                                             const NodataTest& ts, const NodataTest& tr, double n0, double n1) {
     const float s[PX] = {raw.s.x, raw.s.y, raw.s.z, raw.s.w};
@@ -368,12 +372,19 @@ __device__ __forceinline__ RowZ process_row(const RowRaw& raw, bool row_ok, unsi
     } else {
 #pragma unroll
         for (int i = 0; i < PX; ++i) ok[i] = px_valid(s[i], ts) & px_valid(r[i], tr);
+        if constexpr (MODEL == 1 && !PERPX) {
+            // gain-blk-offset re-derives the source mask from the NORMALISED source, whose nodata is NaN
+            // (kernel_model.py:292-298): s * n0 + n1 is NaN exactly where s is (finite block statistics), whatever the
+            // source's own nodata value
+#pragma unroll
+            for (int i = 0; i < PX; ++i) ok[i] = ok[i] & (s[i] == s[i]);
+        }
     }
-    if constexpr (MODEL != 1) {
+    if constexpr (!PERPX) {
         // wave-uniform short cut: nothing to zero, nothing to pack (the usual state away from the edges of real mosaics)
         if (row_ok && full_wave && __all((int)(ok[0] & ok[1] & ok[2] & ok[3]))) {
 #pragma unroll
-            for (int i = 0; i < PX; ++i) z.s[i] = s[i], z.r[i] = r[i];
+            for (int i = 0; i < PX; ++i) z.s[i] = z.e[i] = s[i], z.r[i] = r[i];
             z.m = 0x01010101u;
             z.clean = true;
             return z;
@@ -382,13 +393,14 @@ __device__ __forceinline__ RowZ process_row(const RowRaw& raw, bool row_ok, unsi
 #pragma unroll
     for (int i = 0; i < PX; ++i) {
         bool m = row_ok & (bool)((colbits >> i) & 1u) & ok[i];
-        if constexpr (MODEL == 1) {
-            // gain-blk-offset: the mask is re-derived from the NORMALISED float64 source (kernel_model.py:292-298)
+        if constexpr (PERPX) {
+            // gain-blk-offset with R2: the mask is re-derived from the NORMALISED float64 source (kernel_model.py:292-298)
             const double sd = __dadd_rn(__dmul_rn((double)s[i], n0), n1);
             m = m & !(sd != sd);
         }
         z.s[i] = m ? s[i] : 0.f;
         z.r[i] = m ? r[i] : 0.f;
+        z.e[i] = m ? s[i] : __uint_as_float(RING_SENTINEL);
         z.m |= (m ? 1u : 0u) << (8 * i);
     }
     return z;
@@ -397,8 +409,10 @@ __device__ __forceinline__ RowZ process_row(const RowRaw& raw, bool row_ok, unsi
 // Running float64 column sums of one wave.
 template <int MODEL, bool R2, bool DENSE>
 struct ColSums {
-    static constexpr bool GO = MODEL == 2, BLK = MODEL == 1;
-    static constexpr bool NEED_N = (GO || R2) && !DENSE, NEED_P = GO || R2, NEED_S2 = GO || R2, NEED_R2S = R2;
+    // gain-blk-offset: with R2 the normalised source s' = s * n0 + n1 is formed per pixel in float64 (BLK); without it
+    // the kernel sums the raw source and normalises the window sum (BLKA, see fit_apply_kernel)
+    static constexpr bool GO = MODEL == 2, BLK = MODEL == 1 && R2, BLKA = MODEL == 1 && !R2;
+    static constexpr bool NEED_N = ((GO || R2) && !DENSE) || BLKA, NEED_P = GO || R2, NEED_S2 = GO || R2, NEED_R2S = R2;
     double S[PX], R[PX], P[PX], S2[PX], R2s[PX];
     unsigned N;  // packed bytes
 
@@ -473,9 +487,17 @@ __global__ void __launch_bounds__(WAVE, (CERT_ONLY && RW >= 0 && RW <= 3) ? 4
                                         : ((MODEL == 2 && R2 && !DENSE && (RW < 0 || RW >= 4)) ? HK_FIT_MIN_WAVES_WIDE : HK_FIT_MIN_WAVES))
 fit_apply_kernel(const FitArgs a) {
     using CS = ColSums<MODEL, R2, DENSE>;
-    constexpr bool GO = MODEL == 2, BLK = MODEL == 1;
-    constexpr bool USE_N = GO || R2;
-    static_assert(!(DENSE && BLK), "gain-blk-offset re-derives its mask from the normalised source");
+    // gain-blk-offset (kernel_model.py:276-303) normalises the source with the block's statistics, s' = s * n0 + n1 in
+    // float64 (NumPy >= 2 promotion), and fits `gain` to it.  With R2 (BLK) s' is formed per pixel.  Without (BLKA, the
+    // fused RasterFuse path) the kernel keeps the exact sums of the RAW source and the window count and forms
+    //     sum(s') = RN(RN(n0 * sum(s)) + RN(n1 * N))
+    // per output pixel: algebraically the same number, rounded twice instead of once per pixel and addition -- like the
+    // order of the float64 window summation itself a last-bit freedom of a float64 quantity whose
+    // float32 quotient it moves with probability ~1e-8 per pixel; it halves the kernel's float64 work.
+    constexpr bool GO = MODEL == 2, BLK = MODEL == 1 && R2, BLKA = MODEL == 1 && !R2;
+    constexpr bool USE_N = GO || R2 || BLKA;
+    constexpr bool UNIFORM_N = GO || BLKA;  // builds that track wave-rows whose every window is complete and all-valid
+    static_assert(!(DENSE && MODEL == 1), "gain-blk-offset re-derives its mask from the normalised source");
     extern __shared__ float4 lds4[];
 
     const int lane = threadIdx.x;
@@ -531,10 +553,11 @@ fit_apply_kernel(const FitArgs a) {
     }
 
     double n0 = 0.0, n1 = 0.0;
-    if constexpr (BLK) {
+    if constexpr (MODEL == 1) {
         n0 = a.norm[2 * band];
         n1 = a.norm[2 * band + 1];
     }
+    [[maybe_unused]] const double n1_n_full = __dmul_rn(n1, a.nd_full);  // BLKA: RN(n1 * N) of a complete window
 
     constexpr bool ring = RING == 1;         // full ring: leaving + centre rows
     constexpr bool cring = RING == 2;        // centre-only ring
@@ -558,17 +581,8 @@ fit_apply_kernel(const FitArgs a) {
     // stored as it was loaded; the other rows carry RING_SENTINEL in place of their invalid source pixels
     [[maybe_unused]] unsigned long long ring_clean = 0ull;
     auto ring_encode = [&](const RowZ& z) {
-        float4 v = make_float4(z.s[0], z.s[1], z.s[2], z.s[3]);
-        if constexpr (!DENSE) {
-            if (!z.clean) {
-                const float sent = __uint_as_float(RING_SENTINEL);
-                v.x = (z.m & 0x00000001u) ? v.x : sent;
-                v.y = (z.m & 0x00000100u) ? v.y : sent;
-                v.z = (z.m & 0x00010000u) ? v.z : sent;
-                v.w = (z.m & 0x01000000u) ? v.w : sent;
-            }
-        }
-        return v;
+        if constexpr (DENSE) return make_float4(z.s[0], z.s[1], z.s[2], z.s[3]);
+        else return make_float4(z.e[0], z.e[1], z.e[2], z.e[3]);
     };
     // source values + validity bytes of a ring row (zero fill restored)
     auto ring_decode = [&](const float4& v, bool clean, float (&sv)[PX], unsigned& m) {
@@ -578,12 +592,14 @@ fit_apply_kernel(const FitArgs a) {
             m = 0u;
         } else {
             if (!clean) {
+                // integer form (2-cycle VALU ops): k = min(bits ^ sentinel, 1) is the validity, 0 - k the keep mask
                 m = 0u;
 #pragma unroll
                 for (int i = 0; i < PX; ++i) {
-                    const bool ok = __float_as_uint(sv[i]) != RING_SENTINEL;
-                    sv[i] = ok ? sv[i] : 0.f;
-                    m |= (ok ? 1u : 0u) << (8 * i);
+                    const unsigned b = __float_as_uint(sv[i]);
+                    const unsigned k = min(b ^ RING_SENTINEL, 1u);
+                    sv[i] = __uint_as_float(b & (0u - k));
+                    m |= k << (8 * i);
                 }
             }
         }
@@ -633,14 +649,14 @@ fit_apply_kernel(const FitArgs a) {
     [[maybe_unused]] bool n_uniform = false;
     [[maybe_unused]] bool n_uniform_cols = false;
     [[maybe_unused]] int last_dirty = t_first - 1;
-    if constexpr (GO && MODEL != 1) {
+    if constexpr (UNIFORM_N) {
         bool full = true;
 #pragma unroll
         for (int i = 0; i < PX; ++i) {
             const int c = x + i;
             full &= (c - rw >= 0) && (c + rw < W);
         }
-        n_uniform_cols = lut_ok && __all((int)(!out_lane || full));
+        n_uniform_cols = (GO ? lut_ok : true) && __all((int)(!out_lane || full));
     }
 
     // RING 0 / 2: the re-loaded leaving row runs one iteration ahead where the registers allow it (not in the general
@@ -676,7 +692,7 @@ fit_apply_kernel(const FitArgs a) {
         }
         if constexpr (RING == 0) qc = load_row(sp, rp, a.stride, y_c, H, xq);
 
-        const RowZ znew = process_row<MODEL, DENSE>(q0, t >= 0 && t < H, colbits, full_wave, ts, tr, n0, n1);
+        const RowZ znew = process_row<MODEL, DENSE, MODEL == 1 && R2>(q0, t >= 0 && t < H, colbits, full_wave, ts, tr, n0, n1);
         if constexpr (PFD > 1) {
             q0 = qq[0];
 #pragma unroll
@@ -685,7 +701,7 @@ fit_apply_kernel(const FitArgs a) {
         } else {
             q0 = load_row(sp, rp, a.stride, min(t + 1, t_last), H, xq);  // next row (see above)
         }
-        if constexpr (GO && !DENSE) {
+        if constexpr (UNIFORM_N && !DENSE) {
             if (!znew.clean) last_dirty = t;  // wave-uniform
         }
         RowZ zold;
@@ -712,7 +728,7 @@ fit_apply_kernel(const FitArgs a) {
             ring_v[(slot * 2 + 1) * WAVE + lane] = make_float4(znew.r[0], znew.r[1], znew.r[2], znew.r[3]);
             if constexpr (!DENSE) ring_clean = (ring_clean & ~(1ull << slot)) | ((unsigned long long)znew.clean << slot);
         } else {
-            zold = process_row<MODEL, DENSE>(qo, t_old >= t_first && t_old >= 0 && t_old < H, colbits, full_wave, ts, tr, n0, n1);
+            zold = process_row<MODEL, DENSE, MODEL == 1 && R2>(qo, t_old >= t_first && t_old >= 0 && t_old < H, colbits, full_wave, ts, tr, n0, n1);
             if constexpr (cring) {  // slot2 cycles over rh + 1 rows: the entering row replaces the centre row of rh + 1 ago
                 ring_v[slot2 * WAVE + lane] = ring_encode(znew);
                 if constexpr (!DENSE) ring_clean = (ring_clean & ~(1ull << slot2)) | ((unsigned long long)znew.clean << slot2);
@@ -739,7 +755,7 @@ fit_apply_kernel(const FitArgs a) {
                 const float4 cs4 = ring ? ring_v[(cs_slot * 2 + 0) * WAVE + lane] : ring_v[cs_slot * WAVE + lane];
                 ring_decode(cs4, (ring_clean >> cs_slot) & 1ull, sc, mc);
             } else {
-                const RowZ zc = process_row<MODEL, DENSE>(qc, true, colbits, full_wave, ts, tr, n0, n1);
+                const RowZ zc = process_row<MODEL, DENSE, MODEL == 1 && R2>(qc, true, colbits, full_wave, ts, tr, n0, n1);
 #pragma unroll
                 for (int i = 0; i < PX; ++i) sc[i] = zc.s[i];
                 mc = zc.m;
@@ -781,8 +797,8 @@ fit_apply_kernel(const FitArgs a) {
 #pragma unroll
                     for (int i = 0; i < PX; ++i) Nf[i] = n_uniform ? a.n_full : nrows * ncolf[i];  // exact small integers
                 } else {
-                    if constexpr (GO) n_uniform = n_uniform_cols && last_dirty < t - kh + 1;  // wave-uniform
-                    if (GO && n_uniform) {
+                    if constexpr (UNIFORM_N) n_uniform = n_uniform_cols && last_dirty < t - kh + 1;  // wave-uniform
+                    if (UNIFORM_N && n_uniform) {
 #pragma unroll
                         for (int i = 0; i < PX; ++i) Nf[i] = a.n_full;
                     } else {
@@ -902,9 +918,15 @@ fit_apply_kernel(const FitArgs a) {
                 for (int i = 0; i < PX; ++i) {
                     if constexpr (!GO) Rf[i] = (float)HR[i];  // boxFilter output depth = input depth (float32)
                     if constexpr (GO) {
-                    } else if constexpr (BLK) {
+                    } else if constexpr (MODEL == 1) {
                         // kernel_model.py:265 with a float64 src_sum: np.divide(f32, f64, out=f32); then :301-302
-                        gp[i] = (float)__ddiv_rn((double)Rf[i], HS[i]);
+                        double ssum = HS[i];
+                        if constexpr (BLKA)
+                            ssum = __dadd_rn(__dmul_rn(n0, HS[i]), UN ? n1_n_full : __dmul_rn(n1, (double)Nf[i]));
+                        const double q = fast_quot((double)Rf[i], ssum);
+                        gp[i] = (float)q;
+                        if ((quot_guard(q) < 2u * HK_DIV_GUARD + 1u) | (quot_range(q) > 0x0fd00000u))
+                            gp[i] = (float)__ddiv_rn((double)Rf[i], ssum);
                         o[i] = (float)__dmul_rn((double)gp[i], n1);
                         g[i] = (float)__dmul_rn((double)gp[i], n0);
                     } else {
@@ -1045,7 +1067,7 @@ fit_apply_kernel(const FitArgs a) {
                     if (R2 && a.r2) store4_nt(at(a.r2), masked4(r2v));
                 }
             };
-            if constexpr (GO) {
+            if constexpr (UNIFORM_N) {
                 if (n_uniform) pointwise(std::true_type{});
                 else pointwise(std::false_type{});
             } else {

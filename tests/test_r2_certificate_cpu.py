@@ -41,26 +41,46 @@ def reference_window_math(s, r):
         q = q + hr2
         q = q + (nf * (o * o).astype(F32)).astype(F32).astype(F64)
         r2 = (F32(1) - (q * nd / sstot).astype(F32)).astype(F32)
-    return dict(n=nf, g=g, o=o, sf=sf, rf=rf, hs2=hs2, hr2=hr2, r2=r2)
+        t = (g * sf).astype(F32)
+        tn = (rf - t).astype(F32)
+    return dict(n=nf, g=g, o=o, sf=sf, rf=rf, hs2=hs2, hr2=hr2, r2=r2, num=num, t=t, tn=tn)
 
 
 def certificate(q, kappa, k2=F32(2.0 ** -17)):
-    """ The kernel's expression, operation for operation (hk_kernels.hip, stage B). """
-    g, o, nf, rf, sf = q['g'], q['o'], q['n'], q['rf'], q['sf']
+    """ The kernel's expression, operation for operation (hk_kernels.hip, stage A/B of the gain-offset kernels):
+    fl32(g * num) > kappa * sst + 2^-17 * N*T', with N*T' = g*num + t^2 + N*R2 + tn^2 (t = g*S, tn = R - t). """
+    g, nf, rf = q['g'], q['n'], q['rf']
     with np.errstate(all='ignore'):
-        gg = (g * g).astype(F32)
-        s2f, r2f = q['hs2'].astype(F32), q['hr2'].astype(F32)
+        r2f = q['hr2'].astype(F32)
         nfull = np.full_like(r2f, nf)
+        lhs = (g * q['num']).astype(F32)
         sst = _fma32(nfull, r2f, -(rf * rf).astype(F32))
-        t = _fma32(gg, s2f, _fma32((nf * o).astype(F32), o, r2f))
-        nt = (nf * t).astype(F32)
+        nt = _fma32(q['t'], q['t'], _fma32(q['tn'], q['tn'], _fma32(nfull, r2f, lhs)))
         slack = (k2 * nt).astype(F32)
-        denf = _fma32(nfull, s2f, -(sf * sf).astype(F32))
-        lhs = (gg * denf).astype(F32)
         rhs = _fma32(np.full_like(sst, kappa), sst, slack)
         g_in = (g > F32(2.0 ** -20)) & (g < F32(2.0 ** 20))
         t_in = (nt > F32(2.0 ** -40)) & (nt < F32(2.0 ** 60))
         return (lhs > rhs) & (sst > slack) & g_in & t_in
+
+
+def fast_quotient(num, den):
+    """ Model of hk_kernels.hip fast_quot() + quot_guard(): float32(RN64(num/den)) from a reciprocal of relative error
+    <= 2^-22 and one Newton step; returns (float32 result, needs_ieee_division). """
+    with np.errstate(all='ignore'):
+        y = 1.0 / den
+        # degrade the reciprocal to the hardware's documented accuracy (worst case): perturb by up to 2^-22 relative
+        rng = np.random.default_rng(99)
+        y0 = y * (1.0 + rng.uniform(-1, 1, y.shape) * 2.0 ** -22)
+        e = 1.0 - den * y0                       # one rounding each, like the two fmas
+        y1 = y0 + y0 * e
+        q = num * y1
+        lo = q.view(np.uint64) & np.uint64(0x1fffffff)
+        guard = (lo.astype(np.int64) - (0x10000000 - 1024)) & 0xffffffff
+        hi = (q.view(np.uint64) >> np.uint64(32)).astype(np.int64)
+        e = hi & 0x7ff00000
+        rng_w = np.where(e == 0, 0, (e - 0x38100000) & 0xffffffff)      # a zero quotient is exact
+        again = (guard < 2049) | (rng_w > 0x0fd00000)
+        return q.astype(F32), again
 
 
 def kappa_for(thresh):
@@ -145,3 +165,33 @@ def test_nothing_is_certified_outside_the_magnitude_windows_or_for_impossible_th
     q = reference_window_math(s, r)
     assert not certificate(q, F32(np.inf)).any()          # thresh >= 1: r2_fail_scale() = +inf
     assert not certificate(reference_window_math(s, (-r).astype(F32)), kappa_for(0.25)).any()   # negative gains
+
+
+@pytest.mark.parametrize('kind', ['synth', 'lowvar', 'wild', 'int'])
+def test_fast_quotient_guard_catches_every_rounding_difference(kind):
+    """ Wherever the guard does NOT ask for the IEEE division, float32(num * y1) equals float32(RN64(num / den)) -- with
+    the reciprocal degraded to 2^-22 relative error (the hardware's is 2^-24.4 measured, 2^-23 documented). """
+    rng = np.random.default_rng(zlib.crc32(kind.encode()))
+    s, r = _windows(rng, 400_000, 25, kind)
+    n = s.shape[1]
+    hs, hr = s.astype(F64).sum(1), r.astype(F64).sum(1)
+    hp = (s * r).astype(F32).astype(F64).sum(1)
+    hs2 = (s.astype(F64) ** 2).sum(1)
+    sf, rf, pf = hs.astype(F32), hr.astype(F32), hp.astype(F32)
+    with np.errstate(all='ignore'):
+        num = ((F32(n) * pf).astype(F32) - (sf * rf).astype(F32)).astype(F32).astype(F64)
+        den = F64(n) * hs2 - (sf * sf).astype(F32).astype(F64)
+        exact = (num / den).astype(F32)
+    fast, again = fast_quotient(num, den)
+    same = (fast == exact) | (np.isnan(fast) & np.isnan(exact))
+    assert (same | again).all()
+    assert again.mean() < 1e-3 or kind == 'wild'     # and the guard is rare on ordinary data
+
+
+def test_fast_quotient_special_operands_take_the_ieee_division():
+    num = np.array([1.0, 0.0, -1.0, np.nan, 1.0, 1.0, 1e-30, 1e30], F64)
+    den = np.array([0.0, 0.0, 0.0, 1.0, np.inf, np.nan, 1e30, 1e-30], F64)
+    _, again = fast_quotient(num, den)
+    assert again.all()
+    fast, again = fast_quotient(np.array([0.0, -0.0], F64), np.array([3.0, 3.0], F64))    # exact zeros stay
+    assert not again.any() and (np.signbit(fast) == [False, True]).all()
