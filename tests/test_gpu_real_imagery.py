@@ -283,3 +283,40 @@ def test_fused_refspace_pipeline_equals_step_by_step(pair, model, kernel_shape, 
                              out_dtype='uint8', out_nodata=0)
     assert b_corr.array.dtype == np.uint8
     np.testing.assert_array_equal(b_corr.array, convert_dtype(corr_ra.array, 'uint8', 0))
+
+
+@pytest.mark.parametrize('image', [1, 2, 3, 4])
+def test_published_accuracy_table_of_the_real_stack(image):
+    """ The reference PUBLISHES, for its own test rasters, what the real homonim + OpenCV + GDAL stack prints for
+    `homonim fuse -m gain-blk-offset -k 5 5` (NGI aerial tile x Sentinel-2) followed by `homonim compare` against a
+    Landsat-8 image (docs/cli.rst:47-72, docs/api.rst:33-36; tests/golden/docs_table.json, oracle/gen_docs_table_fixture.py).
+    The SOURCE rows pin GDAL's `average` down-sampling (5 m -> 30 m, nodata handling, grid alignment) and the comparison
+    sums; the CORRECTED rows pin the whole RefSpace chain on real imagery -- average down-sampling onto the 10 m grid,
+    block normalisation, the gain-blk-offset fit, cubic-spline up-sampling of the parameters, apply.  N must agree
+    exactly, r2 / RMSE / rRMSE to every printed digit. """
+    import json
+    import warnings
+    from homonim_amd.compare import RasterCompare
+    from homonim_amd.fuse import RasterFuse
+    from homonim_amd.tiff import read_tiff
+    with open(os.path.join(GOLDEN_DIR, 'docs_table.json')) as f:
+        fx = json.load(f)
+    name = f'ngi_rgb_byte_{image}.tif'
+    src_path = os.path.join(RASTER_DIR, name)
+    l8 = read_tiff(os.path.join(RASTER_DIR, fx['compare']['reference']))
+    bands = [b - 1 for b in fx['compare']['ref_bands_1based']]        # wavelength pairing of homonim/matched_pair.py
+    l8_ra = RasterArray(np.ascontiguousarray(l8.array[bands]), l8.crs, l8.transform, nodata=l8.nodata)
+    src = read_tiff(src_path)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        with RasterCompare(RasterArray(src.array, src.crs, src.transform, nodata=src.nodata), l8_ra) as cmp:
+            src_stats = cmp.process()['Mean']
+        with RasterFuse(src_path, os.path.join(RASTER_DIR, fx['fuse']['reference'])) as rf:
+            corr, _ = rf.process(None, fx['fuse']['model'], tuple(fx['fuse']['kernel_shape']))
+        with RasterCompare(RasterArray(corr, src.crs, src.transform, nodata=float('nan')), l8_ra) as cmp:
+            corr_stats = cmp.process()['Mean']
+    for row, got in ((name, src_stats), (name.replace('.tif', '_FUSE_cREF_mGAIN-BLK-OFFSET_k5_5.tif'), corr_stats)):
+        exp = fx['rows'][row]
+        assert got['n'] == exp['n'], (row, got, exp)
+        for key in ('r2', 'rmse', 'rrmse'):
+            assert f'{got[key]:.3f}' == exp[key], (row, key, got, exp)
