@@ -46,12 +46,18 @@ class SpaceDesc(C.Structure):
 DTYPE_CODES = {'float32': 0, 'uint8': 1, 'uint16': 2, 'int16': 3, 'uint32': 4, 'int32': 5, 'float64': 6}
 
 
+class OutWindow(C.Structure):
+    _fields_ = [('stride', C.c_int64), ('band_stride', C.c_int64), ('row0', C.c_int32), ('col0', C.c_int32),
+                ('rows', C.c_int32), ('cols', C.c_int32)]
+
+
 class DevJob(C.Structure):
     _fields_ = [
         ('src', C.c_void_p), ('ref', C.c_void_p), ('gain', C.c_void_p), ('offset', C.c_void_p), ('r2', C.c_void_p),
         ('corr', C.c_void_p), ('norm', C.c_void_p), ('fail_count', C.c_void_p), ('n_bands', C.c_int32),
         ('height', C.c_int32), ('width', C.c_int32), ('stride', C.c_int64), ('band_stride', C.c_int64),
         ('seg_rows', C.c_int32), ('stream', C.c_int32),
+        ('out_row0', C.c_int32), ('out_col0', C.c_int32), ('out_rows', C.c_int32), ('out_cols', C.c_int32),
     ]  # yapf: disable
 
 
@@ -83,6 +89,8 @@ SIGNATURES = {
                                   C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f32p, _f32p, _P(C.c_uint8)]),
     'hk_fit_apply_io': (C.c_int, [C.c_void_p, _P(FitDesc), _P(IoDesc), C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                   C.c_int32, C.c_int32, _f64p, _f32p, C.c_int32, C.c_void_p, _f64p, _u64p]),
+    'hk_fit_apply_block': (C.c_int, [C.c_void_p, _P(FitDesc), _P(IoDesc), C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                     C.c_int32, C.c_int32, _f64p, C.c_void_p, C.c_int32, C.c_void_p, _P(OutWindow), _f64p, _u64p]),
     'hk_host_alloc': (C.c_int, [C.c_void_p, C.c_size_t, _P(C.c_void_p)]),
     'hk_host_free': (C.c_int, [C.c_void_p, C.c_void_p]),
     'hk_host_register': (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
@@ -289,6 +297,53 @@ class Context:
             corr.ctypes.data_as(vp) if want_corr else None, _ptr(norm, _f64p), C.byref(fail)))
         return params, corr, norm, int(fail.value)
 
+    def fit_apply_block(self, desc: FitDesc, src: np.ndarray, ref: np.ndarray, window, corr_dst: Optional[np.ndarray],
+                        params_dst: Optional[np.ndarray] = None, norm_in: Optional[np.ndarray] = None,
+                        out_nodata: Optional[float] = None):
+        """
+        One block of RasterFuse.process (homonim/fuse.py:295-319) in one call: fit + apply on the read-block
+        ``src`` / ``ref`` (2-D views, any dtype of DTYPE_CODES), and the window ``(row0, col0, rows, cols)`` of it -- the
+        out-block -- written straight into ``corr_dst`` (2-D view of the caller's corrected raster where the out-block
+        belongs, any DTYPE_CODES dtype, unit column stride) and ``params_dst`` (3-D view, float32).  With page-locked
+        arrays (``pin`` / ``pinned_empty``) the transfers are asynchronous.  -> (norm, r2_fail_count)
+        """
+        src, ref = _as_2d_native(src, 'src'), _as_2d_native(ref, 'ref')
+        if src.shape != ref.shape:
+            raise ValueError("'ref_ra' and 'src_ra' must have the same CRS, transform and shape")
+        h, w = src.shape
+        row0, col0, rows, cols = (int(v) for v in window)
+        vp = C.c_void_p
+        n_param = 0
+        stride = band_stride = 0
+        out_dtype = np.dtype(np.float32)
+        if corr_dst is not None:
+            assert corr_dst.shape == (rows, cols) and corr_dst.strides[1] == corr_dst.dtype.itemsize
+            out_dtype = corr_dst.dtype
+            stride = corr_dst.strides[0] // corr_dst.dtype.itemsize
+        if params_dst is not None:
+            assert params_dst.dtype == np.float32 and params_dst.shape[1:] == (rows, cols) and params_dst.strides[2] == 4
+            n_param = params_dst.shape[0]
+            pstride = params_dst.strides[1] // 4
+            assert corr_dst is None or pstride == stride, 'corrected and parameter rasters must share their row stride'
+            stride, band_stride = pstride, params_dst.strides[0] // 4
+        if out_dtype.name not in DTYPE_CODES:
+            raise ValueError(f'unsupported output dtype {out_dtype}')
+        keep_nan = out_nodata is None or (isinstance(out_nodata, float) and math.isnan(out_nodata))
+        io = IoDesc(DTYPE_CODES[src.dtype.name], DTYPE_CODES[ref.dtype.name], DTYPE_CODES[out_dtype.name],
+                    0 if (keep_nan and out_dtype.kind == 'f') or out_nodata is None else 1,
+                    0.0 if out_nodata is None or keep_nan else float(out_nodata))
+        win = OutWindow(stride, band_stride, row0, col0, rows, cols)
+        norm = np.zeros(2, np.float64)
+        fail = C.c_uint64(0)
+        nin = np.ascontiguousarray(norm_in, dtype=np.float64) if norm_in is not None else None
+        _check(self._lib.hk_fit_apply_block(
+            self._h, C.byref(desc), C.byref(io), src.ctypes.data_as(vp), src.strides[0] // src.dtype.itemsize,
+            ref.ctypes.data_as(vp), ref.strides[0] // ref.dtype.itemsize, h, w,
+            _ptr(nin, _f64p) if nin is not None else None,
+            params_dst.ctypes.data_as(vp) if params_dst is not None else None, n_param,
+            corr_dst.ctypes.data_as(vp) if corr_dst is not None else None, C.byref(win), _ptr(norm, _f64p), C.byref(fail)))
+        return norm, int(fail.value)
+
     def apply(self, src: np.ndarray, params: np.ndarray) -> np.ndarray:
         src = _as_f32_2d(src, 'src')
         params = np.ascontiguousarray(params[:2], dtype=np.float32)
@@ -371,12 +426,12 @@ class Context:
         nbytes = int(np.prod(shape)) * dtype.itemsize
         p = C.c_void_p()
         _check(self._lib.hk_host_alloc(self._h, max(nbytes, 1), C.byref(p)))
-        lib, handle, addr = self._lib, self._h, p.value
+        lib, addr = self._lib, p.value
 
         class _Owner:
             def __del__(self_inner):
                 try:
-                    lib.hk_host_free(handle, C.c_void_p(addr))
+                    lib.hk_host_free(None, C.c_void_p(addr))  # page-locked memory outlives the context it came from
                 except Exception:
                     pass
 

@@ -48,6 +48,7 @@ struct Slot {
     size_t norm_ws_bytes = 0;
     void* aux = nullptr;      // on-demand planes + tables of the in-painting branch
     size_t aux_bytes = 0;
+    unsigned long long* fail_host = nullptr;  // pinned word: the r2-mask failure counter comes back with the outputs
     bool busy = false;
 };
 
@@ -220,6 +221,7 @@ void fill_args(hk::FitArgs& a, const hk_fit_desc* d, int xcd_remap) {
         if (m == 0) a.use_ring = 0;
     }
     a.xcd_remap = xcd_remap;
+    a.out_y0 = 0, a.out_y1 = a.height, a.out_x0 = 0, a.out_x1 = a.width;  // store window: the whole job (callers narrow it)
 }
 
 static int env_int(const char* name, int dflt) {
@@ -314,9 +316,54 @@ static int inpaint_band(Slot& sl, const hk::FitArgs& a, const hk_fit_desc* desc,
 // Device-side KernelModel.fit (+ apply when d_corr) of one float32 block already in HBM: block statistics for
 // gain-blk-offset (or the caller's norm), the fused kernel, and the in-painting branch of gain-offset
 // (kernel_model.py:361-371) when valid pixels fail the r2 mask.  d_gain / d_off / d_r2 / d_corr are nullable planes.
+// A fit whose r2-mask outcome has not been looked at yet (run_host reads the counter together with the outputs: one
+// stream synchronisation per block when no pixel fails, which is the usual case on well-conditioned imagery)
+struct FitPending {
+    hk::FitArgs a;
+    bool scratch_params = false;
+    bool active = false;  // gain-offset with a threshold: fit_finish() has to look at the counter
+};
+
+// second half of fit_on_device, once the failure counter is on the host: the certificate-only build's re-run and the
+// in-painting branch (kernel_model.py:361-371).  *requeued = the output planes were (re)written by work queued here.
+int fit_finish(hk_ctx* ctx, Slot& sl, const hk_fit_desc* desc, FitPending& p, unsigned long long n_fail, bool* requeued) {
+    *requeued = false;
+    if (!p.active) return HK_OK;
+    hk::FitArgs& a = p.a;
+    const bool r2 = needs_r2(desc);
+    const size_t plane = (size_t)a.stride * a.height * sizeof(float);
+    if (a.cert_only) {
+        if (n_fail & hk::FIT_RETRY_BIT) {  // the certificate left a wave-row open: the full build decides
+            ctx->cert_only_retried();
+            a.cert_only = 0;
+            HK_HIP(hipMemsetAsync(a.fail_count, 0, sizeof(unsigned long long), sl.stream));
+            HK_HIP(hk::launch_fit_apply(a, desc->model, r2, sl.stream));
+            HK_HIP(hipMemcpyAsync(sl.fail_host, a.fail_count, sizeof(n_fail), hipMemcpyDeviceToHost, sl.stream));
+            HK_HIP(hipStreamSynchronize(sl.stream));
+            n_fail = *sl.fail_host;
+            *requeued = true;
+        } else {
+            ctx->cert_only_settled();
+        }
+    }
+    ctx->expect_r2_failures.store(n_fail > 0 ? 1 : 0);
+    if (n_fail > 0) {
+        const int rc = inpaint_band(sl, a, desc, r2, plane, p.scratch_params);
+        if (rc) return rc;
+        *requeued = true;
+    }
+    return HK_OK;
+}
+
+// Device-side KernelModel.fit (+ apply when d_corr) of one float32 block already in HBM: block statistics for
+// gain-blk-offset (or the caller's norm), the fused kernel, and the in-painting branch of gain-offset
+// (kernel_model.py:361-371) when valid pixels fail the r2 mask.  d_gain / d_off / d_r2 / d_corr are nullable planes.
+// `defer` (nullable): only queue the first pass and leave the r2-mask outcome to the caller (fit_finish); otherwise the
+// stream is synchronised here to read the counter.  `win` (nullable): store window {y0, y1, x0, x1} of the kernel.
 int fit_on_device(hk_ctx* ctx, Slot& sl, const hk_fit_desc* desc, const double* norm_in, float* d_src, float* d_ref,
                   int32_t height, int32_t width, int64_t stride, float* d_gain, float* d_off, float* d_r2, float* d_corr,
-                  double* d_norm, unsigned long long* d_fail, void* d_norm_ws) {
+                  double* d_norm, unsigned long long* d_fail, void* d_norm_ws, FitPending* defer = nullptr,
+                  const int* win = nullptr) {
     const bool blk = desc->model == HK_MODEL_GAIN_BLK_OFFSET;
     const bool r2 = needs_r2(desc);
     const size_t plane = (size_t)stride * height * sizeof(float);
@@ -333,7 +380,9 @@ int fit_on_device(hk_ctx* ctx, Slot& sl, const hk_fit_desc* desc, const double* 
             HK_HIP(hk::launch_block_norm(na, d_norm_ws, d_norm, sl.stream));
         }
     }
-    hk::FitArgs a;
+    FitPending local;
+    FitPending& p = defer ? *defer : local;
+    hk::FitArgs& a = p.a;
     memset(&a, 0, sizeof(a));
     a.src = d_src, a.ref = d_ref, a.gain = d_gain, a.offset = d_off, a.r2 = d_r2, a.corr = d_corr;
     a.norm = blk ? d_norm : nullptr;
@@ -341,7 +390,9 @@ int fit_on_device(hk_ctx* ctx, Slot& sl, const hk_fit_desc* desc, const double* 
     a.height = height, a.width = width, a.stride = stride, a.band_stride = 0, a.n_bands = 1;
     fill_args(a, desc, ctx->xcd_remap);
     fill_grid(a, 0);
-    bool scratch_params = false;
+    // the in-painting branch needs the parameters of the whole block: the store window only narrows the other models
+    if (win && !a.has_thresh) a.out_y0 = win[0], a.out_y1 = win[1], a.out_x0 = win[2], a.out_x1 = win[3];
+    p.scratch_params = false;
     if (a.has_thresh && !d_gain && !d_off && !d_r2 && ctx->expect_r2_failures.load()) {
         // parameters into the slot's scratch planes right away (layout of inpaint_band): no second "first pass"
         int rc = ensure_inpaint_scratch(sl, plane, height, stride);
@@ -349,43 +400,28 @@ int fit_on_device(hk_ctx* ctx, Slot& sl, const hk_fit_desc* desc, const double* 
         char* aux = static_cast<char*>(sl.aux);
         a.gain = reinterpret_cast<float*>(aux + plane), a.offset = reinterpret_cast<float*>(aux + 2 * plane);
         a.r2 = reinterpret_cast<float*>(aux + 3 * plane);
-        scratch_params = true;
+        p.scratch_params = true;
     }
-    a.cert_only = cert_only_eligible(a, desc) && !scratch_params && ctx->try_cert_only();
+    a.cert_only = cert_only_eligible(a, desc) && !p.scratch_params && ctx->try_cert_only();
     HK_HIP(hk::launch_fit_apply(a, desc->model, r2, sl.stream));
+    p.active = a.has_thresh != 0;
+    if (defer || !p.active) return HK_OK;
 
-    if (a.has_thresh) {
-        // kernel_model.py:361-371: when valid pixels fail (r2 > thresh) & (gain > 0), in-paint their offsets from the
-        // passing ones and recompute their gains.  Needs the count on the host (one extra stream sync per call).
-        unsigned long long n_fail = 0;
-        HK_HIP(hipMemcpyAsync(&n_fail, d_fail, sizeof(n_fail), hipMemcpyDeviceToHost, sl.stream));
-        HK_HIP(hipStreamSynchronize(sl.stream));
-        if (a.cert_only) {
-            if (n_fail & hk::FIT_RETRY_BIT) {  // the certificate left a wave-row open: the full build decides
-                ctx->cert_only_retried();
-                a.cert_only = 0;
-                HK_HIP(hipMemsetAsync(d_fail, 0, sizeof(unsigned long long), sl.stream));
-                HK_HIP(hk::launch_fit_apply(a, desc->model, r2, sl.stream));
-                HK_HIP(hipMemcpyAsync(&n_fail, d_fail, sizeof(n_fail), hipMemcpyDeviceToHost, sl.stream));
-                HK_HIP(hipStreamSynchronize(sl.stream));
-            } else {
-                ctx->cert_only_settled();
-            }
-        }
-        ctx->expect_r2_failures.store(n_fail > 0 ? 1 : 0);
-        if (n_fail > 0) {
-            const int rc = inpaint_band(sl, a, desc, r2, plane, scratch_params);
-            if (rc) return rc;
-        }
-    }
-    return HK_OK;
+    // kernel_model.py:361-371: when valid pixels fail (r2 > thresh) & (gain > 0), in-paint their offsets from the
+    // passing ones and recompute their gains.  Needs the count on the host (one extra stream sync per call).
+    HK_HIP(hipMemcpyAsync(sl.fail_host, d_fail, sizeof(unsigned long long), hipMemcpyDeviceToHost, sl.stream));
+    HK_HIP(hipStreamSynchronize(sl.stream));
+    bool requeued = false;
+    return fit_finish(ctx, sl, desc, p, *sl.fail_host, &requeued);
 }
 
 // The whole host-pointer path: stage in (+ typed -> float32), (norm), fused kernel, (float32 -> typed) stage out.
-// `corr_out` / `params_out` nullable; `io` nullable (float32 everywhere).
+// `corr_out` / `params_out` nullable; `io` nullable (float32 everywhere); `ow` nullable: window of the block that is
+// written to corr_out / params_out and their row / plane strides (hk_out_window), else the whole block, packed.
 int run_host(hk_ctx* ctx, const hk_fit_desc* desc, const hk_io_desc* io, const void* src, int64_t src_stride,
              const void* ref, int64_t ref_stride, int32_t height, int32_t width, const double* norm_in, float* params_out,
-             int32_t n_param_bands, void* corr_out, double* norm_out, uint64_t* r2_fail_count, bool norm_only) {
+             int32_t n_param_bands, void* corr_out, double* norm_out, uint64_t* r2_fail_count, bool norm_only,
+             const hk_out_window* ow = nullptr) {
     if (!ctx) return fail(HK_ERR_ARG, "ctx is NULL");
     int rc = validate_desc(desc);
     if (rc) return rc;
@@ -400,6 +436,18 @@ int run_host(hk_ctx* ctx, const hk_fit_desc* desc, const hk_io_desc* io, const v
         if (params_out && n_param_bands != (r2 ? 3 : 2))
             return fail(HK_ERR_ARG, "n_param_bands must be %d for this model configuration", r2 ? 3 : 2);
         if (!params_out && !corr_out) return fail(HK_ERR_ARG, "nothing to compute: params_out and corr_out are NULL");
+    }
+    // output window (defaults: the whole block, written packed)
+    int wr0 = 0, wc0 = 0, wrows = height, wcols = width;
+    int64_t out_stride = width, out_band_stride = (int64_t)height * width;
+    if (ow) {
+        wr0 = ow->row0, wc0 = ow->col0, wrows = ow->rows, wcols = ow->cols;
+        out_stride = ow->stride, out_band_stride = ow->band_stride;
+        if (wr0 < 0 || wc0 < 0 || wrows < 1 || wcols < 1 || wr0 + wrows > height || wc0 + wcols > width)
+            return fail(HK_ERR_ARG, "output window outside the block");
+        if (out_stride < wcols) return fail(HK_ERR_ARG, "output row stride smaller than the window");
+        if (params_out && n_param_bands > 1 && out_band_stride < (int64_t)(wrows - 1) * out_stride + wcols)
+            return fail(HK_ERR_ARG, "output band stride smaller than a plane of the window");
     }
     HK_HIP(hipSetDevice(ctx->device));
 
@@ -462,35 +510,62 @@ int run_host(hk_ctx* ctx, const hk_fit_desc* desc, const hk_io_desc* io, const v
         na.src_nodata = desc->src_nodata, na.ref_nodata = desc->ref_nodata;
         HK_HIP(hk::launch_block_norm(na, d_ws, d_norm, sl.stream));
         if (norm_out) HK_HIP(hipMemcpyAsync(norm_out, d_norm, 2 * sizeof(double), hipMemcpyDeviceToHost, sl.stream));
-    } else {
-        rc = fit_on_device(ctx, sl, desc, norm_in, d_src, d_ref, height, width, stride, d_gain, d_off, d_r2, d_corr, d_norm,
-                           d_fail, d_ws);
-        if (rc) return rc;
-        if (norm_out && blk) HK_HIP(hipMemcpyAsync(norm_out, d_norm, 2 * sizeof(double), hipMemcpyDeviceToHost, sl.stream));
+        HK_HIP(hipStreamSynchronize(sl.stream));
+        return HK_OK;
+    }
 
-        const size_t wbytes = (size_t)width * sizeof(float);
+    // stage out: the window of the block the caller wants, straight into its (strided) arrays
+    const size_t win_off = (size_t)wr0 * stride + wc0;  // elements
+    auto stage_out = [&]() -> int {
+        const size_t wbytes = (size_t)wcols * sizeof(float);
         float* outs[3] = {d_gain, d_off, d_r2};
         if (params_out)
             for (int b = 0; b < n_param_bands; ++b)
-                HK_HIP(hipMemcpy2DAsync(params_out + (size_t)b * height * width, wbytes, outs[b], stride * sizeof(float),
-                                        wbytes, height, hipMemcpyDeviceToHost, sl.stream));
+                HK_HIP(hipMemcpy2DAsync(params_out + (size_t)b * out_band_stride, out_stride * sizeof(float),
+                                        outs[b] + win_off, stride * sizeof(float), wbytes, wrows, hipMemcpyDeviceToHost,
+                                        sl.stream));
         if (corr_out) {
             if (out_cast) {
                 const size_t es = hk::dtype_size(odt);
-                void* d_raw = base + o_raw_o;
+                char* d_raw = base + o_raw_o;
                 HK_HIP(hk::launch_cast_out(odt, d_corr, stride, d_raw, stride, height, width, io->out_has_nodata,
                                            io->out_nodata, sl.stream));
-                HK_HIP(hipMemcpy2DAsync(corr_out, (size_t)width * es, d_raw, stride * es, (size_t)width * es, height,
-                                        hipMemcpyDeviceToHost, sl.stream));
+                HK_HIP(hipMemcpy2DAsync(corr_out, out_stride * es, d_raw + win_off * es, stride * es, (size_t)wcols * es,
+                                        wrows, hipMemcpyDeviceToHost, sl.stream));
             } else {
-                HK_HIP(hipMemcpy2DAsync(corr_out, wbytes, d_corr, stride * sizeof(float), wbytes, height,
-                                        hipMemcpyDeviceToHost, sl.stream));
+                HK_HIP(hipMemcpy2DAsync(corr_out, out_stride * sizeof(float), d_corr + win_off, stride * sizeof(float),
+                                        wbytes, wrows, hipMemcpyDeviceToHost, sl.stream));
             }
         }
-        if (r2_fail_count)
-            HK_HIP(hipMemcpyAsync(r2_fail_count, d_fail, sizeof(uint64_t), hipMemcpyDeviceToHost, sl.stream));
-    }
+        return HK_OK;
+    };
+
+    // The fit, its outputs and its r2-mask counter are queued back to back and the stream is synchronised ONCE; only
+    // when pixels failed the mask (or the certificate-only build asks for its re-run) do the in-painting passes follow,
+    // and the outputs are copied again behind them.
+    FitPending pending;
+    const int kwin[4] = {wr0, wr0 + wrows, wc0 / hk::PX * hk::PX, width};  // rows exactly, columns from the window's first quad
+    rc = fit_on_device(ctx, sl, desc, norm_in, d_src, d_ref, height, width, stride, d_gain, d_off, d_r2, d_corr, d_norm,
+                       d_fail, d_ws, &pending, (ow && !out_cast) ? kwin : nullptr);
+    if (rc) return rc;
+    if (norm_out && blk) HK_HIP(hipMemcpyAsync(norm_out, d_norm, 2 * sizeof(double), hipMemcpyDeviceToHost, sl.stream));
+    if ((rc = stage_out())) return rc;
+    *sl.fail_host = 0;
+    if (pending.active) HK_HIP(hipMemcpyAsync(sl.fail_host, d_fail, sizeof(unsigned long long), hipMemcpyDeviceToHost, sl.stream));
     HK_HIP(hipStreamSynchronize(sl.stream));
+    unsigned long long n_fail = *sl.fail_host;
+    if (pending.active) {
+        bool requeued = false;
+        rc = fit_finish(ctx, sl, desc, pending, n_fail, &requeued);
+        if (rc) return rc;
+        if (requeued) {
+            if ((rc = stage_out())) return rc;
+            HK_HIP(hipMemcpyAsync(sl.fail_host, d_fail, sizeof(unsigned long long), hipMemcpyDeviceToHost, sl.stream));
+            HK_HIP(hipStreamSynchronize(sl.stream));
+            n_fail = *sl.fail_host;  // (the in-painting passes do not count; a re-run of the complete build does)
+        }
+    }
+    if (r2_fail_count) *r2_fail_count = n_fail & ~hk::FIT_RETRY_BIT;
     return HK_OK;
 }
 
@@ -542,6 +617,10 @@ int hk_ctx_create(int device_id, int n_streams, hk_ctx** out) {
             hk_ctx_destroy(ctx);
             return fail(HK_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
         }
+        if (hipHostMalloc(reinterpret_cast<void**>(&s.fail_host), 64, hipHostMallocDefault) != hipSuccess) {
+            hk_ctx_destroy(ctx);
+            return fail(HK_ERR_NOMEM, "hipHostMalloc failed");
+        }
     }
     *out = ctx;
     return HK_OK;
@@ -555,6 +634,7 @@ int hk_ctx_destroy(hk_ctx* ctx) {
         if (s.dev) hipFree(s.dev);
         if (s.norm_ws) hipFree(s.norm_ws);
         if (s.aux) hipFree(s.aux);
+        if (s.fail_host) hipHostFree(s.fail_host);
         if (s.stream) hipStreamDestroy(s.stream);
     }
     delete ctx;
@@ -596,6 +676,14 @@ int hk_fit_apply_io(hk_ctx* ctx, const hk_fit_desc* desc, const hk_io_desc* io, 
                     float* params_out, int32_t n_param_bands, void* corr_out, double* norm_out, uint64_t* r2_fail_count) {
     return run_host(ctx, desc, io, src, src_stride, ref, ref_stride, height, width, norm_in, params_out, n_param_bands,
                     corr_out, norm_out, r2_fail_count, false);
+}
+
+int hk_fit_apply_block(hk_ctx* ctx, const hk_fit_desc* desc, const hk_io_desc* io, const void* src, int64_t src_stride,
+                       const void* ref, int64_t ref_stride, int32_t height, int32_t width, const double* norm_in,
+                       float* params_out, int32_t n_param_bands, void* corr_out, const hk_out_window* window,
+                       double* norm_out, uint64_t* r2_fail_count) {
+    return run_host(ctx, desc, io, src, src_stride, ref, ref_stride, height, width, norm_in, params_out, n_param_bands,
+                    corr_out, norm_out, r2_fail_count, false, window);
 }
 
 int hk_apply(hk_ctx* ctx, const float* src, int64_t src_stride, const float* params, int32_t height, int32_t width,
@@ -852,25 +940,25 @@ int hk_partial_mask(hk_ctx* ctx, const float* in, int64_t in_stride, int32_t in_
 int hk_host_alloc(hk_ctx* ctx, size_t bytes, void** hptr) {
     if (!ctx || !hptr) return fail(HK_ERR_ARG, "NULL argument");
     HK_HIP(hipSetDevice(ctx->device));
-    if (hipHostMalloc(hptr, bytes, hipHostMallocDefault) != hipSuccess)
+    if (hipHostMalloc(hptr, bytes, hipHostMallocPortable) != hipSuccess)
         return fail(HK_ERR_NOMEM, "hipHostMalloc(%zu) failed", bytes);
     return HK_OK;
 }
 int hk_host_free(hk_ctx* ctx, void* hptr) {
-    if (!ctx) return fail(HK_ERR_ARG, "ctx is NULL");
-    HK_HIP(hipSetDevice(ctx->device));
+    // page-locked host memory belongs to no device: `ctx` may be NULL (e.g. the context was destroyed first)
+    (void)ctx;
     HK_HIP(hipHostFree(hptr));
     return HK_OK;
 }
 int hk_host_register(hk_ctx* ctx, void* hptr, size_t bytes) {
     if (!ctx || !hptr) return fail(HK_ERR_ARG, "NULL argument");
     HK_HIP(hipSetDevice(ctx->device));
-    HK_HIP(hipHostRegister(hptr, bytes, hipHostRegisterDefault));
+    HK_HIP(hipHostRegister(hptr, bytes, hipHostRegisterPortable));
     return HK_OK;
 }
 int hk_host_unregister(hk_ctx* ctx, void* hptr) {
-    if (!ctx || !hptr) return fail(HK_ERR_ARG, "NULL argument");
-    HK_HIP(hipSetDevice(ctx->device));
+    if (!hptr) return fail(HK_ERR_ARG, "NULL argument");
+    (void)ctx;  // may be NULL, like hk_host_free
     HK_HIP(hipHostUnregister(hptr));
     return HK_OK;
 }
@@ -917,7 +1005,22 @@ static int check_job(hk_ctx* ctx, const hk_dev_job* job) {
          (uintptr_t)job->r2 | (uintptr_t)job->corr) & 15)
         return fail(HK_ERR_ARG, "device planes must be 16-byte aligned");
     if (job->stream < 0 || job->stream >= (int)ctx->slots.size()) return fail(HK_ERR_ARG, "bad stream index");
+    if (job->out_rows || job->out_cols) {
+        if (job->out_row0 < 0 || job->out_col0 < 0 || job->out_rows < 1 || job->out_cols < 1 ||
+            job->out_row0 + job->out_rows > job->height || job->out_col0 + job->out_cols > job->width)
+            return fail(HK_ERR_ARG, "job store window outside the job");
+        if ((job->out_col0 % hk::PX) != 0 || (((job->out_col0 + job->out_cols) % hk::PX) != 0 && job->out_col0 + job->out_cols != job->width))
+            return fail(HK_ERR_ARG, "job store window must start and end on multiples of %d columns (or at the job's last column)", hk::PX);
+    }
     return HK_OK;
+}
+
+// narrow the kernel's store window to the job's (the halo crop of a block processed in place inside a larger raster)
+static void apply_job_window(hk::FitArgs& a, const hk_dev_job* job) {
+    if (job->out_rows || job->out_cols) {
+        a.out_y0 = job->out_row0, a.out_y1 = job->out_row0 + job->out_rows;
+        a.out_x0 = job->out_col0, a.out_x1 = job->out_col0 + job->out_cols;
+    }
 }
 
 int hk_fit_apply_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* job) {
@@ -936,6 +1039,10 @@ int hk_fit_apply_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* job
     a.n_bands = job->n_bands;
     fill_args(a, desc, ctx->xcd_remap);
     fill_grid(a, job->seg_rows);
+    apply_job_window(a, job);
+    if ((job->out_rows || job->out_cols) && a.has_thresh)
+        return fail(HK_ERR_UNSUPPORTED, "a store window is not supported together with r2_inpaint_thresh (the in-painting "
+                                        "needs the parameters of the whole block)");
     // a band the certificate-only build cannot settle comes back with FIT_RETRY_BIT in its counter; hk_inpaint_dev /
     // hk_inpaint_dev_counts run it again with the full build
     a.cert_only = cert_only_eligible(a, desc) && !ctx->expect_r2_failures.load() && ctx->try_cert_only();
@@ -1199,12 +1306,13 @@ int hk_selftest(hk_ctx* ctx) {
     HK_HIP(hipSetDevice(ctx->device));
     int* d = nullptr;
     HK_HIP(hipMalloc(&d, sizeof(int)));
-    HK_HIP(hipMemset(d, 0, sizeof(int)));
-    HK_HIP(hk::launch_selftest(d, ctx->slots[0].stream));
-    HK_HIP(hipStreamSynchronize(ctx->slots[0].stream));
     int code = -1;
-    HK_HIP(hipMemcpy(&code, d, sizeof(int), hipMemcpyDeviceToHost));
-    HK_HIP(hipFree(d));
+    hipError_t e = hipMemset(d, 0, sizeof(int));
+    if (e == hipSuccess) e = hk::launch_selftest(d, ctx->slots[0].stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->slots[0].stream);
+    if (e == hipSuccess) e = hipMemcpy(&code, d, sizeof(int), hipMemcpyDeviceToHost);
+    hipFree(d);  // on every path
+    if (e != hipSuccess) return fail(HK_ERR_HIP, "self-test launch failed: %s", hipGetErrorString(e));
     if (code != 0) return fail(HK_ERR_HIP, "cross-lane self-test failed (code 0x%x)", code);
     return HK_OK;
 }

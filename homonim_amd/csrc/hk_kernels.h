@@ -49,6 +49,10 @@ struct FitArgs {
     int force_general;      // 1: never take the dense (nodata None) specialisation (testing)
     int use_ring;           // ring mode of fit_apply_kernel: 1 full LDS ring, 2 centre ring + re-loaded leaving row, 0 re-load both
     int xcd_remap;          // G > 0: blockIdx -> unit remap handing each XCD runs of G consecutive units (0: round-robin)
+    // store window: only rows [out_y0, out_y1) x columns [out_x0, out_x1) of the job are written / counted (the halo crop of
+    // homonim/raster_array.py:478-491 when a block of a larger device raster is processed in place); 0,height,0,width = all.
+    // out_x0 and out_x1 are multiples of PX (or out_x1 == width): whole quads are stored.
+    int out_y0, out_y1, out_x0, out_x1;
 };
 
 // model: 0 gain, 1 gain-blk-offset, 2 gain-offset.  with_r2: compute the R2 quantity set.

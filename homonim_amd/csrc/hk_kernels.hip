@@ -539,7 +539,7 @@ fit_apply_kernel(const FitArgs a) {
     unsigned colbits = 0;
 #pragma unroll
     for (int i = 0; i < PX; ++i) colbits |= (x + i >= 0 && x + i < W) ? (1u << i) : 0u;
-    const bool out_lane = lane >= ol && lane < WAVE - ol && lane_in;
+    const bool out_lane = lane >= ol && lane < WAVE - ol && lane_in && x >= a.out_x0 && x < a.out_x1;
 
     // DENSE: the window count is geometric -- (rows of the window inside the raster) x (columns inside the raster)
     [[maybe_unused]] float ncolf[PX];
@@ -744,7 +744,7 @@ fit_apply_kernel(const FitArgs a) {
         }
 
         const int y = t - rh;
-        if (y >= y0) {  // wave-uniform: the first 2*rh iterations only prime the running sums
+        if (y >= y0 && y >= a.out_y0 && y < a.out_y1) {  // wave-uniform: the first 2*rh iterations only prime the running sums
             // centre row of the window
             float sc[PX];
             unsigned mc;

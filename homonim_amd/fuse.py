@@ -208,10 +208,15 @@ def block_pairs_multires(src: Grid, ref: Grid, proc_crs: ProcCrs, n_bands: int, 
                     yield BlockPair(band_i, proc_in, other_in, proc_out, other_out, outer)
 
 
-def shard(items: Sequence, index: int, count: int) -> List:
-    """ The work items of shard ``index`` of ``count`` (round-robin): shards are disjoint and cover ``items``. """
+def shard(items: Sequence, index: int, count: int, contiguous: bool = False) -> List:
+    """ The work items of shard ``index`` of ``count``: round-robin, or -- ``contiguous`` -- consecutive runs of (almost)
+    equal length, which keeps a shard inside as few bands as possible (the block list is band-major,
+    homonim/raster_pair.py:381-389).  Either way the shards are disjoint and cover ``items``. """
     if count < 1 or not (0 <= index < count):
         raise ValueError(f'bad shard {index} of {count}')
+    if contiguous:
+        n = len(items)
+        return list(items[index * n // count:(index + 1) * n // count])
     return list(items[index::count])
 
 
@@ -317,10 +322,11 @@ class RasterFuse:
 
     @staticmethod
     def create_device_config(devices: Optional[Sequence[int]] = None, streams: int = 4, rank: int = 0,
-                             world_size: int = 1) -> Dict:
-        """ (this package only) GPUs of this process, streams per GPU, and this process's shard of the block list. """
+                             world_size: int = 1, contiguous: bool = False, pin: bool = True) -> Dict:
+        """ (this package only) GPUs of this process, streams per GPU, this process's shard of the block list
+        (round-robin, or ``contiguous`` runs), and whether the rasters are page-locked for asynchronous transfers. """
         return dict(devices=None if devices is None else list(devices), streams=int(streams), rank=int(rank),
-                    world_size=int(world_size))
+                    world_size=int(world_size), contiguous=bool(contiguous), pin=bool(pin))
 
     def block_pairs(self, overlap: Tuple[int, int] = (0, 0), max_block_mem: float = math.inf) -> Iterable[BlockPair]:
         if self._same_grid:
@@ -404,10 +410,18 @@ class RasterFuse:
                        out_nodata: Optional[float]):
         """ read -> fused fit+apply (+ output dtype conversion) on the GPU -> write (homonim/fuse.py:295-319) """
         src_ra, ref_ra = self._read(bp)
-        corr_ra, param_ra = model.fit_apply(src_ra, ref_ra, want_params=params is not None, out_dtype=corr.dtype.name,
-                                            out_nodata=out_nodata)
         crop = self._crop(bp)
         rs, cs = bp.src_out_block.toslices()
+        if model.fuses_into(src_ra, ref_ra):
+            # the out-block goes straight from the device into the corrected / parameter rasters (no block-sized
+            # temporaries, no host-side crop copy; asynchronous when the rasters are page-locked)
+            n_src = self._src.shape[0]
+            params_dst = params[bp.band_i::n_src][:, rs, cs] if params is not None else None
+            window = (crop[0].start, crop[1].start, bp.src_out_block.height, bp.src_out_block.width)
+            model.fit_apply_into(src_ra, ref_ra, window, corr[bp.band_i][rs, cs], params_dst, out_nodata=out_nodata)
+            return
+        corr_ra, param_ra = model.fit_apply(src_ra, ref_ra, want_params=params is not None, out_dtype=corr.dtype.name,
+                                            out_nodata=out_nodata)
         corr[bp.band_i][rs, cs] = corr_ra.array[crop]
         if params is not None:
             n_src = self._src.shape[0]
@@ -418,13 +432,16 @@ class RasterFuse:
                 kernel_shape: Tuple[int, int] = KernelModel.default_kernel_shape,
                 param_filename: Optional[Union[str, os.PathLike, bool]] = None, build_ovw: bool = True,
                 overwrite: bool = False, model_config: Optional[Dict] = None, out_profile: Optional[Dict] = None,
-                block_config: Optional[Dict] = None, device_config: Optional[Dict] = None):
+                block_config: Optional[Dict] = None, device_config: Optional[Dict] = None,
+                corr_out: Optional[np.ndarray] = None):
         """
         Same arguments as homonim.RasterFuse.process (fuse.py:321-332) plus ``device_config``.  Returns
         ``(corrected, params)``: float32 arrays (bands, H, W) and (n_param_bands * bands, H, W) or None.  When
         ``corr_filename`` / ``param_filename`` are paths the arrays are also written there: ``.tif`` as a tiled DEFLATE
         GeoTIFF with the reference's FUSE_* provenance tags (homonim_amd/tiff.py), anything else with ``numpy.save``
         (``build_ovw`` and ``out_profile['driver'|'creation_options']`` are accepted and ignored).  With ``world_size > 1`` only this rank's blocks are filled in (others stay nodata).
+        ``corr_out``: a caller-owned corrected raster (bands, H, W) of the output dtype to fill instead of a new one, e.g.
+        page-locked memory of a pipeline that processes many rasters (it is NOT pre-filled with nodata).
         """
         if self._closed:
             raise IoError('The raster pair has been closed')
@@ -455,7 +472,12 @@ class RasterFuse:
         if out_dtype.name not in _hk.DTYPE_CODES:
             raise ValueError(f"unsupported output dtype '{out_profile['dtype']}'")
         fill = (np.nan if out_dtype.kind == 'f' else 0) if nodata is None else nodata
-        corr = np.full((n_src, *self.shape), fill, dtype=out_dtype)
+        if corr_out is not None:
+            if corr_out.shape != (n_src, *self.shape) or corr_out.dtype != out_dtype or not corr_out.flags['C_CONTIGUOUS']:
+                raise ValueError('`corr_out` must be a C-contiguous (bands, height, width) array of the output dtype')
+            corr = corr_out
+        else:
+            corr = np.full((n_src, *self.shape), fill, dtype=out_dtype)
         n_param = 3 if models[0]._emit_r2 else 2
         # parameters live on the processing grid (homonim/fuse.py:254-293): the reference's when proc_crs == ref
         param_shape = self._ref.shape[-2:] if (self._proc_crs == ProcCrs.ref and not self._same_grid) else self.shape
@@ -463,19 +485,18 @@ class RasterFuse:
         process_block = self._process_block if self._same_grid else self._process_block_multires
 
         blocks = list(self.block_pairs(overlap=overlap, max_block_mem=block_config['max_block_mem']))
-        blocks = shard(blocks, device_config['rank'], device_config['world_size'])
-        if block_config['threads'] == 1 and len(models) == 1:
-            for bp in blocks:
-                process_block(bp, models[0], corr, params, nodata)
-        else:
-            workers = max(block_config['threads'], len(models))
-            with ThreadPoolExecutor(max_workers=workers) as ex:
-                futures = [
-                    ex.submit(process_block, bp, models[i % len(models)], corr, params, nodata)
-                    for i, bp in enumerate(blocks)
-                ]
-                for f in as_completed(futures):
-                    f.result()  # re-raise worker exceptions (fuse.py:404-408)
+        blocks = shard(blocks, device_config['rank'], device_config['world_size'], device_config['contiguous'])
+        # page-lock the rasters for the duration of the block loop: H2D / D2H of different blocks then run asynchronously
+        # beside the kernels (hipMemcpyAsync from pageable memory stages through a bounce buffer and blocks the caller)
+        pinned = self._pin(models[0].context, [self._src, self._ref, corr, params]) if device_config['pin'] else []
+        try:
+            self._run_blocks(blocks, models, process_block, corr, params, nodata, block_config)
+        finally:
+            for arr in pinned:
+                try:
+                    models[0].context.unpin(arr)
+                except Exception:
+                    pass
 
         if isinstance(corr_filename, (str, os.PathLike)) or (want_params and isinstance(param_filename, (str, os.PathLike))):
             # provenance tags of homonim/fuse.py:193-207
@@ -489,6 +510,35 @@ class RasterFuse:
                 param_tf = self._ref_transform if (self._proc_crs == ProcCrs.ref and not self._same_grid) else self._transform
                 self._save(param_filename, params, param_tf, float('nan'), meta)
         return corr, params
+
+    @staticmethod
+    def _pin(ctx, arrays) -> List[np.ndarray]:
+        """ hipHostRegister the arrays that can be (C-contiguous, not page-locked yet); returns those that were. """
+        done = []
+        for arr in arrays:
+            if arr is None or not isinstance(arr, np.ndarray) or not arr.flags['C_CONTIGUOUS'] or arr.nbytes == 0:
+                continue
+            try:
+                ctx.pin(arr)
+                done.append(arr)
+            except Exception:
+                pass  # already page-locked (hk_host_alloc / an enclosing registration) or not lockable: stays as it is
+        return done
+
+    @staticmethod
+    def _run_blocks(blocks, models, process_block, corr, params, nodata, block_config):
+        if block_config['threads'] == 1 and len(models) == 1:
+            for bp in blocks:
+                process_block(bp, models[0], corr, params, nodata)
+        else:
+            workers = max(block_config['threads'], len(models))
+            with ThreadPoolExecutor(max_workers=workers) as ex:
+                futures = [
+                    ex.submit(process_block, bp, models[i % len(models)], corr, params, nodata)
+                    for i, bp in enumerate(blocks)
+                ]
+                for f in as_completed(futures):
+                    f.result()  # re-raise worker exceptions (fuse.py:404-408)
 
     def _save(self, filename, array: np.ndarray, transform: Affine, nodata, metadata: Dict):
         """ ``.tif`` / ``.tiff``: tiled DEFLATE GeoTIFF like the reference's default output profile (no overviews);

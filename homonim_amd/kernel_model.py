@@ -152,6 +152,29 @@ class KernelModel:
         corr_ra = RasterArray.from_profile(corr, corr_profile)
         return corr_ra, (RasterArray.from_profile(params, profile) if want_params else None)
 
+    def fuses_into(self, src_ra: RasterArray, ref_ra: RasterArray) -> bool:
+        """ True when ``fit_apply_into`` covers this model configuration for the pair (base-class fit + apply on a shared
+        grid, nothing between them): the wrappers narrow it. """
+        return (ref_ra.transform == src_ra.transform) and (ref_ra.shape == src_ra.shape)
+
+    def fit_apply_into(self, src_ra: RasterArray, ref_ra: RasterArray, window, corr_dst: np.ndarray,
+                       params_dst: Optional[np.ndarray] = None, out_nodata: Optional[float] = RasterArray.default_nodata) -> int:
+        """
+        ``fit_apply`` for the block loop of ``RasterFuse.process`` (homonim/fuse.py:295-319): the window
+        ``(row0, col0, rows, cols)`` of the block -- its out-block, i.e. the block without the halo that
+        raster_array.py:478-491 crops on writing -- goes straight into ``corr_dst`` / ``params_dst``, views of the
+        caller's corrected / parameter rasters (their dtype is the output dtype).  One call = one upload of the read-block,
+        one download of the out-block, one stream synchronisation; asynchronous when the rasters are page-locked.
+        Returns the number of pixels that failed the r2 mask.
+        """
+        if not KernelModel.fuses_into(self, src_ra, ref_ra):
+            raise ValueError("'ref_ra' and 'src_ra' must have the same CRS, transform and shape")
+        _, n_fail = self.context.fit_apply_block(
+            self._desc(src_ra, ref_ra), self._band(src_ra, 'src_ra'), self._band(ref_ra, 'ref_ra'), window, corr_dst,
+            params_dst, out_nodata=out_nodata
+        )
+        return n_fail
+
     def block_norm(self, src_ra: RasterArray, ref_ra: RasterArray) -> np.ndarray:
         """ The [gain, offset] block normalisation of gain-blk-offset (kernel_model.py:216-229), float64[2]. """
         return self.context.block_norm(self._desc(src_ra, ref_ra), self._band(src_ra, 'src_ra'),
@@ -215,6 +238,9 @@ class RefSpaceModel(KernelModel):
         return KernelModel.apply(self, src_ra, param_us_ra)
 
 
+    def fuses_into(self, src_ra: RasterArray, ref_ra: RasterArray) -> bool:
+        return _same_grid(src_ra, ref_ra) and not self._mask_partial
+
     def fit_apply(self, src_ra: RasterArray, ref_ra: RasterArray, want_params: bool = False,
                   out_dtype: str = RasterArray.default_dtype,
                   out_nodata: Optional[float] = RasterArray.default_nodata) -> Tuple[RasterArray, Optional[RasterArray]]:
@@ -260,3 +286,22 @@ class SrcSpaceModel(KernelModel):
         elif not _same_grid(src_ra, ref_ra):
             param_ra.mask = src_ra.mask  # :533 (a no-op on a shared grid)
         return param_ra
+
+    def fuses_into(self, src_ra: RasterArray, ref_ra: RasterArray) -> bool:
+        return _same_grid(src_ra, ref_ra) and not self._mask_partial
+
+    def fit_apply(self, src_ra: RasterArray, ref_ra: RasterArray, want_params: bool = False,
+                  out_dtype: str = RasterArray.default_dtype,
+                  out_nodata: Optional[float] = RasterArray.default_nodata) -> Tuple[RasterArray, Optional[RasterArray]]:
+        """ One fused pass on a shared grid; with ``mask_partial`` (or across grids) the reference's own sequence
+        ``apply(src_ra, fit(src_ra, ref_ra))`` -- SrcSpaceModel.fit masks the parameters with the eroded full-coverage
+        mask (kernel_model.py:526-531), which the fused kernel does not know about. """
+        if self.fuses_into(src_ra, ref_ra):
+            return KernelModel.fit_apply(self, src_ra, ref_ra, want_params, out_dtype, out_nodata)
+        param_ra = self.fit(src_ra.copy(), ref_ra)
+        corr_ra = self.apply(src_ra, param_ra)
+        if np.dtype(out_dtype) != np.float32 or not (out_nodata is None or (isinstance(out_nodata, float) and np.isnan(out_nodata))):
+            from homonim_amd.fuse import convert_dtype
+            arr = convert_dtype(corr_ra.array, str(np.dtype(out_dtype)), out_nodata)
+            corr_ra = RasterArray.from_profile(arr, dict(corr_ra.profile, nodata=out_nodata, dtype=str(np.dtype(out_dtype))))
+        return corr_ra, (param_ra if want_params else None)

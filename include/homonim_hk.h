@@ -161,6 +161,28 @@ int hk_fit_apply_io(hk_ctx* ctx, const hk_fit_desc* desc, const hk_io_desc* io, 
                     float* params_out /* nullable */, int32_t n_param_bands, void* corr_out /* nullable */,
                     double* norm_out, uint64_t* r2_fail_count);
 
+/* Where the outputs of a block go when the caller keeps whole rasters on the host (homonim/fuse.py:310-319 writes the
+ * out-block of every block into the corrected / parameter files, raster_array.py:478-491 crops the halo): rows
+ * [row0, row0 + rows) x columns [col0, col0 + cols) of the block are copied to corr_out / params_out, whose rows are
+ * `stride` elements apart and whose parameter planes `band_stride` elements -- i.e. corr_out points at the pixel of
+ * the caller's raster where the window's first pixel belongs. */
+typedef struct hk_out_window {
+    int64_t stride;       /* elements between rows of corr_out / params_out (>= cols) */
+    int64_t band_stride;  /* elements between the planes of params_out */
+    int32_t row0, col0;   /* first row / column of the block that is written */
+    int32_t rows, cols;   /* size of the written window */
+} hk_out_window;
+
+/* hk_fit_apply_io with an output window: the block loop of RasterFuse.process (homonim/fuse.py:295-319) per call --
+ * read-block in, out-block of the corrected raster (and of the parameters) out, straight into the caller's arrays.
+ * When src / ref / corr_out / params_out are page-locked (hk_host_alloc / hk_host_register) the copies are asynchronous
+ * and the call synchronises its stream once; calls from several threads overlap their transfers and kernels. */
+int hk_fit_apply_block(hk_ctx* ctx, const hk_fit_desc* desc, const hk_io_desc* io, const void* src, int64_t src_stride,
+                       const void* ref, int64_t ref_stride, int32_t height, int32_t width, const double* norm_in,
+                       float* params_out, int32_t n_param_bands, void* corr_out, const hk_out_window* window,
+                       double* norm_out, uint64_t* r2_fail_count);
+
+
 /* RefSpaceModel.fit + RefSpaceModel.apply (homonim/kernel_model.py:476-503) of one block pair on DIFFERENT grids of one
  * CRS, entirely on the device -- source and reference blocks in, corrected block (source grid) out:
  *   source --down_resampling--> reference grid; KernelModel.fit there (incl. block statistics / in-painting);
@@ -186,9 +208,9 @@ int hk_refspace_fit_apply(hk_ctx* ctx, const hk_fit_desc* desc, const hk_io_desc
  * overlap; with pageable memory HIP stages every copy synchronously.  The reference has no counterpart (its blocks are
  * numpy arrays read by rasterio, homonim/raster_pair.py:331-340). */
 int hk_host_alloc(hk_ctx* ctx, size_t bytes, void** hptr);   /* pinned allocation */
-int hk_host_free(hk_ctx* ctx, void* hptr);
-int hk_host_register(hk_ctx* ctx, void* hptr, size_t bytes); /* pin existing memory in place */
-int hk_host_unregister(hk_ctx* ctx, void* hptr);
+int hk_host_free(hk_ctx* ctx, void* hptr);                   /* ctx may be NULL (the memory belongs to no device) */
+int hk_host_register(hk_ctx* ctx, void* hptr, size_t bytes); /* pin existing memory in place (usable from every device) */
+int hk_host_unregister(hk_ctx* ctx, void* hptr);             /* ctx may be NULL */
 
 /* ------------------------------------------------------------------------------------------------------------------
  * device-resident entry points (inputs already in HBM): what bench.py times and what the streaming tile pipeline
@@ -218,6 +240,12 @@ typedef struct {
     int64_t band_stride;   /* elements between band planes, all arrays */
     int32_t seg_rows;      /* rows per wave segment; 0 = library default */
     int32_t stream;        /* index into the context's stream pool */
+    /* Store window of hk_fit_apply_dev, in job coordinates: only these rows / columns of the job are written (and counted).
+     * A block of a larger device-resident raster is processed in place -- src / ref / corr point at the block's first
+     * pixel INCLUDING its halo, height / width are the in-block's -- and only its out-block is stored: the halo crop of
+     * homonim/raster_array.py:478-491 as homonim/fuse.py:310-312 applies it.  All zero = the whole job.  out_col0 and
+     * out_col0 + out_cols must be multiples of 4 (or end at the job's last column).  Not with r2_inpaint_thresh. */
+    int32_t out_row0, out_col0, out_rows, out_cols;
 } hk_dev_job;
 
 /* Launch the fused kernel over all bands of a device-resident job (asynchronous on stream `job->stream`).  With an r2

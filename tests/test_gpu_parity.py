@@ -1248,3 +1248,119 @@ def test_force_proc_crs(ctx):
     p = km.fit(ra50, ra100)
     out = km.apply(ra50, p)
     assert ra50.array[ra50.mask] == pytest.approx(out.array[out.mask], abs=2)
+
+
+# -- round 2: out-block windows (host-pointer and device-resident), SrcSpaceModel.fit_apply with mask_partial ------------
+@pytest.mark.parametrize('model, kernel_shape, thresh, out_dtype', [
+    ('gain-offset', (5, 5), 0.25, 'float32'), ('gain-blk-offset', (5, 5), None, 'float32'), ('gain', (3, 3), None, 'uint8'),
+    ('gain-offset', (5, 5), 0.9999, 'float32'),     # most pixels fail the r2 mask: in-painting passes + second copy-out
+])
+def test_fit_apply_block_writes_the_out_block_in_place(ctx, model, kernel_shape, thresh, out_dtype):
+    """ hk_fit_apply_block = hk_fit_apply_io + crop, written straight into a window of the caller's larger rasters
+    (strided rows, strided parameter planes) -- pageable and page-locked -- must equal the packed result, cropped. """
+    src, ref = onp.synth_pair(301, 515, 21, 'frame+holes')
+    if out_dtype == 'uint8':
+        src, ref = (np.where(np.isnan(a), np.nan, np.round(a * 200)).astype(np.float32) for a in (src, ref))
+    desc = _hk.make_desc(model, kernel_shape, True, thresh, np.nan, np.nan)
+    nodata = 0 if out_dtype == 'uint8' else None
+    exp_p, exp_c, _, exp_fail = ctx.fit_apply(desc, src, ref, 3, want_params=True, want_corr=True, out_dtype=out_dtype,
+                                              out_nodata=nodata)
+    r0, c0, rows, cols = 3, 8, 290, 500
+    for pinned in (False, True):
+        alloc = (lambda shape, dt: ctx.pinned_empty(shape, dt)) if pinned else (lambda shape, dt: np.empty(shape, dt))
+        big_c = alloc((2, 400, 700), out_dtype)     # "corrected raster" of 2 bands: the block lands in band 1 at (50, 100)
+        big_p = alloc((6, 400, 700), np.float32)    # 3 parameters x 2 bands, band-interleaved like the reference's file
+        big_c[:] = 7
+        big_p[:] = 7
+        corr_dst = big_c[1, 50:50 + rows, 100:100 + cols]
+        params_dst = big_p[1::2][:, 50:50 + rows, 100:100 + cols]
+        _, n_fail = ctx.fit_apply_block(desc, src, ref, (r0, c0, rows, cols), corr_dst, params_dst, out_nodata=nodata)
+        assert n_fail == exp_fail
+        got_c, exp_win = np.array(corr_dst), exp_c[r0:r0 + rows, c0:c0 + cols]
+        assert (got_c == exp_win).all() if out_dtype == 'uint8' else bool(((got_c == exp_win) | (np.isnan(got_c) & np.isnan(exp_win))).all())
+        assert_same_f32(np.array(params_dst), exp_p[:, r0:r0 + rows, c0:c0 + cols], 'parameter window')
+        big_c[1, 50:50 + rows, 100:100 + cols] = 7      # nothing outside the window was touched
+        big_p[1::2][:, 50:50 + rows, 100:100 + cols] = 7
+        assert (np.array(big_c) == 7).all() and (np.array(big_p) == 7).all()
+    if thresh == 0.9999:
+        assert exp_fail > 1000
+
+
+@pytest.mark.parametrize('model, kernel_shape', [('gain-blk-offset', (15, 15)), ('gain', (5, 5)), ('gain-offset', (7, 7))])
+def test_device_job_store_window(ctx, oc, model, kernel_shape):
+    """ A block of a larger device-resident raster processed in place (BASELINE.json configs[3]): job = the in-block
+    including its halo, store window = its out-block; pixels outside the window keep their previous contents and the
+    window equals the whole-job result there. """
+    H, W = 520, 1100
+    stride = 1152
+    src, ref = onp.synth_pair(H, W, 33, 'frame+holes')
+    pad = lambda a: np.pad(a, ((0, 0), (0, stride - W)))
+    d = {k: ctx.dev_alloc(4 * stride * H) for k in ('src', 'ref', 'corr', 'full')}
+    ctx.h2d(d['src'], pad(src)), ctx.h2d(d['ref'], pad(ref))
+    marker = np.full((H, stride), -5.0, np.float32)
+    ctx.h2d(d['corr'], marker), ctx.h2d(d['full'], marker)
+    desc = _hk.make_desc(model, kernel_shape, False, None, np.nan, np.nan)
+    norm = ctx.dev_alloc(16)
+    # the in-block: rows 40..440, columns 96..996 of the raster (16-byte aligned origin), out-block inset by 8
+    y0, x0, h, w = 40, 96, 400, 900
+    job = _hk.DevJob()
+    off = 4 * (y0 * stride + x0)
+    job.src, job.ref = d['src'] + off, d['ref'] + off
+    job.gain = job.offset = job.r2 = job.fail_count = None
+    job.norm = norm if model == 'gain-blk-offset' else None
+    job.n_bands, job.height, job.width, job.stride, job.band_stride, job.seg_rows, job.stream = 1, h, w, stride, 0, 0, 0
+    if model == 'gain-blk-offset':
+        ctx.block_norm_dev(desc, job, norm)
+    job.corr = d['full'] + off
+    ctx.fit_apply_dev(desc, job)                               # whole in-block
+    job.corr = d['corr'] + off
+    job.out_row0, job.out_col0, job.out_rows, job.out_cols = 8, 8, h - 16, w - 16
+    ctx.fit_apply_dev(desc, job)                               # out-block only
+    ctx.stream_sync(0)
+    full, win = np.empty((H, stride), np.float32), np.empty((H, stride), np.float32)
+    ctx.d2h(full, d['full']), ctx.d2h(win, d['corr'])
+    inner = (slice(y0 + 8, y0 + h - 8), slice(x0 + 8, x0 + w - 8))
+    assert_same_f32(win[inner], full[inner], 'store window vs whole job')
+    win[inner] = -5.0
+    assert (win == -5.0).all()                                 # the halo (and everything else) was not written
+    # and the block equals the oracle on the in-block
+    nm = None
+    if model == 'gain-blk-offset':
+        nm = np.zeros(2)
+        ctx.d2h(nm, norm)
+    params, _ = onp.fit(model, src[y0:y0 + h, x0:x0 + w], np.nan, ref[y0:y0 + h, x0:x0 + w], np.nan, kernel_shape, False, None,
+                        norm_model=nm)
+    assert_close_ulp(full[y0:y0 + h, x0:x0 + w], onp.apply(src[y0:y0 + h, x0:x0 + w], params), 'in-block vs oracle')
+    for k in d.values():
+        ctx.dev_free(k)
+    ctx.dev_free(norm)
+    # a window that does not start on a quad, or together with the r2 mask, is refused
+    job.out_col0 = 6
+    with pytest.raises(Exception):
+        ctx.fit_apply_dev(desc, job)
+
+
+@pytest.mark.parametrize('case', [c for c in _mask_partial_cases() if c['space'] == 'src'], ids=lambda c: c['name'])
+def test_src_space_fit_apply_honours_mask_partial(ctx, case):
+    """ SrcSpaceModel.fit_apply on a shared grid with mask_partial=True (what RasterFuse(proc_crs='src') calls per block)
+    must apply the eroded full-coverage mask of SrcSpaceModel.fit (kernel_model.py:526-531): same outputs as the
+    reference's fit -> apply goldens. """
+    import os, warnings
+    from conftest import GOLDEN_DIR
+    g = np.load(os.path.join(GOLDEN_DIR, 'mask_partial.npz'))
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        km = SrcSpaceModel(case['model'], tuple(case['kernel_shape']), find_r2=True, mask_partial=True, r2_inpaint_thresh=None)
+    corr_ra, param_ra = km.fit_apply(_ra(g['src'].copy(), np.nan), _ra(g['ref'].copy(), np.nan), want_params=True)
+    exp_p, exp_c = g[case['name'] + '_params'], g[case['name'] + '_corr']
+    assert (np.isnan(param_ra.array) == np.isnan(exp_p)).all() and (np.isnan(corr_ra.array) == np.isnan(exp_c)).all()
+    assert np.isnan(exp_c).sum() > np.isnan(g['src']).sum()          # the mask did shrink
+    ok = ~np.isnan(exp_c)
+    assert np.max(np.abs(corr_ra.array[ok] - exp_c[ok]) / np.maximum(np.abs(exp_c[ok]), 1e-6)) < 1e-5
+    # and through the block loop
+    from homonim_amd.fuse import RasterFuse
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        corr, _ = RasterFuse(g['src'], g['ref'], proc_crs='src').process(
+            None, case['model'], tuple(case['kernel_shape']), model_config=dict(mask_partial=True, r2_inpaint_thresh=None))
+    assert (np.isnan(corr[0]) == np.isnan(exp_c)).all()
