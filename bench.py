@@ -1,17 +1,28 @@
 """
-bench.py -- headline benchmark of the homonim kernel-model hot path on MI355X.
+bench.py -- benchmarks of the homonim kernel-model hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    python bench.py [--config N] [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W [--config N]
 
-Workload (BASELINE.json configs[2], the configuration the metric is quoted on): synthetic float32 4-band
-16384 x 16384 source / reference pair resident in HBM, Model.gain_offset, 5x5 kernel, R2 + r2-mask test
-(r2_inpaint_thresh 0.25), fused fit+apply.  One "step" = one pass of the hot path over the whole 4-band raster = ONE
-kernel launch.  Each rank owns one GPU and its own raster (tiles/bands are independent: no data-path collective),
-so scaling is weak and value = units processed by all ranks / max-over-ranks time.
+--config (index into BASELINE.json `configs`; default 2, the configuration the metric is quoted on):
+  1  synthetic float32 4-band 8192 x 8192, Model.gain 5x5, resident in HBM; one step = one fused launch.
+  2  synthetic float32 4-band 16384 x 16384, Model.gain_offset 5x5 (R2 + r2-mask test, r2_inpaint_thresh 0.25),
+     resident in HBM; one step = one fused launch + the host's look at the failure counters.          [HEADLINE]
+  3  synthetic float32 8-band 16384 x 16384, Model.gain_blk_offset 15x15, cut into the reference's own blocks
+     (4096 x 4096 + 8-pixel halo, homonim/raster_pair.py:342-428), every block normalised by its own statistics and
+     processed in place in the resident raster; blocks are dealt to the ranks in band-major runs.  One step = all
+     128 blocks (STRONG scaling: the work is fixed, ranks split it).
+  4  mosaic of 64 independent 4-band 4096 x 4096 tiles, Model.gain_offset 5x5, one tile per stream, tiles dealt to the
+     ranks (strong scaling).  One step = all tiles.
+Configs 1 and 2 run one raster per rank (weak scaling: tiles / bands are independent, there is no data-path collective).
+
+`value` is always the device-resident rate (inputs in HBM when the timed region starts).  Configs 3 and 4 add
+`end_to_end`: the same blocks / tiles through RasterFuse.process from page-locked HOST rasters (H2D || kernel || D2H on
+the context's streams) -- the PCIe-inclusive rate, never the headline.
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline` and `cpu_baseline`.
-PyTorch is used only for the multi-process rendezvous/barrier when N > 1 (torch.distributed, backend nccl = RCCL).
+PyTorch is used only for the multi-process rendezvous / barrier when N > 1 (torch.distributed, backend nccl = RCCL).
 """
 import argparse
 import json
@@ -27,82 +38,130 @@ sys.path.insert(0, REPO)
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 ALGO_BYTES_PER_PX = 12   # read src 4 + read ref 4 + write corrected 4
 
+CONFIGS = {
+    1: dict(model='gain', kernel=5, size=8192, bands=4),
+    2: dict(model='gain-offset', kernel=5, size=16384, bands=4),
+    3: dict(model='gain-blk-offset', kernel=15, size=16384, bands=8),
+    4: dict(model='gain-offset', kernel=5, size=4096, bands=4, tiles=64),
+}
+
 
 def parse_args():
     p = argparse.ArgumentParser()
     p.add_argument('--gpus', type=int, default=1)
-    p.add_argument('--steps', type=int, default=50)
-    p.add_argument('--warmup', type=int, default=5)
-    p.add_argument('--size', type=int, default=16384, help='raster height = width')
-    p.add_argument('--bands', type=int, default=4)
-    p.add_argument('--model', default='gain-offset', choices=['gain', 'gain-blk-offset', 'gain-offset'])
-    p.add_argument('--kernel', type=int, default=5)
+    p.add_argument('--steps', type=int, default=None)
+    p.add_argument('--warmup', type=int, default=None)
+    p.add_argument('--config', type=int, default=2, choices=sorted(CONFIGS))
+    p.add_argument('--size', type=int, default=None, help='raster (config 4: tile) height = width')
+    p.add_argument('--bands', type=int, default=None)
+    p.add_argument('--tiles', type=int, default=None, help='config 4: number of tiles of the mosaic')
+    p.add_argument('--model', default=None, choices=['gain', 'gain-blk-offset', 'gain-offset'])
+    p.add_argument('--kernel', type=int, default=None)
     p.add_argument('--seg-rows', type=int, default=0)
     p.add_argument('--nodata', type=int, default=0, help='0: no nodata, 1: NaN frame + 0.1%% holes, 2: NaN frame only, 3 / 4: no nodata, noisy reference (35 %% / 85 %% of the pixels fail the r2 mask)')
     p.add_argument('--no-thresh', action='store_true', help='gain-offset without r2_inpaint_thresh (no R2 work)')
     p.add_argument('--params', action='store_true', help='also materialise the gain / offset / R2 planes in the fused launch (find_r2=True; 24 B per pixel*band of HBM traffic, reported against the same 12 algorithmic bytes)')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-parity', action='store_true')
+    p.add_argument('--no-end-to-end', action='store_true', help='configs 3 / 4: skip the PCIe-inclusive RasterFuse pass')
     p.add_argument('--cpu-sample', type=int, default=0, help='CPU baseline sample size (square); 0 = auto')
-    return p.parse_args()
+    args = p.parse_args()
+    preset = CONFIGS[args.config]
+    for k, v in preset.items():
+        if getattr(args, k, None) is None:
+            setattr(args, k, v)
+    if args.steps is None:
+        args.steps = {1: 100, 2: 50, 3: 10, 4: 5}[args.config]
+    if args.warmup is None:
+        args.warmup = {1: 5, 2: 5, 3: 2, 4: 1}[args.config]
+    return args
 
 
+# ----------------------------------------------------------------------------------------------------------------------
 def cpu_baseline(model, k, sample):
     """ Times the oracle (the CPU restatement of the reference path; kind = "port") on a bounded sample of the same
-    workload.  Prefers the compiled C oracle (OpenMP, all host cores), falls back to the numpy one (1 core). """
+    workload: the compiled C oracle on all host cores (the headline CPU figure) and on one, and the numpy restatement
+    (which mirrors the reference's pass structure) on one thread and under a ThreadPoolExecutor over blocks, the shape
+    of homonim/fuse.py:396-408. """
+    from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle_np as onp
     try:
         from oracle import oracle_c
         have_c = oracle_c.available()
     except Exception:
         have_c = False
+    cores = os.cpu_count() or 1
     if sample <= 0:
-        sample = (8192 if (os.cpu_count() or 1) >= 32 else 4096) if have_c else 1536
-    src, ref = onp.synth_pair(sample, sample, seed=0)
+        sample = (8192 if cores >= 32 else 4096) if have_c else 1536
     thresh = 0.25 if model == 'gain-offset' else None
-    if have_c:
-        cores = os.cpu_count() or 1
-        oracle_c.fit_apply(model, src, np.nan, ref, np.nan, (k, k), False, thresh, n_threads=cores)  # warm-up
+    variants = []
+
+    def timed(fn, budget, max_reps):
+        fn()
         t0 = time.perf_counter()
         reps = 0
         while True:
-            oracle_c.fit_apply(model, src, np.nan, ref, np.nan, (k, k), False, thresh, n_threads=cores)
+            fn()
             reps += 1
-            if time.perf_counter() - t0 > 10.0 or reps >= 40:
+            if time.perf_counter() - t0 > budget or reps >= max_reps:
                 break
-        dt = (time.perf_counter() - t0) / reps
-        impl = f'C oracle (oracle/hk_oracle.c, OpenMP {cores} threads)'
-    else:
-        cores = 1
-        t0 = time.perf_counter()
-        params, _ = onp.fit(model, src, np.nan, ref, np.nan, (k, k), False, thresh)
-        onp.apply(src, params)
-        dt = time.perf_counter() - t0
-        impl = 'numpy oracle (oracle/oracle_np.py)'
-    return dict(value=round(sample * sample / dt / 1e6, 3), unit='Mpixels*bands/s', cores=cores, kind='port',
-                sample=f'{sample}x{sample} float32 1-band block of the same synthetic workload, {model} {k}x{k} '
-                       f'fit+apply, {impl}, {dt:.3f} s per pass')
+        return (time.perf_counter() - t0) / reps
+
+    def c_pass(s, r, threads):
+        # gain-blk-offset: the block statistics are part of the fit (kernel_model.py:289)
+        norm = oracle_c.fit_block_norm(s, np.nan, r, np.nan) if model == 'gain-blk-offset' else None
+        oracle_c.fit_apply(model, s, np.nan, r, np.nan, (k, k), False, thresh, norm_model=norm, n_threads=threads)
+
+    if have_c:
+        src, ref = onp.synth_pair(sample, sample, seed=0)
+        dt = timed(lambda: c_pass(src, ref, cores), 8.0, 40)
+        main = dict(value=round(sample * sample / dt / 1e6, 3), cores=cores,
+                    impl=f'C oracle (oracle/hk_oracle.c, OpenMP {cores} threads)', sample_px=sample, seconds=round(dt, 3))
+        s1 = min(sample, 2048)
+        src1, ref1 = np.ascontiguousarray(src[:s1, :s1]), np.ascontiguousarray(ref[:s1, :s1])
+        dt1 = timed(lambda: c_pass(src1, ref1, 1), 3.0, 5)
+        variants.append(dict(value=round(s1 * s1 / dt1 / 1e6, 3), cores=1, impl='C oracle, 1 thread',
+                             sample=f'{s1}x{s1}', seconds=round(dt1, 3)))
+    # numpy restatement: one thread on one block, then min(cores, 16) threads with one block each
+    nb = 1024
+    blocks = [onp.synth_pair(nb, nb, seed=10 + i) for i in range(min(cores, 16))]
+
+    def np_block(pair):
+        params, _ = onp.fit(model, pair[0], np.nan, pair[1], np.nan, (k, k), False, thresh)
+        return onp.apply(pair[0], params)
+
+    t0 = time.perf_counter()
+    np_block(blocks[0])
+    dt_np1 = time.perf_counter() - t0
+    variants.append(dict(value=round(nb * nb / dt_np1 / 1e6, 3), cores=1, impl='numpy oracle (oracle/oracle_np.py), 1 thread',
+                         sample=f'{nb}x{nb}', seconds=round(dt_np1, 3)))
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(len(blocks)) as ex:
+        list(ex.map(np_block, blocks))
+    dt_npt = time.perf_counter() - t0
+    variants.append(dict(value=round(len(blocks) * nb * nb / dt_npt / 1e6, 3), cores=len(blocks),
+                         impl=f'numpy oracle under ThreadPoolExecutor({len(blocks)}) over {nb}x{nb} blocks (the shape of homonim/fuse.py:396-408)',
+                         sample=f'{len(blocks)} blocks of {nb}x{nb}', seconds=round(dt_npt, 3)))
+    if not have_c:
+        main = dict(value=variants[0]['value'], cores=1, impl=variants[0]['impl'], sample_px=nb, seconds=variants[0]['seconds'])
+    return dict(value=main['value'], unit='Mpixels*bands/s', cores=main['cores'], kind='port',
+                sample=f"{main['sample_px']}x{main['sample_px']} float32 1-band block of the same synthetic workload, {model} "
+                       f"{k}x{k} fit+apply, {main['impl']}, {main['seconds']:.3f} s per pass",
+                variants=variants)
 
 
-def parity_spot_check(ctx, args, bufs, stride, band_stride, thresh, n_fail=0):
-    """ Not timed: download a window of band 0 and compare the GPU output with the numpy oracle. """
+def spot_check(ctx, model, k, thresh, nodata_variant, d_src, d_ref, d_corr, stride, H, W, y0, x0, wh, ww, norm=None, n_fail=0):
+    """ Not timed: download a window (whole rows y0 .. y0 + wh of one band plane) and compare the GPU output with the numpy
+    oracle.  `norm`: the block statistics the GPU used (gain-blk-offset).  Returns the parity record. """
     from oracle import oracle_np as onp
-    H = W = args.size
-    k = args.kernel
     r = k // 2
-    wh, ww = min(H, 384), min(W, 1200)
-    y0 = max(0, min(H - wh, H // 3))
-    x0 = max(0, min(W - ww, (W // 2) // 4 * 4))
     rows = np.empty((wh, stride), np.float32)
     win = {}
-    for name in ('src', 'ref', 'corr'):
-        ctx.d2h(rows, bufs[name] + 4 * (y0 * stride))
+    for name, ptr in (('src', d_src), ('ref', d_ref), ('corr', d_corr)):
+        ctx.d2h(rows, ptr + 4 * (y0 * stride))
         win[name] = rows[:, x0:x0 + ww].copy()
-    nodata = np.nan if args.nodata in (1, 2) else None
-    norm = None
-    if args.model == 'gain-blk-offset':
-        norm = bufs['norm_host'][0]
-    params, _ = onp.fit(args.model, win['src'], nodata, win['ref'], nodata, (k, k), False, thresh, norm_model=norm)
+    nodata = np.nan if nodata_variant in (1, 2) else None
+    params, _ = onp.fit(model, win['src'], nodata, win['ref'], nodata, (k, k), False, thresh, norm_model=norm)
     exp = onp.apply(win['src'], params)
     # windows of interior pixels see the same data as on the GPU; drop the r-px rim of the downloaded window (plus the
     # 100-px search radius of the in-painting when pixels failed the r2 mask: it looks that far for passing neighbours)
@@ -120,27 +179,24 @@ def parity_spot_check(ctx, args, bufs, stride, band_stride, thresh, n_fail=0):
 
 def measured_traffic(args):
     """ HBM bytes per launch from the committed rocprofv3 PMC summary (collected in separate --pmc passes, FETCH_SIZE
-    corrected x2 for gfx950) when it was taken at exactly this configuration; None otherwise. """
+    corrected x2 for gfx950) when it was taken at exactly this configuration; None otherwise.  Evidence from
+    profiles/, not a measurement of this run (`traffic_source` says so). """
     try:
         with open(os.path.join(REPO, 'profiles', 'pmc_summary.json')) as f:
             pmc = json.load(f)
         c = pmc['config']
-        if (c['model'], c['kernel'], c['size'], c['bands'], c['nodata'], bool(c.get('no_thresh', False))) == (
+        if args.config in (1, 2) and (c['model'], c['kernel'], c['size'], c['bands'], c['nodata'], bool(c.get('no_thresh', False))) == (
                 args.model, args.kernel, args.size, args.bands, args.nodata, bool(args.no_thresh)) and not args.params:
-            return float(pmc['hbm_traffic_bytes'])
+            return float(pmc['hbm_traffic_bytes']), 'profiles/pmc_summary.json (rocprofv3 --pmc passes of this command, committed)'
     except Exception:
         pass
-    return None
+    return None, None
 
 
-def main():
-    args = parse_args()
-    from homonim_amd import _hk, dist
-    rank, world, local_rank = dist.init()  # torch.distributed (nccl = RCCL) only when WORLD_SIZE > 1
-    n_gpus = args.gpus
-    ctx = _hk.Context(local_rank % max(1, _hk.device_count()), n_streams=2)  # one GPU per rank on a full node
-    ctx.selftest()
-
+# ----------------------------------------------------------------------------------------------------------------------
+# configs 1 / 2 (and the sweeps): one raster resident in HBM per rank, one fused launch per step
+def run_resident(args, ctx, dist, rank, world):
+    from homonim_amd import _hk
     H = W = args.size
     B = args.bands
     k = args.kernel
@@ -153,8 +209,10 @@ def main():
 
     bufs = {name: ctx.dev_alloc(plane_bytes) for name in ('src', 'ref', 'corr') + (('gain', 'offset', 'r2') if args.params else ())}
     bufs['fail'] = ctx.dev_alloc(8 * B)
+    bufs['fail2'] = ctx.dev_alloc(8 * B)
     bufs['norm'] = ctx.dev_alloc(16 * B)
     ctx.memset(bufs['fail'], 0, 8 * B)
+    ctx.memset(bufs['fail2'], 0, 8 * B)
     ctx.synth_fill_dev(bufs['src'], bufs['ref'], B, H, W, stride, band_stride, seed=1234 + rank,
                        nodata_variant=args.nodata, stream=0)
     ctx.stream_sync(0)
@@ -173,9 +231,7 @@ def main():
     # kernel_model.py:363-371) reads counters that were copied to the host behind launch i, AFTER launch i + 1 has been
     # queued -- the stream never drains between steps, and the in-painting passes (if a band has failures; none on the
     # clean synthetic workload) are queued behind launch i + 1 and recompute their band from src / ref.
-    fail_dev = [bufs['fail'], ctx.dev_alloc(8 * B)]
-    bufs['fail2'] = fail_dev[1]
-    ctx.memset(fail_dev[1], 0, 8 * B)
+    fail_dev = [bufs['fail'], bufs['fail2']]
     fail_host = [ctx.pinned_empty((B,), np.uint64) for _ in range(2)]
     fail_ready = [ctx.event(), ctx.event()]
 
@@ -214,73 +270,381 @@ def main():
             n_fail += finish(n_steps - 1)
         return n_fail
 
-    barrier = dist.barrier
-
     run(args.warmup)
     ctx.stream_sync(0)
 
     events = [(ctx.event(), ctx.event()) for _ in range(args.steps)]
-    barrier()
+    dist.barrier()
     ctx.sync()
     t0 = time.perf_counter()
     n_fail = run(args.steps, events)
     ctx.sync()
-    barrier()
+    dist.barrier()
     elapsed = time.perf_counter() - t0
 
     launch_ms = [ctx.event_elapsed_ms(e0, e1) for e0, e1 in events]
     elapsed = dist.max_over_ranks(elapsed)
     n_fail //= max(1, args.steps)
-
     px_bands = H * W * B
-    value = px_bands * args.steps * world / elapsed / 1e6
     avg_ms = float(np.mean(launch_ms))
-    achieved = ALGO_BYTES_PER_PX * px_bands / (avg_ms * 1e-3) / 1e9
 
-    out = None
-    if rank == 0:
-        parity = None
-        if not args.no_parity:
-            if args.model == 'gain-blk-offset':
-                nh = np.zeros((B, 2), np.float64)
-                ctx.d2h(nh, bufs['norm'])
-                bufs['norm_host'] = nh
-            parity = parity_spot_check(ctx, args, bufs, stride, band_stride, thresh, n_fail)
-        cpu = None
-        if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(args.model, k, args.cpu_sample)
-        out = {
-            'metric': 'Mpixels*bands/s fit+apply (5x5 gain-offset, float32)' if (args.model == 'gain-offset' and k == 5)
-                      else f'Mpixels*bands/s fit+apply ({k}x{k} {args.model}, float32)',
-            'value': round(value, 1), 'unit': 'Mpixels*bands/s', 'n_gpus': n_gpus, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32 in/out, f64 window sums', 'data': 'synthetic',
-            'config': {
-                'workload': f'synthetic float32 {B}-band {H}x{W} src/ref resident in HBM per GPU, Model.{args.model}, '
-                            f'kernel {k}x{k}, r2_inpaint_thresh {thresh}, fused fit+apply'
-                            + (' + gain / offset / R2 planes written' if args.params else '')
-                            + (' (BASELINE.json configs[2])' if (args.model, k, H, B, args.nodata, args.no_thresh, args.params)
-                               == ('gain-offset', 5, 16384, 4, 0, False, False) else ''),
-                'bands': B, 'height': H, 'width': W, 'nodata_variant': args.nodata,
-                'parallelism': f'{world} rank(s) x 1 GPU, independent rasters, no collective',
-                'r2_mask_failures_per_step': n_fail,
-            },
-            'roofline': {
-                'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                'frac': round(achieved / HBM_PEAK_GBPS, 4), 'traffic': measured_traffic(args),
-                'kernel': 'hk::fit_apply_kernel', 'avg_launch_ms': round(avg_ms, 4),
-                'algorithmic_bytes_per_launch': ALGO_BYTES_PER_PX * px_bands,
-            },
-            'cpu_baseline': cpu,
-            'parity_spot_check': parity,
-        }
-        print(json.dumps(out), flush=True)
+    parity = None
+    if rank == 0 and not args.no_parity:
+        norm = None
+        if args.model == 'gain-blk-offset':
+            nh = np.zeros((B, 2), np.float64)
+            ctx.d2h(nh, bufs['norm'])
+            norm = nh[0]
+        wh, ww = min(H, 384), min(W, 1200)
+        y0 = max(0, min(H - wh, H // 3))
+        x0 = max(0, min(W - ww, (W // 2) // 4 * 4))
+        parity = spot_check(ctx, args.model, k, thresh, args.nodata, bufs['src'], bufs['ref'], bufs['corr'], stride, H, W,
+                            y0, x0, wh, ww, norm, n_fail)
 
     for pair in events + [tuple(fail_ready)]:
         for e in pair:
             ctx.event_destroy(e)
-    for name in ('src', 'ref', 'corr', 'fail', 'fail2', 'norm'):
-        ctx.dev_free(bufs[name])
+    del fail_host  # page-locked arrays go before the context that allocated them
+    for ptr in bufs.values():
+        ctx.dev_free(ptr)
+
+    # an in-painting step is more than its first launch: when pixels failed, the roofline is taken over the whole step
+    if n_fail:
+        avg_ms = elapsed / args.steps * 1e3
+    traffic, traffic_source = measured_traffic(args)
+    headline = (args.model, k, H, B, args.nodata, args.no_thresh, args.params) == ('gain-offset', 5, 16384, 4, 0, False, False)
+    return dict(
+        value=px_bands * args.steps * world / elapsed / 1e6, elapsed=elapsed, scaling='weak',
+        workload=f'synthetic float32 {B}-band {H}x{W} src/ref resident in HBM per GPU, Model.{args.model}, '
+                 f'kernel {k}x{k}, r2_inpaint_thresh {thresh}, fused fit+apply'
+                 + (' + gain / offset / R2 planes written' if args.params else '')
+                 + (' (BASELINE.json configs[2])' if headline else '')
+                 + (' (BASELINE.json configs[1])' if (args.model, k, H, B, args.nodata, args.params) == ('gain', 5, 8192, 4, 0, False) else ''),
+        config=dict(bands=B, height=H, width=W, nodata_variant=args.nodata,
+                    parallelism=f'{world} rank(s) x 1 GPU, one raster per rank, no collective',
+                    r2_mask_failures_per_step=n_fail),
+        roofline=dict(achieved_bytes=ALGO_BYTES_PER_PX * px_bands, avg_launch_ms=avg_ms, traffic=traffic,
+                      traffic_source=traffic_source,
+                      kernel='hk::fit_apply_kernel' + (' + block statistics (hk_norm.hip)' if args.model == 'gain-blk-offset' else '')
+                             + (' + in-painting passes (whole step)' if n_fail else '')),
+        parity=parity)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# config 3: the reference's blocks of a resident raster, processed in place; ranks split the block positions
+def run_blocks(args, ctx, dist, rank, world):
+    from homonim_amd import _hk, utils
+    from homonim_amd.fuse import block_pairs, shard
+    H = W = args.size
+    B, k = args.bands, args.kernel
+    thresh = 0.25 if (args.model == 'gain-offset' and not args.no_thresh) else None
+    if thresh is not None:
+        raise SystemExit('--config 3 processes blocks in place with a store window: not with r2_inpaint_thresh (use --no-thresh)')
+    overlap = utils.overlap_for_kernel((k, k))
+    all_blocks = list(block_pairs((H, W), B, overlap, 100))  # reference partition at its default max_block_mem (100 MB)
+    # The (band, block) work items of one block POSITION differ only by the band plane they sit in, so the bands of a
+    # position go out as one launch (n_bands = B, band_stride = plane) -- per-band statistics and fits as ever.  Ranks split
+    # the positions; every rank keeps the whole raster resident (25.8 GB of the 288).
+    positions = [bp for bp in all_blocks if bp.band_i == 0]
+    mine = shard(positions, rank, world)
+    stride = (W + 63) // 64 * 64
+    band_stride = stride * H
+    nd = np.nan if args.nodata in (1, 2) else None
+    desc = _hk.make_desc(args.model, (k, k), False, None, nd, nd)
+    bufs = {name: ctx.dev_alloc(4 * band_stride * B) for name in ('src', 'ref', 'corr')}
+    bufs['norm'] = ctx.dev_alloc(16 * B * max(1, len(mine)))
+    ctx.synth_fill_dev(bufs['src'], bufs['ref'], B, H, W, stride, band_stride, seed=1234, nodata_variant=args.nodata, stream=0)
+    ctx.stream_sync(0)
+    n_streams = ctx.n_streams
+
+    jobs = []
+    for i, bp in enumerate(mine):
+        win_in, win_out = bp.src_in_block, bp.src_out_block
+        if (win_in.col_off % 4) or ((win_out.col_off - win_in.col_off) % 4):
+            raise SystemExit(f'block origin {win_in.col_off} is not 16-byte aligned: kernel {k}x{k} needs a halo that is a multiple of 4')
+        off = 4 * (win_in.row_off * stride + win_in.col_off)
+        job = _hk.DevJob()
+        job.src, job.ref, job.corr = bufs['src'] + off, bufs['ref'] + off, bufs['corr'] + off
+        job.gain = job.offset = job.r2 = job.fail_count = None
+        job.norm = bufs['norm'] + 16 * B * i
+        job.n_bands, job.height, job.width, job.stride, job.band_stride = B, win_in.height, win_in.width, stride, band_stride
+        job.seg_rows, job.stream = 0, i % n_streams   # the latency-bound statistics of one position overlap another's fit
+        job.out_row0, job.out_col0 = win_out.row_off - win_in.row_off, win_out.col_off - win_in.col_off
+        job.out_rows, job.out_cols = win_out.height, win_out.width
+        jobs.append(job)
+
+    def step():
+        for job in jobs:
+            if args.model == 'gain-blk-offset':
+                ctx.block_norm_dev(desc, job, job.norm)
+            ctx.fit_apply_dev(desc, job)
+
+    for _ in range(args.warmup):
+        step()
+    ctx.sync()
+    dist.barrier()
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ctx.sync()
+    dist.barrier()
+    elapsed = dist.max_over_ranks(time.perf_counter() - t0)
+    my_px = B * sum(bp.src_out_block.height * bp.src_out_block.width for bp in mine)
+
+    parity = None
+    if rank == 0 and not args.no_parity and jobs:
+        bp = mine[0]
+        nm = np.zeros((B, 2))
+        ctx.d2h(nm, bufs['norm'])
+        wi = bp.src_in_block
+        # a block's statistics are taken over its whole in-block; check a window of band 0's first out-block against the oracle
+        y0, x0 = wi.row_off + 1000, (wi.col_off + 1200) // 4 * 4
+        parity = spot_check(ctx, args.model, k, None, args.nodata, bufs['src'], bufs['ref'], bufs['corr'], stride, H, W, y0, x0,
+                            256, 1000, nm[0], 0)
+
+    e2e = None
+    if not args.no_end_to_end:
+        my_bands = shard(list(range(B)), rank, world, contiguous=True)  # host rasters of this rank's bands only
+        e2e = end_to_end_blocks(args, ctx, dist, bufs, len(my_bands), my_bands[0] if my_bands else 0, stride, band_stride)
+    for ptr in bufs.values():
+        ctx.dev_free(ptr)
+    total_px = H * W * B
+    return dict(
+        value=total_px * args.steps / elapsed / 1e6, elapsed=elapsed, scaling='strong',
+        workload=f'synthetic float32 {B}-band {H}x{W} resident in HBM, Model.{args.model}, kernel {k}x{k}, the reference\'s '
+                 f'{len(all_blocks)} blocks (4096x4096 + {overlap[0]}-px halo, raster_pair.py:342-428) processed in place, '
+                 f'each with its own block statistics; the {B} bands of a block position share a launch (BASELINE.json configs[3])',
+        config=dict(bands=B, height=H, width=W, nodata_variant=args.nodata, blocks=len(all_blocks),
+                    blocks_per_rank=B * len(mine),
+                    parallelism=f'{world} rank(s) x 1 GPU, the {len(positions)} block positions dealt round-robin to the ranks, no collective'),
+        roofline=dict(achieved_bytes=ALGO_BYTES_PER_PX * my_px, avg_launch_ms=elapsed / args.steps * 1e3, traffic=None, traffic_source=None,
+                      kernel=f'one step of this rank: {len(mine)} x (block statistics + hk::fit_apply_kernel over {B} bands), wall time on {n_streams} streams'),
+        parity=parity, end_to_end=e2e)
+
+
+def end_to_end_blocks(args, ctx, dist, bufs, nb, b0, stride, band_stride):
+    """ The same blocks through RasterFuse.process from page-locked host rasters (one pass, PCIe-inclusive); the ranks
+    split the bands. """
+    import warnings
+    from homonim_amd.fuse import RasterFuse
+    H = W = args.size
+    try:
+        src = ctx.pinned_empty((nb, H, stride), np.float32)
+        ref = ctx.pinned_empty((nb, H, stride), np.float32)
+        out = ctx.pinned_empty((nb, H, W), np.float32)
+    except Exception as ex:  # not enough lockable host memory on this box
+        return dict(skipped=f'page-locked host rasters could not be allocated: {ex}')
+    if nb == 0:  # more ranks than bands: keep the collective calls of the other ranks matched
+        dist.barrier(), dist.barrier()
+        dist.max_over_ranks(0.0)
+        return dict(skipped='no band for this rank')
+    ctx.d2h(src, bufs['src'] + 4 * band_stride * b0)
+    ctx.d2h(ref, bufs['ref'] + 4 * band_stride * b0)
+    nd = np.nan if args.nodata in (1, 2) else None
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        rf = RasterFuse(src[:, :, :W], ref[:, :, :W], src_nodata=nd, ref_nodata=nd)
+        kw = dict(model=args.model, kernel_shape=(args.kernel, args.kernel), model_config=dict(r2_inpaint_thresh=None),
+                  block_config=dict(threads=4, max_block_mem=100), device_config=dict(devices=[ctx.device], streams=ctx.n_streams, pin=False),
+                  corr_out=out)
+        rf.process(**kw)  # warm-up: grows the per-stream device slabs
+        dist.barrier()
+        t0 = time.perf_counter()
+        rf.process(**kw)
+        dist.barrier()
+        dt = dist.max_over_ranks(time.perf_counter() - t0)
+    px = args.size * args.size * args.bands
+    res = dict(value=round(px / dt / 1e6, 1), unit='Mpixels*bands/s', seconds=round(dt, 4),
+               path='RasterFuse.process: page-locked host rasters -> H2D || statistics + fused kernel || D2H per block, 4 threads x 4 streams per GPU',
+               pcie_gbps_in=round(8 * px / dt / 1e9, 1), pcie_gbps_out=round(4 * px / dt / 1e9, 1))
+    del src, ref, out
+    return res
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# config 4: mosaic of independent tiles, one tile per stream; ranks split the tile list
+def run_tiles(args, ctx, dist, rank, world):
+    from homonim_amd import _hk
+    from homonim_amd.fuse import shard
+    n = args.size
+    B, k, T = args.bands, args.kernel, args.tiles
+    thresh = 0.25 if (args.model == 'gain-offset' and not args.no_thresh) else None
+    nd = np.nan if args.nodata in (1, 2) else None
+    desc = _hk.make_desc(args.model, (k, k), False, thresh, nd, nd)
+    mine = shard(list(range(T)), rank, world, contiguous=True)
+    stride = (n + 63) // 64 * 64
+    band_stride = stride * n
+    tile_bytes = 4 * band_stride * B
+    n_streams = ctx.n_streams
+    tiles = []
+    for j, t in enumerate(mine):
+        d = {name: ctx.dev_alloc(tile_bytes) for name in ('src', 'ref', 'corr')}
+        d['fail'] = ctx.dev_alloc(8 * B)
+        d['norm'] = ctx.dev_alloc(16 * B)
+        ctx.memset(d['fail'], 0, 8 * B)
+        ctx.synth_fill_dev(d['src'], d['ref'], B, n, n, stride, band_stride, seed=5000 + t, nodata_variant=args.nodata, stream=0)
+        job = _hk.DevJob()
+        job.src, job.ref, job.corr = d['src'], d['ref'], d['corr']
+        job.gain = job.offset = job.r2 = None
+        job.fail_count = d['fail']
+        job.norm = d['norm'] if args.model == 'gain-blk-offset' else None
+        job.n_bands, job.height, job.width, job.stride, job.band_stride = B, n, n, stride, band_stride
+        job.seg_rows, job.stream = 0, j % n_streams
+        tiles.append((d, job, ctx.pinned_empty((B,), np.uint64), ctx.event()))
+    ctx.stream_sync(0)
+
+    def step():
+        """ every tile's fused launch on its stream, then the host's look at the r2-mask counters of all of them """
+        n_fail = 0
+        for d, job, counts, ev in tiles:
+            if args.model == 'gain-blk-offset':
+                ctx.block_norm_dev(desc, job, d['norm'])
+            ctx.fit_apply_dev(desc, job)
+            if thresh is not None:
+                ctx.fail_counts_async(job, counts, ev)
+        if thresh is not None:
+            for d, job, counts, ev in tiles:
+                ctx.event_sync(ev)
+                c = counts.copy()
+                if c.any():
+                    n_fail += ctx.inpaint_dev_counts(desc, job, c)
+        return n_fail
+
+    for _ in range(args.warmup):
+        step()
+    ctx.sync()
+    dist.barrier()
+    ctx.sync()
+    t0 = time.perf_counter()
+    n_fail = 0
+    for _ in range(args.steps):
+        n_fail += step()
+    ctx.sync()
+    dist.barrier()
+    elapsed = dist.max_over_ranks(time.perf_counter() - t0)
+
+    parity = None
+    if rank == 0 and not args.no_parity and tiles:
+        d = tiles[0][0]
+        parity = spot_check(ctx, args.model, k, thresh, args.nodata, d['src'], d['ref'], d['corr'], stride, n, n, n // 3, 1024,
+                            min(n, 384), min(n - 1024, 1200), None, n_fail)
+    e2e = None
+    if not args.no_end_to_end:
+        e2e = end_to_end_tiles(args, ctx, dist, tiles, stride, band_stride, thresh, nd)
+    for d, job, counts, ev in tiles:
+        ctx.event_destroy(ev)
+        for ptr in d.values():
+            ctx.dev_free(ptr)
+    my_px = len(mine) * n * n * B
+    del tiles
+    return dict(
+        value=T * n * n * B * args.steps / elapsed / 1e6, elapsed=elapsed, scaling='strong',
+        workload=f'mosaic of {T} independent {B}-band {n}x{n} float32 tiles resident in HBM, Model.{args.model}, kernel {k}x{k}, '
+                 f'r2_inpaint_thresh {thresh}, one fused launch per tile, tiles dealt round the streams (BASELINE.json configs[4])',
+        config=dict(bands=B, height=n, width=n, tiles=T, tiles_per_rank=len(mine), nodata_variant=args.nodata,
+                    parallelism=f'{world} rank(s) x 1 GPU x {n_streams} streams, consecutive runs of the tile list per rank, no collective',
+                    r2_mask_failures_per_step=n_fail // max(1, args.steps)),
+        roofline=dict(achieved_bytes=ALGO_BYTES_PER_PX * my_px, avg_launch_ms=elapsed / args.steps * 1e3, traffic=None, traffic_source=None,
+                      kernel=f'one step of this rank: {len(mine)} x hk::fit_apply_kernel on {n_streams} streams, wall time'),
+        parity=parity, end_to_end=e2e)
+
+
+def end_to_end_tiles(args, ctx, dist, tiles, stride, band_stride, thresh, nd):
+    """ The rank's tiles as host rasters through RasterFuse.process (one RasterFuse per tile, as one would process a
+    directory of tiles): H2D || kernel || D2H over the context's streams; PCIe-inclusive. """
+    import warnings
+    from concurrent.futures import ThreadPoolExecutor
+    from homonim_amd.fuse import RasterFuse
+    n, B = args.size, args.bands
+    try:
+        import psutil
+        avail = psutil.virtual_memory().available
+    except Exception:
+        avail = 64 << 30
+    per_tile = 3 * 4 * B * n * stride
+    distinct = max(2, min(len(tiles), int(0.3 * avail // per_tile)))
+    host = []
+    try:
+        for j in range(distinct):
+            s, r, o = (ctx.pinned_empty((B, n, stride), np.float32) for _ in range(3))
+            ctx.d2h(s, tiles[j][0]['src'])
+            ctx.d2h(r, tiles[j][0]['ref'])
+            host.append((s, r, o))
+    except Exception as ex:
+        if len(host) < 2:
+            return dict(skipped=f'page-locked host tiles could not be allocated: {ex}')
+    distinct = len(host)
+    kw = dict(model=args.model, kernel_shape=(args.kernel, args.kernel), model_config=dict(r2_inpaint_thresh=thresh),
+              block_config=dict(threads=2, max_block_mem=100),
+              device_config=dict(devices=[ctx.device], streams=ctx.n_streams, pin=False))
+
+    def one(j):
+        s, r, o = host[j % distinct]
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            RasterFuse(s[:, :, :n], r[:, :, :n], src_nodata=nd, ref_nodata=nd).process(corr_out=o[:, :, :n] if stride == n else None, **kw)
+
+    with ThreadPoolExecutor(2) as ex:  # two tiles in flight x two block threads each = the context's four streams
+        list(ex.map(one, range(min(len(tiles), 4))))  # warm-up: grows the per-stream device slabs
+        dist.barrier()
+        t0 = time.perf_counter()
+        list(ex.map(one, range(len(tiles))))
+        dist.barrier()
+        dt = dist.max_over_ranks(time.perf_counter() - t0)
+    px = args.tiles * n * n * B
+    res = dict(value=round(px / dt / 1e6, 1), unit='Mpixels*bands/s', seconds=round(dt, 4), distinct_host_tiles=distinct,
+               path='RasterFuse.process per tile: page-locked host rasters -> H2D || fused kernel || D2H, 2 tiles x 2 block threads on 4 streams per GPU',
+               pcie_gbps_in=round(8 * px / dt / 1e9, 1), pcie_gbps_out=round(4 * px / dt / 1e9, 1))
+    del host
+    return res
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def main():
+    args = parse_args()
+    env_world = int(os.environ.get('WORLD_SIZE', '1'))
+    if args.gpus != env_world:  # before anything touches a GPU: never re-launch from a process that holds a context
+        sys.stderr.write(
+            f'bench.py: --gpus {args.gpus} but WORLD_SIZE is {env_world}: launch the ranks with\n'
+            f'  python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 '
+            f'--master-port 29500 bench.py --gpus {args.gpus} ...\n')
+        sys.exit(2)
+    from homonim_amd import _hk, dist
+    rank, world, local_rank = dist.init()  # torch.distributed (nccl = RCCL) only when WORLD_SIZE > 1
+    ctx = _hk.Context(local_rank % max(1, _hk.device_count()), n_streams=4)  # one GPU per rank on a full node
+    ctx.selftest()
+
+    runner = {1: run_resident, 2: run_resident, 3: run_blocks, 4: run_tiles}[args.config]
+    res = runner(args, ctx, dist, rank, world)
+
+    if rank == 0:
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(args.model, args.kernel, args.cpu_sample)
+        rl = res['roofline']
+        achieved = rl['achieved_bytes'] / (rl['avg_launch_ms'] * 1e-3) / 1e9
+        k = args.kernel
+        out = {
+            'metric': 'Mpixels*bands/s fit+apply (5x5 gain-offset, float32)' if (args.model == 'gain-offset' and k == 5)
+                      else f'Mpixels*bands/s fit+apply ({k}x{k} {args.model}, float32)',
+            'value': round(res['value'], 1), 'unit': 'Mpixels*bands/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(res['elapsed'] / args.steps * 1e3, 4), 'higher_is_better': True,
+            'scaling': res['scaling'], 'vs_baseline': None, 'dtype': 'f32 in/out, f64 window sums', 'data': 'synthetic',
+            'config': dict(workload=res['workload'], baseline_config=args.config, **res['config']),
+            'roofline': {
+                'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                'frac': round(achieved / HBM_PEAK_GBPS, 4), 'traffic': rl['traffic'], 'traffic_source': rl['traffic_source'],
+                'kernel': rl['kernel'], 'avg_launch_ms': round(rl['avg_launch_ms'], 4),
+                'algorithmic_bytes_per_launch': rl['achieved_bytes'],
+            },
+            'cpu_baseline': cpu,
+            'parity_spot_check': res['parity'],
+        }
+        if res.get('end_to_end') is not None:
+            out['end_to_end'] = res['end_to_end']
+        print(json.dumps(out), flush=True)
+
     ctx.close()
     dist.finalize()
 
