@@ -322,11 +322,14 @@ class RasterFuse:
 
     @staticmethod
     def create_device_config(devices: Optional[Sequence[int]] = None, streams: int = 4, rank: int = 0,
-                             world_size: int = 1, contiguous: bool = False, pin: bool = True) -> Dict:
+                             world_size: int = 1, contiguous: bool = False, pin: bool = True,
+                             separate_contexts: bool = False) -> Dict:
         """ (this package only) GPUs of this process, streams per GPU, this process's shard of the block list
-        (round-robin, or ``contiguous`` runs), and whether the rasters are page-locked for asynchronous transfers. """
+        (round-robin, or ``contiguous`` runs), whether the rasters are page-locked for asynchronous transfers, and
+        whether every entry of ``devices`` gets a context of its own even when a device is listed twice. """
         return dict(devices=None if devices is None else list(devices), streams=int(streams), rank=int(rank),
-                    world_size=int(world_size), contiguous=bool(contiguous), pin=bool(pin))
+                    world_size=int(world_size), contiguous=bool(contiguous), pin=bool(pin),
+                    separate_contexts=bool(separate_contexts))
 
     def block_pairs(self, overlap: Tuple[int, int] = (0, 0), max_block_mem: float = math.inf) -> Iterable[BlockPair]:
         if self._same_grid:
@@ -460,10 +463,15 @@ class RasterFuse:
         devices = device_config['devices']
         if devices is None:
             devices = [int(os.environ.get('HOMONIM_AMD_DEVICE', os.environ.get('LOCAL_RANK', '0')))]
-        models = []
+        models, own_contexts, seen = [], [], set()
         for dev in devices:
             m = model_cls(model_type, kernel_shape, find_r2=want_params, **model_config)
-            m.context = _hk.get_context(dev, device_config['streams'])  # cached per process
+            if device_config['separate_contexts'] and dev in seen:
+                m.context = _hk.Context(dev, device_config['streams'])  # a second, independent context on this device
+                own_contexts.append(m.context)
+            else:
+                m.context = _hk.get_context(dev, device_config['streams'])  # cached per process
+            seen.add(dev)
             models.append(m)
 
         n_src = self._src.shape[0]
@@ -497,6 +505,8 @@ class RasterFuse:
                     models[0].context.unpin(arr)
                 except Exception:
                     pass
+            for c in own_contexts:
+                c.close()
 
         if isinstance(corr_filename, (str, os.PathLike)) or (want_params and isinstance(param_filename, (str, os.PathLike))):
             # provenance tags of homonim/fuse.py:193-207

@@ -1,0 +1,72 @@
+"""
+GPU tests of the multi-process / multi-context paths: one process per GPU under torch.distributed.run, every rank its
+shard of the (band x block) list, no data-path collective.  On a 1-GPU box the ranks share
+device 0 and rendezvous over gloo (HOMONIM_AMD_DIST_BACKEND); on a full node the same worker runs one rank per GPU over
+RCCL.
+"""
+import os
+import subprocess
+import sys
+import warnings
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+
+pytestmark = pytest.mark.gpu
+
+from homonim_amd import _hk  # noqa: E402
+from oracle import oracle_np as onp  # noqa: E402
+
+
+def _inputs():
+    pairs = [onp.synth_pair(520, 700, 300 + b, 'frame+holes') for b in range(3)]
+    return np.stack([p[0] for p in pairs]), np.stack([p[1] for p in pairs])
+
+
+def _same(a, b):
+    return bool(((a == b) | (np.isnan(a) & np.isnan(b))).all())
+
+
+@pytest.mark.parametrize('model, k, contiguous', [('gain-offset', 5, False), ('gain-blk-offset', 5, True)])
+def test_two_ranks_process_their_shards_and_the_union_is_the_single_rank_result(tmp_path, model, k, contiguous):
+    from homonim_amd.fuse import RasterFuse
+    env = dict(os.environ, HOMONIM_AMD_DIST_BACKEND='gloo', MASTER_ADDR='127.0.0.1', PYTHONPATH=REPO)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(29600 + (os.getpid() + k + contiguous) % 300), os.path.join(REPO, 'tests', '_rank_worker.py'),
+           str(tmp_path), model, str(k), '1' if contiguous else '0']
+    run = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stderr[-3000:]
+    src, ref = _inputs()
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        full_c, full_p = RasterFuse(src, ref).process(None, model, (k, k), param_filename=True,
+                                                      model_config=dict(r2_inpaint_thresh=0.25),
+                                                      block_config=dict(threads=2, max_block_mem=0.3))
+    parts_c = [np.load(tmp_path / f'corr_{r}.npy') for r in range(2)]
+    parts_p = [np.load(tmp_path / f'params_{r}.npy') for r in range(2)]
+    filled = [~np.isnan(p) for p in parts_c]
+    assert filled[0].any() and filled[1].any() and not (filled[0] & filled[1]).any()      # disjoint, both non-empty
+    assert _same(np.where(filled[0], parts_c[0], parts_c[1]), full_c)                     # and complete
+    fp = [~np.isnan(p) for p in parts_p]
+    assert not (fp[0] & fp[1]).any() and _same(np.where(fp[0], parts_p[0], parts_p[1]), full_p)
+    world, total, slowest = (int(v) for v in (tmp_path / 'summary.txt').read_text().split())
+    assert world == 2 and total == int((~np.isnan(full_c)).sum()) and slowest == 1
+
+
+def test_two_contexts_in_one_process_share_the_block_list(ctx_unused=None):
+    """ device_config(devices=[d0, d1]): one model + context per entry, blocks dealt round the models by the thread pool
+    (fuse.py process()).  With one GPU both entries are device 0 -- two separate contexts (stream pools, staging slabs,
+    certificate / in-painting state) working on one raster at once -- and the result must not change. """
+    from homonim_amd.fuse import RasterFuse
+    src, ref = _inputs()
+    kw = dict(model='gain-offset', kernel_shape=(5, 5), param_filename=True, model_config=dict(r2_inpaint_thresh=0.6),
+              block_config=dict(threads=4, max_block_mem=0.3))
+    n_dev = _hk.device_count()
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        one_c, one_p = RasterFuse(src, ref).process(device_config=dict(devices=[0]), **kw)
+        two_c, two_p = RasterFuse(src, ref).process(device_config=dict(devices=[0, 1 % n_dev], separate_contexts=True), **kw)
+    assert _same(one_c, two_c) and _same(one_p, two_p)
+    assert np.isnan(one_c).sum() < one_c.size
