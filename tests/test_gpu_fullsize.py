@@ -132,3 +132,154 @@ def test_full_size_properties_and_oracle_windows(ctx, oracle, nodata_variant, mo
     finally:
         for k in bufs:
             ctx.dev_free(bufs[k])
+
+
+def _check_windows(oracle, model, k, thresh, nodata, src, ref, got_full, wins, wh, ww, norm=None, origin=(0, 0), full_shape=None):
+    """ oracle on windows (with their halo) of a downloaded plane; returns (#checked, #bitwise different) """
+    H, W = full_shape or src.shape
+    r = k // 2
+    n_checked = n_diff = 0
+    for (y0, x0) in wins:
+        ys, xs = slice(max(0, y0 - r), min(H, y0 + wh + r)), slice(max(0, x0 - r), min(W, x0 + ww + r))
+        s, t = np.ascontiguousarray(src[ys, xs]), np.ascontiguousarray(ref[ys, xs])
+        _, exp, _ = oracle.fit_apply(model, s, nodata, t, nodata, (k, k), False, thresh, norm_model=norm, want_params=False)
+        cy = slice(r if ys.start > 0 else 0, exp.shape[0] - (r if ys.stop < H else 0))
+        cx = slice(r if xs.start > 0 else 0, exp.shape[1] - (r if xs.stop < W else 0))
+        got, exp = got_full[ys, xs][cy, cx], exp[cy, cx]
+        assert (np.isnan(got) == np.isnan(exp)).all()
+        ok = ~np.isnan(exp)
+        d = got[ok] != exp[ok]
+        n_checked += int(ok.sum())
+        n_diff += int(d.sum())
+        if d.any():
+            ulps = np.abs(got[ok][d].view(np.int32).astype(np.int64) - exp[ok][d].view(np.int32).astype(np.int64))
+            assert ulps.max() <= 2
+    return n_checked, n_diff
+
+
+def test_config1_gain_8192_four_bands(ctx, oracle):
+    """ BASELINE.json configs[1] at full size: 4-band 8192 x 8192, Model.gain 5x5, one fused launch; windows of every
+    band against the C oracle, corners included. """
+    n, B = 8192, 4
+    plane = 4 * n * n
+    bufs = {k: ctx.dev_alloc(plane * B) for k in ('src', 'ref', 'corr')}
+    try:
+        ctx.synth_fill_dev(bufs['src'], bufs['ref'], B, n, n, n, n * n, seed=7, nodata_variant=1, stream=0)
+        desc = _hk.make_desc('gain', (5, 5), False, None, np.nan, np.nan)
+        job = _hk.DevJob()
+        job.src, job.ref, job.corr = bufs['src'], bufs['ref'], bufs['corr']
+        job.gain = job.offset = job.r2 = job.norm = job.fail_count = None
+        job.n_bands, job.height, job.width, job.stride, job.band_stride, job.seg_rows, job.stream = B, n, n, n, n * n, 0, 0
+        ctx.fit_apply_dev(desc, job)
+        ctx.stream_sync(0)
+        rng = np.random.default_rng(1)
+        tot = dif = 0
+        for b in range(B):
+            arr = {k: np.empty((n, n), np.float32) for k in bufs}
+            for k in bufs:
+                ctx.d2h(arr[k], bufs[k] + plane * b)
+            wins = [(0, 0), (n - 600, n - 1000)] + [(int(rng.integers(2, n - 602)), int(rng.integers(2, n - 1002))) for _ in range(2)]
+            c, d = _check_windows(oracle, 'gain', 5, None, np.nan, arr['src'], arr['ref'], arr['corr'], wins, 600, 1000)
+            tot, dif = tot + c, dif + d
+        assert dif <= max(2, int(1e-5 * tot)), (dif, tot)
+        print(f'config 1: {tot} px checked, {dif} bitwise mismatches')
+    finally:
+        for k in bufs:
+            ctx.dev_free(bufs[k])
+
+
+def test_config3_block_in_place_with_halo_15x15(ctx, oracle):
+    """ BASELINE.json configs[3] at its block size: a 4096 x 4096 out-block with its 8-pixel halo (a 4112 x 4112 in-block in
+    the interior of a 16384-wide raster), gain-blk-offset 15x15, statistics over the in-block on the device, processed
+    in place with a store window.  Oracle (given the GPU's statistics) on windows; the statistics against numpy's. """
+    from oracle import oracle_np as onp
+    W, k, halo = 16384, 15, 8
+    rows = 4096 + 2 * halo + 64           # a band of rows around the block is enough: the raster's other rows play no role
+    bufs = {name: ctx.dev_alloc(4 * W * rows) for name in ('src', 'ref', 'corr')}
+    norm = ctx.dev_alloc(16)
+    try:
+        ctx.synth_fill_dev(bufs['src'], bufs['ref'], 1, rows, W, W, W * rows, seed=11, nodata_variant=0, stream=0)
+        ctx.memset(bufs['corr'], 0, 4 * W * rows)
+        desc = _hk.make_desc('gain-blk-offset', (k, k), False, None, None, None)
+        y0, x0, hh = 32, 4096 - halo, 4096 + 2 * halo
+        job = _hk.DevJob()
+        off = 4 * (y0 * W + x0)
+        job.src, job.ref, job.corr = bufs['src'] + off, bufs['ref'] + off, bufs['corr'] + off
+        job.gain = job.offset = job.r2 = job.fail_count = None
+        job.norm = norm
+        job.n_bands, job.height, job.width, job.stride, job.band_stride, job.seg_rows, job.stream = 1, hh, hh, W, 0, 0, 0
+        job.out_row0, job.out_col0, job.out_rows, job.out_cols = halo, halo, 4096, 4096
+        ctx.block_norm_dev(desc, job, norm)
+        ctx.fit_apply_dev(desc, job)
+        ctx.stream_sync(0)
+        arr = {name: np.empty((rows, W), np.float32) for name in bufs}
+        for name in bufs:
+            ctx.d2h(arr[name], bufs[name])
+        nm = np.zeros(2)
+        ctx.d2h(nm, norm)
+        blk = (slice(y0, y0 + hh), slice(x0, x0 + hh))
+        exp_nm = onp.fit_block_norm(arr['src'][blk], None, arr['ref'][blk], None)
+        assert np.allclose(nm, exp_nm, rtol=2e-6, atol=0)
+        # nothing outside the out-block was written
+        out = arr['corr'].copy()
+        out[y0 + halo:y0 + halo + 4096, x0 + halo:x0 + halo + 4096] = 0
+        assert not out.any()
+        # the in-block as a stand-alone raster = what the reference's block loop hands to KernelModel.fit
+        s, t = np.ascontiguousarray(arr['src'][blk]), np.ascontiguousarray(arr['ref'][blk])
+        got = arr['corr'][blk]
+        rng = np.random.default_rng(2)
+        wins = [(halo, halo), (halo + 4096 - 500, halo + 4096 - 900)]
+        wins += [(int(rng.integers(halo, halo + 4096 - 500)), int(rng.integers(halo, halo + 4096 - 900))) for _ in range(3)]
+        tot, dif = _check_windows(oracle, 'gain-blk-offset', k, None, None, s, t, got, wins, 500, 900, norm=nm)
+        assert dif <= max(2, int(1e-5 * tot)), (dif, tot)
+        print(f'config 3 block: {tot} px checked, {dif} bitwise mismatches, norm {nm}')
+    finally:
+        for name in bufs:
+            ctx.dev_free(bufs[name])
+        ctx.dev_free(norm)
+
+
+def test_config4_tiles_on_four_streams(ctx, oracle):
+    """ BASELINE.json configs[4] at its tile size: 4-band 4096 x 4096 tiles, gain-offset 5x5 with the r2 mask, eight tiles in
+    flight on the context's four streams at once; every tile's windows against the C oracle and clean failure counters. """
+    n, B, T = 4096, 4, 8
+    plane = 4 * n * n
+    tiles = []
+    try:
+        for t in range(T):
+            d = {k: ctx.dev_alloc(plane * B) for k in ('src', 'ref', 'corr')}
+            d['fail'] = ctx.dev_alloc(8 * B)
+            ctx.memset(d['fail'], 0, 8 * B)
+            ctx.synth_fill_dev(d['src'], d['ref'], B, n, n, n, n * n, seed=900 + t, nodata_variant=2 if t % 2 else 0, stream=0)
+            tiles.append(d)
+        ctx.stream_sync(0)
+        for t, d in enumerate(tiles):
+            nd = np.nan if t % 2 else None
+            desc = _hk.make_desc('gain-offset', (5, 5), False, 0.25, nd, nd)
+            job = _hk.DevJob()
+            job.src, job.ref, job.corr, job.fail_count = d['src'], d['ref'], d['corr'], d['fail']
+            job.gain = job.offset = job.r2 = job.norm = None
+            job.n_bands, job.height, job.width, job.stride, job.band_stride, job.seg_rows = B, n, n, n, n * n, 0
+            job.stream = t % ctx.n_streams
+            ctx.fit_apply_dev(desc, job)
+            d['desc'], d['job'] = desc, job
+        ctx.sync()
+        rng = np.random.default_rng(3)
+        tot = dif = 0
+        for t, d in enumerate(tiles):
+            nd = np.nan if t % 2 else None
+            assert ctx.inpaint_dev(d['desc'], d['job']) == 0       # also settles a certificate-only launch that gave up
+            ctx.stream_sync(d['job'].stream)
+            b = t % B
+            arr = {k: np.empty((n, n), np.float32) for k in ('src', 'ref', 'corr')}
+            for k in arr:
+                ctx.d2h(arr[k], d[k] + plane * b)
+            wins = [(0, 0), (int(rng.integers(2, n - 402)), int(rng.integers(2, n - 802)))]
+            c, e = _check_windows(oracle, 'gain-offset', 5, 0.25, nd, arr['src'], arr['ref'], arr['corr'], wins, 400, 800)
+            tot, dif = tot + c, dif + e
+        assert dif <= max(2, int(1e-5 * tot)), (dif, tot)
+        print(f'config 4 tiles: {tot} px checked, {dif} bitwise mismatches')
+    finally:
+        for d in tiles:
+            for k in ('src', 'ref', 'corr', 'fail'):
+                ctx.dev_free(d[k])
