@@ -186,7 +186,8 @@ def measured_traffic(args):
             pmc = json.load(f)
         c = pmc['config']
         if args.config in (1, 2) and (c['model'], c['kernel'], c['size'], c['bands'], c['nodata'], bool(c.get('no_thresh', False))) == (
-                args.model, args.kernel, args.size, args.bands, args.nodata, bool(args.no_thresh)) and not args.params:
+                args.model, args.kernel, args.size, args.bands, args.nodata, bool(args.no_thresh)) and not args.params \
+                and not c.get('params', False):
             return float(pmc['hbm_traffic_bytes']), 'profiles/pmc_summary.json (rocprofv3 --pmc passes of this command, committed)'
     except Exception:
         pass

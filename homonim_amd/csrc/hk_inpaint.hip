@@ -107,8 +107,8 @@ __global__ void __launch_bounds__(256) inpaint_fill_kernel(const float* __restri
                                                            const unsigned* __restrict__ tie,
                                                            const double* __restrict__ wtab, float* __restrict__ filled) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y;
     if (x >= width) return;
+    for (int y = blockIdx.y; y < height; y += gridDim.y) {  // grid-stride over rows: blocks taller than 65535 rows are fine
     const long long row = (long long)y * stride;
     const long long i = row + x;
     float out = offset[i];
@@ -171,6 +171,7 @@ __global__ void __launch_bounds__(256) inpaint_fill_kernel(const float* __restri
         if (has) out = (float)(vsum / wsum);
     }
     filled[i] = out;
+    }
 }
 
 // workspace: two uint16 distance tables + source flags (1 byte per pixel) + the tie bitmap + the weight table
@@ -190,7 +191,7 @@ hipError_t launch_inpaint_offsets(const float* offset, const float* gain, const 
                        gain, r2, thresh, stride, height, width, flag);
     hipLaunchKernelGGL(inpaint_scan_kernel, dim3((width + 255) / 256, (height + SCAN_ROWS - 1) / SCAN_ROWS), dim3(256), 0,
                        stream, flag, stride, height, width, max_dist, top_d, bot_d);
-    hipLaunchKernelGGL(inpaint_fill_kernel, dim3((width + 255) / 256, height), dim3(256), 0, stream, offset, flag, stride,
+    hipLaunchKernelGGL(inpaint_fill_kernel, dim3((width + 255) / 256, height < 65535 ? height : 65535), dim3(256), 0, stream, offset, flag, stride,
                        height, width, max_dist, top_d, bot_d, tie, wtab, filled);
     return hipGetLastError();
 }

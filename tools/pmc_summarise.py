@@ -32,12 +32,19 @@ if 'SQ_ACTIVE_INST_VALU' in c and 'GRBM_GUI_ACTIVE' in c:
 # from this file only at exactly this configuration
 import argparse
 ap = argparse.ArgumentParser()
-ap.add_argument('--size', type=int, default=16384), ap.add_argument('--bands', type=int, default=4)
-ap.add_argument('--model', default='gain-offset'), ap.add_argument('--kernel', type=int, default=5)
+ap.add_argument('--config', type=int, default=2)
+ap.add_argument('--size', type=int, default=None), ap.add_argument('--bands', type=int, default=None)
+ap.add_argument('--model', default=None), ap.add_argument('--kernel', type=int, default=None)
 ap.add_argument('--nodata', type=int, default=0), ap.add_argument('--no-thresh', action='store_true')
+ap.add_argument('--params', action='store_true')
 cfg, _ = ap.parse_known_args(sys.argv[2:])
+presets = {1: dict(model='gain', kernel=5, size=8192, bands=4), 2: dict(model='gain-offset', kernel=5, size=16384, bands=4),
+           3: dict(model='gain-blk-offset', kernel=15, size=16384, bands=8), 4: dict(model='gain-offset', kernel=5, size=4096, bands=4)}
+for k_, v_ in presets[cfg.config].items():  # the same presets as bench.py --config
+    if getattr(cfg, k_) is None:
+        setattr(cfg, k_, v_)
 out['config'] = dict(model=cfg.model, kernel=cfg.kernel, size=cfg.size, bands=cfg.bands, nodata=cfg.nodata,
-                     no_thresh=cfg.no_thresh)
+                     no_thresh=cfg.no_thresh, params=cfg.params)
 if 'hbm_read_bytes' in out and 'hbm_write_bytes' in out:
     out['hbm_traffic_bytes'] = out['hbm_read_bytes'] + out['hbm_write_bytes']
     out['algorithmic_bytes'] = 12 * cfg.size * cfg.size * cfg.bands
