@@ -208,7 +208,21 @@ def run_resident(args, ctx, dist, rank, world):
     nd = np.nan if args.nodata in (1, 2) else None
     desc = _hk.make_desc(args.model, (k, k), bool(args.params), thresh, nd, nd)
 
-    bufs = {name: ctx.dev_alloc(plane_bytes) for name in ('src', 'ref', 'corr') + (('gain', 'offset', 'r2') if args.params else ())}
+    # HK_BENCH_SKEW (bytes, a multiple of 16): plane i starts i * skew bytes into its allocation, so the six streams of a
+    # pixel position do not share their address bits below the allocation granule (experiment: DRAM channel aliasing)
+    skew = int(os.environ.get('HK_BENCH_SKEW', '0'))
+    names = ('src', 'ref', 'corr') + (('gain', 'offset', 'r2') if args.params else ())
+    if os.environ.get('HK_BENCH_ONE_SLAB', '0') != '0':
+        # experiment: ONE allocation for all planes, back to back and 2 MB aligned.  The --params run (six planes, 24 B per
+        # pixel*band) is bimodal from PROCESS to process (5.1 / 6.2 ms) with either layout and with any HK_BENCH_SKEW
+        # (profiles/r02_params_slab.txt): not an address-phase effect inside the allocations
+        step = (plane_bytes + skew + (2 << 20) - 1) // (2 << 20) * (2 << 20)
+        slab = ctx.dev_alloc(step * len(names))
+        allocs = {name: slab for name in names[:1]}
+        bufs = {name: slab + i * step + i * skew for i, name in enumerate(names)}
+    else:
+        allocs = {name: ctx.dev_alloc(plane_bytes + skew * len(names)) for name in names}
+        bufs = {name: allocs[name] + i * skew for i, name in enumerate(names)}
     bufs['fail'] = ctx.dev_alloc(8 * B)
     bufs['fail2'] = ctx.dev_alloc(8 * B)
     bufs['norm'] = ctx.dev_alloc(16 * B)
@@ -306,7 +320,9 @@ def run_resident(args, ctx, dist, rank, world):
         for e in pair:
             ctx.event_destroy(e)
     del fail_host  # page-locked arrays go before the context that allocated them
-    for ptr in bufs.values():
+    for name in names:
+        bufs.pop(name)
+    for ptr in list(bufs.values()) + list(allocs.values()):
         ctx.dev_free(ptr)
 
     # an in-painting step is more than its first launch: when pixels failed, the roofline is taken over the whole step
