@@ -262,7 +262,7 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
 // float32(RN64(n / d)) without the IEEE float64 division (13 VALU instructions, one of them v_rcp_f64 at quarter rate):
-//     y0 = v_rcp_f64(d)            relative error <= 2^-22 (documented 2^-23; 2^-24.4 measured, profiles/r02_ubench_valu.txt)
+//     y0 = v_rcp_f64(d)            relative error <= 2^-22 ASSUMED (2^-24.4 measured over 4e6 operands, profiles/r02_ubench_valu.txt)
 //     y1 = y0 + y0 * (1 - d * y0)  one Newton step: <= 2^-44 + 2^-53
 //     q  = n * y1                  <= 2^-44 + 2^-52 relative = 513 float64 ulps of q at most
 // RN64(n / d) lies within 514 ulps of q, so both round to the same float32 unless one of its rounding boundaries (the
