@@ -131,6 +131,9 @@ int ensure_dev(Slot& s, size_t bytes) {
     return HK_OK;
 }
 
+// rasterio.enums.Resampling values with a device kernel (hk_resample.hip)
+bool resampling_built(int m) { return m == 0 || m == 1 || m == 2 || m == 3 || m == 4 || m == 5 || m == 8 || m == 9 || m == 13 || m == 14; }
+
 bool needs_r2(const hk_fit_desc* d) {
     return d->find_r2 || (d->model == HK_MODEL_GAIN_OFFSET && d->has_r2_thresh);
 }
@@ -726,10 +729,7 @@ int hk_refspace_fit_apply(hk_ctx* ctx, const hk_fit_desc* desc, const hk_io_desc
     if (src_height < 1 || src_width < 1 || ref_height < 1 || ref_width < 1) return fail(HK_ERR_ARG, "empty raster");
     if (src_stride < src_width || ref_stride < ref_width) return fail(HK_ERR_ARG, "row stride smaller than width");
     for (int m : {space->down_resampling, space->up_resampling})
-        if (m != 0 && m != 1 && m != 3 && m != 5) return fail(HK_ERR_UNSUPPORTED, "resampling %d is not built", m);
-    auto stretched = [](int m, const double* k) { return (m == 1 || m == 3) && (k[0] > 1.0 + 1e-9 || k[2] > 1.0 + 1e-9); };
-    if (stretched(space->down_resampling, space->down) || stretched(space->up_resampling, space->up))
-        return fail(HK_ERR_UNSUPPORTED, "bilinear / cubic_spline down-sampling (stretched kernel) is not built");
+        if (!resampling_built(m)) return fail(HK_ERR_UNSUPPORTED, "resampling %d is not built", m);
     if (!(space->down[0] > 0 && space->down[2] > 0 && space->up[0] > 0 && space->up[2] > 0))
         return fail(HK_ERR_UNSUPPORTED, "flipped or degenerate grid mapping");
     if (src_height > 65535 || ref_height > 65535) return fail(HK_ERR_UNSUPPORTED, "block taller than 65535 rows");
@@ -750,6 +750,7 @@ int hk_refspace_fit_apply(hk_ctx* ctx, const hk_fit_desc* desc, const hk_io_desc
     const size_t o_gain = take(rplane), o_off = take(rplane), o_r2 = r2 ? take(rplane) : 0;
     // bilinear / cubic_spline parameters are up-sampled inside the apply kernel (no full-resolution parameter planes)
     const bool fused_up = (space->up_resampling == 1 || space->up_resampling == 3) && ref_width >= 4 &&
+                          space->up[0] <= 1.0 + 1e-9 && space->up[2] <= 1.0 + 1e-9 &&
                           (long long)ref_height * rs < 0x7fffffffLL;
     const size_t o_gus = fused_up ? 0 : take(splane), o_ous = fused_up ? 0 : take(splane), o_corr = take(splane);
     const size_t o_rowtab = fused_up ? take(hk::upsample_apply_workspace_bytes(src_height)) : 0;
@@ -864,10 +865,9 @@ int hk_reproject(hk_ctx* ctx, const float* src, int32_t n_bands, int32_t src_hei
     if (n_bands < 1 || src_height < 1 || src_width < 1 || dst_height < 1 || dst_width < 1)
         return fail(HK_ERR_ARG, "empty raster");
     if (!(kx > 0.0) || !(ky > 0.0)) return fail(HK_ERR_UNSUPPORTED, "flipped or degenerate grid mapping");
-    if (resampling != 0 && resampling != 1 && resampling != 3 && resampling != 5)
-        return fail(HK_ERR_UNSUPPORTED, "resampling %d is not built (nearest, bilinear, cubic_spline, average are)", resampling);
-    if ((resampling == 1 || resampling == 3) && (kx > 1.0 + 1e-9 || ky > 1.0 + 1e-9))
-        return fail(HK_ERR_UNSUPPORTED, "bilinear / cubic_spline down-sampling (stretched kernel) is not built");
+    if (!resampling_built(resampling))
+        return fail(HK_ERR_UNSUPPORTED, "resampling %d is not built (nearest, bilinear, cubic, cubic_spline, lanczos, "
+                                        "average, max, min, sum, rms are; mode, gauss, med, q1, q3 are not)", resampling);
     if (dst_height > 65535) return fail(HK_ERR_UNSUPPORTED, "destination taller than 65535 rows");
     HK_HIP(hipSetDevice(ctx->device));
     const size_t sbytes = (size_t)n_bands * src_height * src_width * 4, dbytes = (size_t)n_bands * dst_height * dst_width * 4;

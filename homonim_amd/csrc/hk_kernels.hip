@@ -1324,6 +1324,22 @@ __global__ void selftest_kernel(int* result) {
             }
         }
     }
+    {   // the accuracy fast_quot() assumes of v_rcp_f64 (2^-22; appendix B of DESIGN.md) with a factor 2 in hand
+        unsigned long long z = 0x9e3779b97f4a7c15ull * (unsigned long long)(lane + 1);
+        for (int it = 0; it < 512; ++it) {
+            z ^= z << 13, z ^= z >> 7, z ^= z << 17;
+            const double m = 1.0 + (double)(z >> 12) * 0x1p-52;
+            const double d = ldexp((z & 1) ? -m : m, (int)((z >> 1) % 201) - 100);
+            const double y0 = __builtin_amdgcn_rcp(d);
+            const double rel = __fma_rn(-d, y0, 1.0);  // 1 - d*y0 = -eps0 (exact to 2^-53)
+            if (!(fabs(rel) < 0x1p-23)) code |= 512;
+            // and the guarded quotient against the IEEE one
+            const double n = (double)(float)((double)(it + 1) * 0.37 - 90.0);
+            const double q = fast_quot(n, d);
+            const bool again = (quot_guard(q) < 2u * HK_DIV_GUARD + 1u) | (quot_range(q) > 0x0fd00000u);
+            if (!again && (float)q != (float)__ddiv_rn(n, d)) code |= 1024;
+        }
+    }
     if (code) atomicOr(result, code);
 }
 

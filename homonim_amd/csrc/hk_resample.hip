@@ -9,7 +9,12 @@
 //   0 nearest      : source pixel containing the destination centre (floor(x + 1e-10))
 //   5 average      : weighted mean of the valid source pixels under the destination pixel's footprint
 //   1 bilinear / 3 cubic_spline : centre pixel must be valid; separable 2 / 4-tap (cubic B-spline) kernel, invalid or
-//                    outside taps skipped, renormalised by the accumulated weight; up-sampling only
+//                    outside taps skipped, renormalised by the accumulated weight (up-sampling: the fast path below)
+//   1 bilinear / 2 cubic / 3 cubic_spline / 4 lanczos, any scale (resample_conv_kernel): GDAL's GWKResample -- taps
+//                    i in [1 - R', R'] per axis with R' = ceil(R / scale) when the axis is down-sampled (scale =
+//                    min(1, 1 / k) < 1), else R (1, 2, 2, 3); weight f((i - delta) * scale); always renormalised
+//   8 max / 9 min / 13 sum / 14 rms : over the source pixels of the destination pixel's footprint (the window of
+//                    `average`); sum and rms weight the edge pixels by their overlap like average
 // One thread per destination pixel (gather); float64 accumulation, float32 result.
 #include "hk_kernels.h"
 
@@ -54,7 +59,7 @@ __global__ void __launch_bounds__(256) resample_kernel(const ResampleArgs a) {
             const float v = sp[cy * a.src_stride + cx];
             if (rs_valid(v, a.nd_mode, a.nodata)) result = (double)v, got = true;
         }
-    } else if constexpr (MODE == 5) {
+    } else if constexpr (MODE == 5 || MODE == 8 || MODE == 9 || MODE == 13 || MODE == 14) {
         const double y0 = fmax(a.ky * (double)i + a.oy, 0.0), y1 = fmin(a.ky * (double)(i + 1) + a.oy, (double)a.sh);
         const double x0 = fmax(a.kx * (double)j + a.ox, 0.0), x1 = fmin(a.kx * (double)(j + 1) + a.ox, (double)a.sw);
         int iy0 = (int)floor(y0 + 1e-10), iy1 = (int)ceil(y1 - 1e-10);
@@ -72,11 +77,22 @@ __global__ void __launch_bounds__(256) resample_kernel(const ResampleArgs a) {
                     double wx = 1.0;
                     if (ix0 + 1 != ix1) wx = xx == ix0 ? 1.0 - (x0 - (double)ix0) : (xx == ix1 - 1 ? 1.0 - ((double)ix1 - x1) : 1.0);
                     const double wgt = wx * wy;
-                    tot += (double)v * wgt;
+                    if constexpr (MODE == 8) {
+                        tot = wsum > 0.0 ? fmax(tot, (double)v) : (double)v;
+                    } else if constexpr (MODE == 9) {
+                        tot = wsum > 0.0 ? fmin(tot, (double)v) : (double)v;
+                    } else if constexpr (MODE == 14) {
+                        tot += (double)v * (double)v * wgt;
+                    } else {
+                        tot += (double)v * wgt;
+                    }
                     wsum += wgt;
                 }
             }
-            if (wsum > 0.0) result = tot / wsum, got = true;
+            if (wsum > 0.0) {
+                result = (MODE == 5) ? tot / wsum : ((MODE == 14) ? sqrt(tot / wsum) : tot);
+                got = true;
+            }
         }
     } else {
         constexpr int NT = MODE == 1 ? 2 : 4, T0 = MODE == 1 ? 0 : -1;
@@ -111,6 +127,71 @@ __global__ void __launch_bounds__(256) resample_kernel(const ResampleArgs a) {
                 got = true;
             }
         }
+    }
+    dp[(long long)i * a.dst_stride + j] = got ? (float)result : a.dst_fill;
+}
+
+// GDAL's re-sampling kernels as functions of the (scaled) distance: GWKBilinear / GWKCubic (a = -0.5) / GWKBSpline /
+// GWKLanczosSinc (radius 3)
+template <int KIND>
+__device__ __forceinline__ double conv_weight(double x) {
+    const double ax = fabs(x);
+    if constexpr (KIND == 1) {
+        return ax <= 1.0 ? 1.0 - ax : 0.0;
+    } else if constexpr (KIND == 2) {
+        const double x2 = ax * ax;
+        if (ax <= 1.0) return x2 * (1.5 * ax - 2.5) + 1.0;
+        if (ax <= 2.0) return x2 * (-0.5 * ax + 2.5) - 4.0 * ax + 2.0;
+        return 0.0;
+    } else if constexpr (KIND == 3) {
+        if (ax > 2.0) return 0.0;
+        const double xp2 = x + 2.0, xp1 = x + 1.0, xm1 = x - 1.0;
+        const double a = xp2 > 0.0 ? xp2 * xp2 * xp2 : 0.0, b = xp1 > 0.0 ? xp1 * xp1 * xp1 : 0.0;
+        const double c = x > 0.0 ? x * x * x : 0.0, d = xm1 > 0.0 ? xm1 * xm1 * xm1 : 0.0;
+        return (a - 4.0 * b + 6.0 * c - 4.0 * d) / 6.0;
+    } else {
+        if (ax >= 3.0) return 0.0;
+        if (x == 0.0) return 1.0;
+        const double pi = 3.14159265358979323846, px = pi * x, px3 = px / 3.0;
+        return sin(px) * sin(px3) / (px * px3);
+    }
+}
+
+// GWKResample for any scale: bilinear (1) / cubic (2) / cubic_spline (3) / lanczos (4)
+template <int KIND>
+__global__ void __launch_bounds__(256) resample_conv_kernel(const ResampleArgs a) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j >= a.dw) return;
+    const float* __restrict__ sp = a.src + (long long)blockIdx.z * a.src_band_stride;
+    float* __restrict__ dp = a.dst + (long long)blockIdx.z * a.dst_band_stride;
+    constexpr int R = KIND == 1 ? 1 : (KIND == 4 ? 3 : 2);
+    const double xs = a.kx > 1.0 ? 1.0 / a.kx : 1.0, ys = a.ky > 1.0 ? 1.0 / a.ky : 1.0;
+    const int rx = xs < 1.0 ? (int)ceil((double)R / xs) : R, ry = ys < 1.0 ? (int)ceil((double)R / ys) : R;
+    const double sy = a.ky * ((double)i + 0.5) + a.oy, sx = a.kx * ((double)j + 0.5) + a.ox;
+    const long long cy = (long long)floor(sy + 1e-10), cx = (long long)floor(sx + 1e-10);
+    double result = 0.0;
+    bool got = false;
+    if (cx >= 0 && cx < a.sw && cy >= 0 && cy < a.sh && rs_valid(sp[cy * a.src_stride + cx], a.nd_mode, a.nodata)) {
+        const int iy = (int)floor(sy - 0.5), ix = (int)floor(sx - 0.5);
+        const double dy = sy - 0.5 - (double)iy, dx = sx - 0.5 - (double)ix;
+        double acc = 0.0, wacc = 0.0;
+        for (int tj = 1 - ry; tj <= ry; ++tj) {
+            const int yy = iy + tj;
+            if (yy < 0 || yy >= a.sh) continue;
+            const double wy = conv_weight<KIND>(((double)tj - dy) * ys);
+            if (wy == 0.0) continue;
+            for (int ti = 1 - rx; ti <= rx; ++ti) {
+                const int xx = ix + ti;
+                if (xx < 0 || xx >= a.sw) continue;
+                const float v = sp[(long long)yy * a.src_stride + xx];
+                if (!rs_valid(v, a.nd_mode, a.nodata)) continue;
+                const double wgt = conv_weight<KIND>(((double)ti - dx) * xs) * wy;
+                acc += (double)v * wgt;
+                wacc += wgt;
+            }
+        }
+        if (!(fabs(wacc) < 1e-6)) result = acc / wacc, got = true;
     }
     dp[(long long)i * a.dst_stride + j] = got ? (float)result : a.dst_fill;
 }
@@ -353,11 +434,24 @@ hipError_t launch_resample(int mode, const float* src, long long src_stride, lon
     a.dst_band_stride = dst_band_stride, a.sh = sh, a.sw = sw, a.dh = dh, a.dw = dw, a.nd_mode = nd_mode, a.nodata = nodata;
     a.dst_fill = dst_fill, a.kx = kx, a.ox = ox, a.ky = ky, a.oy = oy;
     const dim3 grid((dw + 255) / 256, dh, n_bands), block(256);
+    const bool stretched = kx > 1.0 + 1e-9 || ky > 1.0 + 1e-9;  // an axis is down-sampled: the kernel support scales with it
     switch (mode) {
         case 0: hipLaunchKernelGGL(resample_kernel<0>, grid, block, 0, stream, a); break;
-        case 1: hipLaunchKernelGGL(resample_kernel<1>, grid, block, 0, stream, a); break;
-        case 3: hipLaunchKernelGGL(resample_kernel<3>, grid, block, 0, stream, a); break;
+        case 1:
+            if (stretched) hipLaunchKernelGGL(resample_conv_kernel<1>, grid, block, 0, stream, a);
+            else hipLaunchKernelGGL(resample_kernel<1>, grid, block, 0, stream, a);
+            break;
+        case 2: hipLaunchKernelGGL(resample_conv_kernel<2>, grid, block, 0, stream, a); break;
+        case 3:
+            if (stretched) hipLaunchKernelGGL(resample_conv_kernel<3>, grid, block, 0, stream, a);
+            else hipLaunchKernelGGL(resample_kernel<3>, grid, block, 0, stream, a);
+            break;
+        case 4: hipLaunchKernelGGL(resample_conv_kernel<4>, grid, block, 0, stream, a); break;
         case 5: hipLaunchKernelGGL(resample_kernel<5>, grid, block, 0, stream, a); break;
+        case 8: hipLaunchKernelGGL(resample_kernel<8>, grid, block, 0, stream, a); break;
+        case 9: hipLaunchKernelGGL(resample_kernel<9>, grid, block, 0, stream, a); break;
+        case 13: hipLaunchKernelGGL(resample_kernel<13>, grid, block, 0, stream, a); break;
+        case 14: hipLaunchKernelGGL(resample_kernel<14>, grid, block, 0, stream, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

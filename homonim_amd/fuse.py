@@ -208,6 +208,24 @@ def block_pairs_multires(src: Grid, ref: Grid, proc_crs: ProcCrs, n_bands: int, 
                     yield BlockPair(band_i, proc_in, other_in, proc_out, other_out, outer)
 
 
+def north_up(array: np.ndarray, transform: Optional[Affine]):
+    """ (array, transform) with rows running north to south and columns west to east: a raster whose geo-transform has a
+    positive row step (south-up) or a negative column step is flipped along that axis -- what the reference's
+    ``utils.same_orientation_crs`` obtains by re-projecting it through a WarpedVRT.  Rotated grids are not handled. """
+    if transform is None:
+        return array, transform
+    if transform.b or transform.d:
+        raise NotImplementedError('rotated / sheared rasters are not built (GDAL warp)')
+    a, b, c, d, e, f = transform[:6]
+    if e > 0:
+        array = np.ascontiguousarray(array[..., ::-1, :])
+        f, e = f + e * array.shape[-2], -e
+    if a < 0:
+        array = np.ascontiguousarray(array[..., ::-1])
+        c, a = c + a * array.shape[-1], -a
+    return array, Affine(a, b, c, d, e, f)
+
+
 def shard(items: Sequence, index: int, count: int, contiguous: bool = False) -> List:
     """ The work items of shard ``index`` of ``count``: round-robin, or -- ``contiguous`` -- consecutive runs of (almost)
     equal length, which keeps a shard inside as few bands as possible (the block list is band-major,
@@ -263,6 +281,10 @@ class RasterFuse:
             src = src[None]
         if ref.ndim == 2:
             ref = ref[None]
+        # south-up (or column-mirrored) rasters are brought to north-up first, as the reference does through a WarpedVRT
+        # (homonim/utils.py:190-209; for an axis-aligned raster that re-projection is the flip); outputs are north-up
+        src, transform = north_up(src, transform)
+        ref, ref_transform = north_up(ref, ref_transform)
         if src.ndim != 3 or ref.ndim != 3:
             raise ValueError('`src` and `ref` must be 2-D or 3-D (bands first) arrays')
         if ref.shape[0] < src.shape[0]:

@@ -94,13 +94,14 @@ def _is_affine(obj) -> bool:
 def grid_mapping(src_transform, dst_transform) -> Tuple[float, float, float, float]:
     """
     (kx, ox, ky, oy) with ``src_col = kx * dst_col + ox`` and ``src_row = ky * dst_row + oy`` on continuous pixel
-    coordinates (integers = pixel edges) between two north-up, axis-aligned grids of one CRS -- the only geometry the
-    device re-samplers handle (hk_resample.hip).
+    coordinates (integers = pixel edges) between two axis-aligned grids of one CRS.  A negative factor means the two
+    grids run in opposite directions along that axis (e.g. a south-up raster against a north-up one): the device
+    re-samplers take positive factors, ``RasterArray.reproject`` flips the source array for the others.
     """
     s, d = src_transform, dst_transform
     if s.b or s.d or d.b or d.d:
         raise NotImplementedError('re-projection between rotated / sheared grids is not built')
+    if not (s.a and s.e and d.a and d.e):
+        raise NotImplementedError('degenerate geo-transform')
     kx, ky = d.a / s.a, d.e / s.e
-    if not (kx > 0 and ky > 0):
-        raise NotImplementedError('re-projection between grids of opposite orientation is not built')
     return kx, (d.c - s.c) / s.a, ky, (d.f - s.f) / s.e

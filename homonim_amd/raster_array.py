@@ -184,6 +184,14 @@ class RasterArray:
         from homonim_amd import _hk  # deferred: the carrier itself needs no GPU
         ctx = context or _hk.default_context()
         fill = 0.0 if nodata is None else float(nodata)
-        out = ctx.reproject(self._array, self._nodata, grid_mapping(self._transform, transform), shape, int(resampling),
-                            fill)
+        kx, ox, ky, oy = grid_mapping(self._transform, transform)
+        src = self._array
+        # grids of opposite orientation along an axis (south-up against north-up, mirrored columns): flip the source along
+        # it -- in the flipped array the source coordinate is (size - coordinate), i.e. factor -k and offset size - o.  All of
+        # GDAL's re-sampling kernels are symmetric, so this is the same re-sampling.
+        if ky < 0:
+            src, ky, oy = src[..., ::-1, :], -ky, src.shape[-2] - oy
+        if kx < 0:
+            src, kx, ox = src[..., ::-1], -kx, src.shape[-1] - ox
+        out = ctx.reproject(src, self._nodata, (kx, ox, ky, oy), shape, int(resampling), fill)
         return RasterArray(out, crs, transform, nodata=nodata)

@@ -39,6 +39,8 @@ keep the reference's operation order so results are bitwise reproducible.
 """
 from typing import Optional, Tuple
 
+import math
+
 import numpy as np
 
 F32 = np.float32
@@ -369,7 +371,8 @@ def fit(model: str, src, src_nodata, ref, ref_nodata, kernel_shape=(5, 5), find_
 #   bilinear / cubic_spline : GWKResample -- the source pixel under the destination centre must be valid; separable
 #              2 / 4-tap kernel (cubic B-spline) around it, taps outside the raster or invalid are skipped and the sum is
 #              renormalised by the accumulated weight (nodata below 1e-6).  Up-sampling only (kernel not stretched).
-RESAMPLING_CODES = {'nearest': 0, 'bilinear': 1, 'cubic_spline': 3, 'average': 5}
+RESAMPLING_CODES = {'nearest': 0, 'bilinear': 1, 'cubic': 2, 'cubic_spline': 3, 'lanczos': 4, 'average': 5, 'max': 8,
+                    'min': 9, 'sum': 13, 'rms': 14}
 
 
 COMPARE_KEYS = ('src_sum', 'ref_sum', 'src2_sum', 'ref2_sum', 'src_ref_sum', 'res2_sum', 'mask_sum')
@@ -434,6 +437,84 @@ def _bspline_weights(delta):
     return (w0, w1, w2, w3)
 
 
+def _conv_weight(kind: str, x: float) -> float:
+    """ GDAL's GWKBilinear / GWKCubic (a = -0.5) / GWKBSpline / GWKLanczosSinc (radius 3) at the scaled distance x. """
+    ax = abs(x)
+    if kind == 'bilinear':
+        return 1.0 - ax if ax <= 1.0 else 0.0
+    if kind == 'cubic':
+        x2 = ax * ax
+        if ax <= 1.0:
+            return x2 * (1.5 * ax - 2.5) + 1.0
+        if ax <= 2.0:
+            return x2 * (-0.5 * ax + 2.5) - 4.0 * ax + 2.0
+        return 0.0
+    if kind == 'cubic_spline':
+        if ax > 2.0:
+            return 0.0
+        xp2, xp1, xm1 = x + 2.0, x + 1.0, x - 1.0
+        a = xp2 * xp2 * xp2 if xp2 > 0.0 else 0.0
+        b = xp1 * xp1 * xp1 if xp1 > 0.0 else 0.0
+        c = x * x * x if x > 0.0 else 0.0
+        d = xm1 * xm1 * xm1 if xm1 > 0.0 else 0.0
+        return (a - 4.0 * b + 6.0 * c - 4.0 * d) / 6.0
+    if kind == 'lanczos':
+        if ax >= 3.0:
+            return 0.0
+        if x == 0.0:
+            return 1.0
+        px = math.pi * x
+        px3 = px / 3.0
+        return math.sin(px) * math.sin(px3) / (px * px3)
+    raise NotImplementedError(kind)
+
+
+def _reproject_conv(srcd, valid, mapping, dst_shape, kind):
+    """ GWKResample for any scale: taps i in [1 - R', R'] per axis, R' = ceil(R / scale) on a down-sampled axis (scale =
+    min(1, 1 / k)), weight f((i - delta) * scale), renormalised by the accumulated weight. """
+    kx, ox, ky, oy = mapping
+    sh, sw = srcd.shape
+    dh, dw = dst_shape
+    out = np.zeros((dh, dw), np.float64)
+    got = np.zeros((dh, dw), bool)
+    R = dict(bilinear=1, cubic=2, cubic_spline=2, lanczos=3)[kind]
+    xs = 1.0 / kx if kx > 1.0 else 1.0
+    ys = 1.0 / ky if ky > 1.0 else 1.0
+    rx = int(math.ceil(R / xs)) if xs < 1.0 else R
+    ry = int(math.ceil(R / ys)) if ys < 1.0 else R
+    for i in range(dh):
+        sy = ky * (i + 0.5) + oy
+        cy = int(math.floor(sy + 1e-10))
+        iy = int(math.floor(sy - 0.5))
+        dy = sy - 0.5 - iy
+        for j in range(dw):
+            sx = kx * (j + 0.5) + ox
+            cx = int(math.floor(sx + 1e-10))
+            if cx < 0 or cx >= sw or cy < 0 or cy >= sh or not valid[cy, cx]:
+                continue
+            ix = int(math.floor(sx - 0.5))
+            dx = sx - 0.5 - ix
+            acc = wacc = 0.0
+            for tj in range(1 - ry, ry + 1):
+                a = iy + tj
+                if a < 0 or a >= sh:
+                    continue
+                wy = _conv_weight(kind, (tj - dy) * ys)
+                if wy == 0.0:
+                    continue
+                for ti in range(1 - rx, rx + 1):
+                    b = ix + ti
+                    if b < 0 or b >= sw or not valid[a, b]:
+                        continue
+                    wgt = _conv_weight(kind, (ti - dx) * xs) * wy
+                    acc += srcd[a, b] * wgt
+                    wacc += wgt
+            if not abs(wacc) < 1e-6:
+                out[i, j] = acc / wacc
+                got[i, j] = True
+    return out, got
+
+
 def reproject(src: np.ndarray, src_nodata, mapping, dst_shape, dst_nodata=np.nan, resampling='average',
               dtype=np.float32) -> np.ndarray:
     """ One band (2-D) through the restated GDAL warp kernels; see the block comment above. """
@@ -456,7 +537,9 @@ def reproject(src: np.ndarray, src_nodata, mapping, dst_shape, dst_nodata=np.nan
         ok = iny[:, None] & inx[None, :] & valid[yy, xx]
         out[ok] = srcd[yy, xx][ok]
         got = ok
-    elif resampling == 'average':
+    elif resampling in ('cubic', 'lanczos') or (resampling in ('bilinear', 'cubic_spline') and (kx > 1 + 1e-9 or ky > 1 + 1e-9)):
+        out, got = _reproject_conv(srcd, valid, mapping, dst_shape, resampling)
+    elif resampling in ('average', 'max', 'min', 'sum', 'rms'):
         for i in range(dh):
             y0, y1 = max(ky * i + oy, 0.0), min(ky * (i + 1) + oy, float(sh))
             iy0, iy1 = int(np.floor(y0 + 1e-10)), int(np.ceil(y1 - 1e-10))
@@ -484,14 +567,20 @@ def reproject(src: np.ndarray, src_nodata, mapping, dst_shape, dst_nodata=np.nan
                     for b in range(ix0, ix1):
                         if valid[a, b]:
                             wgt = wx[b - ix0] * wy[a - iy0]
-                            tot += srcd[a, b] * wgt
+                            v = srcd[a, b]
+                            if resampling == 'max':
+                                tot = max(tot, v) if wsum > 0 else v
+                            elif resampling == 'min':
+                                tot = min(tot, v) if wsum > 0 else v
+                            elif resampling == 'rms':
+                                tot += v * v * wgt
+                            else:
+                                tot += v * wgt
                             wsum += wgt
                 if wsum > 0:
-                    out[i, j] = tot / wsum
+                    out[i, j] = tot / wsum if resampling == 'average' else (math.sqrt(tot / wsum) if resampling == 'rms' else tot)
                     got[i, j] = True
     elif resampling in ('bilinear', 'cubic_spline'):
-        if kx > 1 + 1e-9 or ky > 1 + 1e-9:
-            raise NotImplementedError(f'{resampling} down-sampling (stretched kernel)')
         taps = (0, 1) if resampling == 'bilinear' else (-1, 0, 1, 2)
         for i in range(dh):
             sy = ky * (i + 0.5) + oy

@@ -17,6 +17,7 @@ import pytest
 
 from conftest import GOLDEN_CASES, assert_same_f32, case_id
 from homonim_amd import Affine, CRS, KernelModel, Model, RasterArray, RefSpaceModel, SrcSpaceModel, _hk
+from homonim_amd.enums import Resampling
 from oracle import oracle_np as onp
 
 pytestmark = pytest.mark.gpu
@@ -1364,3 +1365,84 @@ def test_src_space_fit_apply_honours_mask_partial(ctx, case):
         corr, _ = RasterFuse(g['src'], g['ref'], proc_crs='src').process(
             None, case['model'], tuple(case['kernel_shape']), model_config=dict(mask_partial=True, r2_inpaint_thresh=None))
     assert (np.isnan(corr[0]) == np.isnan(exp_c)).all()
+
+
+# -- round 2: the other GDAL re-sampling methods, stretched kernels, grids of opposite orientation ---------------------
+@pytest.mark.parametrize('resampling, mapping, dst_shape', [
+    ('bilinear', (2.2, 0.3, 1.9, -0.4), (40, 55)), ('cubic_spline', (3.0, 0., 3.0, 0.), (27, 40)),
+    ('cubic', (.45, -.5, .45, -.5), (180, 270)), ('cubic', (2.5, 0.2, 2.5, 0.1), (30, 45)), ('cubic', (1., 0., 1., 0.), (80, 120)),
+    ('lanczos', (.5, 0., .5, 0.), (160, 240)), ('lanczos', (2.0, 0., 2.0, 0.), (40, 60)),
+    ('max', (2.2, 0.3, 1.9, -0.4), (40, 55)), ('min', (4., 0., 4., 0.), (20, 30)), ('sum', (2., 0., 2., 0.), (40, 60)),
+    ('rms', (2.2, 0.3, 1.9, -0.4), (40, 55)), ('bilinear', (1.5, 0., .5, 0.), (160, 80)),
+])
+@pytest.mark.parametrize('nodata', [np.nan, None])
+def test_more_device_resamplers_equal_oracle(ctx, resampling, mapping, dst_shape, nodata):
+    """ cubic / lanczos / max / min / sum / rms and the stretched (down-sampling) bilinear / cubic_spline kernels of
+    GDAL's GWKResample vs the oracle's restatement: bit-exact float32, except lanczos (its weights go through sin(),
+    whose last bit differs between the device's and the host's libm: 1e-6 relative). """
+    src, _ = onp.synth_pair(80, 120, 14, 'frame+holes' if nodata is not None else 'none')
+    got = ctx.reproject(src, nodata, mapping, dst_shape, onp.RESAMPLING_CODES[resampling], np.nan)
+    exp = onp.reproject(src, nodata, mapping, dst_shape, dst_nodata=np.nan, resampling=resampling)
+    if resampling == 'lanczos':
+        assert (np.isnan(got) == np.isnan(exp)).all()
+        ok = ~np.isnan(exp)
+        assert np.max(np.abs(got[ok] - exp[ok]) / np.abs(exp[ok])) < 1e-6
+    else:
+        assert_same_f32(got, exp, f'{resampling} {mapping}')
+
+
+@pytest.mark.parametrize('resampling', ['bilinear', 'cubic', 'cubic_spline', 'lanczos', 'average', 'max', 'min', 'rms'])
+def test_resamplers_known_answers(ctx, resampling):
+    """ Properties that hold for GDAL whatever its rounding: a constant raster stays constant (up and down), `sum` of whole
+    2 x 2 cells is their sum, max >= average >= min. """
+    const = np.full((40, 60), 3.25, np.float32)
+    code = onp.RESAMPLING_CODES[resampling]
+    for mapping, shape in (((.5, 0., .5, 0.), (80, 120)), ((2., 0., 2., 0.), (20, 30)), ((2.5, .25, 3., .5), (13, 23))):
+        out = ctx.reproject(const, None, mapping, shape, code, np.nan)
+        assert np.allclose(out, 3.25, rtol=1e-6), (resampling, mapping)
+    src, _ = onp.synth_pair(40, 60, 3, 'none')
+    m = (2., 0., 2., 0.)
+    s = ctx.reproject(src, None, m, (20, 30), onp.RESAMPLING_CODES['sum'], np.nan)
+    np.testing.assert_allclose(s, src.reshape(20, 2, 30, 2).astype(np.float64).sum(axis=(1, 3)), rtol=1e-6)
+    mx, mn, av = (ctx.reproject(src, None, m, (20, 30), onp.RESAMPLING_CODES[k], np.nan) for k in ('max', 'min', 'average'))
+    assert (mx >= av).all() and (av >= mn).all()
+    np.testing.assert_array_equal(mx, src.reshape(20, 2, 30, 2).max(axis=(1, 3)))
+
+
+def test_south_up_and_mirrored_grids(ctx):
+    """ reference fixtures tests/conftest.py:423-436,499-517 (south-up rasters): re-sampling between grids of opposite
+    orientation = flipping the array and re-sampling between north-up grids; RasterFuse brings such rasters to north-up
+    first (as utils.same_orientation_crs does through a WarpedVRT) and returns north-up outputs. """
+    import warnings
+    from homonim_amd.fuse import RasterFuse
+    src, ref = onp.synth_pair(120, 90, 5, 'frame+holes')
+    crs = CRS('EPSG:3857')
+    north = Affine(2., 0., 100., 0., -2., 900.)                        # 2 m pixels, origin top-left
+    south = Affine(2., 0., 100., 0., 2., 900. - 2. * 120)              # the same extent, rows bottom-up
+    ra_n = RasterArray(src, crs, north, nodata=np.nan)
+    ra_s = RasterArray(np.ascontiguousarray(src[::-1]), crs, south, nodata=np.nan)
+    coarse = Affine(4., 0., 100., 0., -4., 900.)
+    for rs in (Resampling.average, Resampling.cubic_spline, Resampling.nearest, Resampling.bilinear):
+        a = ra_n.reproject(transform=coarse, shape=(60, 45), resampling=rs) if rs == Resampling.average else ra_n.reproject(
+            transform=Affine(1., 0., 100., 0., -1., 900.), shape=(240, 180), resampling=rs)
+        b = ra_s.reproject(transform=a.transform, shape=a.shape, resampling=rs)
+        assert_same_f32(b.array, a.array, f'south-up source, {rs.name}')
+        # and onto a south-up destination: the flipped result
+        dst_s = Affine(a.transform.a, 0., a.transform.c, 0., -a.transform.e, a.transform.f + a.transform.e * a.shape[0])
+        c = ra_n.reproject(transform=dst_s, shape=a.shape, resampling=rs)
+        assert_same_f32(c.array, a.array[::-1], f'south-up destination, {rs.name}')
+    # mirrored columns
+    west = Affine(-2., 0., 100. + 2. * 90, 0., -2., 900.)
+    ra_w = RasterArray(np.ascontiguousarray(src[:, ::-1]), crs, west, nodata=np.nan)
+    a = ra_n.reproject(transform=coarse, shape=(60, 45), resampling=Resampling.average)
+    assert_same_f32(ra_w.reproject(transform=coarse, shape=(60, 45), resampling=Resampling.average).array, a.array, 'mirrored')
+    # RasterFuse: a south-up source against a north-up reference on a coarser grid
+    ref_c = RasterArray(ref, crs, north, nodata=np.nan).reproject(transform=coarse, shape=(60, 45), resampling=Resampling.average)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        exp, _ = RasterFuse(ra_n, ref_c).process(None, 'gain-blk-offset', (3, 3))
+        got, _ = RasterFuse(ra_s, ref_c).process(None, 'gain-blk-offset', (3, 3))
+        ref_s = RasterArray(np.ascontiguousarray(ref_c.array[::-1]), crs, Affine(4., 0., 100., 0., 4., 900. - 4. * 60), nodata=np.nan)
+        got2, _ = RasterFuse(ra_n, ref_s).process(None, 'gain-blk-offset', (3, 3))
+    assert_same_f32(got, exp, 'south-up source through RasterFuse')
+    assert_same_f32(got2, exp, 'south-up reference through RasterFuse')

@@ -149,5 +149,13 @@ def test_reproject_oracle_invariants():
     assert avg == pytest.approx(r.reshape(4, 3, 6, 3).mean(axis=(1, 3)), rel=1e-6)
     off = onp.reproject(r, None, (1., 30., 1., 0.), (12, 18), dst_nodata=None, resampling='nearest')
     assert (off == 0).all()
+    # stretched kernels (round 2): down-sampling with a convolution kernel scales its support; constants survive, and a
+    # 2:1 bilinear down-sampling of whole cells weights the 4 x 4 neighbourhood (1 3 3 1) x (1 3 3 1) / 64
+    for rs in ('bilinear', 'cubic', 'cubic_spline', 'lanczos'):
+        out = onp.reproject(np.full((12, 18), 2.5, np.float32), None, (2., 0., 2., 0.), (6, 9), resampling=rs)
+        assert np.allclose(out, 2.5, rtol=1e-6), rs
+    bl = onp.reproject(r, None, (2., 0., 2., 0.), (6, 9), resampling='bilinear')
+    w = np.array([1., 3., 3., 1.])
+    assert bl[2, 3] == pytest.approx(float((r[3:7, 5:9].astype(np.float64) * np.outer(w, w)).sum() / 64), rel=1e-6)
     with pytest.raises(NotImplementedError):
-        onp.reproject(r, None, (2., 0., 2., 0.), (6, 9), resampling='cubic_spline')
+        onp.reproject(r, None, (2., 0., 2., 0.), (6, 9), resampling='mode')
