@@ -13,14 +13,16 @@
 // ONE streaming pass over src+ref (8 B per pixel, HBM-bound) instead of a sort:
 //   1. sample:  a 4096-pixel strided sample per band is sorted in one workgroup; it yields the shift of the moment
 //               sums and, per raster, two pivots that bracket the 1st percentile (+-4 sigma of the sample quantile);
-//   2. pass:    every wave streams its rows: count, shifted first/second moments, number of values below the low
-//               pivot, and the ~1 % of values between the pivots compacted through a wave-private LDS stage into a
-//               small HBM buffer (one global atomic per 512 values);
+//   2. pass:    every wave streams its 1 KB chunks: count, shifted first/second moments, number of values below the low
+//               pivot, and the ~1 % of values between the pivots compacted through lane-private LDS queues into a
+//               small HBM buffer (one global atomic per flush of the wave's queues);
 //   3. select:  the two ranks are resolved inside the compacted buffer by a 3-level radix select (11+11+10 bits of the
 //               order-preserving uint32 image of the float) -- integer histograms only, so the result is deterministic.
 // If the pivots miss (or the buffer overflows) a device-side flag routes the band through the same radix select over
 // the full rasters (three more passes); those kernels are always launched and exit immediately otherwise.
 #include "hk_kernels.h"
+
+#include <type_traits>
 
 namespace hk {
 
@@ -28,8 +30,7 @@ constexpr int NORM_THREADS = 256;
 constexpr int L1_BITS = 11, L2_BITS = 11, L3_BITS = 10;
 constexpr int L1_BINS = 1 << L1_BITS, L2_BINS = 1 << L2_BITS, L3_BINS = 1 << L3_BITS;
 constexpr int SAMPLE_N = 4096;     // sample size per band (sorted in LDS by one workgroup)
-constexpr int PASS_WAVES = 2048;   // waves per band in the streaming pass (also the number of partials)
-constexpr int STAGE_N = 512;       // wave-private LDS staging slots per raster
+constexpr int PASS_WAVES = 2048;   // most waves per band in the streaming pass (= the number of partial sums kept)
 constexpr int FB_BLOCKS = 512;     // workgroups per band of the fallback passes
 constexpr int MID_BLOCKS = 256;    // workgroups per compacted buffer of the regular select passes
 
@@ -172,83 +173,150 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
     return v;
 }
 
+// Waves per band of the streaming pass: a function of the block SHAPE only (never of the batch size), so a block's
+// statistics are the same bits whichever launch it travels in; >= 16 chunks of 1 KB per raster per wave.
+static int pass_waves(int height, int width) {
+    const long long chunks = (long long)height * (((width + PX - 1) / PX + WAVE - 1) / WAVE);
+    long long w = chunks / 16;
+    w = w < 64 ? 64 : (w > PASS_WAVES ? PASS_WAVES : w);
+    return (int)w;
+}
+
+// Every lane keeps the values it finds between the pivots in its OWN LDS queue (QCAP slots per raster): the value is
+// written unconditionally to the slot behind the queue's end and the end moves by the compare result, so the loop body
+// has no branch per pixel -- one wave-uniform test per 1 KB chunk asks whether any queue could overflow in the next chunk.
+// The order of the compacted values is irrelevant (the select is a histogram).
+constexpr int QCAP = 16;
+
+// DENSE: neither raster has a nodata value (no validity test at all); otherwise the test is branch-free: `cmp` is the
+// numeric nodata value or NaN (never equal), `nan` says that NaN is the nodata value.
+template <bool DENSE>
 __global__ void __launch_bounds__(WAVE) norm_stream_kernel(const NormArgs a, NormWS* __restrict__ ws_all,
                                                             float* __restrict__ mid_all, size_t mid_cap) {
-    __shared__ float stage[2][STAGE_N];
-    const int band = blockIdx.y, wave = blockIdx.x, lane = threadIdx.x;
+    __shared__ float stage[2][QCAP][WAVE];
+    const int band = blockIdx.y, wave = blockIdx.x, lane = threadIdx.x, G = gridDim.x;
     NormWS& ws = ws_all[band];
     const float* __restrict__ sp = a.src + (long long)band * a.band_stride;
     const float* __restrict__ rp = a.ref + (long long)band * a.band_stride;
     float* mid[2] = {mid_all + ((size_t)band * 2 + 0) * mid_cap, mid_all + ((size_t)band * 2 + 1) * mid_cap};
     const float lo[2] = {ws.lo[0], ws.lo[1]}, hi[2] = {ws.hi[0], ws.hi[1]};
     const double shift[2] = {ws.shift[0], ws.shift[1]};
-    const unsigned long long lane_lt = (1ull << lane) - 1ull;
 
-    unsigned long long n = 0, below[2] = {0, 0};
+    unsigned n = 0, le_hi[2] = {0, 0}, n_in[2] = {0, 0};  // per lane: < 2^32 for any block
     double m1[2] = {0.0, 0.0}, m2[2] = {0.0, 0.0};
-    int fill[2] = {0, 0};  // wave-uniform
+    unsigned cnt[2] = {0, 0};  // per-lane queue lengths
 
     auto flush = [&](int q) {
+        unsigned incl = cnt[q];
+#pragma unroll
+        for (int d = 1; d < WAVE; d <<= 1) {
+            const unsigned v = __shfl_up(incl, d, WAVE);
+            if (lane >= d) incl += v;
+        }
+        const unsigned total = __shfl(incl, WAVE - 1);
         unsigned base = 0;
-        if (lane == 0) base = atomicAdd(&ws.mid_count[q], (unsigned)fill[q]);
+        if (lane == 0) base = atomicAdd(&ws.mid_count[q], total);
         base = __shfl(base, 0);
-        for (int j = lane; j < fill[q]; j += WAVE)
-            if ((size_t)base + j < mid_cap) mid[q][(size_t)base + j] = stage[q][j];
-        fill[q] = 0;
+        const size_t off = (size_t)base + (incl - cnt[q]);
+        for (unsigned j = 0; j < cnt[q]; ++j)
+            if (off + j < mid_cap) mid[q][off + j] = stage[q][j][lane];
+        n_in[q] += cnt[q];
+        cnt[q] = 0;
     };
 
-    const int wq = (a.width + PX - 1) / PX;
-    for (int y = wave; y < a.height; y += gridDim.x) {
-        const long long row = (long long)y * a.stride;
-        for (int xq0 = 0; xq0 < wq; xq0 += WAVE) {  // wave-uniform trip count: the ballots below need all lanes
-            const int xq = xq0 + lane;
-            const int x = xq * PX;
-            float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f), r4 = s4;
-            if (xq < wq) {  // rows are padded to a multiple of PX elements
-                s4 = *reinterpret_cast<const float4*>(sp + row + x);
-                r4 = *reinterpret_cast<const float4*>(rp + row + x);
-            }
-            const float s[PX] = {s4.x, s4.y, s4.z, s4.w}, r[PX] = {r4.x, r4.y, r4.z, r4.w};
+    // the wave's chunks: it = wave, wave + G, ... over rows x chunks-per-row, (y, c) stepped without a division
+    const int wq = (a.width + PX - 1) / PX, cpr = (wq + WAVE - 1) / WAVE;
+    const long long total = (long long)a.height * cpr;
+    const int dy = G / cpr, dc = G % cpr;
+    int py = wave / cpr, pc = wave % cpr;  // position of the next load
+    long long pit = wave;
+    auto fetch = [&](float4& s4, float4& r4, int& x) {
+        // always a valid address (chunk 0 of row 0 for lanes / iterations past the end), x = width marks "no pixels".
+        // The row / chunk part of the address is wave-uniform (scalar registers), the lane adds 16 bytes * lane.
+        const bool live = pit < total;
+        const long long o = live ? (long long)py * a.stride + (long long)pc * (WAVE * PX) : 0ll;
+        const bool ok = live && pc * WAVE + lane < wq;  // rows are padded to a multiple of PX elements
+        const int lo4 = ok ? lane * PX : 0;
+        s4 = *reinterpret_cast<const float4*>(sp + o + lo4);
+        r4 = *reinterpret_cast<const float4*>(rp + o + lo4);
+        x = ok ? (pc * WAVE + lane) * PX : a.width;
+        pit += G, py += dy, pc += dc;
+        if (pc >= cpr) pc -= cpr, ++py;
+    };
+    const float cmp_s = a.src_nd_mode == 2 ? a.src_nodata : __int_as_float(0x7fc00000);
+    const float cmp_r = a.ref_nd_mode == 2 ? a.ref_nodata : __int_as_float(0x7fc00000);
+    const bool nan_s = a.src_nd_mode == 1, nan_r = a.ref_nd_mode == 1;
+    // FULL (wave-uniform): every lane holds four pixels of the row -- with DENSE the body is then straight-line code
+    auto process = [&](const float4& s4, const float4& r4, int x, auto full) {
+        constexpr bool FULL = decltype(full)::value;
+        if (__any((cnt[0] > cnt[1] ? cnt[0] : cnt[1]) > (unsigned)(QCAP - PX))) {  // rare
+            if (__any(cnt[0] > (unsigned)(QCAP - PX))) flush(0);
+            if (__any(cnt[1] > (unsigned)(QCAP - PX))) flush(1);
+        }
+        const float s[PX] = {s4.x, s4.y, s4.z, s4.w}, r[PX] = {r4.x, r4.y, r4.z, r4.w};
+        const int npx = a.width - x;  // <= 0: nothing
 #pragma unroll
-            for (int i = 0; i < PX; ++i) {
-                const bool m = xq < wq && x + i < a.width && nvalid(s[i], a.src_nd_mode, a.src_nodata) &&
-                               nvalid(r[i], a.ref_nd_mode, a.ref_nodata);
-                const float v[2] = {s[i], r[i]};
-                if (m) {
-                    ++n;
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const double d = (double)v[q] - shift[q];
-                        m1[q] += d;
-                        m2[q] += d * d;
-                        below[q] += v[q] < lo[q] ? 1u : 0u;
-                    }
-                }
+        for (int i = 0; i < PX; ++i) {
+            bool m = FULL || i < npx;
+            if constexpr (!DENSE)
+                m = m && !(s[i] == cmp_s) && !(r[i] == cmp_r) && (s[i] == s[i] || !nan_s) && (r[i] == r[i] || !nan_r);
+            const float v[2] = {s[i], r[i]};
+            if (m) {
+                ++n;
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-                    const bool in = m && v[q] >= lo[q] && v[q] <= hi[q];
-                    const unsigned long long bal = __ballot(in);
-                    if (bal) {  // wave-uniform
-                        const int c = __popcll(bal);
-                        if (fill[q] + c > STAGE_N) flush(q);
-                        if (in) stage[q][fill[q] + __popcll(bal & lane_lt)] = v[q];
-                        fill[q] += c;
-                    }
+                    const double d = (double)v[q] - shift[q];
+                    m1[q] += d;
+                    m2[q] = __fma_rn(d, d, m2[q]);
                 }
             }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                // two compares per value: "<= hi" is counted, "in [lo, hi]" moves the queue's end; below = le_hi - in
+                const bool le = m && v[q] <= hi[q], in = le && !(v[q] < lo[q]);
+                stage[q][cnt[q]][lane] = v[q];  // slot cnt <= QCAP - 1 by the test above
+                le_hi[q] += le ? 1u : 0u;
+                cnt[q] += in ? 1u : 0u;
+            }
         }
+    };
+    const bool quads = (a.width % PX) == 0;
+    auto process_any = [&](const float4& s4, const float4& r4, int x) {
+        // wave-uniform: lane 63 holds a whole quad <=> all lanes do
+        if (quads && __shfl(x, WAVE - 1) < a.width) process(s4, r4, x, std::true_type{});
+        else process(s4, r4, x, std::false_type{});
+    };
+
+    // three register sets in rotation (no copies between them: a copy would wait for the load it copies), so two chunks
+    // per raster are in flight while one is processed
+    float4 sA, rA, sB, rB, sC, rC;
+    int xA, xB, xC;
+    fetch(sA, rA, xA);
+    fetch(sB, rB, xB);
+    fetch(sC, rC, xC);
+    for (long long it = wave; it < total;) {
+        process_any(sA, rA, xA);
+        fetch(sA, rA, xA);
+        if ((it += G) >= total) break;
+        process_any(sB, rB, xB);
+        fetch(sB, rB, xB);
+        if ((it += G) >= total) break;
+        process_any(sC, rC, xC);
+        fetch(sC, rC, xC);
+        it += G;
     }
     flush(0);
     flush(1);
-    n = wave_sum(n);
+    const unsigned long long nw = wave_sum((unsigned long long)n);
+    unsigned long long bw[2];
     for (int q = 0; q < 2; ++q) {
         m1[q] = wave_sum(m1[q]);
         m2[q] = wave_sum(m2[q]);
-        below[q] = wave_sum(below[q]);
+        bw[q] = wave_sum((unsigned long long)(le_hi[q] - n_in[q]));  // values below the low pivot
     }
     if (lane == 0) {
-        ws.pn[wave] = n;
-        for (int q = 0; q < 2; ++q) ws.p1[q][wave] = m1[q], ws.p2[q][wave] = m2[q], ws.pbelow[q][wave] = below[q];
+        ws.pn[wave] = nw;
+        for (int q = 0; q < 2; ++q) ws.p1[q][wave] = m1[q], ws.p2[q][wave] = m2[q], ws.pbelow[q][wave] = bw[q];
     }
 }
 
@@ -464,7 +532,11 @@ hipError_t launch_block_norm(const NormArgs& a, void* workspace, double* norm_ou
     if (e != hipSuccess) return e;
     const dim3 bands(a.n_bands), block(NORM_THREADS);
     hipLaunchKernelGGL(norm_sample_kernel, bands, dim3(1024), 0, stream, a, ws);
-    hipLaunchKernelGGL(norm_stream_kernel, dim3(PASS_WAVES, a.n_bands), dim3(WAVE), 0, stream, a, ws, mid, cap_al);
+    const dim3 gstream(pass_waves(a.height, a.width), a.n_bands);
+    if (a.src_nd_mode == 0 && a.ref_nd_mode == 0)
+        hipLaunchKernelGGL(norm_stream_kernel<true>, gstream, dim3(WAVE), 0, stream, a, ws, mid, cap_al);
+    else
+        hipLaunchKernelGGL(norm_stream_kernel<false>, gstream, dim3(WAVE), 0, stream, a, ws, mid, cap_al);
     hipLaunchKernelGGL(norm_stats_kernel, bands, dim3(64), 0, stream, ws, norm_out, cap_al);
     const dim3 gmid(MID_BLOCKS, a.n_bands * 2), gfull(FB_BLOCKS, a.n_bands);
     hipLaunchKernelGGL(norm_mid_hist_kernel<0>, gmid, block, 0, stream, ws, mid, cap_al);
