@@ -660,6 +660,8 @@ def main():
         }
         if res.get('end_to_end') is not None:
             out['end_to_end'] = res['end_to_end']
+        if dist.backend() is not None:
+            out['dist_backend'] = dist.backend()   # 'nccl' = RCCL; absent for a single process without a group
         print(json.dumps(out), flush=True)
 
     ctx.close()

@@ -22,7 +22,8 @@ def init(backend: Optional[str] = None) -> Tuple[int, int, int]:
     """ Join the process group named by the environment; a no-op for single-process runs. """
     rank, world, local_rank = env_ranks()
     _state.update(world=world, rank=rank, local_rank=local_rank)
-    if world > 1 and not _state['initialised']:
+    # HOMONIM_AMD_DIST_FORCE=1: join the group even alone (exercises the RCCL plumbing on a 1-GPU box)
+    if (world > 1 or os.environ.get('HOMONIM_AMD_DIST_FORCE') == '1') and not _state['initialised']:
         import torch
         import torch.distributed as dist
         if backend is None:
@@ -47,6 +48,11 @@ def _reduce(value: float, op_name: str) -> float:
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=getattr(dist.ReduceOp, op_name))
     return float(t.item())
+
+
+def backend() -> Optional[str]:
+    """ Backend of the joined process group (None: single process, no group). """
+    return _state['backend'] if _state['initialised'] else None
 
 
 def barrier():

@@ -70,3 +70,20 @@ def test_two_contexts_in_one_process_share_the_block_list(ctx_unused=None):
         two_c, two_p = RasterFuse(src, ref).process(device_config=dict(devices=[0, 1 % n_dev], separate_contexts=True), **kw)
     assert _same(one_c, two_c) and _same(one_p, two_p)
     assert np.isnan(one_c).sum() < one_c.size
+
+
+def test_bench_joins_an_rccl_group_of_one():
+    """ The driver's N > 1 launch is `python -m torch.distributed.run ... bench.py --gpus N` over RCCL.  A 1-GPU box can
+    still run that plumbing with a group of one: torch's HIP runtime and the library's share the device, the group is
+    created on it (backend nccl = RCCL), the barrier and the MAX / SUM reductions run on device tensors. """
+    import json
+    env = dict(os.environ, HOMONIM_AMD_DIST_FORCE='1', MASTER_ADDR='127.0.0.1', PYTHONPATH=REPO)
+    env.pop('HOMONIM_AMD_DIST_BACKEND', None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', str(29300 + os.getpid() % 200), os.path.join(REPO, 'bench.py'), '--gpus', '1', '--config', '1',
+           '--steps', '3', '--warmup', '1', '--no-cpu-baseline']
+    run = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert run.returncode == 0, run.stderr[-3000:]
+    line = json.loads(run.stdout.strip().splitlines()[-1])
+    assert line['n_gpus'] == 1 and line['value'] > 0 and line['parity_spot_check']['passed']
+    assert line.get('dist_backend') == 'nccl'
