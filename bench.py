@@ -249,9 +249,17 @@ def run_resident(args, ctx, dist, rank, world):
     fail_dev = [bufs['fail'], bufs['fail2']]
     fail_host = [ctx.pinned_empty((B,), np.uint64) for _ in range(2)]
     fail_ready = [ctx.event(), ctx.event()]
+    # ... and two scratch buffers (hk_dev_job.scratch): when failures are expected the launch leaves the in-painting's inputs
+    # (offsets + source flags) there, so the in-painting of step i does not run the fit again for them
+    scratch = [None, None]
+    if thresh is not None and not os.environ.get('HK_BENCH_NO_SCRATCH'):
+        job.scratch_bytes = ctx.job_scratch_bytes(job)
+        scratch = [ctx.dev_alloc(job.scratch_bytes) for _ in range(2)]
+        bufs['scratch0'], bufs['scratch1'] = scratch
 
     def launch(i):
         job.fail_count = fail_dev[i % 2]
+        job.scratch = scratch[i % 2]
         if args.model == 'gain-blk-offset':
             ctx.block_norm_dev(desc, job, bufs['norm'])  # the block statistics are part of the fit
         ctx.fit_apply_dev(desc, job)
@@ -268,6 +276,7 @@ def run_resident(args, ctx, dist, rank, world):
         ctx.event_sync(fail_ready[i % 2])
         counts = fail_host[i % 2].copy()
         job.fail_count = fail_dev[i % 2]  # a band the certificate-only build gave up on is re-counted here
+        job.scratch = scratch[i % 2]
         return ctx.inpaint_dev_counts(desc, job, counts) if counts.any() else 0
 
     def run(n_steps, events=None):
@@ -508,6 +517,10 @@ def run_tiles(args, ctx, dist, rank, world):
         job.norm = d['norm'] if args.model == 'gain-blk-offset' else None
         job.n_bands, job.height, job.width, job.stride, job.band_stride = B, n, n, stride, band_stride
         job.seg_rows, job.stream = 0, j % n_streams
+        if thresh is not None:  # the in-painting's inputs stay with the tile until its counters have been looked at
+            job.scratch_bytes = ctx.job_scratch_bytes(job)
+            d['scratch'] = ctx.dev_alloc(job.scratch_bytes)
+            job.scratch = d['scratch']
         tiles.append((d, job, ctx.pinned_empty((B,), np.uint64), ctx.event()))
     ctx.stream_sync(0)
 

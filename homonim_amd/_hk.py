@@ -58,6 +58,7 @@ class DevJob(C.Structure):
         ('height', C.c_int32), ('width', C.c_int32), ('stride', C.c_int64), ('band_stride', C.c_int64),
         ('seg_rows', C.c_int32), ('stream', C.c_int32),
         ('out_row0', C.c_int32), ('out_col0', C.c_int32), ('out_rows', C.c_int32), ('out_cols', C.c_int32),
+        ('scratch', C.c_void_p), ('scratch_bytes', C.c_uint64),
     ]  # yapf: disable
 
 
@@ -67,6 +68,7 @@ _f32p, _f64p, _u64p = _P(C.c_float), _P(C.c_double), _P(C.c_uint64)
 # name -> (restype, argtypes); kept in one table so tests can check every symbol of the header is exported
 SIGNATURES = {
     'hk_backend_name': (C.c_char_p, []),
+    'hk_dev_job_scratch_bytes': (C.c_uint64, [C.c_int32, C.c_int32, C.c_int64, C.c_int64]),
     'hk_last_error': (C.c_char_p, []),
     'hk_device_count': (C.c_int, [_P(C.c_int)]),
     'hk_ctx_create': (C.c_int, [C.c_int, C.c_int, _P(C.c_void_p)]),
@@ -467,6 +469,10 @@ class Context:
 
     def memset(self, dptr: int, value: int, nbytes: int):
         _check(self._lib.hk_memset(self._h, C.c_void_p(dptr), value, nbytes))
+
+    def job_scratch_bytes(self, job: DevJob) -> int:
+        """ Size of the optional DevJob.scratch (gain-offset with an r2 threshold: the in-painting's inputs). """
+        return int(self._lib.hk_dev_job_scratch_bytes(job.n_bands, job.height, job.stride, job.band_stride))
 
     def fit_apply_dev(self, desc: FitDesc, job: DevJob):
         _check(self._lib.hk_fit_apply_dev(self._h, C.byref(desc), C.byref(job)))

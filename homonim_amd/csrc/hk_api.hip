@@ -287,31 +287,43 @@ static int ensure_inpaint_scratch(Slot& sl, size_t plane, int height, long long 
 // counted (the counter carries the re-run bit).
 static_assert(HK_COUNT_RETRY == hk::FIT_RETRY_BIT, "public and kernel-side re-run bits differ");
 static bool cert_only_eligible(const hk::FitArgs& a, const hk_fit_desc* desc) {
-    return desc->model == HK_MODEL_GAIN_OFFSET && a.has_thresh && a.fail_count && !a.r2 && !a.offset_in;
+    return desc->model == HK_MODEL_GAIN_OFFSET && a.has_thresh && a.fail_count && !a.r2 && !a.offset_in && !a.flag;
 }
 
+// `pre_offset` / `pre_flag` (both or neither): offsets and source flags (r2 > thresh) & (gain > 0) & valid left by the pass
+// that counted the failures (FitArgs::flag) -- the in-painting then starts right away.  `drop_params`: the parameter
+// planes in `a` are scratch, the closing pass need not write them.
 static int inpaint_band(Slot& sl, const hk::FitArgs& a, const hk_fit_desc* desc, bool r2, size_t plane,
-                        bool params_are_scratch = false) {
+                        bool drop_params = false, const float* pre_offset = nullptr, const unsigned char* pre_flag = nullptr) {
     {
         const int rc = ensure_inpaint_scratch(sl, plane, a.height, a.stride);
         if (rc) return rc;
     }
     char* aux = static_cast<char*>(sl.aux);
     float* filled = reinterpret_cast<float*>(aux);
-    float *pg = a.gain, *po = a.offset, *pr = a.r2;
-    if (!pg || !po || !pr) {  // parameters were not materialised by the first pass: run it again into scratch planes
-        pg = reinterpret_cast<float*>(aux + plane), po = reinterpret_cast<float*>(aux + 2 * plane);
-        pr = reinterpret_cast<float*>(aux + 3 * plane);
+    const float *pg = a.gain, *po = a.offset, *pr = a.r2;
+    const unsigned char* flags = nullptr;
+    if (pre_offset && pre_flag) {
+        po = pre_offset, flags = pre_flag;
+    } else if (!pg || !po || !pr) {
+        // parameters were not materialised by the first pass: run it again for what the in-painting reads -- the offsets
+        // and the source flags, which the kernel writes itself (1 byte per pixel)
+        float* scratch_off = reinterpret_cast<float*>(aux + plane);
         hk::FitArgs b = a;
-        b.gain = pg, b.offset = po, b.r2 = pr, b.corr = nullptr, b.fail_count = nullptr;
+        b.gain = nullptr, b.r2 = nullptr, b.offset = scratch_off, b.corr = nullptr, b.fail_count = nullptr;
+        b.flag = hk::inpaint_flag_plane(aux + 4 * plane, a.height, a.stride);
+        b.cert_only = 0;
         HK_HIP(hk::launch_fit_apply(b, desc->model, r2, sl.stream));
+        po = scratch_off, flags = b.flag;
     }
     HK_HIP(hk::launch_inpaint_offsets(po, pg, pr, desc->r2_thresh, a.stride, a.height, a.width, aux + 4 * plane, filled,
-                                      sl.stream));
+                                      sl.stream, flags));
     hk::FitArgs c = a;
     c.offset_in = filled;
     c.fail_count = nullptr;  // already counted
-    if (params_are_scratch) c.gain = c.offset = c.r2 = nullptr;  // nobody reads them after this
+    c.flag = nullptr;
+    c.cert_only = 0;
+    if (drop_params) c.gain = c.offset = c.r2 = nullptr;  // nobody reads them after this
     HK_HIP(hk::launch_fit_apply(c, desc->model, r2, sl.stream));
     return HK_OK;
 }
@@ -323,7 +335,7 @@ static int inpaint_band(Slot& sl, const hk::FitArgs& a, const hk_fit_desc* desc,
 // stream synchronisation per block when no pixel fails, which is the usual case on well-conditioned imagery)
 struct FitPending {
     hk::FitArgs a;
-    bool scratch_params = false;
+    bool scratch_params = false;  // a.offset / a.flag are the slot's scratch (written for the in-painting only)
     bool active = false;  // gain-offset with a threshold: fit_finish() has to look at the counter
 };
 
@@ -351,7 +363,7 @@ int fit_finish(hk_ctx* ctx, Slot& sl, const hk_fit_desc* desc, FitPending& p, un
     }
     ctx->expect_r2_failures.store(n_fail > 0 ? 1 : 0);
     if (n_fail > 0) {
-        const int rc = inpaint_band(sl, a, desc, r2, plane, p.scratch_params);
+        const int rc = inpaint_band(sl, a, desc, r2, plane, p.scratch_params, a.flag ? a.offset : nullptr, a.flag);
         if (rc) return rc;
         *requeued = true;
     }
@@ -396,14 +408,17 @@ int fit_on_device(hk_ctx* ctx, Slot& sl, const hk_fit_desc* desc, const double* 
     // the in-painting branch needs the parameters of the whole block: the store window only narrows the other models
     if (win && !a.has_thresh) a.out_y0 = win[0], a.out_y1 = win[1], a.out_x0 = win[2], a.out_x1 = win[3];
     p.scratch_params = false;
-    if (a.has_thresh && !d_gain && !d_off && !d_r2 && ctx->expect_r2_failures.load()) {
-        // parameters into the slot's scratch planes right away (layout of inpaint_band): no second "first pass"
+    if (a.has_thresh && desc->model == HK_MODEL_GAIN_OFFSET && ctx->expect_r2_failures.load()) {
+        // what the in-painting reads -- offsets and source flags -- into the slot's scratch right away (layout of
+        // inpaint_band): no second "first pass".  With the caller's own offset plane only the flags are scratch.
         int rc = ensure_inpaint_scratch(sl, plane, height, stride);
         if (rc) return rc;
         char* aux = static_cast<char*>(sl.aux);
-        a.gain = reinterpret_cast<float*>(aux + plane), a.offset = reinterpret_cast<float*>(aux + 2 * plane);
-        a.r2 = reinterpret_cast<float*>(aux + 3 * plane);
-        p.scratch_params = true;
+        a.flag = hk::inpaint_flag_plane(aux + 4 * plane, height, stride);
+        if (!d_off) {
+            a.offset = reinterpret_cast<float*>(aux + plane);
+            p.scratch_params = !d_gain && !d_r2;
+        }
     }
     a.cert_only = cert_only_eligible(a, desc) && !p.scratch_params && ctx->try_cert_only();
     HK_HIP(hk::launch_fit_apply(a, desc->model, r2, sl.stream));
@@ -994,6 +1009,23 @@ int hk_memset(hk_ctx* ctx, void* dst, int value, size_t bytes) {
     return HK_OK;
 }
 
+// elements spanned by the job's planes (last band's plane included)
+static size_t job_span(int32_t n_bands, int32_t height, int64_t stride, int64_t band_stride) {
+    const size_t plane = (size_t)stride * (size_t)height;
+    return n_bands > 1 ? (size_t)(n_bands - 1) * (size_t)band_stride + plane : plane;
+}
+uint64_t hk_dev_job_scratch_bytes(int32_t n_bands, int32_t height, int64_t stride, int64_t band_stride) {
+    if (n_bands < 1 || height < 1 || stride < 1 || band_stride < 0) return 0;
+    return (uint64_t)job_span(n_bands, height, stride, band_stride) * 5u;
+}
+// the job's scratch planes (NULL without scratch): offsets (float32) and source flags (1 byte), indexed like the job's planes
+static float* job_scratch_offset(const hk_dev_job* job) { return static_cast<float*>(job->scratch); }
+static unsigned char* job_scratch_flag(const hk_dev_job* job) {
+    return job->scratch ? static_cast<unsigned char*>(job->scratch) +
+                              4 * job_span(job->n_bands, job->height, job->stride, job->band_stride)
+                        : nullptr;
+}
+
 static int check_job(hk_ctx* ctx, const hk_dev_job* job) {
     if (!ctx || !job) return fail(HK_ERR_ARG, "NULL argument");
     if (!job->src || !job->ref) return fail(HK_ERR_ARG, "job src/ref is NULL");
@@ -1005,6 +1037,11 @@ static int check_job(hk_ctx* ctx, const hk_dev_job* job) {
          (uintptr_t)job->r2 | (uintptr_t)job->corr) & 15)
         return fail(HK_ERR_ARG, "device planes must be 16-byte aligned");
     if (job->stream < 0 || job->stream >= (int)ctx->slots.size()) return fail(HK_ERR_ARG, "bad stream index");
+    if (job->scratch) {
+        if ((uintptr_t)job->scratch & 15) return fail(HK_ERR_ARG, "job scratch must be 16-byte aligned");
+        if (job->scratch_bytes < hk_dev_job_scratch_bytes(job->n_bands, job->height, job->stride, job->band_stride))
+            return fail(HK_ERR_ARG, "job scratch smaller than hk_dev_job_scratch_bytes()");
+    }
     if (job->out_rows || job->out_cols) {
         if (job->out_row0 < 0 || job->out_col0 < 0 || job->out_rows < 1 || job->out_cols < 1 ||
             job->out_row0 + job->out_rows > job->height || job->out_col0 + job->out_cols > job->width)
@@ -1046,6 +1083,11 @@ int hk_fit_apply_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* job
     // a band the certificate-only build cannot settle comes back with FIT_RETRY_BIT in its counter; hk_inpaint_dev /
     // hk_inpaint_dev_counts run it again with the full build
     a.cert_only = cert_only_eligible(a, desc) && !ctx->expect_r2_failures.load() && ctx->try_cert_only();
+    if (!a.cert_only && desc->model == HK_MODEL_GAIN_OFFSET && a.has_thresh && job->scratch) {
+        // the complete build leaves the in-painting's inputs in the job's scratch (hk_inpaint_dev_counts starts from them)
+        a.flag = job_scratch_flag(job);
+        if (!a.offset) a.offset = job_scratch_offset(job);
+    }
     HK_HIP(hk::launch_fit_apply(a, desc->model, needs_r2(desc), ctx->slots[job->stream].stream));
     return HK_OK;
 }
@@ -1099,21 +1141,26 @@ int hk_inpaint_dev_counts(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job
         fill_args(a, desc, ctx->xcd_remap);
         fill_grid(a, job->seg_rows);
         std::unique_lock<std::mutex> lk(ctx->mu);  // the slot's scratch may be (re)allocated
-        bool scratch_params = false;
+        // offsets + source flags left by the pass that counted: a count without the re-run bit comes from the complete
+        // build, which writes them whenever the job carries scratch (hk_fit_apply_dev)
+        const float* pre_off = nullptr;
+        const unsigned char* pre_flag = nullptr;
+        if (job->scratch && !(n_fail & hk::FIT_RETRY_BIT)) {
+            pre_flag = job_scratch_flag(job) + off;
+            pre_off = a.offset ? a.offset : job_scratch_offset(job) + off;
+        }
         if (n_fail & hk::FIT_RETRY_BIT) {
-            // the certificate-only build gave up on this band (hk_fit_apply_dev): run the full build, straight into the
-            // in-painting scratch planes when the caller keeps no parameters, and count again
+            // the certificate-only build gave up on this band (hk_fit_apply_dev): run the full build, which leaves the
+            // in-painting's inputs in scratch (the job's, else the slot's), and count again
             if (!job->fail_count) return fail(HK_ERR_ARG, "a band needs its re-run but job->fail_count is NULL");
             retried = true;
             unsigned long long* d_fail = reinterpret_cast<unsigned long long*>(job->fail_count) + b;
-            if (!a.gain && !a.offset) {
-                rc = ensure_inpaint_scratch(sl, plane, a.height, a.stride);
-                if (rc) return rc;
-                char* aux = static_cast<char*>(sl.aux);
-                a.gain = reinterpret_cast<float*>(aux + plane), a.offset = reinterpret_cast<float*>(aux + 2 * plane);
-                a.r2 = reinterpret_cast<float*>(aux + 3 * plane);
-                scratch_params = true;
-            }
+            rc = ensure_inpaint_scratch(sl, plane, a.height, a.stride);
+            if (rc) return rc;
+            char* aux = static_cast<char*>(sl.aux);
+            float* const caller_off = a.offset;
+            a.flag = job->scratch ? job_scratch_flag(job) + off : hk::inpaint_flag_plane(aux + 4 * plane, a.height, a.stride);
+            if (!a.offset) a.offset = job->scratch ? job_scratch_offset(job) + off : reinterpret_cast<float*>(aux + plane);
             a.fail_count = d_fail;
             HK_HIP(hipMemsetAsync(d_fail, 0, sizeof(unsigned long long), sl.stream));
             HK_HIP(hk::launch_fit_apply(a, desc->model, r2, sl.stream));
@@ -1122,11 +1169,12 @@ int hk_inpaint_dev_counts(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job
             lk.unlock();  // other streams' callers need not wait for this stream to drain
             HK_HIP(hipStreamSynchronize(sl.stream));
             lk.lock();
-            a.fail_count = nullptr;
+            pre_off = a.offset, pre_flag = a.flag;
+            a.fail_count = nullptr, a.flag = nullptr, a.offset = caller_off;
         }
         total += n_fail;
         if (n_fail == 0) continue;
-        rc = inpaint_band(sl, a, desc, r2, plane, scratch_params);
+        rc = inpaint_band(sl, a, desc, r2, plane, false, pre_off, pre_flag);
         if (rc) return rc;
     }
     if (retried) ctx->cert_only_retried();

@@ -177,18 +177,26 @@ __global__ void __launch_bounds__(256) inpaint_fill_kernel(const float* __restri
 // workspace: two uint16 distance tables + source flags (1 byte per pixel) + the tie bitmap + the weight table
 size_t inpaint_workspace_bytes(int height, long long stride) { return (size_t)height * stride * 5 + 1024 + TIE_N / 8 + 256 + WTAB_N * 8 + 256; }
 
+// the workspace's source-flag plane: the fit kernel can write it itself (FitArgs::flag), then gain / r2 are not needed here
+unsigned char* inpaint_flag_plane(void* workspace, int height, long long stride) {
+    return reinterpret_cast<unsigned char*>(static_cast<unsigned short*>(workspace) + 2 * (size_t)height * stride);
+}
+
 hipError_t launch_inpaint_offsets(const float* offset, const float* gain, const float* r2, float thresh, long long stride,
-                                  int height, int width, void* workspace, float* filled, hipStream_t stream) {
+                                  int height, int width, void* workspace, float* filled, hipStream_t stream,
+                                  const unsigned char* flag_ready) {
     const size_t plane = (size_t)height * stride;
     unsigned short* top_d = static_cast<unsigned short*>(workspace);
     unsigned short* bot_d = top_d + plane;
-    unsigned char* flag = reinterpret_cast<unsigned char*>(bot_d + plane);
-    unsigned* tie = reinterpret_cast<unsigned*>(flag + (plane + 255) / 256 * 256);
+    unsigned char* ws_flag = inpaint_flag_plane(workspace, height, stride);
+    const unsigned char* flag = flag_ready ? flag_ready : ws_flag;
+    unsigned* tie = reinterpret_cast<unsigned*>(ws_flag + (plane + 255) / 256 * 256);
     double* wtab = reinterpret_cast<double*>(tie + (TIE_N / 32 + 64) / 64 * 64);
     hipLaunchKernelGGL(tie_kernel, dim3((TIE_N / 32 + 255) / 256), dim3(256), 0, stream, tie, wtab);
     const int max_dist = 100;  // rasterio.fill.fillnodata default max_search_distance (kernel_model.py:366)
-    hipLaunchKernelGGL(inpaint_flag_kernel, dim3((width + 255) / 256, height < 1024 ? height : 1024), dim3(256), 0, stream,
-                       gain, r2, thresh, stride, height, width, flag);
+    if (!flag_ready)  // else: the flag plane was written by the fit kernel (FitArgs::flag)
+        hipLaunchKernelGGL(inpaint_flag_kernel, dim3((width + 255) / 256, height < 1024 ? height : 1024), dim3(256), 0, stream,
+                           gain, r2, thresh, stride, height, width, ws_flag);
     hipLaunchKernelGGL(inpaint_scan_kernel, dim3((width + 255) / 256, (height + SCAN_ROWS - 1) / SCAN_ROWS), dim3(256), 0,
                        stream, flag, stride, height, width, max_dist, top_d, bot_d);
     hipLaunchKernelGGL(inpaint_fill_kernel, dim3((width + 255) / 256, height < 65535 ? height : 65535), dim3(256), 0, stream, offset, flag, stride,

@@ -23,6 +23,8 @@ struct FitArgs {
     const double* norm;              // n_bands x 2 (gain-blk-offset)
     const float* offset_in;          // second (in-paint) pass of gain-offset: in-painted offsets, else NULL
     unsigned long long* fail_count;  // n_bands
+    unsigned char* flag;             // gain-offset with a threshold: 1 byte per pixel = (r2 > thresh) & (gain > 0) & valid
+                                     // (kernel_model.py:363), the in-painting's source mask; same strides as the planes; or NULL
     int height, width;
     long long stride;       // elements between rows
     long long band_stride;  // elements between planes
@@ -115,8 +117,12 @@ hipError_t launch_partial_mask(const float* in, int nd_mode, float nodata, const
 // In-painting of the offset band (hk_inpaint.hip; GDALFillNodata restated): sources are pixels with r2 > thresh and
 // gain > 0, everything else is a target.  workspace: inpaint_workspace_bytes(); filled: height x stride float32.
 size_t inpaint_workspace_bytes(int height, long long stride);
+// `flag_ready` (nullable): source flags already written by the fit kernel (FitArgs::flag; 1 byte per pixel, row stride
+// `stride`) -- gain / r2 are then not read.  inpaint_flag_plane(): the workspace's own flag plane, for a fit to write into.
+unsigned char* inpaint_flag_plane(void* workspace, int height, long long stride);
 hipError_t launch_inpaint_offsets(const float* offset, const float* gain, const float* r2, float thresh, long long stride,
-                                  int height, int width, void* workspace, float* filled, hipStream_t stream);
+                                  int height, int width, void* workspace, float* filled, hipStream_t stream,
+                                  const unsigned char* flag_ready = nullptr);
 
 // Re-sampling between axis-aligned grids (hk_resample.hip).  mode = rasterio.enums.Resampling value (0, 1, 3, 5).
 hipError_t launch_resample(int mode, const float* src, long long src_stride, long long src_band_stride, int sh, int sw,

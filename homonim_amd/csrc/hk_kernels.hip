@@ -939,6 +939,8 @@ fit_apply_kernel(const FitArgs a) {
                     r2v[i] = qnan();
                 }
 
+                // source mask of the in-painting (:363): a certified wave-row passes wherever it is valid
+                [[maybe_unused]] unsigned passed = mcu;
                 // ---- stage B: R2 (kernel_model.py:179,189-195|201,203,212-213) ---------------------------------------------
                 if constexpr (R2) {
                     if (want_r2_values || count_fails) {  // wave-uniform
@@ -1020,6 +1022,7 @@ fit_apply_kernel(const FitArgs a) {
                                 }
                                 if constexpr (GO) {
                                     const bool m = (mcu >> (8 * i)) & 1u;
+                                    if (!(r2_ok[i] && (g[i] > 0.f))) passed &= ~(0xffu << (8 * i));
                                     // valid pixels failing (r2 > thresh) & (gain > 0) need in-painting (:363,:370)
                                     const bool failing = count_fails && m && !(r2_ok[i] && (g[i] > 0.f));
                                     if (failing && out_lane) ++nfail;
@@ -1065,6 +1068,9 @@ fit_apply_kernel(const FitArgs a) {
                     if (a.gain) store4_nt(at(a.gain), masked4(g));
                     if (a.offset) store4_nt(at(a.offset), masked4(o));
                     if (R2 && a.r2) store4_nt(at(a.r2), masked4(r2v));
+                    if constexpr (GO && R2 && !CERT_ONLY) {
+                        if (a.flag) *reinterpret_cast<unsigned*>(a.flag + row_off + (xbytes >> 2)) = passed;
+                    }
                 }
             };
             if constexpr (UNIFORM_N) {

@@ -246,7 +246,16 @@ typedef struct {
      * homonim/raster_array.py:478-491 as homonim/fuse.py:310-312 applies it.  All zero = the whole job.  out_col0 and
      * out_col0 + out_cols must be multiples of 4 (or end at the job's last column).  Not with r2_inpaint_thresh. */
     int32_t out_row0, out_col0, out_rows, out_cols;
+    /* Optional device scratch for gain-offset with an r2 threshold (else NULL / 0): hk_dev_job_scratch_bytes() bytes,
+     * 16-byte aligned, owned by the caller and tied to this job until its hk_inpaint_dev / hk_inpaint_dev_counts.  When the
+     * complete kernel build runs the job (r2-mask failures are expected, or the lighter build has just been sent back), it
+     * leaves the in-painting's inputs there -- offsets and the one-byte source flags (r2 > thresh) & (gain > 0) & valid
+     * (kernel_model.py:363) -- and the in-painting starts from them instead of running the fit once more. */
+    void* scratch;
+    uint64_t scratch_bytes;
 } hk_dev_job;
+/* Size of hk_dev_job.scratch for a job of this shape (5 bytes per pixel of the job's planes incl. row / band padding). */
+uint64_t hk_dev_job_scratch_bytes(int32_t n_bands, int32_t height, int64_t stride, int64_t band_stride);
 
 /* Launch the fused kernel over all bands of a device-resident job (asynchronous on stream `job->stream`).  With an r2
  * threshold the pixels failing the mask are only COUNTED (job->fail_count); follow with hk_inpaint_dev. */

@@ -824,17 +824,21 @@ def test_r2_inpainting_vs_oracle(ctx, want_params):
     exp_params, exp_fail = onp.fit_gain_offset(src, np.nan, ref, np.nan, (5, 5), False, 0.25)
     assert exp_fail > 100
     desc = _hk.make_desc('gain-offset', (5, 5), False, 0.25, np.nan, np.nan)
-    params, corr, _, n_fail = ctx.fit_apply(desc, src, ref, 3, want_params=want_params, want_corr=True)
-    assert n_fail == exp_fail
-    if want_params:
-        assert_close_ulp(params, exp_params, 'in-painted params', max_frac=1e-3)
-    assert_close_ulp(corr, onp.apply(src, exp_params), 'corrected after in-painting', max_frac=1e-3)
+    for _ in range(2):  # the second call expects failures: its first pass leaves offsets + source flags for the in-painting
+        params, corr, _, n_fail = ctx.fit_apply(desc, src, ref, 3, want_params=want_params, want_corr=True)
+        assert n_fail == exp_fail
+        if want_params:
+            assert_close_ulp(params, exp_params, 'in-painted params', max_frac=1e-3)
+        assert_close_ulp(corr, onp.apply(src, exp_params), 'corrected after in-painting', max_frac=1e-3)
 
 
-@pytest.mark.parametrize('with_params, split_api', [(False, False), (True, False), (False, True)])
-def test_device_resident_job_with_inpainting(ctx, oc, with_params, split_api):
+@pytest.mark.parametrize('with_params, split_api, scratch', [(False, False, False), (True, False, False), (False, True, False),
+                                                             (False, False, True), (True, False, True), (False, True, True)])
+def test_device_resident_job_with_inpainting(ctx, oc, with_params, split_api, scratch):
     """ hk_fit_apply_dev + hk_inpaint_dev on a 3-band job resident in HBM: only the bands whose r2 mask has failures
-    are in-painted; every band equals the oracle's whole reference branch. """
+    are in-painted; every band equals the oracle's whole reference branch.  Run twice: the second launch expects failures
+    (complete kernel build from the start).  `scratch`: the job carries hk_dev_job.scratch, so the pass that counts the
+    failures leaves offsets + source flags for the in-painting. """
     h, w, nb = 96, 300, 3
     stride = (w + 63) // 64 * 64
     band_stride = stride * h
@@ -861,41 +865,50 @@ def test_device_resident_job_with_inpainting(ctx, oc, with_params, split_api):
         job.norm = None
         job.n_bands, job.height, job.width, job.stride, job.band_stride = nb, h, w, stride, band_stride
         job.seg_rows, job.stream = 0, 0
-        ctx.fit_apply_dev(desc, job)
-        ctx.stream_sync(0)
-        counts = np.zeros(nb, np.uint64)
-        ctx.d2h(counts, d['fail'])           # per-band counts of the first pass ...
-        if split_api:                        # ... consumed and cleared by hk_fail_counts_async + hk_inpaint_dev_counts
-            host_counts = ctx.pinned_empty((nb,), np.uint64)
-            ready = ctx.event()
-            ctx.fail_counts_async(job, host_counts, ready)
-            ctx.event_sync(ready)
-            assert (host_counts == counts).all()
-            n_fail = ctx.inpaint_dev_counts(desc, job, host_counts.copy())
-            ctx.event_destroy(ready)
-        else:                                # ... or by hk_inpaint_dev in one blocking call
-            n_fail = ctx.inpaint_dev(desc, job)
-        ctx.stream_sync(0)
-        cleared = np.ones(nb, np.uint64)
-        ctx.d2h(cleared, d['fail'])
-        assert not cleared.any()
-        out = {k: np.empty((nb, h, stride), np.float32) for k in names if k not in ('src', 'ref')}
-        for k, arr in out.items():
-            ctx.d2h(arr, d[k])
-        exp_total = 0
-        for b in range(nb):
-            exp_params, exp_corr, exp_fail = oc.fit_apply('gain-offset', srcs[b], np.nan, refs[b], np.nan, (5, 5), False, 0.25)
-            exp_total += exp_fail
-            assert (exp_fail > 0) == (b == 1)
-            if int(counts[b]) >> 63:         # certificate-only build: "run this band again", done by hk_inpaint_dev*
-                assert not with_params
-            else:
-                assert int(counts[b]) == exp_fail
-            assert_close_ulp(out['corr'][b, :, :w], exp_corr, f'band {b} corrected', max_frac=1e-3)
-            if with_params:
-                got = np.stack([out['gain'][b, :, :w], out['offset'][b, :, :w], out['r2'][b, :, :w]])
-                assert_close_ulp(got, exp_params, f'band {b} params', max_frac=1e-3)
-        assert n_fail == exp_total
+        if scratch:
+            job.scratch_bytes = ctx.job_scratch_bytes(job)
+            assert job.scratch_bytes == 5 * ((nb - 1) * band_stride + stride * h)
+            d['scratch'] = ctx.dev_alloc(job.scratch_bytes)
+            job.scratch = d['scratch']
+        for round_i in range(2):
+            for k in names:
+                if k not in ('src', 'ref'):
+                    ctx.memset(d[k], 0, nbytes)
+            ctx.fit_apply_dev(desc, job)
+            ctx.stream_sync(0)
+            counts = np.zeros(nb, np.uint64)
+            ctx.d2h(counts, d['fail'])           # per-band counts of the first pass ...
+            if split_api:                        # ... consumed and cleared by hk_fail_counts_async + hk_inpaint_dev_counts
+                host_counts = ctx.pinned_empty((nb,), np.uint64)
+                ready = ctx.event()
+                ctx.fail_counts_async(job, host_counts, ready)
+                ctx.event_sync(ready)
+                assert (host_counts == counts).all()
+                n_fail = ctx.inpaint_dev_counts(desc, job, host_counts.copy())
+                ctx.event_destroy(ready)
+            else:                                # ... or by hk_inpaint_dev in one blocking call
+                n_fail = ctx.inpaint_dev(desc, job)
+            ctx.stream_sync(0)
+            cleared = np.ones(nb, np.uint64)
+            ctx.d2h(cleared, d['fail'])
+            assert not cleared.any()
+            out = {k: np.empty((nb, h, stride), np.float32) for k in names if k not in ('src', 'ref')}
+            for k, arr in out.items():
+                ctx.d2h(arr, d[k])
+            exp_total = 0
+            for b in range(nb):
+                exp_params, exp_corr, exp_fail = oc.fit_apply('gain-offset', srcs[b], np.nan, refs[b], np.nan, (5, 5), False, 0.25)
+                exp_total += exp_fail
+                assert (exp_fail > 0) == (b == 1)
+                if int(counts[b]) >> 63:         # certificate-only build: "run this band again", done by hk_inpaint_dev*
+                    assert not with_params
+                else:
+                    assert int(counts[b]) == exp_fail
+                assert_close_ulp(out['corr'][b, :, :w], exp_corr, f'band {b} corrected', max_frac=1e-3)
+                if with_params:
+                    got = np.stack([out['gain'][b, :, :w], out['offset'][b, :, :w], out['r2'][b, :, :w]])
+                    assert_close_ulp(got, exp_params, f'band {b} params', max_frac=1e-3)
+            assert n_fail == exp_total
     finally:
         for v in d.values():
             ctx.dev_free(v)
