@@ -69,6 +69,8 @@ _f32p, _f64p, _u64p = _P(C.c_float), _P(C.c_double), _P(C.c_uint64)
 SIGNATURES = {
     'hk_backend_name': (C.c_char_p, []),
     'hk_dev_job_scratch_bytes': (C.c_uint64, [C.c_int32, C.c_int32, C.c_int64, C.c_int64]),
+    'hk_block_norm_split_exchange_doubles': (C.c_uint64, [C.c_int32]),
+    'hk_block_norm_split_dev': (C.c_int, [C.c_void_p, _P(FitDesc), _P(DevJob), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     'hk_last_error': (C.c_char_p, []),
     'hk_device_count': (C.c_int, [_P(C.c_int)]),
     'hk_ctx_create': (C.c_int, [C.c_int, C.c_int, _P(C.c_void_p)]),
@@ -469,6 +471,14 @@ class Context:
 
     def memset(self, dptr: int, value: int, nbytes: int):
         _check(self._lib.hk_memset(self._h, C.c_void_p(dptr), value, nbytes))
+
+    def block_norm_split_phase(self, desc: FitDesc, job: DevJob, phase: int, world_size: int, xchg_dev: int, norm_dev: int):
+        """ Queue phase 0..5 of the split-block statistics on this rank's slab (see homonim_amd/split_norm.py). """
+        _check(self._lib.hk_block_norm_split_dev(self._h, C.byref(desc), C.byref(job), phase, world_size,
+                                                 C.c_void_p(xchg_dev), C.c_void_p(norm_dev)))
+
+    def split_exchange_doubles(self, n_bands: int) -> int:
+        return int(self._lib.hk_block_norm_split_exchange_doubles(n_bands))
 
     def job_scratch_bytes(self, job: DevJob) -> int:
         """ Size of the optional DevJob.scratch (gain-offset with an r2 threshold: the in-painting's inputs). """

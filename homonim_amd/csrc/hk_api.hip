@@ -1301,6 +1301,33 @@ int hk_block_norm_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* jo
     return HK_OK;
 }
 
+uint64_t hk_block_norm_split_exchange_doubles(int32_t n_bands) {
+    return n_bands > 0 ? (uint64_t)hk::norm_split_exchange_doubles(n_bands) : 0;
+}
+
+int hk_block_norm_split_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* job, int32_t phase, int32_t world_size,
+                            double* xchg_dev, double* norm_dev) {
+    int rc = validate_desc(desc);
+    if (rc) return rc;
+    rc = check_job(ctx, job);
+    if (rc) return rc;
+    if (!xchg_dev || !norm_dev) return fail(HK_ERR_ARG, "xchg_dev / norm_dev is NULL");
+    if (phase < 0 || phase > 5) return fail(HK_ERR_ARG, "phase %d outside 0..5", phase);
+    if (world_size < 1) return fail(HK_ERR_ARG, "world_size < 1");
+    HK_HIP(hipSetDevice(ctx->device));
+    Slot& sl = ctx->slots[job->stream];
+    // the phases of one block share the stream's workspace: phase 0 sizes it, the others find it as it was left
+    rc = ensure_stream_ws(ctx, sl, hk::norm_workspace_bytes(job->n_bands, job->height, job->width));
+    if (rc) return rc;
+    hk::NormArgs na;
+    na.src = job->src, na.ref = job->ref, na.height = job->height, na.width = job->width, na.stride = job->stride;
+    na.band_stride = job->band_stride, na.n_bands = job->n_bands;
+    na.src_nd_mode = desc->src_nodata_mode, na.ref_nd_mode = desc->ref_nodata_mode;
+    na.src_nodata = desc->src_nodata, na.ref_nodata = desc->ref_nodata;
+    HK_HIP(hk::launch_block_norm_split(na, sl.norm_ws, xchg_dev, 1.0 / (double)world_size, phase, norm_dev, sl.stream));
+    return HK_OK;
+}
+
 int hk_synth_fill_dev(hk_ctx* ctx, float* src, float* ref, int32_t n_bands, int32_t height, int32_t width,
                       int64_t stride, int64_t band_stride, uint64_t seed, int32_t nodata_variant, int32_t stream) {
     if (!ctx || !src || !ref) return fail(HK_ERR_ARG, "NULL argument");

@@ -80,6 +80,11 @@ struct NormArgs {
 // workspace: see norm_workspace_bytes(); norm_out: n_bands x 2 float64 on device.
 size_t norm_workspace_bytes(int n_bands, int height, int width);
 hipError_t launch_block_norm(const NormArgs& a, void* workspace, double* norm_out, hipStream_t stream);
+// The same statistics for a block whose rows are spread over several ranks: six phases on this rank's slab, the caller
+// all-reduces (SUM) the float64 exchange buffer (norm_split_exchange_doubles() values, device) between them.
+size_t norm_split_exchange_doubles(int n_bands);
+hipError_t launch_block_norm_split(const NormArgs& a, void* workspace, double* xchg, double inv_world, int phase,
+                                   double* norm_out, hipStream_t stream);
 
 // Masked comparison sums of homonim/compare.py:243-255 (hk_compare.hip), per band:
 // sums_out[band * 7 + k] = [sum s, sum r, sum s^2, sum r^2, sum s*r, sum (r - s)^2, count] over jointly valid pixels.

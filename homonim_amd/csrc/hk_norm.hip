@@ -523,6 +523,141 @@ __global__ void __launch_bounds__(NORM_THREADS) norm_select_kernel(NormWS* __res
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Split blocks: one block's pixels spread over several ranks (each holds some rows), one result.  Every statistic above
+// is a sum over pixels -- the shifted moments and the integer histograms of the radix select -- so the ranks run the same
+// kernels on their slabs and all-reduce (SUM) a small float64 exchange buffer between the phases:
+//   phase 0  sample -> the slab's shift                     | exchange: 2 values per band (the ranks' mean becomes the shift)
+//   phase 1  moments of the slab about the common shift     | 5 values per band (n, m1, m2 of src and ref)
+//   phase 2  global n, mean, var, ranks; level-1 histogram  | 4 x 2048 counts per band (exact in float64)
+//   phase 3  level-1 digit; level-2 histogram               | 4 x 2048
+//   phase 4  level-2 digit; level-3 histogram               | 4 x 1024
+//   phase 5  level-3 digit -> norm (identical on every rank)
+// The select runs over the full slabs (the path the single-GPU code keeps as its fallback): no pivots to agree on.
+constexpr int SPLIT_XCHG = 4 * L1_BINS;  // float64 values per band in the exchange buffer
+
+size_t norm_split_exchange_doubles(int n_bands) { return (size_t)n_bands * SPLIT_XCHG; }
+
+__global__ void split_put_shift_kernel(NormWS* __restrict__ ws_all, double* __restrict__ xchg) {
+    NormWS& ws = ws_all[blockIdx.x];
+    double* x = xchg + (size_t)blockIdx.x * SPLIT_XCHG;
+    for (int i = threadIdx.x; i < SPLIT_XCHG; i += blockDim.x) x[i] = i < 2 ? ws.shift[i] : 0.0;
+}
+__global__ void split_get_shift_kernel(NormWS* __restrict__ ws_all, const double* __restrict__ xchg, double scale) {
+    if (threadIdx.x != 0) return;
+    NormWS& ws = ws_all[blockIdx.x];
+    const double* x = xchg + (size_t)blockIdx.x * SPLIT_XCHG;
+    for (int q = 0; q < 2; ++q) {
+        ws.shift[q] = x[q] * scale;
+        ws.lo[q] = ws.hi[q] = __int_as_float(0xff800000);  // nothing lies between the pivots: the pass takes the moments only
+    }
+}
+__global__ void split_put_moments_kernel(NormWS* __restrict__ ws_all, double* __restrict__ xchg) {
+    NormWS& ws = ws_all[blockIdx.x];
+    unsigned long long n = 0;
+    double m1[2] = {0.0, 0.0}, m2[2] = {0.0, 0.0};
+    for (int i = threadIdx.x; i < PASS_WAVES; i += WAVE) {  // same order as norm_stats_kernel
+        n += ws.pn[i];
+        for (int q = 0; q < 2; ++q) m1[q] += ws.p1[q][i], m2[q] += ws.p2[q][i];
+    }
+    n = wave_sum(n);
+    for (int q = 0; q < 2; ++q) m1[q] = wave_sum(m1[q]), m2[q] = wave_sum(m2[q]);
+    if (threadIdx.x != 0) return;
+    double* x = xchg + (size_t)blockIdx.x * SPLIT_XCHG;
+    x[0] = (double)n, x[1] = m1[0], x[2] = m2[0], x[3] = m1[1], x[4] = m2[1];
+}
+__global__ void split_get_moments_kernel(NormWS* __restrict__ ws_all, const double* __restrict__ xchg,
+                                         double* __restrict__ norm_out) {
+    if (threadIdx.x != 0) return;
+    NormWS& ws = ws_all[blockIdx.x];
+    const double* x = xchg + (size_t)blockIdx.x * SPLIT_XCHG;
+    const unsigned long long n = (unsigned long long)x[0];
+    ws.n = n;
+    ws.mid_count[0] = ws.mid_count[1] = 0;
+    if (n == 0) {  // kernel_model.py:223-226
+        norm_out[2 * blockIdx.x] = 0.0, norm_out[2 * blockIdx.x + 1] = 0.0;
+        ws.done = 1;
+        return;
+    }
+    for (int q = 0; q < 2; ++q) {
+        const double d = x[1 + 2 * q] / (double)n;
+        ws.mean[q] = ws.shift[q] + d;
+        const double v = x[2 + 2 * q] / (double)n - d * d;
+        ws.var[q] = v > 0.0 ? v : 0.0;
+    }
+    const double vi = 0.01 * (double)(n - 1);
+    const unsigned long long k0 = (unsigned long long)floor(vi);
+    ws.frac = vi - (double)k0;
+    ws.k[0] = k0, ws.k[1] = k0 + 1 < n ? k0 + 1 : n - 1;
+    for (int q = 0; q < 2; ++q)
+        for (int k = 0; k < 2; ++k) ws.sel[q][k].rank = ws.k[k], ws.sel[q][k].prefix = 0;
+    ws.fallback = 1;  // the select runs over the full slabs
+}
+template <int LEVEL>
+__global__ void split_hist_kernel(NormWS* __restrict__ ws_all, double* __restrict__ xchg, int put) {
+    constexpr int NB = LEVEL == 0 ? L1_BINS : (LEVEL == 1 ? L2_BINS : L3_BINS);
+    NormWS& ws = ws_all[blockIdx.x];
+    unsigned* h = LEVEL == 0 ? &ws.hist1[0][0][0] : (LEVEL == 1 ? &ws.hist2[0][0][0] : &ws.hist3[0][0][0]);
+    double* x = xchg + (size_t)blockIdx.x * SPLIT_XCHG;
+    for (int i = threadIdx.x; i < SPLIT_XCHG; i += blockDim.x) {
+        if (put) x[i] = i < 4 * NB ? (double)h[i] : 0.0;
+        else if (i < 4 * NB) h[i] = (unsigned)x[i];
+    }
+}
+
+// One phase of the split-block statistics on this rank's slab (`a`); the caller all-reduces `xchg` between the phases.
+// `inv_world` = 1 / number of ranks (phase 1 turns the sum of the slabs' shifts into their mean).
+hipError_t launch_block_norm_split(const NormArgs& a, void* workspace, double* xchg, double inv_world, int phase,
+                                   double* norm_out, hipStream_t stream) {
+    NormWS* ws = reinterpret_cast<NormWS*>(workspace);
+    const dim3 bands(a.n_bands), block(NORM_THREADS), gfull(FB_BLOCKS, a.n_bands);
+    switch (phase) {
+    case 0: {
+        hipError_t e = hipMemsetAsync(ws, 0, sizeof(NormWS) * (size_t)a.n_bands, stream);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(norm_sample_kernel, bands, dim3(1024), 0, stream, a, ws);
+        hipLaunchKernelGGL(split_put_shift_kernel, bands, block, 0, stream, ws, xchg);
+        break;
+    }
+    case 1: {
+        hipLaunchKernelGGL(split_get_shift_kernel, bands, dim3(WAVE), 0, stream, ws, xchg, inv_world);
+        const dim3 gstream(pass_waves(a.height, a.width), a.n_bands);
+        float* mid = reinterpret_cast<float*>(static_cast<char*>(workspace) + align256(sizeof(NormWS) * (size_t)a.n_bands));
+        const size_t cap_al = align256(mid_capacity((long long)a.height * a.width) * sizeof(float)) / sizeof(float);
+        if (a.src_nd_mode == 0 && a.ref_nd_mode == 0)
+            hipLaunchKernelGGL(norm_stream_kernel<true>, gstream, dim3(WAVE), 0, stream, a, ws, mid, cap_al);
+        else
+            hipLaunchKernelGGL(norm_stream_kernel<false>, gstream, dim3(WAVE), 0, stream, a, ws, mid, cap_al);
+        hipLaunchKernelGGL(split_put_moments_kernel, bands, dim3(WAVE), 0, stream, ws, xchg);
+        break;
+    }
+    case 2:
+        hipLaunchKernelGGL(split_get_moments_kernel, bands, dim3(WAVE), 0, stream, ws, xchg, norm_out);
+        hipLaunchKernelGGL(norm_full_hist_kernel<0>, gfull, block, 0, stream, a, ws);
+        hipLaunchKernelGGL(split_hist_kernel<0>, bands, block, 0, stream, ws, xchg, 1);
+        break;
+    case 3:
+        hipLaunchKernelGGL(split_hist_kernel<0>, bands, block, 0, stream, ws, xchg, 0);
+        hipLaunchKernelGGL(norm_select_kernel<0>, bands, block, 0, stream, ws, norm_out);
+        hipLaunchKernelGGL(norm_full_hist_kernel<1>, gfull, block, 0, stream, a, ws);
+        hipLaunchKernelGGL(split_hist_kernel<1>, bands, block, 0, stream, ws, xchg, 1);
+        break;
+    case 4:
+        hipLaunchKernelGGL(split_hist_kernel<1>, bands, block, 0, stream, ws, xchg, 0);
+        hipLaunchKernelGGL(norm_select_kernel<1>, bands, block, 0, stream, ws, norm_out);
+        hipLaunchKernelGGL(norm_full_hist_kernel<2>, gfull, block, 0, stream, a, ws);
+        hipLaunchKernelGGL(split_hist_kernel<2>, bands, block, 0, stream, ws, xchg, 1);
+        break;
+    case 5:
+        hipLaunchKernelGGL(split_hist_kernel<2>, bands, block, 0, stream, ws, xchg, 0);
+        hipLaunchKernelGGL(norm_select_kernel<2>, bands, block, 0, stream, ws, norm_out);
+        break;
+    default:
+        return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_block_norm(const NormArgs& a, void* workspace, double* norm_out, hipStream_t stream) {
     NormWS* ws = reinterpret_cast<NormWS*>(workspace);
     const size_t cap = mid_capacity((long long)a.height * a.width);

@@ -1,0 +1,113 @@
+"""
+Block statistics of a gain-blk-offset block whose ROWS are spread over several ranks / devices -- the one optional
+collective of the hot path (reference: KernelModel._fit_block_norm, homonim/kernel_model.py:216-229).
+
+    norm[0] = std(ref[mask]) / std(src[mask]);  norm[1] = percentile(ref[mask], 1) - percentile(src[mask], 1) * norm[0]
+
+Every ingredient is a sum over pixels: the shifted float64 moments, and the integer histograms of the exact three-level
+radix select that finds the two order statistics behind the percentile.  So each rank runs the library's kernels on its
+slab (``hk_block_norm_split_dev``, phases 0..5) and the ranks all-reduce (SUM) a small float64 exchange buffer between the
+phases: 2 + 5 + 3 x (<= 8192) values per band, five all-reduces per block.  With ``torch.distributed`` on the ``nccl``
+backend that is RCCL over xGMI, on a tensor that owns the exchange buffer; nothing else of torch touches the data path.
+
+The order statistics are exactly those of the whole block; the std ratio equals the single-device value up to the order of
+the float64 sums (the slabs' partial sums are added rank by rank).
+"""
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from homonim_amd import _hk
+
+N_PHASES = 6
+
+
+class TorchReducer:
+    """ All-reduce (SUM) over a torch.distributed process group of a float64 device buffer owned by a torch tensor.
+    backend nccl (= RCCL on ROCm): in place on the device; gloo (ranks sharing one GPU in tests): through the host. """
+
+    def __init__(self, n_doubles: int, device_index: int, group=None):
+        import torch
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            raise RuntimeError('TorchReducer needs an initialised torch.distributed process group (homonim_amd.dist.init)')
+        self._torch, self._dist, self._group = torch, dist, group
+        self.world_size = dist.get_world_size(group)
+        self.backend = dist.get_backend(group)
+        self.buf = torch.zeros(n_doubles, dtype=torch.float64, device=torch.device('cuda', device_index))
+        torch.cuda.synchronize(device_index)
+        self.ptr = int(self.buf.data_ptr())
+        self._device_index = device_index
+
+    def __call__(self):
+        if self.backend == 'nccl':
+            self._dist.all_reduce(self.buf, op=self._dist.ReduceOp.SUM, group=self._group)
+        else:
+            host = self.buf.cpu()
+            self._dist.all_reduce(host, op=self._dist.ReduceOp.SUM, group=self._group)
+            self.buf.copy_(host)
+        self._torch.cuda.synchronize(self._device_index)  # the library's stream reads the buffer next
+
+
+def block_norm_split(ctx: '_hk.Context', desc: '_hk.FitDesc', job: '_hk.DevJob', reducer: TorchReducer,
+                     norm_dev: Optional[int] = None) -> np.ndarray:
+    """
+    Block statistics over all ranks of ``reducer``'s group; ``job`` describes THIS rank's slab of the block (device planes,
+    any number of rows, the block's width; ``n_bands`` equal on every rank).  Collective: every rank calls it with its slab.
+    Returns norm (n_bands, 2) float64, identical on every rank; ``norm_dev`` (optional device pointer, n_bands x 2 float64)
+    receives it too, ready to be ``job.norm`` of the rank's ``fit_apply_dev``.
+    """
+    nb = int(job.n_bands)
+    if reducer.buf.numel() < ctx.split_exchange_doubles(nb):
+        raise ValueError('exchange buffer smaller than hk_block_norm_split_exchange_doubles(n_bands)')
+    own = norm_dev is None
+    if own:
+        norm_dev = ctx.dev_alloc(16 * nb)
+    try:
+        for phase in range(N_PHASES):
+            ctx.block_norm_split_phase(desc, job, phase, reducer.world_size, reducer.ptr, norm_dev)
+            ctx.stream_sync(job.stream)
+            if phase < N_PHASES - 1:
+                reducer()
+        out = np.zeros((nb, 2), np.float64)
+        ctx.d2h(out, norm_dev)
+        return out
+    finally:
+        if own:
+            ctx.dev_free(norm_dev)
+
+
+def block_norm_split_local(parts: Sequence[Tuple['_hk.Context', '_hk.DevJob']], desc: '_hk.FitDesc') -> List[np.ndarray]:
+    """
+    The same protocol inside ONE process: ``parts`` = (context, slab job) per device (fuse.create_device_config(devices=[...])
+    fan-out), the exchange buffers are summed on the host.  Returns every part's norm (they are identical).
+    """
+    world = len(parts)
+    nb = int(parts[0][1].n_bands)
+    n = parts[0][0].split_exchange_doubles(nb)
+    bufs = [c.dev_alloc(8 * n) for c, _ in parts]
+    norms = [c.dev_alloc(16 * nb) for c, _ in parts]
+    try:
+        for phase in range(N_PHASES):
+            for (c, job), b, nd in zip(parts, bufs, norms):
+                c.block_norm_split_phase(desc, job, phase, world, b, nd)
+            host = []
+            for (c, job), b in zip(parts, bufs):
+                c.stream_sync(job.stream)
+                h = np.zeros(n, np.float64)
+                if phase < N_PHASES - 1:
+                    c.d2h(h, b)
+                host.append(h)
+            if phase < N_PHASES - 1:
+                total = np.sum(host, axis=0)  # rank order, like a ring all-reduce
+                for (c, _), b in zip(parts, bufs):
+                    c.h2d(b, total)
+        out = []
+        for (c, _), nd in zip(parts, norms):
+            o = np.zeros((nb, 2), np.float64)
+            c.d2h(o, nd)
+            out.append(o)
+        return out
+    finally:
+        for (c, _), b, nd in zip(parts, bufs, norms):
+            c.dev_free(b), c.dev_free(nd)

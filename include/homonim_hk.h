@@ -281,6 +281,18 @@ int hk_inpaint_dev_counts(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job
                           uint64_t* n_fail_out);
 /* Per-band block normalisation on device planes -> norm (device, n_bands x 2 float64); asynchronous. */
 int hk_block_norm_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* job, double* norm_dev);
+/* The same statistics (KernelModel._fit_block_norm, homonim/kernel_model.py:216-229) for a block whose ROWS are spread over
+ * `world_size` ranks / devices -- the optional collective of a gain-blk-offset block too large for one GPU.  `job` is this
+ * rank's slab of the block (any number of rows, the block's width).  Phases 0..5 are queued one at a time on job->stream;
+ * between two phases the caller waits for the stream and all-reduces (SUM, float64) the exchange buffer `xchg_dev` over the
+ * ranks (RCCL: torch.distributed.all_reduce on a tensor that owns the buffer; homonim_amd/split_norm.py), all ranks in step.
+ * The buffer holds hk_block_norm_split_exchange_doubles(n_bands) values: the slabs' shifts, then their moments, then the
+ * three histogram levels of the exact radix select (integer counts, exact in float64).  After phase 5 `norm_dev`
+ * (n_bands x 2 float64, device) holds the block's norm, identical on every rank: order statistics exactly those of the whole
+ * block, std ratio equal to the single-device value up to the order of the float64 sums. */
+uint64_t hk_block_norm_split_exchange_doubles(int32_t n_bands);
+int hk_block_norm_split_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* job, int32_t phase, int32_t world_size,
+                            double* xchg_dev, double* norm_dev);
 /* The masked sums of RasterCompare.process / get_block_sums (homonim/compare.py:243-255) on the job's src and ref planes
  * (job->corr etc. are not used), per band into sums_dev (device, n_bands x 7 float64; asynchronous):
  *   [ sum src, sum ref, sum src^2, sum ref^2, sum src*ref, sum (ref - src)^2, number of pixels ]
