@@ -54,6 +54,10 @@ struct NormWS {  // one per band
     int fallback, done;
     // radix select state (shared by the compacted-buffer select and the fallback)
     Sel sel[2][2];  // [src|ref][rank k0|k1]
+    // the select's keys: (f2key(v) - kbase) << ksh.  Over the compacted buffers the window [lo, hi] is stretched over all 32
+    // bits, so the first digit spreads over the whole histogram instead of one hot bin; 0 / 0 = plain keys (full rasters)
+    unsigned kbase[2];
+    int ksh[2];
     float val[2][2];
     unsigned hist1[2][2][L1_BINS], hist2[2][2][L2_BINS], hist3[2][2][L3_BINS];
 };
@@ -78,12 +82,65 @@ __device__ __forceinline__ bool nvalid(float v, int mode, float nodata) {
     return mode == 0 ? true : (mode == 1 ? !(v != v) : !(v == nodata));
 }
 
+__device__ __forceinline__ double wave_sum(double v) {  // fixed butterfly order -> deterministic
+#pragma unroll
+    for (int d = WAVE / 2; d > 0; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
+#pragma unroll
+    for (int d = WAVE / 2; d > 0; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+
+// Find the bin holding rank `rank` in hist[0..NBINS) -- the first bin whose running count exceeds it (the last bin if
+// none does) -- and the rank inside that bin.  One wave: each lane loads a contiguous chunk into registers (independent
+// loads) and sums it, an inclusive scan over the lanes finds the chunk, its lane walks its registers.  The lane that found
+// it returns true.
+template <int NBINS>
+__device__ __forceinline__ bool select_bin(const unsigned* __restrict__ h, unsigned long long rank, unsigned* bin_out,
+                                           unsigned long long* rank_out) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    constexpr int PER = NBINS / WAVE;
+    unsigned v[PER];
+    unsigned long long local = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) v[i] = h[lane * PER + i];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) local += v[i];
+    unsigned long long incl = local;
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        const unsigned long long u = __shfl_up(incl, d, WAVE);
+        if (lane >= d) incl += u;
+    }
+    const unsigned long long hit = __ballot(incl > rank);
+    const int owner = hit ? __ffsll(hit) - 1 : WAVE - 1;
+    if (lane != owner) return false;
+    unsigned long long cum = incl - local;
+    int b = 0;
+    bool found = false;
+#pragma unroll
+    for (int i = 0; i < PER - 1; ++i) {
+        if (!found) {
+            if (cum + v[i] > rank) found = true;
+            else cum += v[i], b = i + 1;
+        }
+    }
+    *bin_out = (unsigned)(lane * PER + b);
+    *rank_out = rank - cum;
+    return true;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // 1. sample
 __global__ void __launch_bounds__(1024) norm_sample_kernel(const NormArgs a, NormWS* __restrict__ ws_all) {
+    static_assert(L1_BINS == L2_BINS && L3_BINS <= L1_BINS, "the sample select shares one histogram shape");
     __shared__ float samp[2][SAMPLE_N];
-    __shared__ unsigned cnt;
-    __shared__ double red[1024];
+    __shared__ unsigned hist[4][L1_BINS];  // one per (raster, rank)
+    __shared__ unsigned cnt, spfx[4], srank[4];
+    __shared__ int need[4];
+    __shared__ double red[2][1024 / WAVE];
     const int band = blockIdx.x, t = threadIdx.x;
     NormWS& ws = ws_all[band];
     const float* __restrict__ sp = a.src + (long long)band * a.band_stride;
@@ -115,64 +172,72 @@ __global__ void __launch_bounds__(1024) norm_sample_kernel(const NormArgs a, Nor
     }
     __syncthreads();
     const unsigned m = cnt;
-    // bitonic sort of both sample arrays (ascending; +inf padding sinks to the end)
-    for (int k = 2; k <= SAMPLE_N; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = t; i < SAMPLE_N; i += 1024) {
-                const int l = i ^ j;
-                if (l > i) {
-                    const bool up = (i & k) == 0;
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const float x0 = samp[q][i], x1 = samp[q][l];
-                        if ((x0 > x1) == up) {
-                            samp[q][i] = x1;
-                            samp[q][l] = x0;
-                        }
-                    }
-                }
-            }
-            __syncthreads();
+    // shift of the moment sums = sample mean (any value works; a close one kills the cancellation): butterfly per wave,
+    // thread 0 adds the 16 wave sums in order
+    {
+        const double ws_s = wave_sum(sum_s), ws_r = wave_sum(sum_r);
+        if ((t & (WAVE - 1)) == 0) red[0][t / WAVE] = ws_s, red[1][t / WAVE] = ws_r;
+    }
+    // sample ranks bracketing the 1st percentile by +-4 sigma of the binomial sample quantile (+ margin); the two order
+    // statistics of each raster's sample are found by a 3-level radix select in LDS (four selects side by side, one
+    // histogram each) -- the values a sort would put at those ranks, at a tenth of the bitonic sort's time
+    if (t == 0) {
+        const double c = 0.01 * (double)m, sd = sqrt(c > 0.0 ? c : 0.0);
+        const long long ia = (long long)floor(c - 4.0 * sd) - 2, ib = (long long)ceil(c + 4.0 * sd) + 3;
+        for (int q = 0; q < 2; ++q) {
+            need[2 * q] = !(m == 0 || ia <= 0), need[2 * q + 1] = !(m == 0 || ib >= (long long)m - 1);
+            srank[2 * q] = need[2 * q] ? (unsigned)ia : 0u, srank[2 * q + 1] = need[2 * q + 1] ? (unsigned)ib : 0u;
+            spfx[2 * q] = spfx[2 * q + 1] = 0u;
         }
     }
-    // shift of the moment sums = sample mean (any value works; a close one kills the cancellation)
-    for (int q = 0; q < 2; ++q) {
-        red[t] = q == 0 ? sum_s : sum_r;
+    __syncthreads();
+    for (int level = 0; level < 3; ++level) {
+        for (int i = t; i < 4 * L1_BINS; i += 1024) (&hist[0][0])[i] = 0;
         __syncthreads();
-        for (int d = 512; d > 0; d >>= 1) {
-            if (t < d) red[t] += red[t + d];
-            __syncthreads();
+        for (int i = t; i < SAMPLE_N; i += 1024) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const unsigned key = f2key(samp[q][i]);
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int sidx = 2 * q + k;
+                    if (level == 0) atomicAdd(&hist[sidx][key >> (32 - L1_BITS)], 1u);
+                    else if (level == 1) {
+                        if ((key >> (32 - L1_BITS)) == spfx[sidx]) atomicAdd(&hist[sidx][(key >> L3_BITS) & (L2_BINS - 1)], 1u);
+                    } else if ((key >> L3_BITS) == spfx[sidx]) atomicAdd(&hist[sidx][key & (L3_BINS - 1)], 1u);
+                }
+            }
         }
-        if (t == 0) {
-            const double mean = m ? red[0] / (double)m : 0.0;
-            ws.shift[q] = (mean == mean && fabs(mean) < 1e300) ? mean : 0.0;
+        __syncthreads();
+        if (t < 4 * WAVE) {  // one wave per select
+            const int sidx = t / WAVE;
+            unsigned bin;
+            unsigned long long rk;
+            bool mine;
+            if (level == 2) mine = select_bin<L3_BINS>(hist[sidx], srank[sidx], &bin, &rk);
+            else mine = select_bin<L1_BINS>(hist[sidx], srank[sidx], &bin, &rk);
+            if (mine) {
+                const int bits = level == 0 ? 0 : (level == 1 ? L2_BITS : L3_BITS);
+                spfx[sidx] = level == 0 ? bin : ((spfx[sidx] << bits) | bin);
+                srank[sidx] = (unsigned)rk;
+            }
         }
         __syncthreads();
     }
     if (t == 0) {
-        // sample ranks bracketing the 1st percentile by +-4 sigma of the binomial sample quantile (+ margin)
-        const double c = 0.01 * (double)m, sd = sqrt(c > 0.0 ? c : 0.0);
-        const long long ia = (long long)floor(c - 4.0 * sd) - 2, ib = (long long)ceil(c + 4.0 * sd) + 3;
         for (int q = 0; q < 2; ++q) {
-            ws.lo[q] = (m == 0 || ia <= 0) ? __int_as_float(0xff800000) : samp[q][ia];
-            ws.hi[q] = (m == 0 || ib >= (long long)m - 1) ? __int_as_float(0x7f800000) : samp[q][ib];
+            double sum = 0.0;
+            for (int i = 0; i < 1024 / WAVE; ++i) sum += red[q][i];
+            const double mean = m ? sum / (double)m : 0.0;
+            ws.shift[q] = (mean == mean && fabs(mean) < 1e300) ? mean : 0.0;
+            ws.lo[q] = need[2 * q] ? key2f(spfx[2 * q]) : __int_as_float(0xff800000);
+            ws.hi[q] = need[2 * q + 1] ? key2f(spfx[2 * q + 1]) : __int_as_float(0x7f800000);
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // 2. streaming pass: one wave per workgroup, wave-private LDS staging of the compacted values
-__device__ __forceinline__ double wave_sum(double v) {  // fixed butterfly order -> deterministic
-#pragma unroll
-    for (int d = WAVE / 2; d > 0; d >>= 1) v += __shfl_xor(v, d);
-    return v;
-}
-__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
-#pragma unroll
-    for (int d = WAVE / 2; d > 0; d >>= 1) v += __shfl_xor(v, d);
-    return v;
-}
-
 // Waves per band of the streaming pass: a function of the block SHAPE only (never of the batch size), so a block's
 // statistics are the same bits whichever launch it travels in; >= 16 chunks of 1 KB per raster per wave.
 static int pass_waves(int height, int width) {
@@ -321,19 +386,39 @@ __global__ void __launch_bounds__(WAVE) norm_stream_kernel(const NormArgs a, Nor
 }
 
 // statistics + ranks + decision whether the compacted buffers bracket both ranks
-__global__ void norm_stats_kernel(NormWS* __restrict__ ws_all, double* __restrict__ norm_out, size_t mid_cap) {
+constexpr int STATS_THREADS = 256;
+__global__ void __launch_bounds__(STATS_THREADS) norm_stats_kernel(NormWS* __restrict__ ws_all, double* __restrict__ norm_out,
+                                                                    size_t mid_cap) {
+    static_assert(PASS_WAVES % STATS_THREADS == 0, "every thread sums the same number of partials");
+    __shared__ unsigned long long sn[STATS_THREADS / WAVE], sb[2][STATS_THREADS / WAVE];
+    __shared__ double s1[2][STATS_THREADS / WAVE], s2[2][STATS_THREADS / WAVE];
     NormWS& ws = ws_all[blockIdx.x];
-    // one wave: every lane sums its stride-64 subset of the per-wave partials in index order, then a fixed butterfly --
-    // deterministic, and 64x shorter than one thread walking all PASS_WAVES entries
+    // every thread sums its stride-256 subset of the per-wave partials in index order (independent loads, issued together),
+    // a fixed butterfly inside each wave, then thread 0 adds the four wave sums in order: deterministic
     unsigned long long n = 0, below[2] = {0, 0};
     double m1[2] = {0.0, 0.0}, m2[2] = {0.0, 0.0};
-    for (int i = threadIdx.x; i < PASS_WAVES; i += WAVE) {
+#pragma unroll
+    for (int j = 0; j < PASS_WAVES / STATS_THREADS; ++j) {
+        const int i = threadIdx.x + j * STATS_THREADS;
         n += ws.pn[i];
+#pragma unroll
         for (int q = 0; q < 2; ++q) m1[q] += ws.p1[q][i], m2[q] += ws.p2[q][i], below[q] += ws.pbelow[q][i];
     }
     n = wave_sum(n);
     for (int q = 0; q < 2; ++q) m1[q] = wave_sum(m1[q]), m2[q] = wave_sum(m2[q]), below[q] = wave_sum(below[q]);
+    const int w = threadIdx.x / WAVE;
+    if ((threadIdx.x & (WAVE - 1)) == 0) {
+        sn[w] = n;
+        for (int q = 0; q < 2; ++q) s1[q][w] = m1[q], s2[q][w] = m2[q], sb[q][w] = below[q];
+    }
+    __syncthreads();
     if (threadIdx.x != 0) return;
+    n = 0;
+    for (int q = 0; q < 2; ++q) m1[q] = m2[q] = 0.0, below[q] = 0;
+    for (int i = 0; i < STATS_THREADS / WAVE; ++i) {
+        n += sn[i];
+        for (int q = 0; q < 2; ++q) m1[q] += s1[q][i], m2[q] += s2[q][i], below[q] += sb[q][i];
+    }
     ws.n = n;
     if (n == 0) {  // kernel_model.py:223-226
         norm_out[2 * blockIdx.x] = 0.0;
@@ -359,20 +444,30 @@ __global__ void norm_stats_kernel(NormWS* __restrict__ ws_all, double* __restric
         ws.sel[q][0].rank = ws.k[0] - below[q];
         ws.sel[q][1].rank = ws.k[1] - below[q];
         ws.sel[q][0].prefix = ws.sel[q][1].prefix = 0;
+        // every compacted value has its key in [f2key(lo), f2key(hi)]: stretch that window over the 32 key bits
+        const unsigned kb = f2key(ws.lo[q]), range = f2key(ws.hi[q]) - kb;
+        ws.kbase[q] = kb;
+        ws.ksh[q] = range ? __clz((int)range) : 0;
     }
     if (fb)
-        for (int q = 0; q < 2; ++q) ws.sel[q][0].rank = ws.k[0], ws.sel[q][1].rank = ws.k[1];
+        for (int q = 0; q < 2; ++q) {
+            ws.sel[q][0].rank = ws.k[0], ws.sel[q][1].rank = ws.k[1];
+            ws.kbase[q] = 0, ws.ksh[q] = 0;  // the full rasters are selected on plain keys
+        }
     ws.fallback = fb;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // 3. radix select: histogram of the next key digit of every value whose higher digits match the rank's prefix
+// (at the first level both ranks of a raster see the same histogram: only [k = 0] is filled and both selects read it)
 __device__ __forceinline__ void hist_add(unsigned* hist, int level, unsigned key, const unsigned (&pfx)[2]) {
+    if (level == 0) {
+        atomicAdd(&hist[key >> (32 - L1_BITS)], 1u);
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-        if (level == 0) {
-            atomicAdd(&hist[k * L1_BINS + (key >> (32 - L1_BITS))], 1u);
-        } else if (level == 1) {
+        if (level == 1) {
             if ((key >> (32 - L1_BITS)) == pfx[k]) atomicAdd(&hist[k * L2_BINS + ((key >> L3_BITS) & (L2_BINS - 1))], 1u);
         } else {
             if ((key >> L3_BITS) == pfx[k]) atomicAdd(&hist[k * L3_BINS + (key & (L3_BINS - 1))], 1u);
@@ -395,35 +490,19 @@ __global__ void __launch_bounds__(NORM_THREADS) norm_mid_hist_kernel(NormWS* __r
     const unsigned cnt = ws.mid_count[q];
     const unsigned pfx[2] = {ws.sel[q][0].prefix, ws.sel[q][1].prefix};
     // 16-byte loads (the buffers are 256-byte aligned), MID_BLOCKS workgroups per buffer: the pass is bound by the loads in
-    // flight, not by the LDS atomics
+    // flight.  The keys are taken relative to the pivot window (NormWS::kbase / ksh): the first digit spreads over all bins
+    // (on plain keys nearly all compacted values shared one top digit and the LDS atomics serialised on it).
+    const unsigned kb = ws.kbase[q];
+    const int ksh = ws.ksh[q];
+    auto rel = [&](float v) { return (f2key(v) - kb) << ksh; };
     const float4* __restrict__ buf4 = reinterpret_cast<const float4*>(buf);
     const unsigned cnt4 = cnt >> 2;
     for (unsigned i = blockIdx.x * NORM_THREADS + threadIdx.x; i < cnt4; i += gridDim.x * NORM_THREADS) {
         const float4 v = buf4[i];
-        if (LEVEL == 0) {
-            // the compacted values lie between two pivots: nearly all share their top digit.  One LDS atomic per wave for the
-            // lanes whose four values all carry the first lane's digit, plain atomics for the (few) other lanes.
-            const unsigned bin[4] = {f2key(v.x) >> (32 - L1_BITS), f2key(v.y) >> (32 - L1_BITS), f2key(v.z) >> (32 - L1_BITS),
-                                     f2key(v.w) >> (32 - L1_BITS)};
-            const int lane = threadIdx.x & 63;
-            const unsigned b0 = __shfl(bin[0], __ffsll((unsigned long long)__ballot(1)) - 1);
-            const bool all4 = bin[0] == b0 && bin[1] == b0 && bin[2] == b0 && bin[3] == b0;
-            const unsigned long long full = __ballot(all4);
-            if (all4) {
-                if (lane == __ffsll(full) - 1) {
-                    atomicAdd(&hist[b0], 4u * (unsigned)__popcll(full));
-                    atomicAdd(&hist[L1_BINS + b0], 4u * (unsigned)__popcll(full));
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) atomicAdd(&hist[bin[j]], 1u), atomicAdd(&hist[L1_BINS + bin[j]], 1u);
-            }
-        } else {
-            hist_add(hist, LEVEL, f2key(v.x), pfx), hist_add(hist, LEVEL, f2key(v.y), pfx);
-            hist_add(hist, LEVEL, f2key(v.z), pfx), hist_add(hist, LEVEL, f2key(v.w), pfx);
-        }
+        hist_add(hist, LEVEL, rel(v.x), pfx), hist_add(hist, LEVEL, rel(v.y), pfx);
+        hist_add(hist, LEVEL, rel(v.z), pfx), hist_add(hist, LEVEL, rel(v.w), pfx);
     }
-    if (blockIdx.x == 0 && threadIdx.x < (cnt & 3u)) hist_add(hist, LEVEL, f2key(buf[(cnt & ~3u) + threadIdx.x]), pfx);
+    if (blockIdx.x == 0 && threadIdx.x < (cnt & 3u)) hist_add(hist, LEVEL, rel(buf[(cnt & ~3u) + threadIdx.x]), pfx);
     __syncthreads();
     unsigned* gh = LEVEL == 0 ? &ws.hist1[q][0][0] : (LEVEL == 1 ? &ws.hist2[q][0][0] : &ws.hist3[q][0][0]);
     for (int i = threadIdx.x; i < 2 * NB; i += NORM_THREADS)
@@ -443,13 +522,15 @@ __global__ void __launch_bounds__(NORM_THREADS) norm_full_hist_kernel(const Norm
     const float* __restrict__ sp = a.src + (long long)band * a.band_stride;
     const float* __restrict__ rp = a.ref + (long long)band * a.band_stride;
     const unsigned pfs[2] = {ws.sel[0][0].prefix, ws.sel[0][1].prefix}, pfr[2] = {ws.sel[1][0].prefix, ws.sel[1][1].prefix};
+    const unsigned kbs = ws.kbase[0], kbr = ws.kbase[1];
+    const int kss = ws.ksh[0], ksr = ws.ksh[1];
     for (int y = blockIdx.x; y < a.height; y += gridDim.x) {
         const long long row = (long long)y * a.stride;
         for (int x = threadIdx.x; x < a.width; x += NORM_THREADS) {
             const float s = sp[row + x], r = rp[row + x];
             if (nvalid(s, a.src_nd_mode, a.src_nodata) && nvalid(r, a.ref_nd_mode, a.ref_nodata)) {
-                hist_add(hist, LEVEL, f2key(s), pfs);
-                hist_add(hist + 2 * NB, LEVEL, f2key(r), pfr);
+                hist_add(hist, LEVEL, (f2key(s) - kbs) << kss, pfs);  // kbase / ksh are 0 / 0 on this path (plain keys)
+                hist_add(hist + 2 * NB, LEVEL, (f2key(r) - kbr) << ksr, pfr);
             }
         }
     }
@@ -457,35 +538,6 @@ __global__ void __launch_bounds__(NORM_THREADS) norm_full_hist_kernel(const Norm
     unsigned* gh = LEVEL == 0 ? &ws.hist1[0][0][0] : (LEVEL == 1 ? &ws.hist2[0][0][0] : &ws.hist3[0][0][0]);
     for (int i = threadIdx.x; i < 4 * NB; i += NORM_THREADS)
         if (hist[i]) atomicAdd(gh + i, hist[i]);
-}
-
-// Find the bin holding rank `rank` in hist[0..nbins) -- the first bin whose running count exceeds it (the last bin if
-// none does) -- and the rank inside that bin.  One wave: each lane sums a contiguous chunk, an inclusive scan over the
-// lanes finds the chunk, its lane walks the chunk.  The lane that found it returns true.
-__device__ __forceinline__ bool select_bin(const unsigned* __restrict__ h, int nbins, unsigned long long rank, unsigned* bin_out,
-                                           unsigned long long* rank_out) {
-    const int lane = threadIdx.x & (WAVE - 1);
-    const int per = nbins / WAVE;
-    unsigned long long local = 0;
-    for (int i = 0; i < per; ++i) local += h[lane * per + i];
-    unsigned long long incl = local;
-#pragma unroll
-    for (int d = 1; d < WAVE; d <<= 1) {
-        const unsigned long long v = __shfl_up(incl, d, WAVE);
-        if (lane >= d) incl += v;
-    }
-    const unsigned long long hit = __ballot(incl > rank);
-    const int owner = hit ? __ffsll(hit) - 1 : WAVE - 1;
-    if (lane != owner) return false;
-    unsigned long long cum = incl - local;
-    int b = lane * per;
-    for (int i = 0; i < per - 1; ++i, ++b) {
-        if (cum + h[b] > rank) break;
-        cum += h[b];
-    }
-    *bin_out = (unsigned)b;
-    *rank_out = rank - cum;
-    return true;
 }
 
 // After each histogram level (of either path): fix the next digit of the four (raster, rank) keys -- one wave each; after
@@ -497,15 +549,16 @@ __global__ void __launch_bounds__(NORM_THREADS) norm_select_kernel(NormWS* __res
     if (ws.done) return;
     {
         const int q = threadIdx.x >> 7, k = (threadIdx.x >> 6) & 1;
-        const unsigned* h = LEVEL == 0 ? ws.hist1[q][k] : (LEVEL == 1 ? ws.hist2[q][k] : ws.hist3[q][k]);
-        const int nb = LEVEL == 0 ? L1_BINS : (LEVEL == 1 ? L2_BINS : L3_BINS);
+        // the first level's histogram is the same for both ranks: only [k = 0] is filled (hist_add)
+        const unsigned* h = LEVEL == 0 ? ws.hist1[q][0] : (LEVEL == 1 ? ws.hist2[q][k] : ws.hist3[q][k]);
+        constexpr int NB = LEVEL == 0 ? L1_BINS : (LEVEL == 1 ? L2_BINS : L3_BINS);
         unsigned bin;
         unsigned long long rk;
-        if (select_bin(h, nb, ws.sel[q][k].rank, &bin, &rk)) {
+        if (select_bin<NB>(h, ws.sel[q][k].rank, &bin, &rk)) {
             const int bits = LEVEL == 0 ? 0 : (LEVEL == 1 ? L2_BITS : L3_BITS);
             ws.sel[q][k].prefix = (LEVEL == 0) ? bin : ((ws.sel[q][k].prefix << bits) | bin);
             ws.sel[q][k].rank = rk;
-            if (LEVEL == 2) ws.val[q][k] = key2f(ws.sel[q][k].prefix);
+            if (LEVEL == 2) ws.val[q][k] = key2f((ws.sel[q][k].prefix >> ws.ksh[q]) + ws.kbase[q]);
         }
     }
     __syncthreads();
@@ -556,7 +609,7 @@ __global__ void split_put_moments_kernel(NormWS* __restrict__ ws_all, double* __
     NormWS& ws = ws_all[blockIdx.x];
     unsigned long long n = 0;
     double m1[2] = {0.0, 0.0}, m2[2] = {0.0, 0.0};
-    for (int i = threadIdx.x; i < PASS_WAVES; i += WAVE) {  // same order as norm_stats_kernel
+    for (int i = threadIdx.x; i < PASS_WAVES; i += WAVE) {  // fixed order: deterministic
         n += ws.pn[i];
         for (int q = 0; q < 2; ++q) m1[q] += ws.p1[q][i], m2[q] += ws.p2[q][i];
     }
@@ -672,7 +725,7 @@ hipError_t launch_block_norm(const NormArgs& a, void* workspace, double* norm_ou
         hipLaunchKernelGGL(norm_stream_kernel<true>, gstream, dim3(WAVE), 0, stream, a, ws, mid, cap_al);
     else
         hipLaunchKernelGGL(norm_stream_kernel<false>, gstream, dim3(WAVE), 0, stream, a, ws, mid, cap_al);
-    hipLaunchKernelGGL(norm_stats_kernel, bands, dim3(64), 0, stream, ws, norm_out, cap_al);
+    hipLaunchKernelGGL(norm_stats_kernel, bands, dim3(STATS_THREADS), 0, stream, ws, norm_out, cap_al);
     const dim3 gmid(MID_BLOCKS, a.n_bands * 2), gfull(FB_BLOCKS, a.n_bands);
     hipLaunchKernelGGL(norm_mid_hist_kernel<0>, gmid, block, 0, stream, ws, mid, cap_al);
     hipLaunchKernelGGL(norm_full_hist_kernel<0>, gfull, block, 0, stream, a, ws);
