@@ -17,7 +17,6 @@
 namespace hk {
 
 constexpr int NONE_Y = 0x7fffffff;
-constexpr unsigned short NONE_D = 0xffff;
 
 // source = (r2 > thresh) & (gain > 0) & valid (kernel_model.py:363): one byte per pixel.  NaN parameters (masked pixels,
 // degenerate windows) compare false.
@@ -32,39 +31,62 @@ __global__ void __launch_bounds__(256) inpaint_flag_kernel(const float* __restri
     }
 }
 
-// Column tables as DISTANCES (uint16): rows up to the nearest source at-or-above (0..max_dist) and down to the nearest
-// source strictly below (1..max_dist + 1), NONE_D when there is none in reach; the search reads the source's value from
-// the offset plane itself.  One thread per (column, chunk of SCAN_ROWS rows): a source is only visible `max_dist` rows
-// away, so a chunk's scan starts `max_dist` rows before (top-down) / after (bottom-up) its first output row with an
-// empty state and reproduces the sequential scan exactly.
-constexpr int SCAN_ROWS = 256;
-__global__ void __launch_bounds__(256) inpaint_scan_kernel(const unsigned char* __restrict__ flag, long long stride, int height,
-                                                           int width, int max_dist, unsigned short* __restrict__ top_d,
-                                                           unsigned short* __restrict__ bot_d) {
+// Column table: per pixel two DISTANCES in one 16-bit word -- low byte: rows up to the nearest source at-or-above
+// (0..max_dist), high byte: rows down to the nearest source strictly below (1..max_dist + 1), NONE_B when there is none in
+// reach (max_dist = 100, rasterio's default; the bytes hold up to 253).  The search reads the source's value from the
+// offset plane itself.  GDAL carries both as the state of two sequential column scans; "the nearest source within reach" is
+// the same thing without the sequence: the flags of a column are packed into 64-row bit words (inpaint_bits_kernel: 64
+// independent byte loads per thread), and every pixel finds its two distances with clz / ctz on at most three words per
+// direction (inpaint_table_kernel: one thread per column and word, no memory access inside its 64-row loop).  The
+// sequential form (one thread per column and 64-row chunk, 100 rows of run-in per direction) took 1.15 ms per 16384^2
+// band whatever its chunk height, load width or unrolling: its loads sit behind data-dependent state updates.
+constexpr unsigned NONE_B = 0xffu;
+constexpr int WORD_ROWS = 64;
+
+__global__ void __launch_bounds__(256) inpaint_bits_kernel(const unsigned char* __restrict__ flag, long long stride, int height,
+                                                           int width, unsigned long long* __restrict__ bits) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= width) return;
-    const int y0 = blockIdx.y * SCAN_ROWS, y1 = min(y0 + SCAN_ROWS, height);
-    // top-down: nearest source at or above each row
-    int last_y = NONE_Y;
-    for (int y = max(0, y0 - max_dist); y < y1; ++y) {
-        const long long i = (long long)y * stride + x;
-        if (flag[i]) {
-            last_y = y;
-        } else if (last_y != NONE_Y && y > max_dist + last_y) {
-            last_y = NONE_Y;
-        }
-        if (y >= y0) top_d[i] = last_y == NONE_Y ? NONE_D : (unsigned short)(y - last_y);
+    const int y0 = blockIdx.y * WORD_ROWS;
+    unsigned lo = 0, hi = 0;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+        const int ya = y0 + r, yb = y0 + 32 + r;
+        // rows past the raster are clamped into it and masked out (the loads stay unconditional and independent)
+        const unsigned char fa = flag[(long long)min(ya, height - 1) * stride + x];
+        const unsigned char fb = flag[(long long)min(yb, height - 1) * stride + x];
+        lo |= (unsigned)(fa != 0 && ya < height) << r;
+        hi |= (unsigned)(fb != 0 && yb < height) << r;
     }
-    // bottom-up: nearest source strictly below each row (the state left by the row underneath)
-    last_y = NONE_Y;
-    for (int y = min(height - 1, y1 + max_dist); y >= y0; --y) {
-        const long long i = (long long)y * stride + x;
-        if (y < y1) bot_d[i] = last_y == NONE_Y ? NONE_D : (unsigned short)(last_y - y);
-        if (flag[i]) {
-            last_y = y;
-        } else if (last_y != NONE_Y && last_y - y > max_dist) {
-            last_y = NONE_Y;
-        }
+    bits[(long long)blockIdx.y * stride + x] = ((unsigned long long)hi << 32) | lo;
+}
+
+__global__ void __launch_bounds__(256) inpaint_table_kernel(const unsigned long long* __restrict__ bits, long long stride,
+                                                            int height, int width, int max_dist,
+                                                            unsigned short* __restrict__ tb) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= width) return;
+    const int wb = blockIdx.y, n_words = (height + WORD_ROWS - 1) / WORD_ROWS;
+    auto word = [&](int w) { return (w >= 0 && w < n_words) ? bits[(long long)w * stride + x] : 0ull; };
+    const unsigned long long wm2 = word(wb - 2), wm1 = word(wb - 1), w0 = word(wb), wp1 = word(wb + 1), wp2 = word(wb + 2);
+    const int y0 = wb * WORD_ROWS, rows = min(WORD_ROWS, height - y0);
+    for (int b = 0; b < rows; ++b) {
+        // up: nearest set bit at or above row y0 + b
+        const unsigned long long m_up = w0 & (~0ull >> (63 - b));
+        int up;
+        if (m_up) up = b - (63 - __clzll((long long)m_up));
+        else if (wm1) up = b + 1 + __clzll((long long)wm1);
+        else if (wm2) up = b + 65 + __clzll((long long)wm2);
+        else up = 1 << 20;
+        // down: nearest set bit strictly below
+        const unsigned long long m_dn = b == 63 ? 0ull : (w0 & (~0ull << (b + 1)));
+        int dn;
+        if (m_dn) dn = (__ffsll((long long)m_dn) - 1) - b;
+        else if (wp1) dn = 64 - b + (__ffsll((long long)wp1) - 1);
+        else if (wp2) dn = 128 - b + (__ffsll((long long)wp2) - 1);
+        else dn = 1 << 20;
+        const unsigned ub = up <= max_dist ? (unsigned)up : NONE_B, db = dn <= max_dist + 1 ? (unsigned)dn : NONE_B;
+        tb[(long long)(y0 + b) * stride + x] = (unsigned short)((db << 8) | ub);
     }
 }
 
@@ -100,10 +122,11 @@ __device__ __forceinline__ void quad_check(int& qd2, int& qx, int& qy, int tx, i
     if (better) qd2 = d2, qx = tx, qy = ty;
 }
 
-__global__ void __launch_bounds__(256) inpaint_fill_kernel(const float* __restrict__ offset, const unsigned char* __restrict__ flag,
+// 8 waves per SIMD (64 VGPRs, three spilled dwords): the search is bound by dependent look-ups, and the step from 6 to 8
+// resident waves was worth 8 % of the whole in-painting branch
+__global__ void __launch_bounds__(256, 8) inpaint_fill_kernel(const float* __restrict__ offset, const unsigned char* __restrict__ flag,
                                                            long long stride, int height, int width, int max_dist,
-                                                           const unsigned short* __restrict__ top_d,
-                                                           const unsigned short* __restrict__ bot_d,
+                                                           const unsigned short* __restrict__ tb,
                                                            const unsigned* __restrict__ tie,
                                                            const double* __restrict__ wtab, float* __restrict__ filled) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
@@ -112,6 +135,15 @@ __global__ void __launch_bounds__(256) inpaint_fill_kernel(const float* __restri
     const long long row = (long long)y * stride;
     const long long i = row + x;
     float out = offset[i];
+    constexpr int G = 5;  // longest group (steps 0..4)
+    unsigned lw[G], rw[G], nlw[G], nrw[G];  // (down << 8) | up distances of the left / right column of each step
+    auto fetch = [&](int first_step, unsigned (&a)[G], unsigned (&c)[G]) {
+#pragma unroll
+        for (int k = 0; k < G; ++k) {
+            const int step = first_step + k;  // steps beyond the bound are clamped into the row and never checked
+            a[k] = tb[row + max(0, x - step)], c[k] = tb[row + min(width - 1, x + step)];
+        }
+    };
     if (!flag[i]) {
         const int none2 = (max_dist + 1) * (max_dist + 1);  // qd = max_dist + 1: "nothing found yet" (a perfect square: no tie)
         int qd2[4] = {none2, none2, none2, none2};
@@ -121,33 +153,23 @@ __global__ void __launch_bounds__(256) inpaint_fill_kernel(const float* __restri
         // checks, which then run in the original order (ascending step; left quadrants before right ones).
         // The look-ups of the NEXT group are issued before the checks of the current one (their latency hides behind the
         // checks; a group that turns out not to be needed costs four cached loads per step and nothing else).
-        constexpr int G = 5;  // longest group (steps 0..4)
-        unsigned short lt[G], lb[G], rt[G], rb[G], nlt[G], nlb[G], nrt[G], nrb[G];
-        auto fetch = [&](int first_step, unsigned short (&a)[G], unsigned short (&b)[G], unsigned short (&c)[G],
-                         unsigned short (&d)[G]) {
-#pragma unroll
-            for (int k = 0; k < G; ++k) {
-                const int step = first_step + k;  // steps beyond the bound are clamped into the row and never checked
-                const long long li = row + max(0, x - step), ri = row + min(width - 1, x + step);
-                a[k] = top_d[li], b[k] = bot_d[li], c[k] = top_d[ri], d[k] = bot_d[ri];
-            }
-        };
         int this_max = max_dist;
         int first = 0;
-        fetch(0, lt, lb, rt, rb);
+        fetch(0, lw, rw);  // (issuing these beside the flag load instead of behind it was measured: no difference)
         while (first <= this_max) {
             const int last = min(this_max, first == 0 ? 4 : first + 3);
-            fetch(last + 1, nlt, nlb, nrt, nrb);
+            fetch(last + 1, nlw, nrw);
 #pragma unroll
             for (int k = 0; k < G; ++k) {
                 const int step = first + k;
                 if (step <= last) {
                     const int lx = max(0, x - step), rx = min(width - 1, x + step);
-                    quad_check(qd2[0], qx[0], qy[0], lx, lt[k] == NONE_D ? NONE_Y : y - (int)lt[k], x, y, tie);  // top left
-                    quad_check(qd2[1], qx[1], qy[1], lx, lb[k] == NONE_D ? NONE_Y : y + (int)lb[k], x, y, tie);  // bottom left
+                    const int lt = lw[k] & 0xffu, lb = lw[k] >> 8, rt = rw[k] & 0xffu, rb = rw[k] >> 8;
+                    quad_check(qd2[0], qx[0], qy[0], lx, lt == (int)NONE_B ? NONE_Y : y - lt, x, y, tie);  // top left
+                    quad_check(qd2[1], qx[1], qy[1], lx, lb == (int)NONE_B ? NONE_Y : y + lb, x, y, tie);  // bottom left
                     if (step != 0) {
-                        quad_check(qd2[2], qx[2], qy[2], rx, rt[k] == NONE_D ? NONE_Y : y - (int)rt[k], x, y, tie);  // top right
-                        quad_check(qd2[3], qx[3], qy[3], rx, rb[k] == NONE_D ? NONE_Y : y + (int)rb[k], x, y, tie);  // bottom right
+                        quad_check(qd2[2], qx[2], qy[2], rx, rt == (int)NONE_B ? NONE_Y : y - rt, x, y, tie);  // top right
+                        quad_check(qd2[3], qx[3], qy[3], rx, rb == (int)NONE_B ? NONE_Y : y + rb, x, y, tie);  // bottom right
                     }
                 }
             }
@@ -156,7 +178,7 @@ __global__ void __launch_bounds__(256) inpaint_fill_kernel(const float* __restri
                 this_max = (int)floor(sqrt((double)max(max(qd2[0], qd2[1]), max(qd2[2], qd2[3]))));
             first = last + 1;
 #pragma unroll
-            for (int k = 0; k < G; ++k) lt[k] = nlt[k], lb[k] = nlb[k], rt[k] = nrt[k], rb[k] = nrb[k];
+            for (int k = 0; k < G; ++k) lw[k] = nlw[k], rw[k] = nrw[k];
         }
         double wsum = 0.0, vsum = 0.0;
         bool has = false;
@@ -174,7 +196,7 @@ __global__ void __launch_bounds__(256) inpaint_fill_kernel(const float* __restri
     }
 }
 
-// workspace: two uint16 distance tables + source flags (1 byte per pixel) + the tie bitmap + the weight table
+// workspace: the distance table (2 of its 4 bytes per pixel are used) + source flags (1 byte per pixel) + the tie bitmap + the weight table
 size_t inpaint_workspace_bytes(int height, long long stride) { return (size_t)height * stride * 5 + 1024 + TIE_N / 8 + 256 + WTAB_N * 8 + 256; }
 
 // the workspace's source-flag plane: the fit kernel can write it itself (FitArgs::flag), then gain / r2 are not needed here
@@ -186,21 +208,24 @@ hipError_t launch_inpaint_offsets(const float* offset, const float* gain, const 
                                   int height, int width, void* workspace, float* filled, hipStream_t stream,
                                   const unsigned char* flag_ready) {
     const size_t plane = (size_t)height * stride;
-    unsigned short* top_d = static_cast<unsigned short*>(workspace);
-    unsigned short* bot_d = top_d + plane;
+    unsigned short* tb = static_cast<unsigned short*>(workspace);  // (down << 8) | up row distances, 2 bytes per pixel
     unsigned char* ws_flag = inpaint_flag_plane(workspace, height, stride);
     const unsigned char* flag = flag_ready ? flag_ready : ws_flag;
     unsigned* tie = reinterpret_cast<unsigned*>(ws_flag + (plane + 255) / 256 * 256);
     double* wtab = reinterpret_cast<double*>(tie + (TIE_N / 32 + 64) / 64 * 64);
     hipLaunchKernelGGL(tie_kernel, dim3((TIE_N / 32 + 255) / 256), dim3(256), 0, stream, tie, wtab);
     const int max_dist = 100;  // rasterio.fill.fillnodata default max_search_distance (kernel_model.py:366)
+    static_assert(100 + 1 < (int)NONE_B, "the table's distance bytes");
     if (!flag_ready)  // else: the flag plane was written by the fit kernel (FitArgs::flag)
         hipLaunchKernelGGL(inpaint_flag_kernel, dim3((width + 255) / 256, height < 1024 ? height : 1024), dim3(256), 0, stream,
                            gain, r2, thresh, stride, height, width, ws_flag);
-    hipLaunchKernelGGL(inpaint_scan_kernel, dim3((width + 255) / 256, (height + SCAN_ROWS - 1) / SCAN_ROWS), dim3(256), 0,
-                       stream, flag, stride, height, width, max_dist, top_d, bot_d);
+    // column bit words in the unused half of the table region (plane / 8 bytes of its 2 * plane spare bytes)
+    unsigned long long* bits = reinterpret_cast<unsigned long long*>(tb + plane);
+    const dim3 gwords((width + 255) / 256, (height + WORD_ROWS - 1) / WORD_ROWS);
+    hipLaunchKernelGGL(inpaint_bits_kernel, gwords, dim3(256), 0, stream, flag, stride, height, width, bits);
+    hipLaunchKernelGGL(inpaint_table_kernel, gwords, dim3(256), 0, stream, bits, stride, height, width, max_dist, tb);
     hipLaunchKernelGGL(inpaint_fill_kernel, dim3((width + 255) / 256, height < 65535 ? height : 65535), dim3(256), 0, stream, offset, flag, stride,
-                       height, width, max_dist, top_d, bot_d, tie, wtab, filled);
+                       height, width, max_dist, tb, tie, wtab, filled);
     return hipGetLastError();
 }
 
