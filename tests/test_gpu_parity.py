@@ -832,6 +832,23 @@ def test_r2_inpainting_vs_oracle(ctx, want_params):
         assert_close_ulp(corr, onp.apply(src, exp_params), 'corrected after in-painting', max_frac=1e-3)
 
 
+def test_r2_inpainting_of_a_block_taller_than_a_grid_dimension(ctx, oc):
+    """ 66 000 rows: the in-painting kernels stride over the rows (a launch has at most 65 535 workgroups along y), and the
+    column bit words / distance table cover the whole height; failing patches near the top, the middle and the last rows. """
+    h, w = 66000, 40
+    src, ref = onp.synth_pair(h, w, 23, 'frame+holes')
+    ref = ref.copy()
+    for y0 in (10, 32990, 65530, 65990):
+        ref[y0:y0 + 6, 8:20] = -3.0
+    exp_params, exp_corr, exp_fail = oc.fit_apply('gain-offset', src, np.nan, ref, np.nan, (5, 5), False, 0.25)
+    assert exp_fail > 200
+    desc = _hk.make_desc('gain-offset', (5, 5), False, 0.25, np.nan, np.nan)
+    params, corr, _, n_fail = ctx.fit_apply(desc, src, ref, 3, want_params=True, want_corr=True)
+    assert n_fail == exp_fail
+    assert_close_ulp(params, exp_params, 'in-painted params', max_frac=1e-3)
+    assert_close_ulp(corr, exp_corr, 'corrected after in-painting', max_frac=1e-3)
+
+
 @pytest.mark.parametrize('with_params, split_api, scratch', [(False, False, False), (True, False, False), (False, True, False),
                                                              (False, False, True), (True, False, True), (False, True, True)])
 def test_device_resident_job_with_inpainting(ctx, oc, with_params, split_api, scratch):
