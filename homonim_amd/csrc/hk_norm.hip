@@ -97,8 +97,8 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 // none does) -- and the rank inside that bin.  One wave: each lane loads a contiguous chunk into registers (independent
 // loads) and sums it, an inclusive scan over the lanes finds the chunk, its lane walks its registers.  The lane that found
 // it returns true.
-template <int NBINS>
-__device__ __forceinline__ bool select_bin(const unsigned* __restrict__ h, unsigned long long rank, unsigned* bin_out,
+template <int NBINS, typename T = unsigned>
+__device__ __forceinline__ bool select_bin(const T* __restrict__ h, unsigned long long rank, unsigned* bin_out,
                                            unsigned long long* rank_out) {
     const int lane = threadIdx.x & (WAVE - 1);
     constexpr int PER = NBINS / WAVE;
@@ -134,110 +134,109 @@ __device__ __forceinline__ bool select_bin(const unsigned* __restrict__ h, unsig
 
 // ---------------------------------------------------------------------------------------------------------------------
 // 1. sample
-__global__ void __launch_bounds__(1024) norm_sample_kernel(const NormArgs a, NormWS* __restrict__ ws_all) {
+// Small on purpose -- 256 threads, 24 KB of LDS: on a GPU filled by other streams' fit kernels (16 waves and 128-160 KB of LDS
+// per CU) a 1024-thread / 48 KB workgroup waited for a CU to drain, 0.3-0.4 ms per block with four streams in flight.  One
+// raster at a time (the sample positions are read twice), 16-bit histogram counters (a sample has 4096 entries).
+constexpr int SAMPLE_THREADS = 256;
+__global__ void __launch_bounds__(SAMPLE_THREADS) norm_sample_kernel(const NormArgs a, NormWS* __restrict__ ws_all) {
     static_assert(L1_BINS == L2_BINS && L3_BINS <= L1_BINS, "the sample select shares one histogram shape");
-    __shared__ float samp[2][SAMPLE_N];
-    __shared__ unsigned hist[4][L1_BINS];  // one per (raster, rank)
-    __shared__ unsigned cnt, spfx[4], srank[4];
-    __shared__ int need[4];
-    __shared__ double red[2][1024 / WAVE];
+    static_assert(SAMPLE_N < 65536, "16-bit histogram counters");
+    __shared__ float samp[SAMPLE_N];
+    __shared__ unsigned hist[2][L1_BINS / 2];  // one per rank, two 16-bit counters per word
+    __shared__ unsigned cnt, spfx[2], srank[2];
+    __shared__ int need[2];
+    __shared__ double red[SAMPLE_THREADS / WAVE];
     const int band = blockIdx.x, t = threadIdx.x;
     NormWS& ws = ws_all[band];
     const float* __restrict__ sp = a.src + (long long)band * a.band_stride;
     const float* __restrict__ rp = a.ref + (long long)band * a.band_stride;
-    if (t == 0) cnt = 0;
-    for (int i = t; i < SAMPLE_N; i += 1024) samp[0][i] = samp[1][i] = __int_as_float(0x7f800000);  // +inf padding
-    __syncthreads();
     const long long total = (long long)a.height * a.width;
     const long long step = total / SAMPLE_N > 0 ? total / SAMPLE_N : 1;
-    double sum_s = 0.0, sum_r = 0.0;
-    for (int j = t; j < SAMPLE_N; j += 1024) {
-        // stratified sample: one pseudo-random pixel per stratum of `step` pixels (a plain stride aliases with the row
-        // length -- e.g. every sample in one column of a nodata frame)
-        unsigned long long hsh = ((unsigned long long)j + 0x9e3779b97f4a7c15ull) * 0xbf58476d1ce4e5b9ull;
-        hsh = (hsh ^ (hsh >> 29)) * 0x94d049bb133111ebull;
-        hsh ^= hsh >> 32;
-        const long long p = (long long)j * step + (long long)(hsh % (unsigned long long)step);
-        if (p < total) {
-            const int y = (int)(p / a.width), x = (int)(p % a.width);
-            const float s = sp[(long long)y * a.stride + x], r = rp[(long long)y * a.stride + x];
-            if (nvalid(s, a.src_nd_mode, a.src_nodata) && nvalid(r, a.ref_nd_mode, a.ref_nodata)) {
-                const unsigned i = atomicAdd(&cnt, 1u);
-                samp[0][i] = s;
-                samp[1][i] = r;
-                sum_s += (double)s;
-                sum_r += (double)r;
-            }
-        }
-    }
-    __syncthreads();
-    const unsigned m = cnt;
-    // shift of the moment sums = sample mean (any value works; a close one kills the cancellation): butterfly per wave,
-    // thread 0 adds the 16 wave sums in order
-    {
-        const double ws_s = wave_sum(sum_s), ws_r = wave_sum(sum_r);
-        if ((t & (WAVE - 1)) == 0) red[0][t / WAVE] = ws_s, red[1][t / WAVE] = ws_r;
-    }
-    // sample ranks bracketing the 1st percentile by +-4 sigma of the binomial sample quantile (+ margin); the two order
-    // statistics of each raster's sample are found by a 3-level radix select in LDS (four selects side by side, one
-    // histogram each) -- the values a sort would put at those ranks, at a tenth of the bitonic sort's time
-    if (t == 0) {
-        const double c = 0.01 * (double)m, sd = sqrt(c > 0.0 ? c : 0.0);
-        const long long ia = (long long)floor(c - 4.0 * sd) - 2, ib = (long long)ceil(c + 4.0 * sd) + 3;
-        for (int q = 0; q < 2; ++q) {
-            need[2 * q] = !(m == 0 || ia <= 0), need[2 * q + 1] = !(m == 0 || ib >= (long long)m - 1);
-            srank[2 * q] = need[2 * q] ? (unsigned)ia : 0u, srank[2 * q + 1] = need[2 * q + 1] ? (unsigned)ib : 0u;
-            spfx[2 * q] = spfx[2 * q + 1] = 0u;
-        }
-    }
-    __syncthreads();
-    for (int level = 0; level < 3; ++level) {
-        for (int i = t; i < 4 * L1_BINS; i += 1024) (&hist[0][0])[i] = 0;
+    for (int q = 0; q < 2; ++q) {
+        if (t == 0) cnt = 0;
+        for (int i = t; i < SAMPLE_N; i += SAMPLE_THREADS) samp[i] = __int_as_float(0x7f800000);  // +inf padding
         __syncthreads();
-        for (int i = t; i < SAMPLE_N; i += 1024) {
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const unsigned key = f2key(samp[q][i]);
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const int sidx = 2 * q + k;
-                    if (level == 0) atomicAdd(&hist[sidx][key >> (32 - L1_BITS)], 1u);
-                    else if (level == 1) {
-                        if ((key >> (32 - L1_BITS)) == spfx[sidx]) atomicAdd(&hist[sidx][(key >> L3_BITS) & (L2_BINS - 1)], 1u);
-                    } else if ((key >> L3_BITS) == spfx[sidx]) atomicAdd(&hist[sidx][key & (L3_BINS - 1)], 1u);
+        double sum = 0.0;
+        for (int j = t; j < SAMPLE_N; j += SAMPLE_THREADS) {
+            // stratified sample: one pseudo-random pixel per stratum of `step` pixels (a plain stride aliases with the row
+            // length -- e.g. every sample in one column of a nodata frame)
+            unsigned long long hsh = ((unsigned long long)j + 0x9e3779b97f4a7c15ull) * 0xbf58476d1ce4e5b9ull;
+            hsh = (hsh ^ (hsh >> 29)) * 0x94d049bb133111ebull;
+            hsh ^= hsh >> 32;
+            const long long p = (long long)j * step + (long long)(hsh % (unsigned long long)step);
+            if (p < total) {
+                const int y = (int)(p / a.width), x = (int)(p % a.width);
+                const float s = sp[(long long)y * a.stride + x], r = rp[(long long)y * a.stride + x];
+                if (nvalid(s, a.src_nd_mode, a.src_nodata) && nvalid(r, a.ref_nd_mode, a.ref_nodata)) {
+                    const float v = q ? r : s;
+                    samp[atomicAdd(&cnt, 1u)] = v;
+                    sum += (double)v;
                 }
             }
         }
         __syncthreads();
-        if (t < 4 * WAVE) {  // one wave per select
-            const int sidx = t / WAVE;
-            unsigned bin;
-            unsigned long long rk;
-            bool mine;
-            if (level == 2) mine = select_bin<L3_BINS>(hist[sidx], srank[sidx], &bin, &rk);
-            else mine = select_bin<L1_BINS>(hist[sidx], srank[sidx], &bin, &rk);
-            if (mine) {
-                const int bits = level == 0 ? 0 : (level == 1 ? L2_BITS : L3_BITS);
-                spfx[sidx] = level == 0 ? bin : ((spfx[sidx] << bits) | bin);
-                srank[sidx] = (unsigned)rk;
+        const unsigned m = cnt;
+        // shift of the moment sums = sample mean (any value works; a close one kills the cancellation): butterfly per
+        // wave, thread 0 adds the wave sums in order
+        {
+            const double wsum = wave_sum(sum);
+            if ((t & (WAVE - 1)) == 0) red[t / WAVE] = wsum;
+        }
+        // sample ranks bracketing the 1st percentile by +-4 sigma of the binomial sample quantile (+ margin); the two order
+        // statistics are found by a 3-level radix select in LDS (one histogram and one wave per rank) -- the values a sort
+        // would put at those ranks, at a fraction of a bitonic sort's time
+        if (t == 0) {
+            const double c = 0.01 * (double)m, sd = sqrt(c > 0.0 ? c : 0.0);
+            const long long ia = (long long)floor(c - 4.0 * sd) - 2, ib = (long long)ceil(c + 4.0 * sd) + 3;
+            need[0] = !(m == 0 || ia <= 0), need[1] = !(m == 0 || ib >= (long long)m - 1);
+            srank[0] = need[0] ? (unsigned)ia : 0u, srank[1] = need[1] ? (unsigned)ib : 0u;
+            spfx[0] = spfx[1] = 0u;
+        }
+        __syncthreads();
+        for (int level = 0; level < 3; ++level) {
+            for (int i = t; i < L1_BINS; i += SAMPLE_THREADS) (&hist[0][0])[i] = 0;
+            __syncthreads();
+            for (int i = t; i < SAMPLE_N; i += SAMPLE_THREADS) {
+                const unsigned key = f2key(samp[i]);
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    unsigned bin;
+                    bool in;
+                    if (level == 0) bin = key >> (32 - L1_BITS), in = true;
+                    else if (level == 1) bin = (key >> L3_BITS) & (L2_BINS - 1), in = (key >> (32 - L1_BITS)) == spfx[k];
+                    else bin = key & (L3_BINS - 1), in = (key >> L3_BITS) == spfx[k];
+                    if (in) atomicAdd(&hist[k][bin >> 1], 1u << (16 * (bin & 1u)));
+                }
             }
+            __syncthreads();
+            if (t < 2 * WAVE) {  // one wave per rank
+                const int k = t / WAVE;
+                const unsigned short* h16 = reinterpret_cast<const unsigned short*>(hist[k]);
+                unsigned bin;
+                unsigned long long rk;
+                bool mine;
+                if (level == 2) mine = select_bin<L3_BINS, unsigned short>(h16, srank[k], &bin, &rk);
+                else mine = select_bin<L1_BINS, unsigned short>(h16, srank[k], &bin, &rk);
+                if (mine) {
+                    const int bits = level == 0 ? 0 : (level == 1 ? L2_BITS : L3_BITS);
+                    spfx[k] = level == 0 ? bin : ((spfx[k] << bits) | bin);
+                    srank[k] = (unsigned)rk;
+                }
+            }
+            __syncthreads();
+        }
+        if (t == 0) {
+            double s_all = 0.0;
+            for (int i = 0; i < SAMPLE_THREADS / WAVE; ++i) s_all += red[i];
+            const double mean = m ? s_all / (double)m : 0.0;
+            ws.shift[q] = (mean == mean && fabs(mean) < 1e300) ? mean : 0.0;
+            ws.lo[q] = need[0] ? key2f(spfx[0]) : __int_as_float(0xff800000);
+            ws.hi[q] = need[1] ? key2f(spfx[1]) : __int_as_float(0x7f800000);
         }
         __syncthreads();
     }
-    if (t == 0) {
-        for (int q = 0; q < 2; ++q) {
-            double sum = 0.0;
-            for (int i = 0; i < 1024 / WAVE; ++i) sum += red[q][i];
-            const double mean = m ? sum / (double)m : 0.0;
-            ws.shift[q] = (mean == mean && fabs(mean) < 1e300) ? mean : 0.0;
-            ws.lo[q] = need[2 * q] ? key2f(spfx[2 * q]) : __int_as_float(0xff800000);
-            ws.hi[q] = need[2 * q + 1] ? key2f(spfx[2 * q + 1]) : __int_as_float(0x7f800000);
-        }
-    }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// 2. streaming pass: one wave per workgroup, wave-private LDS staging of the compacted values
 // Waves per band of the streaming pass: a function of the block SHAPE only (never of the batch size), so a block's
 // statistics are the same bits whichever launch it travels in; >= 16 chunks of 1 KB per raster per wave.
 static int pass_waves(int height, int width) {
@@ -251,7 +250,7 @@ static int pass_waves(int height, int width) {
 // written unconditionally to the slot behind the queue's end and the end moves by the compare result, so the loop body
 // has no branch per pixel -- one wave-uniform test per 1 KB chunk asks whether any queue could overflow in the next chunk.
 // The order of the compacted values is irrelevant (the select is a histogram).
-constexpr int QCAP = 16;
+constexpr int QCAP = 16;  // (8 slots = 4 KB of LDS per wave was measured slower, alone and beside other streams' kernels)
 
 // DENSE: neither raster has a nodata value (no validity test at all); otherwise the test is branch-free: `cmp` is the
 // numeric nodata value or NaN (never equal), `nan` says that NaN is the nodata value.
@@ -302,8 +301,12 @@ __global__ void __launch_bounds__(WAVE) norm_stream_kernel(const NormArgs a, Nor
         const long long o = live ? (long long)py * a.stride + (long long)pc * (WAVE * PX) : 0ll;
         const bool ok = live && pc * WAVE + lane < wq;  // rows are padded to a multiple of PX elements
         const int lo4 = ok ? lane * PX : 0;
-        s4 = *reinterpret_cast<const float4*>(sp + o + lo4);
-        r4 = *reinterpret_cast<const float4*>(rp + o + lo4);
+        // read once: non-temporal, so the pass does not push the rows a tall fit kernel of another stream is about to
+        // re-read out of L2 / the memory-side cache (configs[3], four streams: -4 %)
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        const f4v sv = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(sp + o + lo4));
+        const f4v rv = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(rp + o + lo4));
+        s4 = make_float4(sv.x, sv.y, sv.z, sv.w), r4 = make_float4(rv.x, rv.y, rv.z, rv.w);
         x = ok ? (pc * WAVE + lane) * PX : a.width;
         pit += G, py += dy, pc += dc;
         if (pc >= cpr) pc -= cpr, ++py;
@@ -509,34 +512,34 @@ __global__ void __launch_bounds__(NORM_THREADS) norm_mid_hist_kernel(NormWS* __r
         if (hist[i]) atomicAdd(gh + i, hist[i]);  // integer atomics: order-independent result
 }
 
-// Fallback: the same select over the full rasters (only bands whose pivots missed); PASS 1 also redoes nothing else.
+// Fallback: the same select over the full rasters (only bands whose pivots missed).  grid z = raster: 16 KB of LDS per
+// workgroup -- these kernels are launched for every block and exit at once in the usual case, but a workgroup has to be
+// PLACED before it can exit, and with 32 KB each they queued behind the fit kernels of the other streams.
 template <int LEVEL>
 __global__ void __launch_bounds__(NORM_THREADS) norm_full_hist_kernel(const NormArgs a, NormWS* __restrict__ ws_all) {
     constexpr int NB = LEVEL == 0 ? L1_BINS : (LEVEL == 1 ? L2_BINS : L3_BINS);
-    __shared__ unsigned hist[4 * NB];
-    const int band = blockIdx.y;
+    __shared__ unsigned hist[2 * NB];
+    const int band = blockIdx.y, q = blockIdx.z;
     NormWS& ws = ws_all[band];
     if (ws.done || !ws.fallback) return;
-    for (int i = threadIdx.x; i < 4 * NB; i += NORM_THREADS) hist[i] = 0;
+    for (int i = threadIdx.x; i < 2 * NB; i += NORM_THREADS) hist[i] = 0;
     __syncthreads();
     const float* __restrict__ sp = a.src + (long long)band * a.band_stride;
     const float* __restrict__ rp = a.ref + (long long)band * a.band_stride;
-    const unsigned pfs[2] = {ws.sel[0][0].prefix, ws.sel[0][1].prefix}, pfr[2] = {ws.sel[1][0].prefix, ws.sel[1][1].prefix};
-    const unsigned kbs = ws.kbase[0], kbr = ws.kbase[1];
-    const int kss = ws.ksh[0], ksr = ws.ksh[1];
+    const unsigned pfx[2] = {ws.sel[q][0].prefix, ws.sel[q][1].prefix};
+    const unsigned kb = ws.kbase[q];  // 0 / 0 on this path (plain keys)
+    const int ksh = ws.ksh[q];
     for (int y = blockIdx.x; y < a.height; y += gridDim.x) {
         const long long row = (long long)y * a.stride;
         for (int x = threadIdx.x; x < a.width; x += NORM_THREADS) {
             const float s = sp[row + x], r = rp[row + x];
-            if (nvalid(s, a.src_nd_mode, a.src_nodata) && nvalid(r, a.ref_nd_mode, a.ref_nodata)) {
-                hist_add(hist, LEVEL, (f2key(s) - kbs) << kss, pfs);  // kbase / ksh are 0 / 0 on this path (plain keys)
-                hist_add(hist + 2 * NB, LEVEL, (f2key(r) - kbr) << ksr, pfr);
-            }
+            if (nvalid(s, a.src_nd_mode, a.src_nodata) && nvalid(r, a.ref_nd_mode, a.ref_nodata))
+                hist_add(hist, LEVEL, (f2key(q ? r : s) - kb) << ksh, pfx);
         }
     }
     __syncthreads();
-    unsigned* gh = LEVEL == 0 ? &ws.hist1[0][0][0] : (LEVEL == 1 ? &ws.hist2[0][0][0] : &ws.hist3[0][0][0]);
-    for (int i = threadIdx.x; i < 4 * NB; i += NORM_THREADS)
+    unsigned* gh = LEVEL == 0 ? &ws.hist1[q][0][0] : (LEVEL == 1 ? &ws.hist2[q][0][0] : &ws.hist3[q][0][0]);
+    for (int i = threadIdx.x; i < 2 * NB; i += NORM_THREADS)
         if (hist[i]) atomicAdd(gh + i, hist[i]);
 }
 
@@ -663,12 +666,12 @@ __global__ void split_hist_kernel(NormWS* __restrict__ ws_all, double* __restric
 hipError_t launch_block_norm_split(const NormArgs& a, void* workspace, double* xchg, double inv_world, int phase,
                                    double* norm_out, hipStream_t stream) {
     NormWS* ws = reinterpret_cast<NormWS*>(workspace);
-    const dim3 bands(a.n_bands), block(NORM_THREADS), gfull(FB_BLOCKS, a.n_bands);
+    const dim3 bands(a.n_bands), block(NORM_THREADS), gfull(FB_BLOCKS, a.n_bands, 2);
     switch (phase) {
     case 0: {
         hipError_t e = hipMemsetAsync(ws, 0, sizeof(NormWS) * (size_t)a.n_bands, stream);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(norm_sample_kernel, bands, dim3(1024), 0, stream, a, ws);
+        hipLaunchKernelGGL(norm_sample_kernel, bands, dim3(SAMPLE_THREADS), 0, stream, a, ws);
         hipLaunchKernelGGL(split_put_shift_kernel, bands, block, 0, stream, ws, xchg);
         break;
     }
@@ -719,14 +722,14 @@ hipError_t launch_block_norm(const NormArgs& a, void* workspace, double* norm_ou
     hipError_t e = hipMemsetAsync(ws, 0, sizeof(NormWS) * (size_t)a.n_bands, stream);
     if (e != hipSuccess) return e;
     const dim3 bands(a.n_bands), block(NORM_THREADS);
-    hipLaunchKernelGGL(norm_sample_kernel, bands, dim3(1024), 0, stream, a, ws);
+    hipLaunchKernelGGL(norm_sample_kernel, bands, dim3(SAMPLE_THREADS), 0, stream, a, ws);
     const dim3 gstream(pass_waves(a.height, a.width), a.n_bands);
     if (a.src_nd_mode == 0 && a.ref_nd_mode == 0)
         hipLaunchKernelGGL(norm_stream_kernel<true>, gstream, dim3(WAVE), 0, stream, a, ws, mid, cap_al);
     else
         hipLaunchKernelGGL(norm_stream_kernel<false>, gstream, dim3(WAVE), 0, stream, a, ws, mid, cap_al);
     hipLaunchKernelGGL(norm_stats_kernel, bands, dim3(STATS_THREADS), 0, stream, ws, norm_out, cap_al);
-    const dim3 gmid(MID_BLOCKS, a.n_bands * 2), gfull(FB_BLOCKS, a.n_bands);
+    const dim3 gmid(MID_BLOCKS, a.n_bands * 2), gfull(FB_BLOCKS, a.n_bands, 2);
     hipLaunchKernelGGL(norm_mid_hist_kernel<0>, gmid, block, 0, stream, ws, mid, cap_al);
     hipLaunchKernelGGL(norm_full_hist_kernel<0>, gfull, block, 0, stream, a, ws);
     hipLaunchKernelGGL(norm_select_kernel<0>, bands, block, 0, stream, ws, norm_out);

@@ -22,3 +22,5 @@ run --model gain-blk-offset --kernel 15 --bands 8
 run --nodata 3
 run --params
 run --model gain --params
+run --nodata 4 --steps 3
+run --model gain-blk-offset --nodata 2
