@@ -14,9 +14,10 @@
 // thread per (column, row chunk) for the scans and one thread per pixel for the search.
 #include "hk_kernels.h"
 
+#include <type_traits>
+
 namespace hk {
 
-constexpr int NONE_Y = 0x7fffffff;
 
 // source = (r2 > thresh) & (gain > 0) & valid (kernel_model.py:363): one byte per pixel.  NaN parameters (masked pixels,
 // degenerate windows) compare false.
@@ -112,18 +113,21 @@ __global__ void __launch_bounds__(256) tie_kernel(unsigned* __restrict__ tie, do
     tie[word] = bits;
 }
 
-__device__ __forceinline__ void quad_check(int& qd2, int& qx, int& qy, int tx, int ty, int ox, int oy,
-                                           const unsigned* __restrict__ tie) {
-    if (ty == NONE_Y) return;
-    const int dx = tx - ox, dy = ty - oy;
-    const int d2 = dx * dx + dy * dy;
-    bool better = d2 < qd2;
-    if (d2 == qd2) better = (tie[d2 >> 5] >> (d2 & 31)) & 1u;  // rare
-    if (better) qd2 = d2, qx = tx, qy = ty;
+// floor(sqrt(n)) for 0 <= n < 2^23 (float32 sqrt is correctly rounded and n is exact in float32; the two corrections cost
+// nothing and make the result independent of that argument)
+__device__ __forceinline__ int isqrt_floor(int n) {
+    int r = (int)__fsqrt_rn((float)n);
+    if (r * r > n) --r;
+    if ((r + 1) * (r + 1) <= n) ++r;
+    return r;
 }
 
-// 8 waves per SIMD (64 VGPRs, three spilled dwords): the search is bound by dependent look-ups, and the step from 6 to 8
-// resident waves was worth 8 % of the whole in-painting branch
+// 8 waves per SIMD: the step from 6 to 8 resident waves was worth 8 % of the whole in-painting branch while the search was
+// bound by dependent look-ups.  With the column table as one 16-bit word per pixel it is bound by its VALU instructions
+// (PMC: busy 90-100 %); hence the lean candidate test below: per quadrant the state is the best squared distance and one packed
+// word (column distance << 8 | row distance), a candidate costs ~8 instructions.  (A second copy of the loop for wave-rows
+// away from the raster's edges, with scalar column distances and unclamped look-ups, cost 18 more VGPRs than it saved
+// instructions.)
 __global__ void __launch_bounds__(256, 8) inpaint_fill_kernel(const float* __restrict__ offset, const unsigned char* __restrict__ flag,
                                                            long long stride, int height, int width, int max_dist,
                                                            const unsigned short* __restrict__ tb,
@@ -135,59 +139,75 @@ __global__ void __launch_bounds__(256, 8) inpaint_fill_kernel(const float* __res
     const long long row = (long long)y * stride;
     const long long i = row + x;
     float out = offset[i];
-    constexpr int G = 5;  // longest group (steps 0..4)
-    unsigned lw[G], rw[G], nlw[G], nrw[G];  // (down << 8) | up distances of the left / right column of each step
-    auto fetch = [&](int first_step, unsigned (&a)[G], unsigned (&c)[G]) {
-#pragma unroll
-        for (int k = 0; k < G; ++k) {
-            const int step = first_step + k;  // steps beyond the bound are clamped into the row and never checked
-            a[k] = tb[row + max(0, x - step)], c[k] = tb[row + min(width - 1, x + step)];
-        }
-    };
     if (!flag[i]) {
         const int none2 = (max_dist + 1) * (max_dist + 1);  // qd = max_dist + 1: "nothing found yet" (a perfect square: no tie)
         int qd2[4] = {none2, none2, none2, none2};
-        int qx[4] = {0, 0, 0, 0}, qy[4] = {0, 0, 0, 0};
+        unsigned qs[4] = {0, 0, 0, 0};  // (column distance << 8) | row distance of the quadrant's source
+        const unsigned short* __restrict__ trow = tb + row;
+        // GDAL's QUAD_CHECK on squared integer distances.  `dist` is the column table's byte: NONE_B (no source in reach)
+        // squares to more than any distance the search accepts and more than the initial (max_dist + 1)^2, so it never wins.
+        auto consider = [&](int q, unsigned dist, int dx2, unsigned dx_hi) {
+            const int c = (int)(dist * dist) + dx2;
+            bool better = c < qd2[q];
+            if (c == qd2[q]) better = (tie[c >> 5] >> (c & 31)) & 1u;  // rare
+            qd2[q] = better ? c : qd2[q];
+            qs[q] = better ? (dx_hi | dist) : qs[q];
+        };
         // Steps are taken in groups that end where GDAL re-derives its search bound (after steps 4, 8, 12, ...): the
-        // bound is constant inside a group, so all of the group's table look-ups (4 per step) are issued before the
+        // bound is constant inside a group, so all of the group's table look-ups (2 per step) are issued before the
         // checks, which then run in the original order (ascending step; left quadrants before right ones).
         // The look-ups of the NEXT group are issued before the checks of the current one (their latency hides behind the
-        // checks; a group that turns out not to be needed costs four cached loads per step and nothing else).
-        int this_max = max_dist;
-        int first = 0;
-        fetch(0, lw, rw);  // (issuing these beside the flag load instead of behind it was measured: no difference)
-        while (first <= this_max) {
-            const int last = min(this_max, first == 0 ? 4 : first + 3);
-            fetch(last + 1, nlw, nrw);
+        // checks; a group that turns out not to be needed costs two cached loads per step and nothing else).
+        {
+            constexpr int G = 5;  // longest group (steps 0..4)
+            unsigned lw[G], rw[G], nlw[G], nrw[G];  // (down << 8) | up distances of the left / right column of each step
+            auto fetch = [&](int first_step, unsigned (&a)[G], unsigned (&c)[G]) {
 #pragma unroll
-            for (int k = 0; k < G; ++k) {
-                const int step = first + k;
-                if (step <= last) {
-                    const int lx = max(0, x - step), rx = min(width - 1, x + step);
-                    const int lt = lw[k] & 0xffu, lb = lw[k] >> 8, rt = rw[k] & 0xffu, rb = rw[k] >> 8;
-                    quad_check(qd2[0], qx[0], qy[0], lx, lt == (int)NONE_B ? NONE_Y : y - lt, x, y, tie);  // top left
-                    quad_check(qd2[1], qx[1], qy[1], lx, lb == (int)NONE_B ? NONE_Y : y + lb, x, y, tie);  // bottom left
-                    if (step != 0) {
-                        quad_check(qd2[2], qx[2], qy[2], rx, rt == (int)NONE_B ? NONE_Y : y - rt, x, y, tie);  // top right
-                        quad_check(qd2[3], qx[3], qy[3], rx, rb == (int)NONE_B ? NONE_Y : y + rb, x, y, tie);  // bottom right
+                for (int k = 0; k < G; ++k) {
+                    const int step = first_step + k;
+                    // columns past the raster are clamped into it (GDAL re-checks the edge column)
+                    a[k] = trow[max(0, x - step)], c[k] = trow[min(width - 1, x + step)];
+                }
+            };
+            int this_max = max_dist;
+            int first = 0;
+            fetch(0, lw, rw);  // (issuing these beside the flag load instead of behind it was measured: no difference)
+            while (first <= this_max) {
+                const int last = min(this_max, first == 0 ? 4 : first + 3);
+                fetch(last + 1, nlw, nrw);
+#pragma unroll
+                for (int k = 0; k < G; ++k) {
+                    const int step = first + k;
+                    if (step <= last) {
+                        // column distances (clamped columns: the distance to the edge column)
+                        const int dl = min(step, x), dr = min(step, width - 1 - x);
+                        const int dl2 = dl * dl, dr2 = dr * dr;
+                        consider(0, lw[k] & 0xffu, dl2, (unsigned)dl << 8);  // top left
+                        consider(1, lw[k] >> 8, dl2, (unsigned)dl << 8);     // bottom left
+                        if (step != 0) {
+                            consider(2, rw[k] & 0xffu, dr2, (unsigned)dr << 8);  // top right
+                            consider(3, rw[k] >> 8, dr2, (unsigned)dr << 8);     // bottom right
+                        }
                     }
                 }
-            }
-            // no farther column can beat every quadrant's current distance: floor(max qd) = floor(sqrt(max qd2))
-            if (last >= 4 && (last & 3) == 0)
-                this_max = (int)floor(sqrt((double)max(max(qd2[0], qd2[1]), max(qd2[2], qd2[3]))));
-            first = last + 1;
+                // no farther column can beat every quadrant's current distance: floor(max qd) = floor(sqrt(max qd2))
+                if (last >= 4 && (last & 3) == 0) this_max = isqrt_floor(max(max(qd2[0], qd2[1]), max(qd2[2], qd2[3])));
+                first = last + 1;
 #pragma unroll
-            for (int k = 0; k < G; ++k) lw[k] = nlw[k], rw[k] = nrw[k];
+                for (int k = 0; k < G; ++k) lw[k] = nlw[k], rw[k] = nrw[k];
+            }
         }
         double wsum = 0.0, vsum = 0.0;
         bool has = false;
+#pragma unroll
         for (int q = 0; q < 4; ++q) {
             if (qd2[q] <= max_dist * max_dist) {  // qd <= max_dist
                 const double w = wtab[qd2[q]];
                 has = w != 0.0;
                 wsum += w;
-                vsum += (double)offset[(long long)qy[q] * stride + qx[q]] * w;
+                const int dx = (int)(qs[q] >> 8), dy = (int)(qs[q] & 0xffu);
+                const int sx = q < 2 ? x - dx : x + dx, sy = (q & 1) ? y + dy : y - dy;
+                vsum += (double)offset[(long long)sy * stride + sx] * w;
             }
         }
         if (has) out = (float)(vsum / wsum);
