@@ -11,15 +11,20 @@
 // are EXACT.  numpy runs the same statistics in float32 pairwise arithmetic; the two agree to ~5e-7 relative.
 //
 // ONE streaming pass over src+ref (8 B per pixel, HBM-bound) instead of a sort:
-//   1. sample:  a 4096-pixel strided sample per band is sorted in one workgroup; it yields the shift of the moment
-//               sums and, per raster, two pivots that bracket the 1st percentile (+-4 sigma of the sample quantile);
+//   1. sample:  a 4096-pixel stratified sample per band, taken by one small workgroup: its mean is the shift of the moment
+//               sums and, per raster, two of its order statistics (an LDS radix select) are the pivots that bracket the
+//               1st percentile (+-4 sigma of the sample quantile);
 //   2. pass:    every wave streams its 1 KB chunks: count, shifted first/second moments, number of values below the low
 //               pivot, and the ~1 % of values between the pivots compacted through lane-private LDS queues into a
 //               small HBM buffer (one global atomic per flush of the wave's queues);
 //   3. select:  the two ranks are resolved inside the compacted buffer by a 3-level radix select (11+11+10 bits of the
-//               order-preserving uint32 image of the float) -- integer histograms only, so the result is deterministic.
+//               order-preserving uint32 image of the float, taken relative to the pivot window) -- integer histograms only,
+//               so the result is deterministic.
 // If the pivots miss (or the buffer overflows) a device-side flag routes the band through the same radix select over
 // the full rasters (three more passes); those kernels are always launched and exit immediately otherwise.
+// Every kernel here is sized to be PLACED beside the fit kernels of other streams (<= 24 KB of LDS per workgroup): a block's
+// statistics are a chain of dependent launches, and a workgroup that has to wait for a CU to drain stalls the whole chain.
+// launch_block_norm_split(): the same statistics for a block whose rows are spread over several ranks (see there).
 #include "hk_kernels.h"
 
 #include <type_traits>
@@ -29,7 +34,7 @@ namespace hk {
 constexpr int NORM_THREADS = 256;
 constexpr int L1_BITS = 11, L2_BITS = 11, L3_BITS = 10;
 constexpr int L1_BINS = 1 << L1_BITS, L2_BINS = 1 << L2_BITS, L3_BINS = 1 << L3_BITS;
-constexpr int SAMPLE_N = 4096;     // sample size per band (sorted in LDS by one workgroup)
+constexpr int SAMPLE_N = 4096;     // sample size per band
 constexpr int PASS_WAVES = 2048;   // most waves per band in the streaming pass (= the number of partial sums kept)
 constexpr int FB_BLOCKS = 512;     // workgroups per band of the fallback passes
 constexpr int MID_BLOCKS = 256;    // workgroups per compacted buffer of the regular select passes
