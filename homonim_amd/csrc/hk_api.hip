@@ -290,11 +290,12 @@ static bool cert_only_eligible(const hk::FitArgs& a, const hk_fit_desc* desc) {
     return desc->model == HK_MODEL_GAIN_OFFSET && a.has_thresh && a.fail_count && !a.r2 && !a.offset_in && !a.flag;
 }
 
-// `pre_offset` / `pre_flag` (both or neither): offsets and source flags (r2 > thresh) & (gain > 0) & valid left by the pass
+// `n_fail`: the band's r2-mask failure count.  `pre_offset` / `pre_flag` (both or neither): offsets and source flags (r2 > thresh) & (gain > 0) & valid left by the pass
 // that counted the failures (FitArgs::flag) -- the in-painting then starts right away.  `drop_params`: the parameter
 // planes in `a` are scratch, the closing pass need not write them.
 static int inpaint_band(Slot& sl, const hk::FitArgs& a, const hk_fit_desc* desc, bool r2, size_t plane,
-                        bool drop_params = false, const float* pre_offset = nullptr, const unsigned char* pre_flag = nullptr) {
+                        unsigned long long n_fail, bool drop_params = false, const float* pre_offset = nullptr,
+                        const unsigned char* pre_flag = nullptr) {
     {
         const int rc = ensure_inpaint_scratch(sl, plane, a.height, a.stride);
         if (rc) return rc;
@@ -316,8 +317,9 @@ static int inpaint_band(Slot& sl, const hk::FitArgs& a, const hk_fit_desc* desc,
         HK_HIP(hk::launch_fit_apply(b, desc->model, r2, sl.stream));
         po = scratch_off, flags = b.flag;
     }
+    // n_fail (the failing VALID pixels) is a lower bound of the pixels to fill (nodata pixels are filled as well)
     HK_HIP(hk::launch_inpaint_offsets(po, pg, pr, desc->r2_thresh, a.stride, a.height, a.width, aux + 4 * plane, filled,
-                                      sl.stream, flags));
+                                      sl.stream, flags, n_fail));
     hk::FitArgs c = a;
     c.offset_in = filled;
     c.fail_count = nullptr;  // already counted
@@ -363,7 +365,7 @@ int fit_finish(hk_ctx* ctx, Slot& sl, const hk_fit_desc* desc, FitPending& p, un
     }
     ctx->expect_r2_failures.store(n_fail > 0 ? 1 : 0);
     if (n_fail > 0) {
-        const int rc = inpaint_band(sl, a, desc, r2, plane, p.scratch_params, a.flag ? a.offset : nullptr, a.flag);
+        const int rc = inpaint_band(sl, a, desc, r2, plane, n_fail, p.scratch_params, a.flag ? a.offset : nullptr, a.flag);
         if (rc) return rc;
         *requeued = true;
     }
@@ -1174,7 +1176,7 @@ int hk_inpaint_dev_counts(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job
         }
         total += n_fail;
         if (n_fail == 0) continue;
-        rc = inpaint_band(sl, a, desc, r2, plane, false, pre_off, pre_flag);
+        rc = inpaint_band(sl, a, desc, r2, plane, n_fail, false, pre_off, pre_flag);
         if (rc) return rc;
     }
     if (retried) ctx->cert_only_retried();

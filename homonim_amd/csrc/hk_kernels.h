@@ -124,10 +124,11 @@ hipError_t launch_partial_mask(const float* in, int nd_mode, float nodata, const
 size_t inpaint_workspace_bytes(int height, long long stride);
 // `flag_ready` (nullable): source flags already written by the fit kernel (FitArgs::flag; 1 byte per pixel, row stride
 // `stride`) -- gain / r2 are then not read.  inpaint_flag_plane(): the workspace's own flag plane, for a fit to write into.
+// `n_targets`: the number of pixels to fill if the caller knows it (0 = unknown): picks the search kernel's lane mapping.
 unsigned char* inpaint_flag_plane(void* workspace, int height, long long stride);
 hipError_t launch_inpaint_offsets(const float* offset, const float* gain, const float* r2, float thresh, long long stride,
                                   int height, int width, void* workspace, float* filled, hipStream_t stream,
-                                  const unsigned char* flag_ready = nullptr);
+                                  const unsigned char* flag_ready = nullptr, unsigned long long n_targets = 0);
 
 // Re-sampling between axis-aligned grids (hk_resample.hip).  mode = rasterio.enums.Resampling value (0, 1, 3, 5).
 hipError_t launch_resample(int mode, const float* src, long long src_stride, long long src_band_stride, int sh, int sw,
