@@ -87,3 +87,30 @@ def test_bench_joins_an_rccl_group_of_one():
     line = json.loads(run.stdout.strip().splitlines()[-1])
     assert line['n_gpus'] == 1 and line['value'] > 0 and line['parity_spot_check']['passed']
     assert line.get('dist_backend') == 'nccl'
+
+
+@pytest.mark.parametrize('config', [1, 3])
+def test_bench_with_two_ranks(config):
+    """ `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` as the driver launches it, the two ranks sharing
+    this box's GPU over gloo: config 1 = one raster per rank (weak scaling, the value counts both), config 3 = the block
+    positions split between the ranks (strong scaling).  Rank 0 prints the one JSON line. """
+    import json
+    env = dict(os.environ, HOMONIM_AMD_DIST_BACKEND='gloo', MASTER_ADDR='127.0.0.1', PYTHONPATH=REPO)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(29700 + (os.getpid() + config) % 200), os.path.join(REPO, 'bench.py'), '--gpus', '2',
+           '--config', str(config), '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--no-end-to-end']
+    if config == 3:
+        cmd += ['--size', '8192', '--bands', '2']
+    run = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert run.returncode == 0, run.stderr[-3000:]
+    lines = [ln for ln in run.stdout.strip().splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['value'] > 0 and line['parity_spot_check']['passed']
+    assert line['scaling'] == ('weak' if config == 1 else 'strong') and line['dist_backend'] == 'gloo'
+
+
+def test_bench_refuses_a_rank_count_that_disagrees_with_the_launch():
+    run = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '1'],
+                         env=dict(os.environ, PYTHONPATH=REPO), capture_output=True, text=True, timeout=120)
+    assert run.returncode == 2 and 'torch.distributed.run' in run.stderr
