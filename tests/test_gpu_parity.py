@@ -583,6 +583,51 @@ def test_block_norm_heavy_ties_take_the_fallback_select(ctx):
     assert n2[0] == pytest.approx(e2[0], rel=2e-6) and n2[1] == pytest.approx(e2[1], rel=2e-6, abs=1e-6)
 
 
+@pytest.mark.parametrize('seed', range(40))
+def test_block_norm_randomized_vs_numpy(ctx, seed):
+    """ Block statistics on random shapes (one pixel to a few hundred thousand, widths that are no multiple of 4), the three
+    nodata kinds, continuous / integer-valued (ties: both select paths) / nearly constant data: std ratio and interpolated
+    1st percentile against the numpy restatement of _fit_block_norm (kernel_model.py:216-229). """
+    rng = np.random.default_rng(7000 + seed)
+    h, w = int(rng.integers(1, 500)), int(rng.integers(1, 900))
+    kind = rng.integers(4)
+    if kind == 0:
+        src = rng.uniform(0.05, 1, (h, w))
+    elif kind == 1:
+        src = rng.integers(0, int(rng.choice([4, 40, 255])), (h, w)).astype(float)     # ties
+    elif kind == 2:
+        src = 100 + 1e-3 * rng.normal(size=(h, w))                                      # large mean, tiny spread
+    else:
+        src = np.exp(rng.normal(0, 3, (h, w)))                                          # heavy tail
+    ref = (0.5 + rng.random()) * src + rng.random() + 0.05 * src.std() * rng.normal(size=(h, w))
+    src, ref = src.astype(np.float32), ref.astype(np.float32)
+    nodata = {}
+    for name, arr in (('src', src), ('ref', ref)):
+        k = rng.integers(3)
+        holes = rng.random((h, w)) < [0.0, 0.01, 0.3][rng.integers(3)]
+        nodata[name] = [None, np.nan, -7.0][k]
+        if k:
+            arr[holes] = nodata[name]
+    desc = _hk.make_desc('gain-blk-offset', (5, 5), False, None, nodata['src'], nodata['ref'])
+    norm = ctx.block_norm(desc, src, ref)
+    exp = onp.fit_block_norm(src, nodata['src'], ref, nodata['ref'])
+    what = f'{h}x{w} kind={kind} nodata={nodata}'
+    if not np.isfinite(exp).all() or exp[0] == 0:
+        # degenerate statistics (no valid pixel -> zeros; zero variance -> inf / nan): same class of result
+        assert (np.isfinite(norm) == np.isfinite(exp)).all(), what
+        if np.isfinite(exp).all():
+            assert norm == pytest.approx(exp, rel=2e-6, abs=1e-12), what
+        return
+    tol = 2e-6 if kind != 2 else 2e-3   # float32 pairwise std of "100 + 1e-3 noise" in numpy itself carries ~1e-4
+    assert norm[0] == pytest.approx(exp[0], rel=tol), what
+    # norm[1] = pct(ref) - pct(src) * norm[0] cancels: the tolerance is relative to its two terms
+    valid = np.ones((h, w), bool)
+    for arr, nd in ((src, nodata['src']), (ref, nodata['ref'])):
+        valid &= ~np.isnan(arr) if (nd is not None and np.isnan(nd)) else (np.ones((h, w), bool) if nd is None else arr != nd)
+    terms = abs(float(np.percentile(ref[valid], 1))) + abs(float(np.percentile(src[valid], 1)) * exp[0])
+    assert norm[1] == pytest.approx(exp[1], rel=tol, abs=tol * terms + 1e-12), what
+
+
 def test_pinned_arrays_and_caller_outputs(ctx):
     """ Pinned (page-locked) inputs/outputs through the host-pointer path give the same bytes as pageable ones. """
     src, ref = onp.synth_pair(333, 517, 9, 'frame+holes')
