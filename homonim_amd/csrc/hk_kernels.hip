@@ -482,8 +482,18 @@ struct ColSums {
 //      global memory -- tall kernels: a full ring would cut occupancy to one wave per SIMD, re-loading BOTH rows makes
 //      three streams that all miss L2 and the kernel fabric-bound;
 //   0  both re-loaded (very tall kernels whose centre ring would not fit either).
-template <int MODEL, bool R2, int RW, bool DENSE, int RING, bool CERT_ONLY>
-__global__ void __launch_bounds__(WAVE, (CERT_ONLY && RW >= 0 && RW <= 3) ? 4
+// WPB = waves per workgroup.  The memory-bound builds with a full LDS ring (gain, gain-blk-offset without R2, short kernels)
+// put HK_WPB_MEM ADJACENT STRIPS of one segment into a workgroup and keep them in lock-step with a barrier per row: the
+// workgroup then reads and writes 4 KB of every row together instead of 1 KB per wave at unrelated times, which the HBM
+// pays back -- strip-march pattern without arithmetic 4 720 -> 4 910 GB/s (tools/ubench_strips.hip); gain 5x5 at 16384^2
+// 2.70 -> 2.55 ms, gain-blk-offset 5x5 4.57 -> 4.34 ms (8 waves: 2.51 / 4.38; configs[1]'s smaller raster prefers 4).
+// Not for the VALU-bound gain-offset builds (their waves would only wait for each other: 0 to +2 %) and not for the tall
+// kernels that re-load their leaving rows (15x15: +14 %, the re-loads of a whole workgroup then collide).
+#ifndef HK_WPB_MEM
+#define HK_WPB_MEM 4
+#endif
+template <int MODEL, bool R2, int RW, bool DENSE, int RING, bool CERT_ONLY, int WPB>
+__global__ void __launch_bounds__(WAVE * WPB, (CERT_ONLY && RW >= 0 && RW <= 3) ? 4
                                         : ((MODEL == 2 && R2 && !DENSE && (RW < 0 || RW >= 4)) ? HK_FIT_MIN_WAVES_WIDE : HK_FIT_MIN_WAVES))
 fit_apply_kernel(const FitArgs a) {
     using CS = ColSums<MODEL, R2, DENSE>;
@@ -500,19 +510,22 @@ fit_apply_kernel(const FitArgs a) {
     static_assert(!(DENSE && MODEL == 1), "gain-blk-offset re-derives its mask from the normalised source");
     extern __shared__ float4 lds4[];
 
-    const int lane = threadIdx.x;
-    int unit = blockIdx.x;
+    const int lane = threadIdx.x & (WAVE - 1), wave_in_wg = threadIdx.x >> 6;
+    // a workgroup = WPB adjacent strips of one (segment, band); the strips of a row are padded to a multiple of WPB (a padded
+    // strip lies outside the raster: every lane loads a clamped quad and stores nothing -- it only keeps the barriers whole)
+    const int groups_per_row = (a.n_strips + WPB - 1) / WPB;
+    int group = blockIdx.x;
     if (a.xcd_remap) {
         // workgroups go round-robin to the 8 XCDs (each with its own L2): hand every XCD runs of `xcd_remap` consecutive
         // units, i.e. neighbouring strips of one segment, whose shared cache lines (strips start 16-byte-, not 128-byte-
         // aligned, and overlap by two lanes) are then fetched from HBM once instead of once per strip
-        const int g = a.xcd_remap, slot = blockIdx.x >> 3;
-        unit = ((slot / g) * 8 + (blockIdx.x & 7)) * g + slot % g;
+        const int g = a.xcd_remap / WPB > 0 ? a.xcd_remap / WPB : 1, slot = blockIdx.x >> 3;
+        group = ((slot / g) * 8 + (blockIdx.x & 7)) * g + slot % g;
     }
-    if (unit >= a.total_units) return;
+    if (group >= groups_per_row * a.n_segs * a.n_bands) return;  // the whole workgroup
     // segment-major order: the short tail segments (hk_api.hip fill_grid) are dispatched last
-    const int strip = unit % a.n_strips;
-    const int t0 = unit / a.n_strips;
+    const int strip = (group % groups_per_row) * WPB + wave_in_wg;
+    const int t0 = group / groups_per_row;
     const int band = t0 % a.n_bands;
     const int seg = t0 / a.n_bands;
 
@@ -566,7 +579,8 @@ fit_apply_kernel(const FitArgs a) {
     // kh - 1 rows (8 KB instead of 10 KB per wave at 5x5 = 20 instead of 16 waves per CU).
     constexpr bool RING_AHEAD = ring && MODEL != 2 && !R2;
     const int ring_rows = ring ? (RING_AHEAD ? (kh > 1 ? kh - 1 : 1) : kh) : (cring ? rh + 1 : 0);
-    float4* ring_v = lds4;  // RING 1: [slot][s|r][lane]; RING 2: [slot][lane] (s only)
+    // RING 1: [slot][s|r][lane]; RING 2: [slot][lane] (s only); one ring per wave of the workgroup
+    float4* ring_v = lds4 + (size_t)wave_in_wg * (size_t)(ring_rows * (ring ? 2 : 1) * WAVE);
     // slots start as rows that were never added: zero contribution, no valid pixel
     const float ring_init = DENSE ? 0.f : __uint_as_float(RING_SENTINEL);
     for (int sl = 0; sl < ring_rows; ++sl) {
@@ -678,6 +692,10 @@ fit_apply_kernel(const FitArgs a) {
     int slot_c = ring_mod - rh;  // slot of the centre row of the output produced at this iteration: (slot - rh) mod ring_mod
     if (slot_c >= ring_mod) slot_c -= ring_mod;
     for (int t = t_first; t <= t_last; ++t) {
+        if constexpr (WPB > 1) {
+            // lock-step: the workgroup's strips move down the rows together (same segment: same trip count in every wave)
+            __syncthreads();
+        }
 
         // rows that do not come from LDS: issue their loads now, consume them after the entering row has been folded in
         // (the leaving row t - kh is a zero row if it was never added; the centre row is t - rh)
@@ -1105,18 +1123,30 @@ size_t fit_lds_bytes(int kh, int ring_mode, bool ahead) {
     return 0;
 }
 
-template <int MODEL, bool R2, int RW, bool DENSE, int RING, bool CERT_ONLY>
-static hipError_t launch_build(const FitArgs& a, hipStream_t stream) {
-    const size_t lds = fit_lds_bytes(2 * a.rh + 1, RING, RING == 1 && MODEL != 2 && !R2);
-    if (lds > 64 * 1024) {  // forced LDS ring on a tall kernel (testing): raise the 64 KiB dynamic-LDS default
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fit_apply_kernel<MODEL, R2, RW, DENSE, RING, CERT_ONLY>),
+template <int MODEL, bool R2, int RW, bool DENSE, int RING, bool CERT_ONLY, int WPB>
+static hipError_t launch_wpb(const FitArgs& a, size_t lds, hipStream_t stream) {
+    if (lds * WPB > 64 * 1024) {  // forced LDS ring on a tall kernel (testing): raise the 64 KiB dynamic-LDS default
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fit_apply_kernel<MODEL, R2, RW, DENSE, RING, CERT_ONLY, WPB>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
     }
-    int grid = a.total_units;
-    if (a.xcd_remap) grid = (grid + 8 * a.xcd_remap - 1) / (8 * a.xcd_remap) * (8 * a.xcd_remap);
-    hipLaunchKernelGGL((fit_apply_kernel<MODEL, R2, RW, DENSE, RING, CERT_ONLY>), dim3(grid), dim3(WAVE), lds, stream, a);
+    int grid = (a.n_strips + WPB - 1) / WPB * a.n_segs * a.n_bands;  // workgroups of WPB adjacent strips
+    if (a.xcd_remap) {
+        const int g = a.xcd_remap / WPB > 0 ? a.xcd_remap / WPB : 1;
+        grid = (grid + 8 * g - 1) / (8 * g) * (8 * g);
+    }
+    hipLaunchKernelGGL((fit_apply_kernel<MODEL, R2, RW, DENSE, RING, CERT_ONLY, WPB>), dim3(grid), dim3(WAVE * WPB), lds * WPB,
+                       stream, a);
     return hipGetLastError();
+}
+
+template <int MODEL, bool R2, int RW, bool DENSE, int RING, bool CERT_ONLY>
+static hipError_t launch_build(const FitArgs& a, hipStream_t stream) {
+    const size_t lds = fit_lds_bytes(2 * a.rh + 1, RING, RING == 1 && MODEL != 2 && !R2);
+    if constexpr (MODEL != 2 && !R2 && RING == 1 && HK_WPB_MEM > 1) {
+        if (lds * HK_WPB_MEM <= 64 * 1024) return launch_wpb<MODEL, R2, RW, DENSE, RING, CERT_ONLY, HK_WPB_MEM>(a, lds, stream);
+    }
+    return launch_wpb<MODEL, R2, RW, DENSE, RING, CERT_ONLY, 1>(a, lds, stream);
 }
 
 // gain-offset with the r2 mask exists in two builds.  The FULL one carries the reference's R2 expression inline for the

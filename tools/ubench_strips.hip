@@ -16,7 +16,7 @@ struct Args {
     int seg, n_strips, n_segs, total_units, remap, rh;
 };
 
-template <int WAVES, int DEPTH, bool NT_LD, bool NT_ST>
+template <int WAVES, int DEPTH, bool NT_LD, bool NT_ST, int SYNC = 0>
 __global__ void __launch_bounds__(64 * WAVES) strips(const Args a) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int ublock = blockIdx.x;
@@ -25,7 +25,7 @@ __global__ void __launch_bounds__(64 * WAVES) strips(const Args a) {
         ublock = ((slot / g) * 8 + (blockIdx.x & 7)) * g + slot % g;
     }
     const int unit = ublock * WAVES + w;
-    if (unit >= a.total_units) return;
+    if (unit >= a.total_units && !SYNC) return;  // (the lock-step variants keep every wave: their loads are clamped)
     const int strip = unit % a.n_strips, t0 = unit / a.n_strips, band = t0 % a.n_bands, seg = t0 / a.n_bands;
     const int x = (strip * 62 + lane - 1) * 4;
     const int y0 = seg * a.seg, y1 = min(y0 + a.seg, a.height);
@@ -52,6 +52,9 @@ __global__ void __launch_bounds__(64 * WAVES) strips(const Args a) {
     for (int d = 0; d < DEPTH; ++d) { qs[d] = ld(sp, min(t_first + d, t_last)); qr[d] = ld(rp, min(t_first + d, t_last)); }
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int t = t_first; t <= t_last; ++t) {
+        if constexpr (SYNC > 0) {  // the workgroup's waves (adjacent strips) stay within SYNC rows of each other
+            if (((t - t_first) & (SYNC - 1)) == 0) __syncthreads();
+        }
         const float4 s = qs[0], r = qr[0];
 #pragma unroll
         for (int d = 0; d + 1 < DEPTH; ++d) { qs[d] = qs[d + 1]; qr[d] = qr[d + 1]; }
@@ -59,7 +62,7 @@ __global__ void __launch_bounds__(64 * WAVES) strips(const Args a) {
         qr[DEPTH - 1] = ld(rp, min(t + DEPTH, t_last));
         acc.x += s.x * r.x; acc.y += s.y * r.y; acc.z += s.z * r.z; acc.w += s.w * r.w;
         const int y = t - a.rh;
-        if (y >= y0 && out_lane) {
+        if (y >= y0 && out_lane && unit < a.total_units) {
             float4* p = reinterpret_cast<float4*>(reinterpret_cast<char*>(op + (long long)y * a.stride) + (unsigned)x * 4u);
             const float4 c = make_float4(acc.x + s.x, acc.y + s.y, acc.z + s.z, acc.w + s.w);
             if constexpr (NT_ST) {
@@ -79,16 +82,16 @@ __global__ void __launch_bounds__(256) flat_copy(const float4* __restrict__ s, c
     }
 }
 
-template <int WAVES, int DEPTH, bool NT_LD, bool NT_ST>
+template <int WAVES, int DEPTH, bool NT_LD, bool NT_ST, int SYNC = 0>
 float run(Args a, int reps) {
     a.total_units = a.n_strips * a.n_segs * a.n_bands;
     int blocks = (a.total_units + WAVES - 1) / WAVES;
     if (a.remap) blocks = (blocks + 8 * a.remap - 1) / (8 * a.remap) * (8 * a.remap);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL((strips<WAVES, DEPTH, NT_LD, NT_ST>), dim3(blocks), dim3(64 * WAVES), 0, 0, a);
+    hipLaunchKernelGGL((strips<WAVES, DEPTH, NT_LD, NT_ST, SYNC>), dim3(blocks), dim3(64 * WAVES), 0, 0, a);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((strips<WAVES, DEPTH, NT_LD, NT_ST>), dim3(blocks), dim3(64 * WAVES), 0, 0, a);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((strips<WAVES, DEPTH, NT_LD, NT_ST, SYNC>), dim3(blocks), dim3(64 * WAVES), 0, 0, a);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     CHECK(hipGetLastError());
@@ -158,6 +161,13 @@ int main(int argc, char** argv) {
                 line("1 wave/WG depth 1", run<1, 1, false, false>(a, 10));
                 line("1 wave/WG depth 2 nt stores", run<1, 2, false, true>(a, 10));
                 line("4 waves/WG depth 2 nt stores", run<4, 2, false, true>(a, 10));
+                if (stride == W && remap == 16) {
+                    line("4 waves/WG lock-step 1 row", run<4, 2, false, true, 1>(a, 10));
+                    line("4 waves/WG lock-step 4 rows", run<4, 2, false, true, 4>(a, 10));
+                    line("8 waves/WG lock-step 4 rows", run<8, 2, false, true, 4>(a, 10));
+                    line("16 waves/WG lock-step 4 rows", run<16, 2, false, true, 4>(a, 10));
+                    line("16 waves/WG free", run<16, 2, false, true>(a, 10));
+                }
             }
         }
     }
