@@ -217,9 +217,18 @@ void fill_args(hk::FitArgs& a, const hk_fit_desc* d, int xcd_remap) {
     // ring mode (hk_kernels.hip): full LDS ring while it leaves room for >= 11 waves per CU (kh <= 5), centre-only ring up
     // to kh = 17 (<= 12.5 KB per wave), everything re-loaded beyond
     a.use_ring = (d->kh <= 5 && d->kw <= 7) ? 1 : (d->kh <= 17 ? 2 : 0);
+    // The memory-bound builds (no R2) prefer the full ring well beyond that: re-loading the leaving rows costs them more than
+    // the waves the ring displaces -- gain 7x7 / 9x9 / 11x11 / 15x15 at 16384^2 x 4: 3.25 / 3.40 / 3.45 / 3.95 -> 2.54 / 2.58 /
+    // 2.77 / 3.64 ms; gain-blk-offset (more arithmetic per pixel) only up to 7x7 (fit + statistics 5.11 -> 4.61 ms; 9x9 equal,
+    // 15x15 +21 %)
+    if (!needs_r2(d) && d->kw <= 15) {
+        if (d->model == HK_MODEL_GAIN && d->kh <= 15) a.use_ring = 1;
+        if (d->model == HK_MODEL_GAIN_BLK_OFFSET && d->kh <= 7 && d->kw <= 7) a.use_ring = 1;
+    }
     if (const char* e = getenv("HK_USE_RING")) {  // testing hook
         const int m = atoi(e);
-        if (m == 1 && d->kh <= 63 && d->kw <= 7) a.use_ring = 1;
+        const bool mem_bound = d->model != HK_MODEL_GAIN_OFFSET && !needs_r2(d);
+        if (m == 1 && d->kh <= 63 && (d->kw <= 7 || (mem_bound && d->kw <= 15))) a.use_ring = 1;
         if (m == 2 && d->kh <= 127) a.use_ring = 2;
         if (m == 0) a.use_ring = 0;
     }

@@ -1178,6 +1178,15 @@ static hipError_t launch_rw(const FitArgs& a, hipStream_t stream) {
             case 3: return launch_one<MODEL, R2, 3, DENSE, 1>(a, stream);
             default: break;
         }
+        if constexpr (MODEL != 2 && !R2) {  // the memory-bound builds keep the full ring for wider kernels too (hk_api.hip)
+            switch (a.rw) {
+                case 4: return launch_one<MODEL, R2, 4, DENSE, 1>(a, stream);
+                case 5: return launch_one<MODEL, R2, 5, DENSE, 1>(a, stream);
+                case 6: return launch_one<MODEL, R2, 6, DENSE, 1>(a, stream);
+                case 7: return launch_one<MODEL, R2, 7, DENSE, 1>(a, stream);
+                default: break;
+            }
+        }
     }
     if (a.use_ring == 0) return launch_one<MODEL, R2, -1, DENSE, 0>(a, stream);
     switch (a.rw) {
