@@ -132,7 +132,7 @@ int ensure_dev(Slot& s, size_t bytes) {
 }
 
 // rasterio.enums.Resampling values with a device kernel (hk_resample.hip)
-bool resampling_built(int m) { return m == 0 || m == 1 || m == 2 || m == 3 || m == 4 || m == 5 || m == 8 || m == 9 || m == 13 || m == 14; }
+bool resampling_built(int m) { return (m >= 0 && m <= 6) || (m >= 8 && m <= 14); }  // all of GRA_* but gauss (7: not a warp method)
 
 bool needs_r2(const hk_fit_desc* d) {
     return d->find_r2 || (d->model == HK_MODEL_GAIN_OFFSET && d->has_r2_thresh);
@@ -892,8 +892,8 @@ int hk_reproject(hk_ctx* ctx, const float* src, int32_t n_bands, int32_t src_hei
         return fail(HK_ERR_ARG, "empty raster");
     if (!(kx > 0.0) || !(ky > 0.0)) return fail(HK_ERR_UNSUPPORTED, "flipped or degenerate grid mapping");
     if (!resampling_built(resampling))
-        return fail(HK_ERR_UNSUPPORTED, "resampling %d is not built (nearest, bilinear, cubic, cubic_spline, lanczos, "
-                                        "average, max, min, sum, rms are; mode, gauss, med, q1, q3 are not)", resampling);
+        return fail(HK_ERR_UNSUPPORTED, "resampling %d is not a warp method (GRA_* codes 0..6 and 8..14 are built; 7 = gauss is "
+                                        "an overview-only method in GDAL / rasterio as well)", resampling);
     if (dst_height > 65535) return fail(HK_ERR_UNSUPPORTED, "destination taller than 65535 rows");
     HK_HIP(hipSetDevice(ctx->device));
     const size_t sbytes = (size_t)n_bands * src_height * src_width * 4, dbytes = (size_t)n_bands * dst_height * dst_width * 4;

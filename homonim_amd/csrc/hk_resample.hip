@@ -94,6 +94,50 @@ __global__ void __launch_bounds__(256) resample_kernel(const ResampleArgs a) {
                 got = true;
             }
         }
+    } else if constexpr (MODE == 6 || MODE == 10 || MODE == 11 || MODE == 12) {
+        // GWKAverageOrMode's rank-order branches over the same footprint as `average` (no weights): med / q1 / q3 = element
+        // ceil(q * n - 1) of the sorted valid values; mode = the value whose running count first reaches the highest
+        // count, in row-major scan order.  No per-thread storage: the footprint (a few dozen pixels, cache-resident) is
+        // scanned once per candidate.
+        const double y0 = fmax(a.ky * (double)i + a.oy, 0.0), y1 = fmin(a.ky * (double)(i + 1) + a.oy, (double)a.sh);
+        const double x0 = fmax(a.kx * (double)j + a.ox, 0.0), x1 = fmin(a.kx * (double)(j + 1) + a.ox, (double)a.sw);
+        int iy0 = (int)floor(y0 + 1e-10), iy1 = (int)ceil(y1 - 1e-10);
+        int ix0 = (int)floor(x0 + 1e-10), ix1 = (int)ceil(x1 - 1e-10);
+        if (iy0 == iy1 && iy1 < a.sh) ++iy1;
+        if (ix0 == ix1 && ix1 < a.sw) ++ix1;
+        if (iy1 > iy0 && iy0 >= 0 && ix1 > ix0 && ix0 >= 0) {
+            int n = 0;
+            for (int yy = iy0; yy < iy1; ++yy)
+                for (int xx = ix0; xx < ix1; ++xx) n += rs_valid(sp[(long long)yy * a.src_stride + xx], a.nd_mode, a.nodata) ? 1 : 0;
+            if (n > 0) {
+                constexpr double q = MODE == 10 ? 0.5 : (MODE == 11 ? 0.25 : 0.75);
+                int want = (int)ceil(q * (double)n - 1.0);
+                want = want < 0 ? 0 : want;
+                int best_cnt = 0, best_last = 0;
+                for (int yc = iy0; yc < iy1 && !(MODE != 6 && got); ++yc) {
+                    for (int xc = ix0; xc < ix1; ++xc) {
+                        const float c = sp[(long long)yc * a.src_stride + xc];
+                        if (!rs_valid(c, a.nd_mode, a.nodata)) continue;
+                        int less = 0, equal = 0, last = 0, pos = 0;
+                        for (int yy = iy0; yy < iy1; ++yy)
+                            for (int xx = ix0; xx < ix1; ++xx, ++pos) {
+                                const float v = sp[(long long)yy * a.src_stride + xx];
+                                if (!rs_valid(v, a.nd_mode, a.nodata)) continue;
+                                less += v < c ? 1 : 0;
+                                if (v == c) ++equal, last = pos;
+                            }
+                        if constexpr (MODE == 6) {
+                            // the value that reaches the highest count first = most occurrences, then earliest last occurrence
+                            if (equal > best_cnt || (equal == best_cnt && last < best_last))
+                                best_cnt = equal, best_last = last, result = (double)c, got = true;
+                        } else if (less <= want && want < less + equal) {
+                            result = (double)c, got = true;
+                            break;
+                        }
+                    }
+                }
+            }
+        }
     } else {
         constexpr int NT = MODE == 1 ? 2 : 4, T0 = MODE == 1 ? 0 : -1;
         const double sy = a.ky * ((double)i + 0.5) + a.oy, sx = a.kx * ((double)j + 0.5) + a.ox;
@@ -448,6 +492,10 @@ hipError_t launch_resample(int mode, const float* src, long long src_stride, lon
             break;
         case 4: hipLaunchKernelGGL(resample_conv_kernel<4>, grid, block, 0, stream, a); break;
         case 5: hipLaunchKernelGGL(resample_kernel<5>, grid, block, 0, stream, a); break;
+        case 6: hipLaunchKernelGGL(resample_kernel<6>, grid, block, 0, stream, a); break;
+        case 10: hipLaunchKernelGGL(resample_kernel<10>, grid, block, 0, stream, a); break;
+        case 11: hipLaunchKernelGGL(resample_kernel<11>, grid, block, 0, stream, a); break;
+        case 12: hipLaunchKernelGGL(resample_kernel<12>, grid, block, 0, stream, a); break;
         case 8: hipLaunchKernelGGL(resample_kernel<8>, grid, block, 0, stream, a); break;
         case 9: hipLaunchKernelGGL(resample_kernel<9>, grid, block, 0, stream, a); break;
         case 13: hipLaunchKernelGGL(resample_kernel<13>, grid, block, 0, stream, a); break;

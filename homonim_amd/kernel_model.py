@@ -15,9 +15,10 @@ Differences a caller can observe (all documented in DESIGN.md):
   pixel fails it the reference's GDAL ``fillnodata`` branch is the identity and results are identical; when some
   fail, the offsets are in-painted on the device by a restatement of GDAL's published fill algorithm (parity with
   GDAL itself unpinned, hk_inpaint.hip) and the gains of the failing pixels are recomputed as in :370-371.
-* ``RefSpaceModel`` / ``SrcSpaceModel`` re-sample between same-CRS, north-up, axis-aligned grids on the device
-  (nearest / bilinear / cubic_spline up-sampling / average: a restatement of GDAL's warp kernels, parity with GDAL
-  unpinned); other CRSs, rotations or re-sampling methods raise ``NotImplementedError``.
+* ``RefSpaceModel`` / ``SrcSpaceModel`` re-sample between same-CRS, axis-aligned grids on the device (every
+  ``rasterio.enums.Resampling`` warp method: a restatement of GDAL's warp kernels, pinned against the real stack's
+  published accuracy table for average / cubic_spline, otherwise unpinned); other CRSs and rotations raise
+  ``NotImplementedError``, ``gauss`` is rejected as in rasterio.
 """
 from typing import Dict, Optional, Tuple
 

@@ -368,11 +368,12 @@ def fit(model: str, src, src_nodata, ref, ref_nodata, kernel_shape=(5, 5), find_
 #   nearest  : GWKNearest -- the source pixel containing the destination pixel centre (floor(x + 1e-10)).
 #   average  : GWKAverageOrMode -- weighted mean of the valid source pixels overlapping the destination pixel's footprint,
 #              weight = fractional overlap per axis; nodata when no valid pixel.
+#   mode / med / q1 / q3 : the same function's rank-order branches over the same footprint, unweighted (see the code).
 #   bilinear / cubic_spline : GWKResample -- the source pixel under the destination centre must be valid; separable
 #              2 / 4-tap kernel (cubic B-spline) around it, taps outside the raster or invalid are skipped and the sum is
 #              renormalised by the accumulated weight (nodata below 1e-6).  Up-sampling only (kernel not stretched).
-RESAMPLING_CODES = {'nearest': 0, 'bilinear': 1, 'cubic': 2, 'cubic_spline': 3, 'lanczos': 4, 'average': 5, 'max': 8,
-                    'min': 9, 'sum': 13, 'rms': 14}
+RESAMPLING_CODES = {'nearest': 0, 'bilinear': 1, 'cubic': 2, 'cubic_spline': 3, 'lanczos': 4, 'average': 5, 'mode': 6, 'max': 8,
+                    'min': 9, 'med': 10, 'q1': 11, 'q3': 12, 'sum': 13, 'rms': 14}
 
 
 COMPARE_KEYS = ('src_sum', 'ref_sum', 'src2_sum', 'ref2_sum', 'src_ref_sum', 'res2_sum', 'mask_sum')
@@ -539,7 +540,7 @@ def reproject(src: np.ndarray, src_nodata, mapping, dst_shape, dst_nodata=np.nan
         got = ok
     elif resampling in ('cubic', 'lanczos') or (resampling in ('bilinear', 'cubic_spline') and (kx > 1 + 1e-9 or ky > 1 + 1e-9)):
         out, got = _reproject_conv(srcd, valid, mapping, dst_shape, resampling)
-    elif resampling in ('average', 'max', 'min', 'sum', 'rms'):
+    elif resampling in ('average', 'max', 'min', 'sum', 'rms', 'mode', 'med', 'q1', 'q3'):
         for i in range(dh):
             y0, y1 = max(ky * i + oy, 0.0), min(ky * (i + 1) + oy, float(sh))
             iy0, iy1 = int(np.floor(y0 + 1e-10)), int(np.ceil(y1 - 1e-10))
@@ -562,6 +563,23 @@ def reproject(src: np.ndarray, src_nodata, mapping, dst_shape, dst_nodata=np.nan
                 if ix0 + 1 != ix1:
                     wx[0] = 1 - (x0 - ix0)
                     wx[-1] = 1 - (ix1 - x1)
+                if resampling in ('mode', 'med', 'q1', 'q3'):
+                    # GWKAverageOrMode's rank-order branches (unweighted): quantile = element ceil(q * n - 1) of the sorted
+                    # valid values; mode = the value whose running count first reaches the highest count (row-major scan)
+                    vals = [srcd[a, b] for a in range(iy0, iy1) for b in range(ix0, ix1) if valid[a, b]]
+                    if vals:
+                        if resampling == 'mode':
+                            counts, best, best_n = {}, None, 0
+                            for v in vals:
+                                counts[v] = counts.get(v, 0) + 1
+                                if counts[v] > best_n:
+                                    best, best_n = v, counts[v]
+                            out[i, j] = best
+                        else:
+                            q = {'med': 0.5, 'q1': 0.25, 'q3': 0.75}[resampling]
+                            out[i, j] = sorted(vals)[max(int(math.ceil(q * len(vals) - 1)), 0)]
+                        got[i, j] = True
+                    continue
                 tot = wsum = 0.0
                 for a in range(iy0, iy1):      # row-major accumulation order, as GDAL
                     for b in range(ix0, ix1):

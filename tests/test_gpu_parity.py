@@ -1466,6 +1466,32 @@ def test_more_device_resamplers_equal_oracle(ctx, resampling, mapping, dst_shape
         assert_same_f32(got, exp, f'{resampling} {mapping}')
 
 
+@pytest.mark.parametrize('resampling', ['mode', 'med', 'q1', 'q3'])
+@pytest.mark.parametrize('mapping, dst_shape, nodata', [((2., 0., 2., 0.), (40, 60), None), ((3., .5, 2.5, .25), (31, 39), np.nan),
+                                                        ((6., 0., 6., 0.), (13, 20), np.nan), ((.5, 0., .5, 0.), (160, 240), None)])
+def test_rank_order_resamplers_equal_oracle(ctx, resampling, mapping, dst_shape, nodata):
+    """ GWKAverageOrMode's rank-order branches (mode, med, q1, q3) over the `average` footprint vs the oracle's restatement;
+    integer-valued data so that `mode` has real ties. """
+    rng = np.random.default_rng(31)
+    src = rng.integers(0, 6, (80, 120)).astype(np.float32)
+    if nodata is not None:
+        src[rng.random(src.shape) < 0.1] = np.nan
+        src[:3], src[:, :2] = np.nan, np.nan
+    got = ctx.reproject(src, nodata, mapping, dst_shape, onp.RESAMPLING_CODES[resampling], np.nan)
+    exp = onp.reproject(src, nodata, mapping, dst_shape, dst_nodata=np.nan, resampling=resampling)
+    assert_same_f32(got, exp, f'{resampling} {mapping}')
+    cont, _ = onp.synth_pair(80, 120, 15, 'frame+holes' if nodata is not None else 'none')
+    got = ctx.reproject(cont, nodata, mapping, dst_shape, onp.RESAMPLING_CODES[resampling], np.nan)
+    exp = onp.reproject(cont, nodata, mapping, dst_shape, dst_nodata=np.nan, resampling=resampling)
+    assert_same_f32(got, exp, f'{resampling} {mapping} continuous')
+
+
+def test_gauss_is_not_a_warp_method(ctx):
+    src, _ = onp.synth_pair(20, 30, 1, 'none')
+    with pytest.raises(Exception, match='(?i)resampling'):
+        ctx.reproject(src, None, (2., 0., 2., 0.), (10, 15), 7, np.nan)
+
+
 @pytest.mark.parametrize('resampling', ['bilinear', 'cubic', 'cubic_spline', 'lanczos', 'average', 'max', 'min', 'rms'])
 def test_resamplers_known_answers(ctx, resampling):
     """ Properties that hold for GDAL whatever its rounding: a constant raster stays constant (up and down), `sum` of whole

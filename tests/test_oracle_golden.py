@@ -157,5 +157,13 @@ def test_reproject_oracle_invariants():
     bl = onp.reproject(r, None, (2., 0., 2., 0.), (6, 9), resampling='bilinear')
     w = np.array([1., 3., 3., 1.])
     assert bl[2, 3] == pytest.approx(float((r[3:7, 5:9].astype(np.float64) * np.outer(w, w)).sum() / 64), rel=1e-6)
-    with pytest.raises(NotImplementedError):
-        onp.reproject(r, None, (2., 0., 2., 0.), (6, 9), resampling='mode')
+    # rank-order methods over whole 2 x 2 cells: med / q1 / q3 = element ceil(q * n - 1) of the sorted cell (n = 4: the 2nd,
+    # 1st and 3rd smallest), mode = the value whose count first reaches the maximum in row-major order
+    cells = np.sort(r.reshape(6, 2, 9, 2).transpose(0, 2, 1, 3).reshape(6, 9, 4), axis=2)
+    for rs, k in (('med', 1), ('q1', 0), ('q3', 2)):
+        np.testing.assert_array_equal(onp.reproject(r, None, (2., 0., 2., 0.), (6, 9), resampling=rs), cells[..., k])
+    q = np.array([[5, 7, 7, 1], [7, 5, 5, 1], [2, 2, 3, 3], [9, 2, 3, 3]], np.float32)
+    np.testing.assert_array_equal(onp.reproject(q, None, (2., 0., 2., 0.), (2, 2), resampling='mode'), [[7, 1], [2, 3]])  # 5 7 / 7 5: 7 is second first
+    np.testing.assert_array_equal(onp.reproject(q, None, (4., 0., 4., 0.), (1, 1), resampling='mode'), [[3]])   # 3 occurs four times
+    with pytest.raises((NotImplementedError, KeyError, ValueError)):
+        onp.reproject(r, None, (2., 0., 2., 0.), (6, 9), resampling='gauss')   # not a warp method (rasterio.enums)
