@@ -249,7 +249,11 @@ __global__ void __launch_bounds__(256, 8) inpaint_fill_kernel(const float* __res
 }
 
 // workspace: the distance table (2 of its 4 bytes per pixel are used) + source flags (1 byte per pixel) + the tie bitmap + the weight table
-size_t inpaint_workspace_bytes(int height, long long stride) { return (size_t)height * stride * 5 + 1024 + TIE_N / 8 + 256 + WTAB_N * 8 + 256; }
+// + the column bit words (one 64-bit word per column and 64 rows; a plane of a few rows has more of those than spare table bytes)
+static size_t bit_words(int height, long long stride) { return (size_t)((height + WORD_ROWS - 1) / WORD_ROWS) * (size_t)stride; }
+size_t inpaint_workspace_bytes(int height, long long stride) {
+    return (size_t)height * stride * 5 + 1024 + TIE_N / 8 + 256 + WTAB_N * 8 + 256 + bit_words(height, stride) * 8 + 256;
+}
 
 // the workspace's source-flag plane: the fit kernel can write it itself (FitArgs::flag), then gain / r2 are not needed here
 unsigned char* inpaint_flag_plane(void* workspace, int height, long long stride) {
@@ -271,8 +275,9 @@ hipError_t launch_inpaint_offsets(const float* offset, const float* gain, const 
     if (!flag_ready)  // else: the flag plane was written by the fit kernel (FitArgs::flag)
         hipLaunchKernelGGL(inpaint_flag_kernel, dim3((width + 255) / 256, height < 1024 ? height : 1024), dim3(256), 0, stream,
                            gain, r2, thresh, stride, height, width, ws_flag);
-    // column bit words in the unused half of the table region (plane / 8 bytes of its 2 * plane spare bytes)
-    unsigned long long* bits = reinterpret_cast<unsigned long long*>(tb + plane);
+    // column bit words behind the weight table (256-byte aligned)
+    unsigned long long* bits = reinterpret_cast<unsigned long long*>(
+        (reinterpret_cast<uintptr_t>(wtab + WTAB_N) + 255) / 256 * 256);
     const dim3 gwords((width + 255) / 256, (height + WORD_ROWS - 1) / WORD_ROWS);
     hipLaunchKernelGGL(inpaint_bits_kernel, gwords, dim3(256), 0, stream, flag, stride, height, width, bits);
     hipLaunchKernelGGL(inpaint_table_kernel, gwords, dim3(256), 0, stream, bits, stride, height, width, max_dist, tb);

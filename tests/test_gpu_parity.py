@@ -877,6 +877,27 @@ def test_r2_inpainting_vs_oracle(ctx, want_params):
         assert_close_ulp(corr, onp.apply(src, exp_params), 'corrected after in-painting', max_frac=1e-3)
 
 
+@pytest.mark.parametrize('h', [1, 2, 3, 5, 63, 64, 65])
+def test_r2_inpainting_of_blocks_of_a_few_rows(ctx, oc, h):
+    """ Blocks of one to a few rows (and around the 64-row word height of the column table): the in-painting's bit words,
+    distance table and search on degenerate heights; kernel 1 x 5 so that a single row still has full windows. """
+    w = 300
+    rng = np.random.default_rng(50 + h)
+    src = rng.uniform(0.1, 1, (h, w)).astype(np.float32)
+    ref = (1.3 * src + 0.05 + rng.normal(0, 0.004, (h, w))).astype(np.float32)
+    ref[:, 40:52] = rng.uniform(0, 1, (h, 12)).astype(np.float32)     # uncorrelated stretch: fails the r2 mask
+    ref[h // 2, 200:203] = 5.0
+    src[:, :2] = np.nan
+    exp_params, exp_corr, exp_fail = oc.fit_apply('gain-offset', src, np.nan, ref, np.nan, (1, 5), False, 0.25)
+    assert exp_fail > 0
+    desc = _hk.make_desc('gain-offset', (1, 5), False, 0.25, np.nan, np.nan)
+    for _ in range(2):
+        params, corr, _, n_fail = ctx.fit_apply(desc, src, ref, 3, want_params=True, want_corr=True)
+        assert n_fail == exp_fail
+        assert_close_ulp(params, exp_params, f'in-painted params, {h} rows', max_frac=2e-3)
+        assert_close_ulp(corr, exp_corr, f'corrected, {h} rows', max_frac=2e-3)
+
+
 def test_r2_inpainting_of_a_block_taller_than_a_grid_dimension(ctx, oc):
     """ 66 000 rows: the in-painting kernels stride over the rows (a launch has at most 65 535 workgroups along y), and the
     column bit words / distance table cover the whole height; failing patches near the top, the middle and the last rows. """
