@@ -64,6 +64,7 @@ def parse_args():
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-parity', action='store_true')
     p.add_argument('--no-end-to-end', action='store_true', help='configs 3 / 4: skip the PCIe-inclusive RasterFuse pass')
+    p.add_argument('--no-nan-variant', action='store_true', help='default run: skip the second, shorter measurement on NaN-nodata rasters')
     p.add_argument('--cpu-sample', type=int, default=0, help='CPU baseline sample size (square); 0 = auto')
     args = p.parse_args()
     preset = CONFIGS[args.config]
@@ -650,6 +651,23 @@ def main():
 
     runner = {1: run_resident, 2: run_resident, 3: run_blocks, 4: run_tiles}[args.config]
     res = runner(args, ctx, dist, rank, world)
+    # Through RasterFuse every raster has nodata = nan (raster_array.py:172-188), i.e. the product path runs the GENERAL
+    # kernels; `value` is quoted on BASELINE.json's plain synthetic rasters.  The default run therefore adds a second,
+    # shorter measurement of the same configuration on rasters with a NaN frame (reported beside, never as `value`).
+    nan_variant = None
+    if args.config == 2 and args.nodata == 0 and world == 1 and not args.no_nan_variant and not args.params:
+        import copy
+        a2 = copy.copy(args)
+        a2.nodata, a2.steps, a2.warmup = 2, min(args.steps, 20), 3
+        r2_ = run_resident(a2, ctx, dist, rank, world)
+        rl2 = r2_['roofline']
+        nan_variant = {
+            'workload': 'the same rasters with a 3-pixel NaN frame, src / ref nodata = nan (general kernels: the RasterFuse path)',
+            'value': round(r2_['value'], 1), 'steps': a2.steps, 'ms_per_step': round(r2_['elapsed'] / a2.steps * 1e3, 4),
+            'avg_launch_ms': round(rl2['avg_launch_ms'], 4),
+            'frac': round(rl2['achieved_bytes'] / (rl2['avg_launch_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+            'parity_spot_check': r2_['parity'],
+        }
 
     if rank == 0:
         cpu = None
@@ -676,6 +694,8 @@ def main():
         }
         if res.get('end_to_end') is not None:
             out['end_to_end'] = res['end_to_end']
+        if nan_variant is not None:
+            out['nodata_nan_variant'] = nan_variant
         if dist.backend() is not None:
             out['dist_backend'] = dist.backend()   # 'nccl' = RCCL; absent for a single process without a group
         print(json.dumps(out), flush=True)

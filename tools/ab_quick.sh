@@ -1,4 +1,4 @@
-run() { HOMONIM_AMD_LIB=$1 python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline $2 2>/dev/null | tail -1 | python3 -c "
+run() { HOMONIM_AMD_LIB=$1 python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-nan-variant $2 2>/dev/null | tail -1 | python3 -c "
 import sys, json
 d = json.loads(sys.stdin.read())
 r = d['roofline']
