@@ -329,13 +329,18 @@ static int inpaint_band(Slot& sl, const hk::FitArgs& a, const hk_fit_desc* desc,
     // n_fail (the failing VALID pixels) is a lower bound of the pixels to fill (nodata pixels are filled as well)
     HK_HIP(hk::launch_inpaint_offsets(po, pg, pr, desc->r2_thresh, a.stride, a.height, a.width, aux + 4 * plane, filled,
                                       sl.stream, flags, n_fail));
+    // closing pass: the failing pixels take the in-painted offsets and recomputed gains (kernel_model.py:370-371).  Which
+    // pixels failed is in the flag plane the in-painting just used, so the build WITHOUT the R2 work runs (the R2 plane, if
+    // the caller keeps one, was written by the pass that counted and is not changed by the branch)
     hk::FitArgs c = a;
     c.offset_in = filled;
+    c.flag_in = flags ? flags : hk::inpaint_flag_plane(aux + 4 * plane, a.height, a.stride);
     c.fail_count = nullptr;  // already counted
     c.flag = nullptr;
+    c.r2 = nullptr;
     c.cert_only = 0;
-    if (drop_params) c.gain = c.offset = c.r2 = nullptr;  // nobody reads them after this
-    HK_HIP(hk::launch_fit_apply(c, desc->model, r2, sl.stream));
+    if (drop_params) c.gain = c.offset = nullptr;  // nobody reads them after this
+    HK_HIP(hk::launch_fit_apply(c, desc->model, false, sl.stream));
     return HK_OK;
 }
 

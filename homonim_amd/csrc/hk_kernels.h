@@ -21,7 +21,9 @@ struct FitArgs {
     float* r2;
     float* corr;
     const double* norm;              // n_bands x 2 (gain-blk-offset)
-    const float* offset_in;          // second (in-paint) pass of gain-offset: in-painted offsets, else NULL
+    const float* offset_in;          // closing (in-paint) pass of gain-offset: in-painted offsets, else NULL
+    const unsigned char* flag_in;    // ... with the source flags of the in-painting (1 byte per pixel): the build WITHOUT R2 then
+                                     // takes the r2-mask decision from them instead of evaluating R2 again; else NULL
     unsigned long long* fail_count;  // n_bands
     unsigned char* flag;             // gain-offset with a threshold: 1 byte per pixel = (r2 > thresh) & (gain > 0) & valid
                                      // (kernel_model.py:363), the in-painting's source mask; same strides as the planes; or NULL

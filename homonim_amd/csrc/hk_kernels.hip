@@ -1055,6 +1055,26 @@ fit_apply_kernel(const FitArgs a) {
                     }
                 }
 
+                if constexpr (GO && !R2) {
+                    // Closing pass of the in-painting branch (kernel_model.py:366-371) without the R2 work: which valid pixels
+                    // failed the r2 mask is read from the in-painting's source flags (a.flag_in, written by the pass that
+                    // counted them); they take the in-painted offset and gain = (ref_sum - mask_sum * offset) / src_sum.
+                    if (a.offset_in != nullptr) {  // wave-uniform
+                        const long long q = out_base + (long long)y * a.stride + (lane_in ? x : 0);  // a safe quad for lanes outside
+                        const float4 oin4 = *reinterpret_cast<const float4*>(a.offset_in + q);
+                        const unsigned fl = *reinterpret_cast<const unsigned*>(a.flag_in + q);
+                        const float oin[PX] = {oin4.x, oin4.y, oin4.z, oin4.w};
+#pragma unroll
+                        for (int i = 0; i < PX; ++i) {
+                            const bool failing = ((mcu >> (8 * i)) & 1u) && !((fl >> (8 * i)) & 0xffu);
+                            if (failing) {
+                                o[i] = oin[i];
+                                g[i] = __fdiv_rn(__fsub_rn(Rf[i], __fmul_rn(Nf[i], oin[i])), Sf[i]);
+                            }
+                        }
+                    }
+                }
+
                 // ---- stage C: apply (:461) and where=mask (every parameter write goes into a NaN-filled array, :261,:345) ----
                 // A masked pixel has NaN parameters, hence a NaN corrected value: select once per stored plane.
 #pragma unroll
