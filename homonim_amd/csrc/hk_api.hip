@@ -225,6 +225,13 @@ void fill_args(hk::FitArgs& a, const hk_fit_desc* d, int xcd_remap) {
         if (d->model == HK_MODEL_GAIN && d->kh <= 15) a.use_ring = 1;
         if (d->model == HK_MODEL_GAIN_BLK_OFFSET && d->kh <= 7 && d->kw <= 7) a.use_ring = 1;
     }
+    // ... and, in their lock-step workgroups (hk_kernels.hip WPB), short uniform segments: 32 rows instead of 64 / 128 + 32
+    // (gain 5x5: configs[1] 0.676 -> 0.625 ms, 16384^2 x 4 2.65 -> 2.49 ms on one box; 7x7 2.54 -> 2.47; gain-blk-offset 5x5
+    // -0.5 %).  16 rows are as good or better at 5x5 but load a quarter more rows; taller kernels keep the default.
+    a.seg_rows_pref = 0;
+    if (!needs_r2(d) && a.use_ring == 1 && d->model != HK_MODEL_GAIN_OFFSET &&
+        (d->kh <= 5 || (d->model == HK_MODEL_GAIN && d->kh <= 7)))
+        a.seg_rows_pref = 32;
     if (const char* e = getenv("HK_USE_RING")) {  // testing hook
         const int m = atoi(e);
         const bool mem_bound = d->model != HK_MODEL_GAIN_OFFSET && !needs_r2(d);
@@ -249,6 +256,7 @@ void fill_grid(hk::FitArgs& a, int seg_rows) {
     const int out_w = (hk::WAVE - 2 * a.overlap_lanes) * hk::PX;
     const int kh = 2 * a.rh + 1;
     a.n_strips = (a.width + out_w - 1) / out_w;
+    if (seg_rows <= 0 && a.seg_rows_pref > 0) seg_rows = a.seg_rows_pref;  // the build's own preference (fill_args)
     const int uniform = seg_rows > 0 ? seg_rows : (kh <= 5 ? 64 : (kh <= 9 ? 128 : 256));
     a.seg_rows = uniform < a.height ? uniform : a.height;
     a.seg_rows_tail = a.seg_rows;

@@ -51,6 +51,7 @@ struct FitArgs {
     double nd_full;         // the same as float64
     double inv_n_full;      // RN64(1 / (kh * kw)) -- the 1/N table entry (hk_kernels.hip)
     int force_general;      // 1: never take the dense (nodata None) specialisation (testing)
+    int seg_rows_pref;      // > 0: the build's preferred uniform segment height (hk_api.hip fill_args / fill_grid), 0: the default policy
     int use_ring;           // ring mode of fit_apply_kernel: 1 full LDS ring, 2 centre ring + re-loaded leaving row, 0 re-load both
     int xcd_remap;          // G > 0: blockIdx -> unit remap handing each XCD runs of G consecutive units (0: round-robin)
     // store window: only rows [out_y0, out_y1) x columns [out_x0, out_x1) of the job are written / counted (the halo crop of
