@@ -213,7 +213,6 @@ void fill_args(hk::FitArgs& a, const hk_fit_desc* d, int xcd_remap) {
     a.nd_full = (double)(d->kh * d->kw);
     a.inv_n_full = 1.0 / (double)(d->kh * d->kw);
     a.force_general = getenv("HK_FORCE_GENERAL") ? atoi(getenv("HK_FORCE_GENERAL")) : 0;
-    // LDS row ring only while it leaves room for >= 11 waves per CU (kh <= 5); taller kernels re-load rows (hk_kernels.hip)
     // ring mode (hk_kernels.hip): full LDS ring while it leaves room for >= 11 waves per CU (kh <= 5), centre-only ring up
     // to kh = 17 (<= 12.5 KB per wave), everything re-loaded beyond
     a.use_ring = (d->kh <= 5 && d->kw <= 7) ? 1 : (d->kh <= 17 ? 2 : 0);
