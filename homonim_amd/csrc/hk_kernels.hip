@@ -487,7 +487,7 @@ struct ColSums {
 // workgroup then reads and writes 4 KB of every row together instead of 1 KB per wave at unrelated times, which the HBM
 // pays back -- strip-march pattern without arithmetic 4 720 -> 4 910 GB/s (tools/ubench_strips.hip); gain 5x5 at 16384^2
 // 2.70 -> 2.55 ms, gain-blk-offset 5x5 4.57 -> 4.34 ms (8 waves: 2.51 / 4.38; configs[1]'s smaller raster prefers 4).
-// Not for the VALU-bound gain-offset builds (their waves would only wait for each other: 0 to +2 %) and not for the tall
+// Not for the VALU-bound gain-offset builds with the R2 work (their waves would only wait for each other: 0 to +2 %) and not for the tall
 // kernels that re-load their leaving rows (15x15: +14 %, the re-loads of a whole workgroup then collide).
 #ifndef HK_WPB_MEM
 #define HK_WPB_MEM 4
@@ -1163,7 +1163,9 @@ static hipError_t launch_wpb(const FitArgs& a, size_t lds, hipStream_t stream) {
 template <int MODEL, bool R2, int RW, bool DENSE, int RING, bool CERT_ONLY>
 static hipError_t launch_build(const FitArgs& a, hipStream_t stream) {
     const size_t lds = fit_lds_bytes(2 * a.rh + 1, RING, RING == 1 && MODEL != 2 && !R2);
-    if constexpr (MODEL != 2 && !R2 && RING == 1 && HK_WPB_MEM > 1) {
+    // every build without the R2 work (gain-offset without a threshold gains 3 % as well: 2.77 -> 2.68 ms)
+    constexpr bool LOCKSTEP = !R2 && RING == 1 && HK_WPB_MEM > 1;
+    if constexpr (LOCKSTEP) {
         if (lds * HK_WPB_MEM <= 64 * 1024) return launch_wpb<MODEL, R2, RW, DENSE, RING, CERT_ONLY, HK_WPB_MEM>(a, lds, stream);
     }
     return launch_wpb<MODEL, R2, RW, DENSE, RING, CERT_ONLY, 1>(a, lds, stream);
