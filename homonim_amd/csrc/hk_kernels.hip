@@ -319,14 +319,28 @@ constexpr unsigned RING_SENTINEL = 0x7fc0deadu;
 // 16 bytes.  The load is unconditional: the row is clamped into the raster (wave-uniform, so the row address is a
 // scalar base and the lane offset a 32-bit VGPR -> no per-row vector address arithmetic) and `xq` is a safe in-raster
 // quad for lanes outside it; whatever such a load returns is discarded by process_row (row_ok / colbits).
+// Tall kernels re-load the leaving row from global memory (ring modes 2 / 0): that is the row's LAST use, so the re-load is
+// non-temporal -- it no longer displaces the rows still waiting for theirs (gain-blk-offset 15x15 x 8 bands at 16384^2:
+// 11.09 -> 10.37 ms; gain-offset 15x15 -0.6 %).  Entering rows stay cached: the neighbouring strips and the re-load need them.
+#ifndef HK_NT_LEAVE
+#define HK_NT_LEAVE true
+#endif
+template <bool NT = false>
 __device__ __forceinline__ RowRaw load_row(const float* __restrict__ sp, const float* __restrict__ rp, long long stride,
                                            int row, int height, unsigned xq) {
     const int rc = min(max(row, 0), height - 1);
     const char* __restrict__ ps = reinterpret_cast<const char*>(sp + (long long)rc * stride);
     const char* __restrict__ pr = reinterpret_cast<const char*>(rp + (long long)rc * stride);
     RowRaw o;
-    o.s = *reinterpret_cast<const float4*>(ps + xq);  // xq: this lane's byte offset in the row (32-bit)
-    o.r = *reinterpret_cast<const float4*>(pr + xq);
+    if constexpr (NT) {
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        const f4v sv = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(ps + xq));
+        const f4v rv = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(pr + xq));
+        o.s = make_float4(sv.x, sv.y, sv.z, sv.w), o.r = make_float4(rv.x, rv.y, rv.z, rv.w);
+    } else {
+        o.s = *reinterpret_cast<const float4*>(ps + xq);  // xq: this lane's byte offset in the row (32-bit)
+        o.r = *reinterpret_cast<const float4*>(pr + xq);
+    }
     return o;
 }
 
@@ -677,7 +691,7 @@ fit_apply_kernel(const FitArgs a) {
     // gain-offset kernels, which would spill)
     constexpr bool PF_OLD = !ring && (DENSE || MODEL != 2);
     [[maybe_unused]] RowRaw qo_next;
-    if constexpr (PF_OLD) qo_next = load_row(sp, rp, a.stride, t_first - kh, H, xq);
+    if constexpr (PF_OLD) qo_next = load_row<HK_NT_LEAVE>(sp, rp, a.stride, t_first - kh, H, xq);
     // RING 1: the first leaving row is the zero row the ring was initialised with
     [[maybe_unused]] RowZ zold_next;
 #pragma unroll
@@ -704,9 +718,9 @@ fit_apply_kernel(const FitArgs a) {
         if constexpr (PF_OLD) {
             // the leaving row is fetched one iteration ahead (it comes from L2 / the Infinity Cache): qo_next holds row t_old
             qo = qo_next;
-            qo_next = load_row(sp, rp, a.stride, t_old + 1, H, xq);
+            qo_next = load_row<HK_NT_LEAVE>(sp, rp, a.stride, t_old + 1, H, xq);
         } else if constexpr (!ring) {
-            qo = load_row(sp, rp, a.stride, t_old, H, xq);
+            qo = load_row<HK_NT_LEAVE>(sp, rp, a.stride, t_old, H, xq);
         }
         if constexpr (RING == 0) qc = load_row(sp, rp, a.stride, y_c, H, xq);
 
