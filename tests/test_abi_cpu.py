@@ -51,6 +51,17 @@ def test_backend_name_and_struct_layout(lib):
     assert ctypes.sizeof(_hk.OutWindow) == 2 * 8 + 4 * 4
 
 
+def test_host_only_size_helpers(lib):
+    """ The two size helpers of the header are plain host arithmetic (no device needed): scratch of a device job = 5 bytes
+    per element of the span of its planes; exchange buffer of the split-block statistics = 4 x 2048 float64 per band. """
+    assert lib.hk_dev_job_scratch_bytes(1, 96, 320, 0) == 5 * 96 * 320
+    assert lib.hk_dev_job_scratch_bytes(3, 96, 320, 40000) == 5 * (2 * 40000 + 96 * 320)
+    assert lib.hk_dev_job_scratch_bytes(0, 96, 320, 0) == 0
+    assert lib.hk_block_norm_split_exchange_doubles(1) == 4 * 2048
+    assert lib.hk_block_norm_split_exchange_doubles(8) == 8 * 4 * 2048
+    assert lib.hk_block_norm_split_exchange_doubles(0) == 0
+
+
 def test_no_gpu_fails_loudly(lib):
     """ On a GPU-less host the context cannot be created: DeviceError, never a silent CPU path. """
     if _hk.device_count() > 0:
