@@ -145,6 +145,96 @@ def fit_block_norm(src, src_nodata, ref, ref_nodata) -> np.ndarray:
     return norm_model
 
 
+# ---- the same statistics for a block whose rows are spread over several ranks (homonim_amd/split_norm.py, hk_norm.hip
+# launch_block_norm_split): every ingredient is a sum over pixels, so each rank contributes arrays that are all-reduced (SUM)
+# between the phases.  This is the numpy statement of what each phase contributes and of what is done with the reduced
+# arrays -- the order statistics come out of an exact 3-level radix select on the order-preserving uint32 image of float32.
+SPLIT_BITS = (11, 11, 10)
+
+
+def _f2key(v):
+    u = np.ascontiguousarray(v, F32).view(np.uint32)
+    return np.where(u & np.uint32(0x80000000), ~u, u | np.uint32(0x80000000)).astype(np.uint32)
+
+
+def _key2f(k):
+    k = np.uint32(k)
+    u = (k & np.uint32(0x7fffffff)) if (k & np.uint32(0x80000000)) else np.uint32(~k)
+    return np.array([u], np.uint32).view(F32)[0]
+
+
+def split_norm_slab_values(src, src_nodata, ref, ref_nodata):
+    """ the slab's jointly valid (src, ref) values """
+    mask = mask_of(ref, ref_nodata) & mask_of(src, src_nodata)
+    return src[mask].astype(F32), ref[mask].astype(F32)
+
+
+def split_norm_moments(vals, shift):
+    """ phase 1 contribution: [n, sum(s - shift_s), sum((s - shift_s)^2), sum(r - shift_r), sum((r - shift_r)^2)] """
+    s, r = (v.astype(np.float64) for v in vals)
+    ds, dr = s - shift[0], r - shift[1]
+    return np.array([s.size, ds.sum(), (ds * ds).sum(), dr.sum(), (dr * dr).sum()])
+
+
+def split_norm_hist(vals, level, prefixes):
+    """ phases 2-4 contribution: histograms [raster][rank] of the level's key digit over the values whose higher digits
+    equal the rank's prefix (level 0: every value; both ranks of a raster share one histogram) """
+    out = np.zeros((2, 2, 1 << SPLIT_BITS[level]))
+    for q in range(2):
+        keys = _f2key(vals[q])
+        for k in range(2):
+            if level == 0:
+                if k == 0:
+                    out[q, 0] = np.bincount(keys >> np.uint32(21), minlength=2048)
+            elif level == 1:
+                sel = (keys >> np.uint32(21)) == prefixes[q][k]
+                out[q, k] = np.bincount((keys[sel] >> np.uint32(10)) & np.uint32(2047), minlength=2048)
+            else:
+                sel = (keys >> np.uint32(10)) == prefixes[q][k]
+                out[q, k] = np.bincount(keys[sel] & np.uint32(1023), minlength=1024)
+    return out
+
+
+def split_norm_select(hist, level, prefixes, ranks):
+    """ with the REDUCED histograms: the bin that holds each rank, the new prefixes and the ranks inside those bins """
+    new_p, new_r = [[0, 0], [0, 0]], [[0, 0], [0, 0]]
+    for q in range(2):
+        for k in range(2):
+            h = hist[q, 0 if level == 0 else k]
+            cum = np.cumsum(h)
+            b = int(np.searchsorted(cum, ranks[q][k], side='right'))
+            b = min(b, h.size - 1)
+            new_p[q][k] = b if level == 0 else (prefixes[q][k] << SPLIT_BITS[level]) | b
+            new_r[q][k] = ranks[q][k] - (int(cum[b - 1]) if b else 0)
+    return new_p, new_r
+
+
+def split_norm_finish(moments, shift, prefixes):
+    """ norm from the reduced moments and the two selected order statistics per raster (numpy's _lerp for the percentile) """
+    n = int(moments[0])
+    if n == 0:
+        return np.zeros(2)
+    var = []
+    for q in range(2):
+        d = moments[1 + 2 * q] / n
+        var.append(max(moments[2 + 2 * q] / n - d * d, 0.0))
+    vi = 0.01 * (n - 1)
+    t = vi - math.floor(vi)
+    pct = []
+    for q in range(2):
+        lo, hi = float(_key2f(prefixes[q][0])), float(_key2f(prefixes[q][1]))
+        d = hi - lo
+        pct.append(hi - d * (1 - t) if t >= 0.5 else lo + d * t)
+    n0 = math.sqrt(var[1]) / math.sqrt(var[0])
+    return np.array([n0, pct[1] - pct[0] * n0])
+
+
+def split_norm_ranks(n):
+    vi = 0.01 * (n - 1)
+    k0 = int(math.floor(vi))
+    return [[k0, min(k0 + 1, n - 1)], [k0, min(k0 + 1, n - 1)]]
+
+
 def _fit_gain_arrays(src_array, src_mask, ref_array, ref_mask, kernel_shape, find_r2):
     """ kernel_model.py:231-274 on already-copied arrays (src may be float64 for gain-blk-offset). """
     mask = ref_mask & src_mask  # :245
