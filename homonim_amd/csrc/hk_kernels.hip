@@ -30,6 +30,9 @@ __device__ __forceinline__ int dpp_from_left(int v) {  // value of lane-1; lane 
 __device__ __forceinline__ int dpp_from_right(int v) {  // value of lane+1; lane 63 receives 0
     return __builtin_amdgcn_update_dpp(0, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
 }
+// float32: the compiler folds the shift into the consuming v_add_f32 (DPP operand modifier), no separate move
+__device__ __forceinline__ float dpp_from_left(float v) { return __int_as_float(dpp_from_left(__float_as_int(v))); }
+__device__ __forceinline__ float dpp_from_right(float v) { return __int_as_float(dpp_from_right(__float_as_int(v))); }
 __device__ __forceinline__ double dpp_from_left(double v) {
     int lo = dpp_from_left(__double2loint(v)), hi = dpp_from_left(__double2hiint(v));
     return __hiloint2double(hi, lo);
@@ -80,6 +83,10 @@ __device__ __forceinline__ int bperm_from<int>(int v, int src_lane) {
     return __builtin_amdgcn_ds_bpermute((src_lane & (WAVE - 1)) << 2, v);
 }
 template <>
+__device__ __forceinline__ float bperm_from<float>(float v, int src_lane) {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute((src_lane & (WAVE - 1)) << 2, __float_as_int(v)));
+}
+template <>
 __device__ __forceinline__ double bperm_from<double>(double v, int src_lane) {
     const int a = (src_lane & (WAVE - 1)) << 2;
     return __hiloint2double(__builtin_amdgcn_ds_bpermute(a, __double2hiint(v)), __builtin_amdgcn_ds_bpermute(a, __double2loint(v)));
@@ -120,8 +127,19 @@ __host__ __device__ constexpr bool specific_before(int rw, int i, int j, bool ri
 //     crossbar, one instruction per dword whatever the distance);
 //   * lanes that lie wholly inside all four windows are summed once into a common term.
 // RW = 2: 4 shifted values (8 DPP moves) + 9 adds per 4 pixels; RW = 7: 2 DPP-shifted + 6 permuted values + 13 adds.
-template <int RW, typename T>
-__device__ __forceinline__ void hsum(const T (&V)[PX], T (&H)[PX], int lane) {
+// XCH (float64 quantities of the kernels whose strips overlap by one lane): the distance-1 neighbours' partial sums travel
+// through a wave-private LDS exchange line instead of DPP moves -- the kernel is bound by VALU issue (a 64-bit value costs two
+// 4-cycle v_mov_b32_dpp), while the LDS pipe has room: per quantity and direction one ds_write_b128 + one ds_read_b128 of the
+// neighbour's slot.  `xch` = this lane's 16-byte slot; slots -1 and 64 exist (never written: lanes 0 and 63 are overlap lanes
+// whose sums are discarded).  LDS operations of one wave execute in order, so the line is re-used without waiting.
+__device__ __forceinline__ void xch_order() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+typedef double hk_d2 __attribute__((ext_vector_type(2)));
+template <int RW, typename T, bool XCH = false>
+__device__ __forceinline__ void hsum(const T (&V)[PX], T (&H)[PX], int lane, [[maybe_unused]] char* xch = nullptr) {
     if constexpr (RW == 0) {
 #pragma unroll
         for (int i = 0; i < PX; ++i) H[i] = V[i];
@@ -151,6 +169,26 @@ __device__ __forceinline__ void hsum(const T (&V)[PX], T (&H)[PX], int lane) {
         static_for<1, OL + 1>([&](auto J) {
             constexpr int j = decltype(J)::value;
             T ls[PX + 1], rp[PX + 1];
+            if constexpr (XCH && j == 1 && std::is_same<T, double>::value && (RW == 1 || RW == 2)) {
+                // needed from the left: suf[1..RW], from the right: pre[1..RW]
+                if constexpr (RW == 2) {
+                    *reinterpret_cast<hk_d2*>(xch) = hk_d2{(double)suf[1], (double)suf[2]};
+                    xch_order();
+                    const hk_d2 l = *reinterpret_cast<const hk_d2*>(xch - 16);
+                    xch_order();
+                    *reinterpret_cast<hk_d2*>(xch) = hk_d2{(double)pre[1], (double)pre[2]};
+                    xch_order();
+                    const hk_d2 r = *reinterpret_cast<const hk_d2*>(xch + 16);
+                    xch_order();
+                    ls[1] = (T)l.x, ls[2] = (T)l.y, rp[1] = (T)r.x, rp[2] = (T)r.y;
+                } else {
+                    *reinterpret_cast<hk_d2*>(xch) = hk_d2{(double)suf[1], (double)pre[1]};
+                    xch_order();
+                    ls[1] = (T)*reinterpret_cast<const double*>(xch - 16);
+                    rp[1] = (T)*reinterpret_cast<const double*>(xch + 16 + 8);
+                    xch_order();
+                }
+            } else
             static_for<1, PX + 1>([&](auto K) {
                 constexpr int k = decltype(K)::value;
                 if constexpr (need_left_at(RW, j, k)) {
@@ -223,10 +261,10 @@ __device__ __forceinline__ void hsum_rt(const T (&V)[PX], T (&H)[PX], int rw, in
     }
 }
 
-template <int RW, typename T>
-__device__ __forceinline__ void hsum_any(const T (&V)[PX], T (&H)[PX], int rw, int ol, int lane) {
+template <int RW, typename T, bool XCH = false>
+__device__ __forceinline__ void hsum_any(const T (&V)[PX], T (&H)[PX], int rw, int ol, int lane, char* xch = nullptr) {
     if constexpr (RW >= 0)
-        hsum<RW, T>(V, H, lane);
+        hsum<RW, T, XCH>(V, H, lane, xch);
     else
         hsum_rt<T>(V, H, rw, ol, lane);
 }
@@ -506,6 +544,20 @@ struct ColSums {
 #ifndef HK_WPB_MEM
 #define HK_WPB_MEM 4
 #endif
+// Which float64 horizontal sums exchange their partial sums through LDS (hsum's XCH) instead of DPP: bit 0 S, 1 R, 2 P,
+// 3 S2, 4 R2.  One 16-byte slot per lane + one at each end = XCH_BYTES per wave behind the row rings.
+#ifndef HK_XCH
+#define HK_XCH 0
+#endif
+#ifndef HK_CERT_R2_F32
+#define HK_CERT_R2_F32 1
+#endif
+constexpr size_t XCH_BYTES = (WAVE + 2) * 16;
+template <int MODEL, int RW, int RING, int WPB>
+constexpr int xch_mask() {
+    return (MODEL == 2 && (RW == 1 || RW == 2) && RING == 1 && WPB == 1) ? HK_XCH : 0;
+}
+
 template <int MODEL, bool R2, int RW, bool DENSE, int RING, bool CERT_ONLY, int WPB>
 __global__ void __launch_bounds__(WAVE * WPB, (CERT_ONLY && RW >= 0 && RW <= 3) ? 4
                                         : ((MODEL == 2 && R2 && !DENSE && (RW < 0 || RW >= 4)) ? HK_FIT_MIN_WAVES_WIDE : HK_FIT_MIN_WAVES))
@@ -596,6 +648,9 @@ fit_apply_kernel(const FitArgs a) {
     // RING 1: [slot][s|r][lane]; RING 2: [slot][lane] (s only); one ring per wave of the workgroup
     float4* ring_v = lds4 + (size_t)wave_in_wg * (size_t)(ring_rows * (ring ? 2 : 1) * WAVE);
     // slots start as rows that were never added: zero contribution, no valid pixel
+    constexpr int XCH = xch_mask<MODEL, RW, RING, WPB>();
+    [[maybe_unused]] char* const xch = reinterpret_cast<char*>(lds4 + (size_t)WPB * (size_t)(ring_rows * (ring ? 2 : 1) * WAVE)) +
+                                       (size_t)wave_in_wg * XCH_BYTES + 16 + lane * 16;
     const float ring_init = DENSE ? 0.f : __uint_as_float(RING_SENTINEL);
     for (int sl = 0; sl < ring_rows; ++sl) {
         if constexpr (ring) {
@@ -799,13 +854,13 @@ fit_apply_kernel(const FitArgs a) {
             // one of those float64 quadruples is live beside S2 / R2 (12-16 VGPRs less at the pressure peak)
             double HS[PX], HR[PX];
             [[maybe_unused]] float Sf0[PX], Rf0[PX], Pf0[PX];
-            hsum_any<RW, double>(cs.S, HS, rw, ol, lane);
+            hsum_any<RW, double, (XCH & 1) != 0>(cs.S, HS, rw, ol, lane, xch);
             if constexpr (GO) {
 #pragma unroll
                 for (int i = 0; i < PX; ++i) Sf0[i] = (float)HS[i];
                 __builtin_amdgcn_sched_barrier(0);
             }
-            hsum_any<RW, double>(cs.R, HR, rw, ol, lane);
+            hsum_any<RW, double, (XCH & 2) != 0>(cs.R, HR, rw, ol, lane, xch);
             if constexpr (GO) {
 #pragma unroll
                 for (int i = 0; i < PX; ++i) Rf0[i] = (float)HR[i];
@@ -813,14 +868,30 @@ fit_apply_kernel(const FitArgs a) {
             }
             double HP[PX], HS2[PX], HR2[PX];
             float Nf[PX];
-            if constexpr (CS::NEED_P) hsum_any<RW, double>(cs.P, HP, rw, ol, lane);
+            if constexpr (CS::NEED_P) hsum_any<RW, double, (XCH & 4) != 0>(cs.P, HP, rw, ol, lane, xch);
             if constexpr (GO) {
 #pragma unroll
                 for (int i = 0; i < PX; ++i) Pf0[i] = (float)HP[i];
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if constexpr (CS::NEED_S2) hsum_any<RW, double>(cs.S2, HS2, rw, ol, lane);
-            if constexpr (CS::NEED_R2S) hsum_any<RW, double>(cs.R2s, HR2, rw, ol, lane);
+            if constexpr (CS::NEED_S2) hsum_any<RW, double, (XCH & 8) != 0>(cs.S2, HS2, rw, ol, lane, xch);
+            // Certificate-only build: the window sum of ref^2 feeds nothing but the float32 r2-mask certificate, so its
+            // horizontal stage runs in float32 on the rounded column sums (non-negative terms: <= 5 roundings, relative
+            // error <= 4.03 * 2^-24 instead of 2^-24 -- DESIGN.md appendix A budgets it): four converts + nine float32 adds,
+            // the neighbours' values as DPP operands, instead of nine float64 adds + eight DPP moves + four converts
+            [[maybe_unused]] float HR2f[PX];
+            if constexpr (CS::NEED_R2S && CERT_ONLY && HK_CERT_R2_F32) {
+                float V2[PX];
+#pragma unroll
+                for (int i = 0; i < PX; ++i) V2[i] = (float)cs.R2s[i];
+                hsum_any<RW, float>(V2, HR2f, rw, ol, lane);
+            } else if constexpr (CS::NEED_R2S) {
+                hsum_any<RW, double, (XCH & 16) != 0>(cs.R2s, HR2, rw, ol, lane, xch);
+                if constexpr (CERT_ONLY) {
+#pragma unroll
+                    for (int i = 0; i < PX; ++i) HR2f[i] = (float)HR2[i];
+                }
+            }
             if constexpr (USE_N) {
                 if constexpr (DENSE) {
                     const int nrows_i = min(y + rh, H - 1) - max(y - rh, 0) + 1;
@@ -918,7 +989,9 @@ fit_apply_kernel(const FitArgs a) {
                                     // proves ssres_ref < r2_pass_scale * sstot_ref, i.e. the reference's decision.  N*T' is
                                     // N*T = g^2*den_x + (g*S)^2 + N*R2 + (N*o)^2 rebuilt from this pixel pair's float32
                                     // operands: g*num + t^2 + N*R2 + tn^2 (t = g*S, tn = R - t), within 4*2^-24 of it.
-                                    const f2 R2f = {(float)HR2[2 * j], (float)HR2[2 * j + 1]};
+                                    f2 R2f;
+                                    if constexpr (CERT_ONLY) R2f = HK_P2(HR2f, j);
+                                    else R2f = f2{(float)HR2[2 * j], (float)HR2[2 * j + 1]};
                                     const f2 lhs = g2 * num2;
                                     const f2 sst = pk_fma(Nf2, R2f, -(Rf2 * Rf2));
                                     const f2 NT = pk_fma(t2, t2, pk_fma(tn2, tn2, pk_fma(Nf2, R2f, lhs)));
@@ -1182,7 +1255,7 @@ static hipError_t launch_build(const FitArgs& a, hipStream_t stream) {
     if constexpr (LOCKSTEP) {
         if (lds * HK_WPB_MEM <= 64 * 1024) return launch_wpb<MODEL, R2, RW, DENSE, RING, CERT_ONLY, HK_WPB_MEM>(a, lds, stream);
     }
-    return launch_wpb<MODEL, R2, RW, DENSE, RING, CERT_ONLY, 1>(a, lds, stream);
+    return launch_wpb<MODEL, R2, RW, DENSE, RING, CERT_ONLY, 1>(a, lds + (xch_mask<MODEL, RW, RING, 1>() ? XCH_BYTES : 0), stream);
 }
 
 // gain-offset with the r2 mask exists in two builds.  The FULL one carries the reference's R2 expression inline for the
