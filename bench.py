@@ -66,6 +66,8 @@ def parse_args():
     p.add_argument('--no-end-to-end', action='store_true', help='configs 3 / 4: skip the PCIe-inclusive RasterFuse pass')
     p.add_argument('--no-nan-variant', action='store_true', help='default run: skip the second, shorter measurement on NaN-nodata rasters')
     p.add_argument('--cpu-sample', type=int, default=0, help='CPU baseline sample size (square); 0 = auto')
+    p.add_argument('--no-other-configs', action='store_true', help='default run: skip the compact records of BASELINE configs 1 / 3 / 4')
+    p.add_argument('--no-power-probe', action='store_true', help='default run: skip the package power / clock samples (rocm-smi, ~3 s outside the timed region)')
     args = p.parse_args()
     preset = CONFIGS[args.config]
     for k, v in preset.items():
@@ -75,6 +77,7 @@ def parse_args():
         args.steps = {1: 100, 2: 50, 3: 10, 4: 5}[args.config]
     if args.warmup is None:
         args.warmup = {1: 5, 2: 5, 3: 2, 4: 1}[args.config]
+    args.power_probe = not args.no_power_probe and args.config in (1, 2)
     return args
 
 
@@ -114,10 +117,42 @@ def cpu_baseline(model, k, sample):
         oracle_c.fit_apply(model, s, np.nan, r, np.nan, (k, k), False, thresh, norm_model=norm, n_threads=threads)
 
     if have_c:
+        # The headline CPU figure has the shape of the reference's own block loop (homonim/fuse.py:396-401: one worker thread
+        # per block, os.cpu_count() blocks in flight; raster_pair.py's default 4096 x 4096 blocks): one single-threaded pass
+        # of the C oracle per block, `cores` blocks at a time.
+        try:
+            import psutil
+            avail = psutil.virtual_memory().available
+        except Exception:
+            avail = 32 << 30
+        nbk = 4096
+        distinct = max(1, min(cores, 8))
+        while nbk > 1024 and (cores * 4 + distinct * 2) * 4 * nbk * nbk > 0.5 * avail:
+            nbk //= 2      # a small host: smaller blocks rather than fewer of them in flight
+        pairs = [onp.synth_pair(nbk, nbk, seed=100 + i) for i in range(distinct)]
+
+        def one_block(i):
+            c_pass(pairs[i % distinct][0], pairs[i % distinct][1], 1)
+
+        with ThreadPoolExecutor(cores) as ex:
+            list(ex.map(one_block, range(cores)))          # warm-up round (page faults of the outputs, thread start)
+            t0 = time.perf_counter()
+            rounds = 0
+            while True:
+                list(ex.map(one_block, range(cores)))
+                rounds += 1
+                if time.perf_counter() - t0 > 6.0 or rounds >= 8:
+                    break
+            dtb = (time.perf_counter() - t0) / rounds
+        del pairs
+        main = dict(value=round(cores * nbk * nbk / dtb / 1e6, 3), cores=cores,
+                    impl=f'C oracle (oracle/hk_oracle.c), one thread per {nbk}x{nbk} block, {cores} blocks in flight '
+                         f'(the shape of homonim/fuse.py:396-401)', sample_px=nbk, seconds=round(dtb, 3))
         src, ref = onp.synth_pair(sample, sample, seed=0)
-        dt = timed(lambda: c_pass(src, ref, cores), 8.0, 40)
-        main = dict(value=round(sample * sample / dt / 1e6, 3), cores=cores,
-                    impl=f'C oracle (oracle/hk_oracle.c, OpenMP {cores} threads)', sample_px=sample, seconds=round(dt, 3))
+        dt = timed(lambda: c_pass(src, ref, cores), 5.0, 40)
+        variants.append(dict(value=round(sample * sample / dt / 1e6, 3), cores=cores,
+                             impl=f'C oracle, ONE {sample}x{sample} block row-sliced over {cores} OpenMP threads (round 2\'s headline CPU figure)',
+                             sample=f'{sample}x{sample}', seconds=round(dt, 3)))
         s1 = min(sample, 2048)
         src1, ref1 = np.ascontiguousarray(src[:s1, :s1]), np.ascontiguousarray(ref[:s1, :s1])
         dt1 = timed(lambda: c_pass(src1, ref1, 1), 3.0, 5)
@@ -145,21 +180,28 @@ def cpu_baseline(model, k, sample):
                          sample=f'{len(blocks)} blocks of {nb}x{nb}', seconds=round(dt_npt, 3)))
     if not have_c:
         main = dict(value=variants[0]['value'], cores=1, impl=variants[0]['impl'], sample_px=nb, seconds=variants[0]['seconds'])
-    return dict(value=main['value'], unit='Mpixels*bands/s', cores=main['cores'], kind='port',
-                sample=f"{main['sample_px']}x{main['sample_px']} float32 1-band block of the same synthetic workload, {model} "
-                       f"{k}x{k} fit+apply, {main['impl']}, {main['seconds']:.3f} s per pass",
+    cpu_model = None
+    try:
+        with open('/proc/cpuinfo') as f:
+            cpu_model = next((ln.split(':', 1)[1].strip() for ln in f if ln.startswith('model name')), None)
+    except Exception:
+        pass
+    return dict(value=main['value'], unit='Mpixels*bands/s', cores=main['cores'], kind='port', cpu_model=cpu_model,
+                sample=f"{main['sample_px']}x{main['sample_px']} float32 1-band blocks of the same synthetic workload, {model} "
+                       f"{k}x{k} fit+apply, {main['impl']}, {main['seconds']:.3f} s per round",
                 variants=variants)
 
 
-def spot_check(ctx, model, k, thresh, nodata_variant, d_src, d_ref, d_corr, stride, H, W, y0, x0, wh, ww, norm=None, n_fail=0):
-    """ Not timed: download a window (whole rows y0 .. y0 + wh of one band plane) and compare the GPU output with the numpy
+def spot_check(ctx, model, k, thresh, nodata_variant, d_src, d_ref, d_corr, stride, H, W, y0, x0, wh, ww, norm=None, n_fail=0,
+               band=0, band_stride=0):
+    """ Not timed: download a window (whole rows y0 .. y0 + wh of band plane `band`) and compare the GPU output with the numpy
     oracle.  `norm`: the block statistics the GPU used (gain-blk-offset).  Returns the parity record. """
     from oracle import oracle_np as onp
     r = k // 2
     rows = np.empty((wh, stride), np.float32)
     win = {}
     for name, ptr in (('src', d_src), ('ref', d_ref), ('corr', d_corr)):
-        ctx.d2h(rows, ptr + 4 * (y0 * stride))
+        ctx.d2h(rows, ptr + 4 * (band * band_stride + y0 * stride))
         win[name] = rows[:, x0:x0 + ww].copy()
     nodata = np.nan if nodata_variant in (1, 2) else None
     params, _ = onp.fit(model, win['src'], nodata, win['ref'], nodata, (k, k), False, thresh, norm_model=norm)
@@ -174,8 +216,90 @@ def spot_check(ctx, model, k, thresh, nodata_variant, d_src, d_ref, d_corr, stri
     ok = ~np.isnan(exp)
     rel = float(np.max(np.abs(got[ok] - exp[ok]) / np.maximum(np.abs(exp[ok]), 1e-30))) if ok.any() else 0.0
     n_diff = int((got[ok] != exp[ok]).sum())
-    return dict(window=[int(got.shape[0]), int(got.shape[1])], bitwise_mismatches=n_diff, max_rel_diff=rel,
-                nan_pattern_equal=nan_ok, passed=bool(nan_ok and rel <= 1e-5))
+    return dict(window=[int(got.shape[0]), int(got.shape[1])], band=int(band), origin=[int(y0), int(x0)], bitwise_mismatches=n_diff,
+                max_rel_diff=rel, nan_pattern_equal=nan_ok, passed=bool(nan_ok and rel <= 1e-5))
+
+
+def merge_parity(records):
+    """ several spot-check windows -> one record (`passed` = all of them) that keeps the individual windows """
+    records = [r for r in records if r is not None]
+    if not records:
+        return None
+    if len(records) == 1:
+        return records[0]
+    return dict(window=records[0]['window'], bands=[r['band'] for r in records],
+                bitwise_mismatches=sum(r['bitwise_mismatches'] for r in records),
+                max_rel_diff=max(r['max_rel_diff'] for r in records),
+                nan_pattern_equal=all(r['nan_pattern_equal'] for r in records),
+                passed=all(r['passed'] for r in records), windows=records)
+
+
+def probe_copy(ctx, a, b, out, nbytes, reps=12):
+    """ Achievable bandwidth of THIS box for the fused kernel's byte mix without its stencil: a flat float4 stream, two reads
+    + one write over the run's own planes (hk_stream_probe_dev; shape from tools/ubench_copy.hip), timed with HIP events on
+    the launch stream before the timed region.  SURVEY.md 8(d): "builder also measures achievable copy bandwidth on the box
+    and reports both fractions".  -> GB/s (median over `reps` launches), GB/s (best) """
+    for _ in range(3):
+        ctx.stream_probe_dev(a, b, out, nbytes, 0)
+    evs = [(ctx.event(), ctx.event()) for _ in range(reps)]
+    for e0, e1 in evs:
+        ctx.event_record(e0, 0)
+        ctx.stream_probe_dev(a, b, out, nbytes, 0)
+        ctx.event_record(e1, 0)
+    ctx.stream_sync(0)
+    ms = sorted(ctx.event_elapsed_ms(e0, e1) for e0, e1 in evs)
+    for pair in evs:
+        for e in pair:
+            ctx.event_destroy(e)
+    return 3 * nbytes / (ms[len(ms) // 2] * 1e-3) / 1e9, 3 * nbytes / (ms[0] * 1e-3) / 1e9
+
+
+def power_probe(run_steps, step_ms, seconds=3.0):
+    """ Package power and shader clock while the timed launches repeat back to back for ~`seconds` (OUTSIDE the timed region):
+    rocm-smi samples from a side thread.  The fused 5x5 gain-offset kernel runs at the package power cap with the shader clock
+    throttled, so its time is energy / cap: this record says whether that is the case on this box. """
+    import re
+    import shutil
+    import subprocess
+    import threading
+    smi = shutil.which('rocm-smi') or '/opt/rocm/bin/rocm-smi'
+    if not os.path.exists(smi):
+        return None
+
+    def smi_read(*flags):
+        try:
+            return subprocess.run([smi, *flags], capture_output=True, text=True, timeout=20).stdout
+        except Exception:
+            return ''
+
+    cap = re.search(r'Max Graphics Package Power \(W\):\s*([0-9.]+)', smi_read('--showmaxpower'))
+    samples, stop = [], threading.Event()
+
+    def sampler():
+        while not stop.is_set():
+            t = time.perf_counter()
+            txt = smi_read('--showpower', '--showclocks')
+            w = re.search(r'Package Power \(W\):\s*([0-9.]+)', txt)
+            c = re.search(r'sclk clock level:\s*\S+\s*\((\d+)Mhz\)', txt)
+            if w and c:
+                samples.append((t, float(w.group(1)), float(c.group(1))))
+
+    th = threading.Thread(target=sampler, daemon=True)
+    t0 = time.perf_counter()
+    th.start()
+    n = max(8, int(seconds * 1e3 / max(step_ms, 1e-3)))
+    run_steps(n)
+    t1 = time.perf_counter()
+    stop.set()
+    th.join(timeout=30)
+    # samples taken while the queue was busy (the first ~0.5 s ramps up)
+    busy = [(w, c) for (t, w, c) in samples if t0 + 0.6 <= t <= t1 - 0.3]
+    if not busy:
+        return dict(samples=0)
+    ws, cs = sorted(x[0] for x in busy), sorted(x[1] for x in busy)
+    return dict(package_watts=ws[len(ws) // 2], sclk_mhz=cs[len(cs) // 2], cap_watts=float(cap.group(1)) if cap else None,
+                sclk_max_mhz=2400, samples=len(busy), seconds=round(t1 - t0, 2),
+                method='rocm-smi --showpower --showclocks sampled while the timed launches repeat back to back (outside the timed region); medians')
 
 
 def measured_traffic(args):
@@ -295,6 +419,9 @@ def run_resident(args, ctx, dist, rank, world):
             n_fail += finish(n_steps - 1)
         return n_fail
 
+    # what this box's HBM gives the same byte mix as a flat stream (before anything is timed; it scribbles on corr)
+    copy_med, copy_best = probe_copy(ctx, bufs['src'], bufs['ref'], bufs['corr'], plane_bytes)
+
     run(args.warmup)
     ctx.stream_sync(0)
 
@@ -323,8 +450,21 @@ def run_resident(args, ctx, dist, rank, world):
         wh, ww = min(H, 384), min(W, 1200)
         y0 = max(0, min(H - wh, H // 3))
         x0 = max(0, min(W - ww, (W // 2) // 4 * 4))
-        parity = spot_check(ctx, args.model, k, thresh, args.nodata, bufs['src'], bufs['ref'], bufs['corr'], stride, H, W,
-                            y0, x0, wh, ww, norm, n_fail)
+        checks = [spot_check(ctx, args.model, k, thresh, args.nodata, bufs['src'], bufs['ref'], bufs['corr'], stride, H, W,
+                             y0, x0, wh, ww, norm, n_fail)]
+        if B > 1:
+            # ... and in the LAST band plane of the launch (plane offsets of several GB), at another place of the raster
+            if args.model == 'gain-blk-offset':
+                norm = nh[B - 1]
+            y1 = max(0, min(H - wh, (2 * H) // 3 + 5))
+            x1 = max(0, min(W - ww, (W // 5) // 4 * 4))
+            checks.append(spot_check(ctx, args.model, k, thresh, args.nodata, bufs['src'], bufs['ref'], bufs['corr'], stride, H, W,
+                                     y1, x1, wh, ww, norm, n_fail, band=B - 1, band_stride=band_stride))
+        parity = merge_parity(checks)
+
+    power = None
+    if rank == 0 and world == 1 and getattr(args, 'power_probe', False):
+        power = power_probe(lambda n: (run(n), ctx.sync()), elapsed / args.steps * 1e3)
 
     for pair in events + [tuple(fail_ready)]:
         for e in pair:
@@ -351,10 +491,10 @@ def run_resident(args, ctx, dist, rank, world):
                     parallelism=f'{world} rank(s) x 1 GPU, one raster per rank, no collective',
                     r2_mask_failures_per_step=n_fail),
         roofline=dict(achieved_bytes=ALGO_BYTES_PER_PX * px_bands, avg_launch_ms=avg_ms, traffic=traffic,
-                      traffic_source=traffic_source,
+                      traffic_source=traffic_source, copy_gbps=copy_med, copy_gbps_best=copy_best,
                       kernel='hk::fit_apply_kernel' + (' + block statistics (hk_norm.hip)' if args.model == 'gain-blk-offset' else '')
                              + (' + in-painting passes (whole step)' if n_fail else '')),
-        parity=parity)
+        parity=parity, power=power)
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -382,6 +522,7 @@ def run_blocks(args, ctx, dist, rank, world):
     bufs['norm'] = ctx.dev_alloc(16 * B * max(1, len(mine)))
     ctx.synth_fill_dev(bufs['src'], bufs['ref'], B, H, W, stride, band_stride, seed=1234, nodata_variant=args.nodata, stream=0)
     ctx.stream_sync(0)
+    copy_med, copy_best = probe_copy(ctx, bufs['src'], bufs['ref'], bufs['corr'], 4 * band_stride * B)
     n_streams = ctx.n_streams
 
     jobs = []
@@ -446,6 +587,7 @@ def run_blocks(args, ctx, dist, rank, world):
                     blocks_per_rank=B * len(mine),
                     parallelism=f'{world} rank(s) x 1 GPU, the {len(positions)} block positions dealt round-robin to the ranks, no collective'),
         roofline=dict(achieved_bytes=ALGO_BYTES_PER_PX * my_px, avg_launch_ms=elapsed / args.steps * 1e3, traffic=None, traffic_source=None,
+                      copy_gbps=copy_med, copy_gbps_best=copy_best,
                       kernel=f'one step of this rank: {len(mine)} x (block statistics + hk::fit_apply_kernel over {B} bands), wall time on {n_streams} streams'),
         parity=parity, end_to_end=e2e)
 
@@ -524,6 +666,10 @@ def run_tiles(args, ctx, dist, rank, world):
             job.scratch = d['scratch']
         tiles.append((d, job, ctx.pinned_empty((B,), np.uint64), ctx.event()))
     ctx.stream_sync(0)
+    copy_med = copy_best = None
+    if tiles:
+        d0 = tiles[0][0]
+        copy_med, copy_best = probe_copy(ctx, d0['src'], d0['ref'], d0['corr'], tile_bytes)
 
     def step():
         """ every tile's fused launch on its stream, then the host's look at the r2-mask counters of all of them """
@@ -577,6 +723,7 @@ def run_tiles(args, ctx, dist, rank, world):
                     parallelism=f'{world} rank(s) x 1 GPU x {n_streams} streams, consecutive runs of the tile list per rank, no collective',
                     r2_mask_failures_per_step=n_fail // max(1, args.steps)),
         roofline=dict(achieved_bytes=ALGO_BYTES_PER_PX * my_px, avg_launch_ms=elapsed / args.steps * 1e3, traffic=None, traffic_source=None,
+                      copy_gbps=copy_med, copy_gbps_best=copy_best,
                       kernel=f'one step of this rank: {len(mine)} x hk::fit_apply_kernel on {n_streams} streams, wall time'),
         parity=parity, end_to_end=e2e)
 
@@ -658,7 +805,7 @@ def main():
     if args.config == 2 and args.nodata == 0 and world == 1 and not args.no_nan_variant and not args.params:
         import copy
         a2 = copy.copy(args)
-        a2.nodata, a2.steps, a2.warmup = 2, min(args.steps, 20), 3
+        a2.nodata, a2.steps, a2.warmup, a2.power_probe = 2, min(args.steps, 20), 3, False
         r2_ = run_resident(a2, ctx, dist, rank, world)
         rl2 = r2_['roofline']
         nan_variant = {
@@ -666,8 +813,41 @@ def main():
             'value': round(r2_['value'], 1), 'steps': a2.steps, 'ms_per_step': round(r2_['elapsed'] / a2.steps * 1e3, 4),
             'avg_launch_ms': round(rl2['avg_launch_ms'], 4),
             'frac': round(rl2['achieved_bytes'] / (rl2['avg_launch_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+            'frac_of_copy': round(rl2['achieved_bytes'] / (rl2['avg_launch_ms'] * 1e-3) / 1e9 / rl2['copy_gbps'], 4) if rl2.get('copy_gbps') else None,
             'parity_spot_check': r2_['parity'],
         }
+
+    # BASELINE.json's other configurations, driver-timed beside the headline: a few steps each of configs[1], [3], [4] with
+    # their own parity spot checks -- compact records, never `value` (their full lines: --config N)
+    other = None
+    if args.config == 2 and world == 1 and not args.no_other_configs and not args.params and args.nodata == 0 \
+            and (args.model, args.kernel, args.size, args.bands) == ('gain-offset', 5, 16384, 4):
+        import copy
+        other = {}
+        for cfg, (steps, warm) in {1: (40, 3), 3: (6, 1), 4: (4, 1)}.items():
+            a3 = copy.copy(args)
+            a3.config = cfg
+            for key in ('model', 'kernel', 'size', 'bands', 'tiles'):
+                setattr(a3, key, CONFIGS[cfg].get(key))
+            a3.steps, a3.warmup, a3.no_end_to_end, a3.no_thresh, a3.power_probe, a3.seg_rows = steps, warm, True, False, False, 0
+            c3 = ctx
+            if cfg == 3:   # configs[3] deals its block positions to eight streams (see below)
+                c3 = _hk.Context(ctx.device, n_streams=int(os.environ.get('HK_BENCH_STREAMS', '8')))
+            try:
+                r3 = {1: run_resident, 3: run_blocks, 4: run_tiles}[cfg](a3, c3, dist, rank, world)
+            finally:
+                if c3 is not ctx:
+                    c3.close()
+            rl3 = r3['roofline']
+            ach3 = rl3['achieved_bytes'] / (rl3['avg_launch_ms'] * 1e-3) / 1e9
+            other[str(cfg)] = {
+                'workload': r3['workload'], 'value': round(r3['value'], 1), 'steps': steps, 'scaling': r3['scaling'],
+                'ms_per_step': round(r3['elapsed'] / steps * 1e3, 4), 'avg_launch_ms': round(rl3['avg_launch_ms'], 4),
+                'frac': round(ach3 / HBM_PEAK_GBPS, 4),
+                'frac_of_copy': round(ach3 / rl3['copy_gbps'], 4) if rl3.get('copy_gbps') else None,
+                'parity_passed': None if r3['parity'] is None else bool(r3['parity']['passed']),
+                'parity_bitwise_mismatches': None if r3['parity'] is None else r3['parity']['bitwise_mismatches'],
+            }
 
     if rank == 0:
         cpu = None
@@ -688,6 +868,11 @@ def main():
                 'frac': round(achieved / HBM_PEAK_GBPS, 4), 'traffic': rl['traffic'], 'traffic_source': rl['traffic_source'],
                 'kernel': rl['kernel'], 'avg_launch_ms': round(rl['avg_launch_ms'], 4),
                 'algorithmic_bytes_per_launch': rl['achieved_bytes'],
+                # the same fraction against what THIS box's HBM gives a flat 2-read 1-write float4 stream of the run's planes
+                # (hk_stream_probe_dev, measured before the timed region; SURVEY.md 8(d) "reports both fractions")
+                'copy_gbps_measured': round(rl['copy_gbps'], 1) if rl.get('copy_gbps') else None,
+                'copy_gbps_measured_best': round(rl['copy_gbps_best'], 1) if rl.get('copy_gbps_best') else None,
+                'frac_of_copy': round(achieved / rl['copy_gbps'], 4) if rl.get('copy_gbps') else None,
             },
             'cpu_baseline': cpu,
             'parity_spot_check': res['parity'],
@@ -696,6 +881,10 @@ def main():
             out['end_to_end'] = res['end_to_end']
         if nan_variant is not None:
             out['nodata_nan_variant'] = nan_variant
+        if other is not None:
+            out['other_configs'] = other
+        if res.get('power') is not None:
+            out['power'] = res['power']
         if dist.backend() is not None:
             out['dist_backend'] = dist.backend()   # 'nccl' = RCCL; absent for a single process without a group
         print(json.dumps(out), flush=True)

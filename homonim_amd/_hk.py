@@ -19,7 +19,7 @@ from homonim_amd.errors import DeviceError
 _LIB_PATH = os.environ.get('HOMONIM_AMD_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib',
                                                                'libhomonim_hk.so')
 
-HK_OK, HK_ERR_ARG, HK_ERR_HIP, HK_ERR_NODEVICE, HK_ERR_UNSUPPORTED, HK_ERR_NOMEM = 0, -1, -2, -3, -4, -5
+HK_OK, HK_ERR_ARG, HK_ERR_HIP, HK_ERR_NODEVICE, HK_ERR_UNSUPPORTED, HK_ERR_NOMEM, HK_ERR_ALREADY = 0, -1, -2, -3, -4, -5, -6
 MODEL_CODES = {'gain': 0, 'gain-blk-offset': 1, 'gain-offset': 2}
 NODATA_NONE, NODATA_NAN, NODATA_VALUE = 0, 1, 2
 
@@ -48,7 +48,7 @@ DTYPE_CODES = {'float32': 0, 'uint8': 1, 'uint16': 2, 'int16': 3, 'uint32': 4, '
 
 class OutWindow(C.Structure):
     _fields_ = [('stride', C.c_int64), ('band_stride', C.c_int64), ('row0', C.c_int32), ('col0', C.c_int32),
-                ('rows', C.c_int32), ('cols', C.c_int32)]
+                ('rows', C.c_int32), ('cols', C.c_int32), ('param_stride', C.c_int64)]
 
 
 class DevJob(C.Structure):
@@ -113,6 +113,7 @@ SIGNATURES = {
     'hk_compare_sums_dev': (C.c_int, [C.c_void_p, _P(DevJob), C.c_int32, C.c_float, C.c_int32, C.c_float, C.c_void_p]),
     'hk_synth_fill_dev': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64,
                                     C.c_int64, C.c_uint64, C.c_int32, C.c_int32]),
+    'hk_stream_probe_dev': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32]),
     'hk_event_create': (C.c_int, [C.c_void_p, _P(C.c_void_p)]),
     'hk_event_destroy': (C.c_int, [C.c_void_p, C.c_void_p]),
     'hk_event_record': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
@@ -123,6 +124,9 @@ SIGNATURES = {
 
 _lib = None
 _lib_lock = threading.Lock()
+# page-lock registrations made through Context.pin: (address, bytes) -> [users, registered by us]
+_pins = {}
+_pin_lock = threading.Lock()
 
 
 def lib_path() -> str:
@@ -320,23 +324,30 @@ class Context:
         n_param = 0
         stride = band_stride = 0
         out_dtype = np.dtype(np.float32)
+        pstride = 0
         if corr_dst is not None:
-            assert corr_dst.shape == (rows, cols) and corr_dst.strides[1] == corr_dst.dtype.itemsize
+            if corr_dst.shape != (rows, cols) or corr_dst.strides[1] != corr_dst.dtype.itemsize or \
+                    corr_dst.strides[0] % corr_dst.dtype.itemsize or corr_dst.strides[0] < cols * corr_dst.dtype.itemsize:
+                raise ValueError('`corr_dst` must be a (rows, cols) view of the window with unit column stride')
             out_dtype = corr_dst.dtype
             stride = corr_dst.strides[0] // corr_dst.dtype.itemsize
         if params_dst is not None:
-            assert params_dst.dtype == np.float32 and params_dst.shape[1:] == (rows, cols) and params_dst.strides[2] == 4
+            if params_dst.dtype != np.float32 or params_dst.ndim != 3 or params_dst.shape[1:] != (rows, cols) or \
+                    params_dst.strides[2] != 4 or params_dst.strides[1] % 4 or params_dst.strides[0] % 4 or \
+                    params_dst.strides[1] < 4 * cols or params_dst.strides[0] < 0:
+                raise ValueError('`params_dst` must be a float32 (bands, rows, cols) view of the window with unit column stride')
             n_param = params_dst.shape[0]
-            pstride = params_dst.strides[1] // 4
-            assert corr_dst is None or pstride == stride, 'corrected and parameter rasters must share their row stride'
-            stride, band_stride = pstride, params_dst.strides[0] // 4
+            pstride = params_dst.strides[1] // 4  # its own row stride: the corrected and parameter rasters need not share one
+            band_stride = params_dst.strides[0] // 4
+            if corr_dst is None:
+                stride = pstride
         if out_dtype.name not in DTYPE_CODES:
             raise ValueError(f'unsupported output dtype {out_dtype}')
         keep_nan = out_nodata is None or (isinstance(out_nodata, float) and math.isnan(out_nodata))
         io = IoDesc(DTYPE_CODES[src.dtype.name], DTYPE_CODES[ref.dtype.name], DTYPE_CODES[out_dtype.name],
                     0 if (keep_nan and out_dtype.kind == 'f') or out_nodata is None else 1,
                     0.0 if out_nodata is None or keep_nan else float(out_nodata))
-        win = OutWindow(stride, band_stride, row0, col0, rows, cols)
+        win = OutWindow(stride, band_stride, row0, col0, rows, cols, pstride)
         norm = np.zeros(2, np.float64)
         fail = C.c_uint64(0)
         nin = np.ascontiguousarray(norm_in, dtype=np.float64) if norm_in is not None else None
@@ -443,13 +454,44 @@ class Context:
         buf._owner = _Owner()
         return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
-    def pin(self, arr: np.ndarray):
-        """ Page-lock an existing C-contiguous array in place (hipHostRegister); undo with ``unpin``. """
-        assert arr.flags['C_CONTIGUOUS']
-        _check(self._lib.hk_host_register(self._h, arr.ctypes.data_as(C.c_void_p), arr.nbytes))
+    def pin(self, arr: np.ndarray) -> bool:
+        """ Page-lock an existing C-contiguous array in place (hipHostRegister); undo with ``unpin``.  Registrations are
+        counted per address range across the process: concurrent users of one array (two ``RasterFuse.process`` calls on
+        the same source raster) share one registration and the last ``unpin`` removes it.  Memory that is page-locked
+        already by somebody else (``pinned_empty``, an enclosing registration) is left as it is.  -> whether the range is
+        page-locked now. """
+        if not arr.flags['C_CONTIGUOUS']:
+            raise ValueError('only C-contiguous arrays can be page-locked in place')
+        key = (arr.ctypes.data, arr.nbytes)
+        with _pin_lock:
+            ent = _pins.get(key)
+            if ent is not None:
+                ent[0] += 1
+                return True
+            rc = self._lib.hk_host_register(self._h, C.c_void_p(key[0]), key[1])
+            if rc == HK_ERR_ALREADY:
+                _pins[key] = [1, False]   # not ours to unregister
+                return True
+            _check(rc)
+            _pins[key] = [1, True]
+            return True
 
     def unpin(self, arr: np.ndarray):
-        _check(self._lib.hk_host_unregister(self._h, arr.ctypes.data_as(C.c_void_p)))
+        key = (arr.ctypes.data, arr.nbytes)
+        with _pin_lock:
+            ent = _pins.get(key)
+            if ent is None:
+                return
+            ent[0] -= 1
+            if ent[0] > 0:
+                return
+            del _pins[key]
+            if ent[1]:
+                _check(self._lib.hk_host_unregister(self._h, C.c_void_p(key[0])))
+
+    def stream_probe_dev(self, a_dptr: int, b_dptr: int, out_dptr: int, nbytes: int, stream: int = 0):
+        """ One launch of the flat 2-read 1-write float4 stream out = a + b over three device buffers (hk_stream_probe_dev). """
+        _check(self._lib.hk_stream_probe_dev(self._h, C.c_void_p(a_dptr), C.c_void_p(b_dptr), C.c_void_p(out_dptr), nbytes, stream))
 
     # -- device-resident helpers (bench / streaming) ------------------------------------------------------------------
     def dev_alloc(self, nbytes: int) -> int:

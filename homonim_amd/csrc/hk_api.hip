@@ -33,11 +33,22 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+// HIP keeps a per-thread "last error" until somebody reads it, and the launch wrappers of the kernel files report their
+// launches through hipGetLastError(): a failure this layer hands back to a caller who carries on (e.g. hk_host_register of
+// memory that is page-locked already) would otherwise surface again as the status of that thread's NEXT launch.  So a
+// failing call clears the state it leaves behind, and every entry point that selects the device starts from a clean slate.
 #define HK_HIP(expr)                                                                                       \
     do {                                                                                                   \
         hipError_t _e = (expr);                                                                            \
-        if (_e != hipSuccess)                                                                              \
+        if (_e != hipSuccess) {                                                                            \
+            (void)hipGetLastError();                                                                       \
             return fail(HK_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+        }                                                                                                  \
+    } while (0)
+#define HK_ENTER(ctx)                         \
+    do {                                      \
+        HK_HIP(hipSetDevice((ctx)->device));  \
+        (void)hipGetLastError();              \
     } while (0)
 
 struct Slot {
@@ -480,17 +491,19 @@ int run_host(hk_ctx* ctx, const hk_fit_desc* desc, const hk_io_desc* io, const v
     }
     // output window (defaults: the whole block, written packed)
     int wr0 = 0, wc0 = 0, wrows = height, wcols = width;
-    int64_t out_stride = width, out_band_stride = (int64_t)height * width;
+    int64_t out_stride = width, par_stride = width, out_band_stride = (int64_t)height * width;
     if (ow) {
         wr0 = ow->row0, wc0 = ow->col0, wrows = ow->rows, wcols = ow->cols;
         out_stride = ow->stride, out_band_stride = ow->band_stride;
+        par_stride = ow->param_stride > 0 ? ow->param_stride : ow->stride;
         if (wr0 < 0 || wc0 < 0 || wrows < 1 || wcols < 1 || wr0 + wrows > height || wc0 + wcols > width)
             return fail(HK_ERR_ARG, "output window outside the block");
-        if (out_stride < wcols) return fail(HK_ERR_ARG, "output row stride smaller than the window");
-        if (params_out && n_param_bands > 1 && out_band_stride < (int64_t)(wrows - 1) * out_stride + wcols)
+        if ((corr_out && out_stride < wcols) || (params_out && par_stride < wcols))
+            return fail(HK_ERR_ARG, "output row stride smaller than the window");
+        if (params_out && n_param_bands > 1 && out_band_stride < (int64_t)(wrows - 1) * par_stride + wcols)
             return fail(HK_ERR_ARG, "output band stride smaller than a plane of the window");
     }
-    HK_HIP(hipSetDevice(ctx->device));
+    HK_ENTER(ctx);
 
     const int64_t stride = (width + ROW_ALIGN - 1) / ROW_ALIGN * ROW_ALIGN;
     const size_t plane = (size_t)stride * height * sizeof(float);
@@ -562,7 +575,7 @@ int run_host(hk_ctx* ctx, const hk_fit_desc* desc, const hk_io_desc* io, const v
         float* outs[3] = {d_gain, d_off, d_r2};
         if (params_out)
             for (int b = 0; b < n_param_bands; ++b)
-                HK_HIP(hipMemcpy2DAsync(params_out + (size_t)b * out_band_stride, out_stride * sizeof(float),
+                HK_HIP(hipMemcpy2DAsync(params_out + (size_t)b * out_band_stride, par_stride * sizeof(float),
                                         outs[b] + win_off, stride * sizeof(float), wbytes, wrows, hipMemcpyDeviceToHost,
                                         sl.stream));
         if (corr_out) {
@@ -684,7 +697,7 @@ int hk_ctx_destroy(hk_ctx* ctx) {
 
 int hk_ctx_sync(hk_ctx* ctx) {
     if (!ctx) return fail(HK_ERR_ARG, "ctx is NULL");
-    HK_HIP(hipSetDevice(ctx->device));
+    HK_ENTER(ctx);
     HK_HIP(hipDeviceSynchronize());
     return HK_OK;
 }
@@ -733,7 +746,7 @@ int hk_apply(hk_ctx* ctx, const float* src, int64_t src_stride, const float* par
     if (!src || !params || !out) return fail(HK_ERR_ARG, "NULL pointer argument");
     if (height < 1 || width < 1) return fail(HK_ERR_ARG, "empty raster %d x %d", height, width);
     if (src_stride < width) return fail(HK_ERR_ARG, "row stride smaller than width");
-    HK_HIP(hipSetDevice(ctx->device));
+    HK_ENTER(ctx);
     const int64_t stride = (width + ROW_ALIGN - 1) / ROW_ALIGN * ROW_ALIGN;
     const size_t plane = (size_t)stride * height * sizeof(float);
     SlotLease lease(ctx);
@@ -777,7 +790,7 @@ int hk_refspace_fit_apply(hk_ctx* ctx, const hk_fit_desc* desc, const hk_io_desc
     const bool r2 = needs_r2(desc);
     if (params_out && n_param_bands != (r2 ? 3 : 2))
         return fail(HK_ERR_ARG, "n_param_bands must be %d for this model configuration", r2 ? 3 : 2);
-    HK_HIP(hipSetDevice(ctx->device));
+    HK_ENTER(ctx);
 
     const int64_t ss = (src_width + ROW_ALIGN - 1) / ROW_ALIGN * ROW_ALIGN;  // source-grid row stride
     const int64_t rs = (ref_width + ROW_ALIGN - 1) / ROW_ALIGN * ROW_ALIGN;  // reference-grid row stride
@@ -907,7 +920,7 @@ int hk_reproject(hk_ctx* ctx, const float* src, int32_t n_bands, int32_t src_hei
         return fail(HK_ERR_UNSUPPORTED, "resampling %d is not a warp method (GRA_* codes 0..6 and 8..14 are built; 7 = gauss is "
                                         "an overview-only method in GDAL / rasterio as well)", resampling);
     if (dst_height > 65535) return fail(HK_ERR_UNSUPPORTED, "destination taller than 65535 rows");
-    HK_HIP(hipSetDevice(ctx->device));
+    HK_ENTER(ctx);
     const size_t sbytes = (size_t)n_bands * src_height * src_width * 4, dbytes = (size_t)n_bands * dst_height * dst_width * 4;
     const size_t o_dst = (sbytes + 255) / 256 * 256;
     SlotLease lease(ctx);
@@ -936,7 +949,7 @@ int hk_partial_mask(hk_ctx* ctx, const float* in, int64_t in_stride, int32_t in_
     if ((kh + 2) * (kw + 2) > 65535) return fail(HK_ERR_UNSUPPORTED, "kernel too large for mask_partial");
     if (corr_out && !src) return fail(HK_ERR_ARG, "corr_out needs src");
     if (in_stride < width || (src && src_stride < width)) return fail(HK_ERR_ARG, "row stride smaller than width");
-    HK_HIP(hipSetDevice(ctx->device));
+    HK_ENTER(ctx);
     const int64_t stride = (width + ROW_ALIGN - 1) / ROW_ALIGN * ROW_ALIGN;
     const size_t plane = (size_t)stride * height * sizeof(float);
     size_t total = 0;
@@ -977,7 +990,7 @@ int hk_partial_mask(hk_ctx* ctx, const float* in, int64_t in_stride, int32_t in_
 // ---------------------------------------------------------------------------------------------------------------------
 int hk_host_alloc(hk_ctx* ctx, size_t bytes, void** hptr) {
     if (!ctx || !hptr) return fail(HK_ERR_ARG, "NULL argument");
-    HK_HIP(hipSetDevice(ctx->device));
+    HK_ENTER(ctx);
     if (hipHostMalloc(hptr, bytes, hipHostMallocPortable) != hipSuccess)
         return fail(HK_ERR_NOMEM, "hipHostMalloc(%zu) failed", bytes);
     return HK_OK;
@@ -990,8 +1003,19 @@ int hk_host_free(hk_ctx* ctx, void* hptr) {
 }
 int hk_host_register(hk_ctx* ctx, void* hptr, size_t bytes) {
     if (!ctx || !hptr) return fail(HK_ERR_ARG, "NULL argument");
-    HK_HIP(hipSetDevice(ctx->device));
-    HK_HIP(hipHostRegister(hptr, bytes, hipHostRegisterPortable));
+    HK_ENTER(ctx);
+    // page-locked already (hk_host_alloc, or somebody's registration)?  hipHostRegister answers that case with different
+    // errors (AlreadyRegistered, InvalidValue for hipHostMalloc memory) or not at all, so ask first
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, hptr) == hipSuccess && attr.type == hipMemoryTypeHost)
+        return fail(HK_ERR_ALREADY, "host memory is page-locked already");
+    (void)hipGetLastError();  // pageable memory: the query itself may have failed
+    hipError_t e = hipHostRegister(hptr, bytes, hipHostRegisterPortable);
+    if (e == hipErrorHostMemoryAlreadyRegistered) {
+        (void)hipGetLastError();
+        return fail(HK_ERR_ALREADY, "host memory is page-locked already");
+    }
+    HK_HIP(e);
     return HK_OK;
 }
 int hk_host_unregister(hk_ctx* ctx, void* hptr) {
@@ -1003,31 +1027,31 @@ int hk_host_unregister(hk_ctx* ctx, void* hptr) {
 
 int hk_dev_alloc(hk_ctx* ctx, size_t bytes, void** dptr) {
     if (!ctx || !dptr) return fail(HK_ERR_ARG, "NULL argument");
-    HK_HIP(hipSetDevice(ctx->device));
+    HK_ENTER(ctx);
     if (hipMalloc(dptr, bytes) != hipSuccess) return fail(HK_ERR_NOMEM, "hipMalloc(%zu) failed", bytes);
     return HK_OK;
 }
 int hk_dev_free(hk_ctx* ctx, void* dptr) {
     if (!ctx) return fail(HK_ERR_ARG, "ctx is NULL");
-    HK_HIP(hipSetDevice(ctx->device));
+    HK_ENTER(ctx);
     HK_HIP(hipFree(dptr));
     return HK_OK;
 }
 int hk_memcpy_h2d(hk_ctx* ctx, void* dst, const void* src, size_t bytes) {
     if (!ctx) return fail(HK_ERR_ARG, "ctx is NULL");
-    HK_HIP(hipSetDevice(ctx->device));
+    HK_ENTER(ctx);
     HK_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
     return HK_OK;
 }
 int hk_memcpy_d2h(hk_ctx* ctx, void* dst, const void* src, size_t bytes) {
     if (!ctx) return fail(HK_ERR_ARG, "ctx is NULL");
-    HK_HIP(hipSetDevice(ctx->device));
+    HK_ENTER(ctx);
     HK_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
     return HK_OK;
 }
 int hk_memset(hk_ctx* ctx, void* dst, int value, size_t bytes) {
     if (!ctx) return fail(HK_ERR_ARG, "ctx is NULL");
-    HK_HIP(hipSetDevice(ctx->device));
+    HK_ENTER(ctx);
     HK_HIP(hipMemset(dst, value, bytes));
     return HK_OK;
 }
@@ -1089,7 +1113,7 @@ int hk_fit_apply_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* job
     rc = check_job(ctx, job);
     if (rc) return rc;
     if (desc->model == HK_MODEL_GAIN_BLK_OFFSET && !job->norm) return fail(HK_ERR_ARG, "gain-blk-offset needs job->norm");
-    HK_HIP(hipSetDevice(ctx->device));
+    HK_ENTER(ctx);
     hk::FitArgs a;
     memset(&a, 0, sizeof(a));
     a.src = job->src, a.ref = job->ref, a.gain = job->gain, a.offset = job->offset, a.r2 = job->r2, a.corr = job->corr;
@@ -1119,7 +1143,7 @@ int hk_fail_counts_async(hk_ctx* ctx, const hk_dev_job* job, uint64_t* host_coun
     int rc = check_job(ctx, job);
     if (rc) return rc;
     if (!job->fail_count || !host_counts || !ready) return fail(HK_ERR_ARG, "NULL argument");
-    HK_HIP(hipSetDevice(ctx->device));
+    HK_ENTER(ctx);
     Slot& sl = ctx->slots[job->stream];
     const size_t bytes = (size_t)job->n_bands * sizeof(unsigned long long);
     HK_HIP(hipMemcpyAsync(host_counts, job->fail_count, bytes, hipMemcpyDeviceToHost, sl.stream));
@@ -1131,7 +1155,7 @@ int hk_fail_counts_async(hk_ctx* ctx, const hk_dev_job* job, uint64_t* host_coun
 
 int hk_event_sync(hk_ctx* ctx, hk_event* ev) {
     if (!ctx || !ev) return fail(HK_ERR_ARG, "NULL argument");
-    HK_HIP(hipSetDevice(ctx->device));
+    HK_ENTER(ctx);
     HK_HIP(hipEventSynchronize(ev->ev));
     return HK_OK;
 }
@@ -1145,7 +1169,7 @@ int hk_inpaint_dev_counts(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job
     if (n_fail_out) *n_fail_out = 0;
     if (desc->model != HK_MODEL_GAIN_OFFSET || !desc->has_r2_thresh) return HK_OK;  // nothing to in-paint
     if (!counts) return fail(HK_ERR_ARG, "counts is NULL");
-    HK_HIP(hipSetDevice(ctx->device));
+    HK_ENTER(ctx);
     Slot& sl = ctx->slots[job->stream];
     const bool r2 = needs_r2(desc);
     const size_t plane = (size_t)job->stride * job->height * sizeof(float);
@@ -1216,7 +1240,7 @@ int hk_inpaint_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* job, 
     if (desc->model != HK_MODEL_GAIN_OFFSET || !desc->has_r2_thresh) return HK_OK;  // nothing to in-paint
     if (!job->fail_count) return fail(HK_ERR_ARG, "job->fail_count is NULL");
     if (job->n_bands > 1024) return fail(HK_ERR_ARG, "too many bands");
-    HK_HIP(hipSetDevice(ctx->device));
+    HK_ENTER(ctx);
     Slot& sl = ctx->slots[job->stream];
     std::vector<uint64_t> counts((size_t)job->n_bands);
     HK_HIP(hipMemcpyAsync(counts.data(), job->fail_count, counts.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, sl.stream));
@@ -1255,7 +1279,7 @@ int hk_compare_sums_dev(hk_ctx* ctx, const hk_dev_job* job, int32_t src_nodata_m
     if (rc) return rc;
     if (!sums_dev) return fail(HK_ERR_ARG, "sums_dev is NULL");
     if ((rc = check_nodata_mode(src_nodata_mode)) || (rc = check_nodata_mode(ref_nodata_mode))) return rc;
-    HK_HIP(hipSetDevice(ctx->device));
+    HK_ENTER(ctx);
     Slot& sl = ctx->slots[job->stream];
     rc = ensure_stream_ws(ctx, sl, hk::compare_workspace_bytes(job->n_bands));
     if (rc) return rc;
@@ -1278,7 +1302,7 @@ int hk_compare_sums(hk_ctx* ctx, const float* src, int64_t src_stride, int32_t s
     if (src_stride < width || ref_stride < width) return fail(HK_ERR_ARG, "row stride smaller than width");
     int rc;
     if ((rc = check_nodata_mode(src_nodata_mode)) || (rc = check_nodata_mode(ref_nodata_mode))) return rc;
-    HK_HIP(hipSetDevice(ctx->device));
+    HK_ENTER(ctx);
     const int64_t stride = (width + ROW_ALIGN - 1) / ROW_ALIGN * ROW_ALIGN;
     const size_t plane = (size_t)stride * height * sizeof(float);
     const size_t ws_bytes = hk::compare_workspace_bytes(1);
@@ -1311,7 +1335,7 @@ int hk_block_norm_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* jo
     rc = check_job(ctx, job);
     if (rc) return rc;
     if (!norm_dev) return fail(HK_ERR_ARG, "norm_dev is NULL");
-    HK_HIP(hipSetDevice(ctx->device));
+    HK_ENTER(ctx);
     Slot& sl = ctx->slots[job->stream];
     rc = ensure_stream_ws(ctx, sl, hk::norm_workspace_bytes(job->n_bands, job->height, job->width));
     if (rc) return rc;
@@ -1337,7 +1361,7 @@ int hk_block_norm_split_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_j
     if (!xchg_dev || !norm_dev) return fail(HK_ERR_ARG, "xchg_dev / norm_dev is NULL");
     if (phase < 0 || phase > 5) return fail(HK_ERR_ARG, "phase %d outside 0..5", phase);
     if (world_size < 1) return fail(HK_ERR_ARG, "world_size < 1");
-    HK_HIP(hipSetDevice(ctx->device));
+    HK_ENTER(ctx);
     Slot& sl = ctx->slots[job->stream];
     // the phases of one block share the stream's workspace: phase 0 sizes it, the others find it as it was left
     rc = ensure_stream_ws(ctx, sl, hk::norm_workspace_bytes(job->n_bands, job->height, job->width));
@@ -1355,15 +1379,24 @@ int hk_synth_fill_dev(hk_ctx* ctx, float* src, float* ref, int32_t n_bands, int3
                       int64_t stride, int64_t band_stride, uint64_t seed, int32_t nodata_variant, int32_t stream) {
     if (!ctx || !src || !ref) return fail(HK_ERR_ARG, "NULL argument");
     if (stream < 0 || stream >= (int)ctx->slots.size()) return fail(HK_ERR_ARG, "bad stream index");
-    HK_HIP(hipSetDevice(ctx->device));
+    HK_ENTER(ctx);
     HK_HIP(hk::launch_synth_fill(src, ref, n_bands, height, width, stride, band_stride, seed, nodata_variant,
                                  ctx->slots[stream].stream));
     return HK_OK;
 }
 
+int hk_stream_probe_dev(hk_ctx* ctx, const void* a, const void* b, void* out, size_t n_bytes, int32_t stream) {
+    if (!ctx || !a || !b || !out) return fail(HK_ERR_ARG, "NULL argument");
+    if (n_bytes % 16) return fail(HK_ERR_ARG, "n_bytes must be a multiple of 16");
+    if (stream < 0 || stream >= (int)ctx->slots.size()) return fail(HK_ERR_ARG, "bad stream index");
+    HK_ENTER(ctx);
+    HK_HIP(hk::launch_stream_probe(a, b, out, n_bytes, ctx->slots[stream].stream));
+    return HK_OK;
+}
+
 int hk_event_create(hk_ctx* ctx, hk_event** ev) {
     if (!ctx || !ev) return fail(HK_ERR_ARG, "NULL argument");
-    HK_HIP(hipSetDevice(ctx->device));
+    HK_ENTER(ctx);
     hk_event* e = new (std::nothrow) hk_event();
     if (!e) return fail(HK_ERR_NOMEM, "out of host memory");
     hipError_t he = hipEventCreate(&e->ev);
@@ -1401,7 +1434,7 @@ int hk_stream_sync(hk_ctx* ctx, int32_t stream) {
 
 int hk_selftest(hk_ctx* ctx) {
     if (!ctx) return fail(HK_ERR_ARG, "ctx is NULL");
-    HK_HIP(hipSetDevice(ctx->device));
+    HK_ENTER(ctx);
     int* d = nullptr;
     HK_HIP(hipMalloc(&d, sizeof(int)));
     int code = -1;

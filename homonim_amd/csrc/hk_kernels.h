@@ -150,6 +150,9 @@ hipError_t launch_apply_space(const float* src, long long src_stride, int nd_mod
                               const float* offset, long long par_stride, const float* keep, float* out,
                               long long out_stride, int height, int width, hipStream_t stream);
 
+// flat 2-read 1-write float4 stream (measurement aid: what the HBM gives the fused kernel's byte mix without its stencil)
+hipError_t launch_stream_probe(const void* a, const void* b, void* out, size_t n_bytes, hipStream_t stream);
+
 // returns 0 on pass; writes a diagnostic code otherwise
 hipError_t launch_selftest(int* result_dev, hipStream_t stream);
 

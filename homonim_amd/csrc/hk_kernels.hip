@@ -1419,6 +1419,37 @@ hipError_t launch_synth_fill(float* src, float* ref, int n_bands, int height, in
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Flat 2-read 1-write stream (bench.py `roofline.copy_gbps_measured`; tools/ubench_copy.hip holds the sweep this shape
+// came out of: persistent grid of 4 workgroups per CU, four 16-byte loads in flight per lane and array, non-temporal).
+__global__ void __launch_bounds__(256) stream_probe_kernel(const hk_v4* __restrict__ a, const hk_v4* __restrict__ b,
+                                                           hk_v4* __restrict__ o, size_t n) {
+    constexpr int U = 4;
+    const size_t chunk = (size_t)U * 256;
+    for (size_t base = (size_t)blockIdx.x * chunk; base < n; base += (size_t)gridDim.x * chunk) {
+        hk_v4 va[U], vb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const size_t i = base + (size_t)u * 256 + threadIdx.x;
+            va[u] = i < n ? __builtin_nontemporal_load(a + i) : hk_v4{0.f, 0.f, 0.f, 0.f};
+            vb[u] = i < n ? __builtin_nontemporal_load(b + i) : hk_v4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const size_t i = base + (size_t)u * 256 + threadIdx.x;
+            if (i < n) __builtin_nontemporal_store(va[u] + vb[u], o + i);
+        }
+    }
+}
+
+hipError_t launch_stream_probe(const void* a, const void* b, void* out, size_t n_bytes, hipStream_t stream) {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    hipLaunchKernelGGL(stream_probe_kernel, dim3(cus * 4), dim3(256), 0, stream, reinterpret_cast<const hk_v4*>(a),
+                       reinterpret_cast<const hk_v4*>(b), reinterpret_cast<hk_v4*>(out), n_bytes / 16);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Self-test of the DPP wave shifts + the compile-time horizontal sums against a brute-force definition.
 template <int RW>
 __device__ int hsum_check(int lane) {

@@ -27,7 +27,7 @@ import numpy as np
 
 from homonim_amd import _hk, utils
 from homonim_amd.enums import Model, ProcCrs
-from homonim_amd.errors import BlockSizeError, ConfigWarning, IoError
+from homonim_amd.errors import BlockSizeError, ConfigWarning, DeviceError, IoError
 from homonim_amd.geo import Affine, CRS, Window
 from homonim_amd.kernel_model import KernelModel, RefSpaceModel, SrcSpaceModel
 from homonim_amd.raster_array import RasterArray
@@ -208,6 +208,18 @@ def block_pairs_multires(src: Grid, ref: Grid, proc_crs: ProcCrs, n_bands: int, 
                     yield BlockPair(band_i, proc_in, other_in, proc_out, other_out, outer)
 
 
+def _as_affine(transform, name: str) -> Optional[Affine]:
+    if transform is None or isinstance(transform, Affine):
+        return transform
+    try:
+        vals = [float(v) for v in transform]
+    except TypeError:
+        raise ValueError(f'`{name}` must be an Affine or a sequence of its six coefficients') from None
+    if len(vals) not in (6, 9):
+        raise ValueError(f'`{name}` must be an Affine or a sequence of its six coefficients')
+    return Affine(*vals[:6])
+
+
 def north_up(array: np.ndarray, transform: Optional[Affine]):
     """ (array, transform) with rows running north to south and columns west to east: a raster whose geo-transform has a
     positive row step (south-up) or a negative column step is flipped along that axis -- what the reference's
@@ -281,12 +293,15 @@ class RasterFuse:
             src = src[None]
         if ref.ndim == 2:
             ref = ref[None]
+        if src.ndim != 3 or ref.ndim != 3:
+            raise ValueError('`src` and `ref` must be 2-D or 3-D (bands first) arrays')
+        # transforms may come as plain 6-tuples (a, b, c, d, e, f)
+        transform = _as_affine(transform, 'transform')
+        ref_transform = _as_affine(ref_transform, 'ref_transform')
         # south-up (or column-mirrored) rasters are brought to north-up first, as the reference does through a WarpedVRT
         # (homonim/utils.py:190-209; for an axis-aligned raster that re-projection is the flip); outputs are north-up
         src, transform = north_up(src, transform)
         ref, ref_transform = north_up(ref, ref_transform)
-        if src.ndim != 3 or ref.ndim != 3:
-            raise ValueError('`src` and `ref` must be 2-D or 3-D (bands first) arrays')
         if ref.shape[0] < src.shape[0]:
             raise ValueError('`ref` has fewer bands than `src`')
         self._src, self._ref = src, ref
@@ -551,10 +566,10 @@ class RasterFuse:
             if arr is None or not isinstance(arr, np.ndarray) or not arr.flags['C_CONTIGUOUS'] or arr.nbytes == 0:
                 continue
             try:
-                ctx.pin(arr)
+                ctx.pin(arr)   # counted per address range (Context.pin): concurrent process() calls share a registration
                 done.append(arr)
-            except Exception:
-                pass  # already page-locked (hk_host_alloc / an enclosing registration) or not lockable: stays as it is
+            except DeviceError:
+                pass  # not lockable (ulimit -l, foreign memory): the copies of this array stay synchronous
         return done
 
     @staticmethod

@@ -38,7 +38,8 @@ typedef enum {
     HK_ERR_HIP = -2,       /* HIP runtime error -> Python RuntimeError */
     HK_ERR_NODEVICE = -3,  /* no usable GPU */
     HK_ERR_UNSUPPORTED = -4,
-    HK_ERR_NOMEM = -5
+    HK_ERR_NOMEM = -5,
+    HK_ERR_ALREADY = -6    /* hk_host_register: the range is page-locked already (nothing was changed; do not unregister it) */
 } hk_status;
 
 /* homonim/enums.py:22-41 (Model) */
@@ -167,10 +168,11 @@ int hk_fit_apply_io(hk_ctx* ctx, const hk_fit_desc* desc, const hk_io_desc* io, 
  * `stride` elements apart and whose parameter planes `band_stride` elements -- i.e. corr_out points at the pixel of
  * the caller's raster where the window's first pixel belongs. */
 typedef struct hk_out_window {
-    int64_t stride;       /* elements between rows of corr_out / params_out (>= cols) */
+    int64_t stride;       /* elements between rows of corr_out (and of params_out unless param_stride is set); >= cols */
     int64_t band_stride;  /* elements between the planes of params_out */
     int32_t row0, col0;   /* first row / column of the block that is written */
     int32_t rows, cols;   /* size of the written window */
+    int64_t param_stride; /* elements between rows of params_out when it differs from corr_out's; 0: `stride` serves both */
 } hk_out_window;
 
 /* hk_fit_apply_io with an output window: the block loop of RasterFuse.process (homonim/fuse.py:295-319) per call --
@@ -305,6 +307,12 @@ int hk_compare_sums_dev(hk_ctx* ctx, const hk_dev_job* job, int32_t src_nodata_m
  * nodata_variant 0: none, 1: 3-px NaN frame + 0.1 % NaN holes, 2: frame only, 3 / 4: none, noisy reference (35 % / 85 % r2-mask failures).  Test/bench data only. */
 int hk_synth_fill_dev(hk_ctx* ctx, float* src, float* ref, int32_t n_bands, int32_t height, int32_t width,
                       int64_t stride, int64_t band_stride, uint64_t seed, int32_t nodata_variant, int32_t stream);
+
+/* Measurement aid (bench.py `roofline.copy_gbps_measured`): ONE launch of a flat float4 stream over three device buffers
+ * of n_bytes each -- out[i] = a[i] + b[i], two reads + one write like the fused kernel's 12 bytes per pixel, no stencil,
+ * persistent grid, four 16-byte non-temporal loads in flight per lane and array -- on pooled stream `stream`
+ * (asynchronous; time it with hk_event_*).  n_bytes must be a multiple of 16.  What this box's HBM gives that byte mix. */
+int hk_stream_probe_dev(hk_ctx* ctx, const void* a, const void* b, void* out, size_t n_bytes, int32_t stream);
 
 /* HIP events on the pooled streams, so callers time exactly the stream the kernels run on. */
 int hk_event_create(hk_ctx* ctx, hk_event** ev);

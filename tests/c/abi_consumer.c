@@ -39,7 +39,7 @@ int main(int argc, char** argv) {
 
     /* the structs have the documented C layout */
     if (sizeof(hk_fit_desc) != 40) return 4;
-    if (sizeof(hk_dev_job) != 8 * 8 + 3 * 4 + 4 + 2 * 8 + 2 * 4 + 4 * 4 + 2 * 8 || sizeof(hk_out_window) != 32) return 14;
+    if (sizeof(hk_dev_job) != 8 * 8 + 3 * 4 + 4 + 2 * 8 + 2 * 4 + 4 * 4 + 2 * 8 || sizeof(hk_out_window) != 40) return 14;
     hk_fit_desc desc;
     memset(&desc, 0, sizeof desc);
     desc.model = HK_MODEL_GAIN_OFFSET, desc.kh = 5, desc.kw = 5, desc.has_r2_thresh = 1, desc.r2_thresh = 0.25f;

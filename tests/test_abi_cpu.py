@@ -48,7 +48,7 @@ def test_backend_name_and_struct_layout(lib):
     assert lib.hk_backend_name() == b'hip-gfx950'
     assert ctypes.sizeof(_hk.FitDesc) == 40  # 10 x 4-byte fields, matches hk_fit_desc
     assert ctypes.sizeof(_hk.DevJob) == 8 * 8 + 3 * 4 + 4 + 2 * 8 + 2 * 4 + 4 * 4 + 2 * 8   # ... + the store window + scratch
-    assert ctypes.sizeof(_hk.OutWindow) == 2 * 8 + 4 * 4
+    assert ctypes.sizeof(_hk.OutWindow) == 2 * 8 + 4 * 4 + 8   # ... + the parameter rasters' own row stride
 
 
 def test_host_only_size_helpers(lib):

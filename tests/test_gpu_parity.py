@@ -1568,3 +1568,104 @@ def test_south_up_and_mirrored_grids(ctx):
         got2, _ = RasterFuse(ra_n, ref_s).process(None, 'gain-blk-offset', (3, 3))
     assert_same_f32(got, exp, 'south-up source through RasterFuse')
     assert_same_f32(got2, exp, 'south-up reference through RasterFuse')
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# round 3: hygiene of the host layer
+def test_a_tolerated_hip_failure_does_not_poison_the_next_launch(ctx):
+    """ HIP keeps a per-thread last error until it is read and the launch wrappers report through hipGetLastError():
+    registering memory that is page-locked already (the advertised `corr_out = ctx.pinned_empty(...)` use) must not make
+    the NEXT kernel launch of the calling thread fail.  Also RasterFuse.process with such a corr_out, one thread, pin=True. """
+    from homonim_amd.fuse import RasterFuse
+    src, ref = onp.synth_pair(200, 300, 4, 'frame+holes')
+    arr = np.ascontiguousarray(src)
+    vp = arr.ctypes.data_as(_hk.C.c_void_p)
+    assert ctx._lib.hk_host_unregister(ctx._h, vp) != _hk.HK_OK                          # a failing HIP call, tolerated
+    desc = _hk.make_desc('gain', (3, 3), False, None, np.nan, np.nan)
+    _, c1, _, _ = ctx.fit_apply(desc, src, ref, 2, want_params=False, want_corr=True)     # the next launch on this thread
+    big = np.zeros((64, 1024), np.float32)                                               # (whole pages: see the pin test)
+    bp = big.ctypes.data_as(_hk.C.c_void_p)
+    assert ctx._lib.hk_host_register(ctx._h, bp, big.nbytes) == _hk.HK_OK
+    rc = ctx._lib.hk_host_register(ctx._h, bp, big.nbytes)                               # refused (or counted) by the runtime
+    assert rc in (_hk.HK_ERR_ALREADY, _hk.HK_OK)
+    _, c2, _, _ = ctx.fit_apply(desc, src, ref, 2, want_params=False, want_corr=True)
+    assert ctx._lib.hk_host_unregister(ctx._h, bp) == _hk.HK_OK
+    if rc == _hk.HK_OK:
+        ctx._lib.hk_host_unregister(ctx._h, bp)
+    exp, _ = onp.fit('gain', src, np.nan, ref, np.nan, (3, 3), False, None)
+    assert_same_f32(c1, onp.apply(src, exp), 'launch after a tolerated failure')
+    assert_same_f32(c2, c1, 'launch after a tolerated failure')
+    corr_out = ctx.pinned_empty((1,) + src.shape)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        rf = RasterFuse(src, ref, src_nodata=np.nan, ref_nodata=np.nan)
+        corr, _ = rf.process(model='gain', kernel_shape=(3, 3), corr_out=corr_out, block_config=dict(threads=1),
+                             device_config=dict(devices=[ctx.device], pin=True))
+    assert corr is corr_out
+    assert_same_f32(np.array(corr[0]), onp.apply(src, exp), 'process() into a page-locked corr_out')
+
+
+def test_pin_registrations_are_counted(ctx):
+    """ Two users of one array share a registration; the last unpin removes it; page-locked memory of somebody else is left
+    alone (concurrent RasterFuse.process calls on one source raster). """
+    arr = np.ascontiguousarray(np.random.default_rng(1).random((64, 1024), np.float32))
+    key = (arr.ctypes.data, arr.nbytes)
+    assert ctx.pin(arr) and ctx.pin(arr)
+    assert _hk._pins[key] == [2, True]
+    ctx.unpin(arr)
+    assert _hk._pins[key] == [1, True]
+    # (whether the runtime refuses a second hipHostRegister of a registered range or counts it differs from call to call on
+    # ROCm 7.2 -- the registry above never issues one)
+    ctx.unpin(arr)
+    assert key not in _hk._pins
+    assert ctx._lib.hk_host_register(ctx._h, arr.ctypes.data_as(_hk.C.c_void_p), arr.nbytes) == _hk.HK_OK   # it was released
+    assert ctx._lib.hk_host_unregister(ctx._h, arr.ctypes.data_as(_hk.C.c_void_p)) == _hk.HK_OK
+    foreign = ctx.pinned_empty((16, 16))
+    fkey = (foreign.ctypes.data, foreign.nbytes)
+    assert ctx.pin(foreign) and _hk._pins[fkey][0] == 1
+    ctx.unpin(foreign)                      # only undoes a registration it made itself
+    assert fkey not in _hk._pins
+    foreign[:] = 1.0                        # still alive and page-locked
+    ctx.unpin(arr)                          # unknown range: no-op
+
+
+def test_fit_apply_block_with_different_row_strides_and_bad_views(ctx):
+    """ The corrected and the parameter rasters need not share a row stride (hk_out_window.param_stride); views the copies
+    cannot address raise ValueError (not an assert that `python -O` strips). """
+    src, ref = onp.synth_pair(120, 260, 3, 'frame+holes')
+    desc = _hk.make_desc('gain-offset', (3, 3), False, None, np.nan, np.nan)
+    exp_p, exp_c, _, _ = ctx.fit_apply(desc, src, ref, 2, want_params=True, want_corr=True)
+    r0, c0, rows, cols = 2, 4, 100, 240
+    big_c = np.full((150, 300), 7, np.float32)
+    big_p = np.full((2, 130, 512), 7, np.float32)           # another row stride than the corrected raster's
+    ctx.fit_apply_block(desc, src, ref, (r0, c0, rows, cols), big_c[10:10 + rows, 20:20 + cols], big_p[:, 5:5 + rows, 8:8 + cols])
+    assert_same_f32(big_c[10:10 + rows, 20:20 + cols], exp_c[r0:r0 + rows, c0:c0 + cols], 'corrected window')
+    assert_same_f32(big_p[:, 5:5 + rows, 8:8 + cols], exp_p[:, r0:r0 + rows, c0:c0 + cols], 'parameter window')
+    big_c[10:10 + rows, 20:20 + cols] = 7
+    big_p[:, 5:5 + rows, 8:8 + cols] = 7
+    assert (big_c == 7).all() and (big_p == 7).all()
+    with pytest.raises(ValueError):
+        ctx.fit_apply_block(desc, src, ref, (r0, c0, rows, cols), big_c[10:10 + rows, 20:20 + 2 * cols:2], None)   # column stride 2
+    with pytest.raises(ValueError):
+        ctx.fit_apply_block(desc, src, ref, (r0, c0, rows, cols), big_c[10:10 + rows + 1, 20:20 + cols], None)    # wrong shape
+    with pytest.raises(ValueError):
+        ctx.fit_apply_block(desc, src, ref, (r0, c0, rows, cols), None, big_p.astype(np.float64)[:, 5:5 + rows, 8:8 + cols])
+
+
+def test_stream_probe_adds_its_two_streams(ctx):
+    """ hk_stream_probe_dev (bench.py `roofline.copy_gbps_measured`): out = a + b over device buffers, incl. a ragged tail. """
+    n = 4 * (256 * 4 * 1024 * 3 + 777)     # floats, not a multiple of the kernel's chunk
+    rng = np.random.default_rng(3)
+    a, b = rng.random(n, np.float32), rng.random(n, np.float32)
+    d = [ctx.dev_alloc(4 * n) for _ in range(3)]
+    ctx.h2d(d[0], a), ctx.h2d(d[1], b)
+    ctx.memset(d[2], 0, 4 * n)
+    ctx.stream_probe_dev(d[0], d[1], d[2], 4 * n, stream=0)
+    ctx.stream_sync(0)
+    out = np.empty(n, np.float32)
+    ctx.d2h(out, d[2])
+    assert (out == a + b).all()
+    with pytest.raises(ValueError):
+        ctx.stream_probe_dev(d[0], d[1], d[2], 4 * n + 4)
+    for p in d:
+        ctx.dev_free(p)
