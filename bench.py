@@ -525,21 +525,25 @@ def run_blocks(args, ctx, dist, rank, world):
     copy_med, copy_best = probe_copy(ctx, bufs['src'], bufs['ref'], bufs['corr'], 4 * band_stride * B)
     n_streams = ctx.n_streams
 
+    # experiment (HK_BENCH_C3_BANDS_PER_JOB): fewer bands per launch, so that a job's statistics pass leaves its planes in the
+    # 256 MB Infinity Cache for its fit (a 4104 x 4104 in-block is 135 MB of src + ref per band)
+    bpj = int(os.environ.get('HK_BENCH_C3_BANDS_PER_JOB', str(B)))
     jobs = []
     for i, bp in enumerate(mine):
         win_in, win_out = bp.src_in_block, bp.src_out_block
         if (win_in.col_off % 4) or ((win_out.col_off - win_in.col_off) % 4):
             raise SystemExit(f'block origin {win_in.col_off} is not 16-byte aligned: kernel {k}x{k} needs a halo that is a multiple of 4')
-        off = 4 * (win_in.row_off * stride + win_in.col_off)
-        job = _hk.DevJob()
-        job.src, job.ref, job.corr = bufs['src'] + off, bufs['ref'] + off, bufs['corr'] + off
-        job.gain = job.offset = job.r2 = job.fail_count = None
-        job.norm = bufs['norm'] + 16 * B * i
-        job.n_bands, job.height, job.width, job.stride, job.band_stride = B, win_in.height, win_in.width, stride, band_stride
-        job.seg_rows, job.stream = 0, i % n_streams   # the latency-bound statistics of one position overlap another's fit
-        job.out_row0, job.out_col0 = win_out.row_off - win_in.row_off, win_out.col_off - win_in.col_off
-        job.out_rows, job.out_cols = win_out.height, win_out.width
-        jobs.append(job)
+        for b0 in range(0, B, bpj):
+            off = 4 * (b0 * band_stride + win_in.row_off * stride + win_in.col_off)
+            job = _hk.DevJob()
+            job.src, job.ref, job.corr = bufs['src'] + off, bufs['ref'] + off, bufs['corr'] + off
+            job.gain = job.offset = job.r2 = job.fail_count = None
+            job.norm = bufs['norm'] + 16 * (B * i + b0)
+            job.n_bands, job.height, job.width, job.stride, job.band_stride = min(bpj, B - b0), win_in.height, win_in.width, stride, band_stride
+            job.seg_rows, job.stream = 0, len(jobs) % n_streams   # the latency-bound statistics of one position overlap another's fit
+            job.out_row0, job.out_col0 = win_out.row_off - win_in.row_off, win_out.col_off - win_in.col_off
+            job.out_rows, job.out_cols = win_out.height, win_out.width
+            jobs.append(job)
 
     def step():
         for job in jobs:

@@ -71,6 +71,12 @@ SIGNATURES = {
     'hk_dev_job_scratch_bytes': (C.c_uint64, [C.c_int32, C.c_int32, C.c_int64, C.c_int64]),
     'hk_block_norm_split_exchange_doubles': (C.c_uint64, [C.c_int32]),
     'hk_block_norm_split_dev': (C.c_int, [C.c_void_p, _P(FitDesc), _P(DevJob), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    'hk_comm_unique_id': (C.c_int, [C.c_void_p]),
+    'hk_comm_init': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
+    'hk_comm_destroy': (C.c_int, [C.c_void_p]),
+    'hk_comm_info': (C.c_int, [C.c_void_p, _P(C.c_int32), _P(C.c_int32)]),
+    'hk_comm_allreduce_f64_dev': (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32]),
+    'hk_block_norm_split_comm_dev': (C.c_int, [C.c_void_p, _P(FitDesc), _P(DevJob), C.c_void_p]),
     'hk_last_error': (C.c_char_p, []),
     'hk_device_count': (C.c_int, [_P(C.c_int)]),
     'hk_ctx_create': (C.c_int, [C.c_int, C.c_int, _P(C.c_void_p)]),
@@ -121,6 +127,16 @@ SIGNATURES = {
     'hk_stream_sync': (C.c_int, [C.c_void_p, C.c_int32]),
     'hk_selftest': (C.c_int, [C.c_void_p]),
 }  # yapf: disable
+
+COMM_ID_BYTES = 128   # HK_COMM_ID_BYTES = sizeof(ncclUniqueId)
+
+
+def comm_unique_id() -> bytes:
+    """ A fresh communicator id (hk_comm_unique_id = ncclGetUniqueId): rank 0 calls this and distributes the bytes. """
+    buf = (C.c_ubyte * COMM_ID_BYTES)()
+    _check(load_library().hk_comm_unique_id(buf))
+    return bytes(buf)
+
 
 _lib = None
 _lib_lock = threading.Lock()
@@ -521,6 +537,32 @@ class Context:
 
     def split_exchange_doubles(self, n_bands: int) -> int:
         return int(self._lib.hk_block_norm_split_exchange_doubles(n_bands))
+
+    # -- the library's own RCCL communicator (one per context; the split-block statistics are its one user) ------------
+    def comm_init(self, unique_id: bytes, rank: int, world_size: int):
+        """ Join the RCCL communicator named by ``unique_id`` (``comm_unique_id()`` of rank 0, handed over by the launcher;
+        ``homonim_amd.dist.init_comm`` does that).  Collective: returns when every rank has joined. """
+        if len(unique_id) != COMM_ID_BYTES:
+            raise ValueError(f'the communicator id has {COMM_ID_BYTES} bytes')
+        buf = (C.c_ubyte * COMM_ID_BYTES).from_buffer_copy(unique_id)
+        _check(self._lib.hk_comm_init(self._h, buf, rank, world_size))
+
+    def comm_destroy(self):
+        _check(self._lib.hk_comm_destroy(self._h))
+
+    def comm_info(self):
+        """ -> (rank, world_size) of the context's communicator; (-1, 0) without one. """
+        r, w = C.c_int32(-1), C.c_int32(0)
+        _check(self._lib.hk_comm_info(self._h, C.byref(r), C.byref(w)))
+        return int(r.value), int(w.value)
+
+    def comm_allreduce_f64_dev(self, buf_dptr: int, count: int, stream: int = 0):
+        _check(self._lib.hk_comm_allreduce_f64_dev(self._h, C.c_void_p(buf_dptr), count, stream))
+
+    def block_norm_split_comm_dev(self, desc: FitDesc, job: DevJob, norm_dev: int):
+        """ Split-block statistics of this rank's slab over the context's communicator: six phases + five RCCL all-reduces
+        queued on the job's stream (hk_block_norm_split_comm_dev; asynchronous, collective). """
+        _check(self._lib.hk_block_norm_split_comm_dev(self._h, C.byref(desc), C.byref(job), C.c_void_p(norm_dev)))
 
     def job_scratch_bytes(self, job: DevJob) -> int:
         """ Size of the optional DevJob.scratch (gain-offset with an r2 threshold: the in-painting's inputs). """

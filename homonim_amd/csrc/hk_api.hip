@@ -21,6 +21,9 @@
 #include "../../include/homonim_hk.h"
 #include "hk_kernels.h"
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and prototypes only: librccl is opened at run time (hk_comm_*), not linked
+
 namespace {
 
 thread_local char g_err[512] = "";
@@ -60,7 +63,8 @@ struct Slot {
     void* aux = nullptr;      // on-demand planes + tables of the in-painting branch
     size_t aux_bytes = 0;
     unsigned long long* fail_host = nullptr;  // pinned word: the r2-mask failure counter comes back with the outputs
-    bool busy = false;
+    bool busy = false;         // leased by a host-pointer call (SlotLease)
+    bool dev_touched = false;  // device-resident jobs were queued on this stream since the last lease drained it
 };
 
 constexpr int DEFAULT_SEG_ROWS = 128;
@@ -95,6 +99,12 @@ struct hk_ctx {
         cert_skip.store(p, std::memory_order_relaxed);
     }
     bool cert_disabled = false;  // HK_CERT_ONLY=0 in the environment (A/B measurements)
+    // RCCL communicator of the one data-path collective (hk_comm_init; the split-block statistics)
+    ncclComm_t comm = nullptr;
+    int comm_rank = 0, comm_world = 0;
+    std::mutex comm_mu;          // collectives of one communicator are queued in one order on every rank
+    double* comm_xchg = nullptr; // device exchange buffer of hk_block_norm_split_comm_dev
+    size_t comm_xchg_doubles = 0;
 };
 
 struct hk_event {
@@ -106,27 +116,85 @@ namespace {
 struct SlotLease {
     hk_ctx* ctx;
     int idx;
+    // Host-pointer calls and device-resident jobs share the pooled streams and their scratch (norm_ws, aux).  The rule "do
+    // not mix them on one context concurrently" is enforced here instead of being left to the caller: a lease prefers a
+    // stream no device job has touched; if it has to take one that was, it drains that stream first (the jobs queued on it
+    // are complete before the slot's scratch is re-used), and a device-job call waits while its stream is leased
+    // (dev_slot_enter below).
     SlotLease(hk_ctx* c) : ctx(c), idx(-1) {
-        std::unique_lock<std::mutex> lk(ctx->mu);
-        ctx->cv.wait(lk, [&] {
-            for (size_t i = 0; i < ctx->slots.size(); ++i)
-                if (!ctx->slots[i].busy) {
-                    idx = (int)i;
-                    return true;
+        bool drain = false;
+        {
+            std::unique_lock<std::mutex> lk(ctx->mu);
+            ctx->cv.wait(lk, [&] {
+                int any = -1;
+                for (size_t i = 0; i < ctx->slots.size(); ++i) {
+                    if (ctx->slots[i].busy) continue;
+                    if (!ctx->slots[i].dev_touched) {
+                        idx = (int)i;
+                        return true;
+                    }
+                    if (any < 0) any = (int)i;
                 }
-            return false;
-        });
-        ctx->slots[idx].busy = true;
+                idx = any;
+                return any >= 0;
+            });
+            ctx->slots[idx].busy = true;
+            drain = ctx->slots[idx].dev_touched;
+            ctx->slots[idx].dev_touched = false;
+        }
+        if (drain) (void)hipStreamSynchronize(ctx->slots[idx].stream);
     }
     ~SlotLease() {
         {
             std::lock_guard<std::mutex> lk(ctx->mu);
             ctx->slots[idx].busy = false;
         }
-        ctx->cv.notify_one();
+        ctx->cv.notify_all();
     }
     Slot& slot() { return ctx->slots[idx]; }
 };
+
+// a device-resident job is about to be queued on pooled stream `stream`: wait for a host-pointer call that holds it
+void dev_slot_enter(hk_ctx* ctx, int stream) {
+    std::unique_lock<std::mutex> lk(ctx->mu);
+    ctx->cv.wait(lk, [&] { return !ctx->slots[stream].busy; });
+    ctx->slots[stream].dev_touched = true;
+}
+
+// RCCL, opened on first use: the library itself stays loadable (and its CPU-side tests runnable) where librccl is absent
+struct RcclApi {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+};
+RcclApi& rccl() {
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+            api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (api.lib) break;
+        }
+        if (!api.lib) return;
+        api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(api.lib, "ncclGetUniqueId"));
+        api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(api.lib, "ncclCommInitRank"));
+        api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(api.lib, "ncclCommDestroy"));
+        api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(api.lib, "ncclAllReduce"));
+        api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(api.lib, "ncclGetErrorString"));
+        api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllReduce && api.GetErrorString;
+    });
+    return api;
+}
+#define HK_RCCL(expr)                                                                                         \
+    do {                                                                                                      \
+        ncclResult_t _r = (expr);                                                                             \
+        if (_r != ncclSuccess)                                                                                \
+            return fail(HK_ERR_HIP, "%s failed: %s (%s:%d)", #expr, rccl().GetErrorString(_r), __FILE__, __LINE__); \
+    } while (0)
 
 int ensure_dev(Slot& s, size_t bytes) {
     if (s.dev_bytes >= bytes) return HK_OK;
@@ -691,6 +759,8 @@ int hk_ctx_destroy(hk_ctx* ctx) {
         if (s.fail_host) hipHostFree(s.fail_host);
         if (s.stream) hipStreamDestroy(s.stream);
     }
+    if (ctx->comm && rccl().ok) rccl().CommDestroy(ctx->comm);
+    if (ctx->comm_xchg) hipFree(ctx->comm_xchg);
     delete ctx;
     return HK_OK;
 }
@@ -1073,10 +1143,10 @@ static unsigned char* job_scratch_flag(const hk_dev_job* job) {
                         : nullptr;
 }
 
-static int check_job(hk_ctx* ctx, const hk_dev_job* job) {
+static int check_job(hk_ctx* ctx, const hk_dev_job* job, bool allow_no_rows = false) {
     if (!ctx || !job) return fail(HK_ERR_ARG, "NULL argument");
     if (!job->src || !job->ref) return fail(HK_ERR_ARG, "job src/ref is NULL");
-    if (job->n_bands < 1 || job->height < 1 || job->width < 1) return fail(HK_ERR_ARG, "empty job");
+    if (job->n_bands < 1 || job->height < (allow_no_rows ? 0 : 1) || job->width < 1) return fail(HK_ERR_ARG, "empty job");
     if (job->stride < job->width || (job->stride % hk::PX) != 0)
         return fail(HK_ERR_ARG, "job stride must be >= width and a multiple of %d elements", hk::PX);
     if ((job->band_stride % hk::PX) != 0) return fail(HK_ERR_ARG, "band_stride must be a multiple of %d", hk::PX);
@@ -1096,6 +1166,7 @@ static int check_job(hk_ctx* ctx, const hk_dev_job* job) {
         if ((job->out_col0 % hk::PX) != 0 || (((job->out_col0 + job->out_cols) % hk::PX) != 0 && job->out_col0 + job->out_cols != job->width))
             return fail(HK_ERR_ARG, "job store window must start and end on multiples of %d columns (or at the job's last column)", hk::PX);
     }
+    dev_slot_enter(ctx, job->stream);
     return HK_OK;
 }
 
@@ -1356,7 +1427,7 @@ int hk_block_norm_split_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_j
                             double* xchg_dev, double* norm_dev) {
     int rc = validate_desc(desc);
     if (rc) return rc;
-    rc = check_job(ctx, job);
+    rc = check_job(ctx, job, /*allow_no_rows=*/true);  // a rank without rows of the block takes part with zeros
     if (rc) return rc;
     if (!xchg_dev || !norm_dev) return fail(HK_ERR_ARG, "xchg_dev / norm_dev is NULL");
     if (phase < 0 || phase > 5) return fail(HK_ERR_ARG, "phase %d outside 0..5", phase);
@@ -1364,7 +1435,7 @@ int hk_block_norm_split_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_j
     HK_ENTER(ctx);
     Slot& sl = ctx->slots[job->stream];
     // the phases of one block share the stream's workspace: phase 0 sizes it, the others find it as it was left
-    rc = ensure_stream_ws(ctx, sl, hk::norm_workspace_bytes(job->n_bands, job->height, job->width));
+    rc = ensure_stream_ws(ctx, sl, hk::norm_workspace_bytes(job->n_bands, job->height > 0 ? job->height : 1, job->width));
     if (rc) return rc;
     hk::NormArgs na;
     na.src = job->src, na.ref = job->ref, na.height = job->height, na.width = job->width, na.stride = job->stride;
@@ -1372,6 +1443,97 @@ int hk_block_norm_split_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_j
     na.src_nd_mode = desc->src_nodata_mode, na.ref_nd_mode = desc->ref_nodata_mode;
     na.src_nodata = desc->src_nodata, na.ref_nodata = desc->ref_nodata;
     HK_HIP(hk::launch_block_norm_split(na, sl.norm_ws, xchg_dev, 1.0 / (double)world_size, phase, norm_dev, sl.stream));
+    return HK_OK;
+}
+
+int hk_comm_unique_id(uint8_t id[HK_COMM_ID_BYTES]) {
+    static_assert(HK_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "hk_comm id = ncclUniqueId");
+    if (!id) return fail(HK_ERR_ARG, "id is NULL");
+    if (!rccl().ok) return fail(HK_ERR_UNSUPPORTED, "librccl could not be opened");
+    ncclUniqueId u;
+    HK_RCCL(rccl().GetUniqueId(&u));
+    memcpy(id, u.internal, HK_COMM_ID_BYTES);
+    return HK_OK;
+}
+
+int hk_comm_init(hk_ctx* ctx, const uint8_t id[HK_COMM_ID_BYTES], int32_t rank, int32_t world_size) {
+    if (!ctx || !id) return fail(HK_ERR_ARG, "NULL argument");
+    if (world_size < 1 || rank < 0 || rank >= world_size) return fail(HK_ERR_ARG, "rank %d outside a group of %d", rank, world_size);
+    if (!rccl().ok) return fail(HK_ERR_UNSUPPORTED, "librccl could not be opened");
+    std::lock_guard<std::mutex> lk(ctx->comm_mu);
+    if (ctx->comm) return fail(HK_ERR_ARG, "the context has a communicator already (hk_comm_destroy it first)");
+    HK_ENTER(ctx);
+    ncclUniqueId u;
+    memcpy(u.internal, id, HK_COMM_ID_BYTES);
+    ncclComm_t c = nullptr;
+    HK_RCCL(rccl().CommInitRank(&c, world_size, u, rank));  // collective: returns once every rank has joined
+    ctx->comm = c, ctx->comm_rank = rank, ctx->comm_world = world_size;
+    return HK_OK;
+}
+
+int hk_comm_destroy(hk_ctx* ctx) {
+    if (!ctx) return fail(HK_ERR_ARG, "ctx is NULL");
+    std::lock_guard<std::mutex> lk(ctx->comm_mu);
+    if (!ctx->comm) return HK_OK;
+    HK_ENTER(ctx);
+    HK_HIP(hipDeviceSynchronize());
+    HK_RCCL(rccl().CommDestroy(ctx->comm));
+    ctx->comm = nullptr, ctx->comm_rank = ctx->comm_world = 0;
+    return HK_OK;
+}
+
+int hk_comm_info(hk_ctx* ctx, int32_t* rank, int32_t* world_size) {
+    if (!ctx || !rank || !world_size) return fail(HK_ERR_ARG, "NULL argument");
+    std::lock_guard<std::mutex> lk(ctx->comm_mu);
+    *rank = ctx->comm ? ctx->comm_rank : -1;
+    *world_size = ctx->comm ? ctx->comm_world : 0;
+    return HK_OK;
+}
+
+int hk_comm_allreduce_f64_dev(hk_ctx* ctx, double* buf_dev, uint64_t count, int32_t stream) {
+    if (!ctx || !buf_dev) return fail(HK_ERR_ARG, "NULL argument");
+    if (stream < 0 || stream >= (int)ctx->slots.size()) return fail(HK_ERR_ARG, "bad stream index");
+    std::lock_guard<std::mutex> lk(ctx->comm_mu);
+    if (!ctx->comm) return fail(HK_ERR_ARG, "the context has no communicator (hk_comm_init)");
+    HK_ENTER(ctx);
+    HK_RCCL(rccl().AllReduce(buf_dev, buf_dev, count, ncclDouble, ncclSum, ctx->comm, ctx->slots[stream].stream));
+    return HK_OK;
+}
+
+int hk_block_norm_split_comm_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* job, double* norm_dev) {
+    int rc = validate_desc(desc);
+    if (rc) return rc;
+    rc = check_job(ctx, job, /*allow_no_rows=*/true);
+    if (rc) return rc;
+    if (!norm_dev) return fail(HK_ERR_ARG, "norm_dev is NULL");
+    std::lock_guard<std::mutex> lk(ctx->comm_mu);  // one collective sequence at a time per communicator, every rank alike
+    if (!ctx->comm) return fail(HK_ERR_ARG, "the context has no communicator (hk_comm_init)");
+    HK_ENTER(ctx);
+    Slot& sl = ctx->slots[job->stream];
+    rc = ensure_stream_ws(ctx, sl, hk::norm_workspace_bytes(job->n_bands, job->height > 0 ? job->height : 1, job->width));
+    if (rc) return rc;
+    const size_t n = hk::norm_split_exchange_doubles(job->n_bands);
+    if (ctx->comm_xchg_doubles < n) {
+        if (ctx->comm_xchg) {
+            HK_HIP(hipDeviceSynchronize());  // an earlier sequence on another stream may still read it
+            HK_HIP(hipFree(ctx->comm_xchg));
+            ctx->comm_xchg = nullptr, ctx->comm_xchg_doubles = 0;
+        }
+        if (hipMalloc(reinterpret_cast<void**>(&ctx->comm_xchg), n * sizeof(double)) != hipSuccess)
+            return fail(HK_ERR_NOMEM, "hipMalloc(%zu) failed", n * sizeof(double));
+        ctx->comm_xchg_doubles = n;
+    }
+    hk::NormArgs na;
+    na.src = job->src, na.ref = job->ref, na.height = job->height, na.width = job->width, na.stride = job->stride;
+    na.band_stride = job->band_stride, na.n_bands = job->n_bands;
+    na.src_nd_mode = desc->src_nodata_mode, na.ref_nd_mode = desc->ref_nodata_mode;
+    na.src_nodata = desc->src_nodata, na.ref_nodata = desc->ref_nodata;
+    // six phases on the slab, five all-reduces between them, all queued on the job's stream: no host synchronisation
+    for (int phase = 0; phase < 6; ++phase) {
+        HK_HIP(hk::launch_block_norm_split(na, sl.norm_ws, ctx->comm_xchg, 1.0 / (double)ctx->comm_world, phase, norm_dev, sl.stream));
+        if (phase < 5)
+            HK_RCCL(rccl().AllReduce(ctx->comm_xchg, ctx->comm_xchg, n, ncclDouble, ncclSum, ctx->comm, sl.stream));
+    }
     return HK_OK;
 }
 

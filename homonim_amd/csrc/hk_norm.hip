@@ -640,6 +640,15 @@ __global__ void split_get_moments_kernel(NormWS* __restrict__ ws_all, const doub
         ws.done = 1;
         return;
     }
+    if (n >= (1ull << 32)) {
+        // the select's histogram bins are 32-bit: the all-reduced count of one bin could wrap for a block of 2^32 valid
+        // pixels or more (byte imagery lands in a handful of bins).  Refuse it identically on every rank (x[0] is the
+        // all-reduced count) instead of returning wrong percentiles: NaN statistics.
+        const double qn = __longlong_as_double(0x7ff8000000000000ll);
+        norm_out[2 * blockIdx.x] = qn, norm_out[2 * blockIdx.x + 1] = qn;
+        ws.done = 1;
+        return;
+    }
     for (int q = 0; q < 2; ++q) {
         const double d = x[1 + 2 * q] / (double)n;
         ws.mean[q] = ws.shift[q] + d;
@@ -672,41 +681,45 @@ hipError_t launch_block_norm_split(const NormArgs& a, void* workspace, double* x
                                    double* norm_out, hipStream_t stream) {
     NormWS* ws = reinterpret_cast<NormWS*>(workspace);
     const dim3 bands(a.n_bands), block(NORM_THREADS), gfull(FB_BLOCKS, a.n_bands, 2);
+    // a rank whose slab has no rows takes part with zeros: it skips the kernels that read pixels, not the exchange
+    const bool rows = a.height > 0;
     switch (phase) {
     case 0: {
         hipError_t e = hipMemsetAsync(ws, 0, sizeof(NormWS) * (size_t)a.n_bands, stream);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(norm_sample_kernel, bands, dim3(SAMPLE_THREADS), 0, stream, a, ws);
+        if (rows) hipLaunchKernelGGL(norm_sample_kernel, bands, dim3(SAMPLE_THREADS), 0, stream, a, ws);
         hipLaunchKernelGGL(split_put_shift_kernel, bands, block, 0, stream, ws, xchg);
         break;
     }
     case 1: {
         hipLaunchKernelGGL(split_get_shift_kernel, bands, dim3(WAVE), 0, stream, ws, xchg, inv_world);
-        const dim3 gstream(pass_waves(a.height, a.width), a.n_bands);
-        float* mid = reinterpret_cast<float*>(static_cast<char*>(workspace) + align256(sizeof(NormWS) * (size_t)a.n_bands));
-        const size_t cap_al = align256(mid_capacity((long long)a.height * a.width) * sizeof(float)) / sizeof(float);
-        if (a.src_nd_mode == 0 && a.ref_nd_mode == 0)
-            hipLaunchKernelGGL(norm_stream_kernel<true>, gstream, dim3(WAVE), 0, stream, a, ws, mid, cap_al);
-        else
-            hipLaunchKernelGGL(norm_stream_kernel<false>, gstream, dim3(WAVE), 0, stream, a, ws, mid, cap_al);
+        if (rows) {
+            const dim3 gstream(pass_waves(a.height, a.width), a.n_bands);
+            float* mid = reinterpret_cast<float*>(static_cast<char*>(workspace) + align256(sizeof(NormWS) * (size_t)a.n_bands));
+            const size_t cap_al = align256(mid_capacity((long long)a.height * a.width) * sizeof(float)) / sizeof(float);
+            if (a.src_nd_mode == 0 && a.ref_nd_mode == 0)
+                hipLaunchKernelGGL(norm_stream_kernel<true>, gstream, dim3(WAVE), 0, stream, a, ws, mid, cap_al);
+            else
+                hipLaunchKernelGGL(norm_stream_kernel<false>, gstream, dim3(WAVE), 0, stream, a, ws, mid, cap_al);
+        }
         hipLaunchKernelGGL(split_put_moments_kernel, bands, dim3(WAVE), 0, stream, ws, xchg);
         break;
     }
     case 2:
         hipLaunchKernelGGL(split_get_moments_kernel, bands, dim3(WAVE), 0, stream, ws, xchg, norm_out);
-        hipLaunchKernelGGL(norm_full_hist_kernel<0>, gfull, block, 0, stream, a, ws);
+        if (rows) hipLaunchKernelGGL(norm_full_hist_kernel<0>, gfull, block, 0, stream, a, ws);
         hipLaunchKernelGGL(split_hist_kernel<0>, bands, block, 0, stream, ws, xchg, 1);
         break;
     case 3:
         hipLaunchKernelGGL(split_hist_kernel<0>, bands, block, 0, stream, ws, xchg, 0);
         hipLaunchKernelGGL(norm_select_kernel<0>, bands, block, 0, stream, ws, norm_out);
-        hipLaunchKernelGGL(norm_full_hist_kernel<1>, gfull, block, 0, stream, a, ws);
+        if (rows) hipLaunchKernelGGL(norm_full_hist_kernel<1>, gfull, block, 0, stream, a, ws);
         hipLaunchKernelGGL(split_hist_kernel<1>, bands, block, 0, stream, ws, xchg, 1);
         break;
     case 4:
         hipLaunchKernelGGL(split_hist_kernel<1>, bands, block, 0, stream, ws, xchg, 0);
         hipLaunchKernelGGL(norm_select_kernel<1>, bands, block, 0, stream, ws, norm_out);
-        hipLaunchKernelGGL(norm_full_hist_kernel<2>, gfull, block, 0, stream, a, ws);
+        if (rows) hipLaunchKernelGGL(norm_full_hist_kernel<2>, gfull, block, 0, stream, a, ws);
         hipLaunchKernelGGL(split_hist_kernel<2>, bands, block, 0, stream, ws, xchg, 1);
         break;
     case 5:

@@ -69,6 +69,46 @@ def sum_over_ranks(value: float) -> float:
     return _reduce(value, 'SUM')
 
 
+def init_comm(ctx, id_file: Optional[str] = None) -> Tuple[int, int]:
+    """
+    Give ``ctx`` (a ``homonim_amd._hk.Context``) the library's own RCCL communicator over the ranks of this launch: rank 0
+    makes the id (``hk_comm_unique_id``) and the others receive it -- through the torch.distributed process group when one
+    was joined (``init``; an object broadcast, launcher plumbing only), else through ``id_file`` (or ``$HOMONIM_AMD_COMM_FILE``:
+    rank 0 writes it atomically, the others wait for it).  The collectives themselves (``Context.block_norm_split_comm_dev``)
+    never touch torch.  -> (rank, world_size)
+    """
+    import time
+    from homonim_amd import _hk
+    rank, world, _ = env_ranks()
+    id_file = id_file or os.environ.get('HOMONIM_AMD_COMM_FILE')
+    if _state['initialised'] and id_file is None:
+        import torch.distributed as dist
+        box = [_hk.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        uid = box[0]
+    elif world == 1 and id_file is None:
+        uid = _hk.comm_unique_id()
+    else:
+        if id_file is None:
+            raise RuntimeError('init_comm needs a joined process group (dist.init) or an id file (HOMONIM_AMD_COMM_FILE)')
+        if rank == 0:
+            uid = _hk.comm_unique_id()
+            tmp = f'{id_file}.tmp{os.getpid()}'
+            with open(tmp, 'wb') as f:
+                f.write(uid)
+            os.replace(tmp, id_file)
+        else:
+            t0 = time.time()
+            while not os.path.exists(id_file):
+                if time.time() - t0 > 120:
+                    raise RuntimeError(f'rank {rank}: no communicator id in {id_file} after 120 s')
+                time.sleep(0.02)
+            with open(id_file, 'rb') as f:
+                uid = f.read()
+    ctx.comm_init(uid, rank, world)
+    return rank, world
+
+
 def finalize():
     if _state['initialised']:
         import torch.distributed as dist

@@ -7,8 +7,10 @@ collective of the hot path (reference: KernelModel._fit_bl
 Every ingredient is a sum over pixels: the shifted float64 moments, and the integer histograms of the exact three-level
 radix select that finds the two order statistics behind the percentile.  So each rank runs the library's kernels on its
 slab (``hk_block_norm_split_dev``, phases 0..5) and the ranks all-reduce (SUM) a small float64 exchange buffer between the
-phases: 2 + 5 + 3 x (<= 8192) values per band, five all-reduces per block.  With ``torch.distributed`` on the ``nccl``
-backend that is RCCL over xGMI, on a tensor that owns the exchange buffer; nothing else of torch touches the data path.
+phases: 2 + 5 + 3 x (<= 8192) values per band, five all-reduces per block.  In production the library does that itself
+-- RCCL over xGMI through the context's communicator (``hk_comm_init``, ``hk_block_norm_split_comm_dev``), queued on the
+job's stream without host synchronisation and without torch.  ``TorchReducer`` keeps a host-driven phase loop over a
+``torch.distributed`` group for tests in which several ranks share one GPU (gloo).
 
 The order statistics are exactly those of the whole block; the std ratio equals the single-device value up to the order of
 the float64 sums (the slabs' partial sums are added rank by rank).
@@ -49,20 +51,37 @@ class TorchReducer:
         self._torch.cuda.synchronize(self._device_index)  # the library's stream reads the buffer next
 
 
-def block_norm_split(ctx: '_hk.Context', desc: '_hk.FitDesc', job: '_hk.DevJob', reducer: TorchReducer,
+def block_norm_split(ctx: '_hk.Context', desc: '_hk.FitDesc', job: '_hk.DevJob', reducer: Optional[TorchReducer] = None,
                      norm_dev: Optional[int] = None) -> np.ndarray:
     """
-    Block statistics over all ranks of ``reducer``'s group; ``job`` describes THIS rank's slab of the block (device planes,
-    any number of rows, the block's width; ``n_bands`` equal on every rank).  Collective: every rank calls it with its slab.
+    Block statistics over all ranks; ``job`` describes THIS rank's slab of the block (device planes, any number of rows --
+    none is allowed --, the block's width; ``n_bands`` equal on every rank).  Collective: every rank calls it with its slab.
     Returns norm (n_bands, 2) float64, identical on every rank; ``norm_dev`` (optional device pointer, n_bands x 2 float64)
     receives it too, ready to be ``job.norm`` of the rank's ``fit_apply_dev``.
+
+    ``reducer`` None (the production path): the context's own RCCL communicator (``dist.init_comm`` / ``Context.comm_init``)
+    -- the library queues the six phases and the five all-reduces on the job's stream (``hk_block_norm_split_comm_dev``);
+    no torch, no host synchronisation until the result is read.  A ``TorchReducer`` keeps the phase loop on the host (gloo
+    groups of ranks that share one GPU in tests).
     """
     nb = int(job.n_bands)
-    if reducer.buf.numel() < ctx.split_exchange_doubles(nb):
-        raise ValueError('exchange buffer smaller than hk_block_norm_split_exchange_doubles(n_bands)')
     own = norm_dev is None
     if own:
         norm_dev = ctx.dev_alloc(16 * nb)
+    if reducer is None:
+        try:
+            ctx.block_norm_split_comm_dev(desc, job, norm_dev)
+            ctx.stream_sync(job.stream)
+            out = np.zeros((nb, 2), np.float64)
+            ctx.d2h(out, norm_dev)
+            return out
+        finally:
+            if own:
+                ctx.dev_free(norm_dev)
+    if reducer.buf.numel() < ctx.split_exchange_doubles(nb):
+        if own:
+            ctx.dev_free(norm_dev)
+        raise ValueError('exchange buffer smaller than hk_block_norm_split_exchange_doubles(n_bands)')
     try:
         for phase in range(N_PHASES):
             ctx.block_norm_split_phase(desc, job, phase, reducer.world_size, reducer.ptr, norm_dev)

@@ -218,8 +218,12 @@ int hk_host_unregister(hk_ctx* ctx, void* hptr);             /* ctx may be NULL 
  * device-resident entry points (inputs already in HBM): what bench.py times and what the streaming tile pipeline
  * is built from.  Buffers come from hk_dev_alloc; planes are height x stride float32 with stride % 4 == 0.
  * A job names its stream by index: jobs on one stream must be issued by one host thread at a time (stream order is the
- * only ordering), and a context that serves device-resident jobs should not serve host-pointer calls (hk_fit, ...)
- * concurrently -- those lease the same pooled streams and their scratch buffers.  Use a second context for that.
+ * only ordering).  Host-pointer calls (hk_fit, ...) lease the same pooled streams and their scratch buffers; the library
+ * keeps the two apart at run time: a lease prefers a stream no device job has used, drains one that was used before taking
+ * it, and a device-job call waits while its stream is leased.  Mixing both on one context is therefore safe call by call but
+ * serialises them on that stream -- use a second context where they should overlap, and always when a gain-offset job with
+ * an r2 threshold runs WITHOUT hk_dev_job.scratch: between its hk_fit_apply_dev and its hk_inpaint_dev* the in-painting's
+ * inputs live in the stream's own scratch, which a host-pointer call leasing that stream would overwrite.
  */
 int hk_dev_alloc(hk_ctx* ctx, size_t bytes, void** dptr);
 int hk_dev_free(hk_ctx* ctx, void* dptr);
@@ -295,6 +299,26 @@ int hk_block_norm_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* jo
 uint64_t hk_block_norm_split_exchange_doubles(int32_t n_bands);
 int hk_block_norm_split_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* job, int32_t phase, int32_t world_size,
                             double* xchg_dev, double* norm_dev);
+/* The same with the all-reduces done by the library: RCCL over xGMI, queued on job->stream between the phases -- no host
+ * synchronisation, no tensor library in the data path (BASELINE.json north_star: "RCCL over xGMI only for the optional
+ * block-mean offset reduction").  One process per GPU; every rank creates its context, joins the communicator once
+ * (hk_comm_init) and then calls hk_block_norm_split_comm_dev with its slab of each block, all ranks in the same order.
+ *   hk_comm_unique_id : rank 0 makes the 128-byte id (ncclGetUniqueId) and hands it to the other ranks through whatever
+ *                       launched them (a file, the torch.distributed store, MPI ...: homonim_amd/dist.py init_comm).
+ *   hk_comm_init      : collective over the ranks (ncclCommInitRank); one communicator per context.
+ *   hk_block_norm_split_comm_dev : asynchronous; norm_dev (n_bands x 2 float64, device) is valid in stream order and
+ *                       identical on every rank.  A slab may have no rows (height 0): the rank contributes zeros.
+ *                       A block of 2^32 or more valid pixels gets NaN statistics on every rank (32-bit histogram bins).
+ *   hk_comm_allreduce_f64_dev : in-place SUM of a device buffer over the communicator on a pooled stream (the primitive
+ *                       above; exported for callers with their own phase loop).
+ * librccl is opened at run time on first use (HK_ERR_UNSUPPORTED if it is absent). */
+#define HK_COMM_ID_BYTES 128
+int hk_comm_unique_id(uint8_t id[HK_COMM_ID_BYTES]);
+int hk_comm_init(hk_ctx* ctx, const uint8_t id[HK_COMM_ID_BYTES], int32_t rank, int32_t world_size);
+int hk_comm_destroy(hk_ctx* ctx);
+int hk_comm_info(hk_ctx* ctx, int32_t* rank, int32_t* world_size);   /* rank -1 / world 0: no communicator */
+int hk_comm_allreduce_f64_dev(hk_ctx* ctx, double* buf_dev, uint64_t count, int32_t stream);
+int hk_block_norm_split_comm_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* job, double* norm_dev);
 /* The masked sums of RasterCompare.process / get_block_sums (homonim/compare.py:243-255) on the job's src and ref planes
  * (job->corr etc. are not used), per band into sums_dev (device, n_bands x 7 float64; asynchronous):
  *   [ sum src, sum ref, sum src^2, sum ref^2, sum src*ref, sum (ref - src)^2, number of pixels ]

@@ -188,6 +188,66 @@ def test_config1_gain_8192_four_bands(ctx, oracle):
             ctx.dev_free(bufs[k])
 
 
+def test_config2_headline_launch_four_bands(ctx, oracle):
+    """ BASELINE.json configs[2] exactly as it is benched: ONE fused launch over 4 bands of 16384 x 16384 (gain-offset 5x5 +
+    r2 mask, plane offsets of up to 3.2 GB), windows of EVERY band -- the last one included -- against the C oracle, and the
+    per-band failure counters.  Rows are downloaded in bands of rows (not whole planes: 3 x 4.3 GB of host memory otherwise). """
+    n, B, k = SIZE, 4, K
+    plane = 4 * n * n
+    bufs = {name: ctx.dev_alloc(plane * B) for name in ('src', 'ref', 'corr')}
+    bufs['fail'] = ctx.dev_alloc(8 * B)
+    try:
+        ctx.synth_fill_dev(bufs['src'], bufs['ref'], B, n, n, n, n * n, seed=1234, nodata_variant=0, stream=0)
+        ctx.memset(bufs['fail'], 0, 8 * B)
+        desc = _hk.make_desc('gain-offset', (k, k), False, 0.25, None, None)
+        job = _hk.DevJob()
+        job.src, job.ref, job.corr = bufs['src'], bufs['ref'], bufs['corr']
+        job.gain = job.offset = job.r2 = job.norm = None
+        job.fail_count = bufs['fail']
+        job.n_bands, job.height, job.width, job.stride, job.band_stride, job.seg_rows, job.stream = B, n, n, n, n * n, 0, 0
+        ctx.fit_apply_dev(desc, job)
+        ctx.stream_sync(0)
+        fails = np.zeros(B, np.uint64)
+        ctx.d2h(fails, bufs['fail'])
+        assert not (fails & np.uint64(1 << 63)).any(), 'the certificate-only build asked for a re-run on clean data'
+        assert (fails == 0).all(), fails
+        rng = np.random.default_rng(11)
+        r = k // 2
+        wh, ww = 500, 1200
+        tot = dif = 0
+        for b in range(B):
+            # two row bands per plane: one at an edge (alternating top / bottom), one in the interior
+            y_edge = 0 if b % 2 == 0 else n - wh - r
+            y_int = int(rng.integers(3 * r, n - wh - 3 * r))
+            for y_lo in (y_edge, y_int):
+                y0, y1 = max(0, y_lo - r), min(n, y_lo + wh + r)
+                rows = {name: np.empty((y1 - y0, n), np.float32) for name in ('src', 'ref', 'corr')}
+                for name in rows:
+                    ctx.d2h(rows[name], bufs[name] + plane * b + 4 * n * y0)
+                wins = [(y_lo - y0, 0), (y_lo - y0, n - ww), (y_lo - y0, int(rng.integers(r, n - ww - r)) // 4 * 4)]
+                # windows inside the downloaded band of rows; its top / bottom rim is the raster's edge only when y0 == 0 / y1 == n
+                for (wy, wx) in wins:
+                    ys = slice(max(0, wy - r), min(y1 - y0, wy + wh + r))
+                    xs = slice(max(0, wx - r), min(n, wx + ww + r))
+                    sw, tw = np.ascontiguousarray(rows['src'][ys, xs]), np.ascontiguousarray(rows['ref'][ys, xs])
+                    _, exp, _ = oracle.fit_apply('gain-offset', sw, None, tw, None, (k, k), False, 0.25, want_params=False)
+                    top_edge, bot_edge = (y0 + ys.start == 0), (y0 + ys.stop == n)
+                    cy = slice(0 if top_edge else r, exp.shape[0] - (0 if bot_edge else r))
+                    cx = slice(r if xs.start > 0 else 0, exp.shape[1] - (r if xs.stop < n else 0))
+                    got, exp = rows['corr'][ys, xs][cy, cx], exp[cy, cx]
+                    assert not np.isnan(got).any() and not np.isnan(exp).any()
+                    d = got != exp
+                    tot, dif = tot + got.size, dif + int(d.sum())
+                    if d.any():
+                        ulps = np.abs(got[d].view(np.int32).astype(np.int64) - exp[d].view(np.int32).astype(np.int64))
+                        assert ulps.max() <= 2, (b, ulps.max())
+        assert dif <= max(2, int(1e-5 * tot)), (dif, tot)
+        print(f'config 2 (4 bands, one launch): {tot} px checked in all bands, {dif} bitwise mismatches')
+    finally:
+        for name in bufs:
+            ctx.dev_free(bufs[name])
+
+
 def test_config3_block_in_place_with_halo_15x15(ctx, oracle):
     """ BASELINE.json configs[3] at its block size: a 4096 x 4096 out-block with its 8-pixel halo (a 4112 x 4112 in-block in
     the interior of a 16384-wide raster), gain-blk-offset 15x15, statistics over the in-block on the device, processed

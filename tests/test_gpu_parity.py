@@ -1669,3 +1669,58 @@ def test_stream_probe_adds_its_two_streams(ctx):
         ctx.stream_probe_dev(d[0], d[1], d[2], 4 * n + 4)
     for p in d:
         ctx.dev_free(p)
+
+
+def test_host_calls_and_device_jobs_on_one_stream_are_kept_apart():
+    """ include/homonim_hk.h: host-pointer calls lease the pooled streams device-resident jobs name by index.  The library keeps
+    the two apart at run time (a lease drains a stream that carries device jobs, a device-job call waits while its stream is
+    leased): on a ONE-stream context, a thread of host-pointer calls beside a thread of device jobs (block statistics + fit,
+    i.e. users of the stream's shared scratch) gives the same bytes as each alone. """
+    import threading
+    c1 = _hk.Context(0, n_streams=1)
+    try:
+        src, ref = onp.synth_pair(260, 520, 5, 'frame+holes')
+        desc = _hk.make_desc('gain-blk-offset', (5, 5), False, None, np.nan, np.nan)
+        _, exp_c, exp_norm, _ = c1.fit_apply(desc, src, ref, 2, want_params=False, want_corr=True)
+        stride = 576
+        pad = lambda a: np.ascontiguousarray(np.pad(a, ((0, 0), (0, stride - a.shape[1]))))   # noqa: E731
+        d = {k: c1.dev_alloc(4 * stride * 260) for k in ('src', 'ref', 'corr')}
+        d_norm = c1.dev_alloc(16)
+        c1.h2d(d['src'], pad(src)), c1.h2d(d['ref'], pad(ref))
+        job = _hk.DevJob()
+        job.src, job.ref, job.corr = d['src'], d['ref'], d['corr']
+        job.gain = job.offset = job.r2 = job.fail_count = None
+        job.norm = d_norm
+        job.n_bands, job.height, job.width, job.stride, job.band_stride, job.seg_rows, job.stream = 1, 260, 520, stride, stride * 260, 0, 0
+        errors = []
+
+        def host_loop():
+            try:
+                for _ in range(25):
+                    _, c, n, _ = c1.fit_apply(desc, src, ref, 2, want_params=False, want_corr=True)
+                    assert_same_f32(c, exp_c, 'host-pointer call beside device jobs')
+                    assert (n == exp_norm).all()
+            except Exception as ex:   # noqa: BLE001
+                errors.append(ex)
+
+        def dev_loop():
+            try:
+                out = np.empty((260, stride), np.float32)
+                for _ in range(25):
+                    c1.memset(d['corr'], 0, 4 * stride * 260)
+                    c1.block_norm_dev(desc, job, d_norm)
+                    c1.fit_apply_dev(desc, job)
+                    c1.stream_sync(0)
+                    c1.d2h(out, d['corr'])
+                    assert_same_f32(out[:, :520], exp_c, 'device job beside host-pointer calls')
+            except Exception as ex:   # noqa: BLE001
+                errors.append(ex)
+
+        ts = [threading.Thread(target=host_loop), threading.Thread(target=dev_loop)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        assert not errors, errors[0]
+        for p in list(d.values()) + [d_norm]:
+            c1.dev_free(p)
+    finally:
+        c1.close()

@@ -46,7 +46,7 @@ def _slab_job(c, src, ref, r0, r1, stream=0):
     job = _hk.DevJob()
     job.src, job.ref = d_src, d_ref
     job.corr = job.gain = job.offset = job.r2 = job.norm = job.fail_count = None
-    job.n_bands, job.height, job.width, job.stride, job.band_stride = nb, rows, w, stride, stride * rows
+    job.n_bands, job.height, job.width, job.stride, job.band_stride = nb, rows, w, stride, stride * max(rows, 1)
     job.seg_rows, job.stream = 0, stream
     return job, (d_src, d_ref)
 
@@ -118,9 +118,70 @@ def test_split_statistics_over_a_process_group(ctx, tmp_path, nproc):
     np.testing.assert_allclose(norms[0], exp, rtol=1e-12, atol=0)
 
 
+def _run_comm_workers(tmp_path, world, variant='frame+holes'):
+    """ `world` plain processes, rank r on GPU r, joined through the library's own RCCL communicator (no torch) """
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, PYTHONPATH=REPO, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r))
+        env.pop('HOMONIM_AMD_COMM_FILE', None)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(REPO, 'tests', '_split_norm_comm_worker.py'), str(tmp_path), variant],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    for p in procs:
+        out, err = p.communicate(timeout=600)
+        assert p.returncode == 0, err[-3000:]
+    return [np.load(tmp_path / f'norm_{r}.npy') for r in range(world)]
+
+
 def test_split_statistics_through_rccl(ctx, tmp_path):
-    """ the all-reduce on the device tensor through RCCL (backend nccl) -- a group of one on this box: same plumbing, and
-    the result must then be the whole-block statistics of the single slab. """
+    """ The production path: the LIBRARY binds RCCL (hk_comm_init) and queues the five all-reduces between the six phases on
+    the job's stream itself (hk_block_norm_split_comm_dev) -- no torch in the process (the worker asserts it), no host
+    synchronisation between the phases.  A communicator of one rank on this 1-GPU box: the collectives really run through
+    RCCL and the result must be the whole-block statistics of the single slab. """
+    norms = _run_comm_workers(tmp_path, 1)
+    src, ref = _block('frame+holes')
+    exp = _single(ctx, src, ref, np.nan)
+    np.testing.assert_allclose(norms[0], exp, rtol=1e-12, atol=0)
+
+
+@pytest.mark.parametrize('world', [2, 3, 4])
+def test_split_statistics_through_rccl_over_several_gpus(ctx, tmp_path, world):
+    """ ... and with one process per GPU where the box has them (the driver's 8-GPU node; skipped on a 1-GPU box: RCCL does
+    not put two ranks on one device).  With three or more ranks the last one holds no rows of the block. """
+    if _hk.device_count() < world:
+        pytest.skip(f'needs {world} GPUs')
+    norms = _run_comm_workers(tmp_path, world)
+    for n in norms[1:]:
+        assert (n == norms[0]).all()
+    src, ref = _block('frame+holes')
+    exp = _single(ctx, src, ref, np.nan)
+    np.testing.assert_allclose(norms[0], exp, rtol=1e-12, atol=0)
+
+
+def test_split_statistics_with_a_slab_of_no_rows(ctx):
+    """ a rank without rows of the block takes part with zeros (it used to be refused, leaving the others
+    waiting inside the all-reduce) """
+    src, ref = _block('frame+holes')
+    exp = _single(ctx, src, ref, np.nan)
+    desc = _hk.make_desc('gain-blk-offset', (5, 5), False, None, np.nan, np.nan)
+    ctxs = [_hk.Context(0, n_streams=1) for _ in range(3)]
+    parts, bufs = [], []
+    try:
+        for c, r0, r1 in zip(ctxs, (0, 250, 250), (250, 250, 613)):
+            job, b = _slab_job(c, src, ref, r0, r1)
+            parts.append((c, job)), bufs.append((c, b))
+        norms = split_norm.block_norm_split_local(parts, desc)
+        assert (norms[1] == norms[0]).all() and (norms[2] == norms[0]).all()
+        np.testing.assert_allclose(norms[0], exp, rtol=1e-12, atol=0)
+    finally:
+        for c, (a, b) in bufs:
+            c.dev_free(a), c.dev_free(b)
+        for c in ctxs:
+            c.close()
+
+
+def test_split_statistics_through_a_torch_nccl_group_of_one(ctx, tmp_path):
+    """ the host-driven phase loop with the all-reduce on a torch tensor through RCCL (backend nccl) -- a group of one on this
+    box: same plumbing, and the result must then be the whole-block statistics of the single slab. """
     env = dict(HOMONIM_AMD_DIST_FORCE='1')
     os.environ.pop('HOMONIM_AMD_DIST_BACKEND', None)
     backend, world = _run_worker(tmp_path, 1, 'frame+holes', env)
