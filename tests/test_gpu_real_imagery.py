@@ -320,3 +320,78 @@ def test_published_accuracy_table_of_the_real_stack(image):
         assert got['n'] == exp['n'], (row, got, exp)
         for key in ('r2', 'rmse', 'rrmse'):
             assert f'{got[key]:.3f}' == exp[key], (row, key, got, exp)
+
+
+def _vrt_mosaic(tiles, layout, fill):
+    """ gdal.BuildVRT mosaic of `tiles` (list of (bands, h, w) arrays in the VRT's source order) on the VRT's grid, as GDAL
+    reads it (VRTSimpleSource::GetSrcDstWindow + the nearest-neighbour RasterIO behind it): a source whose DstRect offset has
+    the fractional part f lands at column floor(off) + (1 if f > 0.5 else 0); the destination rectangle covers one pixel more
+    than the source (floor(off) .. ceil(off + size)), which is filled by repeating the source's first (f > 0.5) or last
+    (f <= 0.5) column / row; later sources overwrite earlier ones except where they hold nodata (NaN for float rasters). """
+    nb = tiles[0].shape[0]
+    out = np.full((nb, layout['height'], layout['width']), fill, tiles[0].dtype)
+
+    def axis_index(off, n_src, n_dst_total):
+        o0 = int(np.floor(off + 0.001))
+        o1 = int(np.ceil(off + n_src - 0.001))
+        j = np.arange(o1 - o0)
+        src = np.floor(j + 0.5 - (off - o0) + 1e-10).astype(np.int64).clip(0, n_src - 1)   # GDAL's nearest pixel, clamped
+        keep = (o0 + j >= 0) & (o0 + j < n_dst_total)
+        return o0 + j[keep], src[keep]
+
+    for tile, t in zip(tiles, layout['tiles']):
+        cols, sc = axis_index(t['x_off'], t['width'], layout['width'])
+        rows, sr = axis_index(t['y_off'], t['height'], layout['height'])
+        assert tile.shape[1:] == (t['height'], t['width'])
+        placed = tile[:, sr][:, :, sc]
+        valid = ~np.isnan(placed) if np.isnan(fill) else (placed != t['nodata'])
+        view = out[:, rows[0]:rows[-1] + 1, cols[0]:cols[-1] + 1]
+        view[valid] = placed[valid]
+    return out
+
+
+def test_published_mosaic_table_of_the_real_stack():
+    """ The reference's tutorial notebook prints a SECOND accuracy table of the real homonim + OpenCV + GDAL stack
+    (docs/tutorials/basic_correction.ipynb:299-334; tests/golden/notebook_table.json, oracle/gen_notebook_table_fixture.py):
+    the four NGI tiles fused with Sentinel-2 (gain-blk-offset 5x5), mosaicked (gdal.BuildVRT) and compared PER BAND with
+    the Landsat-8 image -- source mosaic and corrected mosaic, N = 76 143.  All eight band rows + the two mean rows: N
+    exactly, r2 / RMSE / rRMSE to every printed digit.  On top of the per-tile table this pins per-band (not only mean)
+    statistics, the `average` re-sampling over a mosaic with interior nodata seams, and the whole RefSpace chain on all four
+    tiles at once. """
+    import json
+    import warnings
+    from homonim_amd.compare import RasterCompare
+    from homonim_amd.fuse import RasterFuse
+    from homonim_amd.tiff import read_tiff
+    with open(os.path.join(GOLDEN_DIR, 'notebook_table.json')) as f:
+        fx = json.load(f)
+    with open(os.path.join(GOLDEN_DIR, 'docs_table.json')) as f:
+        bands = [b - 1 for b in json.load(f)['compare']['ref_bands_1based']]   # wavelength pairing of homonim/matched_pair.py
+    lay = fx['mosaic']
+    gt = lay['geotransform']
+    mosaic_tf = Affine(gt[1], gt[2], gt[0], gt[4], gt[5], gt[3])
+    l8 = read_tiff(os.path.join(RASTER_DIR, fx['compare']['reference']))
+    l8_ra = RasterArray(np.ascontiguousarray(l8.array[bands]), l8.crs, l8.transform, nodata=l8.nodata)
+    src_tiles, corr_tiles = [], []
+    crs = None
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for t in lay['tiles']:
+            path = os.path.join(RASTER_DIR, t['file'])
+            tif = read_tiff(path)
+            crs = tif.crs
+            src_tiles.append(tif.array)
+            with RasterFuse(path, os.path.join(RASTER_DIR, fx['fuse']['reference'])) as rf:
+                corr, _ = rf.process(None, fx['fuse']['model'], tuple(fx['fuse']['kernel_shape']))
+            corr_tiles.append(corr)
+        results = {}
+        for label, tiles, fill in (('Source', src_tiles, lay['nodata']), ('Corrected', corr_tiles, np.nan)):
+            mosaic = _vrt_mosaic(tiles, lay, np.float32(fill) if label == 'Corrected' else src_tiles[0].dtype.type(fill))
+            ra = RasterArray(mosaic, crs, mosaic_tf, nodata=float(fill))
+            with RasterCompare(ra, l8_ra) as cmp:
+                results[label] = list(cmp.process().values())
+    for label, rows in fx['tables'].items():
+        for got, (name, exp) in zip(results[label], rows.items()):
+            assert got['n'] == exp['n'], (label, name, got, exp)
+            for key in ('r2', 'rmse', 'rrmse'):
+                assert f'{got[key]:.3f}' == exp[key], (label, name, key, got, exp)
