@@ -326,7 +326,7 @@ def run_resident(args, ctx, dist, rank, world):
     H = W = args.size
     B = args.bands
     k = args.kernel
-    stride = (W + 63) // 64 * 64
+    stride = (W + 63) // 64 * 64 + int(os.environ.get('HK_BENCH_ROW_PAD', '0'))   # experiment: rows not a power of two apart
     band_stride = stride * H
     plane_bytes = 4 * band_stride * B
     thresh = 0.25 if (args.model == 'gain-offset' and not args.no_thresh) else None
@@ -514,7 +514,7 @@ def run_blocks(args, ctx, dist, rank, world):
     # the positions; every rank keeps the whole raster resident (25.8 GB of the 288).
     positions = [bp for bp in all_blocks if bp.band_i == 0]
     mine = shard(positions, rank, world)
-    stride = (W + 63) // 64 * 64
+    stride = (W + 63) // 64 * 64 + int(os.environ.get('HK_BENCH_ROW_PAD', '0'))   # experiment: rows not a power of two apart
     band_stride = stride * H
     nd = np.nan if args.nodata in (1, 2) else None
     desc = _hk.make_desc(args.model, (k, k), False, None, nd, nd)
@@ -646,7 +646,7 @@ def run_tiles(args, ctx, dist, rank, world):
     nd = np.nan if args.nodata in (1, 2) else None
     desc = _hk.make_desc(args.model, (k, k), False, thresh, nd, nd)
     mine = shard(list(range(T)), rank, world, contiguous=True)
-    stride = (n + 63) // 64 * 64
+    stride = (n + 63) // 64 * 64 + int(os.environ.get('HK_BENCH_ROW_PAD', '0'))
     band_stride = stride * n
     tile_bytes = 4 * band_stride * B
     n_streams = ctx.n_streams

@@ -302,6 +302,16 @@ void fill_args(hk::FitArgs& a, const hk_fit_desc* d, int xcd_remap) {
     if (!needs_r2(d) && d->kw <= 15) {
         if (d->model == HK_MODEL_GAIN && d->kh <= 15) a.use_ring = 1;
         if (d->model == HK_MODEL_GAIN_BLK_OFFSET && d->kh <= 7 && d->kw <= 7) a.use_ring = 1;
+        // Round 3, the SPLIT ring (rh rows in registers + rh + 1 in LDS: no re-load, 16 instead of 30 KB of LDS at 15x15):
+        // gain 11x11 / 13x13 / 15x15 at 16384^2 x 4: 2.77 / 3.08 / 3.47 -> 2.70 / 2.86 / 3.07 ms (7x7 and 9x9 stay with the
+        // full ring: 2.36 / 2.45 against 2.48 / 2.72); gain-blk-offset incl. statistics 9x9 / 11x11: 5.23 / 5.38 -> 4.95 /
+        // 5.27 ms -- but 13x13 / 15x15 get SLOWER (5.37 / 5.35 -> 5.57 / 5.99): with its float64 normalisation and quotient
+        // per pixel and the 15-wide horizontal sums that kernel is bound by VALU issue, not by the 8 B per pixel the
+        // re-load moves (profiles/r03_sweep_ring.txt).
+        if (d->kw >= 5) {
+            if (d->model == HK_MODEL_GAIN && d->kh >= 11 && d->kh <= 15) a.use_ring = 3;
+            if (d->model == HK_MODEL_GAIN_BLK_OFFSET && d->kh >= 9 && d->kh <= 11) a.use_ring = 3;
+        }
     }
     // ... and, in their lock-step workgroups (hk_kernels.hip WPB), short uniform segments: 32 rows instead of 64 / 128 + 32
     // (gain 5x5: configs[1] 0.676 -> 0.625 ms, 16384^2 x 4 2.65 -> 2.49 ms on one box; 7x7 2.54 -> 2.47; gain-blk-offset 5x5
@@ -315,6 +325,7 @@ void fill_args(hk::FitArgs& a, const hk_fit_desc* d, int xcd_remap) {
         const bool mem_bound = d->model != HK_MODEL_GAIN_OFFSET && !needs_r2(d);
         if (m == 1 && d->kh <= 63 && (d->kw <= 7 || (mem_bound && d->kw <= 15))) a.use_ring = 1;
         if (m == 2 && d->kh <= 127) a.use_ring = 2;
+        if (m == 3 && mem_bound && d->kh >= 7 && d->kh <= 15 && d->kw >= 5 && d->kw <= 15) a.use_ring = 3;
         if (m == 0) a.use_ring = 0;
     }
     a.xcd_remap = xcd_remap;

@@ -533,7 +533,11 @@ struct ColSums {
 //   2  centre row from an LDS ring of rh + 1 rows holding only `s` + mask (20 B per lane-row), leaving row re-loaded from
 //      global memory -- tall kernels: a full ring would cut occupancy to one wave per SIMD, re-loading BOTH rows makes
 //      three streams that all miss L2 and the kernel fabric-bound;
-//   0  both re-loaded (very tall kernels whose centre ring would not fit either).
+//   0  both re-loaded (very tall kernels whose centre ring would not fit either);
+//   3  SPLIT ring (light builds -- gain, gain-blk-offset without R2 -- with 7 <= kh <= 17): the rh newest rows stay in
+//      REGISTERS (8 VGPRs per row), the rh + 1 older ones in an LDS ring (32 B per lane-row): no global re-load of the leaving
+//      row (mode 2 moves 20 instead of 12 bytes per pixel through the fabric at 15x15) with 16 KB instead of 30 KB of LDS per
+//      wave.  The row that leaves the registers IS the window's centre row, so the centre needs no LDS read either.
 // WPB = waves per workgroup.  The memory-bound builds with a full LDS ring (gain, gain-blk-offset without R2, short kernels)
 // put HK_WPB_MEM ADJACENT STRIPS of one segment into a workgroup and keep them in lock-step with a barrier per row: the
 // workgroup then reads and writes 4 KB of every row together instead of 1 KB per wave at unrelated times, which the HBM
@@ -548,6 +552,9 @@ struct ColSums {
 // 3 S2, 4 R2.  One 16-byte slot per lane + one at each end = XCH_BYTES per wave behind the row rings.
 #ifndef HK_XCH
 #define HK_XCH 0
+#endif
+#ifndef HK_SRING_MAX
+#define HK_SRING_MAX 7   // register rows of the split ring (RING 3): kernels up to 15 rows tall
 #endif
 #ifndef HK_CERT_R2_F32
 #define HK_CERT_R2_F32 1
@@ -640,20 +647,22 @@ fit_apply_kernel(const FitArgs a) {
 
     constexpr bool ring = RING == 1;         // full ring: leaving + centre rows
     constexpr bool cring = RING == 2;        // centre-only ring
+    constexpr bool sring = RING == 3;        // split ring: rh rows in registers + rh + 1 rows in LDS
     // The HBM-bound kernels without R2 (gain, gain-blk-offset) read the leaving row from LDS one iteration AHEAD (its
     // latency leaves the loop-carried path), which also frees its slot before the entering row is written: their ring has
     // kh - 1 rows (8 KB instead of 10 KB per wave at 5x5 = 20 instead of 16 waves per CU).
     constexpr bool RING_AHEAD = ring && MODEL != 2 && !R2;
-    const int ring_rows = ring ? (RING_AHEAD ? (kh > 1 ? kh - 1 : 1) : kh) : (cring ? rh + 1 : 0);
+    const int ring_rows = ring ? (RING_AHEAD ? (kh > 1 ? kh - 1 : 1) : kh) : ((cring || sring) ? rh + 1 : 0);
+    constexpr bool ring2p = ring || sring;   // the LDS ring holds both planes (source + reference) of its rows
     // RING 1: [slot][s|r][lane]; RING 2: [slot][lane] (s only); one ring per wave of the workgroup
-    float4* ring_v = lds4 + (size_t)wave_in_wg * (size_t)(ring_rows * (ring ? 2 : 1) * WAVE);
+    float4* ring_v = lds4 + (size_t)wave_in_wg * (size_t)(ring_rows * (ring2p ? 2 : 1) * WAVE);
     // slots start as rows that were never added: zero contribution, no valid pixel
     constexpr int XCH = xch_mask<MODEL, RW, RING, WPB>();
-    [[maybe_unused]] char* const xch = reinterpret_cast<char*>(lds4 + (size_t)WPB * (size_t)(ring_rows * (ring ? 2 : 1) * WAVE)) +
+    [[maybe_unused]] char* const xch = reinterpret_cast<char*>(lds4 + (size_t)WPB * (size_t)(ring_rows * (ring2p ? 2 : 1) * WAVE)) +
                                        (size_t)wave_in_wg * XCH_BYTES + 16 + lane * 16;
     const float ring_init = DENSE ? 0.f : __uint_as_float(RING_SENTINEL);
     for (int sl = 0; sl < ring_rows; ++sl) {
-        if constexpr (ring) {
+        if constexpr (ring2p) {
             ring_v[(sl * 2 + 0) * WAVE + lane] = make_float4(ring_init, ring_init, ring_init, ring_init);
             ring_v[(sl * 2 + 1) * WAVE + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
         } else {
@@ -687,6 +696,20 @@ fit_apply_kernel(const FitArgs a) {
             }
         }
     };
+
+    // RING 3: the rh newest rows live in registers.  The slot (wave-uniform, t mod rh) is run-time, register indices are
+    // not: a switch over the (at most SRING_MAX) slots exchanges the leaving row for the entering one with 16 moves.
+    constexpr int SRING_MAX = HK_SRING_MAX;
+    [[maybe_unused]] float4 rg_s[SRING_MAX], rg_r[SRING_MAX];
+    [[maybe_unused]] unsigned rg_clean = 0u;  // wave-uniform: bit k = the row in register slot k is `clean`
+    if constexpr (sring) {
+#pragma unroll
+        for (int k = 0; k < SRING_MAX; ++k) {
+            rg_s[k] = make_float4(ring_init, ring_init, ring_init, ring_init);
+            rg_r[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    int slot_r = 0;  // RING 3: register slot of this iteration
 
     // 1/N for the offset division (see HK_INV_N): proven for window counts < 2^8
     const bool lut_ok = GO && kh * (2 * rw + 1) <= 255;
@@ -744,7 +767,7 @@ fit_apply_kernel(const FitArgs a) {
 
     // RING 0 / 2: the re-loaded leaving row runs one iteration ahead where the registers allow it (not in the general
     // gain-offset kernels, which would spill)
-    constexpr bool PF_OLD = !ring && (DENSE || MODEL != 2);
+    constexpr bool PF_OLD = !ring && !sring && (DENSE || MODEL != 2);
     [[maybe_unused]] RowRaw qo_next;
     if constexpr (PF_OLD) qo_next = load_row<HK_NT_LEAVE>(sp, rp, a.stride, t_first - kh, H, xq);
     // RING 1: the first leaving row is the zero row the ring was initialised with
@@ -757,7 +780,7 @@ fit_apply_kernel(const FitArgs a) {
     [[maybe_unused]] bool gave_up = false;  // wave-uniform, certificate-only build: this wave has asked for the re-run
     int slot = 0;
     int slot2 = 0;  // RING 2: write slot of the centre ring
-    const int ring_mod = ring ? ring_rows : kh;
+    const int ring_mod = ring2p ? ring_rows : kh;
     int slot_c = ring_mod - rh;  // slot of the centre row of the output produced at this iteration: (slot - rh) mod ring_mod
     if (slot_c >= ring_mod) slot_c -= ring_mod;
     for (int t = t_first; t <= t_last; ++t) {
@@ -774,7 +797,7 @@ fit_apply_kernel(const FitArgs a) {
             // the leaving row is fetched one iteration ahead (it comes from L2 / the Infinity Cache): qo_next holds row t_old
             qo = qo_next;
             qo_next = load_row<HK_NT_LEAVE>(sp, rp, a.stride, t_old + 1, H, xq);
-        } else if constexpr (!ring) {
+        } else if constexpr (!ring && !sring) {
             qo = load_row<HK_NT_LEAVE>(sp, rp, a.stride, t_old, H, xq);
         }
         if constexpr (RING == 0) qc = load_row(sp, rp, a.stride, y_c, H, xq);
@@ -792,6 +815,8 @@ fit_apply_kernel(const FitArgs a) {
             if (!znew.clean) last_dirty = t;  // wave-uniform
         }
         RowZ zold;
+        [[maybe_unused]] float4 mid_s, mid_r;      // RING 3: the row t - rh as it leaves the registers
+        [[maybe_unused]] bool mid_clean = false;
         if constexpr (ring) {
             // leaving row (t - kh) = the slot the entering row overwrites.  The HBM-bound kernels fetch it from LDS one
             // iteration ahead (RING_AHEAD above; 3.06 -> 2.99 ms for `gain` by the latency alone); the VALU-bound kernels do
@@ -814,6 +839,32 @@ fit_apply_kernel(const FitArgs a) {
             ring_v[(slot * 2 + 0) * WAVE + lane] = ring_encode(znew);
             ring_v[(slot * 2 + 1) * WAVE + lane] = make_float4(znew.r[0], znew.r[1], znew.r[2], znew.r[3]);
             if constexpr (!DENSE) ring_clean = (ring_clean & ~(1ull << slot)) | ((unsigned long long)znew.clean << slot);
+        } else if constexpr (sring) {
+            // registers: the row that entered rh iterations ago comes out -- it is the centre row of this iteration's output
+            // and moves on to the LDS ring --, the entering row takes its slot
+            const float4 ns = ring_encode(znew), nr = make_float4(znew.r[0], znew.r[1], znew.r[2], znew.r[3]);
+            mid_clean = (rg_clean >> slot_r) & 1u;
+            rg_clean = (rg_clean & ~(1u << slot_r)) | ((unsigned)znew.clean << slot_r);
+#define HK_RG_SWAP(k) mid_s = rg_s[k], mid_r = rg_r[k], rg_s[k] = ns, rg_r[k] = nr
+#define HK_RG_CASE(k) case k: HK_RG_SWAP(k); break;
+            static_assert(SRING_MAX == 7 || SRING_MAX == 8, "register slots of the split ring");
+            switch (slot_r) {
+                HK_RG_CASE(0) HK_RG_CASE(1) HK_RG_CASE(2) HK_RG_CASE(3) HK_RG_CASE(4) HK_RG_CASE(5)
+                default:
+                    if (SRING_MAX == 7 || slot_r == 6) HK_RG_SWAP(6);
+                    else HK_RG_SWAP(SRING_MAX - 1);
+            }
+#undef HK_RG_CASE
+#undef HK_RG_SWAP
+            // LDS: the row t - kh leaves, the row from the registers takes its slot
+            const bool slot_clean = (ring_clean >> slot) & 1ull;
+            const float4 os = ring_v[(slot * 2 + 0) * WAVE + lane];
+            const float4 orr = ring_v[(slot * 2 + 1) * WAVE + lane];
+            ring_decode(os, slot_clean, zold.s, zold.m);
+            zold.r[0] = orr.x, zold.r[1] = orr.y, zold.r[2] = orr.z, zold.r[3] = orr.w;
+            ring_v[(slot * 2 + 0) * WAVE + lane] = mid_s;
+            ring_v[(slot * 2 + 1) * WAVE + lane] = mid_r;
+            if constexpr (!DENSE) ring_clean = (ring_clean & ~(1ull << slot)) | ((unsigned long long)mid_clean << slot);
         } else {
             zold = process_row<MODEL, DENSE, MODEL == 1 && R2>(qo, t_old >= t_first && t_old >= 0 && t_old < H, colbits, full_wave, ts, tr, n0, n1);
             if constexpr (cring) {  // slot2 cycles over rh + 1 rows: the entering row replaces the centre row of rh + 1 ago
@@ -835,7 +886,9 @@ fit_apply_kernel(const FitArgs a) {
             // centre row of the window
             float sc[PX];
             unsigned mc;
-            if constexpr (ring || cring) {
+            if constexpr (sring) {
+                ring_decode(mid_s, mid_clean, sc, mc);
+            } else if constexpr (ring || cring) {
                 // RING 1: slot_c = (slot - rh) mod kh; RING 2: the slot after the one just written = (slot2 + 1) mod (rh + 1)
                 int cs_slot = slot_c;
                 if constexpr (cring) cs_slot = slot2 + 1 == rh + 1 ? 0 : slot2 + 1;
@@ -1209,6 +1262,7 @@ fit_apply_kernel(const FitArgs a) {
         if (++slot == ring_mod) slot = 0;
         if (++slot_c == ring_mod) slot_c = 0;
         if (++slot2 == rh + 1) slot2 = 0;
+        if (++slot_r >= rh) slot_r = 0;
     }
 
     if constexpr (GO && R2) {
@@ -1227,6 +1281,7 @@ fit_apply_kernel(const FitArgs a) {
 size_t fit_lds_bytes(int kh, int ring_mode, bool ahead) {
     if (ring_mode == 1) return (size_t)(ahead && kh > 1 ? kh - 1 : kh) * 2 * WAVE * sizeof(float4);
     if (ring_mode == 2) return (size_t)(kh / 2 + 1) * WAVE * sizeof(float4);
+    if (ring_mode == 3) return (size_t)(kh / 2 + 1) * 2 * WAVE * sizeof(float4);
     return 0;
 }
 
@@ -1275,7 +1330,14 @@ static hipError_t launch_one(const FitArgs& a, hipStream_t stream) {
 template <int MODEL, bool R2, bool DENSE>
 static hipError_t launch_rw(const FitArgs& a, hipStream_t stream) {
 #ifdef HK_DEV_SUBSET  // development builds: only the 5x5 kernels with the full LDS ring (seconds instead of a minute)
+#ifdef HK_DEV_SUBSET15   // ... or only the 15-wide kernels with the centre / split ring
+    if constexpr (MODEL != 2 && !R2) {
+        if (a.use_ring == 3) return launch_one<MODEL, R2, 7, DENSE, 3>(a, stream);
+    }
+    return launch_one<MODEL, R2, 7, DENSE, 2>(a, stream);
+#else
     return launch_one<MODEL, R2, 2, DENSE, 1>(a, stream);
+#endif
 #else
     // a.use_ring (hk_api.hip): 1 full LDS ring (short, narrow kernels only), 2 centre ring + re-loaded leaving row,
     // 0 everything re-loaded (very tall kernels; run-time width path only, to bound the number of instantiations)
@@ -1298,6 +1360,19 @@ static hipError_t launch_rw(const FitArgs& a, hipStream_t stream) {
         }
     }
     if (a.use_ring == 0) return launch_one<MODEL, R2, -1, DENSE, 0>(a, stream);
+    if constexpr (MODEL != 2 && !R2) {  // split ring (hk_api.hip fill_args): 3 <= rh <= 8
+        if (a.use_ring == 3) {
+            switch (a.rw) {
+                case 2: return launch_one<MODEL, R2, 2, DENSE, 3>(a, stream);
+                case 3: return launch_one<MODEL, R2, 3, DENSE, 3>(a, stream);
+                case 4: return launch_one<MODEL, R2, 4, DENSE, 3>(a, stream);
+                case 5: return launch_one<MODEL, R2, 5, DENSE, 3>(a, stream);
+                case 6: return launch_one<MODEL, R2, 6, DENSE, 3>(a, stream);
+                case 7: return launch_one<MODEL, R2, 7, DENSE, 3>(a, stream);
+                default: break;   // other widths: centre ring
+            }
+        }
+    }
     switch (a.rw) {
         case 0: return launch_one<MODEL, R2, 0, DENSE, 2>(a, stream);
         case 1: return launch_one<MODEL, R2, 1, DENSE, 2>(a, stream);

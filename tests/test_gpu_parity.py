@@ -1570,6 +1570,36 @@ def test_south_up_and_mirrored_grids(ctx):
     assert_same_f32(got2, exp, 'south-up reference through RasterFuse')
 
 
+@pytest.mark.parametrize('model, kernel_shape, nodata', [
+    ('gain', (15, 15), np.nan), ('gain', (11, 11), None), ('gain', (13, 7), np.nan), ('gain', (7, 5), np.nan),
+    ('gain-blk-offset', (9, 9), np.nan), ('gain-blk-offset', (11, 5), np.nan), ('gain-blk-offset', (15, 15), 0.0),
+])
+def test_split_ring_agrees_with_the_other_ring_modes(ctx, model, kernel_shape, nodata, monkeypatch):
+    """ Ring mode 3 (round 3): the rh newest rows of a tall kernel's window stay in registers, the rh + 1 older ones in an LDS
+    ring -- no re-load of the leaving row.  Same bytes as the centre-ring / re-load modes, on rasters with a NaN frame and
+    holes, numeric nodata and none, taller than one wave segment; and equal to the oracle. """
+    import warnings
+    h, w = 700, 530
+    src, ref = onp.synth_pair(h, w, seed=kernel_shape[0] + 100, nodata_variant='none' if nodata is None else 'frame+holes')
+    if nodata == 0.0:
+        src, ref = np.where(np.isnan(src), np.float32(0), src), np.where(np.isnan(ref), np.float32(0), ref)
+    cfg = dict(model=model, kernel_shape=kernel_shape, find_r2=False, r2_inpaint_thresh=None, src_nodata=nodata, ref_nodata=nodata)
+    norm_in = onp.fit_block_norm(src, nodata, ref, nodata) if model == 'gain-blk-offset' else None
+    out = {}
+    for mode in ('3', '2', '0'):
+        monkeypatch.setenv('HK_USE_RING', mode)
+        out[mode] = _fit_via_abi(ctx, cfg, src, ref, norm_in=norm_in)
+    monkeypatch.delenv('HK_USE_RING')
+    out['default'] = _fit_via_abi(ctx, cfg, src, ref, norm_in=norm_in)
+    for mode in ('2', '0', 'default'):
+        assert_same_f32(out['3'][0], out[mode][0], f'params ring mode 3 vs {mode}')
+        assert_same_f32(out['3'][1], out[mode][1], f'corrected ring mode 3 vs {mode}')
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        exp, _ = onp.fit(model, src, nodata, ref, nodata, kernel_shape, False, None, norm_model=norm_in)
+    assert_close_ulp(out['3'][0], exp, 'params')
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # round 3: hygiene of the host layer
 def test_a_tolerated_hip_failure_does_not_poison_the_next_launch(ctx):
