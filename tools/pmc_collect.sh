@@ -11,7 +11,7 @@ i=0
 for g in "${groups[@]}"; do
   out=$root/gpurun_out/pmc_${tag}_$i
   rm -rf "$out"
-  (cd /tmp && timeout 300 rocprofv3 --pmc $g --kernel-trace -d "$out" -o run --output-format csv -- python3 "$root/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-parity --no-nan-variant "$@" > "$out.log" 2>&1)
+  (cd /tmp && timeout 300 rocprofv3 --pmc $g --kernel-trace -d "$out" -o run --output-format csv -- python3 "$root/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-parity --no-nan-variant --no-other-configs --no-power-probe "$@" > "$out.log" 2>&1)
   i=$((i+1))
 done
 python3 "$root/tools/pmc_summarise.py" "$tag" "$@" > "$root/gpurun_out/pmc_${tag}_summary.json"

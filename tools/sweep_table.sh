@@ -1,6 +1,6 @@
 #!/bin/bash
 # The measurement table of DESIGN.md section 6 from one box:  tools/sweep_table.sh > gpurun_out/sweep.txt
-run() { python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-nan-variant "$@" 2>/dev/null | tail -1 | python3 -c "
+run() { python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-nan-variant --no-other-configs --no-power-probe "$@" 2>/dev/null | tail -1 | python3 -c "
 import sys, json
 d = json.loads(sys.stdin.read())
 r = d['roofline']
@@ -24,3 +24,7 @@ run --params
 run --model gain --params
 run --nodata 4 --steps 3
 run --model gain-blk-offset --nodata 2
+run --model gain --kernel 7
+run --model gain --kernel 11
+run --model gain --kernel 15
+run --model gain-blk-offset --kernel 9
