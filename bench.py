@@ -663,7 +663,10 @@ def run_tiles(args, ctx, dist, rank, world):
         job.fail_count = d['fail']
         job.norm = d['norm'] if args.model == 'gain-blk-offset' else None
         job.n_bands, job.height, job.width, job.stride, job.band_stride = B, n, n, stride, band_stride
-        job.seg_rows, job.stream = 0, j % n_streams
+        # launches of different streams overlap each other's tails, so a tile prefers longer wave segments than a launch that has
+        # the GPU to itself (half the priming rows, half the waves): 128 rows 12.4 ms per step against 13.4 at the library's 64
+        # (profiles/r03_c4_segrows.txt; alone, a tile's launch takes 0.300 ms at 64 rows and 0.335 at 128)
+        job.seg_rows, job.stream = (args.seg_rows or (128 if k <= 5 else 0)), j % n_streams
         if thresh is not None:  # the in-painting's inputs stay with the tile until its counters have been looked at
             job.scratch_bytes = ctx.job_scratch_bytes(job)
             d['scratch'] = ctx.dev_alloc(job.scratch_bytes)
