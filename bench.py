@@ -540,7 +540,7 @@ def run_blocks(args, ctx, dist, rank, world):
             job.gain = job.offset = job.r2 = job.fail_count = None
             job.norm = bufs['norm'] + 16 * (B * i + b0)
             job.n_bands, job.height, job.width, job.stride, job.band_stride = min(bpj, B - b0), win_in.height, win_in.width, stride, band_stride
-            job.seg_rows, job.stream = 0, len(jobs) % n_streams   # the latency-bound statistics of one position overlap another's fit
+            job.seg_rows, job.stream = args.seg_rows, len(jobs) % n_streams   # the latency-bound statistics of one position overlap another's fit
             job.out_row0, job.out_col0 = win_out.row_off - win_in.row_off, win_out.col_off - win_in.col_off
             job.out_rows, job.out_cols = win_out.height, win_out.width
             jobs.append(job)
