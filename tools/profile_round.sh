@@ -9,6 +9,7 @@ root=$(pwd)
 python3 bench.py > gpurun_out/${tag}_bench_full.json 2> gpurun_out/${tag}_bench_full.err
 rm -rf gpurun_out/${tag}_stats
 (cd /tmp && rocprofv3 --kernel-trace --stats -d "$root/gpurun_out/${tag}_stats" -o run --output-format csv -- python3 "$root/bench.py" --no-cpu-baseline > "$root/gpurun_out/${tag}_stats.log" 2>&1)
+python3 tools/kstat_by_grid.py gpurun_out/${tag}_stats/run_kernel_trace.csv 3 > gpurun_out/${tag}_kernel_stats_by_grid.csv
 tools/pmc_collect.sh ${tag} > /dev/null 2>&1
 tools/pmc_collect.sh ${tag}_nd2 --nodata 2 > /dev/null 2>&1
 tools/pmc_collect.sh ${tag}_nd1 --nodata 1 > /dev/null 2>&1
