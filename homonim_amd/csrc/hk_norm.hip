@@ -35,7 +35,10 @@ constexpr int NORM_THREADS = 256;
 constexpr int L1_BITS = 11, L2_BITS = 11, L3_BITS = 10;
 constexpr int L1_BINS = 1 << L1_BITS, L2_BINS = 1 << L2_BITS, L3_BINS = 1 << L3_BITS;
 constexpr int SAMPLE_N = 4096;     // sample size per band
-constexpr int PASS_WAVES = 2048;   // most waves per band in the streaming pass (= the number of partial sums kept)
+#ifndef HK_PASS_WAVES
+#define HK_PASS_WAVES 2048
+#endif
+constexpr int PASS_WAVES = HK_PASS_WAVES;  // most waves per band in the streaming pass (= the number of partial sums kept)
 constexpr int FB_BLOCKS = 512;     // workgroups per band of the fallback passes
 constexpr int MID_BLOCKS = 256;    // workgroups per compacted buffer of the regular select passes
 
