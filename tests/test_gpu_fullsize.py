@@ -343,3 +343,130 @@ def test_config4_tiles_on_four_streams(ctx, oracle):
         for d in tiles:
             for k in ('src', 'ref', 'corr', 'fail'):
                 ctx.dev_free(d[k])
+
+
+def test_config3_all_128_blocks_of_the_resident_raster(ctx, oracle):
+    """ BASELINE.json configs[3] at its FULL count: the 8-band 16384 x 16384 raster resident in HBM, cut into the reference's own
+    128 blocks (16 positions x 8 bands; homonim/raster_pair.py:342-428), every block normalised by its own device statistics
+    and processed in place with its out-block as store window -- exactly bench.py --config 3.  Oracle windows in six block
+    positions (corners, edges, interior, the last one) x two bands incl. the last, each with ITS block's statistics; the
+    statistics themselves against numpy's; every pixel of the checked planes written exactly once. """
+    from homonim_amd import utils
+    from homonim_amd.fuse import block_pairs
+    from oracle import oracle_np as onp
+    n, B, k = SIZE, 8, 15
+    plane = n * n
+    bufs = {name: ctx.dev_alloc(4 * plane * B) for name in ('src', 'ref', 'corr')}
+    overlap = utils.overlap_for_kernel((k, k))
+    positions = [bp for bp in block_pairs((n, n), B, overlap, 100) if bp.band_i == 0]
+    assert len(positions) == 16
+    norm = ctx.dev_alloc(16 * B * len(positions))
+    big = _hk.Context(ctx.device, n_streams=8)
+    try:
+        ctx.synth_fill_dev(bufs['src'], bufs['ref'], B, n, n, n, plane, seed=1234, nodata_variant=0, stream=0)
+        ctx.memset(bufs['corr'], 0xff, 4 * plane * B)      # NaN pattern: a pixel nobody stores stays NaN
+        ctx.stream_sync(0)
+        desc = _hk.make_desc('gain-blk-offset', (k, k), False, None, None, None)
+        for i, bp in enumerate(positions):
+            wi, wo = bp.src_in_block, bp.src_out_block
+            off = 4 * (wi.row_off * n + wi.col_off)
+            job = _hk.DevJob()
+            job.src, job.ref, job.corr = bufs['src'] + off, bufs['ref'] + off, bufs['corr'] + off
+            job.gain = job.offset = job.r2 = job.fail_count = None
+            job.norm = norm + 16 * B * i
+            job.n_bands, job.height, job.width, job.stride, job.band_stride = B, wi.height, wi.width, n, plane
+            job.seg_rows, job.stream = 0, i % 8
+            job.out_row0, job.out_col0 = wo.row_off - wi.row_off, wo.col_off - wi.col_off
+            job.out_rows, job.out_cols = wo.height, wo.width
+            big.block_norm_dev(desc, job, job.norm)
+            big.fit_apply_dev(desc, job)
+        big.sync()
+        norms = np.zeros((len(positions), B, 2))
+        ctx.d2h(norms, norm)
+        rng = np.random.default_rng(8)
+        tot = dif = 0
+        r = k // 2
+        for b in (2, B - 1):
+            arr = {name: np.empty((n, n), np.float32) for name in bufs}
+            for name in bufs:
+                ctx.d2h(arr[name], bufs[name] + 4 * plane * b)
+            assert not np.isnan(arr['corr']).any(), 'a pixel of the plane was never stored'
+            for pi in (0, 3, 5, 10, 12, 15):
+                wi, wo = positions[pi].src_in_block, positions[pi].src_out_block
+                blk = (slice(wi.row_off, wi.row_off + wi.height), slice(wi.col_off, wi.col_off + wi.width))
+                s, t = np.ascontiguousarray(arr['src'][blk]), np.ascontiguousarray(arr['ref'][blk])
+                if b == B - 1 and pi in (0, 15):
+                    assert np.allclose(norms[pi, b], onp.fit_block_norm(s, None, t, None), rtol=2e-6, atol=0)
+                got = arr['corr'][blk]
+                # windows inside the out-block (in-block coordinates): its first corner + a random place
+                oy, ox = wo.row_off - wi.row_off, wo.col_off - wi.col_off
+                wins = [(oy, ox), (oy + int(rng.integers(0, wo.height - 300)), ox + int(rng.integers(0, wo.width - 700)))]
+                for (y0, x0) in wins:
+                    ys, xs = slice(max(0, y0 - r), min(wi.height, y0 + 300 + r)), slice(max(0, x0 - r), min(wi.width, x0 + 700 + r))
+                    _, exp, _ = oracle.fit_apply('gain-blk-offset', np.ascontiguousarray(s[ys, xs]), None, np.ascontiguousarray(t[ys, xs]),
+                                                 None, (k, k), False, None, norm_model=norms[pi, b], want_params=False)
+                    cy = slice(y0 - ys.start, y0 - ys.start + 300)
+                    cx = slice(x0 - xs.start, x0 - xs.start + 700)
+                    # the block is a stand-alone raster to the reference: its windows are cut at the in-block's border only
+                    e, g = exp[cy, cx], got[y0:y0 + 300, x0:x0 + 700]
+                    top_cut = ys.start == 0 and y0 - r < 0
+                    assert not top_cut or wi.row_off == 0
+                    d = e != g
+                    tot, dif = tot + e.size, dif + int(d.sum())
+                    if d.any():
+                        ulps = np.abs(g[d].view(np.int32).astype(np.int64) - e[d].view(np.int32).astype(np.int64))
+                        assert ulps.max() <= 2, (b, pi, ulps.max())
+        assert dif <= max(2, int(1e-5 * tot)), (dif, tot)
+        print(f'config 3, all 128 blocks: {tot} px checked in 6 positions x 2 bands, {dif} bitwise mismatches')
+    finally:
+        big.close()
+        for name in bufs:
+            ctx.dev_free(bufs[name])
+        ctx.dev_free(norm)
+
+
+def test_config4_all_64_tiles(ctx, oracle):
+    """ BASELINE.json configs[4] at its FULL count: 64 independent 4-band 4096 x 4096 tiles resident in HBM (51 GB), one fused
+    gain-offset 5x5 launch per tile dealt round four streams with the r2-mask counters checked per tile -- bench.py --config 4.
+    Oracle windows in every eighth tile + the last, in a different band each; all counters clean. """
+    n, B, T = 4096, 4, 64
+    plane = 4 * n * n
+    tiles = []
+    try:
+        for t in range(T):
+            d = {name: ctx.dev_alloc(plane * B) for name in ('src', 'ref', 'corr')}
+            d['fail'] = ctx.dev_alloc(8 * B)
+            ctx.memset(d['fail'], 0, 8 * B)
+            ctx.synth_fill_dev(d['src'], d['ref'], B, n, n, n, n * n, seed=5000 + t, nodata_variant=0, stream=0)
+            tiles.append(d)
+        ctx.stream_sync(0)
+        desc = _hk.make_desc('gain-offset', (5, 5), False, 0.25, None, None)
+        for t, d in enumerate(tiles):
+            job = _hk.DevJob()
+            job.src, job.ref, job.corr, job.fail_count = d['src'], d['ref'], d['corr'], d['fail']
+            job.gain = job.offset = job.r2 = job.norm = None
+            job.n_bands, job.height, job.width, job.stride, job.band_stride, job.seg_rows = B, n, n, n, n * n, 128
+            job.stream = t % ctx.n_streams
+            ctx.fit_apply_dev(desc, job)
+            d['job'] = job
+        ctx.sync()
+        rng = np.random.default_rng(13)
+        tot = dif = 0
+        for t, d in enumerate(tiles):
+            assert ctx.inpaint_dev(desc, d['job']) == 0
+            if t % 8 and t != T - 1:
+                continue
+            ctx.stream_sync(d['job'].stream)
+            b = (t // 8) % B if t != T - 1 else B - 1
+            arr = {name: np.empty((n, n), np.float32) for name in ('src', 'ref', 'corr')}
+            for name in arr:
+                ctx.d2h(arr[name], d[name] + plane * b)
+            wins = [(n - 400, n - 800), (int(rng.integers(2, n - 402)), int(rng.integers(2, n - 802)))]
+            c, e = _check_windows(oracle, 'gain-offset', 5, 0.25, None, arr['src'], arr['ref'], arr['corr'], wins, 400, 800)
+            tot, dif = tot + c, dif + e
+        assert dif <= max(2, int(1e-5 * tot)), (dif, tot)
+        print(f'config 4, all 64 tiles: {tot} px checked in 9 tiles, {dif} bitwise mismatches')
+    finally:
+        for d in tiles:
+            for name in ('src', 'ref', 'corr', 'fail'):
+                ctx.dev_free(d[name])
