@@ -1754,3 +1754,29 @@ def test_host_calls_and_device_jobs_on_one_stream_are_kept_apart():
             c1.dev_free(p)
     finally:
         c1.close()
+
+
+@pytest.mark.parametrize('find_r2', [False, True])
+def test_gain_blk_offset_with_degenerate_block_statistics(ctx, find_r2):
+    """ the fused gain-blk-offset build without R2 normalises the window SUM (n0 * sum(s) + n1 * N) instead of
+    every pixel.  With degenerate block statistics -- a constant source block: std(src) = 0, so norm = (inf | nan, nan) -- the
+    reference's normalised source is NaN everywhere, every pixel is masked and every output is NaN; the window-sum form must
+    give the same (and the per-pixel form used with R2 as well). """
+    import warnings
+    rng = np.random.default_rng(3)
+    src = np.full((96, 300), 0.5, np.float32)   # exactly representable: numpy's float32 mean and std are exact (0.5, 0)
+    ref = (0.5 + rng.random((96, 300))).astype(np.float32)
+    cfg = dict(model='gain-blk-offset', kernel_shape=(5, 5), find_r2=find_r2, r2_inpaint_thresh=None, src_nodata=np.nan, ref_nodata=np.nan)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        norm = onp.fit_block_norm(src, np.nan, ref, np.nan)
+        assert not np.isfinite(norm).all()
+        exp, _ = onp.fit('gain-blk-offset', src, np.nan, ref, np.nan, (5, 5), find_r2, None, norm_model=norm)
+        exp_c = onp.apply(src, exp)
+    got_p, got_c, _, _ = _fit_via_abi(ctx, cfg, src, ref, norm_in=norm)
+    assert np.isnan(exp).all() and np.isnan(exp_c).all()
+    assert np.isnan(got_p).all() and np.isnan(got_c).all()
+    # ... and the statistics the GPU computes itself for that block are the same non-finite pair
+    desc = _hk.make_desc('gain-blk-offset', (5, 5), find_r2, None, np.nan, np.nan)
+    gn = ctx.block_norm(desc, src, ref)
+    assert (np.isnan(gn) == np.isnan(norm)).all() and (gn[~np.isnan(norm)] == norm[~np.isnan(norm)]).all()
