@@ -128,8 +128,11 @@ __device__ __forceinline__ int isqrt_floor(int n) {
 // word (column distance << 8 | row distance), a candidate costs ~8 instructions.  (A second copy of the loop for wave-rows
 // away from the raster's edges, with scalar column distances and unclamped look-ups, cost 18 more VGPRs than it saved
 // instructions.)
+#ifndef HK_FILL_WAVES_FULL
+#define HK_FILL_WAVES_FULL 8
+#endif
 template <bool PACK>
-__global__ void __launch_bounds__(256, 8) inpaint_fill_kernel(const float* __restrict__ offset, const unsigned char* __restrict__ flag,
+__global__ void __launch_bounds__(256, PACK ? 8 : HK_FILL_WAVES_FULL) inpaint_fill_kernel(const float* __restrict__ offset, const unsigned char* __restrict__ flag,
                                                            long long stride, int height, int width, int max_dist,
                                                            const unsigned short* __restrict__ tb,
                                                            const unsigned* __restrict__ tie,
@@ -154,6 +157,9 @@ __global__ void __launch_bounds__(256, 8) inpaint_fill_kernel(const float* __res
     }
     bool active = target;
     int x = x_own;
+    // (without the compaction x is the same in every row of the loop: keep the compiler from hoisting the per-step edge
+    // distances and conditions out of it -- 89 VGPRs instead of 52, i.e. spills at 8 waves per SIMD)
+    asm volatile("" : "+v"(x));
     if constexpr (PACK) {
         const unsigned long long bal = __ballot(target);
         if (lane == 0) wcnt[wv] = (unsigned)__popcll(bal);
@@ -186,47 +192,91 @@ __global__ void __launch_bounds__(256, 8) inpaint_fill_kernel(const float* __res
             qs[q] = better ? (dx_hi | dist) : qs[q];
         };
         // Steps are taken in groups that end where GDAL re-derives its search bound (after steps 4, 8, 12, ...): the
-        // bound is constant inside a group, so all of the group's table look-ups (2 per step) are issued before the
-        // checks, which then run in the original order (ascending step; left quadrants before right ones).
-        // The look-ups of the NEXT group are issued before the checks of the current one (their latency hides behind the
-        // checks; a group that turns out not to be needed costs two cached loads per step and nothing else).
+        // bound is constant inside a group, so all of the group's table look-ups are issued before the checks, which then
+        // run in the original order (ascending step; left quadrants before right ones).  The look-ups of the NEXT group are
+        // issued before the checks of the current one (their latency hides behind the checks; a group that turns out not to be
+        // needed costs two cached loads and nothing else).
+        // Round 3: a group's table words are consecutive 16-bit entries of one row, so they are fetched by two wide loads
+        // (2-byte aligned; steps 0..4: the ten entries around x as 16 + 4 bytes; later groups: 8 bytes per side) instead of
+        // ten / eight 2-byte gathers -- the search was bound by the look-ups' issue and latency, not by its arithmetic.
+        // Lanes whose group reaches past the raster's edge columns assemble the same words entry by entry with GDAL's clamp
+        // (it re-checks the edge column).
         {
-            constexpr int G = 5;  // longest group (steps 0..4)
-            unsigned lw[G], rw[G], nlw[G], nrw[G];  // (down << 8) | up distances of the left / right column of each step
-            auto fetch = [&](int first_step, unsigned (&a)[G], unsigned (&c)[G]) {
+            struct __attribute__((packed, aligned(2))) W5 { unsigned w[5]; };
+            struct __attribute__((packed, aligned(2))) W2 { unsigned w[2]; };
+            // entry j (0-based) of a packed run of 16-bit table words: (down << 8) | up
+            auto up = [](const unsigned* d, int j) { return (d[j >> 1] >> ((j & 1) * 16)) & 0xffu; };
+            auto dn = [](const unsigned* d, int j) { return (d[j >> 1] >> ((j & 1) * 16 + 8)) & 0xffu; };
+            unsigned d0[5];                  // entries 0..9 <-> columns x - 4 .. x + 5 (steps 0..4: left step k = entry 4 - k, right = 4 + k)
+            if (x - 4 >= 0 && x + 5 < width) {
+                const W5 v = *reinterpret_cast<const W5*>(trow + x - 4);
 #pragma unroll
-                for (int k = 0; k < G; ++k) {
-                    const int step = first_step + k;
-                    // columns past the raster are clamped into it (GDAL re-checks the edge column)
-                    a[k] = trow[max(0, x - step)], c[k] = trow[min(width - 1, x + step)];
+                for (int j = 0; j < 5; ++j) d0[j] = v.w[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 5; ++j) d0[j] = 0u;
+#pragma unroll
+                for (int j = 0; j < 9; ++j) {
+                    const int col = j < 4 ? max(0, x - 4 + j) : min(width - 1, x - 4 + j);
+                    d0[j >> 1] |= (unsigned)trow[col] << ((j & 1) * 16);
+                }
+            }
+            // later groups (steps first .. first + 3): left entries 0..3 <-> columns x - first - 3 .. x - first (step first + k = entry
+            // 3 - k), right entries 0..3 <-> columns x + first .. x + first + 3 (step first + k = entry k)
+            auto fetch4 = [&](int first, unsigned (&l)[2], unsigned (&r)[2]) {
+                if (x - first - 3 >= 0 && x + first + 3 < width) {
+                    const W2 lv = *reinterpret_cast<const W2*>(trow + x - first - 3);
+                    const W2 rv = *reinterpret_cast<const W2*>(trow + x + first);
+                    l[0] = lv.w[0], l[1] = lv.w[1], r[0] = rv.w[0], r[1] = rv.w[1];
+                } else {
+                    l[0] = l[1] = r[0] = r[1] = 0u;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        l[j >> 1] |= (unsigned)trow[max(0, x - first - 3 + j)] << ((j & 1) * 16);
+                        r[j >> 1] |= (unsigned)trow[min(width - 1, x + first + j)] << ((j & 1) * 16);
+                    }
                 }
             };
+            unsigned nl[2], nr[2];
+            fetch4(5, nl, nr);
             int this_max = max_dist;
-            int first = 0;
-            fetch(0, lw, rw);  // (issuing these beside the flag load instead of behind it was measured: no difference)
-            while (first <= this_max) {
-                const int last = min(this_max, first == 0 ? 4 : first + 3);
-                fetch(last + 1, nlw, nrw);
+            {   // steps 0 .. 4
+                const int last = min(this_max, 4);
 #pragma unroll
-                for (int k = 0; k < G; ++k) {
-                    const int step = first + k;
-                    if (step <= last) {
-                        // column distances (clamped columns: the distance to the edge column)
-                        const int dl = min(step, x), dr = min(step, width - 1 - x);
+                for (int k = 0; k < 5; ++k) {
+                    if (k <= last) {
+                        const int dl = min(k, x), dr = min(k, width - 1 - x);  // clamped columns: the distance to the edge column
                         const int dl2 = dl * dl, dr2 = dr * dr;
-                        consider(0, lw[k] & 0xffu, dl2, (unsigned)dl << 8);  // top left
-                        consider(1, lw[k] >> 8, dl2, (unsigned)dl << 8);     // bottom left
-                        if (step != 0) {
-                            consider(2, rw[k] & 0xffu, dr2, (unsigned)dr << 8);  // top right
-                            consider(3, rw[k] >> 8, dr2, (unsigned)dr << 8);     // bottom right
+                        consider(0, up(d0, 4 - k), dl2, (unsigned)dl << 8);  // top left
+                        consider(1, dn(d0, 4 - k), dl2, (unsigned)dl << 8);  // bottom left
+                        if (k != 0) {
+                            consider(2, up(d0, 4 + k), dr2, (unsigned)dr << 8);  // top right
+                            consider(3, dn(d0, 4 + k), dr2, (unsigned)dr << 8);  // bottom right
                         }
                     }
                 }
                 // no farther column can beat every quadrant's current distance: floor(max qd) = floor(sqrt(max qd2))
-                if (last >= 4 && (last & 3) == 0) this_max = isqrt_floor(max(max(qd2[0], qd2[1]), max(qd2[2], qd2[3])));
-                first = last + 1;
+                if (last == 4) this_max = isqrt_floor(max(max(qd2[0], qd2[1]), max(qd2[2], qd2[3])));
+            }
+            int first = 5;
+            while (first <= this_max) {
+                const int last = min(this_max, first + 3);
+                const unsigned cl[2] = {nl[0], nl[1]}, cr[2] = {nr[0], nr[1]};
+                fetch4(first + 4, nl, nr);
 #pragma unroll
-                for (int k = 0; k < G; ++k) lw[k] = nlw[k], rw[k] = nrw[k];
+                for (int k = 0; k < 4; ++k) {
+                    const int step = first + k;
+                    if (step <= last) {
+                        const int dl = min(step, x), dr = min(step, width - 1 - x);
+                        const int dl2 = dl * dl, dr2 = dr * dr;
+                        consider(0, up(cl, 3 - k), dl2, (unsigned)dl << 8);
+                        consider(1, dn(cl, 3 - k), dl2, (unsigned)dl << 8);
+                        consider(2, up(cr, k), dr2, (unsigned)dr << 8);
+                        consider(3, dn(cr, k), dr2, (unsigned)dr << 8);
+                    }
+                }
+                if ((last & 3) == 0) this_max = isqrt_floor(max(max(qd2[0], qd2[1]), max(qd2[2], qd2[3])));
+                first = last + 1;
             }
         }
         double wsum = 0.0, vsum = 0.0;
