@@ -1780,3 +1780,21 @@ def test_gain_blk_offset_with_degenerate_block_statistics(ctx, find_r2):
     desc = _hk.make_desc('gain-blk-offset', (5, 5), find_r2, None, np.nan, np.nan)
     gn = ctx.block_norm(desc, src, ref)
     assert (np.isnan(gn) == np.isnan(norm)).all() and (gn[~np.isnan(norm)] == norm[~np.isnan(norm)]).all()
+
+
+@pytest.mark.parametrize('shape', [(1, 1), (3, 7), (5, 300), (16, 40), (11, 11), (40, 1), (130, 259), (257, 65)])
+def test_split_ring_on_rasters_smaller_than_the_kernel_or_the_strip(ctx, shape):
+    """ ring mode 3 on degenerate shapes: rasters smaller than the kernel, narrower than a lane quad, one wave segment + 1 row,
+    one strip + 1 column -- gain 11x11 and gain-blk-offset 9x9 (the kernels that use it by default) against the oracle. """
+    import warnings
+    src, ref = onp.synth_pair(shape[0], shape[1], seed=shape[0] * 1000 + shape[1], nodata_variant='frame+holes' if min(shape) > 8 else 'none')
+    nodata = np.nan
+    for model, k in (('gain', (11, 11)), ('gain-blk-offset', (9, 9)), ('gain', (15, 5))):
+        cfg = dict(model=model, kernel_shape=k, find_r2=False, r2_inpaint_thresh=None, src_nodata=nodata, ref_nodata=nodata)
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            norm_in = onp.fit_block_norm(src, nodata, ref, nodata) if model == 'gain-blk-offset' else None
+            exp, _ = onp.fit(model, src, nodata, ref, nodata, k, False, None, norm_model=norm_in)
+        got = _fit_via_abi(ctx, cfg, src, ref, norm_in=norm_in)
+        assert_close_ulp(got[0], exp, f'{model} {k} on {shape}')
+        assert_close_ulp(got[1], onp.apply(src, exp), f'{model} {k} on {shape}: corrected')
