@@ -58,7 +58,7 @@ def parse_args():
     p.add_argument('--model', default=None, choices=['gain', 'gain-blk-offset', 'gain-offset'])
     p.add_argument('--kernel', type=int, default=None)
     p.add_argument('--seg-rows', type=int, default=0)
-    p.add_argument('--nodata', type=int, default=0, help='0: no nodata, 1: NaN frame + 0.1%% holes, 2: NaN frame only, 3 / 4: no nodata, noisy reference (35 %% / 85 %% of the pixels fail the r2 mask)')
+    p.add_argument('--nodata', type=int, default=0, help='0: no nodata, 1: NaN frame + 0.1%% holes, 2: NaN frame only, 3 / 4: no nodata, noisy reference (35 %% / 85 %% of the pixels fail the r2 mask), 5: low-entropy data (64 source levels, exactly affine reference; the same instruction stream at a lower energy per launch)')
     p.add_argument('--no-thresh', action='store_true', help='gain-offset without r2_inpaint_thresh (no R2 work)')
     p.add_argument('--params', action='store_true', help='also materialise the gain / offset / R2 planes in the fused launch (find_r2=True; 24 B per pixel*band of HBM traffic, reported against the same 12 algorithmic bytes)')
     p.add_argument('--no-cpu-baseline', action='store_true')

@@ -1472,6 +1472,13 @@ __global__ void __launch_bounds__(256) synth_kernel(float* __restrict__ src, flo
         // 3: noisy reference, R2 around the threshold (35 % of the pixels fail 0.25); 4: very noisy (85 % fail, like real pairs)
         float r = g * s + o + (nodata_variant == 3 ? 0.5f : (nodata_variant == 4 ? 1.5f : 0.01f)) * z;
         float sv = s;
+        if (nodata_variant == 5) {
+            // measurement aid: LOW-ENTROPY data -- 64 source levels, the reference an exact affine image of them: few bits toggle
+            // on the wires and in the ALUs.  The instruction stream is the headline's, the energy per launch is not (DESIGN.md
+            // section 5.3).
+            sv = 0.25f + (float)(h0 & 63ull) * 0.0078125f;
+            r = 1.25f * sv + 0.125f;
+        }
         if (nodata_variant == 1 || nodata_variant == 2) {  // 1: NaN frame + 0.1 % holes, 2: NaN frame only
             const bool frame = x < 3 || y < 3 || x >= width - 3 || y >= height - 3;
             const bool holes = nodata_variant == 1;
