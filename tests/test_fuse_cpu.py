@@ -177,3 +177,46 @@ def test_window_helpers():
     assert fuse.expand_window_to_grid(Window(1.2, 3.7, 4.1, 2.0)) == Window(1, 3, 5, 3)
     assert fuse.expand_window_to_grid(Window(-0.5, 2.0, 3.0, 3.0), (1, 2)) == Window(-3, 1, 8, 5)
     assert fuse.round_window_to_grid(Window(1.5, 2.5, 3.0, 3.0)) == Window(2, 2, 2, 4)   # half to even, like np.round
+
+
+def test_communicator_id_travels_through_a_file(tmp_path, monkeypatch):
+    """ dist.init_comm without a torch process group: rank 0 makes the RCCL communicator id (hk_comm_unique_id) and writes it
+    atomically, the other ranks wait for the file; every rank then joins with the same 128 bytes (Context.comm_init).  The
+    library calls are replaced by recorders here (no GPU); the GPU side is tests/test_gpu_split_norm.py. """
+    import threading
+    from homonim_amd import _hk, dist
+    uid = bytes(range(128))
+    made = []
+    monkeypatch.setattr(_hk, 'comm_unique_id', lambda: made.append(1) or uid)
+    monkeypatch.setattr(dist, '_state', dict(dist._state, initialised=False))
+    joined = {}
+
+    class FakeCtx:
+        def __init__(self, rank):
+            self.rank = rank
+
+        def comm_init(self, unique_id, rank, world):
+            joined[rank] = (unique_id, world)
+
+    path = str(tmp_path / 'comm_id.bin')
+    local = threading.local()
+    monkeypatch.setattr(dist, 'env_ranks', lambda: (local.rank, 3, local.rank))
+
+    def run(rank):
+        local.rank = rank
+        assert dist.init_comm(FakeCtx(rank), path) == (rank, 3)
+
+    waiters = [threading.Thread(target=run, args=(r,)) for r in (1, 2)]
+    [t.start() for t in waiters]          # they poll for the file first
+    run(0)
+    [t.join(timeout=30) for t in waiters]
+    assert made == [1]                     # only rank 0 asked the library for an id
+    assert joined == {0: (uid, 3), 1: (uid, 3), 2: (uid, 3)}
+    # a world of one needs neither a group nor a file
+    monkeypatch.setattr(dist, 'env_ranks', lambda: (0, 1, 0))
+    assert dist.init_comm(FakeCtx(0)) == (0, 1) and joined[0] == (uid, 1)
+    # several ranks without either: a clear error, before any collective call
+    monkeypatch.setattr(dist, 'env_ranks', lambda: (1, 2, 1))
+    monkeypatch.delenv('HOMONIM_AMD_COMM_FILE', raising=False)
+    with pytest.raises(RuntimeError):
+        dist.init_comm(FakeCtx(1))
