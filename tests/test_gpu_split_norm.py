@@ -126,9 +126,20 @@ def _run_comm_workers(tmp_path, world, variant='frame+holes'):
         env.pop('HOMONIM_AMD_COMM_FILE', None)
         procs.append(subprocess.Popen([sys.executable, os.path.join(REPO, 'tests', '_split_norm_comm_worker.py'), str(tmp_path), variant],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    results = []
     for p in procs:
-        out, err = p.communicate(timeout=600)
-        assert p.returncode == 0, err[-3000:]
+        try:
+            out, err = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        results.append((p.returncode, err))
+    if world > 1 and any(rc == 77 for rc, _ in results):
+        # the communicator could not be formed on this box (RCCL bootstrap / IPC of the environment): nothing was computed
+        pytest.skip('RCCL communicator over several GPUs could not be initialised here: ' + results[0][1][-300:])
+    for rc, err in results:
+        assert rc == 0, err[-3000:]
     return [np.load(tmp_path / f'norm_{r}.npy') for r in range(world)]
 
 
