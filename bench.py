@@ -402,7 +402,7 @@ def run_resident(args, ctx, dist, rank, world):
         counts = fail_host[i % 2].copy()
         job.fail_count = fail_dev[i % 2]  # a band the certificate-only build gave up on is re-counted here
         job.scratch = scratch[i % 2]
-        return ctx.inpaint_dev_counts(desc, job, counts) if counts.any() else 0
+        return ctx.inpaint_dev_counts(desc, job, counts) if ctx.counts_pending(counts) else 0
 
     def run(n_steps, events=None):
         n_fail = 0
@@ -691,7 +691,7 @@ def run_tiles(args, ctx, dist, rank, world):
             for d, job, counts, ev in tiles:
                 ctx.event_sync(ev)
                 c = counts.copy()
-                if c.any():
+                if ctx.counts_pending(c):
                     n_fail += ctx.inpaint_dev_counts(desc, job, c)
         return n_fail
 

@@ -77,6 +77,7 @@ SIGNATURES = {
     'hk_comm_info': (C.c_int, [C.c_void_p, _P(C.c_int32), _P(C.c_int32)]),
     'hk_comm_allreduce_f64_dev': (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32]),
     'hk_block_norm_split_comm_dev': (C.c_int, [C.c_void_p, _P(FitDesc), _P(DevJob), C.c_void_p]),
+    'hk_counts_pending': (C.c_int, [_P(C.c_uint64), C.c_int32]),
     'hk_last_error': (C.c_char_p, []),
     'hk_device_count': (C.c_int, [_P(C.c_int)]),
     'hk_ctx_create': (C.c_int, [C.c_int, C.c_int, _P(C.c_void_p)]),
@@ -570,6 +571,12 @@ class Context:
 
     def fit_apply_dev(self, desc: FitDesc, job: DevJob):
         _check(self._lib.hk_fit_apply_dev(self._h, C.byref(desc), C.byref(job)))
+
+    def counts_pending(self, counts: np.ndarray) -> bool:
+        """ Do the counters of a launch (``fail_counts_async``) call for its second half, ``inpaint_dev_counts``?  (failing
+        pixels in some band, or a band the lighter kernel build sent back: hk_counts_pending) """
+        c = np.ascontiguousarray(counts, dtype=np.uint64)
+        return bool(self._lib.hk_counts_pending(c.ctypes.data_as(_P(C.c_uint64)), int(c.size)))
 
     def fail_counts_async(self, job: DevJob, host_counts: np.ndarray, ready_event: int):
         """ Queue the copy of the job's failure counters into a PINNED uint64 array, their clearing and `ready_event`. """

@@ -1235,6 +1235,13 @@ int hk_fail_counts_async(hk_ctx* ctx, const hk_dev_job* job, uint64_t* host_coun
     return HK_OK;
 }
 
+int hk_counts_pending(const uint64_t* counts, int32_t n_bands) {
+    if (!counts) return 0;
+    for (int32_t b = 0; b < n_bands; ++b)
+        if (counts[b]) return 1;  // failing pixels, or HK_COUNT_RETRY
+    return 0;
+}
+
 int hk_event_sync(hk_ctx* ctx, hk_event* ev) {
     if (!ctx || !ev) return fail(HK_ERR_ARG, "NULL argument");
     HK_ENTER(ctx);

@@ -172,3 +172,17 @@ def test_raster_array_from_profile():
     from homonim_amd.errors import ImageProfileError
     with pytest.raises(ImageProfileError):
         RasterArray.from_profile(None, dict(crs=CRS(), transform=Affine.identity()))
+
+
+def test_counts_pending_is_host_only(lib):
+    """ hk_counts_pending: callers of the two-halves r2-mask protocol need not interpret the raw counters (the retry bit of the
+    certificate-only build included) -- and it runs without a device. """
+    import ctypes as C
+    u64p = C.POINTER(C.c_uint64)
+    a = np.zeros(5, np.uint64)
+    assert lib.hk_counts_pending(a.ctypes.data_as(u64p), 5) == 0
+    a[3] = 17
+    assert lib.hk_counts_pending(a.ctypes.data_as(u64p), 5) == 1 and lib.hk_counts_pending(a.ctypes.data_as(u64p), 3) == 0
+    a[3], a[0] = 0, 1 << 63          # HK_COUNT_RETRY: the band must be run again with the complete build
+    assert lib.hk_counts_pending(a.ctypes.data_as(u64p), 5) == 1
+    assert lib.hk_counts_pending(None, 5) == 0
