@@ -275,6 +275,11 @@ float r2_fail_scale(float thresh) {
     return kf;
 }
 
+static int env_int_early(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
 void fill_args(hk::FitArgs& a, const hk_fit_desc* d, int xcd_remap) {
     a.rh = d->kh / 2;
     a.rw = d->kw / 2;
@@ -329,6 +334,17 @@ void fill_args(hk::FitArgs& a, const hk_fit_desc* d, int xcd_remap) {
         if (m == 0) a.use_ring = 0;
     }
     a.xcd_remap = xcd_remap;
+    // Fewer resident waves for the dense `gain` kernel on large rasters: at 8 KB of LDS per wave 20 waves per CU stream their rows
+    // at once and the HBM answers with ~5.0 TB/s; 4 KB of unused LDS per wave leave 12 (three lock-step workgroups per CU) and it
+    // answers with 5.4: gain 5x5 at 16384^2 x 4 2.58 -> 2.37 ms, configs[1] 0.631 -> 0.605 ms, 3x3 -2.5 % (profiles/r03_lds_pad.txt).
+    // Not for the general (nodata) build -- its registers keep it at that occupancy already --, not for 7x7 (12 KB ring), not for
+    // launches of less than ~128 M pixels (a 4-band 4096^2 tile: +3 %); the VALU-bound builds want every wave (headline +8 % at 16
+    // -> 14 waves).  -1 = decided by fill_grid() from the job's size.
+    a.lds_pad = 0;
+    if (d->model == HK_MODEL_GAIN && !needs_r2(d) && d->kh <= 5 && d->kw <= 7 && d->src_nodata_mode == HK_NODATA_NONE &&
+        d->ref_nodata_mode == HK_NODATA_NONE && !a.force_general)
+        a.lds_pad = -1;
+    if (getenv("HK_LDS_PAD")) a.lds_pad = env_int_early("HK_LDS_PAD", 0);
     a.out_y0 = 0, a.out_y1 = a.height, a.out_x0 = 0, a.out_x1 = a.width;  // store window: the whole job (callers narrow it)
 }
 
@@ -369,6 +385,7 @@ void fill_grid(hk::FitArgs& a, int seg_rows) {
         }
     }
     a.total_units = a.n_strips * a.n_segs * a.n_bands;
+    if (a.lds_pad < 0) a.lds_pad = ((long long)a.height * a.width * a.n_bands >= (128ll << 20)) ? 4096 : 0;
 }
 
 // kernel_model.py:364-371 for ONE band whose first pass counted failing pixels: in-paint the offsets of the failing

@@ -54,6 +54,7 @@ struct FitArgs {
     int seg_rows_pref;      // > 0: the build's preferred uniform segment height (hk_api.hip fill_args / fill_grid), 0: the default policy
     int use_ring;           // ring mode of fit_apply_kernel: 1 full LDS ring, 2 centre ring + re-loaded leaving row, 0 re-load both
     int xcd_remap;          // G > 0: blockIdx -> unit remap handing each XCD runs of G consecutive units (0: round-robin)
+    int lds_pad;            // unused dynamic LDS bytes per wave: fewer resident waves per CU (hk_api.hip fill_args)
     // store window: only rows [out_y0, out_y1) x columns [out_x0, out_x1) of the job are written / counted (the halo crop of
     // homonim/raster_array.py:478-491 when a block of a larger device raster is processed in place); 0,height,0,width = all.
     // out_x0 and out_x1 are multiples of PX (or out_x1 == width): whole quads are stored.

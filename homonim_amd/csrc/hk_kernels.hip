@@ -1297,8 +1297,9 @@ static hipError_t launch_wpb(const FitArgs& a, size_t lds, hipStream_t stream) {
         const int g = a.xcd_remap / WPB > 0 ? a.xcd_remap / WPB : 1;
         grid = (grid + 8 * g - 1) / (8 * g) * (8 * g);
     }
-    hipLaunchKernelGGL((fit_apply_kernel<MODEL, R2, RW, DENSE, RING, CERT_ONLY, WPB>), dim3(grid), dim3(WAVE * WPB), lds * WPB,
-                       stream, a);
+    // a.lds_pad: extra dynamic LDS per wave that nothing uses -- it only lowers the number of resident waves per CU
+    hipLaunchKernelGGL((fit_apply_kernel<MODEL, R2, RW, DENSE, RING, CERT_ONLY, WPB>), dim3(grid), dim3(WAVE * WPB),
+                       (lds + (size_t)a.lds_pad) * WPB, stream, a);
     return hipGetLastError();
 }
 

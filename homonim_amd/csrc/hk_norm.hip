@@ -35,6 +35,9 @@ constexpr int NORM_THREADS = 256;
 constexpr int L1_BITS = 11, L2_BITS = 11, L3_BITS = 10;
 constexpr int L1_BINS = 1 << L1_BITS, L2_BINS = 1 << L2_BITS, L3_BINS = 1 << L3_BITS;
 constexpr int SAMPLE_N = 4096;     // sample size per band
+#ifndef HK_NORM_LDS_PAD_DEFAULT
+#define HK_NORM_LDS_PAD_DEFAULT 0
+#endif
 #ifndef HK_PASS_WAVES
 #define HK_PASS_WAVES 2048
 #endif
@@ -243,6 +246,13 @@ __global__ void __launch_bounds__(SAMPLE_THREADS) norm_sample_kernel(const NormA
         }
         __syncthreads();
     }
+}
+
+// Unused dynamic LDS per wave of the streaming pass: it only lowers the number of resident waves per CU (8 KB of queues per wave
+// = 20 waves per CU otherwise).  HK_NORM_LDS_PAD overrides (measurement).
+static size_t norm_stream_lds_pad() {
+    static const size_t pad = [] { const char* e = getenv("HK_NORM_LDS_PAD"); return e ? (size_t)atoi(e) : (size_t)HK_NORM_LDS_PAD_DEFAULT; }();
+    return pad;
 }
 
 // Waves per band of the streaming pass: a function of the block SHAPE only (never of the batch size), so a block's
@@ -701,9 +711,9 @@ hipError_t launch_block_norm_split(const NormArgs& a, void* workspace, double* x
             float* mid = reinterpret_cast<float*>(static_cast<char*>(workspace) + align256(sizeof(NormWS) * (size_t)a.n_bands));
             const size_t cap_al = align256(mid_capacity((long long)a.height * a.width) * sizeof(float)) / sizeof(float);
             if (a.src_nd_mode == 0 && a.ref_nd_mode == 0)
-                hipLaunchKernelGGL(norm_stream_kernel<true>, gstream, dim3(WAVE), 0, stream, a, ws, mid, cap_al);
+                hipLaunchKernelGGL(norm_stream_kernel<true>, gstream, dim3(WAVE), norm_stream_lds_pad(), stream, a, ws, mid, cap_al);
             else
-                hipLaunchKernelGGL(norm_stream_kernel<false>, gstream, dim3(WAVE), 0, stream, a, ws, mid, cap_al);
+                hipLaunchKernelGGL(norm_stream_kernel<false>, gstream, dim3(WAVE), norm_stream_lds_pad(), stream, a, ws, mid, cap_al);
         }
         hipLaunchKernelGGL(split_put_moments_kernel, bands, dim3(WAVE), 0, stream, ws, xchg);
         break;
@@ -746,9 +756,9 @@ hipError_t launch_block_norm(const NormArgs& a, void* workspace, double* norm_ou
     hipLaunchKernelGGL(norm_sample_kernel, bands, dim3(SAMPLE_THREADS), 0, stream, a, ws);
     const dim3 gstream(pass_waves(a.height, a.width), a.n_bands);
     if (a.src_nd_mode == 0 && a.ref_nd_mode == 0)
-        hipLaunchKernelGGL(norm_stream_kernel<true>, gstream, dim3(WAVE), 0, stream, a, ws, mid, cap_al);
+        hipLaunchKernelGGL(norm_stream_kernel<true>, gstream, dim3(WAVE), norm_stream_lds_pad(), stream, a, ws, mid, cap_al);
     else
-        hipLaunchKernelGGL(norm_stream_kernel<false>, gstream, dim3(WAVE), 0, stream, a, ws, mid, cap_al);
+        hipLaunchKernelGGL(norm_stream_kernel<false>, gstream, dim3(WAVE), norm_stream_lds_pad(), stream, a, ws, mid, cap_al);
     hipLaunchKernelGGL(norm_stats_kernel, bands, dim3(STATS_THREADS), 0, stream, ws, norm_out, cap_al);
     const dim3 gmid(MID_BLOCKS, a.n_bands * 2), gfull(FB_BLOCKS, a.n_bands, 2);
     hipLaunchKernelGGL(norm_mid_hist_kernel<0>, gmid, block, 0, stream, ws, mid, cap_al);
