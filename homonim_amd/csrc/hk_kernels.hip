@@ -21,6 +21,13 @@
 
 namespace hk {
 
+// Measurement hook (tools/README.md): timing builds with one ingredient of the fused kernel taken out --
+// WRONG results, never shipped.  1: the leaving row is re-loaded from the entering row's address (no far re-load),
+// 2: gain-blk-offset without its float64 quotient, 4: no horizontal sums, 8: no corrected-plane stores.
+#ifndef HK_ABLATE
+#define HK_ABLATE 0
+#endif
+
 // ---------------------------------------------------------------------------------------------------------------------
 // cross-lane primitives
 // bound_ctrl:1 makes lanes without a source read 0, so no `old` operand has to be materialised per shift.
@@ -263,7 +270,10 @@ __device__ __forceinline__ void hsum_rt(const T (&V)[PX], T (&H)[PX], int rw, in
 
 template <int RW, typename T, bool XCH = false>
 __device__ __forceinline__ void hsum_any(const T (&V)[PX], T (&H)[PX], int rw, int ol, int lane, char* xch = nullptr) {
-    if constexpr (RW >= 0)
+    if constexpr ((HK_ABLATE & 4) != 0) {
+#pragma unroll
+        for (int i = 0; i < PX; ++i) H[i] = V[i];
+    } else if constexpr (RW >= 0)
         hsum<RW, T, XCH>(V, H, lane, xch);
     else
         hsum_rt<T>(V, H, rw, ol, lane);
@@ -727,7 +737,10 @@ fit_apply_kernel(const FitArgs a) {
 #ifndef HK_PF_GAIN
 #define HK_PF_GAIN 2  // 4 and 6 rows measured the same (2.91-2.97 ms): the wait is on the LDS ring, not on HBM latency
 #endif
-    constexpr int PFD = (MODEL == 0 && !R2) ? HK_PF_GAIN : 1;
+#ifndef HK_PF_BLKA
+#define HK_PF_BLKA 1  // gain-blk-offset: 2 / 3 / 4 rows in flight measured the same at 15x15 (profiles/r03_blk15_ablation.txt)
+#endif
+    constexpr int PFD = (MODEL == 0 && !R2) ? HK_PF_GAIN : ((MODEL == 1 && !R2) ? HK_PF_BLKA : 1);
     RowRaw q0 = load_row(sp, rp, a.stride, t_first, H, xq);
     [[maybe_unused]] RowRaw qq[PFD > 1 ? PFD - 1 : 1];
     if constexpr (PFD > 1) {
@@ -796,7 +809,7 @@ fit_apply_kernel(const FitArgs a) {
         if constexpr (PF_OLD) {
             // the leaving row is fetched one iteration ahead (it comes from L2 / the Infinity Cache): qo_next holds row t_old
             qo = qo_next;
-            qo_next = load_row<HK_NT_LEAVE>(sp, rp, a.stride, t_old + 1, H, xq);
+            qo_next = load_row<HK_NT_LEAVE>(sp, rp, a.stride, (HK_ABLATE & 1) ? t + 1 : t_old + 1, H, xq);
         } else if constexpr (!ring && !sring) {
             qo = load_row<HK_NT_LEAVE>(sp, rp, a.stride, t_old, H, xq);
         }
@@ -1081,7 +1094,7 @@ fit_apply_kernel(const FitArgs a) {
                         double ssum = HS[i];
                         if constexpr (BLKA)
                             ssum = __dadd_rn(__dmul_rn(n0, HS[i]), UN ? n1_n_full : __dmul_rn(n1, (double)Nf[i]));
-                        const double q = fast_quot((double)Rf[i], ssum);
+                        const double q = (HK_ABLATE & 2) ? __dadd_rn((double)Rf[i], ssum) : fast_quot((double)Rf[i], ssum);
                         gp[i] = (float)q;
                         if ((quot_guard(q) < 2u * HK_DIV_GUARD + 1u) | (quot_range(q) > 0x0fd00000u))
                             gp[i] = (float)__ddiv_rn((double)Rf[i], ssum);
@@ -1242,7 +1255,7 @@ fit_apply_kernel(const FitArgs a) {
                     // wave-uniform row offset (scalar) + this lane's 32-bit byte offset: no per-plane address registers
                     const long long row_off = out_base + (long long)y * a.stride;
                     auto at = [&](float* plane) { return reinterpret_cast<float4*>(reinterpret_cast<char*>(plane + row_off) + xbytes); };
-                    if (a.corr) store4_nt(at(a.corr), make_float4(c[0], c[1], c[2], c[3]));
+                    if (a.corr && !((HK_ABLATE & 8) && c[0] != 123.456f)) store4_nt(at(a.corr), make_float4(c[0], c[1], c[2], c[3]));
                     if (a.gain) store4_nt(at(a.gain), masked4(g));
                     if (a.offset) store4_nt(at(a.offset), masked4(o));
                     if (R2 && a.r2) store4_nt(at(a.r2), masked4(r2v));

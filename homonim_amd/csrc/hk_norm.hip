@@ -38,6 +38,9 @@ constexpr int SAMPLE_N = 4096;     // sample size per band
 #ifndef HK_NORM_LDS_PAD_DEFAULT
 #define HK_NORM_LDS_PAD_DEFAULT 0
 #endif
+#ifndef HK_NORM_ABLATE
+#define HK_NORM_ABLATE 0  // timing experiments only (wrong results): 1 no moments, 2 no compaction queues
+#endif
 #ifndef HK_PASS_WAVES
 #define HK_PASS_WAVES 2048
 #endif
@@ -351,6 +354,7 @@ __global__ void __launch_bounds__(WAVE) norm_stream_kernel(const NormArgs a, Nor
                 ++n;
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
+                    if constexpr ((HK_NORM_ABLATE & 1) != 0) { m1[q] += (double)(v[q] == 1.2345f); continue; }
                     const double d = (double)v[q] - shift[q];
                     m1[q] += d;
                     m2[q] = __fma_rn(d, d, m2[q]);
@@ -358,6 +362,7 @@ __global__ void __launch_bounds__(WAVE) norm_stream_kernel(const NormArgs a, Nor
             }
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
+                if constexpr ((HK_NORM_ABLATE & 2) != 0) { le_hi[q] += (m && v[q] <= hi[q]) ? 1u : 0u; continue; }
                 // two compares per value: "<= hi" is counted, "in [lo, hi]" moves the queue's end; below = le_hi - in
                 const bool le = m && v[q] <= hi[q], in = le && !(v[q] < lo[q]);
                 stage[q][cnt[q]][lane] = v[q];  // slot cnt <= QCAP - 1 by the test above
@@ -373,23 +378,26 @@ __global__ void __launch_bounds__(WAVE) norm_stream_kernel(const NormArgs a, Nor
         else process(s4, r4, x, std::false_type{});
     };
 
-    // three register sets in rotation (no copies between them: a copy would wait for the load it copies), so two chunks
-    // per raster are in flight while one is processed
-    float4 sA, rA, sB, rB, sC, rC;
-    int xA, xB, xC;
-    fetch(sA, rA, xA);
-    fetch(sB, rB, xB);
-    fetch(sC, rC, xC);
+    // HK_NORM_SETS register sets in rotation (no copies between them: a copy would wait for the load it copies), so
+    // HK_NORM_SETS - 1 chunks per raster are in flight while one is processed
+#ifndef HK_NORM_SETS
+#define HK_NORM_SETS 3
+#endif
+    constexpr int NS = HK_NORM_SETS;
+    float4 sQ[NS], rQ[NS];
+    int xQ[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) fetch(sQ[k], rQ[k], xQ[k]);
     for (long long it = wave; it < total;) {
-        process_any(sA, rA, xA);
-        fetch(sA, rA, xA);
-        if ((it += G) >= total) break;
-        process_any(sB, rB, xB);
-        fetch(sB, rB, xB);
-        if ((it += G) >= total) break;
-        process_any(sC, rC, xC);
-        fetch(sC, rC, xC);
-        it += G;
+        bool more = true;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            if (more) {
+                process_any(sQ[k], rQ[k], xQ[k]);
+                fetch(sQ[k], rQ[k], xQ[k]);
+                more = (it += G) < total;
+            }
+        }
     }
     flush(0);
     flush(1);
