@@ -41,7 +41,7 @@ ALGO_BYTES_PER_PX = 12   # read src 4 + read ref 4 + write corrected 4 (SURVEY.m
 CONFIGS = {
     1: dict(model='gain', kernel=5, size=8192, bands=4),
     2: dict(model='gain-offset', kernel=5, size=16384, bands=4),
-    3: dict(model='gain-blk-offset', kernel=15, size=16384, bands=8),
+    3: dict(model='gain-blk-offset', kernel=15, size=16384, bands=8, batches=4),
     4: dict(model='gain-offset', kernel=5, size=4096, bands=4, tiles=64),
 }
 
@@ -58,6 +58,9 @@ def parse_args():
     p.add_argument('--model', default=None, choices=['gain', 'gain-blk-offset', 'gain-offset'])
     p.add_argument('--kernel', type=int, default=None)
     p.add_argument('--seg-rows', type=int, default=0)
+    p.add_argument('--batches', type=int, default=None,
+                   help='configs 3 / 4: the jobs of a step in this many batched launches, one stream each (0 = one launch per job; '
+                        'default 4 for config 3: -4 %%, 0 for config 4: no difference, profiles/r03_batch.txt)')
     p.add_argument('--nodata', type=int, default=0, help='0: no nodata, 1: NaN frame + 0.1%% holes, 2: NaN frame only, 3 / 4: no nodata, noisy reference (35 %% / 85 %% of the pixels fail the r2 mask), 5: low-entropy data (64 source levels, exactly affine reference; the same instruction stream at a lower energy per launch)')
     p.add_argument('--no-thresh', action='store_true', help='gain-offset without r2_inpaint_thresh (no R2 work)')
     p.add_argument('--params', action='store_true', help='also materialise the gain / offset / R2 planes in the fused launch (find_r2=True; 24 B per pixel*band of HBM traffic, reported against the same 12 algorithmic bytes)')
@@ -73,6 +76,8 @@ def parse_args():
     for k, v in preset.items():
         if getattr(args, k, None) is None:
             setattr(args, k, v)
+    if args.batches is None:
+        args.batches = 0
     if args.steps is None:
         args.steps = {1: 100, 2: 50, 3: 10, 4: 5}[args.config]
     if args.warmup is None:
@@ -545,7 +550,26 @@ def run_blocks(args, ctx, dist, rank, world):
             job.out_rows, job.out_cols = win_out.height, win_out.width
             jobs.append(job)
 
+    # Batched launches (hk_block_norm_batch_dev / hk_fit_apply_batch_dev): the rank's jobs in `n_batches` groups, each group one
+    # launch per kernel stage on its own stream (0 = one launch per job, spread over the streams)
+    n_batches = min(int(os.environ.get('HK_BENCH_BATCHES', str(args.batches))), len(jobs))
+    batches = []
+    if n_batches > 0:
+        per = (len(jobs) + n_batches - 1) // n_batches
+        for g in range(n_batches):
+            group = jobs[g * per:(g + 1) * per]
+            for job in group:
+                job.stream = g % n_streams
+            if group:
+                batches.append((ctx.job_array(group), group[0].norm))
+
     def step():
+        if batches:
+            for arr, norm0 in batches:
+                if args.model == 'gain-blk-offset':
+                    ctx.block_norm_batch_dev(desc, arr, norm0)
+                ctx.fit_apply_batch_dev(desc, arr)
+            return
         for job in jobs:
             if args.model == 'gain-blk-offset':
                 ctx.block_norm_dev(desc, job, job.norm)
@@ -586,7 +610,9 @@ def run_blocks(args, ctx, dist, rank, world):
         value=total_px * args.steps / elapsed / 1e6, elapsed=elapsed, scaling='strong',
         workload=f'synthetic float32 {B}-band {H}x{W} resident in HBM, Model.{args.model}, kernel {k}x{k}, the reference\'s '
                  f'{len(all_blocks)} blocks (4096x4096 + {overlap[0]}-px halo, raster_pair.py:342-428) processed in place, '
-                 f'each with its own block statistics; the {B} bands of a block position share a launch (BASELINE.json configs[3])',
+                 f'each with its own block statistics; '
+                 + (f'the {len(jobs)} block positions of the rank in {len(batches)} batched launches per kernel stage' if batches else f'the {B} bands of a block position share a launch')
+                 + ' (BASELINE.json configs[3])',
         config=dict(bands=B, height=H, width=W, nodata_variant=args.nodata, blocks=len(all_blocks),
                     blocks_per_rank=B * len(mine),
                     parallelism=f'{world} rank(s) x 1 GPU, the {len(positions)} block positions dealt round-robin to the ranks, no collective'),
@@ -651,11 +677,14 @@ def run_tiles(args, ctx, dist, rank, world):
     tile_bytes = 4 * band_stride * B
     n_streams = ctx.n_streams
     tiles = []
+    # the counters and statistics of all tiles in one array each: a batched launch fetches / fills them with one copy
+    fail_all = ctx.dev_alloc(8 * B * max(1, len(mine)))
+    norm_all = ctx.dev_alloc(16 * B * max(1, len(mine)))
+    ctx.memset(fail_all, 0, 8 * B * max(1, len(mine)))
     for j, t in enumerate(mine):
         d = {name: ctx.dev_alloc(tile_bytes) for name in ('src', 'ref', 'corr')}
-        d['fail'] = ctx.dev_alloc(8 * B)
-        d['norm'] = ctx.dev_alloc(16 * B)
-        ctx.memset(d['fail'], 0, 8 * B)
+        d['fail'] = fail_all + 8 * B * j
+        d['norm'] = norm_all + 16 * B * j
         ctx.synth_fill_dev(d['src'], d['ref'], B, n, n, stride, band_stride, seed=5000 + t, nodata_variant=args.nodata, stream=0)
         job = _hk.DevJob()
         job.src, job.ref, job.corr = d['src'], d['ref'], d['corr']
@@ -678,8 +707,41 @@ def run_tiles(args, ctx, dist, rank, world):
         d0 = tiles[0][0]
         copy_med, copy_best = probe_copy(ctx, d0['src'], d0['ref'], d0['corr'], tile_bytes)
 
+    # Batched launches: the rank's tiles in `n_batches` groups, each one launch per kernel stage on its own stream
+    n_batches = min(int(os.environ.get('HK_BENCH_BATCHES', str(args.batches))), len(tiles))
+    batches = []
+    if n_batches > 0:
+        per = (len(tiles) + n_batches - 1) // n_batches
+        for g in range(n_batches):
+            group = tiles[g * per:(g + 1) * per]
+            for d, job, counts, ev in group:
+                job.stream = g % n_streams
+            if group:
+                batches.append((ctx.job_array([t[1] for t in group]), group, ctx.pinned_empty((B * len(group),), np.uint64), ctx.event()))
+
+    def step_batched():
+        n_fail = 0
+        for arr, group, counts_all, ev in batches:
+            if args.model == 'gain-blk-offset':
+                ctx.block_norm_batch_dev(desc, arr, group[0][0]['norm'])
+            ctx.fit_apply_batch_dev(desc, arr)
+            if thresh is not None:
+                ctx.fail_counts_batch_async(arr, counts_all, ev)
+        if thresh is not None:
+            for arr, group, counts_all, ev in batches:
+                ctx.event_sync(ev)
+                c_all = counts_all.copy()
+                if ctx.counts_pending(c_all):
+                    for i, (d, job, counts, _) in enumerate(group):
+                        c = c_all[B * i:B * (i + 1)]
+                        if ctx.counts_pending(c):
+                            n_fail += ctx.inpaint_dev_counts(desc, job, c)
+        return n_fail
+
     def step():
         """ every tile's fused launch on its stream, then the host's look at the r2-mask counters of all of them """
+        if batches:
+            return step_batched()
         n_fail = 0
         for d, job, counts, ev in tiles:
             if args.model == 'gain-blk-offset':
@@ -718,8 +780,12 @@ def run_tiles(args, ctx, dist, rank, world):
         e2e = end_to_end_tiles(args, ctx, dist, tiles, stride, band_stride, thresh, nd)
     for d, job, counts, ev in tiles:
         ctx.event_destroy(ev)
-        for ptr in d.values():
-            ctx.dev_free(ptr)
+        for name, ptr in d.items():
+            if name not in ('fail', 'norm'):  # slices of fail_all / norm_all
+                ctx.dev_free(ptr)
+    for arr, group, counts_all, ev in batches:
+        ctx.event_destroy(ev)
+    ctx.dev_free(fail_all), ctx.dev_free(norm_all)
     my_px = len(mine) * n * n * B
     del tiles
     return dict(
@@ -836,6 +902,7 @@ def main():
             a3.config = cfg
             for key in ('model', 'kernel', 'size', 'bands', 'tiles'):
                 setattr(a3, key, CONFIGS[cfg].get(key))
+            a3.batches = CONFIGS[cfg].get('batches', 0)
             a3.steps, a3.warmup, a3.no_end_to_end, a3.no_thresh, a3.power_probe, a3.seg_rows = steps, warm, True, False, False, 0
             c3 = ctx
             if cfg == 3:   # configs[3] deals its block positions to eight streams (see below)

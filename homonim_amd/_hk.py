@@ -117,6 +117,9 @@ SIGNATURES = {
     'hk_inpaint_dev_counts': (C.c_int, [C.c_void_p, _P(FitDesc), _P(DevJob), _P(C.c_uint64), _P(C.c_uint64)]),
     'hk_event_sync': (C.c_int, [C.c_void_p, C.c_void_p]),
     'hk_block_norm_dev': (C.c_int, [C.c_void_p, _P(FitDesc), _P(DevJob), C.c_void_p]),
+    'hk_block_norm_batch_dev': (C.c_int, [C.c_void_p, _P(FitDesc), _P(DevJob), C.c_int32, C.c_void_p]),
+    'hk_fit_apply_batch_dev': (C.c_int, [C.c_void_p, _P(FitDesc), _P(DevJob), C.c_int32]),
+    'hk_fail_counts_batch_async': (C.c_int, [C.c_void_p, _P(DevJob), C.c_int32, _P(C.c_uint64), C.c_void_p]),
     'hk_compare_sums_dev': (C.c_int, [C.c_void_p, _P(DevJob), C.c_int32, C.c_float, C.c_int32, C.c_float, C.c_void_p]),
     'hk_synth_fill_dev': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64,
                                     C.c_int64, C.c_uint64, C.c_int32, C.c_int32]),
@@ -603,6 +606,36 @@ class Context:
 
     def block_norm_dev(self, desc: FitDesc, job: DevJob, norm_dptr: int):
         _check(self._lib.hk_block_norm_dev(self._h, C.byref(desc), C.byref(job), C.c_void_p(norm_dptr)))
+
+    @staticmethod
+    def job_array(jobs) -> 'C.Array':
+        """ The jobs of a batched launch as one contiguous ctypes array (build it once, pass it to every step). """
+        if isinstance(jobs, C.Array):
+            return jobs
+        arr = (DevJob * len(jobs))()
+        for i, j in enumerate(jobs):
+            C.memmove(C.byref(arr, i * C.sizeof(DevJob)), C.byref(j), C.sizeof(DevJob))
+        return arr
+
+    def block_norm_batch_dev(self, desc: FitDesc, jobs, norm_dptr: int):
+        """ The block statistics of many device-resident jobs in one launch per kernel stage (hk_block_norm_batch_dev):
+        job 0's n_bands x 2 float64 first, then job 1's ... into `norm_dptr`; all on jobs[0].stream. """
+        arr = self.job_array(jobs)
+        _check(self._lib.hk_block_norm_batch_dev(self._h, C.byref(desc), arr, len(arr), C.c_void_p(norm_dptr)))
+
+    def fit_apply_batch_dev(self, desc: FitDesc, jobs):
+        """ Many device-resident jobs as ONE fused launch on jobs[0].stream (hk_fit_apply_batch_dev); every job reads its own
+        ``norm`` pointer and, with an r2 threshold, is finished by its own ``inpaint_dev*`` call. """
+        arr = self.job_array(jobs)
+        _check(self._lib.hk_fit_apply_batch_dev(self._h, C.byref(desc), arr, len(arr)))
+
+    def fail_counts_batch_async(self, jobs, host_counts: np.ndarray, ready_event: int):
+        """ ``fail_counts_async`` for the jobs of a batch: all their counters, job after job, into one PINNED uint64 array. """
+        arr = self.job_array(jobs)
+        assert host_counts.dtype == np.uint64 and host_counts.flags['C_CONTIGUOUS']
+        assert host_counts.size >= sum(j.n_bands for j in arr)
+        _check(self._lib.hk_fail_counts_batch_async(self._h, arr, len(arr), host_counts.ctypes.data_as(_P(C.c_uint64)),
+                                                    C.c_void_p(ready_event)))
 
     def compare_sums_dev(self, job: DevJob, src_nodata, ref_nodata, sums_dptr: int):
         (sm, sv), (rm, rv) = nodata_code(src_nodata), nodata_code(ref_nodata)

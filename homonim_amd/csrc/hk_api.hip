@@ -63,6 +63,14 @@ struct Slot {
     void* aux = nullptr;      // on-demand planes + tables of the in-painting branch
     size_t aux_bytes = 0;
     unsigned long long* fail_host = nullptr;  // pinned word: the r2-mask failure counter comes back with the outputs
+    // job / plane tables of the batched device entry points: a small ring of (pinned host, device) buffer pairs; entry i is
+    // re-used once the upload recorded in tbl_ev[i] has been made (the device side is ordered by the stream itself)
+    static constexpr int TBL_RING = 4;
+    void* tbl_host[TBL_RING] = {nullptr, nullptr, nullptr, nullptr};
+    void* tbl_dev[TBL_RING] = {nullptr, nullptr, nullptr, nullptr};
+    size_t tbl_bytes[TBL_RING] = {0, 0, 0, 0};
+    hipEvent_t tbl_ev[TBL_RING] = {nullptr, nullptr, nullptr, nullptr};
+    int tbl_next = 0;
     bool busy = false;         // leased by a host-pointer call (SlotLease)
     bool dev_touched = false;  // device-resident jobs were queued on this stream since the last lease drained it
 };
@@ -785,6 +793,11 @@ int hk_ctx_destroy(hk_ctx* ctx) {
         if (s.norm_ws) hipFree(s.norm_ws);
         if (s.aux) hipFree(s.aux);
         if (s.fail_host) hipHostFree(s.fail_host);
+        for (int i = 0; i < Slot::TBL_RING; ++i) {
+            if (s.tbl_host[i]) hipHostFree(s.tbl_host[i]);
+            if (s.tbl_dev[i]) hipFree(s.tbl_dev[i]);
+            if (s.tbl_ev[i]) hipEventDestroy(s.tbl_ev[i]);
+        }
         if (s.stream) hipStreamDestroy(s.stream);
     }
     if (ctx->comm && rccl().ok) rccl().CommDestroy(ctx->comm);
@@ -1451,6 +1464,207 @@ int hk_block_norm_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* jo
     na.src_nd_mode = desc->src_nodata_mode, na.ref_nd_mode = desc->ref_nodata_mode;
     na.src_nodata = desc->src_nodata, na.ref_nodata = desc->ref_nodata;
     HK_HIP(hk::launch_block_norm(na, sl.norm_ws, norm_dev, sl.stream));
+    return HK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Batched device entry points: many jobs, one launch per kernel stage, all on jobs[0].stream.
+
+// Upload `bytes` of table data to a device buffer of the slot's ring; *dev_out is valid for the kernels queued next on the
+// slot's stream (and until the ring comes round: TBL_RING uploads later, which the stream has ordered behind them).
+static int upload_table(hk_ctx* ctx, Slot& sl, const void* data, size_t bytes, void** dev_out) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    const int i = sl.tbl_next;
+    sl.tbl_next = (sl.tbl_next + 1) % Slot::TBL_RING;
+    if (!sl.tbl_ev[i]) HK_HIP(hipEventCreateWithFlags(&sl.tbl_ev[i], hipEventDisableTiming));
+    else HK_HIP(hipEventSynchronize(sl.tbl_ev[i]));  // the upload that last used this entry's host buffer has been made
+    if (sl.tbl_bytes[i] < bytes) {
+        if (sl.tbl_dev[i]) {
+            HK_HIP(hipStreamSynchronize(sl.stream));  // kernels may still read the old device buffer
+            HK_HIP(hipFree(sl.tbl_dev[i]));
+            HK_HIP(hipHostFree(sl.tbl_host[i]));
+        }
+        sl.tbl_dev[i] = sl.tbl_host[i] = nullptr, sl.tbl_bytes[i] = 0;
+        const size_t cap = (bytes + 4095) / 4096 * 4096;
+        if (hipMalloc(&sl.tbl_dev[i], cap) != hipSuccess) return fail(HK_ERR_NOMEM, "hipMalloc(%zu) failed", cap);
+        if (hipHostMalloc(&sl.tbl_host[i], cap, hipHostMallocDefault) != hipSuccess) {
+            (void)hipFree(sl.tbl_dev[i]);
+            sl.tbl_dev[i] = nullptr;
+            return fail(HK_ERR_NOMEM, "hipHostMalloc(%zu) failed", cap);
+        }
+        sl.tbl_bytes[i] = cap;
+    }
+    memcpy(sl.tbl_host[i], data, bytes);
+    HK_HIP(hipMemcpyAsync(sl.tbl_dev[i], sl.tbl_host[i], bytes, hipMemcpyHostToDevice, sl.stream));
+    HK_HIP(hipEventRecord(sl.tbl_ev[i], sl.stream));
+    *dev_out = sl.tbl_dev[i];
+    return HK_OK;
+}
+
+static int check_batch(hk_ctx* ctx, const hk_dev_job* jobs, int32_t n_jobs) {
+    if (!ctx || !jobs) return fail(HK_ERR_ARG, "NULL argument");
+    if (n_jobs < 1 || n_jobs > 65536) return fail(HK_ERR_ARG, "n_jobs %d outside 1..65536", n_jobs);
+    for (int32_t j = 0; j < n_jobs; ++j) {
+        if (jobs[j].stream != jobs[0].stream) return fail(HK_ERR_ARG, "the jobs of a batch share one stream (job %d differs)", j);
+        const int rc = check_job(ctx, &jobs[j]);
+        if (rc) return rc;
+    }
+    return HK_OK;
+}
+
+int hk_block_norm_batch_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* jobs, int32_t n_jobs, double* norm_dev) {
+    int rc = validate_desc(desc);
+    if (rc) return rc;
+    rc = check_batch(ctx, jobs, n_jobs);
+    if (rc) return rc;
+    if (!norm_dev) return fail(HK_ERR_ARG, "norm_dev is NULL");
+    HK_ENTER(ctx);
+    Slot& sl = ctx->slots[jobs[0].stream];
+    std::vector<hk::NormPlane> planes;
+    int max_h = 0, max_w = 0;
+    long long max_px = 0;
+    for (int32_t j = 0; j < n_jobs; ++j) {
+        const hk_dev_job& job = jobs[j];
+        for (int32_t b = 0; b < job.n_bands; ++b) {
+            hk::NormPlane pl;
+            pl.src = job.src + (long long)b * job.band_stride, pl.ref = job.ref + (long long)b * job.band_stride;
+            pl.stride = job.stride, pl.height = job.height, pl.width = job.width;
+            planes.push_back(pl);
+        }
+        // the largest plane sizes the grid and the compaction buffers of every plane
+        if ((long long)job.height * job.width > max_px) max_px = (long long)job.height * job.width, max_h = job.height, max_w = job.width;
+    }
+    if (planes.size() > 65535) return fail(HK_ERR_ARG, "a batch holds at most 65535 planes");
+    rc = ensure_stream_ws(ctx, sl, hk::norm_workspace_bytes((int)planes.size(), max_h, max_w));
+    if (rc) return rc;
+    void* tbl = nullptr;
+    rc = upload_table(ctx, sl, planes.data(), planes.size() * sizeof(hk::NormPlane), &tbl);
+    if (rc) return rc;
+    hk::NormArgs na;
+    na.planes = static_cast<const hk::NormPlane*>(tbl);
+    na.src = na.ref = nullptr, na.height = max_h, na.width = max_w, na.stride = 0, na.band_stride = 0;
+    na.n_bands = (int)planes.size();
+    na.src_nd_mode = desc->src_nodata_mode, na.ref_nd_mode = desc->ref_nodata_mode;
+    na.src_nodata = desc->src_nodata, na.ref_nodata = desc->ref_nodata;
+    HK_HIP(hk::launch_block_norm(na, sl.norm_ws, norm_dev, sl.stream));
+    return HK_OK;
+}
+
+int hk_fit_apply_batch_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* jobs, int32_t n_jobs) {
+    int rc = validate_desc(desc);
+    if (rc) return rc;
+    rc = check_batch(ctx, jobs, n_jobs);
+    if (rc) return rc;
+    HK_ENTER(ctx);
+    Slot& sl = ctx->slots[jobs[0].stream];
+    const int wpb = hk::fit_lockstep_waves();
+    std::vector<hk::FitJob> table((size_t)n_jobs);
+    hk::FitArgs a0;  // the launch's argument block: everything the jobs share, and job 0's own fields (which the table overrides)
+    memset(&a0, 0, sizeof(a0));
+    long long groups[2] = {0, 0}, total_px = 0;
+    bool cert_only = false, pad_by_size = false;
+    // fill_grid()'s two segment heights, applied to the LAUNCH: the jobs run in order, so the jobs whose units make up the last
+    // ~1.25 generations of resident waves get short segments (they level the end of the launch) and all earlier ones long
+    // segments (half the priming rows).  Results do not depend on the segment height (exact running sums).
+    std::vector<int> seg_of((size_t)n_jobs, 0);
+    {
+        long long units = 0;
+        std::vector<long long> first((size_t)n_jobs + 1, 0);
+        int uniform = 0;
+        bool any_explicit = false;
+        for (int32_t j = 0; j < n_jobs; ++j) {
+            hk::FitArgs a;
+            memset(&a, 0, sizeof(a));
+            a.height = jobs[j].height, a.width = jobs[j].width, a.n_bands = jobs[j].n_bands;
+            fill_args(a, desc, ctx->xcd_remap);
+            fill_grid(a, jobs[j].seg_rows);
+            any_explicit |= jobs[j].seg_rows > 0 || a.seg_rows_pref > 0;
+            if (j == 0) uniform = 2 * a.rh + 1 <= 5 ? 64 : (2 * a.rh + 1 <= 9 ? 128 : 256);
+            first[(size_t)j] = units;
+            units += (long long)a.n_strips * a.n_segs * a.n_bands;
+        }
+        first[(size_t)n_jobs] = units;
+        const long long slots = (long long)env_int("HK_WAVE_SLOTS", 256 * 12);
+        if (!any_explicit && units >= 6 * slots && env_int("HK_BATCH_SEGS", 1)) {
+            const long long tail_from = units - (long long)(1.25 * (double)slots);
+            for (int32_t j = 0; j < n_jobs; ++j) seg_of[(size_t)j] = first[(size_t)j + 1] <= tail_from ? 2 * uniform : uniform / 2;
+        }
+    }
+    for (int32_t j = 0; j < n_jobs; ++j) {
+        const hk_dev_job* job = &jobs[j];
+        if (desc->model == HK_MODEL_GAIN_BLK_OFFSET && !job->norm) return fail(HK_ERR_ARG, "gain-blk-offset needs job->norm (job %d)", j);
+        // what selects the kernel build must not differ inside a launch
+        if ((!job->gain) != (!jobs[0].gain) || (!job->offset) != (!jobs[0].offset) || (!job->r2) != (!jobs[0].r2) ||
+            (!job->corr) != (!jobs[0].corr) || (!job->fail_count) != (!jobs[0].fail_count) || (!job->scratch) != (!jobs[0].scratch))
+            return fail(HK_ERR_ARG, "the jobs of a batch ask for the same set of outputs (job %d differs from job 0)", j);
+        hk::FitArgs a;
+        memset(&a, 0, sizeof(a));
+        a.src = job->src, a.ref = job->ref, a.gain = job->gain, a.offset = job->offset, a.r2 = job->r2, a.corr = job->corr;
+        a.norm = job->norm;
+        a.fail_count = reinterpret_cast<unsigned long long*>(job->fail_count);
+        a.height = job->height, a.width = job->width, a.stride = job->stride, a.band_stride = job->band_stride;
+        a.n_bands = job->n_bands;
+        fill_args(a, desc, ctx->xcd_remap);
+        if (j == 0) pad_by_size = a.lds_pad < 0;  // fill_grid() would decide by the job's size: the launch's counts (below)
+        fill_grid(a, seg_of[(size_t)j] > 0 ? seg_of[(size_t)j] : job->seg_rows);
+        apply_job_window(a, job);
+        if ((job->out_rows || job->out_cols) && a.has_thresh)
+            return fail(HK_ERR_UNSUPPORTED, "a store window is not supported together with r2_inpaint_thresh (the in-painting "
+                                            "needs the parameters of the whole block)");
+        if (j == 0) cert_only = cert_only_eligible(a, desc) && !ctx->expect_r2_failures.load() && ctx->try_cert_only();
+        if (!cert_only && desc->model == HK_MODEL_GAIN_OFFSET && a.has_thresh && job->scratch) {
+            // the complete build leaves the in-painting's inputs in the job's scratch (hk_inpaint_dev_counts starts from them)
+            a.flag = job_scratch_flag(job);
+            if (!a.offset) a.offset = job_scratch_offset(job);
+        }
+        hk::FitJob& e = table[(size_t)j];
+        memset(&e, 0, sizeof(e));
+        e.src = a.src, e.ref = a.ref, e.gain = a.gain, e.offset = a.offset, e.r2 = a.r2, e.corr = a.corr, e.norm = a.norm;
+        e.fail_count = a.fail_count, e.flag = a.flag;
+        e.stride = a.stride, e.band_stride = a.band_stride, e.height = a.height, e.width = a.width, e.n_bands = a.n_bands;
+        e.seg_rows = a.seg_rows, e.n_strips = a.n_strips, e.n_segs = a.n_segs, e.seg_rows_tail = a.seg_rows_tail;
+        e.n_segs_big = a.n_segs_big;
+        e.out_y0 = a.out_y0, e.out_y1 = a.out_y1, e.out_x0 = a.out_x0, e.out_x1 = a.out_x1;
+        e.first_group[0] = (int)groups[0], e.first_group[1] = (int)groups[1];
+        groups[0] += (long long)a.n_strips * a.n_segs * a.n_bands;
+        groups[1] += (long long)((a.n_strips + wpb - 1) / wpb) * a.n_segs * a.n_bands;
+        total_px += (long long)a.height * a.width * a.n_bands;
+        if (groups[0] > 0x7fffff00ll) return fail(HK_ERR_ARG, "the batch has too many wave units for one launch");
+        if (j == 0) a0 = a;
+    }
+    a0.cert_only = cert_only;
+    a0.n_jobs = n_jobs;
+    a0.batch_groups[0] = (int)groups[0], a0.batch_groups[1] = (int)groups[1];
+    if (pad_by_size) a0.lds_pad = total_px >= (128ll << 20) ? 4096 : 0;  // fill_grid()'s occupancy policy, for the whole launch
+    void* tbl = nullptr;
+    rc = upload_table(ctx, sl, table.data(), table.size() * sizeof(hk::FitJob), &tbl);
+    if (rc) return rc;
+    a0.jobs = static_cast<const hk::FitJob*>(tbl);
+    HK_HIP(hk::launch_fit_apply(a0, desc->model, needs_r2(desc), sl.stream));
+    return HK_OK;
+}
+
+int hk_fail_counts_batch_async(hk_ctx* ctx, const hk_dev_job* jobs, int32_t n_jobs, uint64_t* host_counts, hk_event* ready) {
+    int rc = check_batch(ctx, jobs, n_jobs);
+    if (rc) return rc;
+    if (!host_counts || !ready) return fail(HK_ERR_ARG, "NULL argument");
+    for (int32_t j = 0; j < n_jobs; ++j)
+        if (!jobs[j].fail_count) return fail(HK_ERR_ARG, "job %d has no fail_count", j);
+    HK_ENTER(ctx);
+    Slot& sl = ctx->slots[jobs[0].stream];
+    // one copy + one clearing per run of jobs whose counters lie back to back in device memory (a caller that allocates the
+    // counters of a batch as one array gets exactly one of each)
+    size_t done = 0;  // counters copied so far = offset into host_counts
+    for (int32_t j = 0; j < n_jobs;) {
+        uint64_t* const first = jobs[j].fail_count;
+        size_t n = (size_t)jobs[j].n_bands;
+        int32_t k = j + 1;
+        while (k < n_jobs && jobs[k].fail_count == first + n) n += (size_t)jobs[k].n_bands, ++k;
+        HK_HIP(hipMemcpyAsync(host_counts + done, first, n * sizeof(uint64_t), hipMemcpyDeviceToHost, sl.stream));
+        HK_HIP(hipMemsetAsync(first, 0, n * sizeof(uint64_t), sl.stream));
+        done += n, j = k;
+    }
+    HK_HIP(hipEventRecord(ready->ev, sl.stream));
     return HK_OK;
 }
 

@@ -13,7 +13,32 @@ constexpr int WAVE = 64;   // gfx950 wavefront
 // cert_only = 0.  (Counts themselves are < 2^63.)
 constexpr unsigned long long FIT_RETRY_BIT = 1ull << 63;
 
+// One job of a BATCHED launch (FitArgs::jobs, device memory): many device-resident jobs -- the block positions of a mosaic, the
+// tiles of a tile list -- run as ONE kernel launch instead of one launch (and one launch tail) each.  A workgroup finds its job
+// by a binary search over `first_group` and takes the job's planes, shape and unit grid from here instead of from FitArgs.
+struct FitJob {
+    const float* src;
+    const float* ref;
+    float* gain;
+    float* offset;
+    float* r2;
+    float* corr;
+    const double* norm;
+    unsigned long long* fail_count;
+    unsigned char* flag;
+    long long stride, band_stride;
+    int height, width, n_bands;
+    int seg_rows, n_strips, n_segs, seg_rows_tail, n_segs_big;
+    int out_y0, out_y1, out_x0, out_x1;
+    int first_group[2];  // first workgroup of the job in the launch: [0] one strip per workgroup, [1] HK_WPB_MEM strips (lock-step builds)
+    int pad_;
+};
+static_assert(sizeof(FitJob) % 8 == 0, "FitJob entries are read with scalar loads");
+
 struct FitArgs {
+    const FitJob* jobs;     // batched launch: n_jobs entries (device), else NULL -- the fields below then describe the one job
+    int n_jobs;
+    int batch_groups[2];    // batched launch: workgroups of all jobs, [0] one strip per workgroup, [1] HK_WPB_MEM strips
     const float* src;
     const float* ref;
     float* gain;
@@ -63,6 +88,8 @@ struct FitArgs {
 
 // model: 0 gain, 1 gain-blk-offset, 2 gain-offset.  with_r2: compute the R2 quantity set.
 hipError_t launch_fit_apply(const FitArgs& a, int model, bool with_r2, hipStream_t stream);
+// strips per workgroup of the lock-step builds (HK_WPB_MEM): FitJob::first_group[1] / FitArgs::batch_groups[1] count those
+int fit_lockstep_waves();
 // LDS bytes one wave needs (its row ring; hk_kernels.hip)
 size_t fit_lds_bytes(int kh, int ring_mode, bool ahead);
 // lanes per side that overlap with the neighbouring strip for kernel half-width rw
@@ -72,7 +99,15 @@ hipError_t launch_apply(const float* src, const float* gain, const float* offset
                         long long stride, hipStream_t stream);
 
 // Block statistics for gain-blk-offset (kernel_model.py:216-229), per band.
+// One plane of a BATCHED statistics launch (NormArgs::planes, device memory): plane p of the launch = (job, band)
+struct NormPlane {
+    const float* src;
+    const float* ref;
+    long long stride;
+    int height, width;
+};
 struct NormArgs {
+    const NormPlane* planes = nullptr;  // batched launch: n_bands entries (device), else NULL -- the planes are then src/ref + band * band_stride
     const float* src;
     const float* ref;
     int height, width;
@@ -83,6 +118,7 @@ struct NormArgs {
 };
 // workspace: see norm_workspace_bytes(); norm_out: n_bands x 2 float64 on device.
 size_t norm_workspace_bytes(int n_bands, int height, int width);
+// batched: a.planes set, a.n_bands planes, a.height x a.width = the LARGEST plane (sizes the workspace and the grid)
 hipError_t launch_block_norm(const NormArgs& a, void* workspace, double* norm_out, hipStream_t stream);
 // The same statistics for a block whose rows are spread over several ranks: six phases on this rank's slab, the caller
 // all-reduces (SUM) the float64 exchange buffer (norm_split_exchange_doubles() values, device) between them.

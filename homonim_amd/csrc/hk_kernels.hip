@@ -578,7 +578,7 @@ constexpr int xch_mask() {
 template <int MODEL, bool R2, int RW, bool DENSE, int RING, bool CERT_ONLY, int WPB>
 __global__ void __launch_bounds__(WAVE * WPB, (CERT_ONLY && RW >= 0 && RW <= 3) ? 4
                                         : ((MODEL == 2 && R2 && !DENSE && (RW < 0 || RW >= 4)) ? HK_FIT_MIN_WAVES_WIDE : HK_FIT_MIN_WAVES))
-fit_apply_kernel(const FitArgs a) {
+fit_apply_kernel(const FitArgs a_in) {
     using CS = ColSums<MODEL, R2, DENSE>;
     // gain-blk-offset (kernel_model.py:276-303) normalises the source with the block's statistics, s' = s * n0 + n1 in
     // float64 (NumPy >= 2 promotion), and fits `gain` to it.  With R2 (BLK) s' is formed per pixel.  Without (BLKA, the
@@ -594,17 +594,39 @@ fit_apply_kernel(const FitArgs a) {
     extern __shared__ float4 lds4[];
 
     const int lane = threadIdx.x & (WAVE - 1), wave_in_wg = threadIdx.x >> 6;
-    // a workgroup = WPB adjacent strips of one (segment, band); the strips of a row are padded to a multiple of WPB (a padded
-    // strip lies outside the raster: every lane loads a clamped quad and stores nothing -- it only keeps the barriers whole)
-    const int groups_per_row = (a.n_strips + WPB - 1) / WPB;
     int group = blockIdx.x;
-    if (a.xcd_remap) {
+    if (a_in.xcd_remap) {
         // workgroups go round-robin to the 8 XCDs (each with its own L2): hand every XCD runs of `xcd_remap` consecutive
         // units, i.e. neighbouring strips of one segment, whose shared cache lines (strips start 16-byte-, not 128-byte-
         // aligned, and overlap by two lanes) are then fetched from HBM once instead of once per strip
-        const int g = a.xcd_remap / WPB > 0 ? a.xcd_remap / WPB : 1, slot = blockIdx.x >> 3;
+        const int g = a_in.xcd_remap / WPB > 0 ? a_in.xcd_remap / WPB : 1, slot = blockIdx.x >> 3;
         group = ((slot / g) * 8 + (blockIdx.x & 7)) * g + slot % g;
     }
+    // Batched launch (FitArgs::jobs): the workgroup's job is the last one whose first workgroup is not beyond it -- a binary
+    // search over the job table with scalar loads (everything here is uniform over the workgroup) --, and the job's planes, shape
+    // and unit grid replace the launch's.
+    FitArgs a = a_in;
+    if (a_in.jobs != nullptr) {
+        constexpr int FG = WPB > 1 ? 1 : 0;
+        if (group >= a_in.batch_groups[FG]) return;  // the whole workgroup (grid padding)
+        int lo = 0, hi = a_in.n_jobs - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (a_in.jobs[mid].first_group[FG] <= group) lo = mid;
+            else hi = mid - 1;
+        }
+        const FitJob& e = a_in.jobs[lo];
+        group -= e.first_group[FG];
+        a.src = e.src, a.ref = e.ref, a.gain = e.gain, a.offset = e.offset, a.r2 = e.r2, a.corr = e.corr, a.norm = e.norm;
+        a.fail_count = e.fail_count, a.flag = e.flag;
+        a.stride = e.stride, a.band_stride = e.band_stride, a.height = e.height, a.width = e.width, a.n_bands = e.n_bands;
+        a.seg_rows = e.seg_rows, a.n_strips = e.n_strips, a.n_segs = e.n_segs, a.seg_rows_tail = e.seg_rows_tail;
+        a.n_segs_big = e.n_segs_big;
+        a.out_y0 = e.out_y0, a.out_y1 = e.out_y1, a.out_x0 = e.out_x0, a.out_x1 = e.out_x1;
+    }
+    // a workgroup = WPB adjacent strips of one (segment, band); the strips of a row are padded to a multiple of WPB (a padded
+    // strip lies outside the raster: every lane loads a clamped quad and stores nothing -- it only keeps the barriers whole)
+    const int groups_per_row = (a.n_strips + WPB - 1) / WPB;
     if (group >= groups_per_row * a.n_segs * a.n_bands) return;  // the whole workgroup
     // segment-major order: the short tail segments (hk_api.hip fill_grid) are dispatched last
     const int strip = (group % groups_per_row) * WPB + wave_in_wg;
@@ -1291,6 +1313,8 @@ fit_apply_kernel(const FitArgs a) {
 // LDS bytes of one wave: the row ring of the mode (see fit_apply_kernel).  Validity travels inside the source plane
 // (RING_SENTINEL) and the 1/N table sits in global memory, so every build of a kernel shape needs the same amount: 10 KB at
 // 5x5 = 16 waves per CU (8 KB = 20 waves for the kernels that read the leaving row one iteration ahead).
+int fit_lockstep_waves() { return HK_WPB_MEM; }
+
 size_t fit_lds_bytes(int kh, int ring_mode, bool ahead) {
     if (ring_mode == 1) return (size_t)(ahead && kh > 1 ? kh - 1 : kh) * 2 * WAVE * sizeof(float4);
     if (ring_mode == 2) return (size_t)(kh / 2 + 1) * WAVE * sizeof(float4);
@@ -1306,6 +1330,7 @@ static hipError_t launch_wpb(const FitArgs& a, size_t lds, hipStream_t stream) {
         if (e != hipSuccess) return e;
     }
     int grid = (a.n_strips + WPB - 1) / WPB * a.n_segs * a.n_bands;  // workgroups of WPB adjacent strips
+    if (a.jobs) grid = a.batch_groups[WPB > 1 ? 1 : 0];
     if (a.xcd_remap) {
         const int g = a.xcd_remap / WPB > 0 ? a.xcd_remap / WPB : 1;
         grid = (grid + 8 * g - 1) / (8 * g) * (8 * g);

@@ -96,6 +96,25 @@ __device__ __forceinline__ bool nvalid(float v, int mode, float nodata) {
     return mode == 0 ? true : (mode == 1 ? !(v != v) : !(v == nodata));
 }
 
+// geometry of plane p of the launch: the job's band p, or entry p of a batched launch's plane table (uniform over the workgroup)
+struct PlaneRef {
+    const float* sp;
+    const float* rp;
+    long long stride;
+    int height, width;
+};
+__device__ __forceinline__ PlaneRef plane_of(const NormArgs& a, int p) {
+    PlaneRef r;
+    if (a.planes != nullptr) {
+        const NormPlane& e = a.planes[p];
+        r.sp = e.src, r.rp = e.ref, r.stride = e.stride, r.height = e.height, r.width = e.width;
+    } else {
+        r.sp = a.src + (long long)p * a.band_stride, r.rp = a.ref + (long long)p * a.band_stride;
+        r.stride = a.stride, r.height = a.height, r.width = a.width;
+    }
+    return r;
+}
+
 __device__ __forceinline__ double wave_sum(double v) {  // fixed butterfly order -> deterministic
 #pragma unroll
     for (int d = WAVE / 2; d > 0; d >>= 1) v += __shfl_xor(v, d);
@@ -162,9 +181,10 @@ __global__ void __launch_bounds__(SAMPLE_THREADS) norm_sample_kernel(const NormA
     __shared__ double red[SAMPLE_THREADS / WAVE];
     const int band = blockIdx.x, t = threadIdx.x;
     NormWS& ws = ws_all[band];
-    const float* __restrict__ sp = a.src + (long long)band * a.band_stride;
-    const float* __restrict__ rp = a.ref + (long long)band * a.band_stride;
-    const long long total = (long long)a.height * a.width;
+    const PlaneRef pl = plane_of(a, band);
+    const float* __restrict__ sp = pl.sp;
+    const float* __restrict__ rp = pl.rp;
+    const long long total = (long long)pl.height * pl.width;
     const long long step = total / SAMPLE_N > 0 ? total / SAMPLE_N : 1;
     for (int q = 0; q < 2; ++q) {
         if (t == 0) cnt = 0;
@@ -179,8 +199,8 @@ __global__ void __launch_bounds__(SAMPLE_THREADS) norm_sample_kernel(const NormA
             hsh ^= hsh >> 32;
             const long long p = (long long)j * step + (long long)(hsh % (unsigned long long)step);
             if (p < total) {
-                const int y = (int)(p / a.width), x = (int)(p % a.width);
-                const float s = sp[(long long)y * a.stride + x], r = rp[(long long)y * a.stride + x];
+                const int y = (int)(p / pl.width), x = (int)(p % pl.width);
+                const float s = sp[(long long)y * pl.stride + x], r = rp[(long long)y * pl.stride + x];
                 if (nvalid(s, a.src_nd_mode, a.src_nodata) && nvalid(r, a.ref_nd_mode, a.ref_nodata)) {
                     const float v = q ? r : s;
                     samp[atomicAdd(&cnt, 1u)] = v;
@@ -260,7 +280,7 @@ static size_t norm_stream_lds_pad() {
 
 // Waves per band of the streaming pass: a function of the block SHAPE only (never of the batch size), so a block's
 // statistics are the same bits whichever launch it travels in; >= 16 chunks of 1 KB per raster per wave.
-static int pass_waves(int height, int width) {
+__host__ __device__ static inline int pass_waves(int height, int width) {
     const long long chunks = (long long)height * (((width + PX - 1) / PX + WAVE - 1) / WAVE);
     long long w = chunks / 16;
     w = w < 64 ? 64 : (w > PASS_WAVES ? PASS_WAVES : w);
@@ -279,10 +299,15 @@ template <bool DENSE>
 __global__ void __launch_bounds__(WAVE) norm_stream_kernel(const NormArgs a, NormWS* __restrict__ ws_all,
                                                             float* __restrict__ mid_all, size_t mid_cap) {
     __shared__ float stage[2][QCAP][WAVE];
-    const int band = blockIdx.y, wave = blockIdx.x, lane = threadIdx.x, G = gridDim.x;
+    const int band = blockIdx.y, wave = blockIdx.x, lane = threadIdx.x;
     NormWS& ws = ws_all[band];
-    const float* __restrict__ sp = a.src + (long long)band * a.band_stride;
-    const float* __restrict__ rp = a.ref + (long long)band * a.band_stride;
+    const PlaneRef pl = plane_of(a, band);
+    // the plane's own wave count (the grid is sized for the largest plane of a batched launch): a plane's partial sums are the
+    // same bits whichever launch it travels in
+    const int G = pass_waves(pl.height, pl.width);
+    if (wave >= G) return;
+    const float* __restrict__ sp = pl.sp;
+    const float* __restrict__ rp = pl.rp;
     float* mid[2] = {mid_all + ((size_t)band * 2 + 0) * mid_cap, mid_all + ((size_t)band * 2 + 1) * mid_cap};
     const float lo[2] = {ws.lo[0], ws.lo[1]}, hi[2] = {ws.hi[0], ws.hi[1]};
     const double shift[2] = {ws.shift[0], ws.shift[1]};
@@ -310,8 +335,8 @@ __global__ void __launch_bounds__(WAVE) norm_stream_kernel(const NormArgs a, Nor
     };
 
     // the wave's chunks: it = wave, wave + G, ... over rows x chunks-per-row, (y, c) stepped without a division
-    const int wq = (a.width + PX - 1) / PX, cpr = (wq + WAVE - 1) / WAVE;
-    const long long total = (long long)a.height * cpr;
+    const int wq = (pl.width + PX - 1) / PX, cpr = (wq + WAVE - 1) / WAVE;
+    const long long total = (long long)pl.height * cpr;
     const int dy = G / cpr, dc = G % cpr;
     int py = wave / cpr, pc = wave % cpr;  // position of the next load
     long long pit = wave;
@@ -319,7 +344,7 @@ __global__ void __launch_bounds__(WAVE) norm_stream_kernel(const NormArgs a, Nor
         // always a valid address (chunk 0 of row 0 for lanes / iterations past the end), x = width marks "no pixels".
         // The row / chunk part of the address is wave-uniform (scalar registers), the lane adds 16 bytes * lane.
         const bool live = pit < total;
-        const long long o = live ? (long long)py * a.stride + (long long)pc * (WAVE * PX) : 0ll;
+        const long long o = live ? (long long)py * pl.stride + (long long)pc * (WAVE * PX) : 0ll;
         const bool ok = live && pc * WAVE + lane < wq;  // rows are padded to a multiple of PX elements
         const int lo4 = ok ? lane * PX : 0;
         // read once: non-temporal, so the pass does not push the rows a tall fit kernel of another stream is about to
@@ -328,7 +353,7 @@ __global__ void __launch_bounds__(WAVE) norm_stream_kernel(const NormArgs a, Nor
         const f4v sv = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(sp + o + lo4));
         const f4v rv = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(rp + o + lo4));
         s4 = make_float4(sv.x, sv.y, sv.z, sv.w), r4 = make_float4(rv.x, rv.y, rv.z, rv.w);
-        x = ok ? (pc * WAVE + lane) * PX : a.width;
+        x = ok ? (pc * WAVE + lane) * PX : pl.width;
         pit += G, py += dy, pc += dc;
         if (pc >= cpr) pc -= cpr, ++py;
     };
@@ -343,7 +368,7 @@ __global__ void __launch_bounds__(WAVE) norm_stream_kernel(const NormArgs a, Nor
             if (__any(cnt[1] > (unsigned)(QCAP - PX))) flush(1);
         }
         const float s[PX] = {s4.x, s4.y, s4.z, s4.w}, r[PX] = {r4.x, r4.y, r4.z, r4.w};
-        const int npx = a.width - x;  // <= 0: nothing
+        const int npx = pl.width - x;  // <= 0: nothing
 #pragma unroll
         for (int i = 0; i < PX; ++i) {
             bool m = FULL || i < npx;
@@ -371,10 +396,10 @@ __global__ void __launch_bounds__(WAVE) norm_stream_kernel(const NormArgs a, Nor
             }
         }
     };
-    const bool quads = (a.width % PX) == 0;
+    const bool quads = (pl.width % PX) == 0;
     auto process_any = [&](const float4& s4, const float4& r4, int x) {
         // wave-uniform: lane 63 holds a whole quad <=> all lanes do
-        if (quads && __shfl(x, WAVE - 1) < a.width) process(s4, r4, x, std::true_type{});
+        if (quads && __shfl(x, WAVE - 1) < pl.width) process(s4, r4, x, std::true_type{});
         else process(s4, r4, x, std::false_type{});
     };
 
@@ -550,14 +575,15 @@ __global__ void __launch_bounds__(NORM_THREADS) norm_full_hist_kernel(const Norm
     if (ws.done || !ws.fallback) return;
     for (int i = threadIdx.x; i < 2 * NB; i += NORM_THREADS) hist[i] = 0;
     __syncthreads();
-    const float* __restrict__ sp = a.src + (long long)band * a.band_stride;
-    const float* __restrict__ rp = a.ref + (long long)band * a.band_stride;
+    const PlaneRef pl = plane_of(a, band);
+    const float* __restrict__ sp = pl.sp;
+    const float* __restrict__ rp = pl.rp;
     const unsigned pfx[2] = {ws.sel[q][0].prefix, ws.sel[q][1].prefix};
     const unsigned kb = ws.kbase[q];  // 0 / 0 on this path (plain keys)
     const int ksh = ws.ksh[q];
-    for (int y = blockIdx.x; y < a.height; y += gridDim.x) {
-        const long long row = (long long)y * a.stride;
-        for (int x = threadIdx.x; x < a.width; x += NORM_THREADS) {
+    for (int y = blockIdx.x; y < pl.height; y += gridDim.x) {
+        const long long row = (long long)y * pl.stride;
+        for (int x = threadIdx.x; x < pl.width; x += NORM_THREADS) {
             const float s = sp[row + x], r = rp[row + x];
             if (nvalid(s, a.src_nd_mode, a.src_nodata) && nvalid(r, a.ref_nd_mode, a.ref_nodata))
                 hist_add(hist, LEVEL, (f2key(q ? r : s) - kb) << ksh, pfx);
@@ -768,7 +794,10 @@ hipError_t launch_block_norm(const NormArgs& a, void* workspace, double* norm_ou
     else
         hipLaunchKernelGGL(norm_stream_kernel<false>, gstream, dim3(WAVE), norm_stream_lds_pad(), stream, a, ws, mid, cap_al);
     hipLaunchKernelGGL(norm_stats_kernel, bands, dim3(STATS_THREADS), 0, stream, ws, norm_out, cap_al);
-    const dim3 gmid(MID_BLOCKS, a.n_bands * 2), gfull(FB_BLOCKS, a.n_bands, 2);
+    // workgroups per compacted buffer: at least 8 float4 per thread of a full buffer (a 4096^2 block's buffers hold ~0.2 M values:
+    // 256 workgroups would spend their time zeroing and merging 16 KB histograms -- 0.40 -> 0.15 ms for configs[3]'s 128 blocks)
+    const size_t mid_wgs = cap_al / 4 / (NORM_THREADS * 8);
+    const dim3 gmid((unsigned)(mid_wgs < 8 ? 8 : (mid_wgs > MID_BLOCKS ? MID_BLOCKS : mid_wgs)), a.n_bands * 2), gfull(FB_BLOCKS, a.n_bands, 2);
     hipLaunchKernelGGL(norm_mid_hist_kernel<0>, gmid, block, 0, stream, ws, mid, cap_al);
     hipLaunchKernelGGL(norm_full_hist_kernel<0>, gfull, block, 0, stream, a, ws);
     hipLaunchKernelGGL(norm_select_kernel<0>, bands, block, 0, stream, ws, norm_out);

@@ -291,6 +291,21 @@ int hk_inpaint_dev_counts(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job
                           uint64_t* n_fail_out);
 /* Per-band block normalisation on device planes -> norm (device, n_bands x 2 float64); asynchronous. */
 int hk_block_norm_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* job, double* norm_dev);
+/* BATCHED launches: `n_jobs` device-resident jobs -- the block positions of a resident mosaic (homonim/raster_pair.py:342-428
+ * yields them one by one and homonim/fuse.py:395-404 hands each to a thread), the tiles of a tile list -- as ONE launch per
+ * kernel stage on jobs[0].stream (all jobs name that stream) instead of one launch, and one launch tail, per job.  Jobs may
+ * differ in shape, planes and store window; they share `desc` and ask for the same set of outputs (the same pointers are NULL in
+ * every job).  Results are bit-identical to the per-job calls: a job's statistics and wave units do not depend on the launch it
+ * travels in.  hk_block_norm_batch_dev writes the jobs' statistics one after the other (job 0's n_bands x 2 float64, then job
+ * 1's, ...) into norm_dev; hk_fit_apply_batch_dev reads each job's own `norm` pointer (point it into that buffer).  With an r2
+ * threshold every job keeps its own fail_count / scratch and is finished by its own hk_inpaint_dev* call, as after
+ * hk_fit_apply_dev.  The job tables travel through a small ring of pinned staging buffers of the stream: the calls only queue
+ * work. */
+int hk_block_norm_batch_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* jobs, int32_t n_jobs, double* norm_dev);
+int hk_fit_apply_batch_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* jobs, int32_t n_jobs);
+/* hk_fail_counts_async for the jobs of a batch: their counters, job after job (sum of n_bands values), into the pinned
+ * `host_counts`, cleared on the device, ONE event.  Pass each job its own slice to hk_inpaint_dev_counts afterwards. */
+int hk_fail_counts_batch_async(hk_ctx* ctx, const hk_dev_job* jobs, int32_t n_jobs, uint64_t* host_counts, hk_event* ready);
 /* The same statistics (KernelModel._fit_block_norm, homonim/kernel_model.py:216-229) for a block whose ROWS are spread over
  * `world_size` ranks / devices -- the optional collective of a gain-blk-offset block too large for one GPU.  `job` is this
  * rank's slab of the block (any number of rows, the block's width).  Phases 0..5 are queued one at a time on job->stream;

@@ -348,7 +348,7 @@ def test_config4_tiles_on_four_streams(ctx, oracle):
 def test_config3_all_128_blocks_of_the_resident_raster(ctx, oracle):
     """ BASELINE.json configs[3] at its FULL count: the 8-band 16384 x 16384 raster resident in HBM, cut into the reference's own
     128 blocks (16 positions x 8 bands; homonim/raster_pair.py:342-428), every block normalised by its own device statistics
-    and processed in place with its out-block as store window -- exactly bench.py --config 3.  Oracle windows in six block
+    and processed in place with its out-block as store window, in four batched launches per kernel stage -- exactly bench.py --config 3.  Oracle windows in six block
     positions (corners, edges, interior, the last one) x two bands incl. the last, each with ITS block's statistics; the
     statistics themselves against numpy's; every pixel of the checked planes written exactly once. """
     from homonim_amd import utils
@@ -367,6 +367,7 @@ def test_config3_all_128_blocks_of_the_resident_raster(ctx, oracle):
         ctx.memset(bufs['corr'], 0xff, 4 * plane * B)      # NaN pattern: a pixel nobody stores stays NaN
         ctx.stream_sync(0)
         desc = _hk.make_desc('gain-blk-offset', (k, k), False, None, None, None)
+        jobs = []
         for i, bp in enumerate(positions):
             wi, wo = bp.src_in_block, bp.src_out_block
             off = 4 * (wi.row_off * n + wi.col_off)
@@ -375,11 +376,14 @@ def test_config3_all_128_blocks_of_the_resident_raster(ctx, oracle):
             job.gain = job.offset = job.r2 = job.fail_count = None
             job.norm = norm + 16 * B * i
             job.n_bands, job.height, job.width, job.stride, job.band_stride = B, wi.height, wi.width, n, plane
-            job.seg_rows, job.stream = 0, i % 8
+            job.seg_rows, job.stream = 0, i // 4   # four batched launches of four block positions, one stream each
             job.out_row0, job.out_col0 = wo.row_off - wi.row_off, wo.col_off - wi.col_off
             job.out_rows, job.out_cols = wo.height, wo.width
-            big.block_norm_dev(desc, job, job.norm)
-            big.fit_apply_dev(desc, job)
+            jobs.append(job)
+        for g in range(4):
+            arr = big.job_array(jobs[4 * g:4 * g + 4])
+            big.block_norm_batch_dev(desc, arr, jobs[4 * g].norm)
+            big.fit_apply_batch_dev(desc, arr)
         big.sync()
         norms = np.zeros((len(positions), B, 2))
         ctx.d2h(norms, norm)
