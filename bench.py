@@ -590,9 +590,10 @@ def run_blocks(args, ctx, dist, rank, world):
 
     parity = None
     if rank == 0 and not args.no_parity and jobs:
-        bp = mine[0]
+        # the LAST block position of the rank (a batched launch that lost its job table would never get there)
+        bp = mine[-1]
         nm = np.zeros((B, 2))
-        ctx.d2h(nm, bufs['norm'])
+        ctx.d2h(nm, bufs['norm'] + 16 * B * (len(mine) - 1))
         wi = bp.src_in_block
         # a block's statistics are taken over its whole in-block; check a window of band 0's first out-block against the oracle
         y0, x0 = wi.row_off + 1000, (wi.col_off + 1200) // 4 * 4

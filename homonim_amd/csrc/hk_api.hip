@@ -1555,6 +1555,21 @@ int hk_fit_apply_batch_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_jo
     if (rc) return rc;
     rc = check_batch(ctx, jobs, n_jobs);
     if (rc) return rc;
+    for (int32_t j = 1; j < n_jobs; ++j) {
+        const hk_dev_job* job = &jobs[j];
+        // what selects the kernel build must not differ inside a launch (the contract holds for every model)
+        if ((!job->gain) != (!jobs[0].gain) || (!job->offset) != (!jobs[0].offset) || (!job->r2) != (!jobs[0].r2) ||
+            (!job->corr) != (!jobs[0].corr) || (!job->fail_count) != (!jobs[0].fail_count) || (!job->scratch) != (!jobs[0].scratch))
+            return fail(HK_ERR_ARG, "the jobs of a batch ask for the same set of outputs (job %d differs from job 0)", j);
+    }
+    if (!hk::fit_batch_supported(desc->model, needs_r2(desc))) {
+        // builds without the job-table look-up (hk_kernels.h fit_batch_build): one launch per job, in order, same results
+        for (int32_t j = 0; j < n_jobs; ++j) {
+            rc = hk_fit_apply_dev(ctx, desc, &jobs[j]);
+            if (rc) return rc;
+        }
+        return HK_OK;
+    }
     HK_ENTER(ctx);
     Slot& sl = ctx->slots[jobs[0].stream];
     const int wpb = hk::fit_lockstep_waves();
@@ -1593,10 +1608,6 @@ int hk_fit_apply_batch_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_jo
     for (int32_t j = 0; j < n_jobs; ++j) {
         const hk_dev_job* job = &jobs[j];
         if (desc->model == HK_MODEL_GAIN_BLK_OFFSET && !job->norm) return fail(HK_ERR_ARG, "gain-blk-offset needs job->norm (job %d)", j);
-        // what selects the kernel build must not differ inside a launch
-        if ((!job->gain) != (!jobs[0].gain) || (!job->offset) != (!jobs[0].offset) || (!job->r2) != (!jobs[0].r2) ||
-            (!job->corr) != (!jobs[0].corr) || (!job->fail_count) != (!jobs[0].fail_count) || (!job->scratch) != (!jobs[0].scratch))
-            return fail(HK_ERR_ARG, "the jobs of a batch ask for the same set of outputs (job %d differs from job 0)", j);
         hk::FitArgs a;
         memset(&a, 0, sizeof(a));
         a.src = job->src, a.ref = job->ref, a.gain = job->gain, a.offset = job->offset, a.r2 = job->r2, a.corr = job->corr;

@@ -88,6 +88,11 @@ struct FitArgs {
 
 // model: 0 gain, 1 gain-blk-offset, 2 gain-offset.  with_r2: compute the R2 quantity set.
 hipError_t launch_fit_apply(const FitArgs& a, int model, bool with_r2, hipStream_t stream);
+// Which builds of the fused kernel exist with the job-table look-up of a batched launch (FitArgs::jobs): gain-blk-offset without
+// R2 -- the fused RasterFuse path of a block-partitioned mosaic, where one launch for all blocks pays (profiles/r03_batch.txt).
+// The batched entry points run every other model as one launch per job (bit-identical either way).
+constexpr bool fit_batch_build(int model, bool with_r2) { return model == 1 && !with_r2; }
+bool fit_batch_supported(int model, bool with_r2);
 // strips per workgroup of the lock-step builds (HK_WPB_MEM): FitJob::first_group[1] / FitArgs::batch_groups[1] count those
 int fit_lockstep_waves();
 // LDS bytes one wave needs (its row ring; hk_kernels.hip)

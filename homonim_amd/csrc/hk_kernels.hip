@@ -575,7 +575,7 @@ constexpr int xch_mask() {
     return (MODEL == 2 && (RW == 1 || RW == 2) && RING == 1 && WPB == 1) ? HK_XCH : 0;
 }
 
-template <int MODEL, bool R2, int RW, bool DENSE, int RING, bool CERT_ONLY, int WPB>
+template <int MODEL, bool R2, int RW, bool DENSE, int RING, bool CERT_ONLY, int WPB, bool BATCH = false>
 __global__ void __launch_bounds__(WAVE * WPB, (CERT_ONLY && RW >= 0 && RW <= 3) ? 4
                                         : ((MODEL == 2 && R2 && !DENSE && (RW < 0 || RW >= 4)) ? HK_FIT_MIN_WAVES_WIDE : HK_FIT_MIN_WAVES))
 fit_apply_kernel(const FitArgs a_in) {
@@ -602,11 +602,13 @@ fit_apply_kernel(const FitArgs a_in) {
         const int g = a_in.xcd_remap / WPB > 0 ? a_in.xcd_remap / WPB : 1, slot = blockIdx.x >> 3;
         group = ((slot / g) * 8 + (blockIdx.x & 7)) * g + slot % g;
     }
-    // Batched launch (FitArgs::jobs): the workgroup's job is the last one whose first workgroup is not beyond it -- a binary
-    // search over the job table with scalar loads (everything here is uniform over the workgroup) --, and the job's planes, shape
-    // and unit grid replace the launch's.
-    FitArgs a = a_in;
-    if (a_in.jobs != nullptr) {
+    // Batched launch (FitArgs::jobs; the BATCH builds): the workgroup's job is the last one whose first workgroup is not beyond
+    // it -- a binary search over the job table with scalar loads (everything here is uniform over the workgroup) --, and the job's
+    // planes, shape and unit grid replace the launch's.  A build of its own: with the table look-up in every kernel the argument
+    // block's fields hang on one more dependent scalar load at the start of every wave, which the short waves of the memory-bound
+    // builds feel (gain 5x5 at 8192^2 x 4: +8 %; profiles/r03_batch.txt).
+    [[maybe_unused]] FitArgs a_job;
+    if constexpr (BATCH) {
         constexpr int FG = WPB > 1 ? 1 : 0;
         if (group >= a_in.batch_groups[FG]) return;  // the whole workgroup (grid padding)
         int lo = 0, hi = a_in.n_jobs - 1;
@@ -617,13 +619,15 @@ fit_apply_kernel(const FitArgs a_in) {
         }
         const FitJob& e = a_in.jobs[lo];
         group -= e.first_group[FG];
-        a.src = e.src, a.ref = e.ref, a.gain = e.gain, a.offset = e.offset, a.r2 = e.r2, a.corr = e.corr, a.norm = e.norm;
-        a.fail_count = e.fail_count, a.flag = e.flag;
-        a.stride = e.stride, a.band_stride = e.band_stride, a.height = e.height, a.width = e.width, a.n_bands = e.n_bands;
-        a.seg_rows = e.seg_rows, a.n_strips = e.n_strips, a.n_segs = e.n_segs, a.seg_rows_tail = e.seg_rows_tail;
-        a.n_segs_big = e.n_segs_big;
-        a.out_y0 = e.out_y0, a.out_y1 = e.out_y1, a.out_x0 = e.out_x0, a.out_x1 = e.out_x1;
+        a_job = a_in;
+        a_job.src = e.src, a_job.ref = e.ref, a_job.gain = e.gain, a_job.offset = e.offset, a_job.r2 = e.r2, a_job.corr = e.corr;
+        a_job.norm = e.norm, a_job.fail_count = e.fail_count, a_job.flag = e.flag;
+        a_job.stride = e.stride, a_job.band_stride = e.band_stride, a_job.height = e.height, a_job.width = e.width;
+        a_job.n_bands = e.n_bands, a_job.seg_rows = e.seg_rows, a_job.n_strips = e.n_strips, a_job.n_segs = e.n_segs;
+        a_job.seg_rows_tail = e.seg_rows_tail, a_job.n_segs_big = e.n_segs_big;
+        a_job.out_y0 = e.out_y0, a_job.out_y1 = e.out_y1, a_job.out_x0 = e.out_x0, a_job.out_x1 = e.out_x1;
     }
+    const FitArgs& a = BATCH ? a_job : a_in;
     // a workgroup = WPB adjacent strips of one (segment, band); the strips of a row are padded to a multiple of WPB (a padded
     // strip lies outside the raster: every lane loads a clamped quad and stores nothing -- it only keeps the barriers whole)
     const int groups_per_row = (a.n_strips + WPB - 1) / WPB;
@@ -1314,6 +1318,7 @@ fit_apply_kernel(const FitArgs a_in) {
 // (RING_SENTINEL) and the 1/N table sits in global memory, so every build of a kernel shape needs the same amount: 10 KB at
 // 5x5 = 16 waves per CU (8 KB = 20 waves for the kernels that read the leaving row one iteration ahead).
 int fit_lockstep_waves() { return HK_WPB_MEM; }
+bool fit_batch_supported(int model, bool with_r2) { return fit_batch_build(model, with_r2); }
 
 size_t fit_lds_bytes(int kh, int ring_mode, bool ahead) {
     if (ring_mode == 1) return (size_t)(ahead && kh > 1 ? kh - 1 : kh) * 2 * WAVE * sizeof(float4);
@@ -1330,12 +1335,28 @@ static hipError_t launch_wpb(const FitArgs& a, size_t lds, hipStream_t stream) {
         if (e != hipSuccess) return e;
     }
     int grid = (a.n_strips + WPB - 1) / WPB * a.n_segs * a.n_bands;  // workgroups of WPB adjacent strips
-    if (a.jobs) grid = a.batch_groups[WPB > 1 ? 1 : 0];
+    constexpr bool CAN_BATCH = fit_batch_build(MODEL, R2) && !CERT_ONLY;
+    if (a.jobs) {
+        if (!CAN_BATCH) return hipErrorInvalidValue;  // hk_api.hip asks fit_batch_build() first
+        grid = a.batch_groups[WPB > 1 ? 1 : 0];
+    }
     if (a.xcd_remap) {
         const int g = a.xcd_remap / WPB > 0 ? a.xcd_remap / WPB : 1;
         grid = (grid + 8 * g - 1) / (8 * g) * (8 * g);
     }
     // a.lds_pad: extra dynamic LDS per wave that nothing uses -- it only lowers the number of resident waves per CU
+    if constexpr (CAN_BATCH) {
+        if (a.jobs) {
+            if (lds * WPB > 64 * 1024) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fit_apply_kernel<MODEL, R2, RW, DENSE, RING, CERT_ONLY, WPB, true>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e != hipSuccess) return e;
+            }
+            hipLaunchKernelGGL((fit_apply_kernel<MODEL, R2, RW, DENSE, RING, CERT_ONLY, WPB, true>), dim3(grid), dim3(WAVE * WPB),
+                               (lds + (size_t)a.lds_pad) * WPB, stream, a);
+            return hipGetLastError();
+        }
+    }
     hipLaunchKernelGGL((fit_apply_kernel<MODEL, R2, RW, DENSE, RING, CERT_ONLY, WPB>), dim3(grid), dim3(WAVE * WPB),
                        (lds + (size_t)a.lds_pad) * WPB, stream, a);
     return hipGetLastError();
