@@ -604,9 +604,8 @@ fit_apply_kernel(const FitArgs a_in) {
     }
     // Batched launch (FitArgs::jobs; the BATCH builds): the workgroup's job is the last one whose first workgroup is not beyond
     // it -- a binary search over the job table with scalar loads (everything here is uniform over the workgroup) --, and the job's
-    // planes, shape and unit grid replace the launch's.  A build of its own: with the table look-up in every kernel the argument
-    // block's fields hang on one more dependent scalar load at the start of every wave, which the short waves of the memory-bound
-    // builds feel (gain 5x5 at 8192^2 x 4: +8 %; profiles/r03_batch.txt).
+    // planes, shape and unit grid replace the launch's.  A build of its own: with the look-up compiled into every kernel (argument
+    // block copied and patched) the memory-bound builds lost up to 8 % (gain 5x5 at 8192^2 x 4; profiles/r03_batch.txt).
     [[maybe_unused]] FitArgs a_job;
     if constexpr (BATCH) {
         constexpr int FG = WPB > 1 ? 1 : 0;
@@ -655,6 +654,29 @@ fit_apply_kernel(const FitArgs a_in) {
     const bool lane_in = x >= 0 && x < W;
     const unsigned xq = lane_in ? (unsigned)x * 4u : 0u;               // load byte offset: a safe quad for lanes outside
     const unsigned xbytes = (unsigned)(x > 0 ? x : 0) * 4u;            // store byte offset (only lanes inside ever store)
+
+    // The wave's first rows are requested HERE, before the rest of the set-up (column masks, LDS ring, tables), so that their
+    // latency runs beside it: 200 instead of 410 instructions before the first load (measured neutral on every configuration,
+    // profiles/r03_early_loads.txt: the resident waves of a CU cover each other's start).
+    const int t_first = y0 - rh, t_last = y1 - 1 + rh;
+    // One row in flight: the next row's load is issued as soon as the current one has been consumed, so it lands in the
+    // same registers (no queue rotation).  A two-row queue was measured equal or slower (8 more VGPRs + 8 moves per row).
+    // The light `gain` kernel without R2 is HBM-bound (VALU 37 % busy, ~3 waves per SIMD because of the LDS ring): it keeps
+    // HK_PF_GAIN rows in flight in a small register queue (moves are free there).
+#ifndef HK_PF_GAIN
+#define HK_PF_GAIN 2  // 4 and 6 rows measured the same (2.91-2.97 ms): the wait is on the LDS ring, not on HBM latency
+#endif
+#ifndef HK_PF_BLKA
+#define HK_PF_BLKA 1  // gain-blk-offset: 2 / 3 / 4 rows in flight measured the same at 15x15 (profiles/r03_blk15_ablation.txt)
+#endif
+    constexpr int PFD = (MODEL == 0 && !R2) ? HK_PF_GAIN : ((MODEL == 1 && !R2) ? HK_PF_BLKA : 1);
+    RowRaw q0 = load_row(sp, rp, a.stride, t_first, H, xq);
+    [[maybe_unused]] RowRaw qq[PFD > 1 ? PFD - 1 : 1];
+    if constexpr (PFD > 1) {
+#pragma unroll
+        for (int d = 1; d < PFD; ++d) qq[d - 1] = load_row(sp, rp, a.stride, min(t_first + d, t_last), H, xq);
+    }
+
     const bool full_wave = __all((int)(x >= 0 && x + PX <= W));        // no column of this strip needs zeroing
     const NodataTest ts = make_nodata_test(a.src_nd_mode, a.src_nodata);
     const NodataTest tr = make_nodata_test(a.ref_nd_mode, a.ref_nodata);
@@ -697,12 +719,20 @@ fit_apply_kernel(const FitArgs a_in) {
     [[maybe_unused]] char* const xch = reinterpret_cast<char*>(lds4 + (size_t)WPB * (size_t)(ring_rows * (ring2p ? 2 : 1) * WAVE)) +
                                        (size_t)wave_in_wg * XCH_BYTES + 16 + lane * 16;
     const float ring_init = DENSE ? 0.f : __uint_as_float(RING_SENTINEL);
-    for (int sl = 0; sl < ring_rows; ++sl) {
-        if constexpr (ring2p) {
-            ring_v[(sl * 2 + 0) * WAVE + lane] = make_float4(ring_init, ring_init, ring_init, ring_init);
-            ring_v[(sl * 2 + 1) * WAVE + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
-        } else {
-            ring_v[sl * WAVE + lane] = make_float4(ring_init, ring_init, ring_init, ring_init);
+    {
+        // four registers the compiler must treat as unrelated: one ds_write_b128 per slot and plane (the vectorised form of this
+        // loop scattered four ds_write_b32 per slot and plane -- 64 LDS instructions for a 5x5 ring at the start of every wave)
+        float4 fill_s = make_float4(ring_init, ring_init, ring_init, ring_init), fill_r = make_float4(0.f, 0.f, 0.f, 0.f);
+        asm volatile("" : "+v"(fill_s.x), "+v"(fill_s.y), "+v"(fill_s.z), "+v"(fill_s.w));
+        asm volatile("" : "+v"(fill_r.x), "+v"(fill_r.y), "+v"(fill_r.z), "+v"(fill_r.w));
+#pragma clang loop vectorize(disable) unroll(disable)
+        for (int sl = 0; sl < ring_rows; ++sl) {
+            if constexpr (ring2p) {
+                ring_v[(sl * 2 + 0) * WAVE + lane] = fill_s;
+                ring_v[(sl * 2 + 1) * WAVE + lane] = fill_r;
+            } else {
+                ring_v[sl * WAVE + lane] = fill_s;
+            }
         }
     }
     // wave-uniform: bit k = the row in ring slot k is `clean` (inside the raster, every pixel of the strip valid) and is
@@ -754,25 +784,6 @@ fit_apply_kernel(const FitArgs a_in) {
 
     CS cs;
     cs.clear();
-
-    const int t_first = y0 - rh, t_last = y1 - 1 + rh;
-    // One row in flight: the next row's load is issued as soon as the current one has been consumed, so it lands in the
-    // same registers (no queue rotation).  A two-row queue was measured equal or slower (8 more VGPRs + 8 moves per row).
-    // The light `gain` kernel without R2 is HBM-bound (VALU 37 % busy, ~3 waves per SIMD because of the LDS ring): it keeps
-    // HK_PF_GAIN rows in flight in a small register queue (moves are free there).
-#ifndef HK_PF_GAIN
-#define HK_PF_GAIN 2  // 4 and 6 rows measured the same (2.91-2.97 ms): the wait is on the LDS ring, not on HBM latency
-#endif
-#ifndef HK_PF_BLKA
-#define HK_PF_BLKA 1  // gain-blk-offset: 2 / 3 / 4 rows in flight measured the same at 15x15 (profiles/r03_blk15_ablation.txt)
-#endif
-    constexpr int PFD = (MODEL == 0 && !R2) ? HK_PF_GAIN : ((MODEL == 1 && !R2) ? HK_PF_BLKA : 1);
-    RowRaw q0 = load_row(sp, rp, a.stride, t_first, H, xq);
-    [[maybe_unused]] RowRaw qq[PFD > 1 ? PFD - 1 : 1];
-    if constexpr (PFD > 1) {
-#pragma unroll
-        for (int d = 1; d < PFD; ++d) qq[d - 1] = load_row(sp, rp, a.stride, min(t_first + d, t_last), H, xq);
-    }
 
     // r2-mask bookkeeping (gain-offset with a threshold, kernel_model.py:363): R2 values are only materialised when
     // asked for; otherwise pixels are first put through a division-free CERTIFIED test
