@@ -1534,7 +1534,8 @@ int hk_block_norm_batch_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_j
         // the largest plane sizes the grid and the compaction buffers of every plane
         if ((long long)job.height * job.width > max_px) max_px = (long long)job.height * job.width, max_h = job.height, max_w = job.width;
     }
-    if (planes.size() > 65535) return fail(HK_ERR_ARG, "a batch holds at most 65535 planes");
+    // grid.y of the select passes = 2 x planes
+    if (planes.size() > 32767) return fail(HK_ERR_ARG, "a statistics batch holds at most 32767 planes (jobs x bands)");
     rc = ensure_stream_ws(ctx, sl, hk::norm_workspace_bytes((int)planes.size(), max_h, max_w));
     if (rc) return rc;
     void* tbl = nullptr;

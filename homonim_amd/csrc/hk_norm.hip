@@ -291,7 +291,10 @@ __host__ __device__ static inline int pass_waves(int height, int width) {
 // written unconditionally to the slot behind the queue's end and the end moves by the compare result, so the loop body
 // has no branch per pixel -- one wave-uniform test per 1 KB chunk asks whether any queue could overflow in the next chunk.
 // The order of the compacted values is irrelevant (the select is a histogram).
-constexpr int QCAP = 16;  // (8 slots = 4 KB of LDS per wave was measured slower, alone and beside other streams' kernels)
+#ifndef HK_NORM_QCAP
+#define HK_NORM_QCAP 16
+#endif
+constexpr int QCAP = HK_NORM_QCAP;  // (8 slots = 4 KB of LDS per wave was measured slower, alone and beside other streams' kernels)
 
 // DENSE: neither raster has a nodata value (no validity test at all); otherwise the test is branch-free: `cmp` is the
 // numeric nodata value or NaN (never equal), `nan` says that NaN is the nodata value.

@@ -302,7 +302,8 @@ int hk_block_norm_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* jo
  * hk_fit_apply_dev.  The job tables travel through a small ring of pinned staging buffers of the stream: the calls only queue
  * work.  One fused launch exists for gain-blk-offset without R2 (the block-partitioned mosaic, where it pays); for the other
  * models hk_fit_apply_batch_dev queues the jobs' launches one after the other -- the job-table look-up at the start of every
- * wave costs their short waves more than the launches it saves. */
+ * wave costs their short waves more than the launches it saves.  Limits: 65536 jobs, 32767 planes (jobs x bands) per statistics
+ * batch; the statistics workspace of the stream grows to planes x (190 KB + 8 % of the largest plane). */
 int hk_block_norm_batch_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* jobs, int32_t n_jobs, double* norm_dev);
 int hk_fit_apply_batch_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* jobs, int32_t n_jobs);
 /* hk_fail_counts_async for the jobs of a batch: their counters, job after job (sum of n_bands values), into the pinned
