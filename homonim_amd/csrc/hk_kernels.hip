@@ -21,7 +21,7 @@
 
 namespace hk {
 
-// Measurement hook (tools/README.md): timing builds with one ingredient of the fused kernel taken out --
+// Measurement hook (tools/README.md, FLOOR.md section 3): timing builds with one ingredient of the fused kernel taken out --
 // WRONG results, never shipped.  1: the leaving row is re-loaded from the entering row's address (no far re-load),
 // 2: gain-blk-offset without its float64 quotient, 4: no horizontal sums, 8: no corrected-plane stores.
 #ifndef HK_ABLATE
@@ -1545,8 +1545,8 @@ __global__ void __launch_bounds__(256) synth_kernel(float* __restrict__ src, flo
         float sv = s;
         if (nodata_variant == 5) {
             // measurement aid: LOW-ENTROPY data -- 64 source levels, the reference an exact affine image of them: few bits toggle
-            // on the wires and in the ALUs.  The instruction stream is the headline's, the energy per launch is not (DESIGN.md
-            // section 5.3).
+            // on the wires and in the ALUs.  The instruction stream is the headline's, the energy per launch is not (FLOOR.md
+            // section 2).
             sv = 0.25f + (float)(h0 & 63ull) * 0.0078125f;
             r = 1.25f * sv + 0.125f;
         }

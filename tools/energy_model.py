@@ -1,5 +1,5 @@
 """
-The energy model of DESIGN.md section 5.3, reproducible: per-ingredient energies from tools/power_phases.sh's table
+The energy model of FLOOR.md section 2, reproducible: per-ingredient energies from tools/power_phases.sh's table
 (package watts and rate per instruction class / stream, measured beside rocm-smi) + the headline's hot-path instruction mix
 (tools/dis.sh) + its PMC summary (wave count, VALU instructions, HBM bytes) -> energy per launch and the
 launch time at the package power cap.
