@@ -781,6 +781,16 @@ fit_apply_kernel(const FitArgs a_in) {
     const bool lut_ok = GO && kh * (2 * rw + 1) <= 255;
     const bool use_lut = lut_ok;
     const double* __restrict__ inv_lut = HK_INV_N.v;
+    // General gain-offset builds of the narrow kernels: window counts <= 63 are looked up in a LANE-resident copy of the table
+    // (lane n holds RN64(1/n); two ds_bpermute per pixel) instead of a global-memory gather whose latency sits in every
+    // wave-row that has a hole in reach (HK_LANE_LUT, profiles/r03_lane_lut.txt).
+#ifndef HK_LANE_LUT
+#define HK_LANE_LUT 1
+#endif
+    constexpr bool LANE_LUT = HK_LANE_LUT && GO && !DENSE && RW >= 0 && RW <= 3;
+    [[maybe_unused]] const bool lane_lut = LANE_LUT && lut_ok && kh * (2 * rw + 1) <= WAVE - 1;  // wave-uniform
+    [[maybe_unused]] double lut_lane = 0.0;
+    if constexpr (LANE_LUT) lut_lane = inv_lut[lane];
 
     CS cs;
     cs.clear();
@@ -1073,6 +1083,9 @@ fit_apply_kernel(const FitArgs a_in) {
                             if constexpr (UN) {
                                 o2.x = (float)__dmul_rn((double)tn2.x, a.inv_n_full);
                                 o2.y = (float)__dmul_rn((double)tn2.y, a.inv_n_full);
+                            } else if (LANE_LUT && lane_lut) {  // wave-uniform
+                                o2.x = (float)__dmul_rn((double)tn2.x, bperm_from<double>(lut_lane, (int)Nf2.x));
+                                o2.y = (float)__dmul_rn((double)tn2.y, bperm_from<double>(lut_lane, (int)Nf2.y));
                             } else if (use_lut) {  // wave-uniform
                                 o2.x = (float)__dmul_rn((double)tn2.x, inv_lut[(int)Nf2.x]);
                                 o2.y = (float)__dmul_rn((double)tn2.y, inv_lut[(int)Nf2.y]);
