@@ -1035,7 +1035,9 @@ fit_apply_kernel(const FitArgs a_in) {
                 constexpr bool UN = decltype(uniform_n)::value;
                 // the halo lanes only feed their neighbours' horizontal sums: masked out of the pointwise stages, they draw
                 // no power there (the kernel runs at the package's power cap; -0.6 %)
-                if (!out_lane) return;
+                // (not where 1/N comes from the lane-resident table: ds_bpermute returns 0 for a source lane that is switched off,
+                // so that version keeps every lane alive -- stores and counters are guarded by out_lane anyway)
+                if (!(LANE_LUT && !UN && lane_lut) && !out_lane) return;
                 const unsigned mcu = UN ? 0x01010101u : mc;
                 // ---- stage A: gains and offsets -------------------------------------------------------------------------
                 float g[PX], o[PX], r2v[PX], c[PX];

@@ -120,6 +120,8 @@ def test_block_norm_vs_goldens(ctx, goldens, case):
     ('gain-offset', (3, 3), True, None),
     ('gain-offset', (5, 7), True, 0.25),
     ('gain-offset', (7, 5), False, 0.25),
+    ('gain-offset', (7, 7), False, 0.25),   # window counts up to 49 from the lane-resident 1/N table; last strip: 3 live lanes
+    ('gain-offset', (9, 7), True, 0.25),    # 63 = the table's last lane
     ('gain-offset', (9, 9), True, None),
     ('gain-offset', (15, 15), True, 0.25),
     ('gain-offset', (11, 13), True, None),
