@@ -27,6 +27,9 @@ namespace hk {
 #ifndef HK_ABLATE
 #define HK_ABLATE 0
 #endif
+#ifndef HK_PACKED_NSUM
+#define HK_PACKED_NSUM 1  // window counts of the narrow kernels summed as packed bytes (fit_apply_kernel)
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------------
 // cross-lane primitives
@@ -1018,12 +1021,31 @@ fit_apply_kernel(const FitArgs a_in) {
 #pragma unroll
                         for (int i = 0; i < PX; ++i) Nf[i] = a.n_full;
                     } else {
-                        const int VN[PX] = {(int)(cs.N & 0xffu), (int)((cs.N >> 8) & 0xffu), (int)((cs.N >> 16) & 0xffu),
-                                            (int)(cs.N >> 24)};
-                        int HN[PX];
-                        hsum_any<RW, int>(VN, HN, rw, ol, lane);
+                        bool packed = false;
+                        if constexpr (HK_PACKED_NSUM && RW >= 1 && RW <= 3) {
+                            if (kh * (2 * rw + 1) <= 255) {  // wave-uniform: every window count fits a byte
+                                // the four column counts travel and add as the bytes of one word: the 2 * RW + 1 shifted views
+                                // of the 12 columns (left lane | own | right lane) are v_alignbyte_b32 of neighbouring words,
+                                // their byte-wise sum is a plain 32-bit add (no byte can carry), v_cvt_f32_ubyteN unpacks
+                                const unsigned own = cs.N;
+                                const unsigned lw = (unsigned)dpp_from_left((int)own), rw_ = (unsigned)dpp_from_right((int)own);
+                                unsigned hn = own;
 #pragma unroll
-                        for (int i = 0; i < PX; ++i) Nf[i] = (float)HN[i];
+                                for (int k = 1; k <= RW; ++k)
+                                    hn += __builtin_amdgcn_alignbyte(rw_, own, k) + __builtin_amdgcn_alignbyte(own, lw, 4 - k);
+#pragma unroll
+                                for (int i = 0; i < PX; ++i) Nf[i] = (float)((hn >> (8 * i)) & 0xffu);
+                                packed = true;
+                            }
+                        }
+                        if (!packed) {
+                            const int VN[PX] = {(int)(cs.N & 0xffu), (int)((cs.N >> 8) & 0xffu), (int)((cs.N >> 16) & 0xffu),
+                                                (int)(cs.N >> 24)};
+                            int HN[PX];
+                            hsum_any<RW, int>(VN, HN, rw, ol, lane);
+#pragma unroll
+                            for (int i = 0; i < PX; ++i) Nf[i] = (float)HN[i];
+                        }
                     }
                 }
             }
