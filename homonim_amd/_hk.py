@@ -127,6 +127,7 @@ SIGNATURES = {
     'hk_event_create': (C.c_int, [C.c_void_p, _P(C.c_void_p)]),
     'hk_event_destroy': (C.c_int, [C.c_void_p, C.c_void_p]),
     'hk_event_record': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    'hk_stream_wait_event': (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     'hk_event_elapsed_ms': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _P(C.c_float)]),
     'hk_stream_sync': (C.c_int, [C.c_void_p, C.c_int32]),
     'hk_selftest': (C.c_int, [C.c_void_p]),
@@ -656,6 +657,10 @@ class Context:
 
     def event_record(self, ev: int, stream: int = 0):
         _check(self._lib.hk_event_record(self._h, C.c_void_p(ev), stream))
+
+    def stream_wait_event(self, stream: int, ev: int):
+        """ Work queued on `stream` after this call waits (on the device) for `ev` (hk_stream_wait_event). """
+        _check(self._lib.hk_stream_wait_event(self._h, stream, C.c_void_p(ev)))
 
     def event_elapsed_ms(self, start: int, stop: int) -> float:
         ms = C.c_float(0)

@@ -365,6 +365,7 @@ int hk_stream_probe_dev(hk_ctx* ctx, const void* a, const void* b, void* out, si
 int hk_event_create(hk_ctx* ctx, hk_event** ev);
 int hk_event_destroy(hk_ctx* ctx, hk_event* ev);
 int hk_event_record(hk_ctx* ctx, hk_event* ev, int32_t stream);
+int hk_stream_wait_event(hk_ctx* ctx, int32_t stream, hk_event* ev); /* work queued on `stream` after this call waits for the event (device side) */
 int hk_event_sync(hk_ctx* ctx, hk_event* ev);  /* blocks the calling thread until the event has happened */
 int hk_event_elapsed_ms(hk_ctx* ctx, hk_event* start, hk_event* stop, float* ms); /* syncs on `stop` */
 int hk_stream_sync(hk_ctx* ctx, int32_t stream);
