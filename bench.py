@@ -563,27 +563,7 @@ def run_blocks(args, ctx, dist, rank, world):
             if group:
                 batches.append((ctx.job_array(group), group[0].norm))
 
-    # experiment (HK_BENCH_C3_PIPE=1): every batch's statistics on stream 0, its fit on stream 1 behind an event -- the
-    # statistics of batch g + 1 run beside the fit of batch g (with HK_HIGH_PRIO_STREAMS=1 stream 0 has the higher priority)
-    pipe = int(os.environ.get('HK_BENCH_C3_PIPE', '0')) and batches and args.model == 'gain-blk-offset' and n_streams >= 2
-    if pipe:
-        pipe_jobs = []
-        for arr, norm0 in batches:
-            fit_arr = ctx.job_array(list(arr))
-            for j in arr:
-                j.stream = 0
-            for j in fit_arr:
-                j.stream = 1
-            pipe_jobs.append((arr, fit_arr, norm0, ctx.event()))
-
     def step():
-        if pipe:
-            for arr, fit_arr, norm0, ev in pipe_jobs:
-                ctx.block_norm_batch_dev(desc, arr, norm0)
-                ctx.event_record(ev, 0)
-                ctx.stream_wait_event(1, ev)
-                ctx.fit_apply_batch_dev(desc, fit_arr)
-            return
         if batches:
             for arr, norm0 in batches:
                 if args.model == 'gain-blk-offset':

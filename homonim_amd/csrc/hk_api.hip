@@ -769,15 +769,8 @@ int hk_ctx_create(int device_id, int n_streams, hk_ctx** out) {
     // best across models on MI355X (gain 5x5: -12 %, gain-offset without the r2 mask: -4 %, VALU-bound variants: -1 %)
     ctx->xcd_remap = remap ? std::min(std::max(atoi(remap), 0), 256) : 16;
     if (const char* e = getenv("HK_CERT_ONLY")) ctx->cert_disabled = atoi(e) == 0;
-    // HK_HIGH_PRIO_STREAMS=k (measurement): the first k streams of the pool are created at the device's highest priority
-    int hi_streams = 0, prio_lo = 0, prio_hi = 0;
-    if (const char* e = getenv("HK_HIGH_PRIO_STREAMS")) hi_streams = atoi(e);
-    if (hi_streams > 0 && hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) hi_streams = 0;
-    int created = 0;
     for (auto& s : ctx->slots) {
-        hipError_t e = created < hi_streams ? hipStreamCreateWithPriority(&s.stream, hipStreamNonBlocking, prio_hi)
-                                            : hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
-        ++created;
+        hipError_t e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
         if (e != hipSuccess) {
             hk_ctx_destroy(ctx);
             return fail(HK_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
