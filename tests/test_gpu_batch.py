@@ -201,3 +201,40 @@ def test_batch_argument_checks(ctx):
     finally:
         for ptr in d.values():
             ctx.dev_free(ptr)
+
+
+def test_stream_wait_event_orders_two_streams(ctx):
+    """ hk_stream_wait_event: a job on stream 2 that reads what a job on stream 1 writes, ordered on the device by an event
+    (no host wait in between), equals the same two jobs on one stream. """
+    n, B = 1024, 2
+    plane = n * n
+    d = {name: ctx.dev_alloc(4 * plane * B) for name in ('src', 'ref', 'mid', 'out', 'mid1', 'out1')}
+    try:
+        ctx.synth_fill_dev(d['src'], d['ref'], B, n, n, n, plane, seed=5, nodata_variant=0, stream=0)
+        ctx.stream_sync(0)
+        desc = _hk.make_desc('gain', (5, 5), False, None, None, None)
+
+        def job(src, out, stream):
+            j = _hk.DevJob()
+            j.src, j.ref, j.corr = src, d['ref'], out
+            j.gain = j.offset = j.r2 = j.fail_count = j.norm = None
+            j.n_bands, j.height, j.width, j.stride, j.band_stride = B, n, n, n, plane
+            j.seg_rows, j.stream = 0, stream
+            return j
+        ctx.fit_apply_dev(desc, job(d['src'], d['mid1'], 3))
+        ctx.fit_apply_dev(desc, job(d['mid1'], d['out1'], 3))
+        ctx.stream_sync(3)
+        ev = ctx.event()
+        for _ in range(3):
+            ctx.fit_apply_dev(desc, job(d['src'], d['mid'], 1))
+            ctx.event_record(ev, 1)
+            ctx.stream_wait_event(2, ev)
+            ctx.fit_apply_dev(desc, job(d['mid'], d['out'], 2))
+        ctx.stream_sync(2)
+        ctx.event_destroy(ev)
+        a, b = np.empty((B, n, n), np.float32), np.empty((B, n, n), np.float32)
+        ctx.d2h(a, d['out1']), ctx.d2h(b, d['out'])
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    finally:
+        for ptr in d.values():
+            ctx.dev_free(ptr)
