@@ -238,3 +238,53 @@ def test_stream_wait_event_orders_two_streams(ctx):
     finally:
         for ptr in d.values():
             ctx.dev_free(ptr)
+
+
+def test_jobs_of_different_band_counts_and_shapes_in_one_launch(ctx):
+    """ Three unrelated rasters (1, 3 and 2 bands; different heights / widths / strides, one narrower than a strip) as one
+    gain-blk-offset batch == three separate calls: statistics and corrected planes byte for byte. """
+    shapes = [(1, 300, 1003, 1004), (3, 517, 640, 640), (2, 64, 100, 128)]   # bands, height, width, stride
+    desc = _hk.make_desc('gain-blk-offset', (5, 5), False, None, np.nan, np.nan)
+    total_bands = sum(s[0] for s in shapes)
+    norm_a, norm_b = ctx.dev_alloc(16 * total_bands), ctx.dev_alloc(16 * total_bands)
+    rasters = []
+    try:
+        b0 = 0
+        one, many = [], []
+        for i, (B, h, w, stride) in enumerate(shapes):
+            plane = h * stride
+            d = {name: ctx.dev_alloc(4 * plane * B) for name in ('src', 'ref', 'corr_a', 'corr_b')}
+            rasters.append((d, B, h, w, stride))
+            ctx.synth_fill_dev(d['src'], d['ref'], B, h, w, stride, plane, seed=40 + i, nodata_variant=1, stream=0)
+            ctx.memset(d['corr_a'], 0xff, 4 * plane * B), ctx.memset(d['corr_b'], 0xff, 4 * plane * B)
+            for lst, out, norm, stream in ((one, 'corr_a', norm_a, 1), (many, 'corr_b', norm_b, 2)):
+                j = _hk.DevJob()
+                j.src, j.ref, j.corr = d['src'], d['ref'], d[out]
+                j.gain = j.offset = j.r2 = j.fail_count = None
+                j.norm = norm + 16 * b0
+                j.n_bands, j.height, j.width, j.stride, j.band_stride = B, h, w, stride, plane
+                j.seg_rows, j.stream = 0, stream
+                lst.append(j)
+            b0 += B
+        ctx.stream_sync(0)
+        for j in one:
+            ctx.block_norm_dev(desc, j, j.norm)
+            ctx.fit_apply_dev(desc, j)
+        ctx.stream_sync(1)
+        arr = ctx.job_array(many)
+        ctx.block_norm_batch_dev(desc, arr, norm_b)
+        ctx.fit_apply_batch_dev(desc, arr)
+        ctx.stream_sync(2)
+        na, nb = np.zeros((total_bands, 2)), np.zeros((total_bands, 2))
+        ctx.d2h(na, norm_a), ctx.d2h(nb, norm_b)
+        assert np.isfinite(na).all() and np.array_equal(na.view(np.uint64), nb.view(np.uint64))
+        for d, B, h, w, stride in rasters:
+            a, b = np.empty((B, h, stride), np.float32), np.empty((B, h, stride), np.float32)
+            ctx.d2h(a, d['corr_a']), ctx.d2h(b, d['corr_b'])
+            assert np.isfinite(a[:, 8:-8, 8:w - 8]).any()
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (B, h, w)
+    finally:
+        for d, *_ in rasters:
+            for ptr in d.values():
+                ctx.dev_free(ptr)
+        ctx.dev_free(norm_a), ctx.dev_free(norm_b)
