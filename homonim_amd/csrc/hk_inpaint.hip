@@ -14,6 +14,8 @@
 // thread per (column, row chunk) for the scans and one thread per pixel for the search.
 #include "hk_kernels.h"
 
+#include <stdlib.h>
+
 #include <type_traits>
 
 namespace hk {
@@ -122,60 +124,28 @@ __device__ __forceinline__ int isqrt_floor(int n) {
     return r;
 }
 
-// 8 waves per SIMD: the step from 6 to 8 resident waves was worth 8 % of the whole in-painting branch while the search was
-// bound by dependent look-ups.  With the column table as one 16-bit word per pixel it is bound by its VALU instructions
-// (PMC: busy 90-100 %); hence the lean candidate test below: per quadrant the state is the best squared distance and one packed
-// word (column distance << 8 | row distance), a candidate costs ~8 instructions.  (A second copy of the loop for wave-rows
-// away from the raster's edges, with scalar column distances and unclamped look-ups, cost 18 more VGPRs than it saved
-// instructions.)
-#ifndef HK_FILL_WAVES_FULL
-#define HK_FILL_WAVES_FULL 8
-#endif
-template <bool PACK>
-__global__ void __launch_bounds__(256, PACK ? 8 : HK_FILL_WAVES_FULL) inpaint_fill_kernel(const float* __restrict__ offset, const unsigned char* __restrict__ flag,
-                                                           long long stride, int height, int width, int max_dist,
-                                                           const unsigned short* __restrict__ tb,
-                                                           const unsigned* __restrict__ tie,
-                                                           const double* __restrict__ wtab, float* __restrict__ filled) {
-    // Only target pixels search.  PACK (moderate failure rates: the targets are a minority scattered over the lanes): the
-    // workgroup first passes its sources through and COMPACTS its targets (ballot + a 4-entry prefix in LDS), then thread t
-    // searches for target t -- full waves instead of a third of the lanes in every wave (-12 % of the branch at 35 %
-    // failures).  When nearly every pixel is a target the packing only costs its barriers (+3 % at 94 %): the host picks.
-    __shared__ unsigned short lst[PACK ? 256 : 1];
-    __shared__ unsigned wcnt[256 / WAVE];
-    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
-    const int x_own = blockIdx.x * blockDim.x + tid;
-    if constexpr (!PACK) {
-        if (x_own >= width) return;
-    }
-    for (int y = blockIdx.y; y < height; y += gridDim.y) {  // grid-stride over rows: blocks taller than 65535 rows are fine
-    const long long row = (long long)y * stride;
-    bool target = false;
-    if (x_own < width) {
-        target = !flag[row + x_own];
-        if (!target) filled[row + x_own] = offset[row + x_own];  // filled pixels never act as sources: sources pass through
-    }
-    bool active = target;
-    int x = x_own;
-    // (without the compaction x is the same in every row of the loop: keep the compiler from hoisting the per-step edge
-    // distances and conditions out of it -- 89 VGPRs instead of 52, i.e. spills at 8 waves per SIMD)
-    asm volatile("" : "+v"(x));
-    if constexpr (PACK) {
-        const unsigned long long bal = __ballot(target);
-        if (lane == 0) wcnt[wv] = (unsigned)__popcll(bal);
-        __syncthreads();
-        unsigned base = 0, n_targets = 0;
+__device__ __forceinline__ void fill_load_d0(const unsigned short* __restrict__ trow, int x, int width, unsigned (&d0)[5]) {
+    struct __attribute__((packed, aligned(2))) W5 { unsigned w[5]; };
+    if (x - 4 >= 0 && x + 5 < width) {
+        const W5 v = *reinterpret_cast<const W5*>(trow + x - 4);
 #pragma unroll
-        for (int w = 0; w < 256 / WAVE; ++w) {
-            base += w < wv ? wcnt[w] : 0u;
-            n_targets += wcnt[w];
+        for (int j = 0; j < 5; ++j) d0[j] = v.w[j];
+    } else {  // GDAL's clamp: it re-checks the edge column
+#pragma unroll
+        for (int j = 0; j < 5; ++j) d0[j] = 0u;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const int col = j < 4 ? max(0, x - 4 + j) : min(width - 1, x - 4 + j);
+            d0[j >> 1] |= (unsigned)trow[col] << ((j & 1) * 16);
         }
-        if (target) lst[base + (unsigned)__popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)tid;
-        __syncthreads();
-        active = tid < (int)n_targets;
-        if (active) x = blockIdx.x * blockDim.x + lst[tid];
     }
-    if (active) {
+}
+
+// The search of ONE target pixel (x, y): GDAL's quadrant search through the column tables, then the inverse-distance mean of the
+// quadrants' sources.  Returns the filled value (the pixel's own value if no source is in reach).
+__device__ __forceinline__ float fill_one(int x, int y, long long row, const float* __restrict__ offset, long long stride, int width,
+                                          int max_dist, const unsigned short* __restrict__ tb, const unsigned* __restrict__ tie,
+                                          const double* __restrict__ wtab) {
         const long long i = row + x;
         float out = offset[i];  // a target without any source in reach keeps its value
         const int none2 = (max_dist + 1) * (max_dist + 1);  // qd = max_dist + 1: "nothing found yet" (a perfect square: no tie)
@@ -202,25 +172,12 @@ __global__ void __launch_bounds__(256, PACK ? 8 : HK_FILL_WAVES_FULL) inpaint_fi
         // Lanes whose group reaches past the raster's edge columns assemble the same words entry by entry with GDAL's clamp
         // (it re-checks the edge column).
         {
-            struct __attribute__((packed, aligned(2))) W5 { unsigned w[5]; };
             struct __attribute__((packed, aligned(2))) W2 { unsigned w[2]; };
             // entry j (0-based) of a packed run of 16-bit table words: (down << 8) | up
             auto up = [](const unsigned* d, int j) { return (d[j >> 1] >> ((j & 1) * 16)) & 0xffu; };
             auto dn = [](const unsigned* d, int j) { return (d[j >> 1] >> ((j & 1) * 16 + 8)) & 0xffu; };
             unsigned d0[5];                  // entries 0..9 <-> columns x - 4 .. x + 5 (steps 0..4: left step k = entry 4 - k, right = 4 + k)
-            if (x - 4 >= 0 && x + 5 < width) {
-                const W5 v = *reinterpret_cast<const W5*>(trow + x - 4);
-#pragma unroll
-                for (int j = 0; j < 5; ++j) d0[j] = v.w[j];
-            } else {
-#pragma unroll
-                for (int j = 0; j < 5; ++j) d0[j] = 0u;
-#pragma unroll
-                for (int j = 0; j < 9; ++j) {
-                    const int col = j < 4 ? max(0, x - 4 + j) : min(width - 1, x - 4 + j);
-                    d0[j >> 1] |= (unsigned)trow[col] << ((j & 1) * 16);
-                }
-            }
+            fill_load_d0(trow, x, width, d0);
             // later groups (steps first .. first + 3): left entries 0..3 <-> columns x - first - 3 .. x - first (step first + k = entry
             // 3 - k), right entries 0..3 <-> columns x + first .. x + first + 3 (step first + k = entry k)
             auto fetch4 = [&](int first, unsigned (&l)[2], unsigned (&r)[2]) {
@@ -284,7 +241,7 @@ __global__ void __launch_bounds__(256, PACK ? 8 : HK_FILL_WAVES_FULL) inpaint_fi
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             if (qd2[q] <= max_dist * max_dist) {  // qd <= max_dist
-                const double w = wtab[qd2[q]];
+                const double w = wtab[qd2[q]];  // (an LDS copy of the table's head for the tiled kernel: no difference)
                 has = w != 0.0;
                 wsum += w;
                 const int dx = (int)(qs[q] >> 8), dy = (int)(qs[q] & 0xffu);
@@ -293,8 +250,120 @@ __global__ void __launch_bounds__(256, PACK ? 8 : HK_FILL_WAVES_FULL) inpaint_fi
             }
         }
         if (has) out = (float)(vsum / wsum);
-        filled[i] = out;
+        return out;
+}
+
+// 8 waves per SIMD: the step from 6 to 8 resident waves was worth 8 % of the whole in-painting branch while the search was
+// bound by dependent look-ups.  With the column table as one 16-bit word per pixel it is bound by its VALU instructions
+// (PMC: busy 90-100 %); hence the lean candidate test below: per quadrant the state is the best squared distance and one packed
+// word (column distance << 8 | row distance), a candidate costs ~8 instructions.  (A second copy of the loop for wave-rows
+// away from the raster's edges, with scalar column distances and unclamped look-ups, cost 18 more VGPRs than it saved
+// instructions.)
+#ifndef HK_FILL_WAVES_FULL
+#define HK_FILL_WAVES_FULL 8
+#endif
+template <bool PACK>
+__global__ void __launch_bounds__(256, PACK ? 8 : HK_FILL_WAVES_FULL) inpaint_fill_kernel(const float* __restrict__ offset, const unsigned char* __restrict__ flag,
+                                                           long long stride, int height, int width, int max_dist,
+                                                           const unsigned short* __restrict__ tb,
+                                                           const unsigned* __restrict__ tie,
+                                                           const double* __restrict__ wtab, float* __restrict__ filled) {
+    // Only target pixels search.  PACK (moderate failure rates: the targets are a minority scattered over the lanes): the
+    // workgroup first passes its sources through and COMPACTS its targets (ballot + a 4-entry prefix in LDS), then thread t
+    // searches for target t -- full waves instead of a third of the lanes in every wave (-12 % of the branch at 35 %
+    // failures).  When nearly every pixel is a target the packing only costs its barriers (+3 % at 94 %): the host picks.
+    __shared__ unsigned short lst[PACK ? 256 : 1];
+    __shared__ unsigned wcnt[256 / WAVE];
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
+    const int x_own = blockIdx.x * blockDim.x + tid;
+    if constexpr (!PACK) {
+        if (x_own >= width) return;
     }
+    for (int y = blockIdx.y; y < height; y += gridDim.y) {  // grid-stride over rows: blocks taller than 65535 rows are fine
+    const long long row = (long long)y * stride;
+    bool target = false;
+    if (x_own < width) {
+        target = !flag[row + x_own];
+        if (!target) filled[row + x_own] = offset[row + x_own];  // filled pixels never act as sources: sources pass through
+    }
+    bool active = target;
+    int x = x_own;
+    // (without the compaction x is the same in every row of the loop: keep the compiler from hoisting the per-step edge
+    // distances and conditions out of it -- 89 VGPRs instead of 52, i.e. spills at 8 waves per SIMD)
+    asm volatile("" : "+v"(x));
+    if constexpr (PACK) {
+        const unsigned long long bal = __ballot(target);
+        if (lane == 0) wcnt[wv] = (unsigned)__popcll(bal);
+        __syncthreads();
+        unsigned base = 0, n_targets = 0;
+#pragma unroll
+        for (int w = 0; w < 256 / WAVE; ++w) {
+            base += w < wv ? wcnt[w] : 0u;
+            n_targets += wcnt[w];
+        }
+        if (target) lst[base + (unsigned)__popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)tid;
+        __syncthreads();
+        active = tid < (int)n_targets;
+        if (active) x = blockIdx.x * blockDim.x + lst[tid];
+    }
+    if (active) filled[row + x] = fill_one(x, y, row, offset, stride, width, max_dist, tb, tie, wtab);
+    }
+}
+
+// TILED form of the search (round 3): a wave owns a tile of 64 columns x ROWS rows.  The per-row form above starts a workgroup per
+// 256-pixel row piece, and each lives for three dependent memory round trips (flag -> compaction behind two barriers -> table
+// words -> source values): PMC showed its waves WAITING 76 % of their 4.7 us life with the VALU 58 % busy.  Here a wave reads the
+// flags of its whole tile at once, passes the sources through, compacts the tile's targets into a wave-private LDS list (ballot +
+// popcount, no workgroup barrier) and then searches 64 targets per pass -- full waves whatever the failure rate, one wave start per
+// ROWS rows, and the passes of the resident waves overlap each other's look-ups.
+#ifndef HK_FILL_TILE_WAVES
+#define HK_FILL_TILE_WAVES 8
+#endif
+template <int ROWS>
+__global__ void __launch_bounds__(256, HK_FILL_TILE_WAVES) inpaint_fill_tile_kernel(const float* __restrict__ offset, const unsigned char* __restrict__ flag,
+                                                                   long long stride, int height, int width, int max_dist,
+                                                                   const unsigned short* __restrict__ tb,
+                                                                   const unsigned* __restrict__ tie,
+                                                                   const double* __restrict__ wtab, float* __restrict__ filled) {
+    static_assert(ROWS <= 64, "a list entry packs the tile row beside the lane; the row masks are 64-bit");
+    __shared__ unsigned short lst[256 / WAVE][ROWS * WAVE];
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
+    const int x0 = blockIdx.x * blockDim.x + wv * WAVE, x_own = x0 + lane;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const int n_tiles = (height + ROWS - 1) / ROWS;
+    for (int tile = blockIdx.y; tile < n_tiles; tile += gridDim.y) {
+        const int y0 = tile * ROWS;
+        // flags of the whole tile: ROWS independent byte loads per lane, kept as two bit masks (bit r = row y0 + r)
+        unsigned long long src_rows = 0ull, tgt_rows = 0ull;
+#pragma unroll 8
+        for (int r = 0; r < ROWS; ++r) {
+            const bool in = x_own < width && y0 + r < height;
+            const unsigned char f = in ? flag[(long long)(y0 + r) * stride + x_own] : (unsigned char)2;  // 2: outside the raster
+            src_rows |= (unsigned long long)(f == 1) << r;
+            tgt_rows |= (unsigned long long)(f == 0) << r;
+        }
+        int n = 0;  // wave-uniform: targets of the tile so far
+#pragma unroll 4
+        for (int r = 0; r < ROWS; ++r) {
+            const long long i = (long long)(y0 + r) * stride + x_own;
+            if ((src_rows >> r) & 1ull) filled[i] = offset[i];  // filled pixels never act as sources: sources pass through
+            const bool target = (tgt_rows >> r) & 1ull;
+            const unsigned long long bal = __ballot(target);
+            if (target) lst[wv][n + (int)__popcll(bal & lt)] = (unsigned short)((r << 6) | lane);
+            n += (int)__popcll(bal);
+        }
+        __syncthreads();  // (the list is the wave's own; the barrier only orders its LDS writes before the reads below)
+        // passes of 64 targets (an explicit request of pass p + 1's first look-ups while pass p searches was measured slower:
+        // 21.7 against 21.2 ms per step, profiles/r03_fill_tile.txt)
+        for (int p = 0; p < n; p += WAVE) {
+            if (p + lane < n) {
+                const unsigned e = lst[wv][p + lane];
+                const int x = x0 + (int)(e & 63u), y = y0 + (int)(e >> 6);
+                const long long row = (long long)y * stride;
+                filled[row + x] = fill_one(x, y, row, offset, stride, width, max_dist, tb, tie, wtab);
+            }
+        }
+        __syncthreads();  // the next tile re-uses the list
     }
 }
 
@@ -332,8 +401,30 @@ hipError_t launch_inpaint_offsets(const float* offset, const float* gain, const 
     hipLaunchKernelGGL(inpaint_bits_kernel, gwords, dim3(256), 0, stream, flag, stride, height, width, bits);
     hipLaunchKernelGGL(inpaint_table_kernel, gwords, dim3(256), 0, stream, bits, stride, height, width, max_dist, tb);
     const dim3 gfill((width + 255) / 256, height < 65535 ? height : 65535);
-    // n_targets: the number of pixels to fill as the caller knows it (the r2-mask failure count; 0 = unknown)
-    if (n_targets == 0 || (double)n_targets < 0.6 * (double)height * (double)width)
+    // n_targets: the number of pixels to fill as the caller knows it (the r2-mask failure count; 0 = unknown).  Moderate failure
+    // rates take the TILED search (64 columns x 32 rows per wave: 23.3 -> 21.2 ms per step at 35 % failures; 16 rows 21.4, 64 rows
+    // 27.1, profiles/r03_fill_tile.txt); when nearly every pixel is a target the plain one-thread-per-pixel form is faster (41.8
+    // against 48.5 ms at 94 %).  HK_FILL_TILE=0 selects the per-row compacting form of rounds 1-2 (A/B), 4..64 another tile height.
+    static const int tile_env = [] { const char* e = getenv("HK_FILL_TILE"); return e ? atoi(e) : -1; }();
+    const bool moderate = n_targets == 0 || (double)n_targets < 0.6 * (double)height * (double)width;
+    const int tile_rows = tile_env >= 0 ? tile_env : 32;
+    if (moderate && tile_rows > 0) {
+        const int rows = tile_rows >= 64 ? 64 : (tile_rows >= 32 ? 32 : (tile_rows >= 16 ? 16 : (tile_rows >= 8 ? 8 : 4)));
+        const int n_tiles = (height + rows - 1) / rows;
+        const dim3 gt((width + 255) / 256, n_tiles < 65535 ? n_tiles : 65535);
+        if (rows == 64)
+            hipLaunchKernelGGL(inpaint_fill_tile_kernel<64>, gt, dim3(256), 0, stream, offset, flag, stride, height, width, max_dist, tb, tie, wtab, filled);
+        else if (rows == 32)
+            hipLaunchKernelGGL(inpaint_fill_tile_kernel<32>, gt, dim3(256), 0, stream, offset, flag, stride, height, width, max_dist, tb, tie, wtab, filled);
+        else if (rows == 16)
+            hipLaunchKernelGGL(inpaint_fill_tile_kernel<16>, gt, dim3(256), 0, stream, offset, flag, stride, height, width, max_dist, tb, tie, wtab, filled);
+        else if (rows == 8)
+            hipLaunchKernelGGL(inpaint_fill_tile_kernel<8>, gt, dim3(256), 0, stream, offset, flag, stride, height, width, max_dist, tb, tie, wtab, filled);
+        else
+            hipLaunchKernelGGL(inpaint_fill_tile_kernel<4>, gt, dim3(256), 0, stream, offset, flag, stride, height, width, max_dist, tb, tie, wtab, filled);
+        return hipGetLastError();
+    }
+    if (moderate)
         hipLaunchKernelGGL(inpaint_fill_kernel<true>, gfill, dim3(256), 0, stream, offset, flag, stride, height, width, max_dist,
                            tb, tie, wtab, filled);
     else
