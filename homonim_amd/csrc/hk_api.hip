@@ -288,6 +288,19 @@ static int env_int_early(const char* name, int dflt) {
     return e ? atoi(e) : dflt;
 }
 
+// kappa_f <= 1 - c_hi * (1 + 2^-50) with c_hi = r2_fail_above(): `g^2 den < kappa_f * sstot - (rounding slack)` then gives
+// ssres > c_hi * sstot in real arithmetic with room for the float64 comparison, i.e. the reference's decision is False
+// (PROOFS.md appendix A, the fail side).  Rounded DOWN to float32; -inf = failure is never certified that way.
+float r2_failcert_scale(float thresh) {
+    const double c_hi = r2_fail_above(thresh);
+    if (!(c_hi > 0.0) || std::isinf(c_hi)) return -INFINITY;
+    const double k = 1.0 - c_hi * (1.0 + 0x1p-50);
+    if (!(k > 0.0)) return -INFINITY;
+    float kf = (float)k;
+    if ((double)kf > k - 0x1p-60) kf = nextafterf(kf, -INFINITY);
+    return kf;
+}
+
 void fill_args(hk::FitArgs& a, const hk_fit_desc* d, int xcd_remap) {
     a.rh = d->kh / 2;
     a.rw = d->kw / 2;
@@ -299,6 +312,7 @@ void fill_args(hk::FitArgs& a, const hk_fit_desc* d, int xcd_remap) {
     a.has_thresh = (d->model == HK_MODEL_GAIN_OFFSET) ? d->has_r2_thresh : 0;
     a.r2_thresh = d->r2_thresh;
     a.r2_fail_scale = a.has_thresh ? r2_fail_scale(d->r2_thresh) : INFINITY;
+    a.r2_failcert_scale = (a.has_thresh && env_int_early("HK_FAIL_CERT", 1)) ? r2_failcert_scale(d->r2_thresh) : -INFINITY;
     a.r2_pass_below = a.has_thresh ? r2_pass_scale(d->r2_thresh) : -INFINITY;
     a.r2_fail_above = a.has_thresh ? r2_fail_above(d->r2_thresh) : INFINITY;
     a.n_full = (float)(d->kh * d->kw);

@@ -70,6 +70,7 @@ struct FitArgs {
     int cert_only;          // gain-offset + r2 mask, no R2 plane, fail_count set: run the certificate-only build, which
                             // ORs FIT_RETRY_BIT into fail_count[band] when the band has to be re-run (launch_one)
     float r2_fail_scale;    // kappa of the division-free r2-mask certificate: 1 - r2_pass_scale(), rounded up (hk_api.hip)
+    float r2_failcert_scale;  // kappa_f of its mirror image (certain FAILURE; complete build): 1 - r2_fail_above(), rounded down; -inf: none
     double r2_pass_below;   // exact evaluation without R2 output: ssres < r2_pass_below * sstot proves the r2 test true,
     double r2_fail_above;   // ssres > r2_fail_above * sstot proves it false (sstot > 0); in between the division decides
     float n_full;           // kh * kw: the window count of every pixel away from the raster's edges (dense kernels)

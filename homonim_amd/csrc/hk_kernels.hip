@@ -1068,6 +1068,7 @@ fit_apply_kernel(const FitArgs a_in) {
                 // float32 CERTIFICATE below, evaluated right behind each pixel pair's gain while its operands are in
                 // registers; the reference's own R2 expression (stage B) runs only if a pixel stays uncertain
                 [[maybe_unused]] bool try_cert = false, uncertain = false;
+                [[maybe_unused]] unsigned cert_failed = 0u;  // complete build: byte i = 0xff where pixel i is certified FAILING
                 if constexpr (GO && R2) {
                     if (count_fails && !want_r2_values) {  // wave-uniform
                         if (!CERT_ONLY && cert_skip > 0) --cert_skip;  // the rows just above needed the exact evaluation: go straight to it
@@ -1137,6 +1138,13 @@ fit_apply_kernel(const FitArgs a_in) {
                                     const f2 NT = pk_fma(t2, t2, pk_fma(tn2, tn2, pk_fma(Nf2, R2f, lhs)));
                                     const f2 slack = NT * 0x1p-17f;
                                     const f2 rhs = pk_fma(f2{a.r2_fail_scale, a.r2_fail_scale}, sst, slack);
+                                    // The mirror image (complete build; appendix A, "the fail side"): a pixel certainly FAILS if
+                                    // its gain -- bit-exact -- is not positive, or if 0 < lhs < kappa_f * sst - slack.  A wave-row
+                                    // whose every valid pixel is certain one way or the other needs no exact evaluation either:
+                                    // on rasters with failing pixels (real imagery has them block after block) that is nearly
+                                    // every row.
+                                    [[maybe_unused]] f2 rhs_f;
+                                    if constexpr (!CERT_ONLY) rhs_f = pk_fma(f2{a.r2_failcert_scale, a.r2_failcert_scale}, sst, -slack);
 #pragma unroll
                                     for (int e = 0; e < 2; ++e) {
                                         const bool m = (mcu >> (8 * (2 * j + e))) & 1u;
@@ -1145,9 +1153,21 @@ fit_apply_kernel(const FitArgs a_in) {
                                         // 2^-20 < g < 2^20 (also the `gain > 0` half of the decision), 2^-40 < N*T' < 2^60;
                                         // a masked pixel's quantities are arbitrary and must not count
                                         const unsigned gd = __float_as_uint(g2[e]) - 0x35800000u, td = __float_as_uint(NT[e]) - 0x2b800000u;
-                                        gwin = max(gwin, UN ? gd : (m ? gd : 0u));
-                                        twin = max(twin, UN ? td : (m ? td : 0u));
-                                        uncertain |= m & !sure;
+                                        if constexpr (CERT_ONLY) {
+                                            gwin = max(gwin, UN ? gd : (m ? gd : 0u));
+                                            twin = max(twin, UN ? td : (m ? td : 0u));
+                                            uncertain |= m & !sure;
+                                        } else {
+                                            // a pixel whose gain is not positive (or NaN) fails whatever its R2: no error model,
+                                            // no window needed for it
+                                            const bool gpos = g2[e] > 0.f;
+                                            const bool sure_f = !gpos | ((lhs[e] < rhs_f[e]) & (lhs[e] > 0.f) & (sst[e] > slack[e]));
+                                            const bool mg = UN ? gpos : (m & gpos);
+                                            gwin = max(gwin, mg ? gd : 0u);
+                                            twin = max(twin, mg ? td : 0u);
+                                            uncertain |= m & !((sure & gpos) | sure_f);
+                                            cert_failed |= ((m & sure_f) ? 0xffu : 0u) << (8 * (2 * j + e));
+                                        }
                                     }
                                 }
                             }
@@ -1194,6 +1214,12 @@ fit_apply_kernel(const FitArgs a_in) {
                             if (try_cert) {
                                 exact = __any(uncertain);
                                 if (exact) cert_skip = HK_CERT_SKIP;  // failing regions are coherent: skip the certificate for a few rows
+                                if constexpr (!CERT_ONLY) {
+                                    if (!exact) {  // every valid pixel of the wave-row is certified: the failing ones are known
+                                        passed &= ~cert_failed;
+                                        if (out_lane) nfail += (unsigned)__popc(cert_failed & 0x01010101u);
+                                    }
+                                }
                             }
                         }
                         if constexpr (CERT_ONLY) {

@@ -66,6 +66,49 @@ def certificate(q, kappa, k2=F32(2.0 ** -17), r2_rel_err=0.0):
         return (lhs > rhs) & (sst > slack) & g_in & t_in
 
 
+def fail_certificate(q, kappa_f, k2=F32(2.0 ** -17)):
+    """ The mirror image (complete build only, PROOFS.md appendix A, "the fail side"): a pixel certainly FAILS
+    `(r2 > thresh) & (gain > 0)` if its gain is not positive (the gain is bit-exact), or if
+    0 < fl32(g * num) < kappa_f * sst - 2^-17 * N*T' with sst > 2^-17 * N*T' inside the same magnitude windows. """
+    g, nf, rf = q['g'], q['n'], q['rf']
+    with np.errstate(all='ignore'):
+        r2f = q['hr2'].astype(F32)
+        nfull = np.full_like(r2f, nf)
+        lhs = (g * q['num']).astype(F32)
+        sst = _fma32(nfull, r2f, -(rf * rf).astype(F32))
+        nt = _fma32(q['t'], q['t'], _fma32(q['tn'], q['tn'], _fma32(nfull, r2f, lhs)))
+        slack = (k2 * nt).astype(F32)
+        rhs_f = _fma32(np.full_like(sst, kappa_f), sst, -slack)
+        g_in = (g > F32(2.0 ** -20)) & (g < F32(2.0 ** 20))
+        t_in = (nt > F32(2.0 ** -40)) & (nt < F32(2.0 ** 60))
+        gpos = g > 0
+        return ~gpos | ((lhs < rhs_f) & (lhs > 0) & (sst > slack) & g_in & t_in)
+
+
+def kappa_fail_for(thresh):
+    """ Mirror of hk_api.hip r2_failcert_scale(): 1 - c_hi rounded DOWN to float32 (c_hi = r2_fail_above, 2^-40 above the float32
+    rounding boundary of the quotient), -inf where failure cannot be certified. """
+    t = F32(thresh)
+    if not (t < 1):
+        return F32(-np.inf)
+    q = F32(1) - t
+    for _ in range(8):
+        q = np.nextafter(q, F32(np.inf))
+    while not (F32(1) - q > t):
+        q = np.nextafter(q, F32(-np.inf))
+    boundary = 0.5 * (float(q) + float(np.nextafter(q, F32(np.inf))))
+    if not boundary > 0:
+        return F32(-np.inf)
+    c_hi = boundary * (1 + 2.0 ** -40)
+    k = 1 - c_hi * (1 + 2.0 ** -50)
+    if not k > 0:
+        return F32(-np.inf)
+    kf = F32(k)
+    if float(kf) > k - 2.0 ** -60:
+        kf = np.nextafter(kf, F32(-np.inf))
+    return kf
+
+
 def fast_quotient(num, den):
     """ Model of hk_kernels.hip fast_quot() + quot_guard(): float32(RN64(num/den)) from a reciprocal of relative error
     <= 2^-22 and one Newton step; returns (float32 result, needs_ieee_division). """
@@ -120,6 +163,9 @@ def _windows(rng, m, n, kind):
     elif kind == 'marginal':
         s = rng.normal(100, 10, (m, n))
         r = s + 10 ** rng.uniform(0.5, 1.6, (m, 1)) * rng.normal(size=(m, n))
+    elif kind == 'noisy':   # what bench.py --nodata 3 / 4 look like: weak correlation, many windows fail the r2 mask
+        s = rng.uniform(0.05, 1, (m, n))
+        r = 1.2 * s + 0.05 + rng.normal(0, 10 ** rng.uniform(-1.5, 0.3, (m, 1)), (m, n))
     elif kind == 'int':
         s = rng.integers(0, 255, (m, n)).astype(float)
         r = rng.integers(0, 4, (m, n)) + np.round(s * rng.uniform(0.3, 2, (m, 1)))
@@ -146,6 +192,41 @@ def test_certificate_never_contradicts_the_reference_arithmetic(kind, n):
             assert not (certificate(q, kappa_for(thresh), r2_rel_err=err) & ~passes).any()
     if kind in ('synth', 'int') and n >= 9:
         assert n_cert > 0.5 * 4 * len(s)   # and it is not vacuous: well-conditioned data is certified
+
+
+@pytest.mark.parametrize('kind', ['synth', 'lowvar', 'wild', 'marginal', 'int', 'noisy'])
+@pytest.mark.parametrize('n', [2, 9, 25, 225])
+def test_fail_certificate_never_contradicts_the_reference_arithmetic(kind, n):
+    """ The fail side: wherever it says "certainly fails", the reference's arithmetic says (r2 > thresh) & (gain > 0) is False;
+    and it never coincides with the pass certificate. """
+    rng = np.random.default_rng(zlib.crc32(f'fail{kind}{n}'.encode()))
+    s, r = _windows(rng, 120_000 if n < 100 else 30_000, n, kind)
+    q = reference_window_math(s, r)
+    n_cert = n_fail = 0
+    for thresh in (0.0, 0.25, 0.5, 0.9, 0.999):
+        sure_f = fail_certificate(q, kappa_fail_for(thresh))
+        sure_p = certificate(q, kappa_for(thresh))
+        with np.errstate(all='ignore'):
+            passes = (q['r2'] > F32(thresh)) & (q['g'] > 0)
+        assert not (sure_f & passes).any()
+        assert not (sure_f & sure_p).any()
+        n_cert += int(sure_f.sum())
+        n_fail += int((~passes).sum())
+    if kind in ('noisy', 'marginal') and n >= 9:
+        assert n_cert > 0.9 * n_fail   # not vacuous: nearly every failing window is certified
+
+
+def test_the_data_probes_the_fail_bound():
+    rng = np.random.default_rng(15)
+    s, r = _windows(rng, 400_000, 25, 'lowvar')
+    q = reference_window_math(s, r)
+    with np.errstate(all='ignore'):
+        passes = (q['r2'] > F32(0.25)) & (q['g'] > 0)
+    kf = kappa_fail_for(0.25)
+    assert (fail_certificate(q, kf, F32(2.0 ** -24)) & passes).sum() > 0
+    assert (fail_certificate(q, kf, F32(2.0 ** -22)) & passes).sum() == 0
+    assert (fail_certificate(q, kf) & passes).sum() == 0
+    assert not (fail_certificate(q, F32(-np.inf)) & (q['g'] > 0)).any()   # thresh >= 1: only non-positive gains are certain
 
 
 def test_the_data_probes_the_bound():
