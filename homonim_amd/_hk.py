@@ -116,6 +116,7 @@ SIGNATURES = {
     'hk_fail_counts_async': (C.c_int, [C.c_void_p, _P(DevJob), _P(C.c_uint64), C.c_void_p]),
     'hk_inpaint_dev_counts': (C.c_int, [C.c_void_p, _P(FitDesc), _P(DevJob), _P(C.c_uint64), _P(C.c_uint64)]),
     'hk_event_sync': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'hk_r2_certificate_constants': (C.c_int, [C.c_float, _P(C.c_double), _P(C.c_double), _P(C.c_float), _P(C.c_float)]),
     'hk_block_norm_dev': (C.c_int, [C.c_void_p, _P(FitDesc), _P(DevJob), C.c_void_p]),
     'hk_block_norm_batch_dev': (C.c_int, [C.c_void_p, _P(FitDesc), _P(DevJob), C.c_int32, C.c_void_p]),
     'hk_fit_apply_batch_dev': (C.c_int, [C.c_void_p, _P(FitDesc), _P(DevJob), C.c_int32]),
@@ -134,6 +135,13 @@ SIGNATURES = {
 }  # yapf: disable
 
 COMM_ID_BYTES = 128   # HK_COMM_ID_BYTES = sizeof(ncclUniqueId)
+
+
+def r2_certificate_constants(thresh: float):
+    """ (pass_below, fail_above, kappa, kappa_fail) of the r2-mask decision for `thresh` (hk_r2_certificate_constants; host-only). """
+    pb, fa, k, kf = C.c_double(), C.c_double(), C.c_float(), C.c_float()
+    _check(load_library().hk_r2_certificate_constants(C.c_float(thresh), C.byref(pb), C.byref(fa), C.byref(k), C.byref(kf)))
+    return pb.value, fa.value, k.value, kf.value
 
 
 def comm_unique_id() -> bytes:

@@ -1279,6 +1279,14 @@ int hk_fail_counts_async(hk_ctx* ctx, const hk_dev_job* job, uint64_t* host_coun
     return HK_OK;
 }
 
+int hk_r2_certificate_constants(float thresh, double* pass_below, double* fail_above, float* kappa, float* kappa_fail) {
+    if (pass_below) *pass_below = r2_pass_scale(thresh);
+    if (fail_above) *fail_above = r2_fail_above(thresh);
+    if (kappa) *kappa = r2_fail_scale(thresh);
+    if (kappa_fail) *kappa_fail = r2_failcert_scale(thresh);
+    return HK_OK;
+}
+
 int hk_counts_pending(const uint64_t* counts, int32_t n_bands) {
     if (!counts) return 0;
     for (int32_t b = 0; b < n_bands; ++b)

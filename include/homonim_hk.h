@@ -287,6 +287,11 @@ int hk_fail_counts_async(hk_ctx* ctx, const hk_dev_job* job, uint64_t* host_coun
  * run again with the complete build; 0 when the launch's outputs are final.  Callers need not interpret the raw counters
  * (host-only, no device call). */
 int hk_counts_pending(const uint64_t* counts, int32_t n_bands);
+/* The constants the kernels decide `(r2 > thresh) & (gain > 0)` (kernel_model.py:363) with, for checking them against their
+ * derivation (host-only, no device call; PROOFS.md appendix A): ssres < pass_below * sstot proves the decision true,
+ * ssres > fail_above * sstot proves it false (sstot > 0); kappa / kappa_fail are the float32 factors of the division-free
+ * certificate and of its fail side (+inf / -inf: nothing can be certified).  Any pointer may be NULL. */
+int hk_r2_certificate_constants(float thresh, double* pass_below, double* fail_above, float* kappa, float* kappa_fail);
 int hk_inpaint_dev_counts(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* job, const uint64_t* counts,
                           uint64_t* n_fail_out);
 /* Per-band block normalisation on device planes -> norm (device, n_bands x 2 float64); asynchronous. */

@@ -282,3 +282,18 @@ def test_fast_quotient_special_operands_take_the_ieee_division():
     assert again.all()
     fast, again = fast_quotient(np.array([0.0, -0.0], F64), np.array([3.0, 3.0], F64))    # exact zeros stay
     assert not again.any() and (np.signbit(fast) == [False, True]).all()
+
+
+@pytest.mark.parametrize('thresh', [0.0, 0.1, 0.25, 0.5, 0.75, 0.9, 0.999, 0.9999999, -0.5, 1.0, 1.5])
+def test_library_constants_equal_their_numpy_derivation(thresh):
+    """ The factors the kernels use (hk_api.hip r2_pass_scale / r2_fail_above / r2_fail_scale / r2_failcert_scale through the host-only
+    hk_r2_certificate_constants) are the ones this file's model was validated with. """
+    from homonim_amd import _hk
+    pb, fa, k, kf = _hk.r2_certificate_constants(thresh)
+    if not thresh < 1:
+        assert pb == -np.inf and fa == np.inf and k == np.inf and kf == -np.inf
+        return
+    assert F32(k) == kappa_for(thresh)
+    assert F32(kf) == kappa_fail_for(thresh) or (np.isinf(kf) and np.isinf(kappa_fail_for(thresh)))
+    assert 0 < pb < fa and abs(fa / pb - 1) < 2.0 ** -38
+    assert float(kf) < 1 - fa <= float(k) + 2.0 ** -20 if np.isfinite(kf) else True
