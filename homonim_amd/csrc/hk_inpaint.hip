@@ -48,48 +48,67 @@ constexpr int WORD_ROWS = 64;
 
 __global__ void __launch_bounds__(256) inpaint_bits_kernel(const unsigned char* __restrict__ flag, long long stride, int height,
                                                            int width, unsigned long long* __restrict__ bits) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    // a thread packs FOUR adjacent columns: 64 independent 4-byte loads (the flag plane's rows are 4-byte aligned: stride % 4 == 0)
+    // instead of 64 single bytes per column -- a quarter of the load instructions for the same bytes (0.158 -> 0.064 ms per 16384^2 band)
+    const int x = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (x >= width) return;
     const int y0 = blockIdx.y * WORD_ROWS;
-    unsigned lo = 0, hi = 0;
+    unsigned lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int r = 0; r < 32; ++r) {
         const int ya = y0 + r, yb = y0 + 32 + r;
         // rows past the raster are clamped into it and masked out (the loads stay unconditional and independent)
-        const unsigned char fa = flag[(long long)min(ya, height - 1) * stride + x];
-        const unsigned char fb = flag[(long long)min(yb, height - 1) * stride + x];
-        lo |= (unsigned)(fa != 0 && ya < height) << r;
-        hi |= (unsigned)(fb != 0 && yb < height) << r;
+        const unsigned fa = *reinterpret_cast<const unsigned*>(flag + (long long)min(ya, height - 1) * stride + x);
+        const unsigned fb = *reinterpret_cast<const unsigned*>(flag + (long long)min(yb, height - 1) * stride + x);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            lo[c] |= (unsigned)(((fa >> (8 * c)) & 0xffu) != 0 && ya < height) << r;
+            hi[c] |= (unsigned)(((fb >> (8 * c)) & 0xffu) != 0 && yb < height) << r;
+        }
     }
-    bits[(long long)blockIdx.y * stride + x] = ((unsigned long long)hi << 32) | lo;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        if (x + c < width) bits[(long long)blockIdx.y * stride + x + c] = ((unsigned long long)hi[c] << 32) | lo[c];
 }
 
 __global__ void __launch_bounds__(256) inpaint_table_kernel(const unsigned long long* __restrict__ bits, long long stride,
                                                             int height, int width, int max_dist,
                                                             unsigned short* __restrict__ tb) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    // a thread makes the entries of TWO adjacent columns and stores them as one 4-byte word per row (rows are 4-byte aligned and
+    // padded: stride % 4 == 0) -- half the store instructions (measured neutral: the kernel is bound by its 64-row loop)
+    const int x = (blockIdx.x * blockDim.x + threadIdx.x) * 2;
     if (x >= width) return;
     const int wb = blockIdx.y, n_words = (height + WORD_ROWS - 1) / WORD_ROWS;
-    auto word = [&](int w) { return (w >= 0 && w < n_words) ? bits[(long long)w * stride + x] : 0ull; };
-    const unsigned long long wm2 = word(wb - 2), wm1 = word(wb - 1), w0 = word(wb), wp1 = word(wb + 1), wp2 = word(wb + 2);
     const int y0 = wb * WORD_ROWS, rows = min(WORD_ROWS, height - y0);
+    unsigned long long wm2[2], wm1[2], w0[2], wp1[2], wp2[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        auto word = [&](int w) { return (w >= 0 && w < n_words) ? bits[(long long)w * stride + x + c] : 0ull; };  // x + 1 < stride
+        wm2[c] = word(wb - 2), wm1[c] = word(wb - 1), w0[c] = word(wb), wp1[c] = word(wb + 1), wp2[c] = word(wb + 2);
+    }
     for (int b = 0; b < rows; ++b) {
-        // up: nearest set bit at or above row y0 + b
-        const unsigned long long m_up = w0 & (~0ull >> (63 - b));
-        int up;
-        if (m_up) up = b - (63 - __clzll((long long)m_up));
-        else if (wm1) up = b + 1 + __clzll((long long)wm1);
-        else if (wm2) up = b + 65 + __clzll((long long)wm2);
-        else up = 1 << 20;
-        // down: nearest set bit strictly below
-        const unsigned long long m_dn = b == 63 ? 0ull : (w0 & (~0ull << (b + 1)));
-        int dn;
-        if (m_dn) dn = (__ffsll((long long)m_dn) - 1) - b;
-        else if (wp1) dn = 64 - b + (__ffsll((long long)wp1) - 1);
-        else if (wp2) dn = 128 - b + (__ffsll((long long)wp2) - 1);
-        else dn = 1 << 20;
-        const unsigned ub = up <= max_dist ? (unsigned)up : NONE_B, db = dn <= max_dist + 1 ? (unsigned)dn : NONE_B;
-        tb[(long long)(y0 + b) * stride + x] = (unsigned short)((db << 8) | ub);
+        unsigned e[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            // up: nearest set bit at or above row y0 + b
+            const unsigned long long m_up = w0[c] & (~0ull >> (63 - b));
+            int up;
+            if (m_up) up = b - (63 - __clzll((long long)m_up));
+            else if (wm1[c]) up = b + 1 + __clzll((long long)wm1[c]);
+            else if (wm2[c]) up = b + 65 + __clzll((long long)wm2[c]);
+            else up = 1 << 20;
+            // down: nearest set bit strictly below
+            const unsigned long long m_dn = b == 63 ? 0ull : (w0[c] & (~0ull << (b + 1)));
+            int dn;
+            if (m_dn) dn = (__ffsll((long long)m_dn) - 1) - b;
+            else if (wp1[c]) dn = 64 - b + (__ffsll((long long)wp1[c]) - 1);
+            else if (wp2[c]) dn = 128 - b + (__ffsll((long long)wp2[c]) - 1);
+            else dn = 1 << 20;
+            const unsigned ub = up <= max_dist ? (unsigned)up : NONE_B, db = dn <= max_dist + 1 ? (unsigned)dn : NONE_B;
+            e[c] = (db << 8) | ub;
+        }
+        // the second column may lie in the row padding (odd width): its word of `bits` was never written, its entry is never read
+        *reinterpret_cast<unsigned*>(tb + (long long)(y0 + b) * stride + x) = e[0] | (e[1] << 16);
     }
 }
 
@@ -397,9 +416,10 @@ hipError_t launch_inpaint_offsets(const float* offset, const float* gain, const 
     // column bit words behind the weight table (256-byte aligned)
     unsigned long long* bits = reinterpret_cast<unsigned long long*>(
         (reinterpret_cast<uintptr_t>(wtab + WTAB_N) + 255) / 256 * 256);
-    const dim3 gwords((width + 255) / 256, (height + WORD_ROWS - 1) / WORD_ROWS);
-    hipLaunchKernelGGL(inpaint_bits_kernel, gwords, dim3(256), 0, stream, flag, stride, height, width, bits);
-    hipLaunchKernelGGL(inpaint_table_kernel, gwords, dim3(256), 0, stream, bits, stride, height, width, max_dist, tb);
+    const dim3 gbits((width + 1023) / 1024, (height + WORD_ROWS - 1) / WORD_ROWS);  // four columns per thread
+    hipLaunchKernelGGL(inpaint_bits_kernel, gbits, dim3(256), 0, stream, flag, stride, height, width, bits);
+    const dim3 gtable((width + 511) / 512, (height + WORD_ROWS - 1) / WORD_ROWS);  // two columns per thread
+    hipLaunchKernelGGL(inpaint_table_kernel, gtable, dim3(256), 0, stream, bits, stride, height, width, max_dist, tb);
     const dim3 gfill((width + 255) / 256, height < 65535 ? height : 65535);
     // n_targets: the number of pixels to fill as the caller knows it (the r2-mask failure count; 0 = unknown).  Moderate failure
     // rates take the TILED search (64 columns x 32 rows per wave: 23.3 -> 21.2 ms per step at 35 % failures; 16 rows 21.4, 64 rows
