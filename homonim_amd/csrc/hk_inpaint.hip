@@ -86,29 +86,43 @@ __global__ void __launch_bounds__(256) inpaint_table_kernel(const unsigned long 
         auto word = [&](int w) { return (w >= 0 && w < n_words) ? bits[(long long)w * stride + x + c] : 0ull; };  // x + 1 < stride
         wm2[c] = word(wb - 2), wm1[c] = word(wb - 1), w0[c] = word(wb), wp1[c] = word(wb + 1), wp2[c] = word(wb + 2);
     }
-    for (int b = 0; b < rows; ++b) {
+    // Both distances are running counters along the column: U(b) = 0 where bit b is set, else U(b - 1) + 1 (rows up to the nearest
+    // source at or above), D(b) = 1 where bit b + 1 is set, else D(b + 1) + 1 (rows down to the nearest source strictly below); the
+    // words above / below only seed them.  An ascending sweep leaves the 64 U bytes packed in registers, a descending sweep adds D
+    // and stores -- two or three integer operations per row and column instead of 64-bit clz / ffs with three-way selects
+    // (0.247 -> 0.157 ms per 16384^2 band).
+    constexpr int BIG = 1 << 20;
+    unsigned upk[2][WORD_ROWS / 4];
+    int dseed[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        int u = wm1[c] ? __clzll((long long)wm1[c]) : (wm2[c] ? 64 + __clzll((long long)wm2[c]) : BIG);  // U(-1)
+#pragma unroll
+        for (int q = 0; q < WORD_ROWS / 4; ++q) {
+            unsigned pk = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int bb = 4 * q + k;
+                u = ((w0[c] >> bb) & 1ull) ? 0 : min(u + 1, BIG);
+                pk |= (unsigned)(u <= max_dist ? u : (int)NONE_B) << (8 * k);
+            }
+            upk[c][q] = pk;
+        }
+        dseed[c] = wp1[c] ? 1 + (__ffsll((long long)wp1[c]) - 1) : (wp2[c] ? 65 + (__ffsll((long long)wp2[c]) - 1) : BIG);  // D(63)
+    }
+    int d[2] = {dseed[0], dseed[1]};
+#pragma unroll
+    for (int bb = WORD_ROWS - 1; bb >= 0; --bb) {
         unsigned e[2];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            // up: nearest set bit at or above row y0 + b
-            const unsigned long long m_up = w0[c] & (~0ull >> (63 - b));
-            int up;
-            if (m_up) up = b - (63 - __clzll((long long)m_up));
-            else if (wm1[c]) up = b + 1 + __clzll((long long)wm1[c]);
-            else if (wm2[c]) up = b + 65 + __clzll((long long)wm2[c]);
-            else up = 1 << 20;
-            // down: nearest set bit strictly below
-            const unsigned long long m_dn = b == 63 ? 0ull : (w0[c] & (~0ull << (b + 1)));
-            int dn;
-            if (m_dn) dn = (__ffsll((long long)m_dn) - 1) - b;
-            else if (wp1[c]) dn = 64 - b + (__ffsll((long long)wp1[c]) - 1);
-            else if (wp2[c]) dn = 128 - b + (__ffsll((long long)wp2[c]) - 1);
-            else dn = 1 << 20;
-            const unsigned ub = up <= max_dist ? (unsigned)up : NONE_B, db = dn <= max_dist + 1 ? (unsigned)dn : NONE_B;
+            if (bb < WORD_ROWS - 1) d[c] = ((w0[c] >> (bb + 1)) & 1ull) ? 1 : min(d[c] + 1, BIG);
+            const unsigned ub = (upk[c][bb >> 2] >> (8 * (bb & 3))) & 0xffu;
+            const unsigned db = d[c] <= max_dist + 1 ? (unsigned)d[c] : NONE_B;
             e[c] = (db << 8) | ub;
         }
         // the second column may lie in the row padding (odd width): its word of `bits` was never written, its entry is never read
-        *reinterpret_cast<unsigned*>(tb + (long long)(y0 + b) * stride + x) = e[0] | (e[1] << 16);
+        if (bb < rows) *reinterpret_cast<unsigned*>(tb + (long long)(y0 + bb) * stride + x) = e[0] | (e[1] << 16);
     }
 }
 
