@@ -269,18 +269,28 @@ __device__ __forceinline__ float fill_one(int x, int y, long long row, const flo
                 first = last + 1;
             }
         }
+        // The four quadrants' weights and source values are fetched WITHOUT branches -- a quadrant without a source in reach reads
+        // entry 0 of the weight table (0.0) and the pixel's own value, and its terms are selected away -- so that the eight look-ups
+        // go out together: as `if (found) { load; load; accumulate }` per quadrant they made four dependent round trips at the end of
+        // every search (profiles/r03_fill_tile.txt).  The sums run in the same order over the same terms.
+        double w4[4];
+        float v4[4];
+        bool ok4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            ok4[q] = qd2[q] <= max_dist * max_dist;  // qd <= max_dist
+            const int dx = ok4[q] ? (int)(qs[q] >> 8) : 0, dy = ok4[q] ? (int)(qs[q] & 0xffu) : 0;
+            const int sx = q < 2 ? x - dx : x + dx, sy = (q & 1) ? y + dy : y - dy;
+            w4[q] = wtab[ok4[q] ? qd2[q] : 0];
+            v4[q] = offset[(long long)sy * stride + sx];
+        }
         double wsum = 0.0, vsum = 0.0;
         bool has = false;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            if (qd2[q] <= max_dist * max_dist) {  // qd <= max_dist
-                const double w = wtab[qd2[q]];  // (an LDS copy of the table's head for the tiled kernel: no difference)
-                has = w != 0.0;
-                wsum += w;
-                const int dx = (int)(qs[q] >> 8), dy = (int)(qs[q] & 0xffu);
-                const int sx = q < 2 ? x - dx : x + dx, sy = (q & 1) ? y + dy : y - dy;
-                vsum += (double)offset[(long long)sy * stride + sx] * w;
-            }
+            has = ok4[q] ? (w4[q] != 0.0) : has;
+            wsum = ok4[q] ? wsum + w4[q] : wsum;
+            vsum = ok4[q] ? vsum + (double)v4[q] * w4[q] : vsum;
         }
         if (has) out = (float)(vsum / wsum);
         return out;
