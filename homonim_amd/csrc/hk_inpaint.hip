@@ -183,16 +183,22 @@ __device__ __forceinline__ float fill_one(int x, int y, long long row, const flo
         float out = offset[i];  // a target without any source in reach keeps its value
         const int none2 = (max_dist + 1) * (max_dist + 1);  // qd = max_dist + 1: "nothing found yet" (a perfect square: no tie)
         int qd2[4] = {none2, none2, none2, none2};
-        unsigned qs[4] = {0, 0, 0, 0};  // (column distance << 8) | row distance of the quadrant's source
+        // (column distance << 8) | row distance of the quadrant's source: the FIRST and the LAST candidate met at the best distance
+        unsigned qs[4] = {0, 0, 0, 0}, qs_last[4] = {0, 0, 0, 0};
         const unsigned short* __restrict__ trow = tb + row;
         // GDAL's QUAD_CHECK on squared integer distances.  `dist` is the column table's byte: NONE_B (no source in reach)
         // squares to more than any distance the search accepts and more than the initial (max_dist + 1)^2, so it never wins.
+        // A candidate at the SAME squared distance replaces the holder iff GDAL's float comparison says so for that distance (the
+        // `tie` bit of c) -- a property of c alone: with the bit set the last candidate met at the best distance wins, without it
+        // the first.  So the search keeps both, branch-free (two compares, three selects), and the bit is looked up once per
+        // quadrant at the end instead of behind a divergent branch in every one of the 34 candidate tests.
         auto consider = [&](int q, unsigned dist, int dx2, unsigned dx_hi) {
             const int c = (int)(dist * dist) + dx2;
-            bool better = c < qd2[q];
-            if (c == qd2[q]) better = (tie[c >> 5] >> (c & 31)) & 1u;  // rare
-            qd2[q] = better ? c : qd2[q];
-            qs[q] = better ? (dx_hi | dist) : qs[q];
+            const bool lt = c < qd2[q], le = c <= qd2[q];
+            const unsigned cand = dx_hi | dist;
+            qd2[q] = lt ? c : qd2[q];
+            qs[q] = lt ? cand : qs[q];
+            qs_last[q] = le ? cand : qs_last[q];
         };
         // Steps are taken in groups that end where GDAL re-derives its search bound (after steps 4, 8, 12, ...): the
         // bound is constant inside a group, so all of the group's table look-ups are issued before the checks, which then
@@ -279,7 +285,9 @@ __device__ __forceinline__ float fill_one(int x, int y, long long row, const flo
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             ok4[q] = qd2[q] <= max_dist * max_dist;  // qd <= max_dist
-            const int dx = ok4[q] ? (int)(qs[q] >> 8) : 0, dy = ok4[q] ? (int)(qs[q] & 0xffu) : 0;
+            const int cq = ok4[q] ? qd2[q] : 0;
+            const unsigned src = ((tie[cq >> 5] >> (cq & 31)) & 1u) ? qs_last[q] : qs[q];  // (the 1.3 KB bitmap stays in cache)
+            const int dx = ok4[q] ? (int)(src >> 8) : 0, dy = ok4[q] ? (int)(src & 0xffu) : 0;
             const int sx = q < 2 ? x - dx : x + dx, sy = (q & 1) ? y + dy : y - dy;
             w4[q] = wtab[ok4[q] ? qd2[q] : 0];
             v4[q] = offset[(long long)sy * stride + sx];
