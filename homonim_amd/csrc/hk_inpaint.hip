@@ -16,6 +16,8 @@
 
 #include <stdlib.h>
 
+#define HK_SQ(v) __mul24((v), (v))  // squares of column distances <= 100: the full-rate 24-bit multiply (v_mul_lo_u32 runs at a quarter)
+
 #include <type_traits>
 
 namespace hk {
@@ -242,7 +244,7 @@ __device__ __forceinline__ float fill_one(int x, int y, long long row, const flo
                 for (int k = 0; k < 5; ++k) {
                     if (k <= last) {
                         const int dl = min(k, x), dr = min(k, width - 1 - x);  // clamped columns: the distance to the edge column
-                        const int dl2 = dl * dl, dr2 = dr * dr;
+                        const int dl2 = HK_SQ(dl), dr2 = HK_SQ(dr);
                         consider(0, up(d0, 4 - k), dl2, (unsigned)dl << 8);  // top left
                         consider(1, dn(d0, 4 - k), dl2, (unsigned)dl << 8);  // bottom left
                         if (k != 0) {
@@ -264,7 +266,7 @@ __device__ __forceinline__ float fill_one(int x, int y, long long row, const flo
                     const int step = first + k;
                     if (step <= last) {
                         const int dl = min(step, x), dr = min(step, width - 1 - x);
-                        const int dl2 = dl * dl, dr2 = dr * dr;
+                        const int dl2 = HK_SQ(dl), dr2 = HK_SQ(dr);
                         consider(0, up(cl, 3 - k), dl2, (unsigned)dl << 8);
                         consider(1, dn(cl, 3 - k), dl2, (unsigned)dl << 8);
                         consider(2, up(cr, k), dr2, (unsigned)dr << 8);
