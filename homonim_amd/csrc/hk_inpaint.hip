@@ -159,9 +159,10 @@ __device__ __forceinline__ int isqrt_floor(int n) {
     return r;
 }
 
+template <bool INTERIOR = false>
 __device__ __forceinline__ void fill_load_d0(const unsigned short* __restrict__ trow, int x, int width, unsigned (&d0)[5]) {
     struct __attribute__((packed, aligned(2))) W5 { unsigned w[5]; };
-    if (x - 4 >= 0 && x + 5 < width) {
+    if (INTERIOR || (x - 4 >= 0 && x + 5 < width)) {
         const W5 v = *reinterpret_cast<const W5*>(trow + x - 4);
 #pragma unroll
         for (int j = 0; j < 5; ++j) d0[j] = v.w[j];
@@ -178,6 +179,9 @@ __device__ __forceinline__ void fill_load_d0(const unsigned short* __restrict__ 
 
 // The search of ONE target pixel (x, y): GDAL's quadrant search through the column tables, then the inverse-distance mean of the
 // quadrants' sources.  Returns the filled value (the pixel's own value if no source is in reach).
+// INTERIOR (wave-uniform, tiled kernel): no step of any search of the wave can reach the raster's edge columns -- the clamps,
+// their per-lane squares and the entry-by-entry table reads fall away.
+template <bool INTERIOR = false>
 __device__ __forceinline__ float fill_one(int x, int y, long long row, const float* __restrict__ offset, long long stride, int width,
                                           int max_dist, const unsigned short* __restrict__ tb, const unsigned* __restrict__ tie,
                                           const double* __restrict__ wtab) {
@@ -218,11 +222,11 @@ __device__ __forceinline__ float fill_one(int x, int y, long long row, const flo
             auto up = [](const unsigned* d, int j) { return (d[j >> 1] >> ((j & 1) * 16)) & 0xffu; };
             auto dn = [](const unsigned* d, int j) { return (d[j >> 1] >> ((j & 1) * 16 + 8)) & 0xffu; };
             unsigned d0[5];                  // entries 0..9 <-> columns x - 4 .. x + 5 (steps 0..4: left step k = entry 4 - k, right = 4 + k)
-            fill_load_d0(trow, x, width, d0);
+            fill_load_d0<INTERIOR>(trow, x, width, d0);
             // later groups (steps first .. first + 3): left entries 0..3 <-> columns x - first - 3 .. x - first (step first + k = entry
             // 3 - k), right entries 0..3 <-> columns x + first .. x + first + 3 (step first + k = entry k)
             auto fetch4 = [&](int first, unsigned (&l)[2], unsigned (&r)[2]) {
-                if (x - first - 3 >= 0 && x + first + 3 < width) {
+                if (INTERIOR || (x - first - 3 >= 0 && x + first + 3 < width)) {
                     const W2 lv = *reinterpret_cast<const W2*>(trow + x - first - 3);
                     const W2 rv = *reinterpret_cast<const W2*>(trow + x + first);
                     l[0] = lv.w[0], l[1] = lv.w[1], r[0] = rv.w[0], r[1] = rv.w[1];
@@ -243,7 +247,7 @@ __device__ __forceinline__ float fill_one(int x, int y, long long row, const flo
 #pragma unroll
                 for (int k = 0; k < 5; ++k) {
                     if (k <= last) {
-                        const int dl = min(k, x), dr = min(k, width - 1 - x);  // clamped columns: the distance to the edge column
+                        const int dl = INTERIOR ? k : min(k, x), dr = INTERIOR ? k : min(k, width - 1 - x);  // clamped columns: the distance to the edge column
                         const int dl2 = HK_SQ(dl), dr2 = HK_SQ(dr);
                         consider(0, up(d0, 4 - k), dl2, (unsigned)dl << 8);  // top left
                         consider(1, dn(d0, 4 - k), dl2, (unsigned)dl << 8);  // bottom left
@@ -265,7 +269,7 @@ __device__ __forceinline__ float fill_one(int x, int y, long long row, const flo
                 for (int k = 0; k < 4; ++k) {
                     const int step = first + k;
                     if (step <= last) {
-                        const int dl = min(step, x), dr = min(step, width - 1 - x);
+                        const int dl = INTERIOR ? step : min(step, x), dr = INTERIOR ? step : min(step, width - 1 - x);
                         const int dl2 = HK_SQ(dl), dr2 = HK_SQ(dr);
                         consider(0, up(cl, 3 - k), dl2, (unsigned)dl << 8);
                         consider(1, dn(cl, 3 - k), dl2, (unsigned)dl << 8);
@@ -383,6 +387,8 @@ __global__ void __launch_bounds__(256, HK_FILL_TILE_WAVES) inpaint_fill_tile_ker
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
     const int x0 = blockIdx.x * blockDim.x + wv * WAVE, x_own = x0 + lane;
     const unsigned long long lt = (1ull << lane) - 1ull;
+    // wave-uniform: the widest reach of a search (max_dist columns + the 3 extra entries of a group's wide load) stays inside the row
+    const bool interior = x0 - max_dist - 4 >= 0 && x0 + WAVE - 1 + max_dist + 4 < width;
     const int n_tiles = (height + ROWS - 1) / ROWS;
     for (int tile = blockIdx.y; tile < n_tiles; tile += gridDim.y) {
         const int y0 = tile * ROWS;
@@ -413,7 +419,8 @@ __global__ void __launch_bounds__(256, HK_FILL_TILE_WAVES) inpaint_fill_tile_ker
                 const unsigned e = lst[wv][p + lane];
                 const int x = x0 + (int)(e & 63u), y = y0 + (int)(e >> 6);
                 const long long row = (long long)y * stride;
-                filled[row + x] = fill_one(x, y, row, offset, stride, width, max_dist, tb, tie, wtab);
+                filled[row + x] = interior ? fill_one<true>(x, y, row, offset, stride, width, max_dist, tb, tie, wtab)
+                                           : fill_one<false>(x, y, row, offset, stride, width, max_dist, tb, tie, wtab);
             }
         }
         __syncthreads();  // the next tile re-uses the list
