@@ -462,14 +462,14 @@ hipError_t launch_inpaint_offsets(const float* offset, const float* gain, const 
     const dim3 gtable((width + 511) / 512, (height + WORD_ROWS - 1) / WORD_ROWS);  // two columns per thread
     hipLaunchKernelGGL(inpaint_table_kernel, gtable, dim3(256), 0, stream, bits, stride, height, width, max_dist, tb);
     const dim3 gfill((width + 255) / 256, height < 65535 ? height : 65535);
-    // n_targets: the number of pixels to fill as the caller knows it (the r2-mask failure count; 0 = unknown).  Moderate failure
-    // rates take the TILED search (64 columns x 32 rows per wave: 23.3 -> 21.2 ms per step at 35 % failures; 16 rows 21.4, 64 rows
-    // 27.1, profiles/r03_fill_tile.txt); when nearly every pixel is a target the plain one-thread-per-pixel form is faster (41.8
-    // against 48.5 ms at 94 %).  HK_FILL_TILE=0 selects the per-row compacting form of rounds 1-2 (A/B), 4..64 another tile height.
+    // The TILED search (64 columns x 32 rows per wave; 16 rows 21.4 against 21.2 ms per step, 64 rows 27.1 when it was introduced,
+    // profiles/r03_fill_tile.txt) serves every failure rate since its candidate test is branch-free (at 94 % failures 36.7 against
+    // 37.7 ms for the one-thread-per-pixel form).  HK_FILL_TILE=0 selects the per-row forms of rounds 1-2 (A/B; n_targets -- the
+    // number of pixels to fill as the caller knows it, 0 = unknown -- picks between them), 4..64 another tile height.
     static const int tile_env = [] { const char* e = getenv("HK_FILL_TILE"); return e ? atoi(e) : -1; }();
     const bool moderate = n_targets == 0 || (double)n_targets < 0.6 * (double)height * (double)width;
     const int tile_rows = tile_env >= 0 ? tile_env : 32;
-    if (moderate && tile_rows > 0) {
+    if (tile_rows > 0) {
         const int rows = tile_rows >= 64 ? 64 : (tile_rows >= 32 ? 32 : (tile_rows >= 16 ? 16 : (tile_rows >= 8 ? 8 : 4)));
         const int n_tiles = (height + rows - 1) / rows;
         const dim3 gt((width + 255) / 256, n_tiles < 65535 ? n_tiles : 65535);
