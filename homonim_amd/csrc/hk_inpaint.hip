@@ -134,7 +134,8 @@ __global__ void __launch_bounds__(256) inpaint_table_kernel(const unsigned long 
 // property of n alone: tie_kernel tabulates it as a bitmap (TIE_N bits), and the search itself runs on integers -- no
 // sqrt and no float64 in the loop, same decisions.
 constexpr int TIE_N = 2 * 102 * 102;  // > the largest squared distance the search can meet (100^2 + 101^2)
-constexpr int WTAB_N = 100 * 100 + 1;  // weights 1 / qd of the accepted distances (qd <= max_dist = 100)
+constexpr int FILL_MAX_DIST = 100;  // rasterio.fill.fillnodata default max_search_distance (kernel_model.py:366)
+constexpr int WTAB_N = FILL_MAX_DIST * FILL_MAX_DIST + 1;  // weights 1 / qd of the accepted distances (qd <= max_dist = 100)
 __global__ void __launch_bounds__(256) tie_kernel(unsigned* __restrict__ tie, double* __restrict__ wtab) {
     const int word = blockIdx.x * blockDim.x + threadIdx.x;
     // the inverse-distance weights GDAL forms as 1.0 / qd with qd = sqrt(n): a table instead of a sqrt and a division
@@ -378,7 +379,7 @@ __global__ void __launch_bounds__(256, PACK ? 8 : HK_FILL_WAVES_FULL) inpaint_fi
 #endif
 template <int ROWS>
 __global__ void __launch_bounds__(256, HK_FILL_TILE_WAVES) inpaint_fill_tile_kernel(const float* __restrict__ offset, const unsigned char* __restrict__ flag,
-                                                                   long long stride, int height, int width, int max_dist,
+                                                                   long long stride, int height, int width, int max_dist_arg,
                                                                    const unsigned short* __restrict__ tb,
                                                                    const unsigned* __restrict__ tie,
                                                                    const double* __restrict__ wtab, float* __restrict__ filled) {
@@ -387,6 +388,10 @@ __global__ void __launch_bounds__(256, HK_FILL_TILE_WAVES) inpaint_fill_tile_ker
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
     const int x0 = blockIdx.x * blockDim.x + wv * WAVE, x_own = x0 + lane;
     const unsigned long long lt = (1ull << lane) - 1ull;
+    // the search distance as a compile-time constant (the launcher passes FILL_MAX_DIST and nothing else): the first five steps become
+    // straight-line code, the "nothing found yet" and acceptance bounds immediates
+    const int max_dist = FILL_MAX_DIST;
+    (void)max_dist_arg;
     // wave-uniform: the widest reach of a search (max_dist columns + the 3 extra entries of a group's wide load) stays inside the row
     const bool interior = x0 - max_dist - 4 >= 0 && x0 + WAVE - 1 + max_dist + 4 < width;
     const int n_tiles = (height + ROWS - 1) / ROWS;
@@ -449,7 +454,7 @@ hipError_t launch_inpaint_offsets(const float* offset, const float* gain, const 
     unsigned* tie = reinterpret_cast<unsigned*>(ws_flag + (plane + 255) / 256 * 256);
     double* wtab = reinterpret_cast<double*>(tie + (TIE_N / 32 + 64) / 64 * 64);
     hipLaunchKernelGGL(tie_kernel, dim3((TIE_N / 32 + 255) / 256), dim3(256), 0, stream, tie, wtab);
-    const int max_dist = 100;  // rasterio.fill.fillnodata default max_search_distance (kernel_model.py:366)
+    const int max_dist = FILL_MAX_DIST;
     static_assert(100 + 1 < (int)NONE_B, "the table's distance bytes");
     if (!flag_ready)  // else: the flag plane was written by the fit kernel (FitArgs::flag)
         hipLaunchKernelGGL(inpaint_flag_kernel, dim3((width + 255) / 256, height < 1024 ? height : 1024), dim3(256), 0, stream,
