@@ -132,6 +132,7 @@ SIGNATURES = {
     'hk_event_elapsed_ms': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _P(C.c_float)]),
     'hk_stream_sync': (C.c_int, [C.c_void_p, C.c_int32]),
     'hk_selftest': (C.c_int, [C.c_void_p]),
+    'hk_debug_stage_stamps': (C.c_int, [C.c_void_p, _P(C.c_uint64), C.c_int32]),
 }  # yapf: disable
 
 COMM_ID_BYTES = 128   # HK_COMM_ID_BYTES = sizeof(ncclUniqueId)
@@ -645,6 +646,12 @@ class Context:
         assert host_counts.size >= sum(j.n_bands for j in arr)
         _check(self._lib.hk_fail_counts_batch_async(self._h, arr, len(arr), host_counts.ctypes.data_as(_P(C.c_uint64)),
                                                     C.c_void_p(ready_event)))
+
+    def debug_stage_stamps(self, reset: bool = True) -> np.ndarray:
+        """ Stage counters of a -DHK_STAMPS build of the fused kernel (hk_debug_stage_stamps; zeros in the shipped build). """
+        out = (C.c_uint64 * 16)()
+        _check(self._lib.hk_debug_stage_stamps(self._h, out, 1 if reset else 0))
+        return np.array(list(out), dtype=np.uint64)
 
     def compare_sums_dev(self, job: DevJob, src_nodata, ref_nodata, sums_dptr: int):
         (sm, sv), (rm, rv) = nodata_code(src_nodata), nodata_code(ref_nodata)

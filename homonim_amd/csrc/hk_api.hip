@@ -1279,6 +1279,16 @@ int hk_fail_counts_async(hk_ctx* ctx, const hk_dev_job* job, uint64_t* host_coun
     return HK_OK;
 }
 
+int hk_debug_stage_stamps(hk_ctx* ctx, uint64_t out[16], int32_t reset) {
+    if (!ctx || !out) return fail(HK_ERR_ARG, "NULL argument");
+    HK_ENTER(ctx);
+    HK_HIP(hipDeviceSynchronize());
+    unsigned long long tmp[16];
+    HK_HIP(hk::read_stamps(tmp, reset != 0));
+    for (int i = 0; i < 16; ++i) out[i] = tmp[i];
+    return HK_OK;
+}
+
 int hk_r2_certificate_constants(float thresh, double* pass_below, double* fail_above, float* kappa, float* kappa_fail) {
     if (pass_below) *pass_below = r2_pass_scale(thresh);
     if (fail_above) *fail_above = r2_fail_above(thresh);

@@ -94,6 +94,8 @@ hipError_t launch_fit_apply(const FitArgs& a, int model, bool with_r2, hipStream
 // The batched entry points run every other model as one launch per job (bit-identical either way).
 constexpr bool fit_batch_build(int model, bool with_r2) { return model == 1 && !with_r2; }
 bool fit_batch_supported(int model, bool with_r2);
+// stage stamps of a -DHK_STAMPS build of hk_kernels.hip (all zero otherwise): 16 counters, optionally cleared after reading
+hipError_t read_stamps(unsigned long long* out16, bool reset);
 // strips per workgroup of the lock-step builds (HK_WPB_MEM): FitJob::first_group[1] / FitArgs::batch_groups[1] count those
 int fit_lockstep_waves();
 // LDS bytes one wave needs (its row ring; hk_kernels.hip)

@@ -21,6 +21,31 @@
 
 namespace hk {
 
+// In-kernel stage stamps (build with -DHK_STAMPS; tools/stage_stamps.py): every wave accumulates the shader-clock cycles it spends
+// between the marked points of a row iteration (s_memtime; waits for memory land in the stage that needs the data) and adds them
+// to hk_stamps[] when it ends; [15] counts iterations, [14] waves.  Costs ~10 % of the kernel's time; never in the shipped build.
+__device__ unsigned long long hk_stamps[16];
+#ifdef HK_STAMPS
+#define HK_STAMP(k)                                                       \
+    do {                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();     \
+        st_acc[k] += now_ - st_prev;                                      \
+        st_prev = now_;                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                \
+    } while (0)
+#else
+#define HK_STAMP(k) do { } while (0)
+#endif
+hipError_t read_stamps(unsigned long long* out16, bool reset) {
+    hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(hk_stamps), 16 * sizeof(unsigned long long));
+    if (e == hipSuccess && reset) {
+        const unsigned long long zero[16] = {};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(hk_stamps), zero, sizeof(zero));
+    }
+    return e;
+}
+
 // Measurement hook (tools/README.md, FLOOR.md section 3): timing builds with one ingredient of the fused kernel taken out --
 // WRONG results, never shipped.  1: the leaving row is re-loaded from the entering row's address (no far re-load),
 // 2: gain-blk-offset without its float64 quotient, 4: no horizontal sums, 8: no corrected-plane stores.
@@ -846,7 +871,14 @@ fit_apply_kernel(const FitArgs a_in) {
     const int ring_mod = ring2p ? ring_rows : kh;
     int slot_c = ring_mod - rh;  // slot of the centre row of the output produced at this iteration: (slot - rh) mod ring_mod
     if (slot_c >= ring_mod) slot_c -= ring_mod;
+#ifdef HK_STAMPS
+    unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_prev = __builtin_amdgcn_s_memtime(), st_iters = 0;
+#endif
     for (int t = t_first; t <= t_last; ++t) {
+#ifdef HK_STAMPS
+        ++st_iters;
+#endif
+        HK_STAMP(5);  // loop bookkeeping + (first iteration) the set-up
         if constexpr (WPB > 1) {
             // lock-step: the workgroup's strips move down the rows together (same segment: same trip count in every wave)
             __syncthreads();
@@ -866,6 +898,7 @@ fit_apply_kernel(const FitArgs a_in) {
         if constexpr (RING == 0) qc = load_row(sp, rp, a.stride, y_c, H, xq);
 
         const RowZ znew = process_row<MODEL, DENSE, MODEL == 1 && R2>(q0, t >= 0 && t < H, colbits, full_wave, ts, tr, n0, n1);
+        HK_STAMP(0);  // requests of this iteration issued, entering row arrived and classified
         if constexpr (PFD > 1) {
             q0 = qq[0];
 #pragma unroll
@@ -936,6 +969,7 @@ fit_apply_kernel(const FitArgs a_in) {
             }
         }
 
+        HK_STAMP(1);  // next row requested, ring traffic, leaving row arrived and classified
         if (kh == 1) {  // wave-uniform: a 1-row window IS the entering row -- no running sum, exact by construction
             cs.clear();
             cs.template update<true>(znew, n0, n1);
@@ -944,6 +978,7 @@ fit_apply_kernel(const FitArgs a_in) {
             cs.template update<false>(zold, n0, n1);
         }
 
+        HK_STAMP(2);  // column sums updated
         const int y = t - rh;
         if (y >= y0 && y >= a.out_y0 && y < a.out_y1) {  // wave-uniform: the first 2*rh iterations only prime the running sums
             // centre row of the window
@@ -1053,6 +1088,7 @@ fit_apply_kernel(const FitArgs a_in) {
             // The pointwise stages exist in two versions: UN = every stored pixel of this wave-row has the full, all-valid
             // window (n_uniform): the window count, its float64 image and 1/N are scalars and the centre-row mask is all ones,
             // so every mask select and bit test folds away.
+            HK_STAMP(3);  // centre row, horizontal sums, window counts
             auto pointwise = [&](auto uniform_n) {
                 constexpr bool UN = decltype(uniform_n)::value;
                 // the halo lanes only feed their neighbours' horizontal sums: masked out of the pointwise stages, they draw
@@ -1370,6 +1406,7 @@ fit_apply_kernel(const FitArgs a_in) {
             } else {
                 pointwise(std::false_type{});
             }
+            HK_STAMP(4);  // pointwise stages and stores
         }
 
         if (++slot == ring_mod) slot = 0;
@@ -1377,6 +1414,13 @@ fit_apply_kernel(const FitArgs a_in) {
         if (++slot2 == rh + 1) slot2 = 0;
         if (++slot_r >= rh) slot_r = 0;
     }
+#ifdef HK_STAMPS
+    if (lane == 0) {
+        for (int k = 0; k < 6; ++k) atomicAdd(&hk_stamps[k], st_acc[k]);
+        atomicAdd(&hk_stamps[15], st_iters);
+        atomicAdd(&hk_stamps[14], 1ull);
+    }
+#endif
 
     if constexpr (GO && R2) {
         if (a.fail_count != nullptr && a.has_thresh) {

@@ -377,6 +377,9 @@ int hk_stream_sync(hk_ctx* ctx, int32_t stream);
 
 /* Self-test of the cross-lane primitives the kernels rely on (DPP wave shifts); 0 = pass. */
 int hk_selftest(hk_ctx* ctx);
+/* Measurement aid: the stage counters a -DHK_STAMPS build of the fused kernel accumulates (shader-clock cycles per stage of a row
+ * iteration, [14] waves, [15] iterations; all zero in the shipped build; tools/stage_stamps.py).  Synchronises the device. */
+int hk_debug_stage_stamps(hk_ctx* ctx, uint64_t out[16], int32_t reset);
 
 #ifdef __cplusplus
 }
