@@ -5,7 +5,10 @@ hand-written HIP kernels.  This is the stub a homonim maintainer would add to ho
 There is NO CPU fallback: if the library is missing or no gfx950 device is present, every entry point raises
 ``DeviceError`` loudly.
 """
+import atexit
 import ctypes as C
+import sys
+import weakref
 import math
 import os
 import threading
@@ -237,6 +240,20 @@ def _ptr(a: np.ndarray, typ=_f32p):
     return a.ctypes.data_as(typ)
 
 
+_live_contexts = weakref.WeakSet()
+
+
+@atexit.register
+def _close_live_contexts():
+    """ Contexts still open when the interpreter exits are destroyed HERE -- while the library, the HIP runtime and this module
+    are all intact -- instead of from garbage collection during shutdown. """
+    for c in list(_live_contexts):
+        try:
+            c.close()
+        except Exception:
+            pass
+
+
 class Context:
     """ One GPU context (hk_ctx): a device + a pool of streams.  Thread-safe; share it between worker threads. """
 
@@ -251,6 +268,7 @@ class Context:
         self._h = h
         self.device = device
         self.n_streams = n_streams
+        _live_contexts.add(self)
 
     def close(self):
         if getattr(self, '_h', None):
@@ -258,6 +276,10 @@ class Context:
             self._h = None
 
     def __del__(self):
+        # never during interpreter shutdown: by then the order in which the runtime's own objects die is not ours to rely on (a
+        # context that is still open is closed by the atexit hook below, before any teardown starts)
+        if sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:
@@ -475,6 +497,8 @@ class Context:
 
         class _Owner:
             def __del__(self_inner):
+                if sys.is_finalizing():  # the process is going away: its page-locked memory goes with it
+                    return
                 try:
                     lib.hk_host_free(None, C.c_void_p(addr))  # page-locked memory outlives the context it came from
                 except Exception:

@@ -392,8 +392,9 @@ __global__ void __launch_bounds__(256, HK_FILL_TILE_WAVES) inpaint_fill_tile_ker
     // straight-line code, the "nothing found yet" and acceptance bounds immediates
     const int max_dist = FILL_MAX_DIST;
     (void)max_dist_arg;
-    // wave-uniform: the widest reach of a search (max_dist columns + the 3 extra entries of a group's wide load) stays inside the row
-    const bool interior = x0 - max_dist - 4 >= 0 && x0 + WAVE - 1 + max_dist + 4 < width;
+    // wave-uniform: the widest reach of a search stays inside the row -- the group that starts at step max_dist requests the one
+    // after it (steps max_dist + 4 .. + 7) ahead, and a group's wide load covers 4 entries: 7 + 4 columns beyond max_dist
+    const bool interior = x0 - max_dist - 12 >= 0 && x0 + WAVE - 1 + max_dist + 12 < width;
     const int n_tiles = (height + ROWS - 1) / ROWS;
     for (int tile = blockIdx.y; tile < n_tiles; tile += gridDim.y) {
         const int y0 = tile * ROWS;
