@@ -533,16 +533,37 @@ __device__ __forceinline__ void hist_add(unsigned* hist, int level, unsigned key
 }
 
 // LEVEL 0..2 over the compacted buffers (grid: x = workgroups, y = band * 2 + raster)
+// (a band whose pivots missed -- ws.fallback -- is histogrammed over its full rasters by the same launch: the chain of a block's
+// statistics is a sequence of dependent launches, and each one it does not need is one less to be placed beside other streams' kernels)
 template <int LEVEL>
-__global__ void __launch_bounds__(NORM_THREADS) norm_mid_hist_kernel(NormWS* __restrict__ ws_all,
+__global__ void __launch_bounds__(NORM_THREADS) norm_mid_hist_kernel(const NormArgs a, NormWS* __restrict__ ws_all,
                                                                        const float* __restrict__ mid_all, size_t mid_cap) {
     constexpr int NB = LEVEL == 0 ? L1_BINS : (LEVEL == 1 ? L2_BINS : L3_BINS);
     __shared__ unsigned hist[2 * NB];
     const int band = blockIdx.y >> 1, q = blockIdx.y & 1;
     NormWS& ws = ws_all[band];
-    if (ws.done || ws.fallback) return;
+    if (ws.done) return;
     for (int i = threadIdx.x; i < 2 * NB; i += NORM_THREADS) hist[i] = 0;
     __syncthreads();
+    if (ws.fallback) {  // uniform over the workgroup: the select over the full rasters (plain keys)
+        const PlaneRef pl = plane_of(a, band);
+        const unsigned pfx[2] = {ws.sel[q][0].prefix, ws.sel[q][1].prefix};
+        const unsigned kb = ws.kbase[q];
+        const int ksh = ws.ksh[q];
+        for (int y = blockIdx.x; y < pl.height; y += gridDim.x) {
+            const long long row = (long long)y * pl.stride;
+            for (int x = threadIdx.x; x < pl.width; x += NORM_THREADS) {
+                const float s = pl.sp[row + x], r = pl.rp[row + x];
+                if (nvalid(s, a.src_nd_mode, a.src_nodata) && nvalid(r, a.ref_nd_mode, a.ref_nodata))
+                    hist_add(hist, LEVEL, (f2key(q ? r : s) - kb) << ksh, pfx);
+            }
+        }
+        __syncthreads();
+        unsigned* gh = LEVEL == 0 ? &ws.hist1[q][0][0] : (LEVEL == 1 ? &ws.hist2[q][0][0] : &ws.hist3[q][0][0]);
+        for (int i = threadIdx.x; i < 2 * NB; i += NORM_THREADS)
+            if (hist[i]) atomicAdd(gh + i, hist[i]);
+        return;
+    }
     const float* __restrict__ buf = mid_all + ((size_t)band * 2 + q) * mid_cap;
     const unsigned cnt = ws.mid_count[q];
     const unsigned pfx[2] = {ws.sel[q][0].prefix, ws.sel[q][1].prefix};
@@ -800,15 +821,13 @@ hipError_t launch_block_norm(const NormArgs& a, void* workspace, double* norm_ou
     // workgroups per compacted buffer: at least 8 float4 per thread of a full buffer (a 4096^2 block's buffers hold ~0.2 M values:
     // 256 workgroups would spend their time zeroing and merging 16 KB histograms -- 0.40 -> 0.15 ms for configs[3]'s 128 blocks)
     const size_t mid_wgs = cap_al / 4 / (NORM_THREADS * 8);
-    const dim3 gmid((unsigned)(mid_wgs < 8 ? 8 : (mid_wgs > MID_BLOCKS ? MID_BLOCKS : mid_wgs)), a.n_bands * 2), gfull(FB_BLOCKS, a.n_bands, 2);
-    hipLaunchKernelGGL(norm_mid_hist_kernel<0>, gmid, block, 0, stream, ws, mid, cap_al);
-    hipLaunchKernelGGL(norm_full_hist_kernel<0>, gfull, block, 0, stream, a, ws);
+    // (at least 32 workgroups per buffer: a band that fell back has its full rasters histogrammed by the same grid)
+    const dim3 gmid((unsigned)(mid_wgs < 32 ? 32 : (mid_wgs > MID_BLOCKS ? MID_BLOCKS : mid_wgs)), a.n_bands * 2);
+    hipLaunchKernelGGL(norm_mid_hist_kernel<0>, gmid, block, 0, stream, a, ws, mid, cap_al);
     hipLaunchKernelGGL(norm_select_kernel<0>, bands, block, 0, stream, ws, norm_out);
-    hipLaunchKernelGGL(norm_mid_hist_kernel<1>, gmid, block, 0, stream, ws, mid, cap_al);
-    hipLaunchKernelGGL(norm_full_hist_kernel<1>, gfull, block, 0, stream, a, ws);
+    hipLaunchKernelGGL(norm_mid_hist_kernel<1>, gmid, block, 0, stream, a, ws, mid, cap_al);
     hipLaunchKernelGGL(norm_select_kernel<1>, bands, block, 0, stream, ws, norm_out);
-    hipLaunchKernelGGL(norm_mid_hist_kernel<2>, gmid, block, 0, stream, ws, mid, cap_al);
-    hipLaunchKernelGGL(norm_full_hist_kernel<2>, gfull, block, 0, stream, a, ws);
+    hipLaunchKernelGGL(norm_mid_hist_kernel<2>, gmid, block, 0, stream, a, ws, mid, cap_al);
     hipLaunchKernelGGL(norm_select_kernel<2>, bands, block, 0, stream, ws, norm_out);
     return hipGetLastError();
 }
