@@ -6,6 +6,7 @@
 // thread-local error string; any number of host threads may use one context (homonim/fuse.py:396-401).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cfloat>
 #include <cmath>
@@ -53,6 +54,103 @@ int fail(int code, const char* fmt, ...) {
         HK_HIP(hipSetDevice((ctx)->device));  \
         (void)hipGetLastError();              \
     } while (0)
+
+// Every device allocation of the library goes through dev_malloc / dev_free.  HK_GUARD_ALLOC=lo|hi (a debugging switch: GPU
+// AddressSanitizer is not available everywhere) places each allocation in its own mapping of the virtual-memory API with
+// UNMAPPED address ranges on both sides, its first byte at the start of the mapping (lo: reads or writes below the buffer
+// fault) or its last 256-byte unit at the end (hi: those above it do), so an out-of-range access of a kernel ends the
+// process at that launch instead of reading whatever happens to be mapped next to the buffer.
+struct GuardedRange {
+    void* user;
+    void* va;
+    size_t va_bytes;
+    void* mapped;
+    size_t mapped_bytes;
+    hipMemGenericAllocationHandle_t handle;
+};
+int guard_mode() {  // 0 off, 1 lo, 2 hi
+    static const int mode = [] {
+        const char* e = getenv("HK_GUARD_ALLOC");
+        if (!e || !*e || !strcmp(e, "0")) return 0;
+        if (!strcmp(e, "poison")) return 3;  // plain hipMalloc, contents set to 0xAB: nothing may rely on fresh memory being zero
+        return !strcmp(e, "hi") ? 2 : 1;
+    }();
+    return mode;
+}
+std::mutex g_guard_mu;
+std::vector<GuardedRange> g_guarded;
+
+// does a buffer of `have` bytes serve a request for `need`?  (guarded: only an exact fit, so that the request's end is the mapping's)
+bool fits(size_t have, size_t need) { return (guard_mode() && !getenv("HK_GUARD_LOOSE")) ? have == need : have >= need; }
+
+hipError_t dev_malloc(void** out, size_t bytes) {
+    if (!guard_mode()) return hipMalloc(out, bytes);
+    if (guard_mode() == 3) {
+        hipError_t pe = hipMalloc(out, bytes);
+        if (pe == hipSuccess) pe = hipMemset(*out, 0xAB, bytes);
+        if (pe == hipSuccess) pe = hipDeviceSynchronize();
+        return pe;
+    }
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = dev;
+    size_t gran = 0;
+    if ((e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum)) != hipSuccess) return e;
+    const size_t unit = (std::max<size_t>(bytes, 1) + 255) / 256 * 256;
+    GuardedRange g = {};
+    g.mapped_bytes = (unit + gran - 1) / gran * gran;
+    g.va_bytes = g.mapped_bytes + 2 * gran;
+    if ((e = hipMemAddressReserve(&g.va, g.va_bytes, gran, nullptr, 0)) != hipSuccess) return e;
+    g.mapped = static_cast<char*>(g.va) + gran;
+    if ((e = hipMemCreate(&g.handle, g.mapped_bytes, &prop, 0)) != hipSuccess) {
+        (void)hipMemAddressFree(g.va, g.va_bytes);
+        return e;
+    }
+    hipMemAccessDesc access = {};
+    access.location = prop.location;
+    access.flags = hipMemAccessFlagsProtReadWrite;
+    if ((e = hipMemMap(g.mapped, g.mapped_bytes, 0, g.handle, 0)) != hipSuccess ||
+        (e = hipMemSetAccess(g.mapped, g.mapped_bytes, &access, 1)) != hipSuccess) {
+        (void)hipMemUnmap(g.mapped, g.mapped_bytes);
+        (void)hipMemRelease(g.handle);
+        (void)hipMemAddressFree(g.va, g.va_bytes);
+        return e;
+    }
+    g.user = guard_mode() == 2 ? static_cast<char*>(g.mapped) + (g.mapped_bytes - unit) : g.mapped;
+    {
+        std::lock_guard<std::mutex> lk(g_guard_mu);
+        g_guarded.push_back(g);
+    }
+    *out = g.user;
+    // poison + synchronise: nothing may rely on fresh memory being zero, and a kernel queued right behind hipMemSetAccess
+    // on a non-blocking stream was seen to read the new range before its mapping had settled (wrong values, no fault)
+    e = hipMemset(g.mapped, 0xAB, g.mapped_bytes);
+    return e != hipSuccess ? e : hipDeviceSynchronize();
+}
+
+hipError_t dev_free(void* p) {
+    if (!guard_mode() || guard_mode() == 3 || !p) return hipFree(p);
+    GuardedRange g = {};
+    {
+        std::lock_guard<std::mutex> lk(g_guard_mu);
+        for (size_t i = 0; i < g_guarded.size(); ++i)
+            if (g_guarded[i].user == p) {
+                g = g_guarded[i];
+                g_guarded.erase(g_guarded.begin() + i);
+                break;
+            }
+    }
+    if (!g.user) return hipFree(p);  // not one of ours (allocated before the switch was read: cannot happen; or foreign)
+    hipError_t e = hipDeviceSynchronize();  // hipFree's implicit synchronisation
+    if (e != hipSuccess) return e;
+    // the address range stays reserved (and unmapped: a use after free faults as well); the physical memory goes back
+    if ((e = hipMemUnmap(g.mapped, g.mapped_bytes)) != hipSuccess) return e;
+    return hipMemRelease(g.handle);
+}
 
 struct Slot {
     hipStream_t stream = nullptr;
@@ -205,15 +303,15 @@ RcclApi& rccl() {
     } while (0)
 
 int ensure_dev(Slot& s, size_t bytes) {
-    if (s.dev_bytes >= bytes) return HK_OK;
+    if (fits(s.dev_bytes, bytes)) return HK_OK;
     if (s.dev) {
         HK_HIP(hipStreamSynchronize(s.stream));
-        HK_HIP(hipFree(s.dev));
+        HK_HIP(dev_free(s.dev));
         s.dev = nullptr;
         s.dev_bytes = 0;
     }
-    const size_t want = bytes + bytes / 8;
-    if (hipMalloc(&s.dev, want) != hipSuccess) return fail(HK_ERR_NOMEM, "hipMalloc(%zu) failed", want);
+    const size_t want = guard_mode() ? bytes : bytes + bytes / 8;  // (guarded: the buffer ends where its last user's does)
+    if (dev_malloc(&s.dev, want) != hipSuccess) return fail(HK_ERR_NOMEM, "hipMalloc(%zu) failed", want);
     s.dev_bytes = want;
     return HK_OK;
 }
@@ -416,13 +514,13 @@ void fill_grid(hk::FitArgs& a, int seg_rows) {
 // scratch of the in-painting branch: [filled | gain | offset | r2 | column tables]
 static int ensure_inpaint_scratch(Slot& sl, size_t plane, int height, long long stride) {
     const size_t need = 4 * plane + hk::inpaint_workspace_bytes(height, stride);
-    if (sl.aux_bytes < need) {
+    if (!fits(sl.aux_bytes, need)) {
         if (sl.aux) {
             HK_HIP(hipStreamSynchronize(sl.stream));
-            HK_HIP(hipFree(sl.aux));
+            HK_HIP(dev_free(sl.aux));
         }
         sl.aux = nullptr, sl.aux_bytes = 0;
-        if (hipMalloc(&sl.aux, need) != hipSuccess) return fail(HK_ERR_NOMEM, "hipMalloc(%zu) failed", need);
+        if (dev_malloc(&sl.aux, need) != hipSuccess) return fail(HK_ERR_NOMEM, "hipMalloc(%zu) failed", need);
         sl.aux_bytes = need;
     }
     return HK_OK;
@@ -803,19 +901,19 @@ int hk_ctx_destroy(hk_ctx* ctx) {
     hipSetDevice(ctx->device);
     for (auto& s : ctx->slots) {
         if (s.stream) hipStreamSynchronize(s.stream);
-        if (s.dev) hipFree(s.dev);
-        if (s.norm_ws) hipFree(s.norm_ws);
-        if (s.aux) hipFree(s.aux);
+        if (s.dev) dev_free(s.dev);
+        if (s.norm_ws) dev_free(s.norm_ws);
+        if (s.aux) dev_free(s.aux);
         if (s.fail_host) hipHostFree(s.fail_host);
         for (int i = 0; i < Slot::TBL_RING; ++i) {
             if (s.tbl_host[i]) hipHostFree(s.tbl_host[i]);
-            if (s.tbl_dev[i]) hipFree(s.tbl_dev[i]);
+            if (s.tbl_dev[i]) dev_free(s.tbl_dev[i]);
             if (s.tbl_ev[i]) hipEventDestroy(s.tbl_ev[i]);
         }
         if (s.stream) hipStreamDestroy(s.stream);
     }
     if (ctx->comm && rccl().ok) rccl().CommDestroy(ctx->comm);
-    if (ctx->comm_xchg) hipFree(ctx->comm_xchg);
+    if (ctx->comm_xchg) dev_free(ctx->comm_xchg);
     delete ctx;
     return HK_OK;
 }
@@ -1153,13 +1251,13 @@ int hk_host_unregister(hk_ctx* ctx, void* hptr) {
 int hk_dev_alloc(hk_ctx* ctx, size_t bytes, void** dptr) {
     if (!ctx || !dptr) return fail(HK_ERR_ARG, "NULL argument");
     HK_ENTER(ctx);
-    if (hipMalloc(dptr, bytes) != hipSuccess) return fail(HK_ERR_NOMEM, "hipMalloc(%zu) failed", bytes);
+    if (dev_malloc(dptr, bytes) != hipSuccess) return fail(HK_ERR_NOMEM, "hipMalloc(%zu) failed", bytes);
     return HK_OK;
 }
 int hk_dev_free(hk_ctx* ctx, void* dptr) {
     if (!ctx) return fail(HK_ERR_ARG, "ctx is NULL");
     HK_ENTER(ctx);
-    HK_HIP(hipFree(dptr));
+    HK_HIP(dev_free(dptr));
     return HK_OK;
 }
 int hk_memcpy_h2d(hk_ctx* ctx, void* dst, const void* src, size_t bytes) {
@@ -1406,13 +1504,13 @@ static int ensure_stream_ws(hk_ctx* ctx, Slot& sl, size_t need) {
     // device-resident jobs on one stream are issued by one caller at a time (stream order); the lock only protects
     // the (re)allocation against other streams' callers touching the context
     std::lock_guard<std::mutex> lk(ctx->mu);
-    if (sl.norm_ws_bytes < need) {
+    if (!fits(sl.norm_ws_bytes, need)) {
         if (sl.norm_ws) {
             HK_HIP(hipStreamSynchronize(sl.stream));
-            HK_HIP(hipFree(sl.norm_ws));
+            HK_HIP(dev_free(sl.norm_ws));
             sl.norm_ws = nullptr, sl.norm_ws_bytes = 0;
         }
-        if (hipMalloc(&sl.norm_ws, need) != hipSuccess) return fail(HK_ERR_NOMEM, "hipMalloc(%zu) failed", need);
+        if (dev_malloc(&sl.norm_ws, need) != hipSuccess) return fail(HK_ERR_NOMEM, "hipMalloc(%zu) failed", need);
         sl.norm_ws_bytes = need;
     }
     return HK_OK;
@@ -1513,14 +1611,14 @@ static int upload_table(hk_ctx* ctx, Slot& sl, const void* data, size_t bytes, v
     if (sl.tbl_bytes[i] < bytes) {
         if (sl.tbl_dev[i]) {
             HK_HIP(hipStreamSynchronize(sl.stream));  // kernels may still read the old device buffer
-            HK_HIP(hipFree(sl.tbl_dev[i]));
+            HK_HIP(dev_free(sl.tbl_dev[i]));
             HK_HIP(hipHostFree(sl.tbl_host[i]));
         }
         sl.tbl_dev[i] = sl.tbl_host[i] = nullptr, sl.tbl_bytes[i] = 0;
         const size_t cap = (bytes + 4095) / 4096 * 4096;
-        if (hipMalloc(&sl.tbl_dev[i], cap) != hipSuccess) return fail(HK_ERR_NOMEM, "hipMalloc(%zu) failed", cap);
+        if (dev_malloc(&sl.tbl_dev[i], cap) != hipSuccess) return fail(HK_ERR_NOMEM, "hipMalloc(%zu) failed", cap);
         if (hipHostMalloc(&sl.tbl_host[i], cap, hipHostMallocDefault) != hipSuccess) {
-            (void)hipFree(sl.tbl_dev[i]);
+            (void)dev_free(sl.tbl_dev[i]);
             sl.tbl_dev[i] = nullptr;
             return fail(HK_ERR_NOMEM, "hipHostMalloc(%zu) failed", cap);
         }
@@ -1809,10 +1907,10 @@ int hk_block_norm_split_comm_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_
     if (ctx->comm_xchg_doubles < n) {
         if (ctx->comm_xchg) {
             HK_HIP(hipDeviceSynchronize());  // an earlier sequence on another stream may still read it
-            HK_HIP(hipFree(ctx->comm_xchg));
+            HK_HIP(dev_free(ctx->comm_xchg));
             ctx->comm_xchg = nullptr, ctx->comm_xchg_doubles = 0;
         }
-        if (hipMalloc(reinterpret_cast<void**>(&ctx->comm_xchg), n * sizeof(double)) != hipSuccess)
+        if (dev_malloc(reinterpret_cast<void**>(&ctx->comm_xchg), n * sizeof(double)) != hipSuccess)
             return fail(HK_ERR_NOMEM, "hipMalloc(%zu) failed", n * sizeof(double));
         ctx->comm_xchg_doubles = n;
     }
@@ -1898,13 +1996,13 @@ int hk_selftest(hk_ctx* ctx) {
     if (!ctx) return fail(HK_ERR_ARG, "ctx is NULL");
     HK_ENTER(ctx);
     int* d = nullptr;
-    HK_HIP(hipMalloc(&d, sizeof(int)));
+    HK_HIP(dev_malloc(reinterpret_cast<void**>(&d), sizeof(int)));
     int code = -1;
     hipError_t e = hipMemset(d, 0, sizeof(int));
     if (e == hipSuccess) e = hk::launch_selftest(d, ctx->slots[0].stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->slots[0].stream);
     if (e == hipSuccess) e = hipMemcpy(&code, d, sizeof(int), hipMemcpyDeviceToHost);
-    hipFree(d);  // on every path
+    (void)dev_free(d);  // on every path
     if (e != hipSuccess) return fail(HK_ERR_HIP, "self-test launch failed: %s", hipGetErrorString(e));
     if (code != 0) return fail(HK_ERR_HIP, "cross-lane self-test failed (code 0x%x)", code);
     return HK_OK;
