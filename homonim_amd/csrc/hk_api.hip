@@ -81,7 +81,7 @@ std::mutex g_guard_mu;
 std::vector<GuardedRange> g_guarded;
 
 // does a buffer of `have` bytes serve a request for `need`?  (guarded: only an exact fit, so that the request's end is the mapping's)
-bool fits(size_t have, size_t need) { return (guard_mode() && !getenv("HK_GUARD_LOOSE")) ? have == need : have >= need; }
+bool fits(size_t have, size_t need) { return guard_mode() ? have == need : have >= need; }
 
 hipError_t dev_malloc(void** out, size_t bytes) {
     if (!guard_mode()) return hipMalloc(out, bytes);
