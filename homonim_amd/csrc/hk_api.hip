@@ -23,6 +23,8 @@
 #include "hk_kernels.h"
 
 #include <dlfcn.h>
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>  // types only: the loaded HSA runtime is looked up at run time (gpu_fault_report)
 #include <rccl/rccl.h>  // types and prototypes only: librccl is opened at run time (hk_comm_*), not linked
 
 namespace {
@@ -80,13 +82,100 @@ int guard_mode() {  // 0 off, 1 lo, 2 hi
 std::mutex g_guard_mu;
 std::vector<GuardedRange> g_guarded;
 
+// What the library has allocated on the device (a handful of slabs, workspaces and the callers' hk_dev_alloc buffers): a GPU
+// memory fault is reported with its place relative to them (gpu_fault_report).
+struct DevRange {
+    uintptr_t base;
+    size_t bytes;
+};
+std::mutex g_ranges_mu;
+std::vector<DevRange> g_ranges;
+void note_alloc(void* p, size_t bytes) {
+    std::lock_guard<std::mutex> lk(g_ranges_mu);
+    g_ranges.push_back({reinterpret_cast<uintptr_t>(p), bytes});
+}
+void note_free(void* p) {
+    std::lock_guard<std::mutex> lk(g_ranges_mu);
+    for (size_t i = 0; i < g_ranges.size(); ++i)
+        if (g_ranges[i].base == reinterpret_cast<uintptr_t>(p)) {
+            g_ranges[i] = g_ranges.back();
+            g_ranges.pop_back();
+            return;
+        }
+}
+
+// On this stack a GPU memory fault (or hardware exception) ends the process with a bare abort() of the HSA runtime's event thread:
+// no address, no message.  The library therefore registers a system-event callback of its own that says what happened and where
+// the address lies relative to the library's allocations, and then lets the runtime carry on as before (it does not claim to
+// have handled the event).
+hsa_status_t gpu_fault_report(const hsa_amd_event_t* ev, void*) {
+    if (!ev) return HSA_STATUS_ERROR;
+    if (ev->event_type == HSA_AMD_GPU_MEMORY_FAULT_EVENT || ev->event_type == HSA_AMD_GPU_MEMORY_ERROR_EVENT) {
+        const bool fault = ev->event_type == HSA_AMD_GPU_MEMORY_FAULT_EVENT;
+        const uint64_t addr = fault ? ev->memory_fault.virtual_address : ev->memory_error.virtual_address;
+        const uint32_t mask = fault ? ev->memory_fault.fault_reason_mask : ev->memory_error.error_reason_mask;
+        char where[200] = "not near any allocation of libhomonim_hk";
+        {
+            std::lock_guard<std::mutex> lk(g_ranges_mu);
+            uint64_t best = ~0ull;
+            for (const DevRange& r : g_ranges) {
+                if (addr >= r.base && addr < r.base + r.bytes) {
+                    snprintf(where, sizeof where, "INSIDE a library allocation of %zu bytes (offset %llu): freed or remapped under a kernel?",
+                             r.bytes, (unsigned long long)(addr - r.base));
+                    best = 0;
+                    break;
+                }
+                const uint64_t d = addr < r.base ? r.base - addr : addr - (r.base + r.bytes) + 1;
+                if (d < best && d < (64ull << 20)) {
+                    best = d;
+                    if (addr < r.base)
+                        snprintf(where, sizeof where, "%llu bytes BELOW a library allocation of %zu bytes", (unsigned long long)d, r.bytes);
+                    else
+                        snprintf(where, sizeof where, "%llu bytes past the END of a library allocation of %zu bytes",
+                                 (unsigned long long)(d - 1), r.bytes);
+                }
+            }
+        }
+        fprintf(stderr, "[libhomonim_hk] GPU memory %s at 0x%llx, reason mask 0x%x%s%s%s%s: %s\n", fault ? "access fault" : "error",
+                (unsigned long long)addr, mask, (fault && (mask & HSA_AMD_MEMORY_FAULT_PAGE_NOT_PRESENT)) ? " page-not-present" : "",
+                (fault && (mask & HSA_AMD_MEMORY_FAULT_READ_ONLY)) ? " read-only" : "",
+                (fault && (mask & (HSA_AMD_MEMORY_FAULT_DRAMECC | HSA_AMD_MEMORY_FAULT_SRAMECC))) ? " ECC" : "",
+                (fault && (mask & HSA_AMD_MEMORY_FAULT_HANG)) ? " hang/reset" : "", where);
+        fflush(stderr);
+    } else if (ev->event_type == HSA_AMD_GPU_HW_EXCEPTION_EVENT) {
+        fprintf(stderr, "[libhomonim_hk] GPU hardware exception: reset type 0x%x, cause 0x%x%s%s\n", (unsigned)ev->hw_exception.reset_type,
+                (unsigned)ev->hw_exception.reset_cause,
+                (ev->hw_exception.reset_cause & HSA_AMD_HW_EXCEPTION_CAUSE_GPU_HANG) ? " GPU hang" : "",
+                (ev->hw_exception.reset_cause & HSA_AMD_HW_EXCEPTION_CAUSE_ECC) ? " ECC" : "");
+        fflush(stderr);
+    }
+    return HSA_STATUS_ERROR;  // not handled here: the runtime's own handling (ending the process) follows
+}
+void register_gpu_fault_report() {
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* off = getenv("HK_FAULT_REPORT");
+        if (off && !strcmp(off, "0")) return;
+        void* hsa = dlopen("libhsa-runtime64.so.1", RTLD_NOW | RTLD_NOLOAD);  // the instance HIP runs on, or nothing
+        if (!hsa) return;
+        using reg_t = hsa_status_t (*)(hsa_amd_system_event_callback_t, void*);
+        reg_t reg = reinterpret_cast<reg_t>(dlsym(hsa, "hsa_amd_register_system_event_handler"));
+        if (reg) (void)reg(gpu_fault_report, nullptr);
+    });
+}
+
 // does a buffer of `have` bytes serve a request for `need`?  (guarded: only an exact fit, so that the request's end is the mapping's)
 bool fits(size_t have, size_t need) { return guard_mode() ? have == need : have >= need; }
 
 hipError_t dev_malloc(void** out, size_t bytes) {
-    if (!guard_mode()) return hipMalloc(out, bytes);
+    if (!guard_mode()) {
+        const hipError_t pe = hipMalloc(out, bytes);
+        if (pe == hipSuccess) note_alloc(*out, bytes);
+        return pe;
+    }
     if (guard_mode() == 3) {
         hipError_t pe = hipMalloc(out, bytes);
+        if (pe == hipSuccess) note_alloc(*out, bytes);
         if (pe == hipSuccess) pe = hipMemset(*out, 0xAB, bytes);
         if (pe == hipSuccess) pe = hipDeviceSynchronize();
         return pe;
@@ -126,6 +215,7 @@ hipError_t dev_malloc(void** out, size_t bytes) {
         g_guarded.push_back(g);
     }
     *out = g.user;
+    note_alloc(g.user, unit);
     // poison + synchronise: nothing may rely on fresh memory being zero, and a kernel queued right behind hipMemSetAccess
     // on a non-blocking stream was seen to read the new range before its mapping had settled (wrong values, no fault)
     e = hipMemset(g.mapped, 0xAB, g.mapped_bytes);
@@ -133,6 +223,7 @@ hipError_t dev_malloc(void** out, size_t bytes) {
 }
 
 hipError_t dev_free(void* p) {
+    if (p) note_free(p);
     if (!guard_mode() || guard_mode() == 3 || !p) return hipFree(p);
     GuardedRange g = {};
     {
@@ -892,6 +983,7 @@ int hk_ctx_create(int device_id, int n_streams, hk_ctx** out) {
             return fail(HK_ERR_NOMEM, "hipHostMalloc failed");
         }
     }
+    register_gpu_fault_report();  // (HIP, and with it the HSA runtime, is up: the streams above were created on it)
     *out = ctx;
     return HK_OK;
 }
