@@ -104,10 +104,10 @@ void note_free(void* p) {
         }
 }
 
-// On this stack a GPU memory fault (or hardware exception) ends the process with a bare abort() of the HSA runtime's event thread:
-// no address, no message.  The library therefore registers a system-event callback of its own that says what happened and where
-// the address lies relative to the library's allocations, and then lets the runtime carry on as before (it does not claim to
-// have handled the event).
+// A GPU memory fault (or hardware exception) ends the process with an abort() of the HSA runtime's event thread; the runtime names
+// the address, not what it belongs to.  The library registers a system-event callback of its own that says where the address
+// lies relative to the library's allocations, and then lets the runtime carry on as before (it does not claim to have handled
+// the event).
 hsa_status_t gpu_fault_report(const hsa_amd_event_t* ev, void*) {
     if (!ev) return HSA_STATUS_ERROR;
     if (ev->event_type == HSA_AMD_GPU_MEMORY_FAULT_EVENT || ev->event_type == HSA_AMD_GPU_MEMORY_ERROR_EVENT) {
