@@ -264,7 +264,6 @@ struct Slot {
     bool dev_touched = false;  // device-resident jobs were queued on this stream since the last lease drained it
 };
 
-constexpr int DEFAULT_SEG_ROWS = 128;
 constexpr int64_t ROW_ALIGN = 64;  // device rows padded to 64 elements (256 B)
 
 }  // namespace
@@ -990,22 +989,22 @@ int hk_ctx_create(int device_id, int n_streams, hk_ctx** out) {
 
 int hk_ctx_destroy(hk_ctx* ctx) {
     if (!ctx) return HK_OK;
-    hipSetDevice(ctx->device);
+    (void)hipSetDevice(ctx->device);
     for (auto& s : ctx->slots) {
-        if (s.stream) hipStreamSynchronize(s.stream);
-        if (s.dev) dev_free(s.dev);
-        if (s.norm_ws) dev_free(s.norm_ws);
-        if (s.aux) dev_free(s.aux);
-        if (s.fail_host) hipHostFree(s.fail_host);
+        if (s.stream) (void)hipStreamSynchronize(s.stream);
+        if (s.dev) (void)dev_free(s.dev);
+        if (s.norm_ws) (void)dev_free(s.norm_ws);
+        if (s.aux) (void)dev_free(s.aux);
+        if (s.fail_host) (void)hipHostFree(s.fail_host);
         for (int i = 0; i < Slot::TBL_RING; ++i) {
-            if (s.tbl_host[i]) hipHostFree(s.tbl_host[i]);
-            if (s.tbl_dev[i]) dev_free(s.tbl_dev[i]);
-            if (s.tbl_ev[i]) hipEventDestroy(s.tbl_ev[i]);
+            if (s.tbl_host[i]) (void)hipHostFree(s.tbl_host[i]);
+            if (s.tbl_dev[i]) (void)dev_free(s.tbl_dev[i]);
+            if (s.tbl_ev[i]) (void)hipEventDestroy(s.tbl_ev[i]);
         }
-        if (s.stream) hipStreamDestroy(s.stream);
+        if (s.stream) (void)hipStreamDestroy(s.stream);
     }
     if (ctx->comm && rccl().ok) rccl().CommDestroy(ctx->comm);
-    if (ctx->comm_xchg) dev_free(ctx->comm_xchg);
+    if (ctx->comm_xchg) (void)dev_free(ctx->comm_xchg);
     delete ctx;
     return HK_OK;
 }
@@ -2054,7 +2053,7 @@ int hk_event_create(hk_ctx* ctx, hk_event** ev) {
 }
 int hk_event_destroy(hk_ctx* ctx, hk_event* ev) {
     if (!ctx || !ev) return HK_OK;
-    hipEventDestroy(ev->ev);
+    (void)hipEventDestroy(ev->ev);
     delete ev;
     return HK_OK;
 }
