@@ -71,7 +71,11 @@ const char* hk_last_error(void);              /* thread-local text of the last f
 int hk_device_count(int* count);
 /* One context per GPU: owns `n_streams` HIP streams, each with a pinned-host + device staging slot that grows on
  * demand.  Replaces nothing in the reference (its "device" is the host CPU); mirrors the thread pool of
- * homonim/fuse.py:396. */
+ * homonim/fuse.py:396.
+ * Process-wide side effect of the first call: the library adds a system-event callback to the HSA runtime that prints GPU
+ * memory faults (with the place of the address relative to the library's device allocations), memory errors and hardware
+ * exceptions to stderr; it does not claim the event, the runtime's own handling follows (HK_FAULT_REPORT=0: not registered).
+ * Debugging: HK_GUARD_ALLOC=lo|hi places every device allocation of the library between unmapped address ranges. */
 int hk_ctx_create(int device_id, int n_streams, hk_ctx** ctx);
 int hk_ctx_destroy(hk_ctx* ctx);
 int hk_ctx_sync(hk_ctx* ctx);                 /* hipDeviceSynchronize on the context's device */
