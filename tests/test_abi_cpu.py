@@ -44,6 +44,52 @@ def test_header_is_plain_c_and_a_c_program_can_drive_the_library(lib, tmp_path):
     assert 'abi_consumer: ok' in run.stdout
 
 
+def test_ctypes_structs_have_the_offsets_the_c_compiler_gives_the_header(tmp_path):
+    """ Field by field: the ctypes mirrors in homonim_amd/_hk.py against offsetof() / sizeof() of include/homonim_hk.h as gcc
+    lays the structs out (same field names on both sides; a renamed, re-ordered or re-typed field fails here, not on the GPU). """
+    import subprocess
+    pairs = [('hk_fit_desc', _hk.FitDesc), ('hk_io_desc', _hk.IoDesc), ('hk_space_desc', _hk.SpaceDesc),
+             ('hk_out_window', _hk.OutWindow), ('hk_dev_job', _hk.DevJob)]
+    lines = ['#include <stddef.h>', '#include <stdio.h>', '#include "homonim_hk.h"', 'int main(void) {']
+    for cname, cls in pairs:
+        lines.append(f'    printf("{cname} sizeof %zu\\n", sizeof({cname}));')
+        for field in cls._fields_:
+            lines.append(f'    printf("{cname} {field[0]} %zu %zu\\n", offsetof({cname}, {field[0]}), '
+                         f'sizeof((({cname}*)0)->{field[0]}));')
+    lines += ['    return 0;', '}']
+    src = tmp_path / 'layout.c'
+    src.write_text('\n'.join(lines) + '\n')
+    exe = tmp_path / 'layout'
+    subprocess.run(['gcc', '-std=c99', '-Wall', '-Werror', '-I', os.path.join(REPO, 'include'), str(src), '-o', str(exe)],
+                   check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split('\n')
+    seen = {}
+    for ln in out:
+        parts = ln.split()
+        if len(parts) == 3:
+            seen[(parts[0], 'sizeof')] = int(parts[2])
+        elif len(parts) == 4:
+            seen[(parts[0], parts[1])] = (int(parts[2]), int(parts[3]))
+    for cname, cls in pairs:
+        assert ctypes.sizeof(cls) == seen[(cname, 'sizeof')], cname
+        for field in cls._fields_:
+            desc = getattr(cls, field[0])
+            assert (desc.offset, desc.size) == seen[(cname, field[0])], f'{cname}.{field[0]}'
+    # the header declares no field the mirrors lack
+    header = open(os.path.join(REPO, 'include', 'homonim_hk.h')).read()
+    for cname, cls in pairs:
+        body = re.search(r'typedef struct[^{]*\{([^}]*)\}\s*' + cname + ';', header).group(1)
+        body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
+        names = set()
+        for decl in body.split(';'):
+            decl = decl.strip()
+            if not decl:
+                continue
+            for part in decl.split(','):
+                names.add(re.sub(r'\[.*\]', '', part.strip().split()[-1]).lstrip('*'))
+        assert names == {f[0] for f in cls._fields_}, cname
+
+
 def test_backend_name_and_struct_layout(lib):
     assert lib.hk_backend_name() == b'hip-gfx950'
     assert ctypes.sizeof(_hk.FitDesc) == 40  # 10 x 4-byte fields, matches hk_fit_desc
