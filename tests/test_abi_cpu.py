@@ -90,6 +90,46 @@ def test_ctypes_structs_have_the_offsets_the_c_compiler_gives_the_header(tmp_pat
         assert names == {f[0] for f in cls._fields_}, cname
 
 
+def test_ctypes_prototypes_agree_with_the_header_argument_by_argument():
+    """ Every prototype of include/homonim_hk.h against its entry in _hk.SIGNATURES: number of arguments, and per argument
+    pointer / 4-byte int / 8-byte int / float / double (a struct pointer: the mirrored struct).  A scalar passed at the wrong
+    width through ctypes is silent on x86-64 until it is not. """
+    header = open(os.path.join(REPO, 'include', 'homonim_hk.h')).read()
+    header = re.sub(r'/\*.*?\*/', '', header, flags=re.S)
+    protos = re.findall(r'\b([A-Za-z_][A-Za-z0-9_ ]*?[\s\*]+)(hk_[a-z0-9_]+)\s*\(([^)]*)\)\s*;', header)
+    assert len(protos) == len(_hk.SIGNATURES)
+    scalar = {'int': 'i4', 'int32_t': 'i4', 'uint32_t': 'i4', 'int64_t': 'i8', 'uint64_t': 'i8', 'size_t': 'i8',
+              'float': 'f4', 'double': 'f8'}
+    structs = {'hk_fit_desc': _hk.FitDesc, 'hk_io_desc': _hk.IoDesc, 'hk_space_desc': _hk.SpaceDesc,
+               'hk_out_window': _hk.OutWindow, 'hk_dev_job': _hk.DevJob}
+
+    def c_kind(decl):
+        decl = decl.strip()
+        if '*' in decl or '[' in decl:   # (an array parameter is a pointer)
+            base = decl.replace('const', ' ').replace('struct', ' ').split('*')[0].split()[0]
+            return ('ptr', structs.get(base))
+        words = [w for w in decl.replace('const', ' ').split()]
+        return (scalar[words[0]], None)
+
+    def py_kind(t):
+        if t in (ctypes.c_void_p, ctypes.c_char_p) or hasattr(t, 'contents'):
+            pointee = getattr(t, '_type_', None)
+            return ('ptr', pointee if isinstance(pointee, type) and issubclass(pointee, ctypes.Structure) else None)
+        return ({ctypes.c_int: 'i4', ctypes.c_int32: 'i4', ctypes.c_uint32: 'i4', ctypes.c_int64: 'i8', ctypes.c_uint64: 'i8',
+                 ctypes.c_size_t: 'i8', ctypes.c_float: 'f4', ctypes.c_double: 'f8'}[t], None)
+
+    for ret, name, args in protos:
+        restype, argtypes = _hk.SIGNATURES[name]
+        assert py_kind(restype)[0] == ('ptr' if '*' in ret else scalar[ret.split()[-1]]), name
+        decls = [] if args.strip() in ('', 'void') else args.split(',')
+        assert len(decls) == len(argtypes), f'{name}: {len(decls)} arguments in the header, {len(argtypes)} in _hk.SIGNATURES'
+        for i, (decl, t) in enumerate(zip(decls, argtypes)):
+            ck, pk = c_kind(decl), py_kind(t)
+            assert ck[0] == pk[0], f'{name} argument {i} ({decl.strip()}): header {ck[0]}, ctypes {pk[0]}'
+            if ck[1] is not None and pk[1] is not None:
+                assert ck[1] is pk[1], f'{name} argument {i}: {decl.strip()} mirrored by {pk[1].__name__}'
+
+
 def test_backend_name_and_struct_layout(lib):
     assert lib.hk_backend_name() == b'hip-gfx950'
     assert ctypes.sizeof(_hk.FitDesc) == 40  # 10 x 4-byte fields, matches hk_fit_desc
