@@ -130,6 +130,44 @@ def test_ctypes_prototypes_agree_with_the_header_argument_by_argument():
                 assert ck[1] is pk[1], f'{name} argument {i}: {decl.strip()} mirrored by {pk[1].__name__}'
 
 
+def test_the_binding_shown_in_integration_md_matches_the_library():
+    """ INTEGRATION.md shows the ctypes stub a homonim maintainer would add; its struct and its argtypes lines are executed
+    here and compared with the library's own table (same widths argument by argument, same struct layout). """
+    text = open(os.path.join(REPO, 'INTEGRATION.md')).read()
+    block = next(b for b in re.findall(r'```python\n(.*?)```', text, flags=re.S) if 'class _FitDesc' in b)
+    struct_src = re.search(r'(class _FitDesc\(C\.Structure\):.*?\n)\n', block, flags=re.S).group(1)
+    ns = {'C': ctypes}
+    exec(struct_src, ns)
+    exec(re.search(r'(_f32p, _f64p = .*)\n', block).group(1), ns)
+    shown = ns['_FitDesc']
+    assert [(n, t) for n, t in shown._fields_] == [(n, t) for n, t in _hk.FitDesc._fields_]
+
+    class _Fn:
+        pass
+
+    class _Lib:
+        def __getattr__(self, name):
+            fn = self.__dict__.setdefault(name, _Fn())
+            return fn
+
+    ns['_lib'] = _Lib()
+    stmts = re.findall(r'(_lib\.hk_[a-z_]+\.argtypes = \[.*?\])\n', block, flags=re.S)
+    assert len(stmts) >= 2
+    for stmt in stmts:
+        exec(stmt, ns)
+
+    def width(t):
+        if t in (ctypes.c_void_p, ctypes.c_char_p) or hasattr(t, 'contents'):
+            return 'ptr'
+        return ctypes.sizeof(t), t in (ctypes.c_float, ctypes.c_double)
+
+    for name, fn in ns['_lib'].__dict__.items():
+        mine = _hk.SIGNATURES[name][1]
+        assert len(fn.argtypes) == len(mine), name
+        for i, (a, b) in enumerate(zip(fn.argtypes, mine)):
+            assert width(a) == width(b), f'{name} argument {i}'
+
+
 def test_backend_name_and_struct_layout(lib):
     assert lib.hk_backend_name() == b'hip-gfx950'
     assert ctypes.sizeof(_hk.FitDesc) == 40  # 10 x 4-byte fields, matches hk_fit_desc
