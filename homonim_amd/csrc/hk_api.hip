@@ -251,7 +251,26 @@ struct Slot {
     size_t norm_ws_bytes = 0;
     void* aux = nullptr;      // on-demand planes + tables of the in-painting branch
     size_t aux_bytes = 0;
-    unsigned long long* fail_host = nullptr;  // pinned word: the r2-mask failure counter comes back with the outputs
+    // Pinned words of the slot (PIN_BYTES of hipHostMalloc'd memory): small results and arguments travel through them,
+    // never through the caller's pageable memory.  fail_host = the first word (the r2-mask failure counter).
+    unsigned long long* fail_host = nullptr;
+    static constexpr size_t PIN_NORM = 64, PIN_SUMS = 128, PIN_NORM_IN = 192, PIN_WORD = 256, PIN_COUNTS = 1024, PIN_BYTES = 16384;
+    template <class T> T* pin(size_t off) const { return reinterpret_cast<T*>(reinterpret_cast<char*>(fail_host) + off); }
+    // Pinned staging ring of the host-pointer calls (stage_h2d / stage_d2h below): STAGE_N chunks of stage_chunk bytes.
+    // A chunk is re-used once the copy that last used it has completed (stage_ev); a device-to-host chunk additionally
+    // carries the unpacking into the caller's array that follows its copy.
+    static constexpr int STAGE_N = 4;
+    struct StageOut {
+        char* h_dst = nullptr;
+        size_t h_pitch = 0, row_bytes = 0, c_pitch = 0;
+        size_t rows = 0;
+    };
+    char* stage = nullptr;
+    size_t stage_chunk = 0;
+    hipEvent_t stage_ev[STAGE_N] = {nullptr, nullptr, nullptr, nullptr};
+    int stage_state[STAGE_N] = {0, 0, 0, 0};  // 0 free, 1 host-to-device copy queued, 2 device-to-host copy queued (unpack follows)
+    StageOut stage_out[STAGE_N];
+    int stage_next = 0;
     // job / plane tables of the batched device entry points: a small ring of (pinned host, device) buffer pairs; entry i is
     // re-used once the upload recorded in tbl_ev[i] has been made (the device side is ordered by the stream itself)
     static constexpr int TBL_RING = 4;
@@ -301,6 +320,9 @@ struct hk_ctx {
     std::mutex comm_mu;          // collectives of one communicator are queued in one order on every rank
     double* comm_xchg = nullptr; // device exchange buffer of hk_block_norm_split_comm_dev
     size_t comm_xchg_doubles = 0;
+    // hk_memcpy_h2d / hk_memcpy_d2h / hk_selftest: a stream + pinned staging ring of their own, one caller at a time
+    Slot xfer;
+    std::mutex xfer_mu;
 };
 
 struct hk_event {
@@ -404,6 +426,207 @@ int ensure_dev(Slot& s, size_t bytes) {
     if (dev_malloc(&s.dev, want) != hipSuccess) return fail(HK_ERR_NOMEM, "hipMalloc(%zu) failed", want);
     s.dev_bytes = want;
     return HK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Host staging.  BASELINE.json north_star: "blocks stream ... into pinned host buffers and hipMemcpyAsync to HBM".  The HIP
+// runtime is only ever handed page-locked memory: the library's own ring (pack on the host -> ONE contiguous hipMemcpyAsync
+// per chunk -> pitched layout on the device, and the reverse), or the caller's arrays when those are page-locked already
+// (hk_host_alloc / hk_host_register: direct, fully asynchronous).  The runtime's pageable paths -- pinning caller pages on
+// the fly, rect copies into unaligned few-byte rows of a numpy buffer -- are not part of the product.
+constexpr size_t STAGE_CHUNK_MIN = 8u << 20;
+
+// is [p, p + bytes) page-locked host memory known to the runtime?
+bool host_is_pinned(const void* p, size_t bytes) {
+    hipPointerAttribute_t attr;
+    const char* c = static_cast<const char*>(p);
+    bool ok = hipPointerGetAttributes(&attr, c) == hipSuccess && attr.type == hipMemoryTypeHost;
+    if (ok && bytes > 1) ok = hipPointerGetAttributes(&attr, c + bytes - 1) == hipSuccess && attr.type == hipMemoryTypeHost;
+    (void)hipGetLastError();  // pageable memory: the query itself fails
+    return ok;
+}
+
+int ensure_pin(Slot& s) {
+    if (s.fail_host) return HK_OK;
+    if (hipHostMalloc(reinterpret_cast<void**>(&s.fail_host), Slot::PIN_BYTES, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        s.fail_host = nullptr;
+        return fail(HK_ERR_NOMEM, "hipHostMalloc(%zu) failed", (size_t)Slot::PIN_BYTES);
+    }
+    memset(s.fail_host, 0, Slot::PIN_BYTES);
+    return HK_OK;
+}
+
+// the copy (and unpacking) that last used chunk `i` is complete
+int stage_settle(Slot& s, int i) {
+    if (s.stage_state[i] == 0) return HK_OK;
+    HK_HIP(hipEventSynchronize(s.stage_ev[i]));
+    if (s.stage_state[i] == 2) {
+        const Slot::StageOut& o = s.stage_out[i];
+        const char* c = s.stage + (size_t)i * s.stage_chunk;
+        if (o.h_pitch == o.row_bytes && o.c_pitch == o.row_bytes) memcpy(o.h_dst, c, o.rows * o.row_bytes);
+        else
+            for (size_t r = 0; r < o.rows; ++r) memcpy(o.h_dst + r * o.h_pitch, c + r * o.c_pitch, o.row_bytes);
+    }
+    s.stage_state[i] = 0;
+    return HK_OK;
+}
+
+// every queued staging copy of the slot has completed and has been unpacked (the caller's output arrays are final)
+int stage_drain(Slot& s) {
+    if (!s.stage) return HK_OK;
+    for (int k = 0; k < Slot::STAGE_N; ++k) {
+        const int rc = stage_settle(s, (s.stage_next + k) % Slot::STAGE_N);  // oldest first
+        if (rc) return rc;
+    }
+    return HK_OK;
+}
+
+int ensure_stage(Slot& s, size_t min_chunk) {
+    // HK_STAGE_CHUNK_KB: chunk size for tests of the chunked paths (default 8 MB; never below one device row)
+    static const size_t chunk_min = [] {
+        const char* e = getenv("HK_STAGE_CHUNK_KB");
+        return (e && atol(e) > 0) ? (size_t)atol(e) << 10 : STAGE_CHUNK_MIN;
+    }();
+    const size_t want = std::max(min_chunk, chunk_min);
+    if (s.stage && s.stage_chunk >= want) return HK_OK;
+    int rc = stage_drain(s);
+    if (rc) return rc;
+    if (s.stage) HK_HIP(hipHostFree(s.stage));
+    s.stage = nullptr, s.stage_chunk = 0;
+    const size_t chunk = (want + 4095) / 4096 * 4096;
+    if (hipHostMalloc(reinterpret_cast<void**>(&s.stage), chunk * Slot::STAGE_N, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        s.stage = nullptr;
+        return fail(HK_ERR_NOMEM, "hipHostMalloc(%zu) failed", chunk * Slot::STAGE_N);
+    }
+    s.stage_chunk = chunk;
+    for (int i = 0; i < Slot::STAGE_N; ++i)
+        if (!s.stage_ev[i]) HK_HIP(hipEventCreateWithFlags(&s.stage_ev[i], hipEventDisableTiming));
+    return HK_OK;
+}
+
+int stage_take(Slot& s, int* chunk) {
+    const int i = s.stage_next;
+    s.stage_next = (s.stage_next + 1) % Slot::STAGE_N;
+    const int rc = stage_settle(s, i);
+    *chunk = i;
+    return rc;
+}
+
+// `rows` rows of `row_bytes` from the host (rows h_pitch bytes apart) to the device (rows d_pitch bytes apart), queued on the
+// slot's stream.  The host side may be released when the call returns (pageable memory: it has been packed; page-locked
+// memory: the caller keeps it until the stream has been synchronised, as the entry points do before they return).
+int stage_h2d(Slot& s, void* d_dst, size_t d_pitch, const void* h_src, size_t h_pitch, size_t row_bytes, size_t rows) {
+    if (rows == 0 || row_bytes == 0) return HK_OK;
+    if (rows == 1) h_pitch = d_pitch = row_bytes;
+    const bool flat = h_pitch == row_bytes && d_pitch == row_bytes;
+    if (host_is_pinned(h_src, (rows - 1) * h_pitch + row_bytes)) {
+        if (flat) HK_HIP(hipMemcpyAsync(d_dst, h_src, rows * row_bytes, hipMemcpyHostToDevice, s.stream));
+        else HK_HIP(hipMemcpy2DAsync(d_dst, d_pitch, h_src, h_pitch, row_bytes, rows, hipMemcpyHostToDevice, s.stream));
+        return HK_OK;
+    }
+    int rc = ensure_stage(s, flat ? 0 : d_pitch);
+    if (rc) return rc;
+    const char* h = static_cast<const char*>(h_src);
+    char* d = static_cast<char*>(d_dst);
+    if (flat) {  // a byte stream
+        const size_t total = rows * row_bytes;
+        for (size_t off = 0; off < total; off += s.stage_chunk) {
+            const size_t n = std::min(s.stage_chunk, total - off);
+            int i;
+            if ((rc = stage_take(s, &i))) return rc;
+            char* c = s.stage + (size_t)i * s.stage_chunk;
+            memcpy(c, h + off, n);
+            HK_HIP(hipMemcpyAsync(d + off, c, n, hipMemcpyHostToDevice, s.stream));
+            HK_HIP(hipEventRecord(s.stage_ev[i], s.stream));
+            s.stage_state[i] = 1;
+        }
+        return HK_OK;
+    }
+    // packed at the DEVICE pitch: the chunk maps onto the device rows with one contiguous copy (the padding between two
+    // rows travels along; it belongs to the plane and nobody reads it)
+    const size_t per = std::max<size_t>(s.stage_chunk / d_pitch, 1);
+    for (size_t r0 = 0; r0 < rows; r0 += per) {
+        const size_t n = std::min(per, rows - r0);
+        int i;
+        if ((rc = stage_take(s, &i))) return rc;
+        char* c = s.stage + (size_t)i * s.stage_chunk;
+        for (size_t r = 0; r < n; ++r) memcpy(c + r * d_pitch, h + (r0 + r) * h_pitch, row_bytes);
+        HK_HIP(hipMemcpyAsync(d + r0 * d_pitch, c, (n - 1) * d_pitch + row_bytes, hipMemcpyHostToDevice, s.stream));
+        HK_HIP(hipEventRecord(s.stage_ev[i], s.stream));
+        s.stage_state[i] = 1;
+    }
+    return HK_OK;
+}
+
+// the reverse; the caller's array is final after stage_drain() (pageable) / after the stream has been synchronised (pinned)
+int stage_d2h(Slot& s, void* h_dst, size_t h_pitch, const void* d_src, size_t d_pitch, size_t row_bytes, size_t rows) {
+    if (rows == 0 || row_bytes == 0) return HK_OK;
+    if (rows == 1) h_pitch = d_pitch = row_bytes;
+    const bool flat = h_pitch == row_bytes && d_pitch == row_bytes;
+    if (host_is_pinned(h_dst, (rows - 1) * h_pitch + row_bytes)) {
+        if (flat) HK_HIP(hipMemcpyAsync(h_dst, d_src, rows * row_bytes, hipMemcpyDeviceToHost, s.stream));
+        else HK_HIP(hipMemcpy2DAsync(h_dst, h_pitch, d_src, d_pitch, row_bytes, rows, hipMemcpyDeviceToHost, s.stream));
+        return HK_OK;
+    }
+    int rc = ensure_stage(s, flat ? 0 : d_pitch);
+    if (rc) return rc;
+    char* h = static_cast<char*>(h_dst);
+    const char* d = static_cast<const char*>(d_src);
+    if (flat) {
+        const size_t total = rows * row_bytes;
+        for (size_t off = 0; off < total; off += s.stage_chunk) {
+            const size_t n = std::min(s.stage_chunk, total - off);
+            int i;
+            if ((rc = stage_take(s, &i))) return rc;
+            HK_HIP(hipMemcpyAsync(s.stage + (size_t)i * s.stage_chunk, d + off, n, hipMemcpyDeviceToHost, s.stream));
+            HK_HIP(hipEventRecord(s.stage_ev[i], s.stream));
+            s.stage_state[i] = 2;
+            s.stage_out[i].h_dst = h + off, s.stage_out[i].h_pitch = n, s.stage_out[i].row_bytes = n;
+            s.stage_out[i].c_pitch = n, s.stage_out[i].rows = 1;
+        }
+        return HK_OK;
+    }
+    const size_t per = std::max<size_t>(s.stage_chunk / d_pitch, 1);
+    for (size_t r0 = 0; r0 < rows; r0 += per) {
+        const size_t n = std::min(per, rows - r0);
+        int i;
+        if ((rc = stage_take(s, &i))) return rc;
+        HK_HIP(hipMemcpyAsync(s.stage + (size_t)i * s.stage_chunk, d + r0 * d_pitch, (n - 1) * d_pitch + row_bytes,
+                              hipMemcpyDeviceToHost, s.stream));
+        HK_HIP(hipEventRecord(s.stage_ev[i], s.stream));
+        s.stage_state[i] = 2;
+        s.stage_out[i].h_dst = h + r0 * h_pitch, s.stage_out[i].h_pitch = h_pitch, s.stage_out[i].row_bytes = row_bytes;
+        s.stage_out[i].c_pitch = d_pitch, s.stage_out[i].rows = n;
+    }
+    return HK_OK;
+}
+
+// end of a host-pointer call: everything queued on the slot's stream has run and every output array is final
+int stage_finish(Slot& s) {
+    const int rc = stage_drain(s);
+    if (rc) return rc;
+    HK_HIP(hipStreamSynchronize(s.stream));
+    return HK_OK;
+}
+
+void slot_release(Slot& s) {
+    if (s.stream) (void)hipStreamSynchronize(s.stream);
+    if (s.dev) (void)dev_free(s.dev);
+    if (s.norm_ws) (void)dev_free(s.norm_ws);
+    if (s.aux) (void)dev_free(s.aux);
+    if (s.fail_host) (void)hipHostFree(s.fail_host);
+    if (s.stage) (void)hipHostFree(s.stage);
+    for (int i = 0; i < Slot::STAGE_N; ++i)
+        if (s.stage_ev[i]) (void)hipEventDestroy(s.stage_ev[i]);
+    for (int i = 0; i < Slot::TBL_RING; ++i) {
+        if (s.tbl_host[i]) (void)hipHostFree(s.tbl_host[i]);
+        if (s.tbl_dev[i]) (void)dev_free(s.tbl_dev[i]);
+        if (s.tbl_ev[i]) (void)hipEventDestroy(s.tbl_ev[i]);
+    }
+    if (s.stream) (void)hipStreamDestroy(s.stream);
+    s = Slot();
 }
 
 // rasterio.enums.Resampling values with a device kernel (hk_resample.hip)
@@ -725,7 +948,8 @@ int fit_on_device(hk_ctx* ctx, Slot& sl, const hk_fit_desc* desc, const double* 
     HK_HIP(hipMemsetAsync(d_fail, 0, sizeof(unsigned long long), sl.stream));
     if (blk) {
         if (norm_in) {
-            HK_HIP(hipMemcpyAsync(d_norm, norm_in, 2 * sizeof(double), hipMemcpyHostToDevice, sl.stream));
+            memcpy(sl.pin<double>(Slot::PIN_NORM_IN), norm_in, 2 * sizeof(double));  // (caller memory -> pinned words)
+            HK_HIP(hipMemcpyAsync(d_norm, sl.pin<double>(Slot::PIN_NORM_IN), 2 * sizeof(double), hipMemcpyHostToDevice, sl.stream));
         } else {
             hk::NormArgs na;
             na.src = d_src, na.ref = d_ref, na.height = height, na.width = width, na.stride = stride;
@@ -853,8 +1077,8 @@ int run_host(hk_ctx* ctx, const hk_fit_desc* desc, const hk_io_desc* io, const v
     auto stage_in = [&](const void* host, int64_t hstride, int dt, float* dplane, size_t o_raw) -> int {
         const size_t es = hk::dtype_size(dt);
         void* dst = dt ? static_cast<void*>(base + o_raw) : static_cast<void*>(dplane);
-        HK_HIP(hipMemcpy2DAsync(dst, stride * es, host, hstride * es, (size_t)width * es, height, hipMemcpyHostToDevice,
-                                sl.stream));
+        const int src_rc = stage_h2d(sl, dst, stride * es, host, hstride * es, (size_t)width * es, height);
+        if (src_rc) return src_rc;
         if (dt) HK_HIP(hk::launch_cast_in(dt, dst, stride, dplane, stride, height, width, sl.stream));
         return HK_OK;
     };
@@ -869,8 +1093,9 @@ int run_host(hk_ctx* ctx, const hk_fit_desc* desc, const hk_io_desc* io, const v
         na.src_nd_mode = desc->src_nodata_mode, na.ref_nd_mode = desc->ref_nodata_mode;
         na.src_nodata = desc->src_nodata, na.ref_nodata = desc->ref_nodata;
         HK_HIP(hk::launch_block_norm(na, d_ws, d_norm, sl.stream));
-        if (norm_out) HK_HIP(hipMemcpyAsync(norm_out, d_norm, 2 * sizeof(double), hipMemcpyDeviceToHost, sl.stream));
-        HK_HIP(hipStreamSynchronize(sl.stream));
+        HK_HIP(hipMemcpyAsync(sl.pin<double>(Slot::PIN_NORM), d_norm, 2 * sizeof(double), hipMemcpyDeviceToHost, sl.stream));
+        if ((rc = stage_finish(sl))) return rc;
+        if (norm_out) memcpy(norm_out, sl.pin<double>(Slot::PIN_NORM), 2 * sizeof(double));
         return HK_OK;
     }
 
@@ -880,22 +1105,20 @@ int run_host(hk_ctx* ctx, const hk_fit_desc* desc, const hk_io_desc* io, const v
         const size_t wbytes = (size_t)wcols * sizeof(float);
         float* outs[3] = {d_gain, d_off, d_r2};
         if (params_out)
-            for (int b = 0; b < n_param_bands; ++b)
-                HK_HIP(hipMemcpy2DAsync(params_out + (size_t)b * out_band_stride, par_stride * sizeof(float),
-                                        outs[b] + win_off, stride * sizeof(float), wbytes, wrows, hipMemcpyDeviceToHost,
-                                        sl.stream));
+            for (int b = 0; b < n_param_bands; ++b) {
+                const int prc = stage_d2h(sl, params_out + (size_t)b * out_band_stride, par_stride * sizeof(float),
+                                          outs[b] + win_off, stride * sizeof(float), wbytes, wrows);
+                if (prc) return prc;
+            }
         if (corr_out) {
             if (out_cast) {
                 const size_t es = hk::dtype_size(odt);
                 char* d_raw = base + o_raw_o;
                 HK_HIP(hk::launch_cast_out(odt, d_corr, stride, d_raw, stride, height, width, io->out_has_nodata,
                                            io->out_nodata, sl.stream));
-                HK_HIP(hipMemcpy2DAsync(corr_out, out_stride * es, d_raw + win_off * es, stride * es, (size_t)wcols * es,
-                                        wrows, hipMemcpyDeviceToHost, sl.stream));
-            } else {
-                HK_HIP(hipMemcpy2DAsync(corr_out, out_stride * sizeof(float), d_corr + win_off, stride * sizeof(float),
-                                        wbytes, wrows, hipMemcpyDeviceToHost, sl.stream));
+                return stage_d2h(sl, corr_out, out_stride * es, d_raw + win_off * es, stride * es, (size_t)wcols * es, wrows);
             }
+            return stage_d2h(sl, corr_out, out_stride * sizeof(float), d_corr + win_off, stride * sizeof(float), wbytes, wrows);
         }
         return HK_OK;
     };
@@ -908,11 +1131,13 @@ int run_host(hk_ctx* ctx, const hk_fit_desc* desc, const hk_io_desc* io, const v
     rc = fit_on_device(ctx, sl, desc, norm_in, d_src, d_ref, height, width, stride, d_gain, d_off, d_r2, d_corr, d_norm,
                        d_fail, d_ws, &pending, (ow && !out_cast) ? kwin : nullptr);
     if (rc) return rc;
-    if (norm_out && blk) HK_HIP(hipMemcpyAsync(norm_out, d_norm, 2 * sizeof(double), hipMemcpyDeviceToHost, sl.stream));
+    if (norm_out && blk)
+        HK_HIP(hipMemcpyAsync(sl.pin<double>(Slot::PIN_NORM), d_norm, 2 * sizeof(double), hipMemcpyDeviceToHost, sl.stream));
     if ((rc = stage_out())) return rc;
     *sl.fail_host = 0;
     if (pending.active) HK_HIP(hipMemcpyAsync(sl.fail_host, d_fail, sizeof(unsigned long long), hipMemcpyDeviceToHost, sl.stream));
-    HK_HIP(hipStreamSynchronize(sl.stream));
+    if ((rc = stage_finish(sl))) return rc;
+    if (norm_out && blk) memcpy(norm_out, sl.pin<double>(Slot::PIN_NORM), 2 * sizeof(double));
     unsigned long long n_fail = *sl.fail_host;
     if (pending.active) {
         bool requeued = false;
@@ -921,7 +1146,7 @@ int run_host(hk_ctx* ctx, const hk_fit_desc* desc, const hk_io_desc* io, const v
         if (requeued) {
             if ((rc = stage_out())) return rc;
             HK_HIP(hipMemcpyAsync(sl.fail_host, d_fail, sizeof(unsigned long long), hipMemcpyDeviceToHost, sl.stream));
-            HK_HIP(hipStreamSynchronize(sl.stream));
+            if ((rc = stage_finish(sl))) return rc;
             n_fail = *sl.fail_host;  // (the in-painting passes do not count; a re-run of the complete build does)
         }
     }
@@ -977,9 +1202,16 @@ int hk_ctx_create(int device_id, int n_streams, hk_ctx** out) {
             hk_ctx_destroy(ctx);
             return fail(HK_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
         }
-        if (hipHostMalloc(reinterpret_cast<void**>(&s.fail_host), 64, hipHostMallocDefault) != hipSuccess) {
+        if (ensure_pin(s) != HK_OK) {
             hk_ctx_destroy(ctx);
-            return fail(HK_ERR_NOMEM, "hipHostMalloc failed");
+            return HK_ERR_NOMEM;
+        }
+    }
+    {
+        hipError_t e = hipStreamCreateWithFlags(&ctx->xfer.stream, hipStreamNonBlocking);
+        if (e != hipSuccess || ensure_pin(ctx->xfer) != HK_OK) {
+            hk_ctx_destroy(ctx);
+            return e != hipSuccess ? fail(HK_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)) : HK_ERR_NOMEM;
         }
     }
     register_gpu_fault_report();  // (HIP, and with it the HSA runtime, is up: the streams above were created on it)
@@ -990,19 +1222,8 @@ int hk_ctx_create(int device_id, int n_streams, hk_ctx** out) {
 int hk_ctx_destroy(hk_ctx* ctx) {
     if (!ctx) return HK_OK;
     (void)hipSetDevice(ctx->device);
-    for (auto& s : ctx->slots) {
-        if (s.stream) (void)hipStreamSynchronize(s.stream);
-        if (s.dev) (void)dev_free(s.dev);
-        if (s.norm_ws) (void)dev_free(s.norm_ws);
-        if (s.aux) (void)dev_free(s.aux);
-        if (s.fail_host) (void)hipHostFree(s.fail_host);
-        for (int i = 0; i < Slot::TBL_RING; ++i) {
-            if (s.tbl_host[i]) (void)hipHostFree(s.tbl_host[i]);
-            if (s.tbl_dev[i]) (void)dev_free(s.tbl_dev[i]);
-            if (s.tbl_ev[i]) (void)hipEventDestroy(s.tbl_ev[i]);
-        }
-        if (s.stream) (void)hipStreamDestroy(s.stream);
-    }
+    for (auto& s : ctx->slots) slot_release(s);
+    slot_release(ctx->xfer);
     if (ctx->comm && rccl().ok) rccl().CommDestroy(ctx->comm);
     if (ctx->comm_xchg) (void)dev_free(ctx->comm_xchg);
     delete ctx;
@@ -1073,14 +1294,12 @@ int hk_apply(hk_ctx* ctx, const float* src, int64_t src_stride, const float* par
     float* d_off = reinterpret_cast<float*>(base + 2 * plane);
     float* d_out = reinterpret_cast<float*>(base + 3 * plane);
     const size_t wbytes = (size_t)width * sizeof(float);
-    HK_HIP(hipMemcpy2DAsync(d_src, stride * 4, src, src_stride * 4, wbytes, height, hipMemcpyHostToDevice, sl.stream));
-    HK_HIP(hipMemcpy2DAsync(d_gain, stride * 4, params, wbytes, wbytes, height, hipMemcpyHostToDevice, sl.stream));
-    HK_HIP(hipMemcpy2DAsync(d_off, stride * 4, params + (size_t)height * width, wbytes, wbytes, height,
-                            hipMemcpyHostToDevice, sl.stream));
+    if ((rc = stage_h2d(sl, d_src, stride * 4, src, src_stride * 4, wbytes, height))) return rc;
+    if ((rc = stage_h2d(sl, d_gain, stride * 4, params, wbytes, wbytes, height))) return rc;
+    if ((rc = stage_h2d(sl, d_off, stride * 4, params + (size_t)height * width, wbytes, wbytes, height))) return rc;
     HK_HIP(hk::launch_apply(d_src, d_gain, d_off, d_out, height, width, stride, sl.stream));
-    HK_HIP(hipMemcpy2DAsync(out, wbytes, d_out, stride * 4, wbytes, height, hipMemcpyDeviceToHost, sl.stream));
-    HK_HIP(hipStreamSynchronize(sl.stream));
-    return HK_OK;
+    if ((rc = stage_d2h(sl, out, wbytes, d_out, stride * 4, wbytes, height))) return rc;
+    return stage_finish(sl);
 }
 
 int hk_refspace_fit_apply(hk_ctx* ctx, const hk_fit_desc* desc, const hk_io_desc* io, const hk_space_desc* space,
@@ -1146,7 +1365,8 @@ int hk_refspace_fit_apply(hk_ctx* ctx, const hk_fit_desc* desc, const hk_io_desc
                         int w) -> int {
         const size_t es = hk::dtype_size(dt);
         void* dst = dt ? static_cast<void*>(base + o_raw) : static_cast<void*>(dplane);
-        HK_HIP(hipMemcpy2DAsync(dst, dstride * es, host, hstride * es, (size_t)w * es, h, hipMemcpyHostToDevice, sl.stream));
+        const int src_rc = stage_h2d(sl, dst, dstride * es, host, hstride * es, (size_t)w * es, h);
+        if (src_rc) return src_rc;
         if (dt) HK_HIP(hk::launch_cast_in(dt, dst, dstride, dplane, dstride, h, w, sl.stream));
         return HK_OK;
     };
@@ -1203,22 +1423,20 @@ int hk_refspace_fit_apply(hk_ctx* ctx, const hk_fit_desc* desc, const hk_io_desc
         float* outs[3] = {d_gain, d_off, d_r2};
         const size_t wb = (size_t)ref_width * 4;
         for (int b = 0; b < n_param_bands; ++b)
-            HK_HIP(hipMemcpy2DAsync(params_out + (size_t)b * ref_height * ref_width, wb, outs[b], rs * 4, wb, ref_height,
-                                    hipMemcpyDeviceToHost, sl.stream));
+            if ((rc = stage_d2h(sl, params_out + (size_t)b * ref_height * ref_width, wb, outs[b], rs * 4, wb, ref_height))) return rc;
     }
     if (out_cast) {
         const size_t es = hk::dtype_size(odt);
         void* d_raw = base + o_raw_o;
         HK_HIP(hk::launch_cast_out(odt, d_corr, ss, d_raw, ss, src_height, src_width, io->out_has_nodata, io->out_nodata,
                                    sl.stream));
-        HK_HIP(hipMemcpy2DAsync(corr_out, (size_t)src_width * es, d_raw, ss * es, (size_t)src_width * es, src_height,
-                                hipMemcpyDeviceToHost, sl.stream));
+        if ((rc = stage_d2h(sl, corr_out, (size_t)src_width * es, d_raw, ss * es, (size_t)src_width * es, src_height))) return rc;
     } else {
-        HK_HIP(hipMemcpy2DAsync(corr_out, (size_t)src_width * 4, d_corr, ss * 4, (size_t)src_width * 4, src_height,
-                                hipMemcpyDeviceToHost, sl.stream));
+        if ((rc = stage_d2h(sl, corr_out, (size_t)src_width * 4, d_corr, ss * 4, (size_t)src_width * 4, src_height))) return rc;
     }
-    if (r2_fail_count) HK_HIP(hipMemcpyAsync(r2_fail_count, d_fail, sizeof(uint64_t), hipMemcpyDeviceToHost, sl.stream));
-    HK_HIP(hipStreamSynchronize(sl.stream));
+    HK_HIP(hipMemcpyAsync(sl.fail_host, d_fail, sizeof(uint64_t), hipMemcpyDeviceToHost, sl.stream));
+    if ((rc = stage_finish(sl))) return rc;
+    if (r2_fail_count) *r2_fail_count = *sl.fail_host;
     return HK_OK;
 }
 
@@ -1243,13 +1461,12 @@ int hk_reproject(hk_ctx* ctx, const float* src, int32_t n_bands, int32_t src_hei
     if (rc) return rc;
     float* d_src = static_cast<float*>(sl.dev);
     float* d_dst = reinterpret_cast<float*>(static_cast<char*>(sl.dev) + o_dst);
-    HK_HIP(hipMemcpyAsync(d_src, src, sbytes, hipMemcpyHostToDevice, sl.stream));
+    if ((rc = stage_h2d(sl, d_src, sbytes, src, sbytes, sbytes, 1))) return rc;
     HK_HIP(hk::launch_resample(resampling, d_src, src_width, (long long)src_height * src_width, src_height, src_width,
                                n_bands, src_nodata_mode, src_nodata, kx, ox, ky, oy, d_dst, dst_width,
                                (long long)dst_height * dst_width, dst_height, dst_width, dst_fill, sl.stream));
-    HK_HIP(hipMemcpyAsync(dst, d_dst, dbytes, hipMemcpyDeviceToHost, sl.stream));
-    HK_HIP(hipStreamSynchronize(sl.stream));
-    return HK_OK;
+    if ((rc = stage_d2h(sl, dst, dbytes, d_dst, dbytes, dbytes, 1))) return rc;
+    return stage_finish(sl);
 }
 
 int hk_partial_mask(hk_ctx* ctx, const float* in, int64_t in_stride, int32_t in_nodata_mode, float in_nodata,
@@ -1283,22 +1500,21 @@ int hk_partial_mask(hk_ctx* ctx, const float* in, int64_t in_stride, int32_t in_
     float* d_corr = corr_out ? reinterpret_cast<float*>(base + o_corr) : nullptr;
     unsigned char* d_mask = mask_out ? reinterpret_cast<unsigned char*>(base + o_mask) : nullptr;
     const size_t wb = (size_t)width * 4, sb = (size_t)stride * 4;
-    HK_HIP(hipMemcpy2DAsync(d_in, sb, in, in_stride * 4, wb, height, hipMemcpyHostToDevice, sl.stream));
+    if ((rc = stage_h2d(sl, d_in, sb, in, in_stride * 4, wb, height))) return rc;
     for (int b = 0; b < n_param_bands; ++b)
-        HK_HIP(hipMemcpy2DAsync(d_par + (size_t)b * stride * height, sb, params + (size_t)b * height * width, wb, wb, height,
-                                hipMemcpyHostToDevice, sl.stream));
-    if (src) HK_HIP(hipMemcpy2DAsync(d_src, sb, src, src_stride * 4, wb, height, hipMemcpyHostToDevice, sl.stream));
+        if ((rc = stage_h2d(sl, d_par + (size_t)b * stride * height, sb, params + (size_t)b * height * width, wb, wb, height)))
+            return rc;
+    if (src && (rc = stage_h2d(sl, d_src, sb, src, src_stride * 4, wb, height))) return rc;
     HK_HIP(hk::launch_partial_mask(d_in, in_nodata_mode, in_nodata, d_par, n_param_bands, stride * height, d_src, height,
                                    width, stride, kh, kw, reinterpret_cast<unsigned short*>(base + o_cnt), d_pout, d_corr,
                                    d_mask, sl.stream));
     if (params_out)
         for (int b = 0; b < n_param_bands; ++b)
-            HK_HIP(hipMemcpy2DAsync(params_out + (size_t)b * height * width, wb, d_pout + (size_t)b * stride * height, sb,
-                                    wb, height, hipMemcpyDeviceToHost, sl.stream));
-    if (corr_out) HK_HIP(hipMemcpy2DAsync(corr_out, wb, d_corr, sb, wb, height, hipMemcpyDeviceToHost, sl.stream));
-    if (mask_out) HK_HIP(hipMemcpy2DAsync(mask_out, width, d_mask, stride, width, height, hipMemcpyDeviceToHost, sl.stream));
-    HK_HIP(hipStreamSynchronize(sl.stream));
-    return HK_OK;
+            if ((rc = stage_d2h(sl, params_out + (size_t)b * height * width, wb, d_pout + (size_t)b * stride * height, sb, wb, height)))
+                return rc;
+    if (corr_out && (rc = stage_d2h(sl, corr_out, wb, d_corr, sb, wb, height))) return rc;
+    if (mask_out && (rc = stage_d2h(sl, mask_out, width, d_mask, stride, width, height))) return rc;
+    return stage_finish(sl);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1353,15 +1569,21 @@ int hk_dev_free(hk_ctx* ctx, void* dptr) {
 }
 int hk_memcpy_h2d(hk_ctx* ctx, void* dst, const void* src, size_t bytes) {
     if (!ctx) return fail(HK_ERR_ARG, "ctx is NULL");
+    if (!bytes) return HK_OK;
+    if (!dst || !src) return fail(HK_ERR_ARG, "NULL pointer argument");
     HK_ENTER(ctx);
-    HK_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
-    return HK_OK;
+    std::lock_guard<std::mutex> lk(ctx->xfer_mu);
+    const int rc = stage_h2d(ctx->xfer, dst, bytes, src, bytes, bytes, 1);
+    return rc ? rc : stage_finish(ctx->xfer);
 }
 int hk_memcpy_d2h(hk_ctx* ctx, void* dst, const void* src, size_t bytes) {
     if (!ctx) return fail(HK_ERR_ARG, "ctx is NULL");
+    if (!bytes) return HK_OK;
+    if (!dst || !src) return fail(HK_ERR_ARG, "NULL pointer argument");
     HK_ENTER(ctx);
-    HK_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
-    return HK_OK;
+    std::lock_guard<std::mutex> lk(ctx->xfer_mu);
+    const int rc = stage_d2h(ctx->xfer, dst, bytes, src, bytes, bytes, 1);
+    return rc ? rc : stage_finish(ctx->xfer);
 }
 int hk_memset(hk_ctx* ctx, void* dst, int value, size_t bytes) {
     if (!ctx) return fail(HK_ERR_ARG, "ctx is NULL");
@@ -1461,6 +1683,7 @@ int hk_fail_counts_async(hk_ctx* ctx, const hk_dev_job* job, uint64_t* host_coun
     HK_ENTER(ctx);
     Slot& sl = ctx->slots[job->stream];
     const size_t bytes = (size_t)job->n_bands * sizeof(unsigned long long);
+    if (!host_is_pinned(host_counts, bytes)) return fail(HK_ERR_ARG, "host_counts must be page-locked memory (hk_host_alloc / hk_host_register)");
     HK_HIP(hipMemcpyAsync(host_counts, job->fail_count, bytes, hipMemcpyDeviceToHost, sl.stream));
     // the counters are consumed: the next hk_fit_apply_dev into this buffer starts from zero
     HK_HIP(hipMemsetAsync(job->fail_count, 0, bytes, sl.stream));
@@ -1551,11 +1774,13 @@ int hk_inpaint_dev_counts(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job
             a.fail_count = d_fail;
             HK_HIP(hipMemsetAsync(d_fail, 0, sizeof(unsigned long long), sl.stream));
             HK_HIP(hk::launch_fit_apply(a, desc->model, r2, sl.stream));
-            HK_HIP(hipMemcpyAsync(&n_fail, d_fail, sizeof(n_fail), hipMemcpyDeviceToHost, sl.stream));
+            unsigned long long* const word = sl.pin<unsigned long long>(Slot::PIN_WORD);  // (pinned; one caller per stream)
+            HK_HIP(hipMemcpyAsync(word, d_fail, sizeof(n_fail), hipMemcpyDeviceToHost, sl.stream));
             HK_HIP(hipMemsetAsync(d_fail, 0, sizeof(unsigned long long), sl.stream));
             lk.unlock();  // other streams' callers need not wait for this stream to drain
             HK_HIP(hipStreamSynchronize(sl.stream));
             lk.lock();
+            n_fail = *word;
             pre_off = a.offset, pre_flag = a.flag;
             a.fail_count = nullptr, a.flag = nullptr, a.offset = caller_off;
         }
@@ -1583,8 +1808,10 @@ int hk_inpaint_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* job, 
     HK_ENTER(ctx);
     Slot& sl = ctx->slots[job->stream];
     std::vector<uint64_t> counts((size_t)job->n_bands);
-    HK_HIP(hipMemcpyAsync(counts.data(), job->fail_count, counts.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, sl.stream));
+    uint64_t* const pinned = sl.pin<uint64_t>(Slot::PIN_COUNTS);  // <= 1024 counters (checked above)
+    HK_HIP(hipMemcpyAsync(pinned, job->fail_count, counts.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, sl.stream));
     HK_HIP(hipStreamSynchronize(sl.stream));
+    memcpy(counts.data(), pinned, counts.size() * sizeof(uint64_t));
     // the counters are consumed: the next hk_fit_apply_dev of this job starts from zero
     HK_HIP(hipMemsetAsync(job->fail_count, 0, counts.size() * sizeof(uint64_t), sl.stream));
     return hk_inpaint_dev_counts(ctx, desc, job, counts.data(), n_fail_out);
@@ -1656,16 +1883,17 @@ int hk_compare_sums(hk_ctx* ctx, const float* src, int64_t src_stride, int32_t s
     void* d_ws = base + 2 * plane;
     double* d_sums = reinterpret_cast<double*>(base + 2 * plane + ws_bytes);
     const size_t wbytes = (size_t)width * sizeof(float);
-    HK_HIP(hipMemcpy2DAsync(d_src, stride * 4, src, src_stride * 4, wbytes, height, hipMemcpyHostToDevice, sl.stream));
-    HK_HIP(hipMemcpy2DAsync(d_ref, stride * 4, ref, ref_stride * 4, wbytes, height, hipMemcpyHostToDevice, sl.stream));
+    if ((rc = stage_h2d(sl, d_src, stride * 4, src, src_stride * 4, wbytes, height))) return rc;
+    if ((rc = stage_h2d(sl, d_ref, stride * 4, ref, ref_stride * 4, wbytes, height))) return rc;
     hk::CompareArgs ca;
     memset(&ca, 0, sizeof(ca));
     ca.src = d_src, ca.ref = d_ref, ca.height = height, ca.width = width;
     ca.src_stride = ca.ref_stride = stride, ca.src_band_stride = ca.ref_band_stride = 0, ca.n_bands = 1;
     ca.src_nd_mode = src_nodata_mode, ca.ref_nd_mode = ref_nodata_mode, ca.src_nodata = src_nodata, ca.ref_nodata = ref_nodata;
     HK_HIP(hk::launch_compare_sums(ca, d_ws, d_sums, sl.stream));
-    HK_HIP(hipMemcpyAsync(sums_out, d_sums, 7 * sizeof(double), hipMemcpyDeviceToHost, sl.stream));
-    HK_HIP(hipStreamSynchronize(sl.stream));
+    HK_HIP(hipMemcpyAsync(sl.pin<double>(Slot::PIN_SUMS), d_sums, 7 * sizeof(double), hipMemcpyDeviceToHost, sl.stream));
+    if ((rc = stage_finish(sl))) return rc;
+    memcpy(sums_out, sl.pin<double>(Slot::PIN_SUMS), 7 * sizeof(double));
     return HK_OK;
 }
 
@@ -1885,6 +2113,12 @@ int hk_fail_counts_batch_async(hk_ctx* ctx, const hk_dev_job* jobs, int32_t n_jo
         if (!jobs[j].fail_count) return fail(HK_ERR_ARG, "job %d has no fail_count", j);
     HK_ENTER(ctx);
     Slot& sl = ctx->slots[jobs[0].stream];
+    {
+        size_t n_all = 0;
+        for (int32_t j = 0; j < n_jobs; ++j) n_all += (size_t)jobs[j].n_bands;
+        if (!host_is_pinned(host_counts, n_all * sizeof(uint64_t)))
+            return fail(HK_ERR_ARG, "host_counts must be page-locked memory (hk_host_alloc / hk_host_register)");
+    }
     // one copy + one clearing per run of jobs whose counters lie back to back in device memory (a caller that allocates the
     // counters of a batch as one array gets exactly one of each)
     size_t done = 0;  // counters copied so far = offset into host_counts
@@ -2092,7 +2326,9 @@ int hk_selftest(hk_ctx* ctx) {
     hipError_t e = hipMemset(d, 0, sizeof(int));
     if (e == hipSuccess) e = hk::launch_selftest(d, ctx->slots[0].stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->slots[0].stream);
-    if (e == hipSuccess) e = hipMemcpy(&code, d, sizeof(int), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->slots[0].pin<int>(Slot::PIN_WORD), d, sizeof(int), hipMemcpyDeviceToHost, ctx->slots[0].stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->slots[0].stream);
+    if (e == hipSuccess) code = *ctx->slots[0].pin<int>(Slot::PIN_WORD);
     (void)dev_free(d);  // on every path
     if (e != hipSuccess) return fail(HK_ERR_HIP, "self-test launch failed: %s", hipGetErrorString(e));
     if (code != 0) return fail(HK_ERR_HIP, "cross-lane self-test failed (code 0x%x)", code);

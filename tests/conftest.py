@@ -14,6 +14,14 @@ GOLDEN_DIR = os.path.join(REPO, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: test needs a real MI355X (run with -m gpu on the GPU box)')
+    # a fatal signal names its sender, thread and native frames (homonim_amd/abort_trace.py); in front of faulthandler
+    try:
+        from homonim_amd import abort_trace
+        log_dir = os.path.join(REPO, 'gpurun_out')
+        path = os.path.join(log_dir, f'abort_trace_{os.getpid()}.log') if os.path.isdir(log_dir) else None
+        abort_trace.install(path)
+    except Exception as ex:  # diagnostics must never stop a run
+        print(f'[conftest] abort tracer not installed: {ex}', file=sys.stderr)
 
 
 def _nodata(v):
