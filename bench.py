@@ -853,15 +853,57 @@ def end_to_end_tiles(args, ctx, dist, tiles, stride, band_stride, thresh, nd):
 
 
 # ----------------------------------------------------------------------------------------------------------------------
+def launch_ranks(n: int) -> int:
+    """ `python bench.py --gpus N` with no launcher around it: this process -- which has not touched a GPU and never will --
+    starts the N ranks as CHILD processes (one per GPU, the environment torch.distributed.run would give them: RANK /
+    LOCAL_RANK / WORLD_SIZE / MASTER_*), lets rank 0 print the one JSON line on the shared stdout and returns the worst
+    exit code.  The shape of homonim/fuse.py:394-408: one call fans the work out over a pool of workers. """
+    import socket
+    import subprocess
+    port = os.environ.get('MASTER_PORT')
+    if port is None:
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = str(sk.getsockname()[1])
+    base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=port,
+                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r), GROUP_RANK='0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    worst = 0
+    pending = set(range(n))
+    while pending:
+        for r in sorted(pending):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            pending.discard(r)
+            if rc != 0:
+                worst = worst or (rc if rc > 0 else 128 - rc)
+                sys.stderr.write(f'bench.py: rank {r} exited with {rc}; stopping the other ranks\n')
+                for q in pending:   # a rank that lost its peers would wait in a collective for ever
+                    procs[q].terminate()
+        time.sleep(0.05)
+    return worst
+
+
 def main():
     args = parse_args()
-    env_world = int(os.environ.get('WORLD_SIZE', '1'))
-    if args.gpus != env_world:  # before anything touches a GPU: never re-launch from a process that holds a context
+    env_world = os.environ.get('WORLD_SIZE')
+    if env_world is None and args.gpus > 1:  # plain `python bench.py --gpus N`: be the launcher (no GPU call in this process)
+        sys.exit(launch_ranks(args.gpus))
+    if int(env_world or '1') != args.gpus:  # a launcher started a different number of ranks than the command line names
         sys.stderr.write(
             f'bench.py: --gpus {args.gpus} but WORLD_SIZE is {env_world}: launch the ranks with\n'
             f'  python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 '
-            f'--master-port 29500 bench.py --gpus {args.gpus} ...\n')
+            f'--master-port 29500 bench.py --gpus {args.gpus} ...\n(or unset WORLD_SIZE: `python bench.py --gpus N` starts its own ranks)\n')
         sys.exit(2)
+    try:   # a fatal signal names its sender, thread and native frames (homonim_amd/abort_trace.py)
+        from homonim_amd import abort_trace
+        abort_trace.install()
+    except Exception:
+        pass
     from homonim_amd import _hk, dist
     rank, world, local_rank = dist.init()  # torch.distributed (nccl = RCCL) only when WORLD_SIZE > 1
     # one GPU per rank on a full node.  configs[3] deals its block positions to 8 streams: a position's statistics are a chain of
@@ -869,6 +911,22 @@ def main():
     n_streams = int(os.environ.get('HK_BENCH_STREAMS', '8' if args.config == 3 else '4'))
     ctx = _hk.Context(local_rank % max(1, _hk.device_count()), n_streams=n_streams)
     ctx.selftest()
+    # The library's own RCCL communicator over the ranks of this launch (the one data-path collective of the hot path, the
+    # split-block statistics, runs on it): joined here so that every N > 1 run also proves RCCL over xGMI up -- one in-place
+    # all-reduce of a float64 word per rank, which must come back as the number of ranks.
+    rccl_ranks = None
+    if dist.backend() == 'nccl':
+        dist.init_comm(ctx)
+        word = ctx.dev_alloc(8)
+        ctx.h2d(word, np.ones(1, np.float64))
+        ctx.comm_allreduce_f64_dev(word, 1, 0)
+        ctx.stream_sync(0)
+        back = np.zeros(1, np.float64)
+        ctx.d2h(back, word)
+        ctx.dev_free(word)
+        rccl_ranks = ctx.comm_info()[1]
+        if int(back[0]) != world or rccl_ranks != world:
+            raise RuntimeError(f'RCCL all-reduce over {world} rank(s) returned {back[0]} (communicator of {rccl_ranks})')
 
     runner = {1: run_resident, 2: run_resident, 3: run_blocks, 4: run_tiles}[args.config]
     res = runner(args, ctx, dist, rank, world)
@@ -962,6 +1020,7 @@ def main():
             out['power'] = res['power']
         if dist.backend() is not None:
             out['dist_backend'] = dist.backend()   # 'nccl' = RCCL; absent for a single process without a group
+            out['rccl_ranks'] = rccl_ranks         # ranks of the library's own communicator (hk_comm_info); None under gloo
         print(json.dumps(out), flush=True)
 
     ctx.close()

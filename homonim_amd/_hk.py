@@ -69,7 +69,12 @@ _P = C.POINTER
 _f32p, _f64p, _u64p = _P(C.c_float), _P(C.c_double), _P(C.c_uint64)
 
 # name -> (restype, argtypes); kept in one table so tests can check every symbol of the header is exported
+ABI_VERSION = 4   # HK_ABI_VERSION of the include/homonim_hk.h these mirrors were written against
+# entry points declared in include/homonim_hk_devtools.h (measurement / test aids), the rest in include/homonim_hk.h
+DEVTOOLS = ('hk_synth_fill_dev', 'hk_stream_probe_dev', 'hk_debug_stage_stamps', 'hk_r2_certificate_constants')
+
 SIGNATURES = {
+    'hk_abi_version': (C.c_int, []),
     'hk_backend_name': (C.c_char_p, []),
     'hk_dev_job_scratch_bytes': (C.c_uint64, [C.c_int32, C.c_int32, C.c_int64, C.c_int64]),
     'hk_block_norm_split_exchange_doubles': (C.c_uint64, [C.c_int32]),
@@ -177,6 +182,14 @@ def load_library():
                     'homonim_amd has no CPU fallback.'
                 )
             lib = C.CDLL(_LIB_PATH)
+            try:
+                lib.hk_abi_version.restype = C.c_int
+                found = lib.hk_abi_version()
+            except AttributeError:
+                found = None
+            if found != ABI_VERSION:   # struct layouts differ between versions and carry no size field: do not call further
+                raise DeviceError(f'{_LIB_PATH} has ABI version {found}, this binding needs {ABI_VERSION}: rebuild it with '
+                                  '`python -m homonim_amd.build`')
             for name, (restype, argtypes) in SIGNATURES.items():
                 fn = getattr(lib, name)
                 fn.restype = restype

@@ -51,7 +51,8 @@ def _run(cmd):
 def build_hip(force: bool = False, verbose: bool = True) -> str:
     """ Compile homonim_amd/csrc/*.hip for gfx950 into homonim_amd/lib/libhomonim_hk.so (in-tree). """
     os.makedirs(LIB_DIR, exist_ok=True)
-    headers = [os.path.join(CSRC, 'hk_kernels.h'), os.path.join(REPO, 'include', 'homonim_hk.h')]
+    headers = [os.path.join(CSRC, 'hk_kernels.h'), os.path.join(REPO, 'include', 'homonim_hk.h'),
+               os.path.join(REPO, 'include', 'homonim_hk_devtools.h')]
     objs = []
     jobs = []
     for src in HIP_SOURCES:

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "../../include/homonim_hk.h"
+#include "../../include/homonim_hk_devtools.h"
 #include "hk_kernels.h"
 
 #include <dlfcn.h>
@@ -154,8 +155,8 @@ hsa_status_t gpu_fault_report(const hsa_amd_event_t* ev, void*) {
 void register_gpu_fault_report() {
     static std::once_flag once;
     std::call_once(once, [] {
-        const char* off = getenv("HK_FAULT_REPORT");
-        if (off && !strcmp(off, "0")) return;
+        const char* on = getenv("HK_FAULT_REPORT");  // opt-in: a process-wide callback is not a library call's business
+        if (!on || strcmp(on, "1")) return;
         void* hsa = dlopen("libhsa-runtime64.so.1", RTLD_NOW | RTLD_NOLOAD);  // the instance HIP runs on, or nothing
         if (!hsa) return;
         using reg_t = hsa_status_t (*)(hsa_amd_system_event_callback_t, void*);
@@ -251,6 +252,10 @@ struct Slot {
     size_t norm_ws_bytes = 0;
     void* aux = nullptr;      // on-demand planes + tables of the in-painting branch
     size_t aux_bytes = 0;
+    // exchange buffer of hk_block_norm_split_comm_dev on THIS stream: sequences queued on different streams run concurrently on
+    // the device (comm_mu only orders their queuing), so they must not share one
+    double* comm_xchg = nullptr;
+    size_t comm_xchg_doubles = 0;
     // Pinned words of the slot (PIN_BYTES of hipHostMalloc'd memory): small results and arguments travel through them,
     // never through the caller's pageable memory.  fail_host = the first word (the r2-mask failure counter).
     unsigned long long* fail_host = nullptr;
@@ -280,6 +285,7 @@ struct Slot {
     hipEvent_t tbl_ev[TBL_RING] = {nullptr, nullptr, nullptr, nullptr};
     int tbl_next = 0;
     bool busy = false;         // leased by a host-pointer call (SlotLease)
+    int dev_inflight = 0;      // device-job entry points currently queuing on this stream (DevEnter): a lease waits for them
     bool dev_touched = false;  // device-resident jobs were queued on this stream since the last lease drained it
 };
 
@@ -318,8 +324,6 @@ struct hk_ctx {
     ncclComm_t comm = nullptr;
     int comm_rank = 0, comm_world = 0;
     std::mutex comm_mu;          // collectives of one communicator are queued in one order on every rank
-    double* comm_xchg = nullptr; // device exchange buffer of hk_block_norm_split_comm_dev
-    size_t comm_xchg_doubles = 0;
     // hk_memcpy_h2d / hk_memcpy_d2h / hk_selftest: a stream + pinned staging ring of their own, one caller at a time
     Slot xfer;
     std::mutex xfer_mu;
@@ -346,7 +350,7 @@ struct SlotLease {
             ctx->cv.wait(lk, [&] {
                 int any = -1;
                 for (size_t i = 0; i < ctx->slots.size(); ++i) {
-                    if (ctx->slots[i].busy) continue;
+                    if (ctx->slots[i].busy || ctx->slots[i].dev_inflight > 0) continue;
                     if (!ctx->slots[i].dev_touched) {
                         idx = (int)i;
                         return true;
@@ -372,12 +376,28 @@ struct SlotLease {
     Slot& slot() { return ctx->slots[idx]; }
 };
 
-// a device-resident job is about to be queued on pooled stream `stream`: wait for a host-pointer call that holds it
-void dev_slot_enter(hk_ctx* ctx, int stream) {
-    std::unique_lock<std::mutex> lk(ctx->mu);
-    ctx->cv.wait(lk, [&] { return !ctx->slots[stream].busy; });
-    ctx->slots[stream].dev_touched = true;
-}
+// A device-resident job is about to be queued on pooled stream `stream`: wait for a host-pointer call that holds it, and keep
+// the slot from being leased until the entry point has finished queuing (it uses the slot's scratch -- norm_ws, aux, the table
+// ring -- after this check; a lease taken in between would drain an still-empty stream and use the same scratch).
+struct DevEnter {
+    hk_ctx* ctx;
+    int stream;
+    DevEnter(hk_ctx* c, int st) : ctx(c), stream(st) {
+        std::unique_lock<std::mutex> lk(ctx->mu);
+        ctx->cv.wait(lk, [&] { return !ctx->slots[stream].busy; });
+        ctx->slots[stream].dev_touched = true;
+        ++ctx->slots[stream].dev_inflight;
+    }
+    ~DevEnter() {
+        {
+            std::lock_guard<std::mutex> lk(ctx->mu);
+            --ctx->slots[stream].dev_inflight;
+        }
+        ctx->cv.notify_all();
+    }
+    DevEnter(const DevEnter&) = delete;
+    DevEnter& operator=(const DevEnter&) = delete;
+};
 
 // RCCL, opened on first use: the library itself stays loadable (and its CPU-side tests runnable) where librccl is absent
 struct RcclApi {
@@ -616,6 +636,7 @@ void slot_release(Slot& s) {
     if (s.dev) (void)dev_free(s.dev);
     if (s.norm_ws) (void)dev_free(s.norm_ws);
     if (s.aux) (void)dev_free(s.aux);
+    if (s.comm_xchg) (void)dev_free(s.comm_xchg);
     if (s.fail_host) (void)hipHostFree(s.fail_host);
     if (s.stage) (void)hipHostFree(s.stage);
     for (int i = 0; i < Slot::STAGE_N; ++i)
@@ -1158,6 +1179,7 @@ int run_host(hk_ctx* ctx, const hk_fit_desc* desc, const hk_io_desc* io, const v
 
 extern "C" {
 
+int hk_abi_version(void) { return HK_ABI_VERSION; }
 const char* hk_backend_name(void) { return "hip-gfx950"; }
 const char* hk_last_error(void) { return g_err; }
 
@@ -1225,7 +1247,6 @@ int hk_ctx_destroy(hk_ctx* ctx) {
     for (auto& s : ctx->slots) slot_release(s);
     slot_release(ctx->xfer);
     if (ctx->comm && rccl().ok) rccl().CommDestroy(ctx->comm);
-    if (ctx->comm_xchg) (void)dev_free(ctx->comm_xchg);
     delete ctx;
     return HK_OK;
 }
@@ -1632,7 +1653,6 @@ static int check_job(hk_ctx* ctx, const hk_dev_job* job, bool allow_no_rows = fa
         if ((job->out_col0 % hk::PX) != 0 || (((job->out_col0 + job->out_cols) % hk::PX) != 0 && job->out_col0 + job->out_cols != job->width))
             return fail(HK_ERR_ARG, "job store window must start and end on multiples of %d columns (or at the job's last column)", hk::PX);
     }
-    dev_slot_enter(ctx, job->stream);
     return HK_OK;
 }
 
@@ -1649,6 +1669,7 @@ int hk_fit_apply_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* job
     if (rc) return rc;
     rc = check_job(ctx, job);
     if (rc) return rc;
+    DevEnter entered(ctx, job->stream);
     if (desc->model == HK_MODEL_GAIN_BLK_OFFSET && !job->norm) return fail(HK_ERR_ARG, "gain-blk-offset needs job->norm");
     HK_ENTER(ctx);
     hk::FitArgs a;
@@ -1679,6 +1700,7 @@ int hk_fit_apply_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* job
 int hk_fail_counts_async(hk_ctx* ctx, const hk_dev_job* job, uint64_t* host_counts, hk_event* ready) {
     int rc = check_job(ctx, job);
     if (rc) return rc;
+    DevEnter entered(ctx, job->stream);
     if (!job->fail_count || !host_counts || !ready) return fail(HK_ERR_ARG, "NULL argument");
     HK_ENTER(ctx);
     Slot& sl = ctx->slots[job->stream];
@@ -1729,6 +1751,7 @@ int hk_inpaint_dev_counts(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job
     if (rc) return rc;
     rc = check_job(ctx, job);
     if (rc) return rc;
+    DevEnter entered(ctx, job->stream);
     if (n_fail_out) *n_fail_out = 0;
     if (desc->model != HK_MODEL_GAIN_OFFSET || !desc->has_r2_thresh) return HK_OK;  // nothing to in-paint
     if (!counts) return fail(HK_ERR_ARG, "counts is NULL");
@@ -1801,6 +1824,7 @@ int hk_inpaint_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* job, 
     if (rc) return rc;
     rc = check_job(ctx, job);
     if (rc) return rc;
+    DevEnter entered(ctx, job->stream);
     if (n_fail_out) *n_fail_out = 0;
     if (desc->model != HK_MODEL_GAIN_OFFSET || !desc->has_r2_thresh) return HK_OK;  // nothing to in-paint
     if (!job->fail_count) return fail(HK_ERR_ARG, "job->fail_count is NULL");
@@ -1844,6 +1868,7 @@ int hk_compare_sums_dev(hk_ctx* ctx, const hk_dev_job* job, int32_t src_nodata_m
                         int32_t ref_nodata_mode, float ref_nodata, double* sums_dev) {
     int rc = check_job(ctx, job);
     if (rc) return rc;
+    DevEnter entered(ctx, job->stream);
     if (!sums_dev) return fail(HK_ERR_ARG, "sums_dev is NULL");
     if ((rc = check_nodata_mode(src_nodata_mode)) || (rc = check_nodata_mode(ref_nodata_mode))) return rc;
     HK_ENTER(ctx);
@@ -1902,6 +1927,7 @@ int hk_block_norm_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* jo
     if (rc) return rc;
     rc = check_job(ctx, job);
     if (rc) return rc;
+    DevEnter entered(ctx, job->stream);
     if (!norm_dev) return fail(HK_ERR_ARG, "norm_dev is NULL");
     HK_ENTER(ctx);
     Slot& sl = ctx->slots[job->stream];
@@ -1966,11 +1992,12 @@ int hk_block_norm_batch_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_j
     if (rc) return rc;
     rc = check_batch(ctx, jobs, n_jobs);
     if (rc) return rc;
+    DevEnter entered(ctx, jobs[0].stream);
     if (!norm_dev) return fail(HK_ERR_ARG, "norm_dev is NULL");
     HK_ENTER(ctx);
     Slot& sl = ctx->slots[jobs[0].stream];
     std::vector<hk::NormPlane> planes;
-    int max_h = 0, max_w = 0;
+    int max_h = 0, max_w = 0, max_waves = 0;
     long long max_px = 0;
     for (int32_t j = 0; j < n_jobs; ++j) {
         const hk_dev_job& job = jobs[j];
@@ -1980,8 +2007,10 @@ int hk_block_norm_batch_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_j
             pl.stride = job.stride, pl.height = job.height, pl.width = job.width;
             planes.push_back(pl);
         }
-        // the largest plane sizes the grid and the compaction buffers of every plane
+        // the plane with the most pixels sizes the compaction buffers of every plane, the one with the most 1 KB chunks the grid
+        // of the streaming pass (not the same plane in general: 1090 x 1025 has fewer pixels but more chunks than 1100 x 1024)
         if ((long long)job.height * job.width > max_px) max_px = (long long)job.height * job.width, max_h = job.height, max_w = job.width;
+        max_waves = std::max(max_waves, hk::norm_pass_waves(job.height, job.width));
     }
     // grid.y of the select passes = 2 x planes
     if (planes.size() > 32767) return fail(HK_ERR_ARG, "a statistics batch holds at most 32767 planes (jobs x bands)");
@@ -1994,6 +2023,7 @@ int hk_block_norm_batch_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_j
     na.planes = static_cast<const hk::NormPlane*>(tbl);
     na.src = na.ref = nullptr, na.height = max_h, na.width = max_w, na.stride = 0, na.band_stride = 0;
     na.n_bands = (int)planes.size();
+    na.grid_waves = max_waves;
     na.src_nd_mode = desc->src_nodata_mode, na.ref_nd_mode = desc->ref_nodata_mode;
     na.src_nodata = desc->src_nodata, na.ref_nodata = desc->ref_nodata;
     HK_HIP(hk::launch_block_norm(na, sl.norm_ws, norm_dev, sl.stream));
@@ -2005,6 +2035,7 @@ int hk_fit_apply_batch_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_jo
     if (rc) return rc;
     rc = check_batch(ctx, jobs, n_jobs);
     if (rc) return rc;
+    DevEnter entered(ctx, jobs[0].stream);
     for (int32_t j = 1; j < n_jobs; ++j) {
         const hk_dev_job* job = &jobs[j];
         // what selects the kernel build must not differ inside a launch (the contract holds for every model)
@@ -2108,6 +2139,7 @@ int hk_fit_apply_batch_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_jo
 int hk_fail_counts_batch_async(hk_ctx* ctx, const hk_dev_job* jobs, int32_t n_jobs, uint64_t* host_counts, hk_event* ready) {
     int rc = check_batch(ctx, jobs, n_jobs);
     if (rc) return rc;
+    DevEnter entered(ctx, jobs[0].stream);
     if (!host_counts || !ready) return fail(HK_ERR_ARG, "NULL argument");
     for (int32_t j = 0; j < n_jobs; ++j)
         if (!jobs[j].fail_count) return fail(HK_ERR_ARG, "job %d has no fail_count", j);
@@ -2148,6 +2180,7 @@ int hk_block_norm_split_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_j
     if (!xchg_dev || !norm_dev) return fail(HK_ERR_ARG, "xchg_dev / norm_dev is NULL");
     if (phase < 0 || phase > 5) return fail(HK_ERR_ARG, "phase %d outside 0..5", phase);
     if (world_size < 1) return fail(HK_ERR_ARG, "world_size < 1");
+    DevEnter entered(ctx, job->stream);
     HK_ENTER(ctx);
     Slot& sl = ctx->slots[job->stream];
     // the phases of one block share the stream's workspace: phase 0 sizes it, the others find it as it was left
@@ -2221,6 +2254,7 @@ int hk_block_norm_split_comm_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_
     if (rc) return rc;
     rc = check_job(ctx, job, /*allow_no_rows=*/true);
     if (rc) return rc;
+    DevEnter entered(ctx, job->stream);
     if (!norm_dev) return fail(HK_ERR_ARG, "norm_dev is NULL");
     std::lock_guard<std::mutex> lk(ctx->comm_mu);  // one collective sequence at a time per communicator, every rank alike
     if (!ctx->comm) return fail(HK_ERR_ARG, "the context has no communicator (hk_comm_init)");
@@ -2229,15 +2263,15 @@ int hk_block_norm_split_comm_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_
     rc = ensure_stream_ws(ctx, sl, hk::norm_workspace_bytes(job->n_bands, job->height > 0 ? job->height : 1, job->width));
     if (rc) return rc;
     const size_t n = hk::norm_split_exchange_doubles(job->n_bands);
-    if (ctx->comm_xchg_doubles < n) {
-        if (ctx->comm_xchg) {
-            HK_HIP(hipDeviceSynchronize());  // an earlier sequence on another stream may still read it
-            HK_HIP(dev_free(ctx->comm_xchg));
-            ctx->comm_xchg = nullptr, ctx->comm_xchg_doubles = 0;
+    if (sl.comm_xchg_doubles < n) {
+        if (sl.comm_xchg) {
+            HK_HIP(hipStreamSynchronize(sl.stream));  // an earlier sequence on this stream may still use it
+            HK_HIP(dev_free(sl.comm_xchg));
+            sl.comm_xchg = nullptr, sl.comm_xchg_doubles = 0;
         }
-        if (dev_malloc(reinterpret_cast<void**>(&ctx->comm_xchg), n * sizeof(double)) != hipSuccess)
+        if (dev_malloc(reinterpret_cast<void**>(&sl.comm_xchg), n * sizeof(double)) != hipSuccess)
             return fail(HK_ERR_NOMEM, "hipMalloc(%zu) failed", n * sizeof(double));
-        ctx->comm_xchg_doubles = n;
+        sl.comm_xchg_doubles = n;
     }
     hk::NormArgs na;
     na.src = job->src, na.ref = job->ref, na.height = job->height, na.width = job->width, na.stride = job->stride;
@@ -2246,9 +2280,9 @@ int hk_block_norm_split_comm_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_
     na.src_nodata = desc->src_nodata, na.ref_nodata = desc->ref_nodata;
     // six phases on the slab, five all-reduces between them, all queued on the job's stream: no host synchronisation
     for (int phase = 0; phase < 6; ++phase) {
-        HK_HIP(hk::launch_block_norm_split(na, sl.norm_ws, ctx->comm_xchg, 1.0 / (double)ctx->comm_world, phase, norm_dev, sl.stream));
+        HK_HIP(hk::launch_block_norm_split(na, sl.norm_ws, sl.comm_xchg, 1.0 / (double)ctx->comm_world, phase, norm_dev, sl.stream));
         if (phase < 5)
-            HK_RCCL(rccl().AllReduce(ctx->comm_xchg, ctx->comm_xchg, n, ncclDouble, ncclSum, ctx->comm, sl.stream));
+            HK_RCCL(rccl().AllReduce(sl.comm_xchg, sl.comm_xchg, n, ncclDouble, ncclSum, ctx->comm, sl.stream));
     }
     return HK_OK;
 }

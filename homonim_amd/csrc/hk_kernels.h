@@ -123,7 +123,12 @@ struct NormArgs {
     int n_bands;
     int src_nd_mode, ref_nd_mode;
     float src_nodata, ref_nodata;
+    // batched launch: x-extent of the streaming pass's grid = the largest norm_pass_waves() over the planes (a plane with fewer
+    // PIXELS than the largest one can still have more 1 KB chunks: width 1025 has 5 per row, width 1024 has 4); 0 = this shape's
+    int grid_waves = 0;
 };
+// waves per plane of the streaming pass (a function of the plane's shape only)
+int norm_pass_waves(int height, int width);
 // workspace: see norm_workspace_bytes(); norm_out: n_bands x 2 float64 on device.
 size_t norm_workspace_bytes(int n_bands, int height, int width);
 // batched: a.planes set, a.n_bands planes, a.height x a.width = the LARGEST plane (sizes the workspace and the grid)

@@ -803,6 +803,8 @@ hipError_t launch_block_norm_split(const NormArgs& a, void* workspace, double* x
     return hipGetLastError();
 }
 
+int norm_pass_waves(int height, int width) { return pass_waves(height, width); }
+
 hipError_t launch_block_norm(const NormArgs& a, void* workspace, double* norm_out, hipStream_t stream) {
     NormWS* ws = reinterpret_cast<NormWS*>(workspace);
     const size_t cap = mid_capacity((long long)a.height * a.width);
@@ -812,7 +814,7 @@ hipError_t launch_block_norm(const NormArgs& a, void* workspace, double* norm_ou
     if (e != hipSuccess) return e;
     const dim3 bands(a.n_bands), block(NORM_THREADS);
     hipLaunchKernelGGL(norm_sample_kernel, bands, dim3(SAMPLE_THREADS), 0, stream, a, ws);
-    const dim3 gstream(pass_waves(a.height, a.width), a.n_bands);
+    const dim3 gstream(a.grid_waves > 0 ? a.grid_waves : pass_waves(a.height, a.width), a.n_bands);
     if (a.src_nd_mode == 0 && a.ref_nd_mode == 0)
         hipLaunchKernelGGL(norm_stream_kernel<true>, gstream, dim3(WAVE), norm_stream_lds_pad(), stream, a, ws, mid, cap_al);
     else

@@ -91,20 +91,49 @@ def init_comm(ctx, id_file: Optional[str] = None) -> Tuple[int, int]:
     else:
         if id_file is None:
             raise RuntimeError('init_comm needs a joined process group (dist.init) or an id file (HOMONIM_AMD_COMM_FILE)')
+        # The file carries a header -- magic, the launch's token (MASTER_PORT / TORCHELASTIC_RUN_ID / HOMONIM_AMD_LAUNCH_ID),
+        # rank 0's clock -- so that a file left behind by another or an earlier launch is not taken for this one's: rank 0
+        # removes whatever is there before it makes the id, the other ranks skip files with a foreign token or older than
+        # STALE_S, and rank 0 removes the file once the communicator stands (ncclCommInitRank returns when every rank has
+        # joined, i.e. has read it).  Use a fresh path per launch where a crashed launch may be restarted within STALE_S.
+        import struct
+        STALE_S = 600.0
+        token = '|'.join(os.environ.get(k, '') for k in ('MASTER_PORT', 'TORCHELASTIC_RUN_ID', 'HOMONIM_AMD_LAUNCH_ID')).encode()[:64]
+        head = struct.Struct('<8s64sd')
         if rank == 0:
+            try:
+                os.unlink(id_file)
+            except FileNotFoundError:
+                pass
             uid = _hk.comm_unique_id()
             tmp = f'{id_file}.tmp{os.getpid()}'
             with open(tmp, 'wb') as f:
-                f.write(uid)
+                f.write(head.pack(b'HKCOMM01', token, time.time()) + uid)
             os.replace(tmp, id_file)
         else:
             t0 = time.time()
-            while not os.path.exists(id_file):
-                if time.time() - t0 > 120:
-                    raise RuntimeError(f'rank {rank}: no communicator id in {id_file} after 120 s')
-                time.sleep(0.02)
-            with open(id_file, 'rb') as f:
-                uid = f.read()
+            uid = None
+            while uid is None:
+                try:
+                    with open(id_file, 'rb') as f:
+                        blob = f.read()
+                    if len(blob) > head.size:
+                        magic, tok, stamp = head.unpack(blob[:head.size])
+                        if magic == b'HKCOMM01' and tok.rstrip(b'\0') == token and stamp >= t0 - STALE_S:
+                            uid = blob[head.size:]
+                except FileNotFoundError:
+                    pass
+                if uid is None:
+                    if time.time() - t0 > 120:
+                        raise RuntimeError(f'rank {rank}: no communicator id of this launch in {id_file} after 120 s')
+                    time.sleep(0.02)
+        ctx.comm_init(uid, rank, world)
+        if rank == 0:
+            try:
+                os.unlink(id_file)
+            except OSError:
+                pass
+        return rank, world
     ctx.comm_init(uid, rank, world)
     return rank, world
 

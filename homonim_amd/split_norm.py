@@ -9,8 +9,8 @@ radix select that finds the two order statistics behind the percentile.  So each
 slab (``hk_block_norm_split_dev``, phases 0..5) and the ranks all-reduce (SUM) a small float64 exchange buffer between the
 phases: 2 + 5 + 3 x (<= 8192) values per band, five all-reduces per block.  In production the library does that itself
 -- RCCL over xGMI through the context's communicator (``hk_comm_init``, ``hk_block_norm_split_comm_dev``), queued on the
-job's stream without host synchronisation and without torch.  ``TorchReducer`` keeps a host-driven phase loop over a
-``torch.distributed`` group for tests in which several ranks share one GPU (gloo).
+job's stream without host synchronisation and without torch.  A caller-supplied ``reducer`` keeps a host-driven phase loop
+instead (tests in which several ranks share one GPU all-reduce over gloo: tests/_torch_reducer.py); the product has none.
 
 The order statistics are exactly those of the whole block; the std ratio equals the single-device value up to the order of
 the float64 sums (the slabs' partial sums are added rank by rank).
@@ -24,34 +24,7 @@ from homonim_amd import _hk
 N_PHASES = 6
 
 
-class TorchReducer:
-    """ All-reduce (SUM) over a torch.distributed process group of a float64 device buffer owned by a torch tensor.
-    backend nccl (= RCCL on ROCm): in place on the device; gloo (ranks sharing one GPU in tests): through the host. """
-
-    def __init__(self, n_doubles: int, device_index: int, group=None):
-        import torch
-        import torch.distributed as dist
-        if not dist.is_initialized():
-            raise RuntimeError('TorchReducer needs an initialised torch.distributed process group (homonim_amd.dist.init)')
-        self._torch, self._dist, self._group = torch, dist, group
-        self.world_size = dist.get_world_size(group)
-        self.backend = dist.get_backend(group)
-        self.buf = torch.zeros(n_doubles, dtype=torch.float64, device=torch.device('cuda', device_index))
-        torch.cuda.synchronize(device_index)
-        self.ptr = int(self.buf.data_ptr())
-        self._device_index = device_index
-
-    def __call__(self):
-        if self.backend == 'nccl':
-            self._dist.all_reduce(self.buf, op=self._dist.ReduceOp.SUM, group=self._group)
-        else:
-            host = self.buf.cpu()
-            self._dist.all_reduce(host, op=self._dist.ReduceOp.SUM, group=self._group)
-            self.buf.copy_(host)
-        self._torch.cuda.synchronize(self._device_index)  # the library's stream reads the buffer next
-
-
-def block_norm_split(ctx: '_hk.Context', desc: '_hk.FitDesc', job: '_hk.DevJob', reducer: Optional[TorchReducer] = None,
+def block_norm_split(ctx: '_hk.Context', desc: '_hk.FitDesc', job: '_hk.DevJob', reducer=None,
                      norm_dev: Optional[int] = None) -> np.ndarray:
     """
     Block statistics over all ranks; ``job`` describes THIS rank's slab of the block (device planes, any number of rows --
@@ -61,8 +34,9 @@ def block_norm_split(ctx: '_hk.Context', desc: '_hk.FitDesc', job: '_hk.DevJob',
 
     ``reducer`` None (the production path): the context's own RCCL communicator (``dist.init_comm`` / ``Context.comm_init``)
     -- the library queues the six phases and the five all-reduces on the job's stream (``hk_block_norm_split_comm_dev``);
-    no torch, no host synchronisation until the result is read.  A ``TorchReducer`` keeps the phase loop on the host (gloo
-    groups of ranks that share one GPU in tests).
+    no torch, no host synchronisation until the result is read.  A ``reducer`` -- any callable object with ``world_size``,
+    ``ptr`` (device address of a float64 exchange buffer) and ``n_doubles`` that all-reduces (SUM) that buffer over the ranks
+    when called -- keeps the phase loop on the host instead.
     """
     nb = int(job.n_bands)
     own = norm_dev is None
@@ -78,7 +52,7 @@ def block_norm_split(ctx: '_hk.Context', desc: '_hk.FitDesc', job: '_hk.DevJob',
         finally:
             if own:
                 ctx.dev_free(norm_dev)
-    if reducer.buf.numel() < ctx.split_exchange_doubles(nb):
+    if reducer.n_doubles < ctx.split_exchange_doubles(nb):
         if own:
             ctx.dev_free(norm_dev)
         raise ValueError('exchange buffer smaller than hk_block_norm_split_exchange_doubles(n_bands)')

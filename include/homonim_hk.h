@@ -66,16 +66,20 @@ typedef struct {
 /* ------------------------------------------------------------------------------------------------------------------
  * library / context
  */
+/* Version of this header's struct layouts and prototypes.  A consumer built against one header and loading a library of
+ * another must not call further: structs grow at their end between versions (hk_out_window: 32 -> 40 bytes in version 3) and
+ * carry no size field.  hk_abi_version() returns the library's HK_ABI_VERSION; compare it with the header's at load time. */
+#define HK_ABI_VERSION 4
+int hk_abi_version(void);
 const char* hk_backend_name(void);            /* "hip-gfx950" */
 const char* hk_last_error(void);              /* thread-local text of the last failure */
 int hk_device_count(int* count);
 /* One context per GPU: owns `n_streams` HIP streams, each with a pinned-host + device staging slot that grows on
  * demand.  Replaces nothing in the reference (its "device" is the host CPU); mirrors the thread pool of
  * homonim/fuse.py:396.
- * Process-wide side effect of the first call: the library adds a system-event callback to the HSA runtime that prints GPU
- * memory faults (with the place of the address relative to the library's device allocations), memory errors and hardware
- * exceptions to stderr; it does not claim the event, the runtime's own handling follows (HK_FAULT_REPORT=0: not registered).
- * Debugging: HK_GUARD_ALLOC=lo|hi places every device allocation of the library between unmapped address ranges. */
+ * No process-wide side effects by default; the diagnostic switches (HK_FAULT_REPORT=1, HK_GUARD_ALLOC) are described in
+ * homonim_hk_devtools.h.  Every entry point that selects the context's device also clears the calling thread's sticky HIP
+ * "last error" (hipGetLastError), so that an error this library reported does not resurface in the caller's next launch. */
 int hk_ctx_create(int device_id, int n_streams, hk_ctx** ctx);
 int hk_ctx_destroy(hk_ctx* ctx);
 int hk_ctx_sync(hk_ctx* ctx);                 /* hipDeviceSynchronize on the context's device */
@@ -291,11 +295,6 @@ int hk_fail_counts_async(hk_ctx* ctx, const hk_dev_job* job, uint64_t* host_coun
  * run again with the complete build; 0 when the launch's outputs are final.  Callers need not interpret the raw counters
  * (host-only, no device call). */
 int hk_counts_pending(const uint64_t* counts, int32_t n_bands);
-/* The constants the kernels decide `(r2 > thresh) & (gain > 0)` (kernel_model.py:363) with, for checking them against their
- * derivation (host-only, no device call; PROOFS.md appendix A): ssres < pass_below * sstot proves the decision true,
- * ssres > fail_above * sstot proves it false (sstot > 0); kappa / kappa_fail are the float32 factors of the division-free
- * certificate and of its fail side (+inf / -inf: nothing can be certified).  Any pointer may be NULL. */
-int hk_r2_certificate_constants(float thresh, double* pass_below, double* fail_above, float* kappa, float* kappa_fail);
 int hk_inpaint_dev_counts(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* job, const uint64_t* counts,
                           uint64_t* n_fail_out);
 /* Per-band block normalisation on device planes -> norm (device, n_bands x 2 float64); asynchronous. */
@@ -358,17 +357,7 @@ int hk_block_norm_split_comm_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_
  * r2 / RMSE / rRMSE follow from them as in compare.py:142-160. */
 int hk_compare_sums_dev(hk_ctx* ctx, const hk_dev_job* job, int32_t src_nodata_mode, float src_nodata,
                         int32_t ref_nodata_mode, float ref_nodata, double* sums_dev);
-/* Fill device planes with the synthetic workload of SURVEY.md section 8(d) (src ~ U[0.05,1), ref = g*src+o+noise);
- * nodata_variant 0: none, 1: 3-px NaN frame + 0.1 % NaN holes, 2: frame only, 3 / 4: none, noisy reference (35 % / 85 % r2-mask failures), 5: low-entropy data (64 source levels, exactly affine reference:
- * the same instruction stream at a lower energy per launch).  Test/bench data only. */
-int hk_synth_fill_dev(hk_ctx* ctx, float* src, float* ref, int32_t n_bands, int32_t height, int32_t width,
-                      int64_t stride, int64_t band_stride, uint64_t seed, int32_t nodata_variant, int32_t stream);
 
-/* Measurement aid (bench.py `roofline.copy_gbps_measured`): ONE launch of a flat float4 stream over three device buffers
- * of n_bytes each -- out[i] = a[i] + b[i], two reads + one write like the fused kernel's 12 bytes per pixel, no stencil,
- * persistent grid, four 16-byte non-temporal loads in flight per lane and array -- on pooled stream `stream`
- * (asynchronous; time it with hk_event_*).  n_bytes must be a multiple of 16.  What this box's HBM gives that byte mix. */
-int hk_stream_probe_dev(hk_ctx* ctx, const void* a, const void* b, void* out, size_t n_bytes, int32_t stream);
 
 /* HIP events on the pooled streams, so callers time exactly the stream the kernels run on. */
 int hk_event_create(hk_ctx* ctx, hk_event** ev);
@@ -381,9 +370,6 @@ int hk_stream_sync(hk_ctx* ctx, int32_t stream);
 
 /* Self-test of the cross-lane primitives the kernels rely on (DPP wave shifts); 0 = pass. */
 int hk_selftest(hk_ctx* ctx);
-/* Measurement aid: the stage counters a -DHK_STAMPS build of the fused kernel accumulates (shader-clock cycles per stage of a row
- * iteration, [14] waves, [15] iterations; all zero in the shipped build; tools/stage_stamps.py).  Synchronises the device. */
-int hk_debug_stage_stamps(hk_ctx* ctx, uint64_t out[16], int32_t reset);
 
 #ifdef __cplusplus
 }

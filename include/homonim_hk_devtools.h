@@ -1,0 +1,52 @@
+/*
+ * homonim_hk_devtools.h -- measurement and test aids exported by libhomonim_hk.so beside the drop-in boundary.
+ *
+ * Nothing here replaces a reference interface: these entry points exist for bench.py, the test-suite and the tools/ scripts
+ * (synthetic workload on the device, a flat copy stream to price the HBM, kernel stage counters, the constants of the R2
+ * certificate for checking them against their derivation).  A consumer of the hot path needs homonim_hk.h only.
+ *
+ * Diagnostic switches of the library (environment, read once):
+ *   HK_FAULT_REPORT=1   the first hk_ctx_create adds a system-event callback to the HSA runtime (process-wide, never removed)
+ *                       that prints GPU memory faults with the place of the address relative to the library's device
+ *                       allocations, memory errors and hardware exceptions to stderr; it does not claim the event, the
+ *                       runtime's own handling (ending the process) follows.  Off by default.
+ *   HK_GUARD_ALLOC=lo|hi|poison   every device allocation of the library between unmapped address ranges (lo / hi: flush with
+ *                       the lower / upper end), or plain allocations filled with 0xAB: an out-of-range access of a kernel
+ *                       faults at its launch (tests/test_gpu_guard_alloc.py).
+ *   HK_STAGE_CHUNK_KB   size of the pinned staging chunks of the host-pointer calls (default 8192; tests of the chunked paths).
+ */
+#ifndef HOMONIM_HK_DEVTOOLS_H
+#define HOMONIM_HK_DEVTOOLS_H
+
+#include "homonim_hk.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Fill device planes with the synthetic workload of SURVEY.md section 8(d) (src ~ U[0.05,1), ref = g*src+o+noise);
+ * nodata_variant 0: none, 1: 3-px NaN frame + 0.1 % NaN holes, 2: frame only, 3 / 4: none, noisy reference (35 % / 85 % r2-mask failures), 5: low-entropy data (64 source levels, exactly affine reference:
+ * the same instruction stream at a lower energy per launch).  Test/bench data only. */
+int hk_synth_fill_dev(hk_ctx* ctx, float* src, float* ref, int32_t n_bands, int32_t height, int32_t width,
+                      int64_t stride, int64_t band_stride, uint64_t seed, int32_t nodata_variant, int32_t stream);
+
+/* Measurement aid (bench.py `roofline.copy_gbps_measured`): ONE launch of a flat float4 stream over three device buffers
+ * of n_bytes each -- out[i] = a[i] + b[i], two reads + one write like the fused kernel's 12 bytes per pixel, no stencil,
+ * persistent grid, four 16-byte non-temporal loads in flight per lane and array -- on pooled stream `stream`
+ * (asynchronous; time it with hk_event_*).  n_bytes must be a multiple of 16.  What this box's HBM gives that byte mix. */
+int hk_stream_probe_dev(hk_ctx* ctx, const void* a, const void* b, void* out, size_t n_bytes, int32_t stream);
+
+/* The constants the kernels decide `(r2 > thresh) & (gain > 0)` (kernel_model.py:363) with, for checking them against their
+ * derivation (host-only, no device call; PROOFS.md appendix A): ssres < pass_below * sstot proves the decision true,
+ * ssres > fail_above * sstot proves it false (sstot > 0); kappa / kappa_fail are the float32 factors of the division-free
+ * certificate and of its fail side (+inf / -inf: nothing can be certified).  Any pointer may be NULL. */
+int hk_r2_certificate_constants(float thresh, double* pass_below, double* fail_above, float* kappa, float* kappa_fail);
+
+/* Measurement aid: the stage counters a -DHK_STAMPS build of the fused kernel accumulates (shader-clock cycles per stage of a row
+ * iteration, [14] waves, [15] iterations; all zero in the shipped build; tools/stage_stamps.py).  Synchronises the device. */
+int hk_debug_stage_stamps(hk_ctx* ctx, uint64_t out[16], int32_t reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HOMONIM_HK_DEVTOOLS_H */

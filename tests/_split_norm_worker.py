@@ -37,7 +37,9 @@ def main():
     job.corr = job.gain = job.offset = job.r2 = job.norm = job.fail_count = None
     job.n_bands, job.height, job.width, job.stride, job.band_stride = nb, rows, w, stride, stride * rows
     job.seg_rows, job.stream = 0, 1
-    reducer = split_norm.TorchReducer(ctx.split_exchange_doubles(nb), dev)
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    from _torch_reducer import TorchReducer
+    reducer = TorchReducer(ctx.split_exchange_doubles(nb), dev)
     norm = split_norm.block_norm_split(ctx, desc, job, reducer)
     norm2 = split_norm.block_norm_split(ctx, desc, job, reducer)   # the buffers are reusable
     assert (norm == norm2).all()

@@ -15,6 +15,12 @@ from homonim_amd import (Affine, ConfigWarning, CRS, DeviceError, KernelModel, M
                          Resampling, _hk, utils)
 
 
+def _header(which='both'):
+    """ Text of the public header(s): include/homonim_hk.h (the drop-in boundary) and include/homonim_hk_devtools.h (aids). """
+    names = {'main': ['homonim_hk.h'], 'devtools': ['homonim_hk_devtools.h'], 'both': ['homonim_hk.h', 'homonim_hk_devtools.h']}
+    return '\n'.join(open(os.path.join(REPO, 'include', n)).read() for n in names[which])
+
+
 @pytest.fixture(scope='module')
 def lib():
     from homonim_amd import build
@@ -23,13 +29,18 @@ def lib():
 
 
 def test_library_exports_every_declared_symbol(lib):
-    header = open(os.path.join(REPO, 'include', 'homonim_hk.h')).read()
-    declared = set(re.findall(r'\b(hk_[a-z0-9_]+)\s*\(', header))
+    strip = lambda text: re.sub(r'/\*.*?\*/', '', text, flags=re.S)   # noqa: E731
+    declared = set(re.findall(r'\b(hk_[a-z0-9_]+)\s*\(', strip(_header('both'))))
     assert len(declared) >= 20
     for name in declared:
-        assert hasattr(lib, name), f'{name} declared in homonim_hk.h but not exported'
-    # and the ctypes table covers the header exactly
+        assert hasattr(lib, name), f'{name} declared in the headers but not exported'
+    # and the ctypes table covers the headers exactly
     assert declared == set(_hk.SIGNATURES)
+    # the aids live in their own header: the boundary header declares none of them, the devtools header nothing else
+    aids = set(re.findall(r'\b(hk_[a-z0-9_]+)\s*\(', strip(_header('devtools'))))
+    assert aids == set(_hk.DEVTOOLS)
+    assert not aids & set(re.findall(r'\b(hk_[a-z0-9_]+)\s*\(', strip(_header('main'))))
+    assert lib.hk_abi_version() == _hk.ABI_VERSION == int(re.search(r'#define HK_ABI_VERSION (\d+)', _header('main')).group(1))
 
 
 def test_header_is_plain_c_and_a_c_program_can_drive_the_library(lib, tmp_path):
@@ -76,7 +87,7 @@ def test_ctypes_structs_have_the_offsets_the_c_compiler_gives_the_header(tmp_pat
             desc = getattr(cls, field[0])
             assert (desc.offset, desc.size) == seen[(cname, field[0])], f'{cname}.{field[0]}'
     # the header declares no field the mirrors lack
-    header = open(os.path.join(REPO, 'include', 'homonim_hk.h')).read()
+    header = _header('both')
     for cname, cls in pairs:
         body = re.search(r'typedef struct[^{]*\{([^}]*)\}\s*' + cname + ';', header).group(1)
         body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
@@ -94,8 +105,7 @@ def test_ctypes_prototypes_agree_with_the_header_argument_by_argument():
     """ Every prototype of include/homonim_hk.h against its entry in _hk.SIGNATURES: number of arguments, and per argument
     pointer / 4-byte int / 8-byte int / float / double (a struct pointer: the mirrored struct).  A scalar passed at the wrong
     width through ctypes is silent on x86-64 until it is not. """
-    header = open(os.path.join(REPO, 'include', 'homonim_hk.h')).read()
-    header = re.sub(r'/\*.*?\*/', '', header, flags=re.S)
+    header = re.sub(r'/\*.*?\*/', '', _header('both'), flags=re.S)
     protos = re.findall(r'\b([A-Za-z_][A-Za-z0-9_ ]*?[\s\*]+)(hk_[a-z0-9_]+)\s*\(([^)]*)\)\s*;', header)
     assert len(protos) == len(_hk.SIGNATURES)
     scalar = {'int': 'i4', 'int32_t': 'i4', 'uint32_t': 'i4', 'int64_t': 'i8', 'uint64_t': 'i8', 'size_t': 'i8',

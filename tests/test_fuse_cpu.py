@@ -190,15 +190,23 @@ def test_communicator_id_travels_through_a_file(tmp_path, monkeypatch):
     monkeypatch.setattr(_hk, 'comm_unique_id', lambda: made.append(1) or uid)
     monkeypatch.setattr(dist, '_state', dict(dist._state, initialised=False))
     joined = {}
+    all_in = threading.Barrier(3)
 
     class FakeCtx:
-        def __init__(self, rank):
-            self.rank = rank
+        def __init__(self, rank, collective=True):
+            self.rank, self.collective = rank, collective
 
         def comm_init(self, unique_id, rank, world):
             joined[rank] = (unique_id, world)
+            if self.collective and world > 1:
+                all_in.wait(timeout=30)   # ncclCommInitRank returns once every rank has joined
 
     path = str(tmp_path / 'comm_id.bin')
+    # a file left behind by an earlier launch (another MASTER_PORT) is not this launch's id: rank 0 replaces it, the others skip it
+    import struct
+    with open(path, 'wb') as f:
+        f.write(struct.pack('<8s64sd', b'HKCOMM01', b'1|stale|', 0.0) + bytes(128))
+    monkeypatch.setenv('MASTER_PORT', '29999')
     local = threading.local()
     monkeypatch.setattr(dist, 'env_ranks', lambda: (local.rank, 3, local.rank))
 
@@ -212,6 +220,7 @@ def test_communicator_id_travels_through_a_file(tmp_path, monkeypatch):
     [t.join(timeout=30) for t in waiters]
     assert made == [1]                     # only rank 0 asked the library for an id
     assert joined == {0: (uid, 3), 1: (uid, 3), 2: (uid, 3)}
+    assert not os.path.exists(path)        # rank 0 removes the id once the communicator stands
     # a world of one needs neither a group nor a file
     monkeypatch.setattr(dist, 'env_ranks', lambda: (0, 1, 0))
     assert dist.init_comm(FakeCtx(0)) == (0, 1) and joined[0] == (uid, 1)
@@ -220,3 +229,15 @@ def test_communicator_id_travels_through_a_file(tmp_path, monkeypatch):
     monkeypatch.delenv('HOMONIM_AMD_COMM_FILE', raising=False)
     with pytest.raises(RuntimeError):
         dist.init_comm(FakeCtx(1))
+
+
+def test_bench_launcher_reports_a_failing_rank():
+    """ `python bench.py --gpus 2` starts its own ranks; without a GPU both fail loudly (no CPU fallback) and the launcher --
+    which itself makes no GPU call -- stops the others and hands back a non-zero exit code, no JSON line. """
+    env = dict(os.environ, PYTHONPATH=REPO, HIP_VISIBLE_DEVICES='-1', HOMONIM_AMD_DIST_BACKEND='gloo')
+    for key in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT'):
+        env.pop(key, None)
+    run = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '1', '--config', '1'],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert run.returncode not in (0, 2), run.stderr[-2000:]
+    assert 'rank' in run.stderr and not [ln for ln in run.stdout.splitlines() if ln.startswith('{')]

@@ -288,3 +288,44 @@ def test_jobs_of_different_band_counts_and_shapes_in_one_launch(ctx):
             for ptr in d.values():
                 ctx.dev_free(ptr)
         ctx.dev_free(norm_a), ctx.dev_free(norm_b)
+
+
+def test_statistics_batch_with_a_smaller_plane_that_has_more_chunks(ctx, oracle):
+    """ The streaming pass of the statistics strides every plane by its OWN wave count, which follows the number of 1 KB
+    chunks (rows x ceil(ceil(w / 4) / 64)), not the number of pixels: 1090 x 1025 has fewer pixels than 1100 x 1024 but 5
+    instead of 4 chunks per row.  The launch's grid must cover the plane with the most chunks (round-3 advice: it was sized
+    from the plane with the most pixels, and the other plane's last waves never ran). """
+    shapes = [(1100, 1024), (1090, 1025), (64, 4000)]
+    strides = [(w + 3) // 4 * 4 for _, w in shapes]
+    desc = _hk.make_desc('gain-blk-offset', (5, 5), False, None, None, None)
+    bufs, jobs_one, jobs_many = [], [], []
+    norm1, norm2 = ctx.dev_alloc(16 * len(shapes)), ctx.dev_alloc(16 * len(shapes))
+    host = []
+    try:
+        for i, ((h, w), st) in enumerate(zip(shapes, strides)):
+            s, r = ctx.dev_alloc(4 * h * st), ctx.dev_alloc(4 * h * st)
+            bufs += [s, r]
+            ctx.synth_fill_dev(s, r, 1, h, w, st, h * st, seed=5 + i, nodata_variant=0, stream=0)
+            for jobs, norm, stream in ((jobs_one, norm1, 1), (jobs_many, norm2, 2)):
+                job = _hk.DevJob()
+                job.src, job.ref, job.norm = s, r, norm + 16 * i
+                job.n_bands, job.height, job.width, job.stride, job.band_stride, job.stream = 1, h, w, st, h * st, stream
+                jobs.append(job)
+        ctx.stream_sync(0)
+        for job in jobs_one:
+            ctx.block_norm_dev(desc, job, job.norm)
+        ctx.stream_sync(1)
+        ctx.block_norm_batch_dev(desc, ctx.job_array(jobs_many), norm2)
+        ctx.stream_sync(2)
+        a, b = np.zeros((len(shapes), 2)), np.zeros((len(shapes), 2))
+        ctx.d2h(a, norm1), ctx.d2h(b, norm2)
+        assert np.array_equal(a.view(np.uint64), b.view(np.uint64)), (a, b)
+        for i, ((h, w), st) in enumerate(zip(shapes, strides)):   # ... and they are the oracle's statistics
+            s, r = np.empty((h, st), np.float32), np.empty((h, st), np.float32)
+            ctx.d2h(s, bufs[2 * i]), ctx.d2h(r, bufs[2 * i + 1])
+            exp = oracle.fit_block_norm(np.ascontiguousarray(s[:, :w]), None, np.ascontiguousarray(r[:, :w]), None)
+            assert np.allclose(b[i], exp, rtol=2e-6, atol=1e-9), (i, b[i], exp)
+    finally:
+        for p in bufs:
+            ctx.dev_free(p)
+        ctx.dev_free(norm1), ctx.dev_free(norm2)

@@ -87,6 +87,7 @@ def test_bench_joins_an_rccl_group_of_one():
     line = json.loads(run.stdout.strip().splitlines()[-1])
     assert line['n_gpus'] == 1 and line['value'] > 0 and line['parity_spot_check']['passed']
     assert line.get('dist_backend') == 'nccl'
+    assert line.get('rccl_ranks') == 1   # the library's own communicator (hk_comm_info) stands and its all-reduce ran
 
 
 @pytest.mark.parametrize('config', [1, 3])
@@ -111,6 +112,26 @@ def test_bench_with_two_ranks(config):
 
 
 def test_bench_refuses_a_rank_count_that_disagrees_with_the_launch():
+    """ A launcher that started ONE rank (WORLD_SIZE=1) for a command line that names two: refused before any GPU call. """
     run = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '1'],
-                         env=dict(os.environ, PYTHONPATH=REPO), capture_output=True, text=True, timeout=120)
+                         env=dict(os.environ, PYTHONPATH=REPO, WORLD_SIZE='1'), capture_output=True, text=True, timeout=120)
     assert run.returncode == 2 and 'torch.distributed.run' in run.stderr
+
+
+def test_bench_launches_its_own_ranks():
+    """ Plain `python bench.py --gpus 2` (no launcher, WORLD_SIZE unset): the parent process -- which never touches a GPU --
+    starts the two ranks as child processes with the torchrun environment and relays rank 0's ONE JSON line
+    (homonim/fuse.py:394-408: one call fans out over the workers).  The ranks share this box's GPU over gloo. """
+    import json
+    env = dict(os.environ, HOMONIM_AMD_DIST_BACKEND='gloo', PYTHONPATH=REPO)
+    for key in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR'):
+        env.pop(key, None)
+    cmd = [sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--config', '1', '--steps', '3', '--warmup', '1',
+           '--no-cpu-baseline']
+    run = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert run.returncode == 0, run.stderr[-3000:]
+    lines = [ln for ln in run.stdout.strip().splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['value'] > 0 and line['parity_spot_check']['passed']
+    assert line['scaling'] == 'weak' and line['dist_backend'] == 'gloo' and line['rccl_ranks'] is None
