@@ -784,7 +784,7 @@ void fill_args(hk::FitArgs& a, const hk_fit_desc* d, int xcd_remap) {
         const bool mem_bound = d->model != HK_MODEL_GAIN_OFFSET && !needs_r2(d);
         if (m == 1 && d->kh <= 63 && (d->kw <= 7 || (mem_bound && d->kw <= 15))) a.use_ring = 1;
         if (m == 2 && d->kh <= 127) a.use_ring = 2;
-        if (m == 3 && mem_bound && d->kh >= 7 && d->kh <= 15 && d->kw >= 5 && d->kw <= 15) a.use_ring = 3;
+        if (m == 3 && mem_bound && d->kh >= 7 && d->kh / 2 <= hk::split_ring_rows(d->model) && d->kw >= 5 && d->kw <= 15) a.use_ring = 3;
         if (m == 0) a.use_ring = 0;
     }
     a.xcd_remap = xcd_remap;

@@ -114,6 +114,15 @@ struct NormPlane {
     long long stride;
     int height, width;
 };
+// Register rows of the split ring (ring mode 3 of the fused kernel) a build holds = the largest kernel half-height it serves.
+#ifndef HK_SRING_MAX
+#define HK_SRING_MAX 7
+#endif
+#ifndef HK_SRING_MAX_BLK
+#define HK_SRING_MAX_BLK 5
+#endif
+__host__ __device__ constexpr int split_ring_rows(int model) { return model == 1 ? HK_SRING_MAX_BLK : HK_SRING_MAX; }
+
 struct NormArgs {
     const NormPlane* planes = nullptr;  // batched launch: n_bands entries (device), else NULL -- the planes are then src/ref + band * band_stride
     const float* src;

@@ -591,9 +591,8 @@ struct ColSums {
 #ifndef HK_XCH
 #define HK_XCH 0
 #endif
-#ifndef HK_SRING_MAX
-#define HK_SRING_MAX 7   // register rows of the split ring (RING 3): kernels up to 15 rows tall
-#endif
+// (HK_SRING_MAX / HK_SRING_MAX_BLK, hk_kernels.h: register rows of the split ring -- 7 = kernels up to 15 rows tall; the
+// gain-blk-offset builds use the mode up to 11 rows only (hk_api.hip fill_args) and hold 5: 16 VGPRs less, no spill)
 #ifndef HK_CERT_R2_F32
 #define HK_CERT_R2_F32 1
 #endif
@@ -603,9 +602,29 @@ constexpr int xch_mask() {
     return (MODEL == 2 && (RW == 1 || RW == 2) && RING == 1 && WPB == 1) ? HK_XCH : 0;
 }
 
+// Waves per SIMD the register allocator has to leave room for.  Four for the certificate-only build of the narrow kernels (128
+// VGPRs), three (168 VGPRs) by default -- and two (256 VGPRs) for the builds that do not fit into 168 without spilling to
+// scratch memory (HK_NOSPILL; tools/kernel_regs.py --spills lists none with it): the wide NaN-aware builds with the R2 work
+// and the NaN-aware split-ring builds of `gain` -- measured equal or 10-15 % FASTER at two waves, profiles/r04_nospill.txt.  Where
+// two waves were slower the registers were found elsewhere: gain-blk-offset's split ring holds 5 instead of 7 rows (it serves
+// kernels up to 11 rows), dense gain-offset + R2 at the run-time width gives up its leaving row in flight (PF_OLD).
+#ifndef HK_NOSPILL
+#define HK_NOSPILL 1
+#endif
+template <int MODEL, bool R2, int RW, bool DENSE, int RING, bool CERT_ONLY>
+constexpr int fit_min_waves() {
+    if (CERT_ONLY && RW >= 0 && RW <= 3) return 4;
+    if (MODEL == 2 && R2 && !DENSE && (RW < 0 || RW >= 4)) return HK_FIT_MIN_WAVES_WIDE;
+    if (HK_NOSPILL) {
+        if (MODEL == 2 && R2 && !DENSE && RW == 3) return 2;               // gain-offset + R2, 7 wide, NaN-aware
+        if (MODEL != 2 && R2 && !DENSE && RW >= 4 && RING == 2) return 2;  // gain / gain-blk-offset + R2, 9-15 wide, NaN-aware
+        if (RING == 3 && !DENSE && MODEL == 0 && RW >= 5) return 2;        // gain, NaN-aware split ring, 11-15 wide
+    }
+    return HK_FIT_MIN_WAVES;
+}
+
 template <int MODEL, bool R2, int RW, bool DENSE, int RING, bool CERT_ONLY, int WPB, bool BATCH = false>
-__global__ void __launch_bounds__(WAVE * WPB, (CERT_ONLY && RW >= 0 && RW <= 3) ? 4
-                                        : ((MODEL == 2 && R2 && !DENSE && (RW < 0 || RW >= 4)) ? HK_FIT_MIN_WAVES_WIDE : HK_FIT_MIN_WAVES))
+__global__ void __launch_bounds__(WAVE * WPB, (fit_min_waves<MODEL, R2, RW, DENSE, RING, CERT_ONLY>()))
 fit_apply_kernel(const FitArgs a_in) {
     using CS = ColSums<MODEL, R2, DENSE>;
     // gain-blk-offset (kernel_model.py:276-303) normalises the source with the block's statistics, s' = s * n0 + n1 in
@@ -793,7 +812,7 @@ fit_apply_kernel(const FitArgs a_in) {
 
     // RING 3: the rh newest rows live in registers.  The slot (wave-uniform, t mod rh) is run-time, register indices are
     // not: a switch over the (at most SRING_MAX) slots exchanges the leaving row for the entering one with 16 moves.
-    constexpr int SRING_MAX = HK_SRING_MAX;
+    constexpr int SRING_MAX = split_ring_rows(MODEL);
     [[maybe_unused]] float4 rg_s[SRING_MAX], rg_r[SRING_MAX];
     [[maybe_unused]] unsigned rg_clean = 0u;  // wave-uniform: bit k = the row in register slot k is `clean`
     if constexpr (sring) {
@@ -855,7 +874,13 @@ fit_apply_kernel(const FitArgs a_in) {
 
     // RING 0 / 2: the re-loaded leaving row runs one iteration ahead where the registers allow it (not in the general
     // gain-offset kernels, which would spill)
-    constexpr bool PF_OLD = !ring && !sring && (DENSE || MODEL != 2);
+    // The dense gain-offset + R2 builds of the run-time width are 4-6 registers short at three waves per SIMD when that row is
+    // in flight ACROSS the pointwise stage (their register peak; two waves cost them 16-30 %): the everything-re-loaded build
+    // requests the row at the END of the iteration instead, so that the load still runs beside the loop's bookkeeping and the
+    // next entering row's classification; the centre-ring build (kernels 17 wide, up to 17 tall) does without (HK_NOSPILL)
+    constexpr bool PF_TIGHT = HK_NOSPILL && MODEL == 2 && R2 && DENSE && RW < 0;
+    constexpr bool PF_OLD = !ring && !sring && (DENSE || MODEL != 2) && !(PF_TIGHT && cring);
+    constexpr bool PF_LATE = PF_OLD && PF_TIGHT;
     [[maybe_unused]] RowRaw qo_next;
     if constexpr (PF_OLD) qo_next = load_row<HK_NT_LEAVE>(sp, rp, a.stride, t_first - kh, H, xq);
     // RING 1: the first leaving row is the zero row the ring was initialised with
@@ -891,7 +916,7 @@ fit_apply_kernel(const FitArgs a_in) {
         if constexpr (PF_OLD) {
             // the leaving row is fetched one iteration ahead (it comes from L2 / the Infinity Cache): qo_next holds row t_old
             qo = qo_next;
-            qo_next = load_row<HK_NT_LEAVE>(sp, rp, a.stride, (HK_ABLATE & 1) ? t + 1 : t_old + 1, H, xq);
+            if constexpr (!PF_LATE) qo_next = load_row<HK_NT_LEAVE>(sp, rp, a.stride, (HK_ABLATE & 1) ? t + 1 : t_old + 1, H, xq);
         } else if constexpr (!ring && !sring) {
             qo = load_row<HK_NT_LEAVE>(sp, rp, a.stride, t_old, H, xq);
         }
@@ -943,12 +968,13 @@ fit_apply_kernel(const FitArgs a_in) {
             rg_clean = (rg_clean & ~(1u << slot_r)) | ((unsigned)znew.clean << slot_r);
 #define HK_RG_SWAP(k) mid_s = rg_s[k], mid_r = rg_r[k], rg_s[k] = ns, rg_r[k] = nr
 #define HK_RG_CASE(k) case k: HK_RG_SWAP(k); break;
-            static_assert(SRING_MAX == 7 || SRING_MAX == 8, "register slots of the split ring");
-            switch (slot_r) {
-                HK_RG_CASE(0) HK_RG_CASE(1) HK_RG_CASE(2) HK_RG_CASE(3) HK_RG_CASE(4) HK_RG_CASE(5)
-                default:
-                    if (SRING_MAX == 7 || slot_r == 6) HK_RG_SWAP(6);
-                    else HK_RG_SWAP(SRING_MAX - 1);
+            static_assert(SRING_MAX >= 5 && SRING_MAX <= 8, "register slots of the split ring");
+            switch (slot_r) {   // slot_r < rh <= SRING_MAX (launch_rw); the last slot is the default
+                HK_RG_CASE(0) HK_RG_CASE(1) HK_RG_CASE(2) HK_RG_CASE(3)
+                case 4: if constexpr (SRING_MAX > 5) { HK_RG_SWAP(4); break; }
+                case 5: if constexpr (SRING_MAX > 6) { HK_RG_SWAP(5 < SRING_MAX ? 5 : 0); break; }
+                case 6: if constexpr (SRING_MAX > 7) { HK_RG_SWAP(6 < SRING_MAX ? 6 : 0); break; }
+                default: HK_RG_SWAP(SRING_MAX - 1);
             }
 #undef HK_RG_CASE
 #undef HK_RG_SWAP
@@ -1409,6 +1435,10 @@ fit_apply_kernel(const FitArgs a_in) {
             HK_STAMP(4);  // pointwise stages and stores
         }
 
+        if constexpr (PF_LATE) {
+            __builtin_amdgcn_sched_barrier(0);  // (not hoisted back above the pointwise stage)
+            qo_next = load_row<HK_NT_LEAVE>(sp, rp, a.stride, t - kh + 1, H, xq);
+        }
         if (++slot == ring_mod) slot = 0;
         if (++slot_c == ring_mod) slot_c = 0;
         if (++slot2 == rh + 1) slot2 = 0;
@@ -1538,8 +1568,8 @@ static hipError_t launch_rw(const FitArgs& a, hipStream_t stream) {
         }
     }
     if (a.use_ring == 0) return launch_one<MODEL, R2, -1, DENSE, 0>(a, stream);
-    if constexpr (MODEL != 2 && !R2) {  // split ring (hk_api.hip fill_args): 3 <= rh <= 8
-        if (a.use_ring == 3) {
+    if constexpr (MODEL != 2 && !R2) {  // split ring (hk_api.hip fill_args): rh rows in registers
+        if (a.use_ring == 3 && a.rh <= split_ring_rows(MODEL)) {
             switch (a.rw) {
                 case 2: return launch_one<MODEL, R2, 2, DENSE, 3>(a, stream);
                 case 3: return launch_one<MODEL, R2, 3, DENSE, 3>(a, stream);
