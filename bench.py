@@ -860,6 +860,14 @@ def launch_ranks(n: int) -> int:
     exit code.  The shape of homonim/fuse.py:394-408: one call fans the work out over a pool of workers. """
     import socket
     import subprocess
+    if os.environ.get('HK_NO_FIRST_PROCESS_PROBE') != '1':
+        try:   # a child is the lease's first GPU process (see main); this launcher itself makes no GPU call
+            from homonim_amd import first_process
+            probe = first_process.run()
+            if probe['rc'] != 0:
+                sys.stderr.write(f"bench.py: THE FIRST GPU PROCESS OF THIS RUN DIED OR FAILED (rc {probe['rc']}):\n{probe['output']}\n")
+        except Exception as ex:
+            sys.stderr.write(f'bench.py: first-process probe not run: {ex}\n')
     port = os.environ.get('MASTER_PORT')
     if port is None:
         with socket.socket() as sk:
@@ -904,6 +912,18 @@ def main():
         abort_trace.install()
     except Exception:
         pass
+    # single-process runs: a child is the lease's first GPU process (homonim_amd/first_process.py; round 3's aborts only ever hit
+    # first processes).  Before this process touches the GPU; reported, never fatal.  (Ranks of a launch: the launcher did it.)
+    first_probe = None
+    if env_world is None and os.environ.get('HK_NO_FIRST_PROCESS_PROBE') != '1':
+        try:
+            from homonim_amd import first_process
+            first_probe = first_process.run()
+            if first_probe['rc'] != 0:
+                sys.stderr.write(f"bench.py: THE FIRST GPU PROCESS OF THIS RUN DIED OR FAILED (rc {first_probe['rc']}):\n{first_probe['output']}\n")
+            first_probe = {'rc': first_probe['rc'], 'seconds': first_probe['seconds']}
+        except Exception as ex:
+            sys.stderr.write(f'bench.py: first-process probe not run: {ex}\n')
     from homonim_amd import _hk, dist
     rank, world, local_rank = dist.init()  # torch.distributed (nccl = RCCL) only when WORLD_SIZE > 1
     # one GPU per rank on a full node.  configs[3] deals its block positions to 8 streams: a position's statistics are a chain of
@@ -1018,6 +1038,8 @@ def main():
             out['other_configs'] = other
         if res.get('power') is not None:
             out['power'] = res['power']
+        if first_probe is not None:
+            out['first_gpu_process_probe'] = first_probe   # rc 0: the child that used the GPU before this process ended normally
         if dist.backend() is not None:
             out['dist_backend'] = dist.backend()   # 'nccl' = RCCL; absent for a single process without a group
             out['rccl_ranks'] = rccl_ranks         # ranks of the library's own communicator (hk_comm_info); None under gloo

@@ -24,6 +24,36 @@ def pytest_configure(config):
         print(f'[conftest] abort tracer not installed: {ex}', file=sys.stderr)
 
 
+_probe = {}
+
+
+def pytest_sessionstart(session):
+    """ A run that selects the GPU tests first lets a CHILD process be the lease's first GPU process (homonim_amd/first_process.py):
+    round 3's aborts only ever hit first processes.  Its fate is part of the report header; it never fails the run. """
+    expr = session.config.getoption('markexpr', '') or ''
+    if 'gpu' not in expr or 'not gpu' in expr or os.environ.get('HK_NO_FIRST_PROCESS_PROBE') == '1':
+        return
+    try:
+        from homonim_amd import first_process
+        _probe.update(first_process.run())
+    except Exception as ex:
+        _probe.update(rc=None, seconds=0, output=f'probe not run: {ex}')
+    if _probe.get('rc') == 0:   # (`-q` prints no report header: say it here)
+        last = (_probe.get('output') or '').splitlines()[-1:] or ['']
+        sys.__stderr__.write(f"[conftest] first GPU process probe: rc 0 in {_probe.get('seconds')} s -- {last[0]}\n")
+        sys.__stderr__.flush()
+    else:   # loud, on the real stderr, whatever pytest captures
+        sys.__stderr__.write(f"\n[conftest] THE FIRST GPU PROCESS OF THIS RUN DIED OR FAILED (rc {_probe.get('rc')}):\n{_probe.get('output')}\n\n")
+        sys.__stderr__.flush()
+
+
+def pytest_report_header(config):
+    if _probe:
+        last = (_probe.get('output') or '').splitlines()[-1:] or ['']
+        return f"first GPU process probe: rc {_probe.get('rc')} in {_probe.get('seconds')} s -- {last[0]}"
+    return None
+
+
 def _nodata(v):
     return None if v is None else (float('nan') if v == 'nan' else float(v))
 
