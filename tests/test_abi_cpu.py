@@ -320,3 +320,24 @@ def test_counts_pending_is_host_only(lib):
     a[3], a[0] = 0, 1 << 63          # HK_COUNT_RETRY: the band must be run again with the complete build
     assert lib.hk_counts_pending(a.ctypes.data_as(u64p), 5) == 1
     assert lib.hk_counts_pending(None, 5) == 0
+
+
+def test_every_entry_point_of_the_boundary_header_has_a_row_in_integration_md():
+    """ include/homonim_hk.h holds the drop-in boundary only: each of its entry points is named in INTEGRATION.md's table of what
+    it replaces in the reference (`hk_event_*` covers a family, `hk_host_alloc/free` a pair); the aids of
+    include/homonim_hk_devtools.h are named there as aids. """
+    text = open(os.path.join(REPO, 'INTEGRATION.md')).read()
+    named, families = set(), []
+    for tok in re.findall(r'hk_[a-z0-9_]+\*?(?:/[a-z0-9_]+)*', text):
+        head, *alts = tok.split('/')
+        if head.endswith('*'):
+            families.append(head[:-1])
+            continue
+        named.add(head)
+        prefix = head[:head.rfind('_') + 1]
+        named.update(prefix + a for a in alts)
+    strip = lambda t: re.sub(r'/\*.*?\*/', '', t, flags=re.S)   # noqa: E731
+    declared = set(re.findall(r'\b(hk_[a-z0-9_]+)\s*\(', strip(_header('main'))))
+    missing = sorted(n for n in declared if n not in named and not any(n.startswith(f) for f in families))
+    assert not missing, f'entry points of homonim_hk.h without a row in INTEGRATION.md: {missing}'
+    assert all(n in named for n in _hk.DEVTOOLS)
