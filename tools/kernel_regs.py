@@ -38,10 +38,16 @@ def demangle(names):
 
 
 if __name__ == '__main__':
-    args = [a for a in sys.argv[1:] if not a.startswith('--')]
+    argv = list(sys.argv[1:])
+    grep_text = None
+    if '--grep' in argv:
+        i = argv.index('--grep')
+        grep_text = argv[i + 1]
+        del argv[i:i + 2]
+    args = [a for a in argv if not a.startswith('--')]
     obj = args[0] if args else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'homonim_amd', 'lib', 'hk_kernels.o')
     ks = kernels(obj)
-    grep = sys.argv[sys.argv.index('--grep') + 1] if '--grep' in sys.argv else None
+    grep = grep_text
     names = demangle([k['name'] for k in ks])
     fit = [(k, n) for k, n in zip(ks, names) if 'fit_apply_kernel' in n]
     bad = [(k, n) for k, n in fit if k['scratch'] or k['spills']]

@@ -5,6 +5,7 @@
 set -u
 tag=$1; shift
 export TMPDIR=/tmp
+export HK_NO_FIRST_PROCESS_PROBE=1   # profiles of the bench process alone
 root=$(pwd)
 groups=("GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD" "FETCH_SIZE" "WRITE_SIZE")
 i=0

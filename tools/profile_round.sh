@@ -5,6 +5,7 @@
 set -u
 tag=$1
 export TMPDIR=/tmp
+export HK_NO_FIRST_PROCESS_PROBE=1   # profiles of the bench process alone
 root=$(pwd)
 python3 bench.py > gpurun_out/${tag}_bench_full.json 2> gpurun_out/${tag}_bench_full.err
 rm -rf gpurun_out/${tag}_stats
