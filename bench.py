@@ -862,7 +862,7 @@ def launch_ranks(n: int) -> int:
     import subprocess
     if os.environ.get('HK_NO_FIRST_PROCESS_PROBE') != '1':
         try:   # a child is the lease's first GPU process (see main); this launcher itself makes no GPU call
-            from homonim_amd import first_process
+            from harness import first_process
             probe = first_process.run()
             if probe['rc'] != 0:
                 sys.stderr.write(f"bench.py: THE FIRST GPU PROCESS OF THIS RUN DIED OR FAILED (rc {probe['rc']}):\n{probe['output']}\n")
@@ -907,17 +907,17 @@ def main():
             f'  python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 '
             f'--master-port 29500 bench.py --gpus {args.gpus} ...\n(or unset WORLD_SIZE: `python bench.py --gpus N` starts its own ranks)\n')
         sys.exit(2)
-    try:   # a fatal signal names its sender, thread and native frames (homonim_amd/abort_trace.py)
-        from homonim_amd import abort_trace
+    try:   # a fatal signal names its sender, thread and native frames (harness/abort_trace.py)
+        from harness import abort_trace
         abort_trace.install()
     except Exception:
         pass
-    # single-process runs: a child is the lease's first GPU process (homonim_amd/first_process.py; round 3's aborts only ever hit
+    # single-process runs: a child is the lease's first GPU process (harness/first_process.py; round 3's aborts only ever hit
     # first processes).  Before this process touches the GPU; reported, never fatal.  (Ranks of a launch: the launcher did it.)
     first_probe = None
     if env_world is None and os.environ.get('HK_NO_FIRST_PROCESS_PROBE') != '1':
         try:
-            from homonim_amd import first_process
+            from harness import first_process
             first_probe = first_process.run()
             if first_probe['rc'] != 0:
                 sys.stderr.write(f"bench.py: THE FIRST GPU PROCESS OF THIS RUN DIED OR FAILED (rc {first_probe['rc']}):\n{first_probe['output']}\n")

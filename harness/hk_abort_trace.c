@@ -1,4 +1,4 @@
-/* hk_abort_trace.c -- diagnostic helper of the test / bench harness (libhk_abort_trace.so; NOT part of libhomonim_hk.so).
+/* hk_abort_trace.c -- diagnostic helper of the test / bench harness (harness/_build/libhk_abort_trace.so; NOT part of the product).
  *
  * A GPU process that dies of SIGABRT usually dies on a native thread of the HSA runtime (memory fault, queue error,
  * hardware exception: the runtime prints one line to fd 2 and calls abort()).  Under pytest that line is lost when fd 2

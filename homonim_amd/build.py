@@ -19,9 +19,6 @@ HIP_SOURCES = ['hk_kernels.hip', 'hk_norm.hip', 'hk_convert.hip', 'hk_mask.hip',
 # -ffp-contract=off: numpy never fuses a*b+c; the kernels must round exactly where the reference does.
 HIPCC_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wall', '-Wno-unused-function']
 
-TRACE_SRC = os.path.join(CSRC, 'hk_abort_trace.c')
-TRACE_LIB = os.path.join(LIB_DIR, 'libhk_abort_trace.so')
-
 ORACLE_DIR = os.path.join(REPO, 'oracle')
 ORACLE_BUILD = os.path.join(ORACLE_DIR, '_build')
 ORACLE_LIB = os.path.join(ORACLE_BUILD, 'libhk_oracle.so')
@@ -73,16 +70,6 @@ def build_hip(force: bool = False, verbose: bool = True) -> str:
     return LIB_PATH
 
 
-def build_abort_trace(force: bool = False, verbose: bool = True) -> str:
-    """ Compile the harness's abort tracer (plain C, no GPU code; loaded by tests/conftest.py and bench.py only). """
-    os.makedirs(LIB_DIR, exist_ok=True)
-    if force or _stale(TRACE_LIB, [TRACE_SRC]):
-        _run(['gcc', '-O1', '-g', '-std=gnu11', '-fPIC', '-shared', '-o', TRACE_LIB, TRACE_SRC])
-        if verbose:
-            print(f'[homonim_amd.build] built {TRACE_LIB}', flush=True)
-    return TRACE_LIB
-
-
 def build_oracle(force: bool = False, verbose: bool = True) -> str:
     """ Compile the plain-C oracle (test infrastructure; never loaded by the product). """
     src = os.path.join(ORACLE_DIR, 'hk_oracle.c')
@@ -100,5 +87,4 @@ def build_oracle(force: bool = False, verbose: bool = True) -> str:
 if __name__ == '__main__':
     force = '--force' in sys.argv
     build_hip(force)
-    build_abort_trace(force)
     build_oracle(force)

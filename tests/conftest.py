@@ -14,9 +14,9 @@ GOLDEN_DIR = os.path.join(REPO, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: test needs a real MI355X (run with -m gpu on the GPU box)')
-    # a fatal signal names its sender, thread and native frames (homonim_amd/abort_trace.py); in front of faulthandler
+    # a fatal signal names its sender, thread and native frames (harness/abort_trace.py); in front of faulthandler
     try:
-        from homonim_amd import abort_trace
+        from harness import abort_trace
         log_dir = os.path.join(REPO, 'gpurun_out')
         path = os.path.join(log_dir, f'abort_trace_{os.getpid()}.log') if os.path.isdir(log_dir) else None
         abort_trace.install(path)
@@ -28,13 +28,13 @@ _probe = {}
 
 
 def pytest_sessionstart(session):
-    """ A run that selects the GPU tests first lets a CHILD process be the lease's first GPU process (homonim_amd/first_process.py):
+    """ A run that selects the GPU tests first lets a CHILD process be the lease's first GPU process (harness/first_process.py):
     round 3's aborts only ever hit first processes.  Its fate is part of the report header; it never fails the run. """
     expr = session.config.getoption('markexpr', '') or ''
     if 'gpu' not in expr or 'not gpu' in expr or os.environ.get('HK_NO_FIRST_PROCESS_PROBE') == '1':
         return
     try:
-        from homonim_amd import first_process
+        from harness import first_process
         _probe.update(first_process.run())
     except Exception as ex:
         _probe.update(rc=None, seconds=0, output=f'probe not run: {ex}')

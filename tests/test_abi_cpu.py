@@ -216,6 +216,17 @@ def test_product_never_imports_oracle():
                     'build_oracle', '').replace('libhk_oracle', '').replace("'hk_oracle.c'", ''), f
 
 
+def test_product_never_imports_the_harness_diagnostics():
+    """ harness/ (abort tracer, first-GPU-process probe) serves tests/conftest.py, bench.py and smoke() only. """
+    for root, _, files in os.walk(os.path.join(REPO, 'homonim_amd')):
+        for f in files:
+            if f.endswith('.py'):
+                text = open(os.path.join(root, f)).read()
+                assert 'import harness' not in text and 'from harness' not in text, f
+    from harness import abort_trace
+    assert os.path.exists(abort_trace.build())   # plain C, gcc only
+
+
 # -- reference tests/test_kernel_model.py:296-334 (error behaviour, config) -------------------------------------------
 @pytest.mark.parametrize('model, kernel_shape', [
     (Model.gain, (0, 0)), (Model.gain_blk_offset, (0, 0)), (Model.gain_offset, (4, 5)), (Model.gain_offset, (1, 1)),
