@@ -39,6 +39,18 @@ def run(out_path: str):
         par[:, rng.random((h, w)) < 0.01] = np.nan
         pm, cm, mm = ctx.partial_mask(a, np.nan, par, (5, 5), src=a, want_params=True, want_corr=True, want_mask=True)
         res[name + '_p'], res[name + '_c'], res[name + '_m'] = pm, cm, mm
+    # the block loop of RasterFuse.process: out-windows of blocks with halos, written straight into strided caller rasters
+    # (hk_fit_apply_block; pageable arrays, no registration)
+    import warnings
+    from homonim_amd.fuse import RasterFuse
+    cube_s = np.stack([onp.synth_pair(300, 410, 40 + b, 'frame+holes')[0] for b in range(3)])
+    cube_r = np.stack([onp.synth_pair(300, 410, 40 + b, 'frame+holes')[1] for b in range(3)])
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        corr_f, par_f = RasterFuse(cube_s, cube_r, src_nodata=np.nan, ref_nodata=np.nan).process(
+            None, 'gain-offset', (5, 5), param_filename=True, block_config=dict(threads=2, max_block_mem=0.05),
+            device_config=dict(devices=[0], streams=2, pin=False))
+    res['fuse_corr'], res['fuse_params'] = np.asarray(corr_f), np.asarray(par_f)
     res['apply'] = ctx.apply(src, params[:2])
     res['reproject'] = ctx.reproject(np.stack([src, ref]), np.nan, (2.0, 0.0, 2.0, 0.0), (166, 258), 5, np.nan)
     res['sums'] = ctx.compare_sums(src, np.nan, ref, np.nan)
