@@ -472,7 +472,7 @@ __device__ __forceinline__ RowZ process_row(const RowRaw& raw, bool row_ok, unsi
     }
     if constexpr (!PERPX) {
         // wave-uniform short cut: nothing to zero, nothing to pack (the usual state away from the edges of real mosaics)
-        if (row_ok && full_wave && (((HK_ABLATE & 16) != 0) || __all((int)(ok[0] & ok[1] & ok[2] & ok[3])))) {  // (16: timing experiment)
+        if (row_ok && full_wave && __all((int)(ok[0] & ok[1] & ok[2] & ok[3]))) {
 #pragma unroll
             for (int i = 0; i < PX; ++i) z.s[i] = z.e[i] = s[i], z.r[i] = r[i];
             z.m = 0x01010101u;
@@ -550,7 +550,7 @@ struct ColSums {
             R[i] = ADD ? __dadd_rn(R[i], dr) : __dsub_rn(R[i], dr);
             if constexpr (NEED_R2S) R2s[i] = __fma_rn(ADD ? dr : -dr, dr, R2s[i]);
         }
-        if constexpr (NEED_N && !(HK_ABLATE & 32)) N = ADD ? N + z.m : N - z.m;  // (32: timing experiment)
+        if constexpr (NEED_N) N = ADD ? N + z.m : N - z.m;
     }
 };
 
