@@ -16,6 +16,7 @@
         return 2;                                                 \
     }
 
+typedef int (*hk_abi_version_fn)(void);
 typedef const char* (*hk_backend_name_fn)(void);
 typedef const char* (*hk_last_error_fn)(void);
 typedef int (*hk_device_count_fn)(int*);
@@ -32,6 +33,11 @@ int main(int argc, char** argv) {
     if (!lib) {
         fprintf(stderr, "dlopen: %s\n", dlerror());
         return 1;
+    }
+    LOAD(hk_abi_version)
+    if (hk_abi_version_p() != HK_ABI_VERSION) { /* struct layouts differ between versions and carry no size field */
+        fprintf(stderr, "library ABI %d, header %d\n", hk_abi_version_p(), HK_ABI_VERSION);
+        return 5;
     }
     LOAD(hk_backend_name) LOAD(hk_last_error) LOAD(hk_device_count) LOAD(hk_ctx_create) LOAD(hk_ctx_destroy)
     LOAD(hk_fit_apply) LOAD(hk_compare_sums)

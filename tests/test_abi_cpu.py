@@ -53,6 +53,11 @@ def test_header_is_plain_c_and_a_c_program_can_drive_the_library(lib, tmp_path):
     run = subprocess.run([str(exe), _hk.lib_path()], capture_output=True, text=True, timeout=120)
     assert run.returncode == 0, (run.returncode, run.stdout, run.stderr)
     assert 'abi_consumer: ok' in run.stdout
+    # the aids' header is plain C as well
+    src = tmp_path / 'devtools.c'
+    src.write_text('#include "homonim_hk_devtools.h"\nint main(void) { return HK_ABI_VERSION > 0 ? 0 : 1; }\n')
+    subprocess.run(['gcc', '-std=c99', '-pedantic', '-Wall', '-Werror', '-I', os.path.join(REPO, 'include'), str(src), '-o',
+                    str(tmp_path / 'devtools')], check=True)
 
 
 def test_ctypes_structs_have_the_offsets_the_c_compiler_gives_the_header(tmp_path):
