@@ -189,9 +189,16 @@ __device__ __forceinline__ float fill_one(int x, int y, long long row, const flo
         const long long i = row + x;
         float out = offset[i];  // a target without any source in reach keeps its value
         const int none2 = (max_dist + 1) * (max_dist + 1);  // qd = max_dist + 1: "nothing found yet" (a perfect square: no tie)
-        int qd2[4] = {none2, none2, none2, none2};
-        // (column distance << 8) | row distance of the quadrant's source: the FIRST and the LAST candidate met at the best distance
-        unsigned qs[4] = {0, 0, 0, 0}, qs_last[4] = {0, 0, 0, 0};
+        // Per quadrant the search state is two KEYS (round 4): (squared distance << 15) | source word, the source word being
+        // (column distance << 8) | row distance (15 bits; the squared distance of any table byte and column step fits 17).  The
+        // smallest key is the FIRST candidate met at the best distance (steps ascend, so among equal distances the smallest
+        // column distance came first), the smallest key with the source word's bits inverted is the LAST one: two unsigned
+        // minima per candidate instead of two compares and three selects.  A candidate that does not beat "nothing found yet"
+        // leaves the initial keys in place; quadrants whose best distance exceeds max_dist are dropped at the end as before.
+        constexpr unsigned SRC_BITS = 15u, SRC_MASK = (1u << SRC_BITS) - 1u;
+        unsigned kf[4], kl[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) kf[q] = kl[q] = ((unsigned)none2 << SRC_BITS) | SRC_MASK;
         const unsigned short* __restrict__ trow = tb + row;
         // GDAL's QUAD_CHECK on squared integer distances.  `dist` is the column table's byte: NONE_B (no source in reach)
         // squares to more than any distance the search accepts and more than the initial (max_dist + 1)^2, so it never wins.
@@ -199,14 +206,13 @@ __device__ __forceinline__ float fill_one(int x, int y, long long row, const flo
         // `tie` bit of c) -- a property of c alone: with the bit set the last candidate met at the best distance wins, without it
         // the first.  So the search keeps both, branch-free (two compares, three selects), and the bit is looked up once per
         // quadrant at the end instead of behind a divergent branch in every one of the 34 candidate tests.
-        auto consider = [&](int q, unsigned dist, int dx2, unsigned dx_hi) {
-            const int c = (int)(dist * dist) + dx2;
-            const bool lt = c < qd2[q], le = c <= qd2[q];
-            const unsigned cand = dx_hi | dist;
-            qd2[q] = lt ? c : qd2[q];
-            qs[q] = lt ? cand : qs[q];
-            qs_last[q] = le ? cand : qs_last[q];
+        // dxk = (dx^2 << 15) | (dx << 8): the step's share of the key (wave-uniform away from the raster's edge columns)
+        auto consider = [&](int q, unsigned dist, unsigned dxk) {
+            const unsigned key = ((unsigned)HK_SQ((int)dist) << SRC_BITS) + (dxk + dist);
+            kf[q] = min(kf[q], key);
+            kl[q] = min(kl[q], key ^ SRC_MASK);
         };
+        auto worst_qd2 = [&]() { return (int)(max(max(kf[0], kf[1]), max(kf[2], kf[3])) >> SRC_BITS); };
         // Steps are taken in groups that end where GDAL re-derives its search bound (after steps 4, 8, 12, ...): the
         // bound is constant inside a group, so all of the group's table look-ups are issued before the checks, which then
         // run in the original order (ascending step; left quadrants before right ones).  The look-ups of the NEXT group are
@@ -249,36 +255,42 @@ __device__ __forceinline__ float fill_one(int x, int y, long long row, const flo
                 for (int k = 0; k < 5; ++k) {
                     if (k <= last) {
                         const int dl = INTERIOR ? k : min(k, x), dr = INTERIOR ? k : min(k, width - 1 - x);  // clamped columns: the distance to the edge column
-                        const int dl2 = HK_SQ(dl), dr2 = HK_SQ(dr);
-                        consider(0, up(d0, 4 - k), dl2, (unsigned)dl << 8);  // top left
-                        consider(1, dn(d0, 4 - k), dl2, (unsigned)dl << 8);  // bottom left
+                        const unsigned dlk = ((unsigned)HK_SQ(dl) << SRC_BITS) | ((unsigned)dl << 8);
+                        const unsigned drk = ((unsigned)HK_SQ(dr) << SRC_BITS) | ((unsigned)dr << 8);
+                        consider(0, up(d0, 4 - k), dlk);  // top left
+                        consider(1, dn(d0, 4 - k), dlk);  // bottom left
                         if (k != 0) {
-                            consider(2, up(d0, 4 + k), dr2, (unsigned)dr << 8);  // top right
-                            consider(3, dn(d0, 4 + k), dr2, (unsigned)dr << 8);  // bottom right
+                            consider(2, up(d0, 4 + k), drk);  // top right
+                            consider(3, dn(d0, 4 + k), drk);  // bottom right
                         }
                     }
                 }
                 // no farther column can beat every quadrant's current distance: floor(max qd) = floor(sqrt(max qd2))
-                if (last == 4) this_max = isqrt_floor(max(max(qd2[0], qd2[1]), max(qd2[2], qd2[3])));
+                if (last == 4) this_max = isqrt_floor(worst_qd2());
             }
             int first = 5;
             while (first <= this_max) {
-                const int last = min(this_max, first + 3);
+                // The whole group is tested even when the bound falls inside it: a column farther than floor(sqrt(worst
+                // quadrant distance^2)) cannot beat or tie any quadrant (its squared column distance alone exceeds every best),
+                // so GDAL's bound only ever decides when to STOP, and a per-step predicate (an exec-mask round trip per step) buys
+                // nothing.  Groups start at 5, 9, ..., 97: no step beyond max_dist = 100.
+                const int last = first + 3;
                 const unsigned cl[2] = {nl[0], nl[1]}, cr[2] = {nr[0], nr[1]};
                 fetch4(first + 4, nl, nr);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int step = first + k;
-                    if (step <= last) {
+                    {
                         const int dl = INTERIOR ? step : min(step, x), dr = INTERIOR ? step : min(step, width - 1 - x);
-                        const int dl2 = HK_SQ(dl), dr2 = HK_SQ(dr);
-                        consider(0, up(cl, 3 - k), dl2, (unsigned)dl << 8);
-                        consider(1, dn(cl, 3 - k), dl2, (unsigned)dl << 8);
-                        consider(2, up(cr, k), dr2, (unsigned)dr << 8);
-                        consider(3, dn(cr, k), dr2, (unsigned)dr << 8);
+                        const unsigned dlk = ((unsigned)HK_SQ(dl) << SRC_BITS) | ((unsigned)dl << 8);
+                        const unsigned drk = ((unsigned)HK_SQ(dr) << SRC_BITS) | ((unsigned)dr << 8);
+                        consider(0, up(cl, 3 - k), dlk);
+                        consider(1, dn(cl, 3 - k), dlk);
+                        consider(2, up(cr, k), drk);
+                        consider(3, dn(cr, k), drk);
                     }
                 }
-                if ((last & 3) == 0) this_max = isqrt_floor(max(max(qd2[0], qd2[1]), max(qd2[2], qd2[3])));
+                this_max = min(this_max, isqrt_floor(worst_qd2()));
                 first = last + 1;
             }
         }
@@ -291,12 +303,13 @@ __device__ __forceinline__ float fill_one(int x, int y, long long row, const flo
         bool ok4[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            ok4[q] = qd2[q] <= max_dist * max_dist;  // qd <= max_dist
-            const int cq = ok4[q] ? qd2[q] : 0;
-            const unsigned src = ((tie[cq >> 5] >> (cq & 31)) & 1u) ? qs_last[q] : qs[q];  // (the 1.3 KB bitmap stays in cache)
+            const int qd2 = (int)(kf[q] >> SRC_BITS);
+            ok4[q] = qd2 <= max_dist * max_dist;  // qd <= max_dist
+            const int cq = ok4[q] ? qd2 : 0;
+            const unsigned src = ((tie[cq >> 5] >> (cq & 31)) & 1u) ? ((kl[q] & SRC_MASK) ^ SRC_MASK) : (kf[q] & SRC_MASK);  // (the 1.3 KB bitmap stays in cache)
             const int dx = ok4[q] ? (int)(src >> 8) : 0, dy = ok4[q] ? (int)(src & 0xffu) : 0;
             const int sx = q < 2 ? x - dx : x + dx, sy = (q & 1) ? y + dy : y - dy;
-            w4[q] = wtab[ok4[q] ? qd2[q] : 0];
+            w4[q] = wtab[cq];
             v4[q] = offset[(long long)sy * stride + sx];
         }
         double wsum = 0.0, vsum = 0.0;
