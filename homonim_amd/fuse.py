@@ -359,11 +359,15 @@ class RasterFuse:
 
     @staticmethod
     def create_device_config(devices: Optional[Sequence[int]] = None, streams: int = 4, rank: int = 0,
-                             world_size: int = 1, contiguous: bool = False, pin: bool = True,
+                             world_size: int = 1, contiguous: bool = False, pin: bool = False,
                              separate_contexts: bool = False) -> Dict:
         """ (this package only) GPUs of this process, streams per GPU, this process's shard of the block list
-        (round-robin, or ``contiguous`` runs), whether the rasters are page-locked for asynchronous transfers, and
-        whether every entry of ``devices`` gets a context of its own even when a device is listed twice. """
+        (round-robin, or ``contiguous`` runs), whether every entry of ``devices`` gets a context of its own even when a
+        device is listed twice, and ``pin``: False (default) -- the caller's rasters travel through the library's own
+        page-locked staging ring, the GPU never touches caller-allocated pages (rasters that are page-locked already,
+        e.g. ``Context.pinned_empty``, are still copied directly); True -- the rasters are registered in place for the
+        duration of the block loop (``hipHostRegister``) and copied directly: 10-17 % more end-to-end throughput
+        (profiles/r04_streamed_host.txt) at the price of GPU accesses to the caller's own heap pages. """
         return dict(devices=None if devices is None else list(devices), streams=int(streams), rank=int(rank),
                     world_size=int(world_size), contiguous=bool(contiguous), pin=bool(pin),
                     separate_contexts=bool(separate_contexts))
@@ -531,8 +535,8 @@ class RasterFuse:
 
         blocks = list(self.block_pairs(overlap=overlap, max_block_mem=block_config['max_block_mem']))
         blocks = shard(blocks, device_config['rank'], device_config['world_size'], device_config['contiguous'])
-        # page-lock the rasters for the duration of the block loop: H2D / D2H of different blocks then run asynchronously
-        # beside the kernels (hipMemcpyAsync from pageable memory stages through a bounce buffer and blocks the caller)
+        # on request: page-lock the rasters in place for the duration of the block loop (direct copies); by default pageable
+        # rasters go through the context's pinned staging ring (hk_api.hip stage_h2d / stage_d2h) block by block
         pinned = self._pin(models[0].context, [self._src, self._ref, corr, params]) if device_config['pin'] else []
         try:
             self._run_blocks(blocks, models, process_block, corr, params, nodata, block_config)
