@@ -1,0 +1,39 @@
+""" The harness diagnostics (harness/, never imported by the product): the abort tracer names a fatal signal raised on a NATIVE
+thread -- sender, thread, native frames -- and rescues what the process last wrote to a captured stderr.  This is the tool that
+showed the round-3 abort to be a GPU memory access fault (profiles/r04_abort_caught.txt). """
+import os
+import subprocess
+import sys
+
+from conftest import REPO
+
+_CHILD = r'''
+import ctypes, os, sys, tempfile, time
+sys.path.insert(0, %(repo)r)
+from harness import abort_trace
+real = os.dup(2)
+cap = tempfile.TemporaryFile()
+os.dup2(cap.fileno(), 2)                      # what pytest's fd capture does during a test
+assert abort_trace.install(fd=real)
+os.write(2, b"Memory access fault by GPU node-2 (stand-in for the runtime's last words)\n")
+libc = ctypes.CDLL(None)
+t = ctypes.c_ulong()
+libc.pthread_create(ctypes.byref(t), None, ctypes.c_void_p(ctypes.cast(libc.abort, ctypes.c_void_p).value), None)
+time.sleep(5)
+'''
+
+
+def test_abort_on_a_native_thread_is_named_and_the_captured_stderr_rescued():
+    run = subprocess.run([sys.executable, '-c', _CHILD % dict(repo=REPO)], capture_output=True, text=True, timeout=60)
+    assert run.returncode == -6, run.returncode            # SIGABRT, default action after the report
+    err = run.stderr
+    assert '[hk_abort_trace] signal 6' in err and 'raised by this process (abort/raise)' in err
+    assert 'abort+0x' in err or 'abort' in err              # native frames of the aborting thread
+    assert 'tail of the captured stderr' in err and "stand-in for the runtime's last words" in err
+
+
+def test_first_process_probe_reports_without_a_gpu():
+    """ harness/first_process.py as conftest / bench.py use it: a child process; without a GPU it says so and exits 0. """
+    from harness import first_process
+    res = first_process.run(timeout=120)
+    assert res['rc'] == 0 and 'no GPU' in res['output']
