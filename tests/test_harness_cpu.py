@@ -33,7 +33,7 @@ def test_abort_on_a_native_thread_is_named_and_the_captured_stderr_rescued():
 
 
 def test_first_process_probe_reports_without_a_gpu():
-    """ harness/first_process.py as conftest / bench.py use it: a child process; without a GPU it says so and exits 0. """
+    """ harness/first_process.py as conftest / bench.py use it: a child process; without a GPU it says so and exits 0 (with one it works for two seconds). """
     from harness import first_process
     res = first_process.run(timeout=120)
-    assert res['rc'] == 0 and 'no GPU' in res['output']
+    assert res['rc'] == 0 and ('no GPU' in res['output'] or 'host-pointer calls as the first GPU process' in res['output'])
