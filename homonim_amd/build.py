@@ -17,7 +17,9 @@ LIB_DIR = os.path.join(PKG, 'lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libhomonim_hk.so')
 HIP_SOURCES = ['hk_kernels.hip', 'hk_norm.hip', 'hk_convert.hip', 'hk_mask.hip', 'hk_inpaint.hip', 'hk_resample.hip', 'hk_compare.hip', 'hk_api.hip']
 # -ffp-contract=off: numpy never fuses a*b+c; the kernels must round exactly where the reference does.
-HIPCC_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wall', '-Wno-unused-function']
+# -Wno-bitwise-instead-of-logical: `a | b` / `a & b` on booleans is deliberate in the kernels (no short-circuit branch per pixel).
+HIPCC_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wall', '-Wno-unused-function',
+               '-Wno-bitwise-instead-of-logical']
 
 ORACLE_DIR = os.path.join(REPO, 'oracle')
 ORACLE_BUILD = os.path.join(ORACLE_DIR, '_build')
@@ -42,6 +44,8 @@ def _run(cmd):
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if res.returncode != 0:
         raise RuntimeError(f'build step failed: {" ".join(cmd)}\n{res.stdout}')
+    if res.stdout.strip():   # warnings are not swallowed: the build is meant to be warning-free
+        print(res.stdout, flush=True)
     return res.stdout
 
 

@@ -391,7 +391,8 @@ __global__ void __launch_bounds__(256, PACK ? 8 : HK_FILL_WAVES_FULL) inpaint_fi
 #define HK_FILL_TILE_WAVES 8
 #endif
 template <int ROWS>
-__global__ void __launch_bounds__(256, HK_FILL_TILE_WAVES) inpaint_fill_tile_kernel(const float* __restrict__ offset, const unsigned char* __restrict__ flag,
+__global__ void __launch_bounds__(256, (ROWS <= 32 ? HK_FILL_TILE_WAVES : 5))  // (64-row tiles: the target lists' 32 KB of LDS per workgroup allow five)
+inpaint_fill_tile_kernel(const float* __restrict__ offset, const unsigned char* __restrict__ flag,
                                                                    long long stride, int height, int width, int max_dist_arg,
                                                                    const unsigned short* __restrict__ tb,
                                                                    const unsigned* __restrict__ tie,

@@ -103,6 +103,9 @@ static void hsum_into_ring(const WinState* ws, int slot) {
     }
 }
 
+/* (defined below) */
+int hk_oracle_fill_nodata(float* image, const unsigned char* mask, int H, int W, double max_search_distance);
+
 /*
  * KernelModel.fit (+ apply) on one band (kernel_model.py:411-463).
  *   params_out: n_param_bands x H x W or NULL; corr_out: H x W or NULL; norm: float64[2] for gain-blk-offset.
