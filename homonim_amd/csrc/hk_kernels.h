@@ -89,6 +89,19 @@ struct FitArgs {
 
 // model: 0 gain, 1 gain-blk-offset, 2 gain-offset.  with_r2: compute the R2 quantity set.
 hipError_t launch_fit_apply(const FitArgs& a, int model, bool with_r2, hipStream_t stream);
+// ... which dispatches to one translation unit per (model, with_r2) (hk_fit_tu.hip)
+hipError_t launch_fit_m0_r0(const FitArgs& a, hipStream_t stream);
+hipError_t launch_fit_m0_r1(const FitArgs& a, hipStream_t stream);
+hipError_t launch_fit_m1_r0(const FitArgs& a, hipStream_t stream);
+hipError_t launch_fit_m1_r1(const FitArgs& a, hipStream_t stream);
+hipError_t launch_fit_m2_r0(const FitArgs& a, hipStream_t stream);
+hipError_t launch_fit_m2_r1(const FitArgs& a, hipStream_t stream);
+hipError_t read_stamps_m0_r0(unsigned long long* acc16, bool reset);
+hipError_t read_stamps_m0_r1(unsigned long long* acc16, bool reset);
+hipError_t read_stamps_m1_r0(unsigned long long* acc16, bool reset);
+hipError_t read_stamps_m1_r1(unsigned long long* acc16, bool reset);
+hipError_t read_stamps_m2_r0(unsigned long long* acc16, bool reset);
+hipError_t read_stamps_m2_r1(unsigned long long* acc16, bool reset);
 // Which builds of the fused kernel exist with the job-table look-up of a batched launch (FitArgs::jobs): gain-blk-offset without
 // R2 -- the fused RasterFuse path of a block-partitioned mosaic, where one launch for all blocks pays (profiles/r03_batch.txt).
 // The batched entry points run every other model as one launch per job (bit-identical either way).

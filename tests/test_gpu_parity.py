@@ -153,6 +153,31 @@ def test_multi_strip_multi_segment_vs_oracle(ctx, model, kernel_shape, find_r2, 
         assert n_fail == aux
 
 
+@pytest.mark.parametrize('model, find_r2, thresh', [
+    ('gain', False, None), ('gain', True, None), ('gain-blk-offset', False, None), ('gain-blk-offset', True, None),
+    ('gain-offset', False, None), ('gain-offset', True, None), ('gain-offset', False, 0.25), ('gain-offset', True, 0.25),
+])
+@pytest.mark.parametrize('kernel_shape', [(17, 17), (21, 9), (31, 31), (9, 21), (5, 19), (33, 35), (3, 25), (45, 13), (7, 41)])
+@pytest.mark.parametrize('variant', ['frame+holes', 'none'])
+def test_kernels_wider_than_15_vs_oracle(ctx, oc, model, find_r2, thresh, kernel_shape, variant):
+    """ Kernels wider than 15 (the reference's integration suite runs 31 x 31 -- tests/integration.py:36-37,42-43 -- and
+    utils.validate_kernel_shape admits any odd shape, utils.py:104-133) take the builds that know kw // 2 mod 4 at compile time and
+    kw // 8 at run time (hk_fit_kernel.h hsum_wide): every residue, one to four whole neighbour lanes per side, short / tall
+    (centre ring; everything re-loaded beyond 31 rows), all three models, with and without R2 and the r2 mask, NaN holes and
+    nodata None, on a raster of several strips (208 - 232 output columns each) and row segments, against the C oracle. """
+    h, w = 290, 1003
+    src, ref = onp.synth_pair(h, w, seed=kernel_shape[0] * 64 + kernel_shape[1], nodata_variant=variant)
+    nodata = np.nan if variant != 'none' else None
+    cfg = dict(model=model, kernel_shape=kernel_shape, find_r2=find_r2, r2_inpaint_thresh=thresh, src_nodata=nodata, ref_nodata=nodata)
+    norm_in = onp.fit_block_norm(src, nodata, ref, nodata) if model == 'gain-blk-offset' else None
+    exp_params, exp_corr, exp_fail = oc.fit_apply(model, src, nodata, ref, nodata, kernel_shape, find_r2, thresh, norm_model=norm_in)
+    params, corr, norm, n_fail = _fit_via_abi(ctx, cfg, src, ref, norm_in=norm_in)
+    assert_close_ulp(params, exp_params, 'params')
+    assert_close_ulp(corr, exp_corr, 'corrected')
+    if model == 'gain-offset' and thresh is not None:
+        assert n_fail == exp_fail
+
+
 @pytest.mark.parametrize('seed', range(120))
 def test_randomized_configurations_vs_oracle(ctx, oc, seed):
     """ A seeded sweep over the configuration space (model, odd kernel shape up to 17 x 17, R2 output, threshold, the

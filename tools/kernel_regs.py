@@ -1,6 +1,6 @@
 """ Register / scratch / LDS figures of every kernel in a HIP object or library, from the code object's metadata notes.
 
-    python tools/kernel_regs.py [homonim_amd/lib/hk_kernels.o] [--spills] [--grep TEXT]
+    python tools/kernel_regs.py [OBJECT ...] [--spills] [--grep TEXT]      (default: homonim_amd/lib/hk_fit_m*.o)
 
 Lists the builds that use scratch memory (private_segment_fixed_size > 0 or vgpr_spill_count > 0) with --spills. """
 import os
@@ -45,8 +45,10 @@ if __name__ == '__main__':
         grep_text = argv[i + 1]
         del argv[i:i + 2]
     args = [a for a in argv if not a.startswith('--')]
-    obj = args[0] if args else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'homonim_amd', 'lib', 'hk_kernels.o')
-    ks = kernels(obj)
+    lib_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'homonim_amd', 'lib')
+    # default: the translation units of the fused kernel (homonim_amd/build.py FIT_TUS)
+    objs = args if args else sorted(os.path.join(lib_dir, f) for f in os.listdir(lib_dir) if f.startswith('hk_fit_m') and f.endswith('.o'))
+    ks = [k for obj in objs for k in kernels(obj)]
     grep = grep_text
     names = demangle([k['name'] for k in ks])
     fit = [(k, n) for k, n in zip(ks, names) if 'fit_apply_kernel' in n]

@@ -28,3 +28,13 @@ run --model gain --kernel 7
 run --model gain --kernel 11
 run --model gain --kernel 15
 run --model gain-blk-offset --kernel 9
+# kernels wider than 15 (round 5: hsum_wide builds)
+run --kernel 17
+run --kernel 21
+run --kernel 31
+run --kernel 17 --nodata 2
+run --kernel 21 --nodata 2
+run --kernel 31 --nodata 2
+run --kernel 31 --nodata 1
+run --model gain --kernel 31
+run --model gain-blk-offset --kernel 31
