@@ -281,14 +281,14 @@ __device__ __forceinline__ void hsum(const T (&V)[PX], T (&H)[PX], int lane, [[m
 // (lane distance, partial length) pair with two shuffles and a select per output each: 5-10 x the time per pixel of 15 wide.)
 struct WideLanes {
     int f;           // F = rw / 4 (wave-uniform)
-    int lf, rf;      // ds_bpermute byte addresses of the lanes F to the left / right of this one
-    int lf1, rf1;    // ... F + 1
+    int lf1, rf;     // ds_bpermute byte addresses of the lane F + 1 to the left / F to the right of this one; the lanes F to the
+                     // left / F + 1 to the right are these + 4 (the instruction's offset field: two address registers, not four;
+                     // where the sum runs past lane 63 the reader is an overlap lane)
 };
 __device__ __forceinline__ WideLanes make_wide_lanes(int rw, int lane) {
     WideLanes w;
     w.f = rw / PX;
-    w.lf = ((lane - w.f) & (WAVE - 1)) << 2, w.rf = ((lane + w.f) & (WAVE - 1)) << 2;
-    w.lf1 = ((lane - w.f - 1) & (WAVE - 1)) << 2, w.rf1 = ((lane + w.f + 1) & (WAVE - 1)) << 2;
+    w.lf1 = ((lane - w.f - 1) & (WAVE - 1)) << 2, w.rf = ((lane + w.f) & (WAVE - 1)) << 2;
     return w;
 }
 // value at a precomputed ds_bpermute address (lanes without a source read some other lane: overlap lanes only, see bperm_from)
@@ -323,8 +323,8 @@ __device__ __forceinline__ void hsum_wide(const T (&V)[PX], T (&H)[PX], const Wi
         T ls[PX + 1], rp[PX + 1];
         static_for<1, PX + 1>([&](auto K) {
             constexpr int k = decltype(K)::value;
-            if constexpr (need_left_at(RV, j, k)) ls[k] = bperm_at(suf[k], j == 2 ? wl.lf : wl.lf1);
-            if constexpr (need_right_at(RV, j, k)) rp[k] = bperm_at(pre[k], j == 2 ? wl.rf : wl.rf1);
+            if constexpr (need_left_at(RV, j, k)) ls[k] = bperm_at(suf[k], j == 2 ? wl.lf1 + 4 : wl.lf1);
+            if constexpr (need_right_at(RV, j, k)) rp[k] = bperm_at(pre[k], j == 2 ? wl.rf : wl.rf + 4);
         });
         if constexpr (lane_full_for_all(RV, j)) {
             common = common + ls[PX];
@@ -670,12 +670,17 @@ constexpr int xch_mask() {
 #ifndef HK_NOSPILL
 #define HK_NOSPILL 1
 #endif
+#ifndef HK_CERT_WIDE_3WAVES
+#define HK_CERT_WIDE_3WAVES 1
+#endif
 template <int MODEL, bool R2, int RW, bool DENSE, int RING, bool CERT_ONLY>
 constexpr int fit_min_waves() {
     if (CERT_ONLY && RW >= 0 && RW <= 3) return 4;
-    if (MODEL == 2 && R2 && !DENSE && (RW < 0 || RW >= 4)) return HK_FIT_MIN_WAVES_WIDE;
+    // (their certificate-only builds fit into 168 registers -- round 5: 17 wide on NaN-nodata rasters 6.46 -> 5.56 ms, 9 - 15 wide
+    // equal -- except kw / 2 mod 4 = 1 .. 3 beyond 15 wide, two registers short and as fast at two waves: profiles/r05_ab_cert_wide_waves.txt)
+    if (MODEL == 2 && R2 && !DENSE && (RW < 0 || RW >= 4) && !(CERT_ONLY && HK_CERT_WIDE_3WAVES && RW >= -1)) return HK_FIT_MIN_WAVES_WIDE;
     if (HK_NOSPILL) {
-        if (RW < 0 && R2) return 2;                                        // wider than 15 with the R2 work (10 - 28 spilled registers at three)
+        if (RW < 0 && R2 && !CERT_ONLY) return 2;                          // wider than 15 with the R2 work (10 - 28 spilled registers at three)
         if (MODEL == 2 && R2 && !DENSE && RW == 3) return 2;               // gain-offset + R2, 7 wide, NaN-aware
         if (MODEL != 2 && R2 && !DENSE && RW >= 4 && RING == 2) return 2;  // gain / gain-blk-offset + R2, 9-15 wide, NaN-aware
         if (RING == 3 && !DENSE && MODEL == 0 && RW >= 5) return 2;        // gain, NaN-aware split ring, 11-15 wide
@@ -936,7 +941,8 @@ fit_apply_kernel(const FitArgs a_in) {
     // RING 0 / 2: the re-loaded leaving row runs one iteration ahead where the registers allow it (not in the general
     // gain-offset kernels, which would spill)
     // (the builds of the kernels wider than 15 with the R2 work run at two waves per SIMD -- fit_min_waves -- and have the registers)
-    constexpr bool PF_OLD = !ring && !sring && (DENSE || MODEL != 2 || (RW < 0 && R2));
+    // ... and the certificate-only builds of those widths, which stay at three waves, do not: 4 - 6 registers short with the row in flight)
+    constexpr bool PF_OLD = !ring && !sring && (DENSE || MODEL != 2 || (RW < 0 && R2)) && !(RW < 0 && CERT_ONLY);
     [[maybe_unused]] RowRaw qo_next;
     if constexpr (PF_OLD) qo_next = load_row<HK_NT_LEAVE>(sp, rp, a.stride, t_first - kh, H, xq);
     // RING 1: the first leaving row is the zero row the ring was initialised with
@@ -1577,7 +1583,7 @@ static hipError_t launch_build(const FitArgs& a, hipStream_t stream) {
 // sets FIT_RETRY_BIT in the band's fail counter and the host re-runs the band with the full build.
 template <int MODEL, bool R2, int RW, bool DENSE, int RING>
 static hipError_t launch_one(const FitArgs& a, hipStream_t stream) {
-    if constexpr (MODEL == 2 && R2 && (RING == 1 || RING == 2) && RW >= 0) {
+    if constexpr (MODEL == 2 && R2 && (RING == 1 || RING == 2)) {
         if (a.cert_only && a.has_thresh && a.fail_count && !a.r2 && !a.offset_in)
             return launch_build<MODEL, R2, RW, DENSE, RING, true>(a, stream);
     }

@@ -176,6 +176,13 @@ def test_kernels_wider_than_15_vs_oracle(ctx, oc, model, find_r2, thresh, kernel
     assert_close_ulp(corr, exp_corr, 'corrected')
     if model == 'gain-offset' and thresh is not None:
         assert n_fail == exp_fail
+    if not find_r2:
+        # the fused path of RasterFuse (corrected block only): with the r2 mask that is the certificate-only build of these widths
+        desc = _hk.make_desc(model, kernel_shape, False, thresh, nodata, nodata)
+        for _ in range(2):   # (the first call of a context may start with the complete build)
+            _, corr_f, _, n_fail_f = ctx.fit_apply(desc, src, ref, 2, want_params=False, want_corr=True, norm_in=norm_in)
+            assert_close_ulp(corr_f, exp_corr, 'corrected (fused)')
+            assert n_fail_f == (exp_fail if thresh is not None else 0)
 
 
 @pytest.mark.parametrize('seed', range(120))
