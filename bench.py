@@ -71,6 +71,11 @@ def parse_args():
     p.add_argument('--cpu-sample', type=int, default=0, help='CPU baseline sample size (square); 0 = auto')
     p.add_argument('--no-other-configs', action='store_true', help='default run: skip the compact records of BASELINE configs 1 / 3 / 4')
     p.add_argument('--no-power-probe', action='store_true', help='default run: skip the package power / clock samples (rocm-smi, ~3 s outside the timed region)')
+    p.add_argument('--as-rank', default=None, metavar='R/N',
+                   help='configs 3 / 4 on ONE GPU: run exactly the shard rank R of an N-rank launch would run, alone (no process group, no '
+                        'peers) -- a projection aid for strong scaling, never a scaling measurement')
+    p.add_argument('--no-projection', action='store_true',
+                   help='configs 3 / 4 at one rank: skip the single-GPU projection (every rank\'s shard of an N = 2 / 4 / 8 launch timed alone)')
     args = p.parse_args()
     preset = CONFIGS[args.config]
     for k, v in preset.items():
@@ -83,7 +88,60 @@ def parse_args():
     if args.warmup is None:
         args.warmup = {1: 5, 2: 5, 3: 2, 4: 1}[args.config]
     args.power_probe = not args.no_power_probe and args.config in (1, 2)
+    if args.as_rank is not None:
+        try:
+            r, n = (int(v) for v in args.as_rank.split('/'))
+            assert 0 <= r < n
+        except Exception:
+            p.error('--as-rank wants R/N with 0 <= R < N')
+        if args.config not in (3, 4) or args.gpus != 1:
+            p.error('--as-rank applies to --config 3 / 4 on one GPU')
+        args.as_rank = (r, n)
     return args
+
+
+class SoloDist:
+    """ The process group of a rank that runs alone (`--as-rank R/N`, the single-GPU projection): nobody to wait for. """
+
+    @staticmethod
+    def barrier():
+        pass
+
+    @staticmethod
+    def max_over_ranks(value):
+        return float(value)
+
+    @staticmethod
+    def backend():
+        return None
+
+
+def timed_steps(ctx, step, steps, warmup):
+    """ seconds per step of `step()` on this GPU alone: warm-up, then `steps` steps between two device synchronisations """
+    for _ in range(warmup):
+        step()
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    ctx.sync()
+    return (time.perf_counter() - t0) / max(1, steps)
+
+
+def project_scaling(t1_ms, shard_ms_of):
+    """ Single-GPU PROJECTION of strong scaling: `shard_ms_of(r, n)` = the time of rank r's shard of an n-rank launch, run alone
+    on this GPU.  If the ranks of a real launch do not disturb each other (separate GPUs and HBM stacks; no data-path
+    collective), an n-rank step takes the slowest shard's time: speedup = t(1) / max_r t_shard(r, n).  What a projection cannot
+    see: host-side contention of n processes (launch threads, PCIe root complexes), clocks of a fully loaded node. """
+    out = {}
+    for n in (2, 4, 8):
+        ms = [shard_ms_of(r, n) for r in range(n)]
+        worst = max(ms)
+        out[str(n)] = dict(shard_ms=[round(v, 4) for v in ms], max_shard_ms=round(worst, 4),
+                           projected_speedup=round(t1_ms / worst, 3) if worst > 0 else None,
+                           projected_efficiency=round(t1_ms / (n * worst), 4) if worst > 0 else None)
+    return dict(kind='PROJECTION from one GPU -- every shard of an N-rank launch timed ALONE on this GPU; not a scaling measurement',
+                t1_ms=round(t1_ms, 4), by_world_size=out)
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -519,6 +577,10 @@ def run_blocks(args, ctx, dist, rank, world):
     # the positions; every rank keeps the whole raster resident (25.8 GB of the 288).
     positions = [bp for bp in all_blocks if bp.band_i == 0]
     mine = shard(positions, rank, world)
+    for bp in positions:
+        win_in, win_out = bp.src_in_block, bp.src_out_block
+        if (win_in.col_off % 4) or ((win_out.col_off - win_in.col_off) % 4):
+            raise SystemExit(f'block origin {win_in.col_off} is not 16-byte aligned: kernel {k}x{k} needs a halo that is a multiple of 4')
     stride = (W + 63) // 64 * 64 + int(os.environ.get('HK_BENCH_ROW_PAD', '0'))   # experiment: rows not a power of two apart
     band_stride = stride * H
     nd = np.nan if args.nodata in (1, 2) else None
@@ -533,47 +595,50 @@ def run_blocks(args, ctx, dist, rank, world):
     # experiment (HK_BENCH_C3_BANDS_PER_JOB): fewer bands per launch, so that a job's statistics pass leaves its planes in the
     # 256 MB Infinity Cache for its fit (a 4104 x 4104 in-block is 135 MB of src + ref per band)
     bpj = int(os.environ.get('HK_BENCH_C3_BANDS_PER_JOB', str(B)))
-    jobs = []
-    for i, bp in enumerate(mine):
-        win_in, win_out = bp.src_in_block, bp.src_out_block
-        if (win_in.col_off % 4) or ((win_out.col_off - win_in.col_off) % 4):
-            raise SystemExit(f'block origin {win_in.col_off} is not 16-byte aligned: kernel {k}x{k} needs a halo that is a multiple of 4')
-        for b0 in range(0, B, bpj):
-            off = 4 * (b0 * band_stride + win_in.row_off * stride + win_in.col_off)
-            job = _hk.DevJob()
-            job.src, job.ref, job.corr = bufs['src'] + off, bufs['ref'] + off, bufs['corr'] + off
-            job.gain = job.offset = job.r2 = job.fail_count = None
-            job.norm = bufs['norm'] + 16 * (B * i + b0)
-            job.n_bands, job.height, job.width, job.stride, job.band_stride = min(bpj, B - b0), win_in.height, win_in.width, stride, band_stride
-            job.seg_rows, job.stream = args.seg_rows, len(jobs) % n_streams   # the latency-bound statistics of one position overlap another's fit
-            job.out_row0, job.out_col0 = win_out.row_off - win_in.row_off, win_out.col_off - win_in.col_off
-            job.out_rows, job.out_cols = win_out.height, win_out.width
-            jobs.append(job)
 
-    # Batched launches (hk_block_norm_batch_dev / hk_fit_apply_batch_dev): the rank's jobs in `n_batches` groups, each group one
-    # launch per kernel stage on its own stream (0 = one launch per job, spread over the streams)
-    n_batches = min(int(os.environ.get('HK_BENCH_BATCHES', str(args.batches))), len(jobs))
-    batches = []
-    if n_batches > 0:
-        per = (len(jobs) + n_batches - 1) // n_batches
-        for g in range(n_batches):
-            group = jobs[g * per:(g + 1) * per]
-            for job in group:
-                job.stream = g % n_streams
-            if group:
-                batches.append((ctx.job_array(group), group[0].norm))
+    def make_step(my_positions, norm_buf):
+        """ the jobs of a rank that holds `my_positions` and the function that queues one step of them -> (step, jobs, batches) """
+        jobs = []
+        for i, bp in enumerate(my_positions):
+            win_in, win_out = bp.src_in_block, bp.src_out_block
+            for b0 in range(0, B, bpj):
+                off = 4 * (b0 * band_stride + win_in.row_off * stride + win_in.col_off)
+                job = _hk.DevJob()
+                job.src, job.ref, job.corr = bufs['src'] + off, bufs['ref'] + off, bufs['corr'] + off
+                job.gain = job.offset = job.r2 = job.fail_count = None
+                job.norm = norm_buf + 16 * (B * i + b0)
+                job.n_bands, job.height, job.width, job.stride, job.band_stride = min(bpj, B - b0), win_in.height, win_in.width, stride, band_stride
+                job.seg_rows, job.stream = args.seg_rows, len(jobs) % n_streams   # the latency-bound statistics of one position overlap another's fit
+                job.out_row0, job.out_col0 = win_out.row_off - win_in.row_off, win_out.col_off - win_in.col_off
+                job.out_rows, job.out_cols = win_out.height, win_out.width
+                jobs.append(job)
+        # Batched launches (hk_block_norm_batch_dev / hk_fit_apply_batch_dev): the rank's jobs in `n_batches` groups, each group one
+        # launch per kernel stage on its own stream (0 = one launch per job, spread over the streams)
+        n_batches = min(int(os.environ.get('HK_BENCH_BATCHES', str(args.batches))), len(jobs))
+        batches = []
+        if n_batches > 0:
+            per = (len(jobs) + n_batches - 1) // n_batches
+            for g in range(n_batches):
+                group = jobs[g * per:(g + 1) * per]
+                for job in group:
+                    job.stream = g % n_streams
+                if group:
+                    batches.append((ctx.job_array(group), group[0].norm))
 
-    def step():
-        if batches:
-            for arr, norm0 in batches:
+        def step():
+            if batches:
+                for arr, norm0 in batches:
+                    if args.model == 'gain-blk-offset':
+                        ctx.block_norm_batch_dev(desc, arr, norm0)
+                    ctx.fit_apply_batch_dev(desc, arr)
+                return
+            for job in jobs:
                 if args.model == 'gain-blk-offset':
-                    ctx.block_norm_batch_dev(desc, arr, norm0)
-                ctx.fit_apply_batch_dev(desc, arr)
-            return
-        for job in jobs:
-            if args.model == 'gain-blk-offset':
-                ctx.block_norm_dev(desc, job, job.norm)
-            ctx.fit_apply_dev(desc, job)
+                    ctx.block_norm_dev(desc, job, job.norm)
+                ctx.fit_apply_dev(desc, job)
+        return step, jobs, batches
+
+    step, jobs, batches = make_step(mine, bufs['norm'])
 
     for _ in range(args.warmup):
         step()
@@ -600,6 +665,21 @@ def run_blocks(args, ctx, dist, rank, world):
         parity = spot_check(ctx, args.model, k, None, args.nodata, bufs['src'], bufs['ref'], bufs['corr'], stride, H, W, y0, x0,
                             256, 1000, nm[0], 0)
 
+    projection = None
+    if world == 1 and not args.no_projection and args.as_rank is None:
+        # what rank r of an n-rank launch would run, alone on this GPU (tools: bench.py --config 3 --as-rank R/N)
+        pnorm = ctx.dev_alloc(16 * B * len(positions))
+        psteps = max(2, min(args.steps, 4))
+
+        def shard_ms(r, n):
+            sub = shard(positions, r, n)
+            if not sub:
+                return 0.0
+            st, _, _ = make_step(sub, pnorm)
+            return timed_steps(ctx, st, psteps, 1) * 1e3
+        projection = project_scaling(elapsed / args.steps * 1e3, shard_ms)
+        ctx.dev_free(pnorm)
+
     e2e = None
     if not args.no_end_to_end:
         my_bands = shard(list(range(B)), rank, world, contiguous=True)  # host rasters of this rank's bands only
@@ -620,7 +700,7 @@ def run_blocks(args, ctx, dist, rank, world):
         roofline=dict(achieved_bytes=ALGO_BYTES_PER_PX * my_px, avg_launch_ms=elapsed / args.steps * 1e3, traffic=None, traffic_source=None,
                       copy_gbps=copy_med, copy_gbps_best=copy_best,
                       kernel=f'one step of this rank: {len(mine)} x (block statistics + hk::fit_apply_kernel over {B} bands), wall time on {n_streams} streams'),
-        parity=parity, end_to_end=e2e)
+        parity=parity, end_to_end=e2e, projection=projection)
 
 
 def end_to_end_blocks(args, ctx, dist, bufs, nb, b0, stride, band_stride):
@@ -708,55 +788,62 @@ def run_tiles(args, ctx, dist, rank, world):
         d0 = tiles[0][0]
         copy_med, copy_best = probe_copy(ctx, d0['src'], d0['ref'], d0['corr'], tile_bytes)
 
-    # Batched launches: the rank's tiles in `n_batches` groups, each one launch per kernel stage on its own stream
-    n_batches = min(int(os.environ.get('HK_BENCH_BATCHES', str(args.batches))), len(tiles))
-    batches = []
-    if n_batches > 0:
-        per = (len(tiles) + n_batches - 1) // n_batches
-        for g in range(n_batches):
-            group = tiles[g * per:(g + 1) * per]
-            for d, job, counts, ev in group:
-                job.stream = g % n_streams
-            if group:
-                batches.append((ctx.job_array([t[1] for t in group]), group, ctx.pinned_empty((B * len(group),), np.uint64), ctx.event()))
+    def make_step(my_tiles):
+        """ the function that queues one step of a rank holding `my_tiles` (streams dealt within the rank) -> (step, batches) """
+        for j, (d, job, counts, ev) in enumerate(my_tiles):
+            job.stream = j % n_streams
+        # Batched launches: the rank's tiles in `n_batches` groups, each one launch per kernel stage on its own stream
+        n_batches = min(int(os.environ.get('HK_BENCH_BATCHES', str(args.batches))), len(my_tiles))
+        batches = []
+        if n_batches > 0:
+            per = (len(my_tiles) + n_batches - 1) // n_batches
+            for g in range(n_batches):
+                group = my_tiles[g * per:(g + 1) * per]
+                for d, job, counts, ev in group:
+                    job.stream = g % n_streams
+                if group:
+                    batches.append((ctx.job_array([t[1] for t in group]), group, ctx.pinned_empty((B * len(group),), np.uint64), ctx.event()))
 
-    def step_batched():
-        n_fail = 0
-        for arr, group, counts_all, ev in batches:
-            if args.model == 'gain-blk-offset':
-                ctx.block_norm_batch_dev(desc, arr, group[0][0]['norm'])
-            ctx.fit_apply_batch_dev(desc, arr)
-            if thresh is not None:
-                ctx.fail_counts_batch_async(arr, counts_all, ev)
-        if thresh is not None:
+        def step_batched():
+            n_fail = 0
             for arr, group, counts_all, ev in batches:
-                ctx.event_sync(ev)
-                c_all = counts_all.copy()
-                if ctx.counts_pending(c_all):
-                    for i, (d, job, counts, _) in enumerate(group):
-                        c = c_all[B * i:B * (i + 1)]
-                        if ctx.counts_pending(c):
-                            n_fail += ctx.inpaint_dev_counts(desc, job, c)
-        return n_fail
-
-    def step():
-        """ every tile's fused launch on its stream, then the host's look at the r2-mask counters of all of them """
-        if batches:
-            return step_batched()
-        n_fail = 0
-        for d, job, counts, ev in tiles:
-            if args.model == 'gain-blk-offset':
-                ctx.block_norm_dev(desc, job, d['norm'])
-            ctx.fit_apply_dev(desc, job)
+                if args.model == 'gain-blk-offset':
+                    ctx.block_norm_batch_dev(desc, arr, group[0][0]['norm'])
+                ctx.fit_apply_batch_dev(desc, arr)
+                if thresh is not None:
+                    ctx.fail_counts_batch_async(arr, counts_all, ev)
             if thresh is not None:
-                ctx.fail_counts_async(job, counts, ev)
-        if thresh is not None:
-            for d, job, counts, ev in tiles:
-                ctx.event_sync(ev)
-                c = counts.copy()
-                if ctx.counts_pending(c):
-                    n_fail += ctx.inpaint_dev_counts(desc, job, c)
-        return n_fail
+                for arr, group, counts_all, ev in batches:
+                    ctx.event_sync(ev)
+                    c_all = counts_all.copy()
+                    if ctx.counts_pending(c_all):
+                        for i, (d, job, counts, _) in enumerate(group):
+                            c = c_all[B * i:B * (i + 1)]
+                            if ctx.counts_pending(c):
+                                n_fail += ctx.inpaint_dev_counts(desc, job, c)
+            return n_fail
+
+        def step():
+            """ every tile's fused launch on its stream, then the host's look at the r2-mask counters of all of them """
+            if batches:
+                return step_batched()
+            n_fail = 0
+            for d, job, counts, ev in my_tiles:
+                if args.model == 'gain-blk-offset':
+                    ctx.block_norm_dev(desc, job, d['norm'])
+                ctx.fit_apply_dev(desc, job)
+                if thresh is not None:
+                    ctx.fail_counts_async(job, counts, ev)
+            if thresh is not None:
+                for d, job, counts, ev in my_tiles:
+                    ctx.event_sync(ev)
+                    c = counts.copy()
+                    if ctx.counts_pending(c):
+                        n_fail += ctx.inpaint_dev_counts(desc, job, c)
+            return n_fail
+        return step, batches
+
+    step, batches = make_step(tiles)
 
     for _ in range(args.warmup):
         step()
@@ -776,6 +863,24 @@ def run_tiles(args, ctx, dist, rank, world):
         d = tiles[0][0]
         parity = spot_check(ctx, args.model, k, thresh, args.nodata, d['src'], d['ref'], d['corr'], stride, n, n, n // 3, 1024,
                             min(n, 384), min(n - 1024, 1200), None, n_fail)
+    projection = None
+    if world == 1 and not args.no_projection and args.as_rank is None and tiles:
+        # what rank r of an n-rank launch would run, alone on this GPU (tools: bench.py --config 4 --as-rank R/N)
+        psteps = max(2, min(args.steps, 4))
+
+        def shard_ms(r, n):
+            sub = [tiles[j] for j in shard(list(range(T)), r, n, contiguous=True)]
+            if not sub:
+                return 0.0
+            st, sub_batches = make_step(sub)
+            ms = timed_steps(ctx, st, psteps, 1) * 1e3
+            for arr, group, counts_all, ev in sub_batches:
+                ctx.event_destroy(ev)
+            return ms
+        projection = project_scaling(elapsed / args.steps * 1e3, shard_ms)
+        for j, (d, job, counts, ev) in enumerate(tiles):
+            job.stream = j % n_streams
+
     e2e = None
     if not args.no_end_to_end:
         e2e = end_to_end_tiles(args, ctx, dist, tiles, stride, band_stride, thresh, nd)
@@ -799,7 +904,7 @@ def run_tiles(args, ctx, dist, rank, world):
         roofline=dict(achieved_bytes=ALGO_BYTES_PER_PX * my_px, avg_launch_ms=elapsed / args.steps * 1e3, traffic=None, traffic_source=None,
                       copy_gbps=copy_med, copy_gbps_best=copy_best,
                       kernel=f'one step of this rank: {len(mine)} x hk::fit_apply_kernel on {n_streams} streams, wall time'),
-        parity=parity, end_to_end=e2e)
+        parity=parity, end_to_end=e2e, projection=projection)
 
 
 def end_to_end_tiles(args, ctx, dist, tiles, stride, band_stride, thresh, nd):
@@ -860,14 +965,13 @@ def launch_ranks(n: int) -> int:
     exit code.  The shape of homonim/fuse.py:394-408: one call fans the work out over a pool of workers. """
     import socket
     import subprocess
-    if os.environ.get('HK_NO_FIRST_PROCESS_PROBE') != '1':
-        try:   # a child is the lease's first GPU process (see main); this launcher itself makes no GPU call
-            from harness import first_process
-            probe = first_process.run()
-            if probe['rc'] != 0:
-                sys.stderr.write(f"bench.py: THE FIRST GPU PROCESS OF THIS RUN DIED OR FAILED (rc {probe['rc']}):\n{probe['output']}\n")
-        except Exception as ex:
-            sys.stderr.write(f'bench.py: first-process probe not run: {ex}\n')
+    probe_failed = False
+    try:   # HK_FIRST_PROCESS_PROBE=1: a child is the lease's first GPU process (see main); this launcher itself makes no GPU call
+        from harness import first_process
+        probe = first_process.gate()
+        probe_failed = bool(probe and probe['fatal'])
+    except Exception as ex:
+        sys.stderr.write(f'bench.py: first-process probe not run: {ex}\n')
     port = os.environ.get('MASTER_PORT')
     if port is None:
         with socket.socket() as sk:
@@ -893,7 +997,7 @@ def launch_ranks(n: int) -> int:
                 for q in pending:   # a rank that lost its peers would wait in a collective for ever
                     procs[q].terminate()
         time.sleep(0.05)
-    return worst
+    return worst or (3 if probe_failed else 0)   # a process of this run died: the run fails, whatever the ranks printed
 
 
 def main():
@@ -912,20 +1016,21 @@ def main():
         abort_trace.install()
     except Exception:
         pass
-    # single-process runs: a child is the lease's first GPU process (harness/first_process.py; round 3's aborts only ever hit
-    # first processes).  Before this process touches the GPU; reported, never fatal.  (Ranks of a launch: the launcher did it.)
+    # HK_FIRST_PROCESS_PROBE=1 (off by default since round 5): a child is the lease's first GPU process (harness/first_process.py;
+    # round 3's aborts only ever hit first processes).  If it dies, this run prints its line and then exits 3: a green run
+    # means no process died.  (Ranks of a launch: the launcher did it.)
     first_probe = None
-    if env_world is None and os.environ.get('HK_NO_FIRST_PROCESS_PROBE') != '1':
+    if env_world is None:
         try:
             from harness import first_process
-            first_probe = first_process.run()
-            if first_probe['rc'] != 0:
-                sys.stderr.write(f"bench.py: THE FIRST GPU PROCESS OF THIS RUN DIED OR FAILED (rc {first_probe['rc']}):\n{first_probe['output']}\n")
-            first_probe = {'rc': first_probe['rc'], 'seconds': first_probe['seconds']}
+            first_probe = first_process.gate()
         except Exception as ex:
             sys.stderr.write(f'bench.py: first-process probe not run: {ex}\n')
-    from homonim_amd import _hk, dist
+    from homonim_amd import _hk, dist, topology
     rank, world, local_rank = dist.init()  # torch.distributed (nccl = RCCL) only when WORLD_SIZE > 1
+    # Host placement: this rank's threads onto the cores of its GPU's NUMA node, BEFORE anything page-locked is allocated
+    # (the staging rings of the context, the host rasters of `end_to_end`): SURVEY.md 8(e) "NUMA-local pinned buffers"
+    placement = topology.bind_to_device(local_rank % max(1, _hk.device_count()))
     # one GPU per rank on a full node.  configs[3] deals its block positions to 8 streams: a position's statistics are a chain of
     # small latency-bound kernels, and with 4 streams the GPU still idled between them (12.1 -> 11.5 ms per step)
     n_streams = int(os.environ.get('HK_BENCH_STREAMS', '8' if args.config == 3 else '4'))
@@ -954,7 +1059,15 @@ def main():
             sys.stderr.write(f'bench.py: rank {rank}: the library\'s RCCL communicator is not usable: {rccl_error}\n')
 
     runner = {1: run_resident, 2: run_resident, 3: run_blocks, 4: run_tiles}[args.config]
-    res = runner(args, ctx, dist, rank, world)
+    if args.as_rank is not None:   # the shard of rank R of N, alone on this GPU: no group, no peers
+        res = runner(args, ctx, SoloDist, args.as_rank[0], args.as_rank[1])
+        my_px = res['roofline']['achieved_bytes'] / ALGO_BYTES_PER_PX
+        res['value'] = my_px * args.steps / res['elapsed'] / 1e6   # what THIS GPU did, not a whole-job rate
+        res['scaling'] = f'none: rank {args.as_rank[0]} of {args.as_rank[1]} run alone (projection aid)'
+        res['config']['as_rank'] = dict(rank=args.as_rank[0], of=args.as_rank[1], shard_ms=round(res['elapsed'] / args.steps * 1e3, 4),
+                                        note='one rank\'s shard of a strong-scaling launch on one GPU: not a scaling measurement')
+    else:
+        res = runner(args, ctx, dist, rank, world)
     # Through RasterFuse every raster has nodata = nan (raster_array.py:172-188), i.e. the product path runs the GENERAL
     # kernels; `value` is quoted on BASELINE.json's plain synthetic rasters.  The default run therefore adds a second,
     # shorter measurement of the same configuration on rasters with a NaN frame (reported beside, never as `value`).
@@ -1010,6 +1123,8 @@ def main():
             }
             if r3.get('end_to_end') is not None:   # PCIe-inclusive, host rasters: never `value`
                 other[str(cfg)]['end_to_end'] = r3['end_to_end']
+            if r3.get('projection') is not None:   # every rank's shard of an N-rank launch alone on this GPU: a projection
+                other[str(cfg)]['projected_scaling_single_gpu'] = r3['projection']
 
     if rank == 0:
         cpu = None
@@ -1041,6 +1156,9 @@ def main():
         }
         if res.get('end_to_end') is not None:
             out['end_to_end'] = res['end_to_end']
+        if res.get('projection') is not None:
+            out['projected_scaling_single_gpu'] = res['projection']
+        out['host_placement'] = topology.summary(placement)   # of rank 0; every rank binds to its own GPU's node
         if nan_variant is not None:
             out['nodata_nan_variant'] = nan_variant
         if other is not None:
@@ -1058,6 +1176,8 @@ def main():
 
     ctx.close()
     dist.finalize()
+    if first_probe is not None and first_probe['fatal']:
+        sys.exit(3)
 
 
 if __name__ == '__main__':

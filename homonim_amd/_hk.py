@@ -71,7 +71,7 @@ _f32p, _f64p, _u64p = _P(C.c_float), _P(C.c_double), _P(C.c_uint64)
 # name -> (restype, argtypes); kept in one table so tests can check every symbol of the header is exported
 ABI_VERSION = 4   # HK_ABI_VERSION of the include/homonim_hk.h these mirrors were written against
 # entry points declared in include/homonim_hk_devtools.h (measurement / test aids), the rest in include/homonim_hk.h
-DEVTOOLS = ('hk_synth_fill_dev', 'hk_stream_probe_dev', 'hk_debug_stage_stamps', 'hk_r2_certificate_constants')
+DEVTOOLS = ('hk_synth_fill_dev', 'hk_stream_probe_dev', 'hk_debug_stage_stamps', 'hk_r2_certificate_constants', 'hk_debug_staging_counters')
 
 SIGNATURES = {
     'hk_abi_version': (C.c_int, []),
@@ -88,6 +88,7 @@ SIGNATURES = {
     'hk_counts_pending': (C.c_int, [_P(C.c_uint64), C.c_int32]),
     'hk_last_error': (C.c_char_p, []),
     'hk_device_count': (C.c_int, [_P(C.c_int)]),
+    'hk_device_pci_bus_id': (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
     'hk_ctx_create': (C.c_int, [C.c_int, C.c_int, _P(C.c_void_p)]),
     'hk_ctx_destroy': (C.c_int, [C.c_void_p]),
     'hk_ctx_sync': (C.c_int, [C.c_void_p]),
@@ -141,6 +142,7 @@ SIGNATURES = {
     'hk_stream_sync': (C.c_int, [C.c_void_p, C.c_int32]),
     'hk_selftest': (C.c_int, [C.c_void_p]),
     'hk_debug_stage_stamps': (C.c_int, [C.c_void_p, _P(C.c_uint64), C.c_int32]),
+    'hk_debug_staging_counters': (C.c_int, [_P(C.c_uint64), C.c_int32]),
 }  # yapf: disable
 
 COMM_ID_BYTES = 128   # HK_COMM_ID_BYTES = sizeof(ncclUniqueId)
@@ -754,3 +756,18 @@ def device_count() -> int:
     n = C.c_int(0)
     load_library().hk_device_count(C.byref(n))
     return int(n.value)
+
+
+def staging_counters(reset: bool = False):
+    """ (copies queued straight from / to page-locked caller arrays, chunks through the pinned staging ring) since the process
+    started or the last reset (hk_debug_staging_counters; test aid). """
+    out = (C.c_uint64 * 2)()
+    _check(load_library().hk_debug_staging_counters(out, 1 if reset else 0))
+    return int(out[0]), int(out[1])
+
+
+def device_pci_bus_id(device: int) -> str:
+    """ PCI bus address of HIP device ``device`` as sysfs spells it, e.g. '0000:c1:00.0' (homonim_amd/topology.py). """
+    buf = C.create_string_buffer(32)
+    _check(load_library().hk_device_pci_bus_id(int(device), buf, 32))
+    return buf.value.decode()

@@ -9,12 +9,14 @@
 #include <algorithm>
 #include <atomic>
 #include <cfloat>
+#include <cctype>
 #include <cmath>
 #include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -252,6 +254,12 @@ struct Slot {
     size_t norm_ws_bytes = 0;
     void* aux = nullptr;      // on-demand planes + tables of the in-painting branch
     size_t aux_bytes = 0;
+    // ... and a second set with a stream of its own: the bands of a job that need in-painting alternate between the two, so that
+    // one band's memory-bound closing pass runs beside the next band's latency-bound search (hk_inpaint_dev_counts)
+    void* aux2 = nullptr;
+    size_t aux2_bytes = 0;
+    hipStream_t stream2 = nullptr;
+    hipEvent_t lane_ev[2] = {nullptr, nullptr};  // [0] main stream -> second lane, [1] second lane -> main stream
     // exchange buffer of hk_block_norm_split_comm_dev on THIS stream: sequences queued on different streams run concurrently on
     // the device (comm_mu only orders their queuing), so they must not share one
     double* comm_xchg = nullptr;
@@ -335,6 +343,8 @@ struct hk_event {
 
 namespace {
 
+void stage_abandon(Slot& s);  // (host staging, below)
+
 struct SlotLease {
     hk_ctx* ctx;
     int idx;
@@ -367,6 +377,8 @@ struct SlotLease {
         if (drain) (void)hipStreamSynchronize(ctx->slots[idx].stream);
     }
     ~SlotLease() {
+        // a call that ends through stage_finish() leaves no chunk queued; one that returned an error earlier does -- see stage_abandon
+        stage_abandon(ctx->slots[idx]);
         {
             std::lock_guard<std::mutex> lk(ctx->mu);
             ctx->slots[idx].busy = false;
@@ -456,14 +468,60 @@ int ensure_dev(Slot& s, size_t bytes) {
 // the fly, rect copies into unaligned few-byte rows of a numpy buffer -- are not part of the product.
 constexpr size_t STAGE_CHUNK_MIN = 8u << 20;
 
-// is [p, p + bytes) page-locked host memory known to the runtime?
-bool host_is_pinned(const void* p, size_t bytes) {
-    hipPointerAttribute_t attr;
-    const char* c = static_cast<const char*>(p);
-    bool ok = hipPointerGetAttributes(&attr, c) == hipSuccess && attr.type == hipMemoryTypeHost;
-    if (ok && bytes > 1) ok = hipPointerGetAttributes(&attr, c + bytes - 1) == hipSuccess && attr.type == hipMemoryTypeHost;
-    (void)hipGetLastError();  // pageable memory: the query itself fails
-    return ok;
+// Page-locked host ranges this library made (hk_host_alloc, hk_host_register), process-wide: base -> bytes.  A caller array
+// is handed to the runtime's copy engines directly only if ONE of these ranges holds all of it -- every row, every byte between
+// the first and the last.  (Rounds 3-4 asked the runtime about the array's first and last byte: a strided view whose ends lie in
+// two different registered ranges with pageable memory between them passed, and the runtime pinned the gap on the fly -- the
+// path of profiles/r04_abort_caught.txt.)  Memory page-locked by other means is unknown here and goes through the staging ring.
+struct PinnedRanges {
+    std::mutex mu;
+    std::map<uintptr_t, size_t> r;
+    void add(const void* p, size_t n) {
+        std::lock_guard<std::mutex> lk(mu);
+        r[reinterpret_cast<uintptr_t>(p)] = n;
+    }
+    void remove(const void* p) {
+        std::lock_guard<std::mutex> lk(mu);
+        r.erase(reinterpret_cast<uintptr_t>(p));
+    }
+    bool covers(const void* p, size_t n) {
+        const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = r.upper_bound(a);
+        if (it == r.begin()) return false;
+        --it;
+        return a >= it->first && n <= it->second && a - it->first <= it->second - n;
+    }
+};
+PinnedRanges& pinned_ranges() {
+    static PinnedRanges g;
+    return g;
+}
+// copies handed to the runtime straight from / to caller memory, and chunks that went through the staging ring (hk_debug_staging_counters)
+std::atomic<unsigned long long> g_direct_copies{0}, g_staged_chunks{0};
+
+// is [p, p + bytes) inside one page-locked range of this library?
+bool host_is_pinned(const void* p, size_t bytes) { return bytes > 0 && pinned_ranges().covers(p, bytes); }
+
+// HK_ASSERT_PINNED=1 (the test-suite sets it): before a caller pointer goes to hipMemcpy*Async directly, ask the runtime about
+// EVERY page of every row; a page it does not know as host memory fails the call instead of being pinned on the fly.
+bool assert_pinned_on() {
+    static const bool on = [] { const char* e = getenv("HK_ASSERT_PINNED"); return e && atoi(e) != 0; }();
+    return on;
+}
+int check_rows_pinned(const void* p, size_t pitch, size_t row_bytes, size_t rows) {
+    const char* base = static_cast<const char*>(p);
+    for (size_t r = 0; r < rows; ++r) {
+        const uintptr_t a0 = reinterpret_cast<uintptr_t>(base + r * pitch), a1 = a0 + row_bytes - 1;
+        for (uintptr_t pg = a0 & ~(uintptr_t)4095; pg <= a1; pg += 4096) {
+            hipPointerAttribute_t attr;
+            const void* q = reinterpret_cast<const void*>(pg < a0 ? a0 : pg);
+            const bool ok = hipPointerGetAttributes(&attr, q) == hipSuccess && attr.type == hipMemoryTypeHost;
+            (void)hipGetLastError();
+            if (!ok) return fail(HK_ERR_ARG, "HK_ASSERT_PINNED: host address %p (row %zu) is not page-locked but was about to be copied directly", q, r);
+        }
+    }
+    return HK_OK;
 }
 
 int ensure_pin(Slot& s) {
@@ -527,6 +585,7 @@ int ensure_stage(Slot& s, size_t min_chunk) {
 }
 
 int stage_take(Slot& s, int* chunk) {
+    g_staged_chunks.fetch_add(1, std::memory_order_relaxed);
     const int i = s.stage_next;
     s.stage_next = (s.stage_next + 1) % Slot::STAGE_N;
     const int rc = stage_settle(s, i);
@@ -542,6 +601,11 @@ int stage_h2d(Slot& s, void* d_dst, size_t d_pitch, const void* h_src, size_t h_
     if (rows == 1) h_pitch = d_pitch = row_bytes;
     const bool flat = h_pitch == row_bytes && d_pitch == row_bytes;
     if (host_is_pinned(h_src, (rows - 1) * h_pitch + row_bytes)) {
+        if (assert_pinned_on()) {
+            const int rc = check_rows_pinned(h_src, h_pitch, row_bytes, rows);
+            if (rc) return rc;
+        }
+        g_direct_copies.fetch_add(1, std::memory_order_relaxed);
         if (flat) HK_HIP(hipMemcpyAsync(d_dst, h_src, rows * row_bytes, hipMemcpyHostToDevice, s.stream));
         else HK_HIP(hipMemcpy2DAsync(d_dst, d_pitch, h_src, h_pitch, row_bytes, rows, hipMemcpyHostToDevice, s.stream));
         return HK_OK;
@@ -586,6 +650,11 @@ int stage_d2h(Slot& s, void* h_dst, size_t h_pitch, const void* d_src, size_t d_
     if (rows == 1) h_pitch = d_pitch = row_bytes;
     const bool flat = h_pitch == row_bytes && d_pitch == row_bytes;
     if (host_is_pinned(h_dst, (rows - 1) * h_pitch + row_bytes)) {
+        if (assert_pinned_on()) {
+            const int rc = check_rows_pinned(h_dst, h_pitch, row_bytes, rows);
+            if (rc) return rc;
+        }
+        g_direct_copies.fetch_add(1, std::memory_order_relaxed);
         if (flat) HK_HIP(hipMemcpyAsync(h_dst, d_src, rows * row_bytes, hipMemcpyDeviceToHost, s.stream));
         else HK_HIP(hipMemcpy2DAsync(h_dst, h_pitch, d_src, d_pitch, row_bytes, rows, hipMemcpyDeviceToHost, s.stream));
         return HK_OK;
@@ -623,6 +692,18 @@ int stage_d2h(Slot& s, void* h_dst, size_t h_pitch, const void* d_src, size_t d_
     return HK_OK;
 }
 
+// A host-pointer call is ending WITHOUT stage_finish (an error return somewhere behind a stage_d2h): its queued chunks still name
+// the caller's output arrays, which the caller may free as soon as it sees the error -- the next call on this slot must not unpack
+// into them.  Let the copies that were queued complete (they write the ring, never the caller) and forget them.
+void stage_abandon(Slot& s) {
+    bool any = false;
+    for (int i = 0; i < Slot::STAGE_N; ++i) any |= s.stage_state[i] != 0;
+    if (!any) return;
+    if (s.stream) (void)hipStreamSynchronize(s.stream);
+    (void)hipGetLastError();
+    for (int i = 0; i < Slot::STAGE_N; ++i) s.stage_state[i] = 0;
+}
+
 // end of a host-pointer call: everything queued on the slot's stream has run and every output array is final
 int stage_finish(Slot& s) {
     const int rc = stage_drain(s);
@@ -636,6 +717,11 @@ void slot_release(Slot& s) {
     if (s.dev) (void)dev_free(s.dev);
     if (s.norm_ws) (void)dev_free(s.norm_ws);
     if (s.aux) (void)dev_free(s.aux);
+    if (s.stream2) (void)hipStreamSynchronize(s.stream2);
+    if (s.aux2) (void)dev_free(s.aux2);
+    for (auto& ev : s.lane_ev)
+        if (ev) (void)hipEventDestroy(ev);
+    if (s.stream2) (void)hipStreamDestroy(s.stream2);
     if (s.comm_xchg) (void)dev_free(s.comm_xchg);
     if (s.fail_host) (void)hipHostFree(s.fail_host);
     if (s.stage) (void)hipHostFree(s.stage);
@@ -847,17 +933,27 @@ void fill_grid(hk::FitArgs& a, int seg_rows) {
 // pixels from the passing ones (restated GDALFillNodata) and run the fit again with `offset_in`, which recomputes their
 // gains and re-applies.  `a` is the first pass's argument block (n_bands == 1).
 // scratch of the in-painting branch: [filled | gain | offset | r2 | column tables]
-static int ensure_inpaint_scratch(Slot& sl, size_t plane, int height, long long stride) {
+static int ensure_inpaint_scratch(Slot& sl, size_t plane, int height, long long stride, int lane = 0) {
     const size_t need = 4 * plane + hk::inpaint_workspace_bytes(height, stride);
-    if (!fits(sl.aux_bytes, need)) {
-        if (sl.aux) {
-            HK_HIP(hipStreamSynchronize(sl.stream));
-            HK_HIP(dev_free(sl.aux));
+    void*& aux = lane ? sl.aux2 : sl.aux;
+    size_t& aux_bytes = lane ? sl.aux2_bytes : sl.aux_bytes;
+    if (!fits(aux_bytes, need)) {
+        if (aux) {
+            HK_HIP(hipStreamSynchronize(lane ? sl.stream2 : sl.stream));
+            HK_HIP(dev_free(aux));
         }
-        sl.aux = nullptr, sl.aux_bytes = 0;
-        if (dev_malloc(&sl.aux, need) != hipSuccess) return fail(HK_ERR_NOMEM, "hipMalloc(%zu) failed", need);
-        sl.aux_bytes = need;
+        aux = nullptr, aux_bytes = 0;
+        if (dev_malloc(&aux, need) != hipSuccess) return fail(HK_ERR_NOMEM, "hipMalloc(%zu) failed", need);
+        aux_bytes = need;
     }
+    return HK_OK;
+}
+
+// the second lane of the in-painting branch (Slot::stream2 / aux2), made on first use
+static int ensure_inpaint_lane(Slot& sl) {
+    if (!sl.stream2) HK_HIP(hipStreamCreateWithFlags(&sl.stream2, hipStreamNonBlocking));
+    for (auto& ev : sl.lane_ev)
+        if (!ev) HK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     return HK_OK;
 }
 
@@ -871,14 +967,16 @@ static bool cert_only_eligible(const hk::FitArgs& a, const hk_fit_desc* desc) {
 // `n_fail`: the band's r2-mask failure count.  `pre_offset` / `pre_flag` (both or neither): offsets and source flags (r2 > thresh) & (gain > 0) & valid left by the pass
 // that counted the failures (FitArgs::flag) -- the in-painting then starts right away.  `drop_params`: the parameter
 // planes in `a` are scratch, the closing pass need not write them.
+// `lane` 1: on the slot's second stream with its second scratch set (the caller orders the lanes, hk_inpaint_dev_counts)
 static int inpaint_band(Slot& sl, const hk::FitArgs& a, const hk_fit_desc* desc, bool r2, size_t plane,
                         unsigned long long n_fail, bool drop_params = false, const float* pre_offset = nullptr,
-                        const unsigned char* pre_flag = nullptr) {
+                        const unsigned char* pre_flag = nullptr, int lane = 0) {
     {
-        const int rc = ensure_inpaint_scratch(sl, plane, a.height, a.stride);
+        const int rc = ensure_inpaint_scratch(sl, plane, a.height, a.stride, lane);
         if (rc) return rc;
     }
-    char* aux = static_cast<char*>(sl.aux);
+    const hipStream_t stream = lane ? sl.stream2 : sl.stream;
+    char* aux = static_cast<char*>(lane ? sl.aux2 : sl.aux);
     float* filled = reinterpret_cast<float*>(aux);
     const float *pg = a.gain, *po = a.offset, *pr = a.r2;
     const unsigned char* flags = nullptr;
@@ -892,12 +990,12 @@ static int inpaint_band(Slot& sl, const hk::FitArgs& a, const hk_fit_desc* desc,
         b.gain = nullptr, b.r2 = nullptr, b.offset = scratch_off, b.corr = nullptr, b.fail_count = nullptr;
         b.flag = hk::inpaint_flag_plane(aux + 4 * plane, a.height, a.stride);
         b.cert_only = 0;
-        HK_HIP(hk::launch_fit_apply(b, desc->model, r2, sl.stream));
+        HK_HIP(hk::launch_fit_apply(b, desc->model, r2, stream));
         po = scratch_off, flags = b.flag;
     }
     // n_fail (the failing VALID pixels) is a lower bound of the pixels to fill (nodata pixels are filled as well)
     HK_HIP(hk::launch_inpaint_offsets(po, pg, pr, desc->r2_thresh, a.stride, a.height, a.width, aux + 4 * plane, filled,
-                                      sl.stream, flags, n_fail));
+                                      stream, flags, n_fail));
     // closing pass: the failing pixels take the in-painted offsets and recomputed gains (kernel_model.py:370-371).  Which
     // pixels failed is in the flag plane the in-painting just used, so the build WITHOUT the R2 work runs (the R2 plane, if
     // the caller keeps one, was written by the pass that counted and is not changed by the branch)
@@ -909,7 +1007,7 @@ static int inpaint_band(Slot& sl, const hk::FitArgs& a, const hk_fit_desc* desc,
     c.r2 = nullptr;
     c.cert_only = 0;
     if (drop_params) c.gain = c.offset = nullptr;  // nobody reads them after this
-    HK_HIP(hk::launch_fit_apply(c, desc->model, false, sl.stream));
+    HK_HIP(hk::launch_fit_apply(c, desc->model, false, stream));
     return HK_OK;
 }
 
@@ -1156,6 +1254,11 @@ int run_host(hk_ctx* ctx, const hk_fit_desc* desc, const hk_io_desc* io, const v
     if (norm_out && blk)
         HK_HIP(hipMemcpyAsync(sl.pin<double>(Slot::PIN_NORM), d_norm, 2 * sizeof(double), hipMemcpyDeviceToHost, sl.stream));
     if ((rc = stage_out())) return rc;
+    {   // HK_TEST_FAIL_AFTER_D2H=1 (homonim_hk_devtools.h): the call fails HERE, its result copies queued and not yet unpacked --
+        // the state every HIP error between a stage_d2h and stage_finish leaves (tests/test_gpu_staging.py)
+        const char* e = getenv("HK_TEST_FAIL_AFTER_D2H");
+        if (e && atoi(e) != 0) return fail(HK_ERR_HIP, "HK_TEST_FAIL_AFTER_D2H: injected failure behind the result copies");
+    }
     *sl.fail_host = 0;
     if (pending.active) HK_HIP(hipMemcpyAsync(sl.fail_host, d_fail, sizeof(unsigned long long), hipMemcpyDeviceToHost, sl.stream));
     if ((rc = stage_finish(sl))) return rc;
@@ -1193,6 +1296,15 @@ int hk_device_count(int* count) {
         return fail(HK_ERR_NODEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
     }
     *count = n;
+    return HK_OK;
+}
+
+int hk_device_pci_bus_id(int device_id, char* out, int len) {
+    if (!out || len < 13) return fail(HK_ERR_ARG, "bus-id buffer is NULL or shorter than 13 bytes");
+    out[0] = '\0';
+    hipError_t e = hipDeviceGetPCIBusId(out, len, device_id);
+    if (e != hipSuccess) return fail(HK_ERR_NODEVICE, "hipDeviceGetPCIBusId(%d): %s", device_id, hipGetErrorString(e));
+    for (char* c = out; *c; ++c) *c = (char)tolower((unsigned char)*c);   // sysfs spells bus addresses in lower case
     return HK_OK;
 }
 
@@ -1545,11 +1657,13 @@ int hk_host_alloc(hk_ctx* ctx, size_t bytes, void** hptr) {
     HK_ENTER(ctx);
     if (hipHostMalloc(hptr, bytes, hipHostMallocPortable) != hipSuccess)
         return fail(HK_ERR_NOMEM, "hipHostMalloc(%zu) failed", bytes);
+    pinned_ranges().add(*hptr, bytes);
     return HK_OK;
 }
 int hk_host_free(hk_ctx* ctx, void* hptr) {
     // page-locked host memory belongs to no device: `ctx` may be NULL (e.g. the context was destroyed first)
     (void)ctx;
+    pinned_ranges().remove(hptr);
     HK_HIP(hipHostFree(hptr));
     return HK_OK;
 }
@@ -1568,12 +1682,20 @@ int hk_host_register(hk_ctx* ctx, void* hptr, size_t bytes) {
         return fail(HK_ERR_ALREADY, "host memory is page-locked already");
     }
     HK_HIP(e);
+    pinned_ranges().add(hptr, bytes);
     return HK_OK;
 }
 int hk_host_unregister(hk_ctx* ctx, void* hptr) {
     if (!hptr) return fail(HK_ERR_ARG, "NULL argument");
     (void)ctx;  // may be NULL, like hk_host_free
+    pinned_ranges().remove(hptr);
     HK_HIP(hipHostUnregister(hptr));
+    return HK_OK;
+}
+int hk_debug_staging_counters(uint64_t out[2], int32_t reset) {
+    if (!out) return fail(HK_ERR_ARG, "out is NULL");
+    out[0] = g_direct_copies.load(), out[1] = g_staged_chunks.load();
+    if (reset) g_direct_copies.store(0), g_staged_chunks.store(0);
     return HK_OK;
 }
 
@@ -1595,8 +1717,10 @@ int hk_memcpy_h2d(hk_ctx* ctx, void* dst, const void* src, size_t bytes) {
     if (!dst || !src) return fail(HK_ERR_ARG, "NULL pointer argument");
     HK_ENTER(ctx);
     std::lock_guard<std::mutex> lk(ctx->xfer_mu);
-    const int rc = stage_h2d(ctx->xfer, dst, bytes, src, bytes, bytes, 1);
-    return rc ? rc : stage_finish(ctx->xfer);
+    int rc = stage_h2d(ctx->xfer, dst, bytes, src, bytes, bytes, 1);
+    if (!rc) rc = stage_finish(ctx->xfer);
+    if (rc) stage_abandon(ctx->xfer);
+    return rc;
 }
 int hk_memcpy_d2h(hk_ctx* ctx, void* dst, const void* src, size_t bytes) {
     if (!ctx) return fail(HK_ERR_ARG, "ctx is NULL");
@@ -1604,8 +1728,10 @@ int hk_memcpy_d2h(hk_ctx* ctx, void* dst, const void* src, size_t bytes) {
     if (!dst || !src) return fail(HK_ERR_ARG, "NULL pointer argument");
     HK_ENTER(ctx);
     std::lock_guard<std::mutex> lk(ctx->xfer_mu);
-    const int rc = stage_d2h(ctx->xfer, dst, bytes, src, bytes, bytes, 1);
-    return rc ? rc : stage_finish(ctx->xfer);
+    int rc = stage_d2h(ctx->xfer, dst, bytes, src, bytes, bytes, 1);
+    if (!rc) rc = stage_finish(ctx->xfer);
+    if (rc) stage_abandon(ctx->xfer);   // (a second chunk that failed leaves the first one queued with the caller's pointer)
+    return rc;
 }
 int hk_memset(hk_ctx* ctx, void* dst, int value, size_t bytes) {
     if (!ctx) return fail(HK_ERR_ARG, "ctx is NULL");
@@ -1762,9 +1888,26 @@ int hk_inpaint_dev_counts(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job
     const size_t plane = (size_t)job->stride * job->height * sizeof(float);
     unsigned long long total = 0;
     bool retried = false;
+    // Two lanes (round 5): the bands that need the branch alternate between the job's stream and the slot's second stream, each
+    // with a scratch set of its own -- a band's chain is tables -> search (latency-bound) -> closing pass (memory-bound), and the
+    // chains of consecutive bands now overlap instead of running back to back (profiles/r05_inpaint_*.txt).  The second lane
+    // starts behind everything queued on the job's stream so far and the job's stream ends behind the second lane: callers see
+    // one stream as before.  HK_INPAINT_LANES=1: one lane (A/B).
+    static const bool two_lanes = [] { const char* e = getenv("HK_INPAINT_LANES"); return !(e && atoi(e) == 1); }();
+    int n_need = 0;
+    for (int b = 0; b < job->n_bands; ++b) n_need += counts[b] != 0;
+    const bool lanes = two_lanes && n_need > 1;
+    bool lane1_used = false;
+    int k_band = 0;
+    if (lanes) {
+        rc = ensure_inpaint_lane(sl);
+        if (rc) return rc;
+    }
     for (int b = 0; b < job->n_bands; ++b) {
         unsigned long long n_fail = counts[b];
         if (n_fail == 0) continue;
+        // (a band the lighter build sent back is counted again on the job's stream: it stays on the first lane)
+        const int lane = (lanes && (k_band++ & 1) && !(n_fail & hk::FIT_RETRY_BIT)) ? 1 : 0;
         const long long off = (long long)b * job->band_stride;
         hk::FitArgs a;
         memset(&a, 0, sizeof(a));
@@ -1810,8 +1953,17 @@ int hk_inpaint_dev_counts(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job
         }
         total += n_fail;
         if (n_fail == 0) continue;
-        rc = inpaint_band(sl, a, desc, r2, plane, n_fail, false, pre_off, pre_flag);
+        if (lane && !lane1_used) {   // the second lane starts behind the pass that counted (and whatever else the stream holds)
+            HK_HIP(hipEventRecord(sl.lane_ev[0], sl.stream));
+            HK_HIP(hipStreamWaitEvent(sl.stream2, sl.lane_ev[0], 0));
+            lane1_used = true;
+        }
+        rc = inpaint_band(sl, a, desc, r2, plane, n_fail, false, pre_off, pre_flag, lane);
         if (rc) return rc;
+    }
+    if (lane1_used) {   // ... and the job's stream goes on behind it
+        HK_HIP(hipEventRecord(sl.lane_ev[1], sl.stream2));
+        HK_HIP(hipStreamWaitEvent(sl.stream, sl.lane_ev[1], 0));
     }
     if (retried) ctx->cert_only_retried();
     else if (ctx->cert_skip.load(std::memory_order_relaxed) == 0) ctx->cert_only_settled();
@@ -2358,12 +2510,15 @@ int hk_selftest(hk_ctx* ctx) {
     int* d = nullptr;
     HK_HIP(dev_malloc(reinterpret_cast<void**>(&d), sizeof(int)));
     int code = -1;
-    hipError_t e = hipMemset(d, 0, sizeof(int));
-    if (e == hipSuccess) e = hk::launch_selftest(d, ctx->slots[0].stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->slots[0].stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(ctx->slots[0].pin<int>(Slot::PIN_WORD), d, sizeof(int), hipMemcpyDeviceToHost, ctx->slots[0].stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->slots[0].stream);
-    if (e == hipSuccess) code = *ctx->slots[0].pin<int>(Slot::PIN_WORD);
+    // on the transfer slot, one caller at a time: the pooled streams and their pinned words belong to leased / device-job calls
+    // (PIN_WORD of slot 0 is where hk_inpaint_dev_counts reads a band's failure count from)
+    std::lock_guard<std::mutex> lk(ctx->xfer_mu);
+    Slot& xs = ctx->xfer;
+    hipError_t e = hipMemsetAsync(d, 0, sizeof(int), xs.stream);
+    if (e == hipSuccess) e = hk::launch_selftest(d, xs.stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(xs.pin<int>(Slot::PIN_WORD), d, sizeof(int), hipMemcpyDeviceToHost, xs.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(xs.stream);
+    if (e == hipSuccess) code = *xs.pin<int>(Slot::PIN_WORD);
     (void)dev_free(d);  // on every path
     if (e != hipSuccess) return fail(HK_ERR_HIP, "self-test launch failed: %s", hipGetErrorString(e));
     if (code != 0) return fail(HK_ERR_HIP, "cross-lane self-test failed (code 0x%x)", code);

@@ -91,51 +91,87 @@ def init_comm(ctx, id_file: Optional[str] = None) -> Tuple[int, int]:
     else:
         if id_file is None:
             raise RuntimeError('init_comm needs a joined process group (dist.init) or an id file (HOMONIM_AMD_COMM_FILE)')
-        # The file carries a header -- magic, the launch's token (MASTER_PORT / TORCHELASTIC_RUN_ID / HOMONIM_AMD_LAUNCH_ID),
-        # rank 0's clock -- so that a file left behind by another or an earlier launch is not taken for this one's: rank 0
-        # removes whatever is there before it makes the id, the other ranks skip files with a foreign token or older than
-        # STALE_S, and rank 0 removes the file once the communicator stands (ncclCommInitRank returns when every rank has
-        # joined, i.e. has read it).  Use a fresh path per launch where a crashed launch may be restarted within STALE_S.
-        import struct
-        STALE_S = 600.0
-        token = '|'.join(os.environ.get(k, '') for k in ('MASTER_PORT', 'TORCHELASTIC_RUN_ID', 'HOMONIM_AMD_LAUNCH_ID')).encode()[:64]
-        head = struct.Struct('<8s64sd')
-        if rank == 0:
-            try:
-                os.unlink(id_file)
-            except FileNotFoundError:
-                pass
-            uid = _hk.comm_unique_id()
-            tmp = f'{id_file}.tmp{os.getpid()}'
-            with open(tmp, 'wb') as f:
-                f.write(head.pack(b'HKCOMM01', token, time.time()) + uid)
-            os.replace(tmp, id_file)
-        else:
-            t0 = time.time()
-            uid = None
-            while uid is None:
-                try:
-                    with open(id_file, 'rb') as f:
-                        blob = f.read()
-                    if len(blob) > head.size:
-                        magic, tok, stamp = head.unpack(blob[:head.size])
-                        if magic == b'HKCOMM01' and tok.rstrip(b'\0') == token and stamp >= t0 - STALE_S:
-                            uid = blob[head.size:]
-                except FileNotFoundError:
-                    pass
-                if uid is None:
-                    if time.time() - t0 > 120:
-                        raise RuntimeError(f'rank {rank}: no communicator id of this launch in {id_file} after 120 s')
-                    time.sleep(0.02)
+        uid = _file_rendezvous(id_file, rank, world, _hk.comm_unique_id)
         ctx.comm_init(uid, rank, world)
-        if rank == 0:
-            try:
-                os.unlink(id_file)
-            except OSError:
-                pass
+        if rank == 0:   # ncclCommInitRank returns when every rank has joined, i.e. has read the id
+            for path in [id_file] + [f'{id_file}.{kind}{r}' for kind in ('hello', 'ack') for r in range(1, world)]:
+                try:
+                    os.unlink(path)
+                except OSError:
+                    pass
         return rank, world
     ctx.comm_init(uid, rank, world)
     return rank, world
+
+
+def _file_rendezvous(id_file: str, rank: int, world: int, make_uid, timeout: float = 120.0) -> bytes:
+    """
+    The communicator id from rank 0 to the others through files, safe against whatever an earlier (crashed) launch left at the
+    same path: every other rank announces itself with a fresh random nonce (``<id_file>.hello<r>``), rank 0 publishes the id
+    together with the nonces it saw, a rank takes only an id file that names ITS nonce and acknowledges it
+    (``<id_file>.ack<r>``), and rank 0 goes on -- into ncclCommInitRank, which has no timeout of its own -- only when every
+    rank has acknowledged the file it last wrote.  A stale hello makes rank 0 publish once more when the fresh one arrives; a
+    stale id or ack file never matches a fresh nonce.  No launcher token is needed (rounds 3-4 keyed the file on MASTER_PORT /
+    TORCHELASTIC_RUN_ID and accepted any young file when neither was set).  Every wait ends with a clear error after ``timeout``.
+    """
+    import json
+    import struct
+    import time
+    magic = b'HKCOMM02'
+
+    def put(path, blob):
+        tmp = f'{path}.tmp{os.getpid()}.{rank}'
+        with open(tmp, 'wb') as f:
+            f.write(blob)
+        os.replace(tmp, path)
+
+    def get(path):
+        try:
+            with open(path, 'rb') as f:
+                return f.read()
+        except OSError:
+            return None
+
+    t0 = time.time()
+    if rank != 0:
+        nonce = os.urandom(8).hex()
+        put(f'{id_file}.hello{rank}', nonce.encode())
+        while True:
+            blob = get(id_file)
+            if blob and blob[:8] == magic and len(blob) > 12:
+                n = struct.unpack('<I', blob[8:12])[0]
+                try:
+                    seen = json.loads(blob[12:12 + n].decode())
+                except ValueError:
+                    seen = {}
+                if seen.get(str(rank)) == nonce:
+                    put(f'{id_file}.ack{rank}', nonce.encode())
+                    return blob[12 + n:]
+            if time.time() - t0 > timeout:
+                raise RuntimeError(f'rank {rank}: no communicator id of this launch in {id_file} after {timeout:.0f} s')
+            time.sleep(0.01)
+    try:
+        os.unlink(id_file)
+    except OSError:
+        pass
+    uid = make_uid()
+    written = None
+    while True:
+        cur = {}
+        for r in range(1, world):
+            blob = get(f'{id_file}.hello{r}')
+            if blob:
+                cur[str(r)] = blob.decode(errors='replace')
+        if len(cur) == world - 1 and cur != written:
+            head = json.dumps(cur).encode()
+            put(id_file, magic + struct.pack('<I', len(head)) + head + uid)
+            written = cur
+        if written is not None and all((get(f'{id_file}.ack{r}') or b'').decode(errors='replace') == written[str(r)] for r in range(1, world)):
+            return uid
+        if time.time() - t0 > timeout:
+            missing = [r for r in range(1, world) if str(r) not in cur]
+            raise RuntimeError(f'rank 0: ranks {missing or "(all announced, not all acknowledged)"} did not join through {id_file} within {timeout:.0f} s')
+        time.sleep(0.01)
 
 
 def finalize():

@@ -359,15 +359,17 @@ class RasterFuse:
 
     @staticmethod
     def create_device_config(devices: Optional[Sequence[int]] = None, streams: int = 4, rank: int = 0,
-                             world_size: int = 1, contiguous: bool = False, pin: bool = False,
+                             world_size: int = 1, contiguous: bool = False, pin: bool = True,
                              separate_contexts: bool = False) -> Dict:
         """ (this package only) GPUs of this process, streams per GPU, this process's shard of the block list
         (round-robin, or ``contiguous`` runs), whether every entry of ``devices`` gets a context of its own even when a
-        device is listed twice, and ``pin``: False (default) -- the caller's rasters travel through the library's own
-        page-locked staging ring, the GPU never touches caller-allocated pages (rasters that are page-locked already,
-        e.g. ``Context.pinned_empty``, are still copied directly); True -- the rasters are registered in place for the
-        duration of the block loop (``hipHostRegister``) and copied directly: 10-17 % more end-to-end throughput
-        (profiles/r04_streamed_host.txt) at the price of GPU accesses to the caller's own heap pages. """
+        device is listed twice, and ``pin``: True (default) -- the rasters are registered in place for the duration of the
+        block loop (``hk_host_register``) and copied directly: 10-17 % more end-to-end throughput than through the staging
+        ring (profiles/r04_streamed_host.txt); a raster that cannot be registered (``ulimit -l``, foreign memory) and every
+        array the library did not page-lock itself travel through the library's own page-locked staging ring, so the runtime
+        is never handed pageable memory either way (the registered path ran clean as the first process of five fresh
+        leases, profiles/r04_abort_followup.txt); False -- everything through the staging ring: the GPU never touches
+        caller-allocated pages. """
         return dict(devices=None if devices is None else list(devices), streams=int(streams), rank=int(rank),
                     world_size=int(world_size), contiguous=bool(contiguous), pin=bool(pin),
                     separate_contexts=bool(separate_contexts))

@@ -74,6 +74,11 @@ int hk_abi_version(void);
 const char* hk_backend_name(void);            /* "hip-gfx950" */
 const char* hk_last_error(void);              /* thread-local text of the last failure */
 int hk_device_count(int* count);
+/* PCI bus address of HIP device `device_id` as sysfs spells it ("0000:c1:00.0"; `len` >= 13), so that a rank can look up its
+ * GPU's NUMA node (/sys/bus/pci/devices/<address>/numa_node) and run its host threads -- the staging copies, the pinned
+ * allocations -- on that node's cores (homonim_amd/topology.py).  The reference's "devices" are the host's own cores
+ * (homonim/fuse.py:396-401: a ThreadPoolExecutor); there is nothing to place. */
+int hk_device_pci_bus_id(int device_id, char* out, int len);
 /* One context per GPU: owns `n_streams` HIP streams, each with a pinned-host + device staging slot that grows on
  * demand.  Replaces nothing in the reference (its "device" is the host CPU); mirrors the thread pool of
  * homonim/fuse.py:396.

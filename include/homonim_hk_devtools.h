@@ -14,6 +14,13 @@
  *                       the lower / upper end), or plain allocations filled with 0xAB: an out-of-range access of a kernel
  *                       faults at its launch (tests/test_gpu_guard_alloc.py).
  *   HK_STAGE_CHUNK_KB   size of the pinned staging chunks of the host-pointer calls (default 8192; tests of the chunked paths).
+ *   HK_ASSERT_PINNED=1  a caller array is copied directly (not through the staging ring) only when ONE range page-locked through
+ *                       hk_host_alloc / hk_host_register holds all of it; with this switch the library also asks the HIP runtime
+ *                       about every page of every row of such an array before the copy is queued and fails the call
+ *                       (HK_ERR_ARG) if one is not page-locked host memory.  The test-suite runs with it.
+ *   HK_TEST_FAIL_AFTER_D2H=1   (read at every call) fault injection for the test-suite: hk_fit / hk_fit_apply* on host pointers
+ *                       fail right behind their queued result copies -- where a HIP error would leave them -- so that the
+ *                       abandonment of those copies can be observed (no later call may write the failed call's output arrays).
  */
 #ifndef HOMONIM_HK_DEVTOOLS_H
 #define HOMONIM_HK_DEVTOOLS_H
@@ -45,6 +52,11 @@ int hk_r2_certificate_constants(float thresh, double* pass_below, double* fail_a
 /* Measurement aid: the stage counters a -DHK_STAMPS build of the fused kernel accumulates (shader-clock cycles per stage of a row
  * iteration, [14] waves, [15] iterations; all zero in the shipped build; tools/stage_stamps.py).  Synchronises the device. */
 int hk_debug_stage_stamps(hk_ctx* ctx, uint64_t out[16], int32_t reset);
+
+/* Test aid: how the host-pointer entry points moved caller memory since the process started (or the last reset), all contexts:
+ * out[0] = copies queued straight from / to caller arrays (page-locked through this library), out[1] = chunks that went through
+ * the pinned staging ring. */
+int hk_debug_staging_counters(uint64_t out[2], int32_t reset);
 
 #ifdef __cplusplus
 }

@@ -24,14 +24,20 @@ def pytest_configure(config):
         print(f'[conftest] abort tracer not installed: {ex}', file=sys.stderr)
 
 
+# the library checks every page of every caller array it is about to copy directly (hk_api.hip check_rows_pinned): a host pointer
+# that is not page-locked fails its call in the test-suite instead of being pinned on the fly by the runtime
+os.environ.setdefault('HK_ASSERT_PINNED', '1')
+
 _probe = {}
 
 
 def pytest_sessionstart(session):
-    """ A run that selects the GPU tests first lets a CHILD process be the lease's first GPU process (harness/first_process.py):
-    round 3's aborts only ever hit first processes.  Its fate is part of the report header; it never fails the run. """
+    """ HK_FIRST_PROCESS_PROBE=1: a run that selects the GPU tests first lets a CHILD process be the lease's first GPU process
+    (harness/first_process.py: round 3's aborts only ever hit first processes; the cause was removed in round 4 and the probe is
+    off by default since round 5).  When it runs, its death is the run's failure: pytest_sessionfinish turns the exit status
+    non-zero -- a green run means no process died. """
     expr = session.config.getoption('markexpr', '') or ''
-    if 'gpu' not in expr or 'not gpu' in expr or os.environ.get('HK_NO_FIRST_PROCESS_PROBE') == '1':
+    if 'gpu' not in expr or 'not gpu' in expr or os.environ.get('HK_FIRST_PROCESS_PROBE') != '1':
         return
     try:
         from harness import first_process
@@ -45,6 +51,14 @@ def pytest_sessionstart(session):
     else:   # loud, on the real stderr, whatever pytest captures
         sys.__stderr__.write(f"\n[conftest] THE FIRST GPU PROCESS OF THIS RUN DIED OR FAILED (rc {_probe.get('rc')}):\n{_probe.get('output')}\n\n")
         sys.__stderr__.flush()
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if _probe and _probe.get('rc') != 0:
+        sys.__stderr__.write(f"[conftest] the first-GPU-process probe ended with rc {_probe.get('rc')}: this run FAILS whatever its tests did\n")
+        sys.__stderr__.flush()
+        if session.exitstatus == 0:
+            session.exitstatus = 3
 
 
 def pytest_report_header(config):

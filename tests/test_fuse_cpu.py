@@ -203,10 +203,18 @@ def test_communicator_id_travels_through_a_file(tmp_path, monkeypatch):
 
     path = str(tmp_path / 'comm_id.bin')
     # a file left behind by an earlier launch (another MASTER_PORT) is not this launch's id: rank 0 replaces it, the others skip it
+    # ... whatever its format and however young, with no launcher token in the environment at all: an id file, a hello and an
+    # acknowledgement of a crashed launch of THIS protocol (their nonces are not this launch's)
+    import json
     import struct
+    head = json.dumps({'1': 'feedfacefeedface', '2': 'deadbeefdeadbeef'}).encode()
     with open(path, 'wb') as f:
-        f.write(struct.pack('<8s64sd', b'HKCOMM01', b'1|stale|', 0.0) + bytes(128))
-    monkeypatch.setenv('MASTER_PORT', '29999')
+        f.write(b'HKCOMM02' + struct.pack('<I', len(head)) + head + bytes(128))
+    for name, text in (('hello1', 'feedfacefeedface'), ('ack1', 'feedfacefeedface'), ('ack2', 'deadbeefdeadbeef')):
+        with open(f'{path}.{name}', 'w') as f:
+            f.write(text)
+    for key in ('MASTER_PORT', 'TORCHELASTIC_RUN_ID', 'HOMONIM_AMD_LAUNCH_ID'):
+        monkeypatch.delenv(key, raising=False)
     local = threading.local()
     monkeypatch.setattr(dist, 'env_ranks', lambda: (local.rank, 3, local.rank))
 

@@ -107,3 +107,67 @@ def test_unpinned_count_buffers_are_refused():
         ctx.event_destroy(ev)
     finally:
         ctx.dev_free(d)
+
+
+def test_a_view_over_two_registered_ranges_with_a_pageable_gap_is_staged():
+    """ Direct copies are for arrays that ONE page-locked range of the library holds entirely.  A strided view whose first rows lie
+    in one registered range and whose last rows lie in another, with pageable memory between them, used to pass (the first and the
+    last byte were asked about) and reached hipMemcpy2DAsync as "pinned" -- the runtime then pins the gap on the fly, the path of
+    the round-3 abort.  It must travel through the staging ring, and give the same bytes; the same view inside one registered
+    range is copied directly.  (The suite runs with HK_ASSERT_PINNED=1: a direct copy of a pageable page fails its call.) """
+    assert os.environ.get('HK_ASSERT_PINNED') == '1'
+    ctx = _hk.default_context()
+    page, part = 4096, 64 * 1024
+    buf = np.zeros(3 * part + 2 * page, np.uint8)
+    a0 = (-buf.ctypes.data) % page                        # first page boundary inside the buffer
+    h, w, pitch = 48, 500, 4096                           # 16 rows per 64 KB part
+    src_full, ref_full = onp.synth_pair(h, w, 77, 'frame+holes')
+    view = np.ndarray((h, w), np.float32, buffer=buf, offset=a0, strides=(pitch, 4))
+    view[:] = src_full
+    assert view.ctypes.data % page == 0 and view.strides == (pitch, 4)
+    desc = _hk.make_desc('gain-offset', (5, 5), False, 0.25, np.nan, np.nan)
+    _, exp, _, _ = ctx.fit_apply(desc, np.ascontiguousarray(view), ref_full, 2, want_params=False, want_corr=True)
+    first, last = buf[a0:a0 + part], buf[a0 + 2 * part:a0 + 3 * part]
+    ctx.pin(first), ctx.pin(last)
+    try:
+        _hk.staging_counters(reset=True)
+        _, got, _, _ = ctx.fit_apply(desc, view, ref_full, 2, want_params=False, want_corr=True)
+        direct, staged = _hk.staging_counters(reset=True)
+        assert direct == 0 and staged > 0, (direct, staged)      # src (the gap view) and ref, corr (plain numpy) all staged
+        assert np.array_equal(got, exp, equal_nan=True)
+        # the rows inside ONE registered range: copied directly
+        _, got16, _, _ = ctx.fit_apply(desc, view[:16], ref_full[:16], 2, want_params=False, want_corr=True)
+        direct, staged = _hk.staging_counters(reset=True)
+        assert direct >= 1, (direct, staged)
+        _, exp16, _, _ = ctx.fit_apply(desc, np.ascontiguousarray(view[:16]), ref_full[:16], 2, want_params=False, want_corr=True)
+        assert np.array_equal(got16, exp16, equal_nan=True)
+    finally:
+        ctx.unpin(first), ctx.unpin(last)
+    # unregistered again: nothing of the buffer is copied directly any more
+    _hk.staging_counters(reset=True)
+    ctx.fit_apply(desc, view[:16], ref_full[:16], 2, want_params=False, want_corr=True)
+    assert _hk.staging_counters()[0] == 0
+
+
+def test_an_error_between_the_copies_leaves_no_pointer_behind(monkeypatch):
+    """ A host-pointer call that fails after it queued results for unpacking must not leave the caller's output pointer in the
+    staging ring: the next call on that stream would unpack up to 8 MB into memory the caller has usually freed by then (round-4
+    advisor finding).  HK_TEST_FAIL_AFTER_D2H makes hk_fit_apply fail exactly there; afterwards the failed call's output array
+    must stay as the caller left it, whatever runs on the context's streams. """
+    ctx = _hk.Context(0, n_streams=1)   # one stream: the next call takes the failed call's slot
+    try:
+        src, ref = onp.synth_pair(300, 500, 3, 'none')
+        desc = _hk.make_desc('gain', (5, 5), False, None, None, None)
+        _, exp, _, _ = ctx.fit_apply(desc, src, ref, 2, want_params=False, want_corr=True)
+        victim = np.full(src.shape, -1.0, np.float32)
+        monkeypatch.setenv('HK_TEST_FAIL_AFTER_D2H', '1')
+        with pytest.raises(Exception, match='HK_TEST_FAIL_AFTER_D2H'):
+            ctx.fit_apply(desc, src, ref, 2, want_params=False, want_corr=True, out_corr=victim)
+        monkeypatch.delenv('HK_TEST_FAIL_AFTER_D2H')
+        victim[:] = -2.0   # "freed and re-used"
+        for _ in range(6):   # more calls than the ring has chunks
+            _, got, _, _ = ctx.fit_apply(desc, src, ref, 2, want_params=False, want_corr=True)
+            assert np.array_equal(got, exp, equal_nan=True)
+        assert (victim == -2.0).all(), 'a later call unpacked the failed call\'s result into its output array'
+    finally:
+        ctx.close()

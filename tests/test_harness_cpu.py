@@ -37,3 +37,33 @@ def test_first_process_probe_reports_without_a_gpu():
     from harness import first_process
     res = first_process.run(timeout=120)
     assert res['rc'] == 0 and ('no GPU' in res['output'] or 'host-pointer calls as the first GPU process' in res['output'])
+
+
+def test_a_dying_probe_fails_the_run(tmp_path):
+    """ A green run means no process died: with the probe switched on (HK_FIRST_PROCESS_PROBE=1) and made to die the way round 3's
+    first GPU processes did, a pytest session whose own tests all pass ends non-zero, and bench.py's gate says `fatal`. """
+    test = tmp_path / 'test_ok.py'
+    test.write_text('import pytest\n\n@pytest.mark.gpu\ndef test_ok():\n    assert True\n')
+    (tmp_path / 'conftest.py').write_text(open(os.path.join(REPO, 'tests', 'conftest.py')).read())
+    os.makedirs(tmp_path / 'golden', exist_ok=True)
+    env = dict(os.environ, HK_FIRST_PROCESS_PROBE='1', HK_FIRST_PROCESS_TEST_DIE='1', PYTHONPATH=REPO)
+    # (the copied conftest resolves REPO from its own location: point it back at the repository's golden vectors)
+    src = (tmp_path / 'conftest.py').read_text().replace(
+        "REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))", f"REPO = {REPO!r}")
+    (tmp_path / 'conftest.py').write_text(src)
+    run = subprocess.run([sys.executable, '-m', 'pytest', str(test), '-q', '-m', 'gpu', '-p', 'no:cacheprovider'], cwd=tmp_path, env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert '1 passed' in run.stdout, run.stdout + run.stderr
+    assert run.returncode != 0, run.stdout + run.stderr
+    assert 'this run FAILS' in run.stderr
+    # the same session with a probe that lives: green
+    env.pop('HK_FIRST_PROCESS_TEST_DIE')
+    run = subprocess.run([sys.executable, '-m', 'pytest', str(test), '-q', '-m', 'gpu', '-p', 'no:cacheprovider'], cwd=tmp_path, env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stdout + run.stderr
+    # bench.py's side of it
+    code = 'import sys; sys.path.insert(0, %r); from harness import first_process as f; g = f.gate(); sys.exit(3 if g and g["fatal"] else 0)' % REPO
+    env['HK_FIRST_PROCESS_TEST_DIE'] = '1'
+    assert subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, timeout=300).returncode == 3
+    env.pop('HK_FIRST_PROCESS_PROBE')
+    assert subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, timeout=300).returncode == 0   # off: nothing runs

@@ -1,0 +1,81 @@
+""" Host placement (homonim_amd/topology.py): the sysfs parsers on a canned tree of a two-socket, eight-GPU node. """
+import os
+
+import pytest
+
+from homonim_amd import topology
+
+GPUS = {  # PCI address -> NUMA node (the layout of an 8 x MI355X node: four GPUs per socket)
+    '0000:05:00.0': 0, '0000:15:00.0': 0, '0000:65:00.0': 0, '0000:75:00.0': 0,
+    '0000:85:00.0': 1, '0000:95:00.0': 1, '0000:e5:00.0': 1, '0000:f5:00.0': 1,
+}
+
+
+@pytest.fixture
+def sysfs(tmp_path):
+    root = tmp_path / 'sys'
+    for node, cpus in ((0, '0-63,128-191\n'), (1, '64-127,192-255\n')):
+        d = root / 'devices' / 'system' / 'node' / f'node{node}'
+        d.mkdir(parents=True)
+        (d / 'cpulist').write_text(cpus)
+    for i, (bdf, node) in enumerate(GPUS.items()):
+        d = root / 'bus' / 'pci' / 'devices' / bdf
+        d.mkdir(parents=True)
+        (d / 'numa_node').write_text(f'{node}\n')
+        (d / 'uevent').write_text(f'DRIVER=amdgpu\nPCI_CLASS=38000\nPCI_SLOT_NAME={bdf}\n')
+        c = root / 'class' / 'drm' / f'card{i}'
+        c.mkdir(parents=True)
+        os.symlink(d, c / 'device')
+        (root / 'class' / 'drm' / f'card{i}-DP-1').mkdir()   # connectors are not cards
+    # a device whose node the firmware does not name, and an integrated VGA controller without the file
+    d = root / 'bus' / 'pci' / 'devices' / '0000:03:00.0'
+    d.mkdir(parents=True)
+    (d / 'numa_node').write_text('-1\n')
+    (root / 'bus' / 'pci' / 'devices' / '0000:04:00.0').mkdir()
+    return str(root)
+
+
+def test_cpulist():
+    assert topology.parse_cpulist('0-3,8,10-11\n') == [0, 1, 2, 3, 8, 10, 11]
+    assert topology.parse_cpulist('5') == [5]
+    assert topology.parse_cpulist('') == []
+    assert topology.parse_cpulist('3,1-2,2') == [1, 2, 3]
+
+
+def test_gpu_node_and_cpus(sysfs):
+    assert topology.pci_numa_node('0000:05:00.0', sysfs) == 0
+    assert topology.pci_numa_node('0000:E5:00.0', sysfs) == 1     # HIP spells the address in upper case
+    assert topology.pci_numa_node('0000:03:00.0', sysfs) is None  # -1
+    assert topology.pci_numa_node('0000:04:00.0', sysfs) is None  # no file
+    assert topology.pci_numa_node('0000:aa:00.0', sysfs) is None  # no device
+    cpus = topology.node_cpus(1, sysfs)
+    assert len(cpus) == 128 and cpus[0] == 64 and cpus[63] == 127 and cpus[64] == 192 and cpus[-1] == 255
+    assert topology.node_cpus(7, sysfs) == []
+
+
+def test_placement_respects_the_allowed_cpus(sysfs):
+    p = topology.placement_for('0000:95:00.0', sysfs)
+    assert p['numa_node'] == 1 and len(p['cpus']) == 128
+    p = topology.placement_for('0000:95:00.0', sysfs, allowed=list(range(60, 70)))
+    assert p['cpus'] == [64, 65, 66, 67, 68, 69]
+    p = topology.placement_for('0000:95:00.0', sysfs, allowed=[0, 1])   # a container pinned to the other socket
+    assert p['cpus'] == []
+    assert topology.placement_for('0000:03:00.0', sysfs) == dict(bus_id='0000:03:00.0', numa_node=None, cpus=[])
+
+
+def test_cards_and_summary(sysfs):
+    cards = topology.drm_cards(sysfs)
+    assert cards == GPUS
+    rec = dict(topology.placement_for('0000:05:00.0', sysfs), bound=True, threads=3, reason=None)
+    s = topology.summary(rec)
+    assert s['cpus'] == '0-63,128-191' and s['n_cpus'] == 128 and s['numa_node'] == 0 and s['bound'] and s['threads'] == 3
+
+
+def test_bind_without_a_library_or_gpu_is_a_record_not_an_error(monkeypatch):
+    monkeypatch.setenv('HOMONIM_AMD_NO_BIND', '1')
+    assert topology.bind_to_device(0)['bound'] is False
+    monkeypatch.delenv('HOMONIM_AMD_NO_BIND')
+    before = os.sched_getaffinity(0)
+    rec = topology.bind_to_device(0, sysfs_root='/nonexistent')   # no GPU here: the record says why, the affinity stays
+    assert rec['bound'] is False and rec['reason']
+    assert os.sched_getaffinity(0) == before
