@@ -254,12 +254,6 @@ struct Slot {
     size_t norm_ws_bytes = 0;
     void* aux = nullptr;      // on-demand planes + tables of the in-painting branch
     size_t aux_bytes = 0;
-    // ... and a second set with a stream of its own: the bands of a job that need in-painting alternate between the two, so that
-    // one band's memory-bound closing pass runs beside the next band's latency-bound search (hk_inpaint_dev_counts)
-    void* aux2 = nullptr;
-    size_t aux2_bytes = 0;
-    hipStream_t stream2 = nullptr;
-    hipEvent_t lane_ev[2] = {nullptr, nullptr};  // [0] main stream -> second lane, [1] second lane -> main stream
     // exchange buffer of hk_block_norm_split_comm_dev on THIS stream: sequences queued on different streams run concurrently on
     // the device (comm_mu only orders their queuing), so they must not share one
     double* comm_xchg = nullptr;
@@ -717,11 +711,6 @@ void slot_release(Slot& s) {
     if (s.dev) (void)dev_free(s.dev);
     if (s.norm_ws) (void)dev_free(s.norm_ws);
     if (s.aux) (void)dev_free(s.aux);
-    if (s.stream2) (void)hipStreamSynchronize(s.stream2);
-    if (s.aux2) (void)dev_free(s.aux2);
-    for (auto& ev : s.lane_ev)
-        if (ev) (void)hipEventDestroy(ev);
-    if (s.stream2) (void)hipStreamDestroy(s.stream2);
     if (s.comm_xchg) (void)dev_free(s.comm_xchg);
     if (s.fail_host) (void)hipHostFree(s.fail_host);
     if (s.stage) (void)hipHostFree(s.stage);
@@ -933,27 +922,17 @@ void fill_grid(hk::FitArgs& a, int seg_rows) {
 // pixels from the passing ones (restated GDALFillNodata) and run the fit again with `offset_in`, which recomputes their
 // gains and re-applies.  `a` is the first pass's argument block (n_bands == 1).
 // scratch of the in-painting branch: [filled | gain | offset | r2 | column tables]
-static int ensure_inpaint_scratch(Slot& sl, size_t plane, int height, long long stride, int lane = 0) {
+static int ensure_inpaint_scratch(Slot& sl, size_t plane, int height, long long stride) {
     const size_t need = 4 * plane + hk::inpaint_workspace_bytes(height, stride);
-    void*& aux = lane ? sl.aux2 : sl.aux;
-    size_t& aux_bytes = lane ? sl.aux2_bytes : sl.aux_bytes;
-    if (!fits(aux_bytes, need)) {
-        if (aux) {
-            HK_HIP(hipStreamSynchronize(lane ? sl.stream2 : sl.stream));
-            HK_HIP(dev_free(aux));
+    if (!fits(sl.aux_bytes, need)) {
+        if (sl.aux) {
+            HK_HIP(hipStreamSynchronize(sl.stream));
+            HK_HIP(dev_free(sl.aux));
         }
-        aux = nullptr, aux_bytes = 0;
-        if (dev_malloc(&aux, need) != hipSuccess) return fail(HK_ERR_NOMEM, "hipMalloc(%zu) failed", need);
-        aux_bytes = need;
+        sl.aux = nullptr, sl.aux_bytes = 0;
+        if (dev_malloc(&sl.aux, need) != hipSuccess) return fail(HK_ERR_NOMEM, "hipMalloc(%zu) failed", need);
+        sl.aux_bytes = need;
     }
-    return HK_OK;
-}
-
-// the second lane of the in-painting branch (Slot::stream2 / aux2), made on first use
-static int ensure_inpaint_lane(Slot& sl) {
-    if (!sl.stream2) HK_HIP(hipStreamCreateWithFlags(&sl.stream2, hipStreamNonBlocking));
-    for (auto& ev : sl.lane_ev)
-        if (!ev) HK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     return HK_OK;
 }
 
@@ -967,16 +946,15 @@ static bool cert_only_eligible(const hk::FitArgs& a, const hk_fit_desc* desc) {
 // `n_fail`: the band's r2-mask failure count.  `pre_offset` / `pre_flag` (both or neither): offsets and source flags (r2 > thresh) & (gain > 0) & valid left by the pass
 // that counted the failures (FitArgs::flag) -- the in-painting then starts right away.  `drop_params`: the parameter
 // planes in `a` are scratch, the closing pass need not write them.
-// `lane` 1: on the slot's second stream with its second scratch set (the caller orders the lanes, hk_inpaint_dev_counts)
 static int inpaint_band(Slot& sl, const hk::FitArgs& a, const hk_fit_desc* desc, bool r2, size_t plane,
                         unsigned long long n_fail, bool drop_params = false, const float* pre_offset = nullptr,
-                        const unsigned char* pre_flag = nullptr, int lane = 0) {
+                        const unsigned char* pre_flag = nullptr) {
     {
-        const int rc = ensure_inpaint_scratch(sl, plane, a.height, a.stride, lane);
+        const int rc = ensure_inpaint_scratch(sl, plane, a.height, a.stride);
         if (rc) return rc;
     }
-    const hipStream_t stream = lane ? sl.stream2 : sl.stream;
-    char* aux = static_cast<char*>(lane ? sl.aux2 : sl.aux);
+    const hipStream_t stream = sl.stream;
+    char* aux = static_cast<char*>(sl.aux);
     float* filled = reinterpret_cast<float*>(aux);
     const float *pg = a.gain, *po = a.offset, *pr = a.r2;
     const unsigned char* flags = nullptr;
@@ -1888,26 +1866,9 @@ int hk_inpaint_dev_counts(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job
     const size_t plane = (size_t)job->stride * job->height * sizeof(float);
     unsigned long long total = 0;
     bool retried = false;
-    // Two lanes (round 5): the bands that need the branch alternate between the job's stream and the slot's second stream, each
-    // with a scratch set of its own -- a band's chain is tables -> search (latency-bound) -> closing pass (memory-bound), and the
-    // chains of consecutive bands now overlap instead of running back to back (profiles/r05_inpaint_*.txt).  The second lane
-    // starts behind everything queued on the job's stream so far and the job's stream ends behind the second lane: callers see
-    // one stream as before.  HK_INPAINT_LANES=1: one lane (A/B).
-    static const bool two_lanes = [] { const char* e = getenv("HK_INPAINT_LANES"); return !(e && atoi(e) == 1); }();
-    int n_need = 0;
-    for (int b = 0; b < job->n_bands; ++b) n_need += counts[b] != 0;
-    const bool lanes = two_lanes && n_need > 1;
-    bool lane1_used = false;
-    int k_band = 0;
-    if (lanes) {
-        rc = ensure_inpaint_lane(sl);
-        if (rc) return rc;
-    }
     for (int b = 0; b < job->n_bands; ++b) {
         unsigned long long n_fail = counts[b];
         if (n_fail == 0) continue;
-        // (a band the lighter build sent back is counted again on the job's stream: it stays on the first lane)
-        const int lane = (lanes && (k_band++ & 1) && !(n_fail & hk::FIT_RETRY_BIT)) ? 1 : 0;
         const long long off = (long long)b * job->band_stride;
         hk::FitArgs a;
         memset(&a, 0, sizeof(a));
@@ -1953,17 +1914,8 @@ int hk_inpaint_dev_counts(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job
         }
         total += n_fail;
         if (n_fail == 0) continue;
-        if (lane && !lane1_used) {   // the second lane starts behind the pass that counted (and whatever else the stream holds)
-            HK_HIP(hipEventRecord(sl.lane_ev[0], sl.stream));
-            HK_HIP(hipStreamWaitEvent(sl.stream2, sl.lane_ev[0], 0));
-            lane1_used = true;
-        }
-        rc = inpaint_band(sl, a, desc, r2, plane, n_fail, false, pre_off, pre_flag, lane);
+        rc = inpaint_band(sl, a, desc, r2, plane, n_fail, false, pre_off, pre_flag);
         if (rc) return rc;
-    }
-    if (lane1_used) {   // ... and the job's stream goes on behind it
-        HK_HIP(hipEventRecord(sl.lane_ev[1], sl.stream2));
-        HK_HIP(hipStreamWaitEvent(sl.stream, sl.lane_ev[1], 0));
     }
     if (retried) ctx->cert_only_retried();
     else if (ctx->cert_skip.load(std::memory_order_relaxed) == 0) ctx->cert_only_settled();
