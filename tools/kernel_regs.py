@@ -19,10 +19,11 @@ def kernels(obj):
         cos = [f for f in os.listdir(tmp) if 'gfx950' in f]
         # llvm-objdump writes the bundles next to the INPUT on some versions
         src_dir = os.path.dirname(obj)
-        stray = [f for f in os.listdir(src_dir) if f.startswith(os.path.basename(obj) + '.') and 'gfx950' in f]
+        bundles = [f for f in os.listdir(src_dir) if f.startswith(os.path.basename(obj) + '.0.')]   # (some versions write them beside the INPUT)
+        stray = [f for f in bundles if 'gfx950' in f]
         path = os.path.join(tmp, cos[0]) if cos else os.path.join(src_dir, stray[0])
         notes = subprocess.run([f'{LLVM}/llvm-readelf', '--notes', path], capture_output=True, text=True).stdout
-        for f in stray:
+        for f in bundles:
             os.unlink(os.path.join(src_dir, f))
     out = []
     for e in re.split(r'\n\s+- \.agpr_count', notes)[1:]:
