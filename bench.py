@@ -22,7 +22,7 @@ Configs 1 and 2 run one raster per rank (weak scaling: tiles / bands are indepen
 the context's streams) -- the PCIe-inclusive rate, never the headline.
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline` and `cpu_baseline`.
-PyTorch is used only for the multi-process rendezvous / barrier when N > 1 (torch.distributed, backend nccl = RCCL).
+No PyTorch anywhere: the ranks of a launch meet over loopback TCP (homonim_amd/dist.py); RCCL is the library's own communicator.
 """
 import argparse
 import json
@@ -1027,7 +1027,7 @@ def main():
         except Exception as ex:
             sys.stderr.write(f'bench.py: first-process probe not run: {ex}\n')
     from homonim_amd import _hk, dist, topology
-    rank, world, local_rank = dist.init()  # torch.distributed (nccl = RCCL) only when WORLD_SIZE > 1
+    rank, world, local_rank = dist.init()  # the ranks meet over loopback TCP, only when WORLD_SIZE > 1 (homonim_amd/dist.py)
     # Host placement: this rank's threads onto the cores of its GPU's NUMA node, BEFORE anything page-locked is allocated
     # (the staging rings of the context, the host rasters of `end_to_end`): SURVEY.md 8(e) "NUMA-local pinned buffers"
     placement = topology.bind_to_device(local_rank % max(1, _hk.device_count()))
@@ -1040,7 +1040,7 @@ def main():
     # split-block statistics, runs on it): joined here so that every N > 1 run also proves RCCL over xGMI up -- one in-place
     # all-reduce of a float64 word per rank, which must come back as the number of ranks.
     rccl_ranks, rccl_error = None, None
-    if dist.backend() == 'nccl':
+    if dist.backend() == 'rccl':
         try:   # reported, not fatal: the timed path has no collective, a rank's shard does not depend on this communicator
             dist.init_comm(ctx)
             word = ctx.dev_alloc(8)
@@ -1168,8 +1168,8 @@ def main():
         if first_probe is not None:
             out['first_gpu_process_probe'] = first_probe   # rc 0: the child that used the GPU before this process ended normally
         if dist.backend() is not None:
-            out['dist_backend'] = dist.backend()   # 'nccl' = RCCL; absent for a single process without a group
-            out['rccl_ranks'] = rccl_ranks         # ranks of the library's own communicator (hk_comm_info); None under gloo
+            out['dist_backend'] = dist.backend()   # 'rccl': one GPU per rank, the library's RCCL communicator joined; 'host': ranks share a GPU; absent for a single process
+            out['rccl_ranks'] = rccl_ranks         # ranks of the library's own communicator (hk_comm_info); None under 'host'
             if rccl_error:
                 out['rccl_error'] = rccl_error
         print(json.dumps(out), flush=True)

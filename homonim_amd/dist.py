@@ -1,64 +1,147 @@
 """
-Multi-process plumbing for one-process-per-GPU runs (``python -m torch.distributed.run ... bench.py``).
+Multi-process plumbing for one-process-per-GPU runs (``python -m torch.distributed.run ... bench.py``, ``bench.py --gpus N``,
+or any launcher that sets RANK / LOCAL_RANK / WORLD_SIZE).
 
 The hot path has NO data-path collective: (band x block) work items are independent, every rank
-works on its own shard and the only exchanges are a barrier and scalar reductions for timing / bookkeeping.  Those go
-through ``torch.distributed`` -- backend "nccl" (= RCCL over xGMI on ROCm) when this rank has a GPU, "gloo" otherwise
-(CPU tests).  torch is imported lazily and only when WORLD_SIZE > 1.
+works on its own shard and the only exchanges are a barrier and scalar reductions for timing / bookkeeping.  Since round 5 they
+need no tensor library: the ranks of ONE node meet over loopback TCP --
+
+* rank 0 listens on an ephemeral port of 127.0.0.1 and publishes it through a small file in the temporary directory, named after
+  the launch (MASTER_PORT / TORCHELASTIC_RUN_ID / HOMONIM_AMD_LAUNCH_ID) and exchanged with the nonce handshake of
+  ``_file_rendezvous`` (a file an earlier, crashed launch left behind is never taken for this launch's);
+* ``barrier`` / ``max_over_ranks`` / ``sum_over_ranks`` are a gather to rank 0 and a reply to everybody (N - 1 small messages each
+  way; ~0.1 ms for 8 ranks -- they bracket timed regions, they are never inside one);
+* the one real exchange of the hot path, the statistics of a gain-blk-offset block whose rows are spread over GPUs, runs on the
+  LIBRARY's RCCL communicator (``init_comm``: the id travels over the same sockets; the collectives are queued by
+  libhomonim_hk.so on the job's stream, homonim_amd/split_norm.py).
+
+``backend()`` says which of the two this launch is: 'rccl' (one GPU per rank; ``init_comm`` is expected to work) or 'host' (several
+ranks share a GPU or have none -- smoke tests; HOMONIM_AMD_DIST_BACKEND=host, the legacy value 'gloo' means the same).
 """
 import os
-from typing import Optional, Tuple
+import socket
+import struct
+import tempfile
+import time
+from typing import List, Optional, Tuple
 
-_state = dict(initialised=False, world=1, rank=0, local_rank=0, backend=None)
+_state = dict(initialised=False, world=1, rank=0, local_rank=0, backend=None, server=None, peers=None, sock=None)
+_TIMEOUT = 180.0
 
 
 def env_ranks() -> Tuple[int, int, int]:
-    """ (rank, world_size, local_rank) from the torchrun environment (1-process defaults). """
+    """ (rank, world_size, local_rank) from the launcher's environment (1-process defaults). """
     return (int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1')),
             int(os.environ.get('LOCAL_RANK', '0')))
 
 
+def _launch_token() -> str:
+    parts = [os.environ.get(k, '') for k in ('MASTER_PORT', 'TORCHELASTIC_RUN_ID', 'HOMONIM_AMD_LAUNCH_ID')]
+    return '_'.join(''.join(c if c.isalnum() else '-' for c in p) for p in parts)
+
+
+def _send_msg(sock: socket.socket, payload: bytes):
+    sock.sendall(struct.pack('<I', len(payload)) + payload)
+
+
+def _recv_exact(sock: socket.socket, n: int) -> bytes:
+    buf = bytearray()
+    while len(buf) < n:
+        chunk = sock.recv(n - len(buf))
+        if not chunk:
+            raise ConnectionError('a peer rank closed its connection')
+        buf += chunk
+    return bytes(buf)
+
+
+def _recv_msg(sock: socket.socket) -> bytes:
+    (n,) = struct.unpack('<I', _recv_exact(sock, 4))
+    return _recv_exact(sock, n)
+
+
 def init(backend: Optional[str] = None) -> Tuple[int, int, int]:
-    """ Join the process group named by the environment; a no-op for single-process runs. """
+    """ Meet the other ranks of the launch named by the environment; a no-op for single-process runs. """
     rank, world, local_rank = env_ranks()
     _state.update(world=world, rank=rank, local_rank=local_rank)
-    # HOMONIM_AMD_DIST_FORCE=1: join the group even alone (exercises the RCCL plumbing on a 1-GPU box)
+    # HOMONIM_AMD_DIST_FORCE=1: set the plumbing up even alone (exercises it on a 1-GPU box)
     if (world > 1 or os.environ.get('HOMONIM_AMD_DIST_FORCE') == '1') and not _state['initialised']:
-        import torch
-        import torch.distributed as dist
         if backend is None:
-            # HOMONIM_AMD_DIST_BACKEND=gloo: several ranks sharing one GPU (smoke tests on a 1-GPU box)
-            backend = os.environ.get('HOMONIM_AMD_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        if backend == 'nccl':
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+            backend = os.environ.get('HOMONIM_AMD_DIST_BACKEND')
+        if backend is None:
+            from homonim_amd import _hk
+            try:
+                n_dev = _hk.device_count()
+            except Exception:
+                n_dev = 0
+            backend = 'rccl' if n_dev >= world else 'host'   # one GPU per rank, else the ranks share what there is
+        backend = {'gloo': 'host', 'nccl': 'rccl'}.get(backend, backend)
+        if backend not in ('host', 'rccl'):
+            raise ValueError(f"unknown HOMONIM_AMD_DIST_BACKEND {backend!r}: 'rccl' (one GPU per rank) or 'host'")
+        path = os.path.join(tempfile.gettempdir(), f'homonim_amd_rdzv_{os.getuid()}_{_launch_token()}')
+        if rank == 0:
+            server = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            server.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            server.bind(('127.0.0.1', 0))
+            server.listen(max(8, world))
+            port = server.getsockname()[1]
+            if world > 1:
+                _file_rendezvous(path, 0, world, lambda: struct.pack('<I', port), timeout=_TIMEOUT)
+            server.settimeout(_TIMEOUT)
+            peers: List[Optional[socket.socket]] = [None] * world
+            for _ in range(world - 1):
+                conn, _addr = server.accept()
+                conn.settimeout(_TIMEOUT)
+                conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                (r,) = struct.unpack('<I', _recv_msg(conn))
+                if not (0 < r < world) or peers[r] is not None:
+                    raise RuntimeError(f'rank 0: unexpected peer announced itself as rank {r}')
+                peers[r] = conn
+            for p in (path, *(f'{path}.{kind}{r}' for kind in ('hello', 'ack') for r in range(1, world))):
+                try:
+                    os.unlink(p)
+                except OSError:
+                    pass
+            _state.update(server=server, peers=peers)
         else:
-            dist.init_process_group(backend=backend)
+            (port,) = struct.unpack('<I', _file_rendezvous(path, rank, world, None, timeout=_TIMEOUT))
+            sock = socket.create_connection(('127.0.0.1', port), timeout=_TIMEOUT)
+            sock.settimeout(_TIMEOUT)
+            sock.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            _send_msg(sock, struct.pack('<I', rank))
+            _state.update(sock=sock)
         _state.update(initialised=True, backend=backend)
+        barrier()   # everybody is in
     return rank, world, local_rank
 
 
+def _exchange(payload: bytes, reduce_fn) -> bytes:
+    """ Gather every rank's payload at rank 0, reduce, reply the result to all. """
+    if not _state['initialised'] or _state['world'] == 1:
+        return reduce_fn([payload])
+    if _state['rank'] == 0:
+        parts = [payload] + [_recv_msg(_state['peers'][r]) for r in range(1, _state['world'])]
+        out = reduce_fn(parts)
+        for r in range(1, _state['world']):
+            _send_msg(_state['peers'][r], out)
+        return out
+    _send_msg(_state['sock'], payload)
+    return _recv_msg(_state['sock'])
+
+
 def _reduce(value: float, op_name: str) -> float:
-    if not _state['initialised']:
-        return float(value)
-    import torch
-    import torch.distributed as dist
-    device = f"cuda:{_state['local_rank']}" if _state['backend'] == 'nccl' else 'cpu'
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=getattr(dist.ReduceOp, op_name))
-    return float(t.item())
+    fn = {'MAX': max, 'SUM': sum}[op_name]
+    out = _exchange(struct.pack('<d', float(value)), lambda parts: struct.pack('<d', fn(struct.unpack('<d', p)[0] for p in parts)))
+    return struct.unpack('<d', out)[0]
 
 
 def backend() -> Optional[str]:
-    """ Backend of the joined process group (None: single process, no group). """
+    """ 'rccl' / 'host' once the ranks have met (None: single process, nothing to meet). """
     return _state['backend'] if _state['initialised'] else None
 
 
 def barrier():
     if _state['initialised']:
-        import torch.distributed as dist
-        dist.barrier()
+        _exchange(b'', lambda parts: b'')
 
 
 def max_over_ranks(value: float) -> float:
@@ -69,28 +152,28 @@ def sum_over_ranks(value: float) -> float:
     return _reduce(value, 'SUM')
 
 
+def broadcast_bytes(payload: Optional[bytes]) -> bytes:
+    """ rank 0's ``payload`` on every rank. """
+    return _exchange(payload if (_state['rank'] == 0 and payload is not None) else b'', lambda parts: parts[0])
+
+
 def init_comm(ctx, id_file: Optional[str] = None) -> Tuple[int, int]:
     """
     Give ``ctx`` (a ``homonim_amd._hk.Context``) the library's own RCCL communicator over the ranks of this launch: rank 0
-    makes the id (``hk_comm_unique_id``) and the others receive it -- through the torch.distributed process group when one
-    was joined (``init``; an object broadcast, launcher plumbing only), else through ``id_file`` (or ``$HOMONIM_AMD_COMM_FILE``:
-    rank 0 writes it atomically, the others wait for it).  The collectives themselves (``Context.block_norm_split_comm_dev``)
-    never touch torch.  -> (rank, world_size)
+    makes the id (``hk_comm_unique_id``) and the others receive it -- over the sockets of ``init`` when the ranks have met, else
+    through ``id_file`` (or ``$HOMONIM_AMD_COMM_FILE``; ``_file_rendezvous``).  The collectives themselves
+    (``Context.block_norm_split_comm_dev``) are queued by the library.  -> (rank, world_size)
     """
-    import time
     from homonim_amd import _hk
     rank, world, _ = env_ranks()
     id_file = id_file or os.environ.get('HOMONIM_AMD_COMM_FILE')
     if _state['initialised'] and id_file is None:
-        import torch.distributed as dist
-        box = [_hk.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        uid = box[0]
+        uid = broadcast_bytes(_hk.comm_unique_id() if rank == 0 else None)
     elif world == 1 and id_file is None:
         uid = _hk.comm_unique_id()
     else:
         if id_file is None:
-            raise RuntimeError('init_comm needs a joined process group (dist.init) or an id file (HOMONIM_AMD_COMM_FILE)')
+            raise RuntimeError('init_comm needs the ranks to have met (dist.init) or an id file (HOMONIM_AMD_COMM_FILE)')
         uid = _file_rendezvous(id_file, rank, world, _hk.comm_unique_id)
         ctx.comm_init(uid, rank, world)
         if rank == 0:   # ncclCommInitRank returns when every rank has joined, i.e. has read the id
@@ -106,17 +189,15 @@ def init_comm(ctx, id_file: Optional[str] = None) -> Tuple[int, int]:
 
 def _file_rendezvous(id_file: str, rank: int, world: int, make_uid, timeout: float = 120.0) -> bytes:
     """
-    The communicator id from rank 0 to the others through files, safe against whatever an earlier (crashed) launch left at the
-    same path: every other rank announces itself with a fresh random nonce (``<id_file>.hello<r>``), rank 0 publishes the id
-    together with the nonces it saw, a rank takes only an id file that names ITS nonce and acknowledges it
-    (``<id_file>.ack<r>``), and rank 0 goes on -- into ncclCommInitRank, which has no timeout of its own -- only when every
+    A small blob from rank 0 to the others through files, safe against whatever an earlier (crashed) launch left at the
+    same path: every other rank announces itself with a fresh random nonce (``<id_file>.hello<r>``), rank 0 publishes the blob
+    together with the nonces it saw, a rank takes only a file that names ITS nonce and acknowledges it
+    (``<id_file>.ack<r>``), and rank 0 goes on -- e.g. into ncclCommInitRank, which has no timeout of its own -- only when every
     rank has acknowledged the file it last wrote.  A stale hello makes rank 0 publish once more when the fresh one arrives; a
-    stale id or ack file never matches a fresh nonce.  No launcher token is needed (rounds 3-4 keyed the file on MASTER_PORT /
+    stale blob or ack file never matches a fresh nonce.  No launcher token is needed (rounds 3-4 keyed the file on MASTER_PORT /
     TORCHELASTIC_RUN_ID and accepted any young file when neither was set).  Every wait ends with a clear error after ``timeout``.
     """
     import json
-    import struct
-    import time
     magic = b'HKCOMM02'
 
     def put(path, blob):
@@ -148,7 +229,7 @@ def _file_rendezvous(id_file: str, rank: int, world: int, make_uid, timeout: flo
                     put(f'{id_file}.ack{rank}', nonce.encode())
                     return blob[12 + n:]
             if time.time() - t0 > timeout:
-                raise RuntimeError(f'rank {rank}: no communicator id of this launch in {id_file} after {timeout:.0f} s')
+                raise RuntimeError(f'rank {rank}: nothing of this launch in {id_file} after {timeout:.0f} s')
             time.sleep(0.01)
     try:
         os.unlink(id_file)
@@ -176,6 +257,14 @@ def _file_rendezvous(id_file: str, rank: int, world: int, make_uid, timeout: flo
 
 def finalize():
     if _state['initialised']:
-        import torch.distributed as dist
-        dist.destroy_process_group()
-        _state['initialised'] = False
+        try:
+            barrier()   # nobody closes a socket somebody else still reads
+        except Exception:
+            pass
+        for s in (_state.get('peers') or []):
+            if s is not None:
+                s.close()
+        for key in ('sock', 'server'):
+            if _state.get(key) is not None:
+                _state[key].close()
+        _state.update(initialised=False, backend=None, server=None, peers=None, sock=None)

@@ -1,7 +1,7 @@
 """
 Worker of tests/test_gpu_split_norm.py, started by `python -m torch.distributed.run --nproc-per-node N`: every rank holds a
 slab of rows of one 3-band block and takes part in the split-block statistics (homonim_amd/split_norm.py); rank 0 saves
-the result.  On a 1-GPU box the ranks share device 0 (gloo, or an RCCL group of one).  Not a test module.
+the result.  On a 1-GPU box the ranks share device 0 (torch gloo group, or a torch RCCL group of one).  Not a test module.
 """
 import os
 import sys
@@ -16,6 +16,12 @@ def main():
     out_dir, variant = sys.argv[1], sys.argv[2]
     from homonim_amd import _hk, dist, split_norm
     from oracle import oracle_np as onp  # input generator only (test infrastructure)
+    # the all-reduce of this test is torch.distributed's (gloo when the ranks share a GPU).  torch brings a HIP runtime of its own:
+    # it has to open the device BEFORE the library's runtime makes its first call (hk_device_count included) -- the other order
+    # leaves torch with "No HIP GPUs are available"
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    from _torch_reducer import TorchReducer, init_torch_group
+    init_torch_group(dist.env_ranks()[2])
     rank, world, local_rank = dist.init()
     dev = local_rank % _hk.device_count()
     ctx = _hk.Context(dev, n_streams=2)
@@ -37,8 +43,6 @@ def main():
     job.corr = job.gain = job.offset = job.r2 = job.norm = job.fail_count = None
     job.n_bands, job.height, job.width, job.stride, job.band_stride = nb, rows, w, stride, stride * rows
     job.seg_rows, job.stream = 0, 1
-    sys.path.insert(0, os.path.join(REPO, 'tests'))
-    from _torch_reducer import TorchReducer
     reducer = TorchReducer(ctx.split_exchange_doubles(nb), dev)
     norm = split_norm.block_norm_split(ctx, desc, job, reducer)
     norm2 = split_norm.block_norm_split(ctx, desc, job, reducer)   # the buffers are reusable
@@ -52,6 +56,8 @@ def main():
     ctx.close()
     dist.barrier()
     dist.finalize()
+    import torch.distributed as tdist
+    tdist.destroy_process_group()
 
 
 if __name__ == '__main__':

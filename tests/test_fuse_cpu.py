@@ -99,7 +99,7 @@ _WORKER = r'''
 import os, sys, json
 sys.path.insert(0, {repo!r})
 from homonim_amd import dist, fuse, utils
-rank, world, local_rank = dist.init()          # gloo (HOMONIM_AMD_DIST_BACKEND, set by the test)
+rank, world, local_rank = dist.init()          # loopback TCP between the ranks (backend 'host': no GPU here)
 blocks = list(fuse.block_pairs((3000, 2000), 3, utils.overlap_for_kernel((5, 5)), 4))
 mine = fuse.shard(blocks, rank, world)
 px = sum(b.src_out_block.width * b.src_out_block.height for b in mine)
@@ -115,10 +115,12 @@ dist.finalize()
 
 @pytest.mark.timeout(180)
 def test_rank_sharding_gloo_world2(tmp_path):
-    """ The N>1 path of bench.py / RasterFuse: every rank takes a disjoint shard, scalar reductions over gloo. """
+    """ The N>1 path of bench.py / RasterFuse under the driver's launcher: every rank takes a disjoint shard; barrier and scalar
+    reductions over the ranks' own loopback rendezvous (homonim_amd/dist.py; HOMONIM_AMD_DIST_BACKEND=gloo is the legacy name of
+    'host').  The torch gloo all-reduce of two ranks is tests/test_split_norm_cpu.py::test_protocol_with_two_gloo_ranks. """
     script = tmp_path / 'worker.py'
     script.write_text(_WORKER.format(repo=REPO))
-    # gloo explicitly: on a host WITH GPUs the default would be nccl, which needs one device per rank
+    # 'host' explicitly (legacy spelling): on a box WITH GPUs the default is 'rccl', which wants one device per rank
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='1', HOMONIM_AMD_DIST_BACKEND='gloo')
     res = subprocess.run(
         [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
@@ -237,6 +239,54 @@ def test_communicator_id_travels_through_a_file(tmp_path, monkeypatch):
     monkeypatch.delenv('HOMONIM_AMD_COMM_FILE', raising=False)
     with pytest.raises(RuntimeError):
         dist.init_comm(FakeCtx(1))
+
+
+_WORKER8 = r'''
+import os, sys, json, time
+sys.path.insert(0, {repo!r})
+from homonim_amd import dist
+rank, world, local_rank = dist.init()
+assert dist.backend() == 'host'
+t0 = time.perf_counter()
+for _ in range(200):
+    dist.barrier()
+per_barrier_us = (time.perf_counter() - t0) / 200 * 1e6
+assert dist.max_over_ranks(float(rank)) == world - 1
+assert dist.sum_over_ranks(float(rank)) == world * (world - 1) / 2
+blob = dist.broadcast_bytes(bytes(range(128)) if rank == 0 else None)
+assert blob == bytes(range(128))
+slowest = dist.max_over_ranks(per_barrier_us)
+if rank == 0:
+    print(json.dumps(dict(world=world, barrier_us=slowest)))
+dist.finalize()
+'''
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize('launcher', ['torchrun', 'plain'])
+def test_eight_ranks_meet_without_a_tensor_library(tmp_path, launcher):
+    """ The driver's 8-GPU launch (python -m torch.distributed.run --nproc-per-node 8) and a plain launcher that only sets RANK /
+    WORLD_SIZE / MASTER_PORT: eight ranks meet over loopback TCP (homonim_amd/dist.py), barrier, reduce and broadcast -- the
+    plumbing bench.py --gpus 8 brackets its timed region with, here without GPUs.  A barrier of 8 ranks stays well under a
+    millisecond (it never sits inside a timed region, only around one). """
+    script = tmp_path / 'worker8.py'
+    script.write_text(_WORKER8.format(repo=REPO))
+    env = dict(os.environ, OMP_NUM_THREADS='1', HOMONIM_AMD_DIST_BACKEND='host')
+    for key in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR', 'TORCHELASTIC_RUN_ID'):
+        env.pop(key, None)
+    if launcher == 'torchrun':
+        res = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=8', '--master-addr', '127.0.0.1',
+                              '--master-port', '29641', str(script)], capture_output=True, text=True, env=env, timeout=280)
+        assert res.returncode == 0, res.stderr[-2000:]
+        out = res.stdout
+    else:
+        procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE='8', MASTER_PORT='29642'),
+                                  stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(8)]
+        outs = [p.communicate(timeout=280) for p in procs]
+        assert all(p.returncode == 0 for p in procs), [e[-500:] for _, e in outs]
+        out = outs[0][0]
+    rec = json.loads([ln for ln in out.splitlines() if ln.startswith('{')][-1])
+    assert rec['world'] == 8 and rec['barrier_us'] < 5000, rec
 
 
 def test_bench_launcher_reports_a_failing_rank():

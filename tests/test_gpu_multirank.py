@@ -1,8 +1,8 @@
 """
 GPU tests of the multi-process / multi-context paths: one process per GPU under torch.distributed.run, every rank its
 shard of the (band x block) list, no data-path collective.  On a 1-GPU box the ranks share
-device 0 and rendezvous over gloo (HOMONIM_AMD_DIST_BACKEND); on a full node the same worker runs one rank per GPU over
-RCCL.
+device 0 (HOMONIM_AMD_DIST_BACKEND=host); on a full node the same worker runs one rank per GPU and joins the library's RCCL
+communicator.  The ranks meet over loopback TCP (homonim_amd/dist.py): no tensor library on either path.
 """
 import os
 import subprocess
@@ -32,7 +32,7 @@ def _same(a, b):
 @pytest.mark.parametrize('model, k, contiguous', [('gain-offset', 5, False), ('gain-blk-offset', 5, True)])
 def test_two_ranks_process_their_shards_and_the_union_is_the_single_rank_result(tmp_path, model, k, contiguous):
     from homonim_amd.fuse import RasterFuse
-    env = dict(os.environ, HOMONIM_AMD_DIST_BACKEND='gloo', MASTER_ADDR='127.0.0.1', PYTHONPATH=REPO)
+    env = dict(os.environ, HOMONIM_AMD_DIST_BACKEND='host', MASTER_ADDR='127.0.0.1', PYTHONPATH=REPO)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', str(29600 + (os.getpid() + k + contiguous) % 300), os.path.join(REPO, 'tests', '_rank_worker.py'),
            str(tmp_path), model, str(k), '1' if contiguous else '0']
@@ -74,8 +74,8 @@ def test_two_contexts_in_one_process_share_the_block_list(ctx_unused=None):
 
 def test_bench_joins_an_rccl_group_of_one():
     """ The driver's N > 1 launch is `python -m torch.distributed.run ... bench.py --gpus N` over RCCL.  A 1-GPU box can
-    still run that plumbing with a group of one: torch's HIP runtime and the library's share the device, the group is
-    created on it (backend nccl = RCCL), the barrier and the MAX / SUM reductions run on device tensors. """
+    still run that plumbing with a launch of one rank: the rank sets the rendezvous up alone, joins the library's RCCL
+    communicator (a communicator of one) and all-reduces a word on it. """
     import json
     env = dict(os.environ, HOMONIM_AMD_DIST_FORCE='1', MASTER_ADDR='127.0.0.1', PYTHONPATH=REPO)
     env.pop('HOMONIM_AMD_DIST_BACKEND', None)
@@ -86,17 +86,17 @@ def test_bench_joins_an_rccl_group_of_one():
     assert run.returncode == 0, run.stderr[-3000:]
     line = json.loads(run.stdout.strip().splitlines()[-1])
     assert line['n_gpus'] == 1 and line['value'] > 0 and line['parity_spot_check']['passed']
-    assert line.get('dist_backend') == 'nccl'
+    assert line.get('dist_backend') == 'rccl'
     assert line.get('rccl_ranks') == 1   # the library's own communicator (hk_comm_info) stands and its all-reduce ran
 
 
 @pytest.mark.parametrize('config', [1, 3])
 def test_bench_with_two_ranks(config):
     """ `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` as the driver launches it, the two ranks sharing
-    this box's GPU over gloo: config 1 = one raster per rank (weak scaling, the value counts both), config 3 = the block
+    this box's GPU (backend 'host'): config 1 = one raster per rank (weak scaling, the value counts both), config 3 = the block
     positions split between the ranks (strong scaling).  Rank 0 prints the one JSON line. """
     import json
-    env = dict(os.environ, HOMONIM_AMD_DIST_BACKEND='gloo', MASTER_ADDR='127.0.0.1', PYTHONPATH=REPO)
+    env = dict(os.environ, HOMONIM_AMD_DIST_BACKEND='host', MASTER_ADDR='127.0.0.1', PYTHONPATH=REPO)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', str(29700 + (os.getpid() + config) % 200), os.path.join(REPO, 'bench.py'), '--gpus', '2',
            '--config', str(config), '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--no-end-to-end']
@@ -108,7 +108,7 @@ def test_bench_with_two_ranks(config):
     assert len(lines) == 1
     line = json.loads(lines[0])
     assert line['n_gpus'] == 2 and line['value'] > 0 and line['parity_spot_check']['passed']
-    assert line['scaling'] == ('weak' if config == 1 else 'strong') and line['dist_backend'] == 'gloo'
+    assert line['scaling'] == ('weak' if config == 1 else 'strong') and line['dist_backend'] == 'host'
 
 
 def test_bench_refuses_a_rank_count_that_disagrees_with_the_launch():
@@ -121,9 +121,9 @@ def test_bench_refuses_a_rank_count_that_disagrees_with_the_launch():
 def test_bench_launches_its_own_ranks():
     """ Plain `python bench.py --gpus 2` (no launcher, WORLD_SIZE unset): the parent process -- which never touches a GPU --
     starts the two ranks as child processes with the torchrun environment and relays rank 0's ONE JSON line
-    (homonim/fuse.py:394-408: one call fans out over the workers).  The ranks share this box's GPU over gloo. """
+    (homonim/fuse.py:394-408: one call fans out over the workers).  The ranks share this box's GPU (backend 'host'). """
     import json
-    env = dict(os.environ, HOMONIM_AMD_DIST_BACKEND='gloo', PYTHONPATH=REPO)
+    env = dict(os.environ, HOMONIM_AMD_DIST_BACKEND='host', PYTHONPATH=REPO)
     for key in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR'):
         env.pop(key, None)
     cmd = [sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--config', '1', '--steps', '3', '--warmup', '1',
@@ -134,4 +134,4 @@ def test_bench_launches_its_own_ranks():
     assert len(lines) == 1
     line = json.loads(lines[0])
     assert line['n_gpus'] == 2 and line['value'] > 0 and line['parity_spot_check']['passed']
-    assert line['scaling'] == 'weak' and line['dist_backend'] == 'gloo' and line['rccl_ranks'] is None
+    assert line['scaling'] == 'weak' and line['dist_backend'] == 'host' and line['rccl_ranks'] is None

@@ -70,7 +70,8 @@ import numpy as np, torch, torch.distributed as dist
 from homonim_amd import dist as hdist
 from oracle import oracle_np as onp
 from test_split_norm_cpu import _protocol
-rank, world, _ = hdist.init()
+rank, world, _ = hdist.init()          # the product's rendezvous (loopback TCP)
+dist.init_process_group(backend='gloo')  # ... and torch's gloo group for this test's all-reduce
 src, ref = onp.synth_pair(200, 300, 3, 'frame+holes')
 edges = [0, 83, 200]
 mine = onp.split_norm_slab_values(src[edges[rank]:edges[rank + 1]], np.nan, ref[edges[rank]:edges[rank + 1]], np.nan)
@@ -85,6 +86,7 @@ norm, prefixes = _protocol([mine] + [mine] * (world - 1), lambda parts: allreduc
 with open(os.path.join({out!r}, 'rank_%d.json' % rank), 'w') as f:
     json.dump(dict(rank=rank, norm=[float(v) for v in norm], prefixes=[[int(x) for x in row] for row in prefixes]), f)
 hdist.finalize()
+dist.destroy_process_group()
 '''
 
 
