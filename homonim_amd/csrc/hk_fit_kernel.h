@@ -181,7 +181,13 @@ __device__ __forceinline__ void xch_order() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 typedef double hk_d2 __attribute__((ext_vector_type(2)));
-template <int RW, typename T, bool XCH = false>
+// DPP2: the neighbours at distance 2 through two chained wave shifts (four v_mov_b32_dpp per float64 value) instead of the LDS
+// crossbar (two ds_bpermute_b32).  One ds_bpermute costs the CU 2.6 ns whichever SIMD issued it, a DPP move 0.6 ns of one SIMD's
+// issue (profiles/r05_ubench_xlane.txt): the builds whose five float64 quantities make them crossbar-bound gain, the VALU-bound ones lose.
+#ifndef HK_DPP2
+#define HK_DPP2 1
+#endif
+template <int RW, typename T, bool XCH = false, bool DPP2 = false>
 __device__ __forceinline__ void hsum(const T (&V)[PX], T (&H)[PX], int lane, [[maybe_unused]] char* xch = nullptr) {
     if constexpr (RW == 0) {
 #pragma unroll
@@ -236,10 +242,12 @@ __device__ __forceinline__ void hsum(const T (&V)[PX], T (&H)[PX], int lane, [[m
                 constexpr int k = decltype(K)::value;
                 if constexpr (need_left_at(RW, j, k)) {
                     if constexpr (j == 1) ls[k] = dpp_from_left(suf[k]);
+                    else if constexpr (j == 2 && DPP2) ls[k] = dpp_from_left(dpp_from_left(suf[k]));
                     else ls[k] = bperm_from<T>(suf[k], lane - j);
                 }
                 if constexpr (need_right_at(RW, j, k)) {
                     if constexpr (j == 1) rp[k] = dpp_from_right(pre[k]);
+                    else if constexpr (j == 2 && DPP2) rp[k] = dpp_from_right(dpp_from_right(pre[k]));
                     else rp[k] = bperm_from<T>(pre[k], lane + j);
                 }
             });
@@ -351,14 +359,14 @@ __device__ __forceinline__ void hsum_wide(const T (&V)[PX], T (&H)[PX], const Wi
     });
 }
 
-// RW >= 0: compile-time half-width; RW = -1 - E: wide kernel with rw mod 4 == E (hsum_wide)
-template <int RW, typename T, bool XCH = false>
+// RW >= 0: compile-time half-width; RW = -1 - E: wide kernel with rw mod 4 == E (hsum_wide).  DPP2: see hsum.
+template <int RW, typename T, bool XCH = false, bool DPP2 = false>
 __device__ __forceinline__ void hsum_any(const T (&V)[PX], T (&H)[PX], const WideLanes& wl, int lane, char* xch = nullptr) {
     if constexpr ((HK_ABLATE & 4) != 0) {
 #pragma unroll
         for (int i = 0; i < PX; ++i) H[i] = V[i];
     } else if constexpr (RW >= 0)
-        hsum<RW, T, XCH>(V, H, lane, xch);
+        hsum<RW, T, XCH, DPP2>(V, H, lane, xch);
     else
         hsum_wide<-1 - RW, T>(V, H, wl, lane);
 }
@@ -829,6 +837,12 @@ fit_apply_kernel(const FitArgs a_in) {
     float4* ring_v = lds4 + (size_t)wave_in_wg * (size_t)(ring_rows * (ring2p ? 2 : 1) * WAVE);
     // slots start as rows that were never added: zero contribution, no valid pixel
     constexpr int XCH = xch_mask<MODEL, RW, RING, WPB>();
+    // The 15-wide builds of `gain` and gain-offset fetch their distance-2 neighbours through two chained DPP shifts instead of
+    // ds_bpermute (hsum DPP2): 15 x 15 gain-offset + r2 mask 4.51 -> 4.44 ms dense, 4.96 -> 4.61 on NaN-nodata rasters, 5.91 -> 5.51
+    // with scattered holes, `gain` 3.08 -> 2.99; 9 - 13 wide equal or 2 % slower, gain-blk-offset (VALU-bound) 1 % slower: not those
+    // (profiles/r05_ab_dpp2_15wide.txt).  Kernels wider than 15 gain nothing from the same exchange (profiles/r05_ab_dpp_chain_wide.txt:
+    // at 31 wide the launch moves 2.16 x its algorithmic bytes through the HBM -- the re-loaded leaving rows -- and is bound there).
+    constexpr bool DPPX = HK_DPP2 && RW == 7 && MODEL != 1;
     [[maybe_unused]] char* const xch = reinterpret_cast<char*>(lds4 + (size_t)WPB * (size_t)(ring_rows * (ring2p ? 2 : 1) * WAVE)) +
                                        (size_t)wave_in_wg * XCH_BYTES + 16 + lane * 16;
     const float ring_init = DENSE ? 0.f : __uint_as_float(RING_SENTINEL);
@@ -1093,13 +1107,13 @@ fit_apply_kernel(const FitArgs a_in) {
             // one of those float64 quadruples is live beside S2 / R2 (12-16 VGPRs less at the pressure peak)
             double HS[PX], HR[PX];
             [[maybe_unused]] float Sf0[PX], Rf0[PX], Pf0[PX];
-            hsum_any<RW, double, (XCH & 1) != 0>(cs.S, HS, wl, lane, xch);
+            hsum_any<RW, double, (XCH & 1) != 0, DPPX>(cs.S, HS, wl, lane, xch);
             if constexpr (GO) {
 #pragma unroll
                 for (int i = 0; i < PX; ++i) Sf0[i] = (float)HS[i];
                 __builtin_amdgcn_sched_barrier(0);
             }
-            hsum_any<RW, double, (XCH & 2) != 0>(cs.R, HR, wl, lane, xch);
+            hsum_any<RW, double, (XCH & 2) != 0, DPPX>(cs.R, HR, wl, lane, xch);
             if constexpr (GO) {
 #pragma unroll
                 for (int i = 0; i < PX; ++i) Rf0[i] = (float)HR[i];
@@ -1107,13 +1121,13 @@ fit_apply_kernel(const FitArgs a_in) {
             }
             double HP[PX], HS2[PX], HR2[PX];
             float Nf[PX];
-            if constexpr (CS::NEED_P) hsum_any<RW, double, (XCH & 4) != 0>(cs.P, HP, wl, lane, xch);
+            if constexpr (CS::NEED_P) hsum_any<RW, double, (XCH & 4) != 0, DPPX>(cs.P, HP, wl, lane, xch);
             if constexpr (GO) {
 #pragma unroll
                 for (int i = 0; i < PX; ++i) Pf0[i] = (float)HP[i];
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if constexpr (CS::NEED_S2) hsum_any<RW, double, (XCH & 8) != 0>(cs.S2, HS2, wl, lane, xch);
+            if constexpr (CS::NEED_S2) hsum_any<RW, double, (XCH & 8) != 0, DPPX>(cs.S2, HS2, wl, lane, xch);
             // Certificate-only build: the window sum of ref^2 feeds nothing but the float32 r2-mask certificate, so its
             // horizontal stage runs in float32 on the rounded column sums (non-negative terms: <= 5 roundings, relative
             // error <= 4.03 * 2^-24 instead of 2^-24 -- DESIGN.md appendix A budgets it): four converts + nine float32 adds,
@@ -1123,9 +1137,9 @@ fit_apply_kernel(const FitArgs a_in) {
                 float V2[PX];
 #pragma unroll
                 for (int i = 0; i < PX; ++i) V2[i] = (float)cs.R2s[i];
-                hsum_any<RW, float>(V2, HR2f, wl, lane);
+                hsum_any<RW, float, false, DPPX>(V2, HR2f, wl, lane);
             } else if constexpr (CS::NEED_R2S) {
-                hsum_any<RW, double, (XCH & 16) != 0>(cs.R2s, HR2, wl, lane, xch);
+                hsum_any<RW, double, (XCH & 16) != 0, DPPX>(cs.R2s, HR2, wl, lane, xch);
                 if constexpr (CERT_ONLY) {
 #pragma unroll
                     for (int i = 0; i < PX; ++i) HR2f[i] = (float)HR2[i];
@@ -1165,7 +1179,7 @@ fit_apply_kernel(const FitArgs a_in) {
                             const int VN[PX] = {(int)(cs.N & 0xffu), (int)((cs.N >> 8) & 0xffu), (int)((cs.N >> 16) & 0xffu),
                                                 (int)(cs.N >> 24)};
                             int HN[PX];
-                            hsum_any<RW, int>(VN, HN, wl, lane);
+                            hsum_any<RW, int, false, DPPX>(VN, HN, wl, lane);
 #pragma unroll
                             for (int i = 0; i < PX; ++i) Nf[i] = (float)HN[i];
                         }

@@ -242,6 +242,16 @@ __global__ void selftest_kernel(int* result) {
     if (hsum_check<2>(lane)) code |= 16;
     if (hsum_check<3>(lane)) code |= 32;
     if (hsum_check<7>(lane)) code |= 64;
+    {   // 15 wide with the distance-2 neighbours through chained DPP shifts
+        double V[PX], Hd[PX], Hc[PX];
+#pragma unroll
+        for (int i = 0; i < PX; ++i) V[i] = (double)((lane * PX + i) * 3 + 1) + 0.5;
+        hsum<7, double>(V, Hd, lane);
+        hsum<7, double, false, true>(V, Hc, lane);
+        if (lane >= 2 && lane < WAVE - 2)
+            for (int i = 0; i < PX; ++i)
+                if (Hd[i] != Hc[i]) code |= 64;
+    }
     if (hsum_check<4>(lane) || hsum_check<5>(lane) || hsum_check<6>(lane)) code |= 256;
     // kernels wider than 15: E = rw mod 4 at compile time, F = rw / 4 at run time (F = 1 .. 6: 9 to 55 wide)
     if (hsum_wide_check<0>(lane) || hsum_wide_check<1>(lane) || hsum_wide_check<2>(lane) || hsum_wide_check<3>(lane)) code |= 128;
