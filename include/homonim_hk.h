@@ -68,8 +68,8 @@ typedef struct {
  */
 /* Version of this header's struct layouts and prototypes.  A consumer built against one header and loading a library of
  * another must not call further: structs grow at their end between versions (hk_out_window: 32 -> 40 bytes in version 3) and
- * carry no size field.  hk_abi_version() returns the library's HK_ABI_VERSION; compare it with the header's at load time. */
-#define HK_ABI_VERSION 4
+ * carry no size field; version 5 added entry points (hk_device_pci_bus_id; hk_debug_staging_counters in the devtools header).  hk_abi_version() returns the library's HK_ABI_VERSION; compare it with the header's at load time. */
+#define HK_ABI_VERSION 5
 int hk_abi_version(void);
 const char* hk_backend_name(void);            /* "hip-gfx950" */
 const char* hk_last_error(void);              /* thread-local text of the last failure */

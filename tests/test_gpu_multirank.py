@@ -135,3 +135,65 @@ def test_bench_launches_its_own_ranks():
     line = json.loads(lines[0])
     assert line['n_gpus'] == 2 and line['value'] > 0 and line['parity_spot_check']['passed']
     assert line['scaling'] == 'weak' and line['dist_backend'] == 'host' and line['rccl_ranks'] is None
+
+
+@pytest.mark.parametrize('config', [3, 4])
+def test_bench_as_rank_and_the_single_gpu_projection(config):
+    """ `bench.py --as-rank R/N` runs exactly the shard rank R of an N-rank launch would run, alone (no group, no peers), and the plain
+    single-rank line of configs 3 / 4 carries `projected_scaling_single_gpu`: every shard of an N = 2 / 4 / 8 launch timed alone --
+    labelled a projection, never `value`, never a scaling claim.  (homonim/fuse.py:394-408, raster_pair.py:379-428: the work items the
+    ranks split.) """
+    import json
+    env = dict(os.environ, PYTHONPATH=REPO)
+    for key in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR'):
+        env.pop(key, None)
+    small = ['--size', '8192', '--bands', '2'] if config == 3 else ['--size', '1024', '--tiles', '16']
+    base = [sys.executable, os.path.join(REPO, 'bench.py'), '--config', str(config), '--steps', '2', '--warmup', '1', '--no-cpu-baseline',
+            '--no-end-to-end'] + small
+    run = subprocess.run(base, env=env, capture_output=True, text=True, timeout=900)
+    assert run.returncode == 0, run.stderr[-3000:]
+    line = json.loads([ln for ln in run.stdout.strip().splitlines() if ln.startswith('{')][-1])
+    proj = line['projected_scaling_single_gpu']
+    assert 'PROJECTION' in proj['kind'] and set(proj['by_world_size']) == {'2', '4', '8'}
+    for n, rec in proj['by_world_size'].items():
+        assert len(rec['shard_ms']) == int(n) and rec['max_shard_ms'] == max(rec['shard_ms'])
+        assert rec['projected_speedup'] == pytest.approx(proj['t1_ms'] / rec['max_shard_ms'], rel=1e-3)
+    assert line['scaling'] == 'strong' and line['n_gpus'] == 1 and 'host_placement' in line
+    # one rank of four, alone
+    run = subprocess.run(base + ['--as-rank', '1/4'], env=env, capture_output=True, text=True, timeout=900)
+    assert run.returncode == 0, run.stderr[-3000:]
+    solo = json.loads([ln for ln in run.stdout.strip().splitlines() if ln.startswith('{')][-1])
+    assert solo['config']['as_rank']['rank'] == 1 and solo['config']['as_rank']['of'] == 4
+    assert 'alone' in solo['scaling'] and 'projected_scaling_single_gpu' not in solo
+    assert solo['parity_spot_check'] is None or solo['parity_spot_check']['passed']
+    # its rate is what THIS GPU did on a quarter of the work, not a whole-job figure
+    whole = line['value'] * line['ms_per_step']
+    assert solo['value'] * solo['ms_per_step'] == pytest.approx(whole / 4, rel=0.3)
+    # and the argument is refused where it has no meaning
+    bad = subprocess.run(base[:2] + ['--config', '2', '--as-rank', '0/2'], env=env, capture_output=True, text=True, timeout=120)
+    assert bad.returncode == 2
+
+
+def test_rank_binds_to_the_numa_node_of_its_gpu():
+    """ homonim_amd/topology.py on the box: the library names the GPU's PCI address, sysfs its NUMA node; when sysfs says, every thread
+    of the process ends up on that node's CPUs (a box that does not say is left alone, with the reason in the record). """
+    from homonim_amd import topology
+    before = os.sched_getaffinity(0)
+    try:
+        bus = _hk.device_pci_bus_id(0)
+        assert len(bus) >= 12 and bus == bus.lower() and bus.count(':') == 2
+        rec = topology.bind_to_device(0)
+        assert rec['bus_id'] == bus
+        if rec['bound']:
+            assert rec['numa_node'] is not None and set(os.sched_getaffinity(0)) == set(rec['cpus']) and rec['threads'] >= 1
+            for tid in os.listdir('/proc/self/task'):
+                assert set(os.sched_getaffinity(int(tid))) <= set(rec['cpus'])
+        else:
+            assert rec['reason']
+        assert topology.summary(rec)['bus_id'] == bus
+    finally:
+        for tid in os.listdir('/proc/self/task'):
+            try:
+                os.sched_setaffinity(int(tid), before)
+            except OSError:
+                pass
