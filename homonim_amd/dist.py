@@ -26,7 +26,7 @@ import time
 from typing import List, Optional, Tuple
 
 _state = dict(initialised=False, world=1, rank=0, local_rank=0, backend=None, server=None, peers=None, sock=None)
-_TIMEOUT = 180.0
+_TIMEOUT = 900.0   # a rank may sit in a barrier while rank 0 times its CPU baseline; a lost peer still ends the wait
 
 
 def env_ranks() -> Tuple[int, int, int]:
