@@ -932,9 +932,15 @@ def end_to_end_tiles(args, ctx, dist, tiles, stride, band_stride, thresh, nd):
         if len(host) < 2:
             return dict(skipped=f'page-locked host tiles could not be allocated: {ex}')
     distinct = len(host)
+    # Four tiles in flight x two block threads each on a context of eight streams (round 5; two tiles on four streams left the link
+    # idle at every tile's end: 5.2 -> 6.3 Gpixel*bands/s = 41.6 -> 50.3 GB/s host-to-device, same box).  The resident part of the
+    # configuration keeps its four streams; this pass has a context of its own.
+    in_flight = int(os.environ.get('HK_BENCH_E2E_TILES', '4'))
+    blk_threads = int(os.environ.get('HK_BENCH_E2E_THREADS', '2'))
+    n_e2e_streams = int(os.environ.get('HK_BENCH_E2E_STREAMS', '8'))
     kw = dict(model=args.model, kernel_shape=(args.kernel, args.kernel), model_config=dict(r2_inpaint_thresh=thresh),
-              block_config=dict(threads=2, max_block_mem=100),
-              device_config=dict(devices=[ctx.device], streams=ctx.n_streams, pin=False))
+              block_config=dict(threads=blk_threads, max_block_mem=100),
+              device_config=dict(devices=[ctx.device], streams=n_e2e_streams, pin=False))
 
     def one(j):
         s, r, o = host[j % distinct]
@@ -942,7 +948,7 @@ def end_to_end_tiles(args, ctx, dist, tiles, stride, band_stride, thresh, nd):
             warnings.simplefilter('ignore')
             RasterFuse(s[:, :, :n], r[:, :, :n], src_nodata=nd, ref_nodata=nd).process(corr_out=o[:, :, :n] if stride == n else None, **kw)
 
-    with ThreadPoolExecutor(2) as ex:  # two tiles in flight x two block threads each = the context's four streams
+    with ThreadPoolExecutor(in_flight) as ex:
         list(ex.map(one, range(min(len(tiles), 4))))  # warm-up: grows the per-stream device slabs
         dist.barrier()
         t0 = time.perf_counter()
@@ -951,7 +957,7 @@ def end_to_end_tiles(args, ctx, dist, tiles, stride, band_stride, thresh, nd):
         dt = dist.max_over_ranks(time.perf_counter() - t0)
     px = args.tiles * n * n * B
     res = dict(value=round(px / dt / 1e6, 1), unit='Mpixels*bands/s', seconds=round(dt, 4), distinct_host_tiles=distinct,
-               path='RasterFuse.process per tile: page-locked host rasters -> H2D || fused kernel || D2H, 2 tiles x 2 block threads on 4 streams per GPU',
+               path=f'RasterFuse.process per tile: page-locked host rasters -> H2D || fused kernel || D2H, {in_flight} tiles x {blk_threads} block threads on {n_e2e_streams} streams per GPU',
                pcie_gbps_in=round(8 * px / dt / 1e9, 1), pcie_gbps_out=round(4 * px / dt / 1e9, 1))
     del host
     return res
