@@ -864,7 +864,9 @@ fit_apply_kernel(const FitArgs a_in) {
     }
     // wave-uniform: bit k = the row in ring slot k is `clean` (inside the raster, every pixel of the strip valid) and is
     // stored as it was loaded; the other rows carry RING_SENTINEL in place of their invalid source pixels
+    // (64 slots: a centre ring of more rows -- kernels 129 to 255 rows tall -- marks no row clean and decodes every one the long way)
     [[maybe_unused]] unsigned long long ring_clean = 0ull;
+    [[maybe_unused]] const bool clean_bits_ok = ring_rows <= 64;
     auto ring_encode = [&](const RowZ& z) {
         if constexpr (DENSE) return make_float4(z.s[0], z.s[1], z.s[2], z.s[3]);
         else return make_float4(z.e[0], z.e[1], z.e[2], z.e[3]);
@@ -1067,7 +1069,9 @@ fit_apply_kernel(const FitArgs a_in) {
             zold = process_row<MODEL, DENSE, MODEL == 1 && R2>(qo, t_old >= t_first && t_old >= 0 && t_old < H, colbits, full_wave, ts, tr, n0, n1);
             if constexpr (cring) {  // slot2 cycles over rh + 1 rows: the entering row replaces the centre row of rh + 1 ago
                 ring_v[slot2 * WAVE + lane] = ring_encode(znew);
-                if constexpr (!DENSE) ring_clean = (ring_clean & ~(1ull << slot2)) | ((unsigned long long)znew.clean << slot2);
+                if constexpr (!DENSE) {
+                    if (clean_bits_ok) ring_clean = (ring_clean & ~(1ull << slot2)) | ((unsigned long long)znew.clean << slot2);
+                }
             }
         }
 
@@ -1093,7 +1097,7 @@ fit_apply_kernel(const FitArgs a_in) {
                 int cs_slot = slot_c;
                 if constexpr (cring) cs_slot = slot2 + 1 == rh + 1 ? 0 : slot2 + 1;
                 const float4 cs4 = ring ? ring_v[(cs_slot * 2 + 0) * WAVE + lane] : ring_v[cs_slot * WAVE + lane];
-                ring_decode(cs4, (ring_clean >> cs_slot) & 1ull, sc, mc);
+                ring_decode(cs4, clean_bits_ok && ((ring_clean >> (cs_slot & 63)) & 1ull), sc, mc);
             } else {
                 const RowZ zc = process_row<MODEL, DENSE, MODEL == 1 && R2>(qc, true, colbits, full_wave, ts, tr, n0, n1);
 #pragma unroll

@@ -185,6 +185,26 @@ def test_kernels_wider_than_15_vs_oracle(ctx, oc, model, find_r2, thresh, kernel
             assert n_fail_f == (exp_fail if thresh is not None else 0)
 
 
+@pytest.mark.parametrize('model, find_r2, thresh', [('gain', False, None), ('gain-blk-offset', True, None), ('gain-offset', False, 0.25),
+                                                    ('gain-offset', True, None)])
+@pytest.mark.parametrize('kernel_shape', [(63, 5), (129, 3), (35, 7), (255, 1), (33, 9), (61, 15)])
+def test_tall_kernels_vs_oracle(ctx, oc, model, find_r2, thresh, kernel_shape):
+    """ Kernels taller than the centre ring's default limit (31 rows): up to 7 wide they keep the centre ring whatever their height (1 KB
+    of LDS per wave and row of the half-height: 128 KB at 255 rows, one wave per CU), from 9 wide both rows are re-loaded (ring mode 0:
+    the builds of hsum_wide, also for the 9 - 15 wide kernels that have compile-time builds otherwise).  utils.validate_kernel_shape
+    admits any odd shape (utils.py:104-133). """
+    h, w = 300, 700
+    src, ref = onp.synth_pair(h, w, seed=kernel_shape[0] + kernel_shape[1], nodata_variant='frame+holes')
+    cfg = dict(model=model, kernel_shape=kernel_shape, find_r2=find_r2, r2_inpaint_thresh=thresh, src_nodata=np.nan, ref_nodata=np.nan)
+    norm_in = onp.fit_block_norm(src, np.nan, ref, np.nan) if model == 'gain-blk-offset' else None
+    exp_params, exp_corr, exp_fail = oc.fit_apply(model, src, np.nan, ref, np.nan, kernel_shape, find_r2, thresh, norm_model=norm_in)
+    params, corr, norm, n_fail = _fit_via_abi(ctx, cfg, src, ref, norm_in=norm_in)
+    assert_close_ulp(params, exp_params, 'params')
+    assert_close_ulp(corr, exp_corr, 'corrected')
+    if thresh is not None:
+        assert n_fail == exp_fail
+
+
 @pytest.mark.parametrize('seed', range(120))
 def test_randomized_configurations_vs_oracle(ctx, oc, seed):
     """ A seeded sweep over the configuration space (model, odd kernel shape up to 17 x 17, R2 output, threshold, the

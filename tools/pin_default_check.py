@@ -7,13 +7,15 @@ n, B = 8192, 4
 rng = np.random.default_rng(0)
 src = rng.random((B, n, n), dtype=np.float32) + 0.05
 ref = (1.2 * src + 0.05).astype(np.float32)
+import os
+THREADS = int(os.environ.get("T", "4"))
 for pin in (False, True, False, True):
     out = np.empty((B, n, n), np.float32)
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
         rf = RasterFuse(src, ref)
-        kw = dict(model='gain-offset', kernel_shape=(5, 5), model_config=dict(r2_inpaint_thresh=0.25), block_config=dict(threads=4, max_block_mem=100),
-                  device_config=dict(streams=4, pin=pin), corr_out=out)
+        kw = dict(model='gain-offset', kernel_shape=(5, 5), model_config=dict(r2_inpaint_thresh=0.25), block_config=dict(threads=THREADS, max_block_mem=int(os.environ.get("MB", "100"))),
+                  device_config=dict(streams=int(os.environ.get("S", "4")), pin=pin), corr_out=out)
         rf.process(**kw)
         t0 = time.perf_counter(); rf.process(**kw); dt = time.perf_counter() - t0
     print(f'pin={pin}: {dt*1e3:.1f} ms  {B*n*n/dt/1e6:.0f} Mpx*b/s')
