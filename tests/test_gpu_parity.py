@@ -187,9 +187,11 @@ def test_kernels_wider_than_15_vs_oracle(ctx, oc, model, find_r2, thresh, kernel
 
 @pytest.mark.parametrize('model, find_r2, thresh', [('gain', False, None), ('gain-blk-offset', True, None), ('gain-offset', False, 0.25),
                                                     ('gain-offset', True, None)])
-@pytest.mark.parametrize('kernel_shape', [(63, 5), (129, 3), (35, 7), (255, 1), (33, 9), (61, 15)])
+@pytest.mark.parametrize('kernel_shape', [(63, 5), (129, 3), (35, 7), (255, 1), (33, 9), (61, 15), (5, 151), (9, 193), (3, 101), (1, 63), (41, 57)])
 def test_tall_kernels_vs_oracle(ctx, oc, model, find_r2, thresh, kernel_shape):
-    """ Kernels taller than the centre ring's default limit (31 rows): up to 7 wide they keep the centre ring whatever their height (1 KB
+    """ The extremes of the shape space: very wide kernels (up to the 193 columns a strip's overlap lanes allow: 24 whole neighbour lanes
+    per side, window counts beyond the 1/N table), a single row, and kernels taller than the centre ring's default limit (31 rows): up to
+    7 wide they keep the centre ring whatever their height (1 KB
     of LDS per wave and row of the half-height: 128 KB at 255 rows, one wave per CU), from 9 wide both rows are re-loaded (ring mode 0:
     the builds of hsum_wide, also for the 9 - 15 wide kernels that have compile-time builds otherwise).  utils.validate_kernel_shape
     admits any odd shape (utils.py:104-133). """
