@@ -36,16 +36,19 @@ __global__ void __launch_bounds__(256) inpaint_flag_kernel(const float* __restri
     }
 }
 
-// Column table: per pixel two DISTANCES in one 16-bit word -- low byte: rows up to the nearest source at-or-above
-// (0..max_dist), high byte: rows down to the nearest source strictly below (1..max_dist + 1), NONE_B when there is none in
-// reach (max_dist = 100, rasterio's default; the bytes hold up to 253).  The search reads the source's value from the
-// offset plane itself.  GDAL carries both as the state of two sequential column scans; "the nearest source within reach" is
+// Column table: per pixel two SQUARED row distances in one 32-bit word (round 5; rounds 1-4: the distances as two bytes) -- low
+// half: rows up to the nearest source at-or-above (0..max_dist), squared; high half: rows down to the nearest source strictly
+// below (1..max_dist + 1), squared; NONE_SQ when there is none in reach (max_dist = 100, rasterio's default).  A candidate test
+// of the search then needs no multiplication and no separate row-distance field: its key is (entry half << 15) + a per-step
+// constant (fill_one), five instructions instead of seven; the row distance comes back as an exact square root at the finish.
+// The search reads the source's value from the offset plane itself.  GDAL carries both as the state of two sequential column scans; "the nearest source within reach" is
 // the same thing without the sequence: the flags of a column are packed into 64-row bit words (inpaint_bits_kernel: 64
 // independent byte loads per thread), and every pixel finds its two distances with clz / ctz on at most three words per
 // direction (inpaint_table_kernel: one thread per column and word, no memory access inside its 64-row loop).  The
 // sequential form (one thread per column and 64-row chunk, 100 rows of run-in per direction) took 1.15 ms per 16384^2
 // band whatever its chunk height, load width or unrolling: its loads sit behind data-dependent state updates.
-constexpr unsigned NONE_B = 0xffu;
+constexpr unsigned NONE_B = 0xffu;      // (row-distance byte of the table kernel's sweeps: none in reach)
+constexpr unsigned NONE_SQ = 0x7fffu;  // squared-distance half of a table entry: none in reach (beats nothing: > 2 * 101^2)
 constexpr int WORD_ROWS = 64;
 
 __global__ void __launch_bounds__(256) inpaint_bits_kernel(const unsigned char* __restrict__ flag, long long stride, int height,
@@ -75,9 +78,9 @@ __global__ void __launch_bounds__(256) inpaint_bits_kernel(const unsigned char* 
 
 __global__ void __launch_bounds__(256) inpaint_table_kernel(const unsigned long long* __restrict__ bits, long long stride,
                                                             int height, int width, int max_dist,
-                                                            unsigned short* __restrict__ tb) {
-    // a thread makes the entries of TWO adjacent columns and stores them as one 4-byte word per row (rows are 4-byte aligned and
-    // padded: stride % 4 == 0) -- half the store instructions (measured neutral: the kernel is bound by its 64-row loop)
+                                                            unsigned* __restrict__ tb) {
+    // a thread makes the entries of TWO adjacent columns and stores them as one 8-byte pair per row (rows are padded: stride % 4 == 0;
+    // the table starts 256-byte aligned)
     const int x = (blockIdx.x * blockDim.x + threadIdx.x) * 2;
     if (x >= width) return;
     const int wb = blockIdx.y, n_words = (height + WORD_ROWS - 1) / WORD_ROWS;
@@ -120,11 +123,12 @@ __global__ void __launch_bounds__(256) inpaint_table_kernel(const unsigned long 
         for (int c = 0; c < 2; ++c) {
             if (bb < WORD_ROWS - 1) d[c] = ((w0[c] >> (bb + 1)) & 1ull) ? 1 : min(d[c] + 1, BIG);
             const unsigned ub = (upk[c][bb >> 2] >> (8 * (bb & 3))) & 0xffu;
-            const unsigned db = d[c] <= max_dist + 1 ? (unsigned)d[c] : NONE_B;
-            e[c] = (db << 8) | ub;
+            const unsigned usq = ub == NONE_B ? NONE_SQ : (unsigned)HK_SQ((int)ub);
+            const unsigned dsq = d[c] <= max_dist + 1 ? (unsigned)HK_SQ(d[c]) : NONE_SQ;
+            e[c] = (dsq << 16) | usq;
         }
         // the second column may lie in the row padding (odd width): its word of `bits` was never written, its entry is never read
-        if (bb < rows) *reinterpret_cast<unsigned*>(tb + (long long)(y0 + bb) * stride + x) = e[0] | (e[1] << 16);
+        if (bb < rows) *reinterpret_cast<uint2*>(tb + (long long)(y0 + bb) * stride + x) = make_uint2(e[0], e[1]);
     }
 }
 
@@ -161,20 +165,15 @@ __device__ __forceinline__ int isqrt_floor(int n) {
 }
 
 template <bool INTERIOR = false>
-__device__ __forceinline__ void fill_load_d0(const unsigned short* __restrict__ trow, int x, int width, unsigned (&d0)[5]) {
-    struct __attribute__((packed, aligned(2))) W5 { unsigned w[5]; };
+__device__ __forceinline__ void fill_load_d0(const unsigned* __restrict__ trow, int x, int width, unsigned (&d0)[10]) {
+    struct __attribute__((packed, aligned(4))) W10 { unsigned w[10]; };
     if (INTERIOR || (x - 4 >= 0 && x + 5 < width)) {
-        const W5 v = *reinterpret_cast<const W5*>(trow + x - 4);
+        const W10 v = *reinterpret_cast<const W10*>(trow + x - 4);
 #pragma unroll
-        for (int j = 0; j < 5; ++j) d0[j] = v.w[j];
+        for (int j = 0; j < 10; ++j) d0[j] = v.w[j];
     } else {  // GDAL's clamp: it re-checks the edge column
 #pragma unroll
-        for (int j = 0; j < 5; ++j) d0[j] = 0u;
-#pragma unroll
-        for (int j = 0; j < 9; ++j) {
-            const int col = j < 4 ? max(0, x - 4 + j) : min(width - 1, x - 4 + j);
-            d0[j >> 1] |= (unsigned)trow[col] << ((j & 1) * 16);
-        }
+        for (int j = 0; j < 10; ++j) d0[j] = trow[j < 4 ? max(0, x - 4 + j) : min(width - 1, x - 4 + j)];
     }
 }
 
@@ -184,31 +183,32 @@ __device__ __forceinline__ void fill_load_d0(const unsigned short* __restrict__ 
 // their per-lane squares and the entry-by-entry table reads fall away.
 template <bool INTERIOR = false>
 __device__ __forceinline__ float fill_one(int x, int y, long long row, const float* __restrict__ offset, long long stride, int width,
-                                          int max_dist, const unsigned short* __restrict__ tb, const unsigned* __restrict__ tie,
+                                          int max_dist, const unsigned* __restrict__ tb, const unsigned* __restrict__ tie,
                                           const double* __restrict__ wtab) {
         const long long i = row + x;
         float out = offset[i];  // a target without any source in reach keeps its value
         const int none2 = (max_dist + 1) * (max_dist + 1);  // qd = max_dist + 1: "nothing found yet" (a perfect square: no tie)
-        // Per quadrant the search state is two KEYS (round 4): (squared distance << 15) | source word, the source word being
-        // (column distance << 8) | row distance (15 bits; the squared distance of any table byte and column step fits 17).  The
-        // smallest key is the FIRST candidate met at the best distance (steps ascend, so among equal distances the smallest
-        // column distance came first), the smallest key with the source word's bits inverted is the LAST one: two unsigned
-        // minima per candidate instead of two compares and three selects.  A candidate that does not beat "nothing found yet"
-        // leaves the initial keys in place; quadrants whose best distance exceeds max_dist are dropped at the end as before.
+        // Per quadrant the search state is two KEYS (round 4): (squared distance << 15) | (column distance << 8).  The smallest key
+        // is the FIRST candidate met at the best distance (steps ascend, so among equal distances the smallest column distance came
+        // first), the smallest key with the low 15 bits inverted is the LAST one: two unsigned minima per candidate instead of two
+        // compares and three selects.  A candidate that does not beat "nothing found yet" leaves the initial keys in place; quadrants
+        // whose best distance exceeds max_dist are dropped at the end as before.  (Round 5: the table holds SQUARED row distances, so a
+        // candidate's key is one shift-add of its table half and the step's constant; the row distance of the winner is the exact
+        // square root of what is left of its squared distance at the finish.)
         constexpr unsigned SRC_BITS = 15u, SRC_MASK = (1u << SRC_BITS) - 1u;
         unsigned kf[4], kl[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) kf[q] = kl[q] = ((unsigned)none2 << SRC_BITS) | SRC_MASK;
-        const unsigned short* __restrict__ trow = tb + row;
-        // GDAL's QUAD_CHECK on squared integer distances.  `dist` is the column table's byte: NONE_B (no source in reach)
-        // squares to more than any distance the search accepts and more than the initial (max_dist + 1)^2, so it never wins.
+        const unsigned* __restrict__ trow = tb + row;
+        // GDAL's QUAD_CHECK on squared integer distances.  `sq` is the column table's half word: NONE_SQ (no source in reach) is more
+        // than any squared distance the search accepts and more than the initial (max_dist + 1)^2, so it never wins.
         // A candidate at the SAME squared distance replaces the holder iff GDAL's float comparison says so for that distance (the
         // `tie` bit of c) -- a property of c alone: with the bit set the last candidate met at the best distance wins, without it
-        // the first.  So the search keeps both, branch-free (two compares, three selects), and the bit is looked up once per
-        // quadrant at the end instead of behind a divergent branch in every one of the 34 candidate tests.
+        // the first.  So the search keeps both, branch-free, and the bit is looked up once per quadrant at the end instead of behind
+        // a divergent branch in every one of the 34 candidate tests.
         // dxk = (dx^2 << 15) | (dx << 8): the step's share of the key (wave-uniform away from the raster's edge columns)
-        auto consider = [&](int q, unsigned dist, unsigned dxk) {
-            const unsigned key = ((unsigned)HK_SQ((int)dist) << SRC_BITS) + (dxk + dist);
+        auto consider = [&](int q, unsigned sq, unsigned dxk) {
+            const unsigned key = (sq << SRC_BITS) + dxk;
             kf[q] = min(kf[q], key);
             kl[q] = min(kl[q], key ^ SRC_MASK);
         };
@@ -224,29 +224,29 @@ __device__ __forceinline__ float fill_one(int x, int y, long long row, const flo
         // Lanes whose group reaches past the raster's edge columns assemble the same words entry by entry with GDAL's clamp
         // (it re-checks the edge column).
         {
-            struct __attribute__((packed, aligned(2))) W2 { unsigned w[2]; };
-            // entry j (0-based) of a packed run of 16-bit table words: (down << 8) | up
-            auto up = [](const unsigned* d, int j) { return (d[j >> 1] >> ((j & 1) * 16)) & 0xffu; };
-            auto dn = [](const unsigned* d, int j) { return (d[j >> 1] >> ((j & 1) * 16 + 8)) & 0xffu; };
-            unsigned d0[5];                  // entries 0..9 <-> columns x - 4 .. x + 5 (steps 0..4: left step k = entry 4 - k, right = 4 + k)
+            struct __attribute__((packed, aligned(4))) W4 { unsigned w[4]; };
+            // entry j of a run of table words: low half = squared distance up, high half = squared distance down
+            auto up = [](const unsigned* d, int j) { return d[j] & 0xffffu; };
+            auto dn = [](const unsigned* d, int j) { return d[j] >> 16; };
+            unsigned d0[10];                 // entries 0..9 <-> columns x - 4 .. x + 5 (steps 0..4: left step k = entry 4 - k, right = 4 + k)
             fill_load_d0<INTERIOR>(trow, x, width, d0);
             // later groups (steps first .. first + 3): left entries 0..3 <-> columns x - first - 3 .. x - first (step first + k = entry
             // 3 - k), right entries 0..3 <-> columns x + first .. x + first + 3 (step first + k = entry k)
-            auto fetch4 = [&](int first, unsigned (&l)[2], unsigned (&r)[2]) {
+            auto fetch4 = [&](int first, unsigned (&l)[4], unsigned (&r)[4]) {
                 if (INTERIOR || (x - first - 3 >= 0 && x + first + 3 < width)) {
-                    const W2 lv = *reinterpret_cast<const W2*>(trow + x - first - 3);
-                    const W2 rv = *reinterpret_cast<const W2*>(trow + x + first);
-                    l[0] = lv.w[0], l[1] = lv.w[1], r[0] = rv.w[0], r[1] = rv.w[1];
+                    const W4 lv = *reinterpret_cast<const W4*>(trow + x - first - 3);
+                    const W4 rv = *reinterpret_cast<const W4*>(trow + x + first);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) l[j] = lv.w[j], r[j] = rv.w[j];
                 } else {
-                    l[0] = l[1] = r[0] = r[1] = 0u;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        l[j >> 1] |= (unsigned)trow[max(0, x - first - 3 + j)] << ((j & 1) * 16);
-                        r[j >> 1] |= (unsigned)trow[min(width - 1, x + first + j)] << ((j & 1) * 16);
+                        l[j] = trow[max(0, x - first - 3 + j)];
+                        r[j] = trow[min(width - 1, x + first + j)];
                     }
                 }
             };
-            unsigned nl[2], nr[2];
+            unsigned nl[4], nr[4];
             fetch4(5, nl, nr);
             int this_max = max_dist;
             {   // steps 0 .. 4
@@ -275,7 +275,7 @@ __device__ __forceinline__ float fill_one(int x, int y, long long row, const flo
                 // so GDAL's bound only ever decides when to STOP, and a per-step predicate (an exec-mask round trip per step) buys
                 // nothing.  Groups start at 5, 9, ..., 97: no step beyond max_dist = 100.
                 const int last = first + 3;
-                const unsigned cl[2] = {nl[0], nl[1]}, cr[2] = {nr[0], nr[1]};
+                const unsigned cl[4] = {nl[0], nl[1], nl[2], nl[3]}, cr[4] = {nr[0], nr[1], nr[2], nr[3]};
                 fetch4(first + 4, nl, nr);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -307,7 +307,8 @@ __device__ __forceinline__ float fill_one(int x, int y, long long row, const flo
             ok4[q] = qd2 <= max_dist * max_dist;  // qd <= max_dist
             const int cq = ok4[q] ? qd2 : 0;
             const unsigned src = ((tie[cq >> 5] >> (cq & 31)) & 1u) ? ((kl[q] & SRC_MASK) ^ SRC_MASK) : (kf[q] & SRC_MASK);  // (the 1.3 KB bitmap stays in cache)
-            const int dx = ok4[q] ? (int)(src >> 8) : 0, dy = ok4[q] ? (int)(src & 0xffu) : 0;
+            const int dx = ok4[q] ? (int)(src >> 8) : 0;
+            const int dy = (int)__fsqrt_rn((float)(cq - dx * dx));  // exact: a perfect square <= 101^2 (0 for a quadrant that is dropped)
             const int sx = q < 2 ? x - dx : x + dx, sy = (q & 1) ? y + dy : y - dy;
             w4[q] = wtab[cq];
             v4[q] = offset[(long long)sy * stride + sx];
@@ -336,7 +337,7 @@ __device__ __forceinline__ float fill_one(int x, int y, long long row, const flo
 template <bool PACK>
 __global__ void __launch_bounds__(256, PACK ? 8 : HK_FILL_WAVES_FULL) inpaint_fill_kernel(const float* __restrict__ offset, const unsigned char* __restrict__ flag,
                                                            long long stride, int height, int width, int max_dist,
-                                                           const unsigned short* __restrict__ tb,
+                                                           const unsigned* __restrict__ tb,
                                                            const unsigned* __restrict__ tie,
                                                            const double* __restrict__ wtab, float* __restrict__ filled) {
     // Only target pixels search.  PACK (moderate failure rates: the targets are a minority scattered over the lanes): the
@@ -394,7 +395,7 @@ template <int ROWS>
 __global__ void __launch_bounds__(256, (ROWS <= 32 ? HK_FILL_TILE_WAVES : 5))  // (64-row tiles: the target lists' 32 KB of LDS per workgroup allow five)
 inpaint_fill_tile_kernel(const float* __restrict__ offset, const unsigned char* __restrict__ flag,
                                                                    long long stride, int height, int width, int max_dist_arg,
-                                                                   const unsigned short* __restrict__ tb,
+                                                                   const unsigned* __restrict__ tb,
                                                                    const unsigned* __restrict__ tie,
                                                                    const double* __restrict__ wtab, float* __restrict__ filled) {
     static_assert(ROWS <= 64, "a list entry packs the tile row beside the lane; the row masks are 64-bit");
@@ -463,7 +464,7 @@ hipError_t launch_inpaint_offsets(const float* offset, const float* gain, const 
                                   int height, int width, void* workspace, float* filled, hipStream_t stream,
                                   const unsigned char* flag_ready, unsigned long long n_targets) {
     const size_t plane = (size_t)height * stride;
-    unsigned short* tb = static_cast<unsigned short*>(workspace);  // (down << 8) | up row distances, 2 bytes per pixel
+    unsigned* tb = static_cast<unsigned*>(workspace);  // (down^2 << 16) | up^2 row distances, 4 bytes per pixel
     unsigned char* ws_flag = inpaint_flag_plane(workspace, height, stride);
     const unsigned char* flag = flag_ready ? flag_ready : ws_flag;
     unsigned* tie = reinterpret_cast<unsigned*>(ws_flag + (plane + 255) / 256 * 256);
