@@ -6,7 +6,8 @@ The hot path has NO data-path collective: (band x block) work items are independ
 works on its own shard and the only exchanges are a barrier and scalar reductions for timing / bookkeeping.  Since round 5 they
 need no tensor library: the ranks of ONE node meet over loopback TCP --
 
-* rank 0 listens on an ephemeral port of 127.0.0.1 and publishes it through a small file in the temporary directory, named after
+* rank 0 listens on an ephemeral port of 127.0.0.1 and publishes it through a small file in a private (0700) directory under the
+  temporary directory, named after
   the launch (MASTER_PORT / TORCHELASTIC_RUN_ID / HOMONIM_AMD_LAUNCH_ID) and exchanged with the nonce handshake of
   ``_file_rendezvous`` (a file an earlier, crashed launch left behind is never taken for this launch's);
 * ``barrier`` / ``max_over_ranks`` / ``sum_over_ranks`` are a gather to rank 0 and a reply to everybody (N - 1 small messages each
@@ -38,6 +39,21 @@ def env_ranks() -> Tuple[int, int, int]:
 def _launch_token() -> str:
     parts = [os.environ.get(k, '') for k in ('MASTER_PORT', 'TORCHELASTIC_RUN_ID', 'HOMONIM_AMD_LAUNCH_ID')]
     return '_'.join(''.join(c if c.isalnum() else '-' for c in p) for p in parts)
+
+
+def _private_dir() -> str:
+    """ A directory of this user's own (mode 0700, owner checked) under the temporary directory: the port hand-over of a launch must
+    not be readable or pre-creatable by another user of the box. """
+    d = os.path.join(tempfile.gettempdir(), f'homonim_amd_{os.getuid()}')
+    try:
+        os.mkdir(d, 0o700)
+    except FileExistsError:
+        pass
+    st = os.lstat(d)
+    import stat
+    if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+        raise RuntimeError(f'{d} is not a private directory of uid {os.getuid()} (mode {oct(st.st_mode & 0o777)}): refusing to rendezvous through it')
+    return d
 
 
 def _send_msg(sock: socket.socket, payload: bytes):
@@ -77,7 +93,7 @@ def init(backend: Optional[str] = None) -> Tuple[int, int, int]:
         backend = {'gloo': 'host', 'nccl': 'rccl'}.get(backend, backend)
         if backend not in ('host', 'rccl'):
             raise ValueError(f"unknown HOMONIM_AMD_DIST_BACKEND {backend!r}: 'rccl' (one GPU per rank) or 'host'")
-        path = os.path.join(tempfile.gettempdir(), f'homonim_amd_rdzv_{os.getuid()}_{_launch_token()}')
+        path = os.path.join(_private_dir(), f'rdzv_{_launch_token()}')
         if rank == 0:
             server = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             server.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
