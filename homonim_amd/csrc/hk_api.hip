@@ -2,7 +2,7 @@
 //
 // Owns: one HIP device per context, a pool of streams each with a device staging slab, argument validation
 // (mirrors homonim/utils.py:104-133 and homonim/kernel_model.py:430-431,459-460 error behaviour as status codes),
-// and the dispatch to the gfx950 kernels in hk_kernels.hip / hk_norm.hip.  No global mutable state besides the
+// and the dispatch to the gfx950 kernels in hk_fit_kernel.h (through hk_kernels.hip) / hk_norm.hip.  No global mutable state besides the
 // thread-local error string; any number of host threads may use one context (homonim/fuse.py:396-401).
 #include <hip/hip_runtime.h>
 
@@ -304,7 +304,7 @@ struct hk_ctx {
     // the last gain-offset call with a threshold found pixels failing the r2 mask: real imagery usually does, block after
     // block, so the next call materialises the parameters in its first pass instead of re-running it for the in-painting
     std::atomic<int> expect_r2_failures{0};
-    // certificate-only build of the gain-offset kernel (hk_kernels.hip launch_one): tried first unless it recently had to
+    // certificate-only build of the gain-offset kernel (hk_fit_kernel.h launch_one): tried first unless it recently had to
     // be re-run; every re-run doubles the number of eligible launches that go straight to the full build (<= 1024)
     std::atomic<int> cert_skip{0}, cert_penalty{1};
 
@@ -848,7 +848,7 @@ void fill_args(hk::FitArgs& a, const hk_fit_desc* d, int xcd_remap) {
             if (d->model == HK_MODEL_GAIN_BLK_OFFSET && d->kh >= 9 && d->kh <= 11) a.use_ring = 3;
         }
     }
-    // ... and, in their lock-step workgroups (hk_kernels.hip WPB), short uniform segments: 32 rows instead of 64 / 128 + 32
+    // ... and, in their lock-step workgroups (hk_fit_kernel.h WPB), short uniform segments: 32 rows instead of 64 / 128 + 32
     // (gain 5x5: configs[1] 0.676 -> 0.625 ms, 16384^2 x 4 2.65 -> 2.49 ms on one box; 7x7 2.54 -> 2.47; gain-blk-offset 5x5
     // -0.5 %).  16 rows are as good or better at 5x5 but load a quarter more rows; taller kernels keep the default.
     a.seg_rows_pref = 0;
@@ -1305,7 +1305,7 @@ int hk_ctx_create(int device_id, int n_streams, hk_ctx** out) {
     ctx->device = device_id;
     ctx->slots.resize(n_streams);
     const char* remap = getenv("HK_XCD_REMAP");
-    // runs of this many consecutive units (neighbouring strips) per XCD, 0 = plain round-robin (hk_kernels.hip); 16 measured
+    // runs of this many consecutive units (neighbouring strips) per XCD, 0 = plain round-robin (hk_fit_kernel.h); 16 measured
     // best across models on MI355X (gain 5x5: -12 %, gain-offset without the r2 mask: -4 %, VALU-bound variants: -1 %)
     ctx->xcd_remap = remap ? std::min(std::max(atoi(remap), 0), 256) : 16;
     if (const char* e = getenv("HK_CERT_ONLY")) ctx->cert_disabled = atoi(e) == 0;

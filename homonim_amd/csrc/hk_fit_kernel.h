@@ -623,7 +623,7 @@ struct ColSums {
 
 // ---------------------------------------------------------------------------------------------------------------------
 // The fused kernel.  MODEL: 0 gain, 1 gain-blk-offset, 2 gain-offset.  R2: compute the R2 quantity set.
-// RW: compile-time kernel half-width, or -1 for the run-time path.  DENSE: both inputs have nodata None.
+// RW: compile-time kernel half-width, or -1 - E for the kernels wider than 15 whose half-width is 4 F + E (F run-time, hsum_wide).  DENSE: both inputs have nodata None.
 #ifndef HK_CERT_SKIP
 #define HK_CERT_SKIP 3  // rows for which the r2-mask certificate is not attempted after it failed (measured)
 #endif
@@ -674,7 +674,7 @@ constexpr int xch_mask() {
 // scratch memory (HK_NOSPILL; tools/kernel_regs.py --spills lists none with it): the wide NaN-aware builds with the R2 work
 // and the NaN-aware split-ring builds of `gain` -- measured equal or 10-15 % FASTER at two waves, profiles/r04_nospill.txt.  Where
 // two waves were slower the registers were found elsewhere: gain-blk-offset's split ring holds 5 instead of 7 rows (it serves
-// kernels up to 11 rows), dense gain-offset + R2 at the run-time width gives up its leaving row in flight (PF_OLD).
+// kernels up to 11 rows), the certificate-only builds of the kernels wider than 15 give up their leaving row in flight (PF_OLD).
 #ifndef HK_NOSPILL
 #define HK_NOSPILL 1
 #endif

@@ -1,4 +1,4 @@
-// hk_kernels.h -- launch interface between the C-ABI host layer (hk_api.hip) and the gfx950 kernels (hk_kernels.hip).
+// hk_kernels.h -- launch interface between the C-ABI host layer (hk_api.hip) and the gfx950 kernels (hk_fit_kernel.h: the fused kernel; hk_kernels.hip: its dispatch, apply, synthetic data, self-test).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -75,7 +75,7 @@ struct FitArgs {
     double r2_fail_above;   // ssres > r2_fail_above * sstot proves it false (sstot > 0); in between the division decides
     float n_full;           // kh * kw: the window count of every pixel away from the raster's edges (dense kernels)
     double nd_full;         // the same as float64
-    double inv_n_full;      // RN64(1 / (kh * kw)) -- the 1/N table entry (hk_kernels.hip)
+    double inv_n_full;      // RN64(1 / (kh * kw)) -- the 1/N table entry (hk_fit_kernel.h)
     int force_general;      // 1: never take the dense (nodata None) specialisation (testing)
     int seg_rows_pref;      // > 0: the build's preferred uniform segment height (hk_api.hip fill_args / fill_grid), 0: the default policy
     int use_ring;           // ring mode of fit_apply_kernel: 1 full LDS ring, 2 centre ring + re-loaded leaving row, 0 re-load both
@@ -107,11 +107,11 @@ hipError_t read_stamps_m2_r1(unsigned long long* acc16, bool reset);
 // The batched entry points run every other model as one launch per job (bit-identical either way).
 constexpr bool fit_batch_build(int model, bool with_r2) { return model == 1 && !with_r2; }
 bool fit_batch_supported(int model, bool with_r2);
-// stage stamps of a -DHK_STAMPS build of hk_kernels.hip (all zero otherwise): 16 counters, optionally cleared after reading
+// stage stamps of a -DHK_STAMPS build of the fused kernel (all zero otherwise): 16 counters, optionally cleared after reading
 hipError_t read_stamps(unsigned long long* out16, bool reset);
 // strips per workgroup of the lock-step builds (HK_WPB_MEM): FitJob::first_group[1] / FitArgs::batch_groups[1] count those
 int fit_lockstep_waves();
-// LDS bytes one wave needs (its row ring; hk_kernels.hip)
+// LDS bytes one wave needs (its row ring; hk_fit_kernel.h)
 size_t fit_lds_bytes(int kh, int ring_mode, bool ahead);
 // lanes per side that overlap with the neighbouring strip for kernel half-width rw
 inline int overlap_lanes_for(int rw) { return (rw + PX - 1) / PX; }

@@ -1071,7 +1071,7 @@ def _dev_job_corr_only(c, src, ref, thresh, kernel_shape=(5, 5)):
 
 
 def test_certificate_only_build_and_its_rerun_protocol(oc, monkeypatch):
-    """ Gain-offset jobs that keep no R2 plane start with the certificate-only kernel build (hk_kernels.hip launch_one).
+    """ Gain-offset jobs that keep no R2 plane start with the certificate-only kernel build (hk_fit_kernel.h launch_one).
     On rasters it settles, the result equals the complete build's bit for bit; where it cannot, the band's counter comes
     back with HK_COUNT_RETRY, hk_inpaint_dev re-runs the band with the complete build (same results again), and the
     context goes straight to the complete build for the next launches. """

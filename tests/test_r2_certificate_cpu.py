@@ -1,6 +1,6 @@
 """
 CPU test: numerical validation of the division-free r2-mask CERTIFICATE of the fused kernel (DESIGN.md appendix A;
-hk_kernels.hip stage B) on a numpy model of the same float32 expression.
+hk_fit_kernel.h stage B) on a numpy model of the same float32 expression.
 
 For millions of random windows -- incl. low-variance / large-mean, wildly scaled, marginal-R2 and integer data -- the
 reference's own arithmetic (kernel_model.py:338-351 gains/offsets, :179-195 R2, :363 mask; float64 sums of squares as
@@ -47,7 +47,7 @@ def reference_window_math(s, r):
 
 
 def certificate(q, kappa, k2=F32(2.0 ** -17), r2_rel_err=0.0):
-    """ The kernel's expression, operation for operation (hk_kernels.hip, stage A/B of the gain-offset kernels):
+    """ The kernel's expression, operation for operation (hk_fit_kernel.h, stage A/B of the gain-offset kernels):
     fl32(g * num) > kappa * sst + 2^-17 * N*T', with N*T' = g*num + t^2 + N*R2 + tn^2 (t = g*S, tn = R - t).
     r2_rel_err: the certificate-only build sums ref^2 horizontally in float32 (rounded column sums, <= 5 roundings of
     non-negative terms): its float32 window sum is within 4.03 * 2^-24 of the float64 one instead of 2^-24 -- modelled as
@@ -110,7 +110,7 @@ def kappa_fail_for(thresh):
 
 
 def fast_quotient(num, den):
-    """ Model of hk_kernels.hip fast_quot() + quot_guard(): float32(RN64(num/den)) from a reciprocal of relative error
+    """ Model of hk_fit_kernel.h fast_quot() + quot_guard(): float32(RN64(num/den)) from a reciprocal of relative error
     <= 2^-22 and one Newton step; returns (float32 result, needs_ieee_division). """
     with np.errstate(all='ignore'):
         y = 1.0 / den
