@@ -207,15 +207,19 @@ def test_tall_kernels_vs_oracle(ctx, oc, model, find_r2, thresh, kernel_shape):
         assert n_fail == exp_fail
 
 
-@pytest.mark.parametrize('seed', range(120))
+@pytest.mark.parametrize('seed', range(180))
 def test_randomized_configurations_vs_oracle(ctx, oc, seed):
-    """ A seeded sweep over the configuration space (model, odd kernel shape up to 17 x 17, R2 output, threshold, the
-    three nodata kinds on either raster, raster shape from one pixel to a few strips / segments, fused vs parameter
-    output): every draw must reproduce the C oracle (= the reference's whole fit branch incl. in-painting). """
+    """ A seeded sweep over the configuration space (model, odd kernel shape up to 17 x 15 -- seeds from 120: 17 to 63 rows by 17 to
+    55 columns, the builds of kernels wider than 15 --, R2 output, threshold, the three nodata kinds on either raster, raster shape
+    from one pixel to a few strips / segments, fused vs parameter output): every draw must reproduce the C oracle (= the reference's
+    whole fit branch incl. in-painting). """
     import warnings
     rng = np.random.default_rng(1000 + seed)
     model = ['gain', 'gain-blk-offset', 'gain-offset'][rng.integers(3)]
-    kshape = (int(rng.choice([1, 3, 5, 7, 9, 15, 17])), int(rng.choice([1, 3, 5, 7, 9, 13, 15])))
+    if seed < 120:
+        kshape = (int(rng.choice([1, 3, 5, 7, 9, 15, 17])), int(rng.choice([1, 3, 5, 7, 9, 13, 15])))
+    else:
+        kshape = (int(rng.choice([17, 19, 21, 23, 27, 31, 33, 45, 63])), int(rng.choice([17, 19, 21, 23, 25, 27, 29, 31, 35, 41, 55])))
     if model == 'gain-offset' and kshape[0] * kshape[1] < 2:
         kshape = (3, 3)
     find_r2 = bool(rng.integers(2))
