@@ -299,3 +299,27 @@ def test_bench_launcher_reports_a_failing_rank():
                          env=env, capture_output=True, text=True, timeout=300)
     assert run.returncode not in (0, 2), run.stderr[-2000:]
     assert 'rank' in run.stderr and not [ln for ln in run.stdout.splitlines() if ln.startswith('{')]
+
+
+def test_projection_arithmetic_and_the_as_rank_argument(monkeypatch):
+    """ bench.py's single-GPU projection of strong scaling (no GPU needed for its arithmetic): an N-rank step lasts as long as its
+    slowest shard; speed-up = t(1) / max shard, efficiency = speed-up / N.  `--as-rank R/N` is refused outside configs 3 / 4. """
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(REPO, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    table = {2: [5.0, 5.5], 4: [2.6, 2.9, 2.7, 2.5], 8: [1.4] * 7 + [1.6]}
+    proj = bench.project_scaling(10.0, lambda r, n: table[n][r])
+    assert 'PROJECTION' in proj['kind'] and proj['t1_ms'] == 10.0
+    by = proj['by_world_size']
+    assert by['2']['max_shard_ms'] == 5.5 and by['2']['projected_speedup'] == pytest.approx(10 / 5.5, abs=1e-3)
+    assert by['4']['projected_efficiency'] == pytest.approx(10 / (4 * 2.9), abs=1e-4)
+    assert by['8']['shard_ms'] == table[8] and by['8']['projected_speedup'] == pytest.approx(6.25)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--config', '3', '--as-rank', '3/8'])
+    assert bench.parse_args().as_rank == (3, 8)
+    for bad in (['--config', '2', '--as-rank', '0/2'], ['--config', '3', '--as-rank', '8/8'], ['--config', '4', '--as-rank', 'x'],
+                ['--config', '3', '--gpus', '2', '--as-rank', '0/2']):
+        monkeypatch.setattr(sys, 'argv', ['bench.py'] + bad)
+        with pytest.raises(SystemExit):
+            bench.parse_args()
+    assert bench.SoloDist.max_over_ranks(3.5) == 3.5 and bench.SoloDist.backend() is None
