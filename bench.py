@@ -157,7 +157,10 @@ def cpu_baseline(model, k, sample):
         have_c = oracle_c.available()
     except Exception:
         have_c = False
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))   # the CPUs this process may run on (a container's share, not the box's count)
+    except (AttributeError, OSError):
+        cores = os.cpu_count() or 1
     if sample <= 0:
         sample = (8192 if cores >= 32 else 4096) if have_c else 1536
     thresh = 0.25 if model == 'gain-offset' else None
@@ -1036,6 +1039,7 @@ def main():
     rank, world, local_rank = dist.init()  # the ranks meet over loopback TCP, only when WORLD_SIZE > 1 (homonim_amd/dist.py)
     # Host placement: this rank's threads onto the cores of its GPU's NUMA node, BEFORE anything page-locked is allocated
     # (the staging rings of the context, the host rasters of `end_to_end`): SURVEY.md 8(e) "NUMA-local pinned buffers"
+    affinity_before = os.sched_getaffinity(0)   # (the CPU baseline below gets the whole host back)
     placement = topology.bind_to_device(local_rank % max(1, _hk.device_count()))
     # one GPU per rank on a full node.  configs[3] deals its block positions to 8 streams: a position's statistics are a chain of
     # small latency-bound kernels, and with 4 streams the GPU still idled between them (12.1 -> 11.5 ms per step)
@@ -1135,6 +1139,9 @@ def main():
     if rank == 0:
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
+            # the baseline is the HOST's: its worker threads (created from this thread) may use every CPU the launcher allowed, not
+            # only the GPU's NUMA node this rank was bound to for its staging work; the GPU part of the run is over
+            os.sched_setaffinity(0, affinity_before)
             cpu = cpu_baseline(args.model, args.kernel, args.cpu_sample)
         rl = res['roofline']
         achieved = rl['achieved_bytes'] / (rl['avg_launch_ms'] * 1e-3) / 1e9
