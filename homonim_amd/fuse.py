@@ -585,11 +585,18 @@ class RasterFuse:
                 process_block(bp, models[0], corr, params, nodata)
         else:
             workers = max(block_config['threads'], len(models))
+            several = len({m.context.device for m in models}) > 1
+
+            def on_device(bp, model):
+                # several GPUs in one process: the worker that packs this block into a GPU's pinned staging ring runs on that GPU's
+                # NUMA node (topology.bind_current_thread; one process per GPU binds the whole process instead: dist / bench.py)
+                if several:
+                    from homonim_amd import topology
+                    topology.bind_current_thread(model.context.device)
+                return process_block(bp, model, corr, params, nodata)
+
             with ThreadPoolExecutor(max_workers=workers) as ex:
-                futures = [
-                    ex.submit(process_block, bp, models[i % len(models)], corr, params, nodata)
-                    for i, bp in enumerate(blocks)
-                ]
+                futures = [ex.submit(on_device, bp, models[i % len(models)]) for i, bp in enumerate(blocks)]
                 for f in as_completed(futures):
                     f.result()  # re-raise worker exceptions (fuse.py:404-408)
 

@@ -136,6 +136,45 @@ def bind_to_device(device: int, sysfs_root: str = '/sys') -> dict:
     return rec
 
 
+_device_cpus: Dict[int, List[int]] = {}
+_thread_device = None   # threading.local, made on first use
+
+
+def bind_current_thread(device: int, sysfs_root: str = '/sys') -> bool:
+    """ Run the CALLING thread on the cores next to HIP device `device` (one process driving several GPUs: RasterFuse with a device
+    list deals its blocks to worker threads; the thread that packs a block into a GPU's pinned staging ring should run on that GPU's
+    socket).  The placement of a device is looked up once; a thread that is already bound to the device costs nothing.  -> whether
+    the thread is bound now.  Never raises; HOMONIM_AMD_NO_BIND=1 turns it off. """
+    global _thread_device
+    import threading
+    if os.environ.get('HOMONIM_AMD_NO_BIND') == '1':
+        return False
+    if _thread_device is None:
+        _thread_device = threading.local()
+    if getattr(_thread_device, 'device', None) == device:
+        return True
+    cpus = _device_cpus.get(device)
+    if cpus is None:
+        try:
+            from homonim_amd import _hk
+            try:
+                allowed = sorted(os.sched_getaffinity(0))
+            except (AttributeError, OSError):
+                allowed = None
+            cpus = placement_for(_hk.device_pci_bus_id(device), sysfs_root, allowed)['cpus']
+        except Exception:
+            cpus = []
+        _device_cpus[device] = cpus
+    if not cpus:
+        return False
+    try:
+        os.sched_setaffinity(0, cpus)   # 0: the calling thread
+    except OSError:
+        return False
+    _thread_device.device = device
+    return True
+
+
 def summary(rec: dict) -> dict:
     """ The placement record as bench.py prints it: the CPU list as a range string. """
     cpus = rec.get('cpus') or []

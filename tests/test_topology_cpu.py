@@ -79,3 +79,30 @@ def test_bind_without_a_library_or_gpu_is_a_record_not_an_error(monkeypatch):
     rec = topology.bind_to_device(0, sysfs_root='/nonexistent')   # no GPU here: the record says why, the affinity stays
     assert rec['bound'] is False and rec['reason']
     assert os.sched_getaffinity(0) == before
+
+
+def test_a_worker_thread_binds_to_its_device_and_remembers_it(monkeypatch):
+    """ Several GPUs in one process (RasterFuse with a device list): a worker thread is bound per block to the CPUs of the block's GPU;
+    the look-up happens once per device, a thread already on the device's node makes no system call. """
+    import threading
+    calls = []
+    allowed = sorted(os.sched_getaffinity(0))
+    monkeypatch.setattr(topology, '_device_cpus', {0: allowed[:1], 1: allowed[-1:], 2: []})
+    monkeypatch.setattr(topology, '_thread_device', None)
+    real = os.sched_setaffinity
+    monkeypatch.setattr(os, 'sched_setaffinity', lambda pid, cpus: (calls.append((pid, tuple(cpus))), real(pid, cpus))[1])
+    out = {}
+
+    def worker():
+        out['a'] = topology.bind_current_thread(0), sorted(os.sched_getaffinity(0))
+        out['b'] = topology.bind_current_thread(0)                      # already there: no call
+        out['c'] = topology.bind_current_thread(1), sorted(os.sched_getaffinity(0))
+        out['d'] = topology.bind_current_thread(2)                      # a device whose node sysfs does not name: left alone
+    before = os.sched_getaffinity(0)
+    t = threading.Thread(target=worker)
+    t.start(), t.join()
+    assert out['a'] == (True, allowed[:1]) and out['b'] is True and out['c'] == (True, allowed[-1:]) and out['d'] is False
+    assert calls == [(0, tuple(allowed[:1])), (0, tuple(allowed[-1:]))]
+    assert os.sched_getaffinity(0) == before      # the calling (main) thread is untouched
+    monkeypatch.setenv('HOMONIM_AMD_NO_BIND', '1')
+    assert topology.bind_current_thread(0) is False
