@@ -1051,20 +1051,43 @@ def main():
     # all-reduce of a float64 word per rank, which must come back as the number of ranks.
     rccl_ranks, rccl_error = None, None
     if dist.backend() == 'rccl':
-        try:   # reported, not fatal: the timed path has no collective, a rank's shard does not depend on this communicator
-            dist.init_comm(ctx)
-            word = ctx.dev_alloc(8)
-            ctx.h2d(word, np.ones(1, np.float64))
-            ctx.comm_allreduce_f64_dev(word, 1, 0)
-            ctx.stream_sync(0)
-            back = np.zeros(1, np.float64)
-            ctx.d2h(back, word)
-            ctx.dev_free(word)
-            rccl_ranks = ctx.comm_info()[1]
-            if int(back[0]) != world or rccl_ranks != world:
-                rccl_error = f'all-reduce over {world} rank(s) returned {back[0]} (communicator of {rccl_ranks})'
-        except Exception as ex:
-            rccl_error = f'{type(ex).__name__}: {ex}'
+        # Reported, never fatal, and never allowed to hang the run: the timed path has no collective, a rank's shard does not depend on
+        # this communicator.  ncclCommInitRank returns only when EVERY rank has joined and has no timeout of its own, so a rank whose
+        # librccl is missing (or whose bootstrap fails) would leave its peers waiting for ever: the join runs on a side thread with a
+        # deadline, and the ranks agree over the launch's sockets (dist.sum_over_ranks) whether everybody got in before anybody queues
+        # the all-reduce.
+        import threading
+        joined = {}
+
+        def join():
+            try:
+                dist.init_comm(ctx)
+                joined['ok'] = True
+            except Exception as ex:
+                joined['err'] = f'{type(ex).__name__}: {ex}'
+        th = threading.Thread(target=join, daemon=True)
+        th.start()
+        th.join(timeout=float(os.environ.get('HK_BENCH_RCCL_TIMEOUT', '120')))
+        mine_ok = bool(joined.get('ok'))
+        if not mine_ok:
+            rccl_error = joined.get('err') or 'joining the communicator did not return within the deadline (a peer never joined?)'
+        all_ok = dist.sum_over_ranks(1.0 if mine_ok else 0.0) == float(world)
+        if all_ok:
+            try:
+                word = ctx.dev_alloc(8)
+                ctx.h2d(word, np.ones(1, np.float64))
+                ctx.comm_allreduce_f64_dev(word, 1, 0)
+                ctx.stream_sync(0)
+                back = np.zeros(1, np.float64)
+                ctx.d2h(back, word)
+                ctx.dev_free(word)
+                rccl_ranks = ctx.comm_info()[1]
+                if int(back[0]) != world or rccl_ranks != world:
+                    rccl_error = f'all-reduce over {world} rank(s) returned {back[0]} (communicator of {rccl_ranks})'
+            except Exception as ex:
+                rccl_error = f'{type(ex).__name__}: {ex}'
+        elif rccl_error is None:
+            rccl_error = 'another rank could not join the communicator'
         if rccl_error:
             sys.stderr.write(f'bench.py: rank {rank}: the library\'s RCCL communicator is not usable: {rccl_error}\n')
 

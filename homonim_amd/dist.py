@@ -184,7 +184,16 @@ def init_comm(ctx, id_file: Optional[str] = None) -> Tuple[int, int]:
     rank, world, _ = env_ranks()
     id_file = id_file or os.environ.get('HOMONIM_AMD_COMM_FILE')
     if _state['initialised'] and id_file is None:
-        uid = broadcast_bytes(_hk.comm_unique_id() if rank == 0 else None)
+        payload = None
+        if rank == 0:   # a rank 0 that cannot make the id (no librccl) tells the others instead of leaving them in the exchange
+            try:
+                payload = b'\x01' + _hk.comm_unique_id()
+            except Exception as ex:
+                payload = b'\x00' + f'{type(ex).__name__}: {ex}'.encode()
+        blob = broadcast_bytes(payload)
+        if blob[:1] != b'\x01':
+            raise RuntimeError('rank 0 could not make the RCCL communicator id: ' + blob[1:].decode(errors='replace'))
+        uid = blob[1:]
     elif world == 1 and id_file is None:
         uid = _hk.comm_unique_id()
     else:

@@ -323,3 +323,40 @@ def test_projection_arithmetic_and_the_as_rank_argument(monkeypatch):
         with pytest.raises(SystemExit):
             bench.parse_args()
     assert bench.SoloDist.max_over_ranks(3.5) == 3.5 and bench.SoloDist.backend() is None
+
+
+_WORKER_NOID = r'''
+import os, sys, time
+sys.path.insert(0, {repo!r})
+from homonim_amd import _hk, dist
+rank, world, _ = dist.init()
+def no_rccl():
+    raise _hk.DeviceError('librccl not found (stand-in)')
+_hk.comm_unique_id = no_rccl
+class Ctx:
+    def comm_init(self, uid, r, w):
+        raise AssertionError('nobody may get as far as ncclCommInitRank')
+t0 = time.time()
+try:
+    dist.init_comm(Ctx())
+    sys.exit(5)
+except RuntimeError as ex:
+    assert 'could not make the RCCL communicator id' in str(ex) and 'librccl not found' in str(ex), str(ex)
+assert time.time() - t0 < 30
+assert dist.sum_over_ranks(1.0) == world      # the launch's sockets are still in step
+dist.finalize()
+'''
+
+
+@pytest.mark.timeout(120)
+def test_a_rank_zero_without_rccl_tells_the_others(tmp_path):
+    """ dist.init_comm over the launch's sockets: if rank 0 cannot make the communicator id, EVERY rank gets the error at once -- nobody
+    is left waiting in the exchange (or, worse, inside ncclCommInitRank, which has no timeout). """
+    script = tmp_path / 'worker_noid.py'
+    script.write_text(_WORKER_NOID.format(repo=REPO))
+    env = dict(os.environ, OMP_NUM_THREADS='1', HOMONIM_AMD_DIST_BACKEND='host', WORLD_SIZE='3', MASTER_PORT='29651')
+    env.pop('HOMONIM_AMD_COMM_FILE', None)
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for r in range(3)]
+    outs = [p.communicate(timeout=100) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [e[-800:] for _, e in outs]
