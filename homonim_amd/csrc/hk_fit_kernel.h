@@ -441,7 +441,7 @@ __device__ __forceinline__ void store4_nt(float4* p, float4 v) {
 // 24-bit integer) and an integer n < 2^16 the quotient t / n is never an exact float32 rounding midpoint (that would need the
 // power of two in n to exceed n) and never closer to one than 1 / (2 n) units of the quotient's last place, i.e. 2^-41 relative,
 // while f64(t) * RN64(1/n) is within 2^-52 of it -- so rounding that product to float32 IS the IEEE float32 division
-// (kernel_model.py:351: float32 `t / mask_sum`).  Only wave-rows with a hole or a raster edge in their windows read the table
+// (kernel_model.py:351: float32 `t / mask_sum`; PROOFS.md appendix C, tests/test_inv_n_cpu.py).  Only wave-rows with a hole or a raster edge in their windows read the table
 // (elsewhere 1/N is a kernel argument, valid for every window the launcher admits: kh * kw < 2^16), so it lives in global memory
 // (8 KB, cache-resident) and costs no LDS.  1023 covers kernels up to 31 x 33; larger windows divide (those rows only).
 constexpr int HK_INV_N_MAX = 1023;
