@@ -827,9 +827,10 @@ void fill_args(hk::FitArgs& a, const hk_fit_desc* d, int xcd_remap) {
     a.inv_n_full = 1.0 / (double)(d->kh * d->kw);
     a.force_general = getenv("HK_FORCE_GENERAL") ? atoi(getenv("HK_FORCE_GENERAL")) : 0;
     // ring mode (hk_fit_kernel.h): full LDS ring while it leaves room for >= 11 waves per CU (kh <= 5), centre-only ring up
-    // to kh = HK_CRING_MAX_KH (1 KB per wave and row of the half-height), everything re-loaded beyond -- that path exists
+    // to kh = HK_CRING_MAX_KH = 39 (1 KB per wave and row of the half-height; 33 - 39 rows: 3 - 13 % faster than re-loading, from 41 rows
+    // slower -- headline workload, round 5), everything re-loaded beyond -- that path exists
     // for kernels from 9 wide only (launch_rw), narrower ones keep the centre ring whatever their height (kh <= 255: 128 KB)
-    a.use_ring = (d->kh <= 5 && d->kw <= 7) ? 1 : ((d->kh <= env_int_early("HK_CRING_MAX_KH", 31) || d->kw <= 7) ? 2 : 0);
+    a.use_ring = (d->kh <= 5 && d->kw <= 7) ? 1 : ((d->kh <= env_int_early("HK_CRING_MAX_KH", 39) || d->kw <= 7) ? 2 : 0);
     // The memory-bound builds (no R2) prefer the full ring well beyond that: re-loading the leaving rows costs them more than
     // the waves the ring displaces -- gain 7x7 / 9x9 / 11x11 / 15x15 at 16384^2 x 4: 3.25 / 3.40 / 3.45 / 3.95 -> 2.54 / 2.58 /
     // 2.77 / 3.64 ms; gain-blk-offset (more arithmetic per pixel) only up to 7x7 (fit + statistics 5.11 -> 4.61 ms; 9x9 equal,

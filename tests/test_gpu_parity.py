@@ -163,7 +163,7 @@ def test_kernels_wider_than_15_vs_oracle(ctx, oc, model, find_r2, thresh, kernel
     """ Kernels wider than 15 (the reference's integration suite runs 31 x 31 -- tests/integration.py:36-37,42-43 -- and
     utils.validate_kernel_shape admits any odd shape, utils.py:104-133) take the builds that know kw // 2 mod 4 at compile time and
     kw // 8 at run time (hk_fit_kernel.h hsum_wide): every residue, one to four whole neighbour lanes per side, short / tall
-    (centre ring; everything re-loaded beyond 31 rows), all three models, with and without R2 and the r2 mask, NaN holes and
+    (centre ring; everything re-loaded beyond 39 rows), all three models, with and without R2 and the r2 mask, NaN holes and
     nodata None, on a raster of several strips (208 - 232 output columns each) and row segments, against the C oracle. """
     h, w = 290, 1003
     src, ref = onp.synth_pair(h, w, seed=kernel_shape[0] * 64 + kernel_shape[1], nodata_variant=variant)
@@ -190,7 +190,7 @@ def test_kernels_wider_than_15_vs_oracle(ctx, oc, model, find_r2, thresh, kernel
 @pytest.mark.parametrize('kernel_shape', [(63, 5), (129, 3), (35, 7), (255, 1), (33, 9), (61, 15), (5, 151), (9, 193), (3, 101), (1, 63), (41, 57)])
 def test_tall_kernels_vs_oracle(ctx, oc, model, find_r2, thresh, kernel_shape):
     """ The extremes of the shape space: very wide kernels (up to the 193 columns a strip's overlap lanes allow: 24 whole neighbour lanes
-    per side, window counts beyond the 1/N table), a single row, and kernels taller than the centre ring's default limit (31 rows): up to
+    per side, window counts beyond the 1/N table), a single row, and kernels taller than the centre ring's default limit (39 rows): up to
     7 wide they keep the centre ring whatever their height (1 KB
     of LDS per wave and row of the half-height: 128 KB at 255 rows, one wave per CU), from 9 wide both rows are re-loaded (ring mode 0:
     the builds of hsum_wide, also for the 9 - 15 wide kernels that have compile-time builds otherwise).  utils.validate_kernel_shape
