@@ -618,6 +618,10 @@ def run_blocks(args, ctx, dist, rank, world):
         # Batched launches (hk_block_norm_batch_dev / hk_fit_apply_batch_dev): the rank's jobs in `n_batches` groups, each group one
         # launch per kernel stage on its own stream (0 = one launch per job, spread over the streams)
         n_batches = min(int(os.environ.get('HK_BENCH_BATCHES', str(args.batches))), len(jobs))
+        if len(jobs) <= 4 and 'HK_BENCH_BATCHES' not in os.environ:
+            # a rank of a wide launch holds a few block positions only: one launch per position on a stream each, so that one position's
+            # latency-bound statistics chain runs beside the other's fit (the shard of rank 3 of 8: 1.60 ms against 1.70 as two batches)
+            n_batches = 0
         batches = []
         if n_batches > 0:
             per = (len(jobs) + n_batches - 1) // n_batches
