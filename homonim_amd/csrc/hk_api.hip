@@ -948,7 +948,7 @@ static bool cert_only_eligible(const hk::FitArgs& a, const hk_fit_desc* desc) {
 // that counted the failures (FitArgs::flag) -- the in-painting then starts right away.  `drop_params`: the parameter
 // planes in `a` are scratch, the closing pass need not write them.
 static int inpaint_band(Slot& sl, const hk::FitArgs& a, const hk_fit_desc* desc, bool r2, size_t plane,
-                        unsigned long long n_fail, bool drop_params = false, const float* pre_offset = nullptr,
+                        unsigned long long n_fail, bool drop_params = false, float* pre_offset = nullptr,
                         const unsigned char* pre_flag = nullptr) {
     {
         const int rc = ensure_inpaint_scratch(sl, plane, a.height, a.stride);
@@ -956,8 +956,8 @@ static int inpaint_band(Slot& sl, const hk::FitArgs& a, const hk_fit_desc* desc,
     }
     const hipStream_t stream = sl.stream;
     char* aux = static_cast<char*>(sl.aux);
-    float* filled = reinterpret_cast<float*>(aux);
-    const float *pg = a.gain, *po = a.offset, *pr = a.r2;
+    const float *pg = a.gain, *pr = a.r2;
+    float* po = a.offset;
     const unsigned char* flags = nullptr;
     if (pre_offset && pre_flag) {
         po = pre_offset, flags = pre_flag;
@@ -972,14 +972,17 @@ static int inpaint_band(Slot& sl, const hk::FitArgs& a, const hk_fit_desc* desc,
         HK_HIP(hk::launch_fit_apply(b, desc->model, r2, stream));
         po = scratch_off, flags = b.flag;
     }
+    // The failing pixels' offsets are in-painted IN PLACE (round 5; a separate `filled` plane cost a pass-through of every source
+    // pixel): sources are read only where the flag is 1, targets written only where it is 0, and the closing pass -- which reads the
+    // plane at the failing pixels only -- rewrites the caller's offset plane whole when there is one.
     // n_fail (the failing VALID pixels) is a lower bound of the pixels to fill (nodata pixels are filled as well)
-    HK_HIP(hk::launch_inpaint_offsets(po, pg, pr, desc->r2_thresh, a.stride, a.height, a.width, aux + 4 * plane, filled,
-                                      stream, flags, n_fail));
+    HK_HIP(hk::launch_inpaint_offsets(po, pg, pr, desc->r2_thresh, a.stride, a.height, a.width, aux + 4 * plane, stream, flags,
+                                      n_fail));
     // closing pass: the failing pixels take the in-painted offsets and recomputed gains (kernel_model.py:370-371).  Which
     // pixels failed is in the flag plane the in-painting just used, so the build WITHOUT the R2 work runs (the R2 plane, if
     // the caller keeps one, was written by the pass that counted and is not changed by the branch)
     hk::FitArgs c = a;
-    c.offset_in = filled;
+    c.offset_in = po;
     c.flag_in = flags ? flags : hk::inpaint_flag_plane(aux + 4 * plane, a.height, a.stride);
     c.fail_count = nullptr;  // already counted
     c.flag = nullptr;
@@ -1882,7 +1885,7 @@ int hk_inpaint_dev_counts(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job
         std::unique_lock<std::mutex> lk(ctx->mu);  // the slot's scratch may be (re)allocated
         // offsets + source flags left by the pass that counted: a count without the re-run bit comes from the complete
         // build, which writes them whenever the job carries scratch (hk_fit_apply_dev)
-        const float* pre_off = nullptr;
+        float* pre_off = nullptr;
         const unsigned char* pre_flag = nullptr;
         if (job->scratch && !(n_fail & hk::FIT_RETRY_BIT)) {
             pre_flag = job_scratch_flag(job) + off;

@@ -52,13 +52,15 @@ constexpr unsigned NONE_SQ = 0x7fffu;  // squared-distance half of a table entry
 constexpr int WORD_ROWS = 64;
 
 __global__ void __launch_bounds__(256) inpaint_bits_kernel(const unsigned char* __restrict__ flag, long long stride, int height,
-                                                           int width, unsigned long long* __restrict__ bits) {
+                                                           int width, unsigned long long* __restrict__ bits,
+                                                           unsigned long long* __restrict__ tbits) {
     // a thread packs FOUR adjacent columns: 64 independent 4-byte loads (the flag plane's rows are 4-byte aligned: stride % 4 == 0)
     // instead of 64 single bytes per column -- a quarter of the load instructions for the same bytes (0.158 -> 0.064 ms per 16384^2 band)
+    // `tbits` (round 5): the TARGETS (flag 0) in the same layout -- the search reads a tile's targets as one word per column
     const int x = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (x >= width) return;
     const int y0 = blockIdx.y * WORD_ROWS;
-    unsigned lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
+    unsigned lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0}, tlo[4] = {0, 0, 0, 0}, thi[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int r = 0; r < 32; ++r) {
         const int ya = y0 + r, yb = y0 + 32 + r;
@@ -67,13 +69,18 @@ __global__ void __launch_bounds__(256) inpaint_bits_kernel(const unsigned char* 
         const unsigned fb = *reinterpret_cast<const unsigned*>(flag + (long long)min(yb, height - 1) * stride + x);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            lo[c] |= (unsigned)(((fa >> (8 * c)) & 0xffu) != 0 && ya < height) << r;
-            hi[c] |= (unsigned)(((fb >> (8 * c)) & 0xffu) != 0 && yb < height) << r;
+            lo[c] |= (unsigned)(((fa >> (8 * c)) & 1u) != 0 && ya < height) << r;  // (flag 2: neither source nor target)
+            hi[c] |= (unsigned)(((fb >> (8 * c)) & 1u) != 0 && yb < height) << r;
+            tlo[c] |= (unsigned)(((fa >> (8 * c)) & 0xffu) == 0 && ya < height) << r;
+            thi[c] |= (unsigned)(((fb >> (8 * c)) & 0xffu) == 0 && yb < height) << r;
         }
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c)
-        if (x + c < width) bits[(long long)blockIdx.y * stride + x + c] = ((unsigned long long)hi[c] << 32) | lo[c];
+        if (x + c < width) {
+            bits[(long long)blockIdx.y * stride + x + c] = ((unsigned long long)hi[c] << 32) | lo[c];
+            tbits[(long long)blockIdx.y * stride + x + c] = ((unsigned long long)thi[c] << 32) | tlo[c];
+        }
 }
 
 __global__ void __launch_bounds__(256) inpaint_table_kernel(const unsigned long long* __restrict__ bits, long long stride,
@@ -182,7 +189,7 @@ __device__ __forceinline__ void fill_load_d0(const unsigned* __restrict__ trow, 
 // INTERIOR (wave-uniform, tiled kernel): no step of any search of the wave can reach the raster's edge columns -- the clamps,
 // their per-lane squares and the entry-by-entry table reads fall away.
 template <bool INTERIOR = false>
-__device__ __forceinline__ float fill_one(int x, int y, long long row, const float* __restrict__ offset, long long stride, int width,
+__device__ __forceinline__ float fill_one(int x, int y, long long row, const float* offset, long long stride, int width,
                                           int max_dist, const unsigned* __restrict__ tb, const unsigned* __restrict__ tie,
                                           const double* __restrict__ wtab) {
         const long long i = row + x;
@@ -325,83 +332,155 @@ __device__ __forceinline__ float fill_one(int x, int y, long long row, const flo
         return out;
 }
 
-// 8 waves per SIMD: the step from 6 to 8 resident waves was worth 8 % of the whole in-painting branch while the search was
-// bound by dependent look-ups.  With the column table as one 16-bit word per pixel it is bound by its VALU instructions
-// (PMC: busy 90-100 %); hence the lean candidate test below: per quadrant the state is the best squared distance and one packed
-// word (column distance << 8 | row distance), a candidate costs ~8 instructions.  (A second copy of the loop for wave-rows
-// away from the raster's edges, with scalar column distances and unclamped look-ups, cost 18 more VGPRs than it saved
-// instructions.)
-#ifndef HK_FILL_WAVES_FULL
-#define HK_FILL_WAVES_FULL 8
-#endif
-template <bool PACK>
-__global__ void __launch_bounds__(256, PACK ? 8 : HK_FILL_WAVES_FULL) inpaint_fill_kernel(const float* __restrict__ offset, const unsigned char* __restrict__ flag,
-                                                           long long stride, int height, int width, int max_dist,
-                                                           const unsigned* __restrict__ tb,
-                                                           const unsigned* __restrict__ tie,
-                                                           const double* __restrict__ wtab, float* __restrict__ filled) {
-    // Only target pixels search.  PACK (moderate failure rates: the targets are a minority scattered over the lanes): the
-    // workgroup first passes its sources through and COMPACTS its targets (ballot + a 4-entry prefix in LDS), then thread t
-    // searches for target t -- full waves instead of a third of the lanes in every wave (-12 % of the branch at 35 %
-    // failures).  When nearly every pixel is a target the packing only costs its barriers (+3 % at 94 %): the host picks.
-    __shared__ unsigned short lst[PACK ? 256 : 1];
-    __shared__ unsigned wcnt[256 / WAVE];
-    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
-    const int x_own = blockIdx.x * blockDim.x + tid;
-    if constexpr (!PACK) {
-        if (x_own >= width) return;
+// ---- The PACKED search (round 5) ------------------------------------------------------------------------------------------
+// Where the sources are dense -- the usual case: a failing pixel has passing ones a few pixels away in every quadrant -- the search
+// state fits 16 bits per quadrant: key = (squared distance << 5) | column distance, for squared distances below FAST_CLIP and
+// columns up to FAST_LAST away.  A table word holds the two row distances of a column (up | down << 16), so ONE packed
+// instruction serves two quadrants: per column visited the search costs five VALU instructions (clip, two multiply-adds with the
+// step's constants, two minima) where the 32-bit keys of fill_one() cost ten.  The decisions are the same ones:
+//   * first / last candidate at the best squared distance = smallest key with the column distance / its complement in the low bits;
+//   * a quadrant is SETTLED after step S when its best squared distance is below (S + 1)^2: any candidate in a farther column,
+//     and any candidate whose row distance was clipped (>= FAST_CLIP > (FAST_LAST + 1)^2), is strictly farther -- it can neither
+//     beat nor tie the holder, which is all GDAL's search could still do with it (its own bound only decides when to stop);
+//   * a target with a quadrant that does not settle by FAST_LAST (no source nearby, or none at all) is handed to fill_one().
+// The table words come from LDS: the per-lane gathers of fill_one() (every lane its own row piece) kept the texture path busy
+// 32 cycles per wave instruction and the waves waiting 71-82 % of their lives (PMC, profiles/r05b_inpaint_packed.txt); a
+// workgroup now stages the table of its tile plus FAST_HALO columns either side once, coalesced, and the search reads it from
+// there.  The finish reads the weight 1 / sqrt(n) (n's tie bit is its sign) and a square root from small LDS tables, and the
+// source's value from the plane; all four quadrants of a settled target hold a source within max_dist, so GDAL's acceptance tests are true by
+// construction.
+typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_min_u16(unsigned a, unsigned b) {
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(us2_t, a), __builtin_bit_cast(us2_t, b)));
+}
+__device__ __forceinline__ unsigned pk_max_u16(unsigned a, unsigned b) {
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(us2_t, a), __builtin_bit_cast(us2_t, b)));
+}
+// per half: a * 32 + c (no carry between the halves; the callers keep every half below 2^16)
+__device__ __forceinline__ unsigned pk_mad32_u16(unsigned a, unsigned c) {
+    unsigned r;
+    asm("v_pk_mad_u16 %0, %1, 32, %2 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(c));
+    return r;
+}
+constexpr int FAST_LAST = 24;        // last column distance of the packed search (groups end at 4, 8, ..., 24)
+constexpr unsigned FAST_CLIP = 1263; // row distances squared are clipped here: (1263 + 24^2) * 32 + 31 < 65536, and 1263 > 25^2
+constexpr int FAST_HALO = 24;        // table columns staged either side of a workgroup's 256 (>= FAST_LAST, a multiple of 4)
+constexpr int FAST_COLS = 256 + 2 * FAST_HALO, FAST_PITCH = FAST_COLS + 4;  // (pitch % 32 == 20: the rows of a pass spread over the banks)
+static_assert((FAST_CLIP + FAST_LAST * FAST_LAST) * 32 + 31 <= 0xffffu, "a packed key overflows its half");
+static_assert(FAST_CLIP > (FAST_LAST + 1) * (FAST_LAST + 1), "a clipped candidate could settle a quadrant");
+static_assert(FAST_HALO >= FAST_LAST && FAST_HALO % 4 == 0, "the staged halo");
+// What the finish looks up per quadrant, kept in LDS: for every squared distance n a settled quadrant can have, the weight
+// 1 / sqrt(n) with n's TIE BIT AS ITS SIGN (weights are positive; the sums take the magnitude through the operand modifier),
+// and the square roots of the perfect squares (the winner's row distance from what is left of n beside its column distance).
+constexpr int FTAB_N = (FAST_LAST + 1) * (FAST_LAST + 1);  // a settled quadrant's squared distance is below this
+struct FastTables {
+    double w[FTAB_N];
+    unsigned char root[FTAB_N + 7];
+};
+static_assert(sizeof(FastTables) % 8 == 0, "copied in 8-byte pieces");
+
+__global__ void __launch_bounds__(256) fast_table_kernel(FastTables* __restrict__ ft) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= FTAB_N + 7) return;
+    if (n < FTAB_N) {
+        const double q = sqrt((double)n);
+        const double w = n ? 1.0 / q : 0.0;
+        ft->w[n] = __dmul_rn(q, q) > (double)n ? -w : w;
     }
-    for (int y = blockIdx.y; y < height; y += gridDim.y) {  // grid-stride over rows: blocks taller than 65535 rows are fine
-    const long long row = (long long)y * stride;
-    bool target = false;
-    if (x_own < width) {
-        target = !flag[row + x_own];
-        if (!target) filled[row + x_own] = offset[row + x_own];  // filled pixels never act as sources: sources pass through
-    }
-    bool active = target;
-    int x = x_own;
-    // (without the compaction x is the same in every row of the loop: keep the compiler from hoisting the per-step edge
-    // distances and conditions out of it -- 89 VGPRs instead of 52, i.e. spills at 8 waves per SIMD)
-    asm volatile("" : "+v"(x));
-    if constexpr (PACK) {
-        const unsigned long long bal = __ballot(target);
-        if (lane == 0) wcnt[wv] = (unsigned)__popcll(bal);
-        __syncthreads();
-        unsigned base = 0, n_targets = 0;
-#pragma unroll
-        for (int w = 0; w < 256 / WAVE; ++w) {
-            base += w < wv ? wcnt[w] : 0u;
-            n_targets += wcnt[w];
-        }
-        if (target) lst[base + (unsigned)__popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)tid;
-        __syncthreads();
-        active = tid < (int)n_targets;
-        if (active) x = blockIdx.x * blockDim.x + lst[tid];
-    }
-    if (active) filled[row + x] = fill_one(x, y, row, offset, stride, width, max_dist, tb, tie, wtab);
-    }
+    ft->root[n] = (unsigned char)isqrt_floor(n);
 }
 
-// TILED form of the search (round 3): a wave owns a tile of 64 columns x ROWS rows.  The per-row form above starts a workgroup per
-// 256-pixel row piece, and each lives for three dependent memory round trips (flag -> compaction behind two barriers -> table
-// words -> source values): PMC showed its waves WAITING 76 % of their 4.7 us life with the VALU 58 % busy.  Here a wave reads the
-// flags of its whole tile at once, passes the sources through, compacts the tile's targets into a wave-private LDS list (ballot +
-// popcount, no workgroup barrier) and then searches 64 targets per pass -- full waves whatever the failure rate, one wave start per
-// ROWS rows, and the passes of the resident waves overlap each other's look-ups.
+// The packed search of ONE target of a wave whose searches stay inside the staged tile.  `c0`: the target's own entry of the
+// staged table; `base` + `rel0`: the target's pixel of the plane as a 32-bit offset from a point FAST_HALO rows and columns before
+// the tile (so that every source's offset is non-negative).  Returns true and the filled value when all four quadrants settled;
+// false when the target has to go through fill_one().  `cont_min`: a group of columns is searched only while at least that many
+// lanes of the wave still need it.  Called by every lane of a pass that has a target (the votes count those lanes only).
+__device__ __forceinline__ bool fill_fast(const unsigned* c0, const float* __restrict__ base, unsigned rel0, int stride,
+                                          const FastTables& ft, int cont_min, float& out) {
+    unsigned kfL = ~0u, klL = ~0u, kfR = ~0u, klR = ~0u;  // (down | up) halves: left quadrants 1 | 0, right quadrants 3 | 2
+    auto cons = [](unsigned e, int k, unsigned& kf, unsigned& kl) {
+        const unsigned ec = pk_min_u16(e, FAST_CLIP * 0x10001u);
+        kf = pk_min_u16(kf, pk_mad32_u16(ec, (unsigned)((k * k << 5) + k) * 0x10001u));
+        kl = pk_min_u16(kl, pk_mad32_u16(ec, (unsigned)((k * k << 5) + 31 - k) * 0x10001u));
+    };
+    auto worst = [&]() {
+        const unsigned m = pk_max_u16(kfL, kfR);
+        return max(m & 0xffffu, m >> 16);
+    };
+    cons(c0[0], 0, kfL, klL);  // the own column belongs to the left quadrants
+#pragma unroll
+    for (int k = 1; k <= 4; ++k) {
+        cons(c0[-k], k, kfL, klL);
+        cons(c0[k], k, kfR, klR);
+    }
+    bool ok = worst() < (25u << 5);
+#pragma unroll
+    for (int first = 5; first <= FAST_LAST - 3; first += 4) {
+        const unsigned long long open = __ballot(!ok);
+        if (open == 0ull || (int)__popcll(open) < cont_min) break;
+#pragma unroll
+        for (int k = first; k < first + 4; ++k) {
+            cons(c0[-k], k, kfL, klL);
+            cons(c0[k], k, kfR, klR);
+        }
+        ok = worst() < ((unsigned)((first + 4) * (first + 4)) << 5);
+    }
+    if (!ok) return false;
+    // (in stages, so that the four quadrants' look-ups travel together)
+    double ws[4];
+    float v4[4];
+    unsigned n4[4], dx4[4], dy4[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        n4[q] = ((q < 2 ? kfL : kfR) >> ((q & 1) ? 21 : 5)) & 0x7ffu;
+        ws[q] = ft.w[n4[q]];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const unsigned kf = q < 2 ? kfL : kfR, kl = q < 2 ? klL : klR;
+        const int sh = (q & 1) ? 16 : 0;
+        dx4[q] = __double2hiint(ws[q]) < 0 ? 31u - ((kl >> sh) & 31u) : (kf >> sh) & 31u;  // tie bit set: the last candidate at the best distance
+        dy4[q] = ft.root[n4[q] - dx4[q] * dx4[q]];  // (a perfect square)
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        // source = (y -/+ dy, x -/+ dx): rows and columns count from FAST_HALO before the tile, so nothing is negative
+        const unsigned rel = (q & 1) ? __umul24(dy4[q], (unsigned)stride) + rel0 : rel0 - __umul24(dy4[q], (unsigned)stride);
+        v4[q] = base[q < 2 ? rel - dx4[q] : rel + dx4[q]];
+    }
+    double wsum = 0.0, vsum = 0.0;  // the same sums in the same order as fill_one()
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        wsum = wsum + fabs(ws[q]);
+        vsum = vsum + (double)v4[q] * fabs(ws[q]);
+    }
+    out = (float)(vsum / wsum);
+    return true;
+}
+
+// TILED form of the search (round 3): a wave owns a tile of 64 columns x ROWS rows.  The per-row forms of rounds 1-2 started a
+// workgroup per 256-pixel row piece, and each lived for three dependent memory round trips (flag -> compaction behind two barriers
+// -> table words -> source values): PMC showed its waves WAITING 76 % of their 4.7 us life with the VALU 58 % busy.  Here a wave
+// takes the targets of its whole tile at once (one word of the column bit planes per lane), compacts them into a wave-private LDS
+// list (ballot + popcount) and then searches 64 targets per pass -- full waves whatever the failure rate, one wave start per ROWS
+// rows.  Round 5: the workgroup stages its tile of the distance table in LDS and a pass runs the packed search on it (fill_fast);
+// the targets it cannot settle go back to the front of the list and take fill_one() at the end of the tile, 64 at a time.
+// The filled values are written IN PLACE: a filled pixel never acts as a source (sources are read where flag == 1, targets are
+// written where flag == 0), and the closing pass reads the plane only at the failing pixels.
 #ifndef HK_FILL_TILE_WAVES
-#define HK_FILL_TILE_WAVES 8
+#define HK_FILL_TILE_WAVES 4
 #endif
 template <int ROWS>
-__global__ void __launch_bounds__(256, (ROWS <= 32 ? HK_FILL_TILE_WAVES : 5))  // (64-row tiles: the target lists' 32 KB of LDS per workgroup allow five)
-inpaint_fill_tile_kernel(const float* __restrict__ offset, const unsigned char* __restrict__ flag,
-                                                                   long long stride, int height, int width, int max_dist_arg,
-                                                                   const unsigned* __restrict__ tb,
-                                                                   const unsigned* __restrict__ tie,
-                                                                   const double* __restrict__ wtab, float* __restrict__ filled) {
-    static_assert(ROWS <= 64, "a list entry packs the tile row beside the lane; the row masks are 64-bit");
+__global__ void __launch_bounds__(256, (ROWS <= 8 ? 8 : (ROWS <= 16 ? HK_FILL_TILE_WAVES : 2)))
+inpaint_fill_tile_kernel(float* plane, const unsigned long long* __restrict__ tbits, long long stride, int height, int width,
+                         int max_dist_arg, const unsigned* __restrict__ tb, const unsigned* __restrict__ tie,
+                         const double* __restrict__ wtab, const FastTables* __restrict__ ftab, int fast, int cont_min) {
+    static_assert(ROWS == 8 || ROWS == 16 || ROWS == 32, "tiles divide the 64-row words of the bit planes; list + staged table fit the LDS of a CU at least twice");
     __shared__ unsigned short lst[256 / WAVE][ROWS * WAVE];
+    __shared__ unsigned tile[ROWS * FAST_PITCH];
+    __shared__ FastTables ftl;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
-    const int x0 = blockIdx.x * blockDim.x + wv * WAVE, x_own = x0 + lane;
+    const int xb = blockIdx.x * blockDim.x, x0 = xb + wv * WAVE, x_own = x0 + lane;
     const unsigned long long lt = (1ull << lane) - 1ull;
     // the search distance as a compile-time constant (the launcher passes FILL_MAX_DIST and nothing else): the first five steps become
     // straight-line code, the "nothing found yet" and acceptance bounds immediates
@@ -410,49 +489,79 @@ inpaint_fill_tile_kernel(const float* __restrict__ offset, const unsigned char* 
     // wave-uniform: the widest reach of a search stays inside the row -- the group that starts at step max_dist requests the one
     // after it (steps max_dist + 4 .. + 7) ahead, and a group's wide load covers 4 entries: 7 + 4 columns beyond max_dist
     const bool interior = x0 - max_dist - 12 >= 0 && x0 + WAVE - 1 + max_dist + 12 < width;
+    const bool fast_ok = fast && x0 - FAST_HALO >= 0 && x0 + WAVE - 1 + FAST_HALO < width;  // (no packed search reads a column outside the raster)
+    for (int j = tid; j < (int)(sizeof(FastTables) / 8); j += 256)
+        reinterpret_cast<unsigned long long*>(&ftl)[j] = reinterpret_cast<const unsigned long long*>(ftab)[j];
     const int n_tiles = (height + ROWS - 1) / ROWS;
-    for (int tile = blockIdx.y; tile < n_tiles; tile += gridDim.y) {
-        const int y0 = tile * ROWS;
-        // flags of the whole tile: ROWS independent byte loads per lane, kept as two bit masks (bit r = row y0 + r)
-        unsigned long long src_rows = 0ull, tgt_rows = 0ull;
-#pragma unroll 8
-        for (int r = 0; r < ROWS; ++r) {
-            const bool in = x_own < width && y0 + r < height;
-            const unsigned char f = in ? flag[(long long)(y0 + r) * stride + x_own] : (unsigned char)2;  // 2: outside the raster
-            src_rows |= (unsigned long long)(f == 1) << r;
-            tgt_rows |= (unsigned long long)(f == 0) << r;
+    for (int tile_i = blockIdx.y; tile_i < n_tiles; tile_i += gridDim.y) {
+        const int y0 = tile_i * ROWS;
+        // (never dereferenced before the raster's first pixel: sources and targets lie inside it)
+        float* const origin = plane + ((long long)(y0 - FAST_HALO) * stride + (xb - FAST_HALO));
+        if (fast) {  // the tile's piece of the distance table, FAST_HALO columns either side (16-byte pieces: stride % 4 == 0)
+            for (int j = tid; j < ROWS * (FAST_COLS / 4); j += 256) {
+                const int r = j / (FAST_COLS / 4), c4 = j - r * (FAST_COLS / 4), xs = xb - FAST_HALO + 4 * c4;
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (y0 + r < height && xs >= 0 && xs + 3 < stride) v = *reinterpret_cast<const uint4*>(tb + (long long)(y0 + r) * stride + xs);
+                *reinterpret_cast<uint4*>(&tile[r * FAST_PITCH + 4 * c4]) = v;
+            }
+        }
+        // the tile's targets: bit r of the lane's word = row y0 + r of its column (rows past the raster are clear)
+        unsigned long long tgt_rows = 0ull;
+        if (x_own < width) {
+            tgt_rows = tbits[(long long)(y0 / WORD_ROWS) * stride + x_own] >> (y0 % WORD_ROWS);
+            tgt_rows &= (1ull << ROWS) - 1ull;
         }
         int n = 0;  // wave-uniform: targets of the tile so far
 #pragma unroll 4
         for (int r = 0; r < ROWS; ++r) {
-            const long long i = (long long)(y0 + r) * stride + x_own;
-            if ((src_rows >> r) & 1ull) filled[i] = offset[i];  // filled pixels never act as sources: sources pass through
             const bool target = (tgt_rows >> r) & 1ull;
             const unsigned long long bal = __ballot(target);
             if (target) lst[wv][n + (int)__popcll(bal & lt)] = (unsigned short)((r << 6) | lane);
             n += (int)__popcll(bal);
         }
-        __syncthreads();  // (the list is the wave's own; the barrier only orders its LDS writes before the reads below)
+        __syncthreads();  // the staged table (and the first tile's ftl) for everyone; the list is the wave's own
+        int n_slow = n;
+        if (fast_ok) {
+            n_slow = 0;  // wave-uniform: targets handed on to fill_one(), packed at the front of the list (n_slow <= p: behind the reads)
+            for (int p = 0; p < n; p += WAVE) {
+                const bool act = p + lane < n;
+                const unsigned e = act ? lst[wv][p + lane] : 0u;
+                bool settled = false;
+                if (act) {
+                    const int r = (int)(e >> 6), xl = wv * WAVE + (int)(e & 63u);
+                    float v;
+                    const unsigned rel0 = (unsigned)(r + FAST_HALO) * (unsigned)stride + (unsigned)(xl + FAST_HALO);
+                    settled = fill_fast(&tile[r * FAST_PITCH + FAST_HALO + xl], origin, rel0, (int)stride, ftl, cont_min, v);
+                    if (settled) origin[rel0] = v;
+                }
+                const unsigned long long bal = __ballot(act && !settled);
+                if (act && !settled) lst[wv][n_slow + (int)__popcll(bal & lt)] = (unsigned short)e;
+                n_slow += (int)__popcll(bal);
+            }
+        }
         // passes of 64 targets (an explicit request of pass p + 1's first look-ups while pass p searches was measured slower:
         // 21.7 against 21.2 ms per step, profiles/r03_fill_tile.txt)
-        for (int p = 0; p < n; p += WAVE) {
-            if (p + lane < n) {
+        for (int p = 0; p < n_slow; p += WAVE) {
+            if (p + lane < n_slow) {
                 const unsigned e = lst[wv][p + lane];
                 const int x = x0 + (int)(e & 63u), y = y0 + (int)(e >> 6);
                 const long long row = (long long)y * stride;
-                filled[row + x] = interior ? fill_one<true>(x, y, row, offset, stride, width, max_dist, tb, tie, wtab)
-                                           : fill_one<false>(x, y, row, offset, stride, width, max_dist, tb, tie, wtab);
+                const float v = interior ? fill_one<true>(x, y, row, plane, stride, width, max_dist, tb, tie, wtab)
+                                         : fill_one<false>(x, y, row, plane, stride, width, max_dist, tb, tie, wtab);
+                plane[row + x] = v;
             }
         }
-        __syncthreads();  // the next tile re-uses the list
+        __syncthreads();  // the next tile re-uses the list and the staged table
     }
 }
 
-// workspace: the distance table (2 of its 4 bytes per pixel are used) + source flags (1 byte per pixel) + the tie bitmap + the weight table
-// + the column bit words (one 64-bit word per column and 64 rows; a plane of a few rows has more of those than spare table bytes)
+// workspace: the distance table + source flags (1 byte per pixel) + the tie bitmap + the weight table
+// + the column bit words of sources and targets (one 64-bit word each per column and 64 rows; a plane of a few rows has more of
+// those than spare table bytes) + the packed search's table
 static size_t bit_words(int height, long long stride) { return (size_t)((height + WORD_ROWS - 1) / WORD_ROWS) * (size_t)stride; }
 size_t inpaint_workspace_bytes(int height, long long stride) {
-    return (size_t)height * stride * 5 + 1024 + TIE_N / 8 + 256 + WTAB_N * 8 + 256 + bit_words(height, stride) * 8 + 256;
+    return (size_t)height * stride * 5 + 1024 + TIE_N / 8 + 256 + WTAB_N * 8 + 256 + 2 * (bit_words(height, stride) * 8 + 256)
+           + sizeof(FastTables) + 256;
 }
 
 // the workspace's source-flag plane: the fit kernel can write it itself (FitArgs::flag), then gain / r2 are not needed here
@@ -460,8 +569,8 @@ unsigned char* inpaint_flag_plane(void* workspace, int height, long long stride)
     return reinterpret_cast<unsigned char*>(static_cast<unsigned short*>(workspace) + 2 * (size_t)height * stride);
 }
 
-hipError_t launch_inpaint_offsets(const float* offset, const float* gain, const float* r2, float thresh, long long stride,
-                                  int height, int width, void* workspace, float* filled, hipStream_t stream,
+hipError_t launch_inpaint_offsets(float* offset, const float* gain, const float* r2, float thresh, long long stride,
+                                  int height, int width, void* workspace, hipStream_t stream,
                                   const unsigned char* flag_ready, unsigned long long n_targets) {
     const size_t plane = (size_t)height * stride;
     unsigned* tb = static_cast<unsigned*>(workspace);  // (down^2 << 16) | up^2 row distances, 4 bytes per pixel
@@ -475,43 +584,38 @@ hipError_t launch_inpaint_offsets(const float* offset, const float* gain, const 
     if (!flag_ready)  // else: the flag plane was written by the fit kernel (FitArgs::flag)
         hipLaunchKernelGGL(inpaint_flag_kernel, dim3((width + 255) / 256, height < 1024 ? height : 1024), dim3(256), 0, stream,
                            gain, r2, thresh, stride, height, width, ws_flag);
-    // column bit words behind the weight table (256-byte aligned)
-    unsigned long long* bits = reinterpret_cast<unsigned long long*>(
-        (reinterpret_cast<uintptr_t>(wtab + WTAB_N) + 255) / 256 * 256);
+    // column bit words behind the weight table (256-byte aligned): sources, then targets; the packed search's table behind them
+    auto align256 = [](void* p) { return reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(p) + 255) / 256 * 256); };
+    unsigned long long* bits = static_cast<unsigned long long*>(align256(wtab + WTAB_N));
+    unsigned long long* tbits = static_cast<unsigned long long*>(align256(bits + bit_words(height, stride)));
+    FastTables* ftab = static_cast<FastTables*>(align256(tbits + bit_words(height, stride)));
+    hipLaunchKernelGGL(fast_table_kernel, dim3((FTAB_N + 7 + 255) / 256), dim3(256), 0, stream, ftab);
     const dim3 gbits((width + 1023) / 1024, (height + WORD_ROWS - 1) / WORD_ROWS);  // four columns per thread
-    hipLaunchKernelGGL(inpaint_bits_kernel, gbits, dim3(256), 0, stream, flag, stride, height, width, bits);
+    hipLaunchKernelGGL(inpaint_bits_kernel, gbits, dim3(256), 0, stream, flag, stride, height, width, bits, tbits);
     const dim3 gtable((width + 511) / 512, (height + WORD_ROWS - 1) / WORD_ROWS);  // two columns per thread
     hipLaunchKernelGGL(inpaint_table_kernel, gtable, dim3(256), 0, stream, bits, stride, height, width, max_dist, tb);
-    const dim3 gfill((width + 255) / 256, height < 65535 ? height : 65535);
-    // The TILED search (64 columns x 32 rows per wave; 16 rows 21.4 against 21.2 ms per step, 64 rows 27.1 when it was introduced,
-    // profiles/r03_fill_tile.txt) serves every failure rate since its candidate test is branch-free (at 94 % failures 36.7 against
-    // 37.7 ms for the one-thread-per-pixel form).  HK_FILL_TILE=0 selects the per-row forms of rounds 1-2 (A/B; n_targets -- the
-    // number of pixels to fill as the caller knows it, 0 = unknown -- picks between them), 4..64 another tile height.
+    // The TILED search (64 columns x ROWS rows per wave).  HK_FILL_TILE = 8 / 16 / 32: the tile height (8: eight workgroups per
+    // CU beside their staged tables); HK_FILL_FAST=0: without the packed search (A/B); HK_FILL_CONT: lanes that must still be open
+    // for the packed search to go on to the next group of columns.
+    (void)n_targets;
     static const int tile_env = [] { const char* e = getenv("HK_FILL_TILE"); return e ? atoi(e) : -1; }();
-    const bool moderate = n_targets == 0 || (double)n_targets < 0.6 * (double)height * (double)width;
-    const int tile_rows = tile_env >= 0 ? tile_env : 32;
-    if (tile_rows > 0) {
-        const int rows = tile_rows >= 64 ? 64 : (tile_rows >= 32 ? 32 : (tile_rows >= 16 ? 16 : (tile_rows >= 8 ? 8 : 4)));
-        const int n_tiles = (height + rows - 1) / rows;
-        const dim3 gt((width + 255) / 256, n_tiles < 65535 ? n_tiles : 65535);
-        if (rows == 64)
-            hipLaunchKernelGGL(inpaint_fill_tile_kernel<64>, gt, dim3(256), 0, stream, offset, flag, stride, height, width, max_dist, tb, tie, wtab, filled);
-        else if (rows == 32)
-            hipLaunchKernelGGL(inpaint_fill_tile_kernel<32>, gt, dim3(256), 0, stream, offset, flag, stride, height, width, max_dist, tb, tie, wtab, filled);
-        else if (rows == 16)
-            hipLaunchKernelGGL(inpaint_fill_tile_kernel<16>, gt, dim3(256), 0, stream, offset, flag, stride, height, width, max_dist, tb, tie, wtab, filled);
-        else if (rows == 8)
-            hipLaunchKernelGGL(inpaint_fill_tile_kernel<8>, gt, dim3(256), 0, stream, offset, flag, stride, height, width, max_dist, tb, tie, wtab, filled);
-        else
-            hipLaunchKernelGGL(inpaint_fill_tile_kernel<4>, gt, dim3(256), 0, stream, offset, flag, stride, height, width, max_dist, tb, tie, wtab, filled);
-        return hipGetLastError();
-    }
-    if (moderate)
-        hipLaunchKernelGGL(inpaint_fill_kernel<true>, gfill, dim3(256), 0, stream, offset, flag, stride, height, width, max_dist,
-                           tb, tie, wtab, filled);
-    else
-        hipLaunchKernelGGL(inpaint_fill_kernel<false>, gfill, dim3(256), 0, stream, offset, flag, stride, height, width, max_dist,
-                           tb, tie, wtab, filled);
+    static const int fast_env = [] { const char* e = getenv("HK_FILL_FAST"); return e ? atoi(e) : 1; }();
+    static const int cont_env = [] { const char* e = getenv("HK_FILL_CONT"); return e ? atoi(e) : 1; }();
+    const int tile_rows = tile_env > 0 ? tile_env : 8;
+    const int rows = tile_rows >= 32 ? 32 : (tile_rows >= 16 ? 16 : 8);
+    const int n_tiles = (height + rows - 1) / rows;
+    // a workgroup takes several tiles (it copies the finish tables into LDS once)
+    const int per_wg = 32 / rows, wgs_y = (n_tiles + per_wg - 1) / per_wg;
+    const dim3 gt((width + 255) / 256, wgs_y < 65535 ? wgs_y : 65535);
+    // the packed search addresses the plane through 32-bit offsets from its tile and 24-bit multiplies by the row stride
+    const int fast = (fast_env && stride < (1ll << 23)) ? 1 : 0;
+#define HK_FILL_LAUNCH(R)                                                                                                            \
+    hipLaunchKernelGGL(inpaint_fill_tile_kernel<R>, gt, dim3(256), 0, stream, offset, tbits, stride, height, width, max_dist, tb, tie, \
+                       wtab, ftab, fast, cont_env)
+    if (rows == 32) HK_FILL_LAUNCH(32);
+    else if (rows == 8) HK_FILL_LAUNCH(8);
+    else HK_FILL_LAUNCH(16);
+#undef HK_FILL_LAUNCH
     return hipGetLastError();
 }
 

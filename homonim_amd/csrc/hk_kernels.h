@@ -195,14 +195,15 @@ hipError_t launch_partial_mask(const float* in, int nd_mode, float nodata, const
                                unsigned char* mask_out, hipStream_t stream);
 
 // In-painting of the offset band (hk_inpaint.hip; GDALFillNodata restated): sources are pixels with r2 > thresh and
-// gain > 0, everything else is a target.  workspace: inpaint_workspace_bytes(); filled: height x stride float32.
+// gain > 0 (flag 1), flag 0 pixels are targets and are filled IN PLACE (a filled pixel never acts as a source: sources are read
+// where the flag is 1 only), any other flag value is neither.  workspace: inpaint_workspace_bytes().
 size_t inpaint_workspace_bytes(int height, long long stride);
 // `flag_ready` (nullable): source flags already written by the fit kernel (FitArgs::flag; 1 byte per pixel, row stride
 // `stride`) -- gain / r2 are then not read.  inpaint_flag_plane(): the workspace's own flag plane, for a fit to write into.
-// `n_targets`: the number of pixels to fill if the caller knows it (0 = unknown): picks the search kernel's lane mapping.
+// `n_targets`: the number of pixels to fill if the caller knows it (0 = unknown; unused since the tiled search serves every rate).
 unsigned char* inpaint_flag_plane(void* workspace, int height, long long stride);
-hipError_t launch_inpaint_offsets(const float* offset, const float* gain, const float* r2, float thresh, long long stride,
-                                  int height, int width, void* workspace, float* filled, hipStream_t stream,
+hipError_t launch_inpaint_offsets(float* offset, const float* gain, const float* r2, float thresh, long long stride,
+                                  int height, int width, void* workspace, hipStream_t stream,
                                   const unsigned char* flag_ready = nullptr, unsigned long long n_targets = 0);
 
 // Re-sampling between axis-aligned grids (hk_resample.hip).  mode = rasterio.enums.Resampling value (0, 1, 3, 5).

@@ -958,6 +958,34 @@ def test_r2_inpainting_of_blocks_of_a_few_rows(ctx, oc, h):
         assert_close_ulp(corr, exp_corr, f'corrected, {h} rows', max_frac=2e-3)
 
 
+@pytest.mark.parametrize('sd, frame, lo, hi', [(0.45, False, 0.15, 0.6), (0.45, True, 0.15, 0.6), (0.9, False, 0.6, 0.97),
+                                                 (2.5, True, 0.9, 0.999), (0.3, False, 0.0005, 0.1)])
+def test_r2_inpainting_of_noisy_pairs(ctx, oc, sd, frame, lo, hi):
+    """ Failing pixels scattered all over a raster wide enough for the PACKED search (hk_inpaint.hip fill_fast: 16-bit keys, two
+    quadrants per instruction) in the middle columns and the general one at the edges: from a few failing pixels among many sources
+    to a few sources among failing pixels (searches that run past the packed range and are handed on).  Bit for bit against the
+    restatement, offsets and gains of every pixel. """
+    h, w = 150, 710
+    rng = np.random.default_rng(int(sd * 100) + frame)
+    src = rng.uniform(0.05, 1, (h, w)).astype(np.float32)
+    ref = (1.3 * src + 0.05 + rng.normal(0, sd, (h, w))).astype(np.float32)
+    if frame:
+        src[:3], src[-3:], src[:, :3], src[:, -3:] = np.nan, np.nan, np.nan, np.nan
+        holes = rng.uniform(size=(h, w)) < 0.002
+        src[holes] = np.nan
+        ref[60:75, 300:330] = np.nan   # a hole larger than the window: pixels that are neither sources nor worth filling
+    exp_params, exp_corr, exp_fail = oc.fit_apply('gain-offset', src, np.nan, ref, np.nan, (5, 5), False, 0.25)
+    valid = int(np.count_nonzero(~np.isnan(exp_params[0])))
+    assert lo < exp_fail / valid < hi, exp_fail / valid
+    desc = _hk.make_desc('gain-offset', (5, 5), False, 0.25, np.nan, np.nan)
+    for _ in range(2):
+        params, corr, _, n_fail = ctx.fit_apply(desc, src, ref, 3, want_params=True, want_corr=True)
+        assert n_fail == exp_fail
+        for got, exp, what in ((params[1], exp_params[1], 'in-painted offsets'), (params[0], exp_params[0], 'gains'), (corr, exp_corr, 'corrected')):
+            bad = np.argwhere(~((got == exp) | (np.isnan(got) & np.isnan(exp))))
+            assert len(bad) == 0, f'{what}, noise {sd}: {len(bad)} pixels differ, first at {bad[:5].tolist()}'
+
+
 def test_r2_inpainting_of_a_block_taller_than_a_grid_dimension(ctx, oc):
     """ 66 000 rows: the in-painting kernels stride over the rows (a launch has at most 65 535 workgroups along y), and the
     column bit words / distance table cover the whole height; failing patches near the top, the middle and the last rows. """
