@@ -336,8 +336,8 @@ __device__ __forceinline__ float fill_one(int x, int y, long long row, const flo
 // Where the sources are dense -- the usual case: a failing pixel has passing ones a few pixels away in every quadrant -- the search
 // state fits 16 bits per quadrant: key = (squared distance << 5) | column distance, for squared distances below FAST_CLIP and
 // columns up to FAST_LAST away.  A table word holds the two row distances of a column (up | down << 16), so ONE packed
-// instruction serves two quadrants: per column visited the search costs five VALU instructions (clip, two multiply-adds with the
-// step's constants, two minima) where the 32-bit keys of fill_one() cost ten.  The decisions are the same ones:
+// instruction serves two quadrants: per column visited the search costs four VALU instructions (two additions of the step's
+// constants, two minima; the words are clipped and scaled when they are staged) where the 32-bit keys of fill_one() cost ten.  The decisions are the same ones:
 //   * first / last candidate at the best squared distance = smallest key with the column distance / its complement in the low bits;
 //   * a quadrant is SETTLED after step S when its best squared distance is below (S + 1)^2: any candidate in a farther column,
 //     and any candidate whose row distance was clipped (>= FAST_CLIP > (FAST_LAST + 1)^2), is strictly farther -- it can neither
@@ -356,11 +356,8 @@ __device__ __forceinline__ unsigned pk_min_u16(unsigned a, unsigned b) {
 __device__ __forceinline__ unsigned pk_max_u16(unsigned a, unsigned b) {
     return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(us2_t, a), __builtin_bit_cast(us2_t, b)));
 }
-// per half: a * 32 + c (no carry between the halves; the callers keep every half below 2^16)
-__device__ __forceinline__ unsigned pk_mad32_u16(unsigned a, unsigned c) {
-    unsigned r;
-    asm("v_pk_mad_u16 %0, %1, 32, %2 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(c));
-    return r;
+__device__ __forceinline__ unsigned pk_add_u16(unsigned a, unsigned b) {  // (no carry between the halves; the callers keep every half below 2^16)
+    return __builtin_bit_cast(unsigned, __builtin_bit_cast(us2_t, a) + __builtin_bit_cast(us2_t, b));
 }
 constexpr int FAST_LAST = 24;        // last column distance of the packed search (groups end at 4, 8, ..., 24)
 constexpr unsigned FAST_CLIP = 1263; // row distances squared are clipped here: (1263 + 24^2) * 32 + 31 < 65536, and 1263 > 25^2
@@ -373,6 +370,10 @@ static_assert(FAST_HALO >= FAST_LAST && FAST_HALO % 4 == 0, "the staged halo");
 // 1 / sqrt(n) with n's TIE BIT AS ITS SIGN (weights are positive; the sums take the magnitude through the operand modifier),
 // and the square roots of the perfect squares (the winner's row distance from what is left of n beside its column distance).
 constexpr int FTAB_N = (FAST_LAST + 1) * (FAST_LAST + 1);  // a settled quadrant's squared distance is below this
+// a word of the distance table as the packed search wants it: both halves clipped to FAST_CLIP and shifted into the key's place
+__device__ __forceinline__ unsigned fast_stage_word(unsigned e) {
+    return __builtin_bit_cast(unsigned, __builtin_bit_cast(us2_t, pk_min_u16(e, FAST_CLIP * 0x10001u)) << (us2_t)(5));
+}
 struct FastTables {
     double w[FTAB_N];
     unsigned char root[FTAB_N + 7];
@@ -398,10 +399,10 @@ __global__ void __launch_bounds__(256) fast_table_kernel(FastTables* __restrict_
 __device__ __forceinline__ bool fill_fast(const unsigned* c0, const float* __restrict__ base, unsigned rel0, int stride,
                                           const FastTables& ft, int cont_min, float& out) {
     unsigned kfL = ~0u, klL = ~0u, kfR = ~0u, klR = ~0u;  // (down | up) halves: left quadrants 1 | 0, right quadrants 3 | 2
+    // `e`: a staged table word -- both halves clipped and scaled already (fast_stage_word)
     auto cons = [](unsigned e, int k, unsigned& kf, unsigned& kl) {
-        const unsigned ec = pk_min_u16(e, FAST_CLIP * 0x10001u);
-        kf = pk_min_u16(kf, pk_mad32_u16(ec, (unsigned)((k * k << 5) + k) * 0x10001u));
-        kl = pk_min_u16(kl, pk_mad32_u16(ec, (unsigned)((k * k << 5) + 31 - k) * 0x10001u));
+        kf = pk_min_u16(kf, pk_add_u16(e, (unsigned)((k * k << 5) + k) * 0x10001u));
+        kl = pk_min_u16(kl, pk_add_u16(e, (unsigned)((k * k << 5) + 31 - k) * 0x10001u));
     };
     auto worst = [&]() {
         const unsigned m = pk_max_u16(kfL, kfR);
@@ -500,9 +501,10 @@ inpaint_fill_tile_kernel(float* plane, const unsigned long long* __restrict__ tb
         if (fast) {  // the tile's piece of the distance table, FAST_HALO columns either side (16-byte pieces: stride % 4 == 0)
             for (int j = tid; j < ROWS * (FAST_COLS / 4); j += 256) {
                 const int r = j / (FAST_COLS / 4), c4 = j - r * (FAST_COLS / 4), xs = xb - FAST_HALO + 4 * c4;
-                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                uint4 v = make_uint4(0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu);  // (outside the raster: no source in reach)
                 if (y0 + r < height && xs >= 0 && xs + 3 < stride) v = *reinterpret_cast<const uint4*>(tb + (long long)(y0 + r) * stride + xs);
-                *reinterpret_cast<uint4*>(&tile[r * FAST_PITCH + 4 * c4]) = v;
+                *reinterpret_cast<uint4*>(&tile[r * FAST_PITCH + 4 * c4]) =
+                    make_uint4(fast_stage_word(v.x), fast_stage_word(v.y), fast_stage_word(v.z), fast_stage_word(v.w));
             }
         }
         // the tile's targets: bit r of the lane's word = row y0 + r of its column (rows past the raster are clear)
