@@ -1502,7 +1502,8 @@ fit_apply_kernel(const FitArgs a_in) {
                     if (a.offset) store4_nt(at(a.offset), masked4(o));
                     if (R2 && a.r2) store4_nt(at(a.r2), masked4(r2v));
                     if constexpr (GO && R2 && !CERT_ONLY) {
-                        if (a.flag) *reinterpret_cast<unsigned*>(a.flag + row_off + (xbytes >> 2)) = passed;
+                        // 1: source of the in-painting, 0: target, 2: invalid -- neither (what a fill would put there is reset to NaN anyway, kernel_model.py:367)
+                        if (a.flag) *reinterpret_cast<unsigned*>(a.flag + row_off + (xbytes >> 2)) = passed | ((~mcu & 0x01010101u) << 1);
                     }
                 }
             };

@@ -50,7 +50,7 @@ struct FitArgs {
     const unsigned char* flag_in;    // ... with the source flags of the in-painting (1 byte per pixel): the build WITHOUT R2 then
                                      // takes the r2-mask decision from them instead of evaluating R2 again; else NULL
     unsigned long long* fail_count;  // n_bands
-    unsigned char* flag;             // gain-offset with a threshold: 1 byte per pixel = (r2 > thresh) & (gain > 0) & valid
+    unsigned char* flag;             // gain-offset with a threshold: 1 byte per pixel = 1: (r2 > thresh) & (gain > 0) & valid, 0: valid and failing, 2: invalid
                                      // (kernel_model.py:363), the in-painting's source mask; same strides as the planes; or NULL
     int height, width;
     long long stride;       // elements between rows
