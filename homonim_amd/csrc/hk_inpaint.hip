@@ -349,6 +349,9 @@ __device__ __forceinline__ float fill_one(int x, int y, long long row, const flo
 // there.  The finish reads the weight 1 / sqrt(n) (n's tie bit is its sign) and a square root from small LDS tables, and the
 // source's value from the plane; all four quadrants of a settled target hold a source within max_dist, so GDAL's acceptance tests are true by
 // construction.
+#ifndef HK_FAST_LAST
+#define HK_FAST_LAST 24
+#endif
 typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned pk_min_u16(unsigned a, unsigned b) {
     return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(us2_t, a), __builtin_bit_cast(us2_t, b)));
@@ -359,9 +362,9 @@ __device__ __forceinline__ unsigned pk_max_u16(unsigned a, unsigned b) {
 __device__ __forceinline__ unsigned pk_add_u16(unsigned a, unsigned b) {  // (no carry between the halves; the callers keep every half below 2^16)
     return __builtin_bit_cast(unsigned, __builtin_bit_cast(us2_t, a) + __builtin_bit_cast(us2_t, b));
 }
-constexpr int FAST_LAST = 24;        // last column distance of the packed search (groups end at 4, 8, ..., 24)
+constexpr int FAST_LAST = HK_FAST_LAST;        // last column distance of the packed search (groups end at 4, 8, ..., 24)
 constexpr unsigned FAST_CLIP = 1263; // row distances squared are clipped here: (1263 + 24^2) * 32 + 31 < 65536, and 1263 > 25^2
-constexpr int FAST_HALO = 24;        // table columns staged either side of a workgroup's 256 (>= FAST_LAST, a multiple of 4)
+constexpr int FAST_HALO = HK_FAST_LAST;        // table columns staged either side of a workgroup's 256 (>= FAST_LAST, a multiple of 4)
 constexpr int FAST_COLS = 256 + 2 * FAST_HALO, FAST_PITCH = FAST_COLS + 4;  // (pitch % 32 == 20: the rows of a pass spread over the banks)
 static_assert((FAST_CLIP + FAST_LAST * FAST_LAST) * 32 + 31 <= 0xffffu, "a packed key overflows its half");
 static_assert(FAST_CLIP > (FAST_LAST + 1) * (FAST_LAST + 1), "a clipped candidate could settle a quadrant");
