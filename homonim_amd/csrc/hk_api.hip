@@ -922,9 +922,10 @@ void fill_grid(hk::FitArgs& a, int seg_rows) {
 // kernel_model.py:364-371 for ONE band whose first pass counted failing pixels: in-paint the offsets of the failing
 // pixels from the passing ones (restated GDALFillNodata) and run the fit again with `offset_in`, which recomputes their
 // gains and re-applies.  `a` is the first pass's argument block (n_bands == 1).
-// scratch of the in-painting branch: [filled | gain | offset | r2 | column tables]
+// scratch of the in-painting branch: [offset | column tables] (rounds 1-4 kept a `filled` plane and room for gain / r2 in front: the
+// targets are filled in place since round 5)
 static int ensure_inpaint_scratch(Slot& sl, size_t plane, int height, long long stride) {
-    const size_t need = 4 * plane + hk::inpaint_workspace_bytes(height, stride);
+    const size_t need = plane + hk::inpaint_workspace_bytes(height, stride);
     if (!fits(sl.aux_bytes, need)) {
         if (sl.aux) {
             HK_HIP(hipStreamSynchronize(sl.stream));
@@ -964,10 +965,10 @@ static int inpaint_band(Slot& sl, const hk::FitArgs& a, const hk_fit_desc* desc,
     } else if (!pg || !po || !pr) {
         // parameters were not materialised by the first pass: run it again for what the in-painting reads -- the offsets
         // and the source flags, which the kernel writes itself (1 byte per pixel)
-        float* scratch_off = reinterpret_cast<float*>(aux + plane);
+        float* scratch_off = reinterpret_cast<float*>(aux);
         hk::FitArgs b = a;
         b.gain = nullptr, b.r2 = nullptr, b.offset = scratch_off, b.corr = nullptr, b.fail_count = nullptr;
-        b.flag = hk::inpaint_flag_plane(aux + 4 * plane, a.height, a.stride);
+        b.flag = hk::inpaint_flag_plane(aux + plane, a.height, a.stride);
         b.cert_only = 0;
         HK_HIP(hk::launch_fit_apply(b, desc->model, r2, stream));
         po = scratch_off, flags = b.flag;
@@ -976,14 +977,14 @@ static int inpaint_band(Slot& sl, const hk::FitArgs& a, const hk_fit_desc* desc,
     // pixel): sources are read only where the flag is 1, targets written only where it is 0, and the closing pass -- which reads the
     // plane at the failing pixels only -- rewrites the caller's offset plane whole when there is one.
     // n_fail (the failing VALID pixels) is a lower bound of the pixels to fill (nodata pixels are filled as well)
-    HK_HIP(hk::launch_inpaint_offsets(po, pg, pr, desc->r2_thresh, a.stride, a.height, a.width, aux + 4 * plane, stream, flags,
+    HK_HIP(hk::launch_inpaint_offsets(po, pg, pr, desc->r2_thresh, a.stride, a.height, a.width, aux + plane, stream, flags,
                                       n_fail));
     // closing pass: the failing pixels take the in-painted offsets and recomputed gains (kernel_model.py:370-371).  Which
     // pixels failed is in the flag plane the in-painting just used, so the build WITHOUT the R2 work runs (the R2 plane, if
     // the caller keeps one, was written by the pass that counted and is not changed by the branch)
     hk::FitArgs c = a;
     c.offset_in = po;
-    c.flag_in = flags ? flags : hk::inpaint_flag_plane(aux + 4 * plane, a.height, a.stride);
+    c.flag_in = flags ? flags : hk::inpaint_flag_plane(aux + plane, a.height, a.stride);
     c.fail_count = nullptr;  // already counted
     c.flag = nullptr;
     c.r2 = nullptr;
@@ -1080,9 +1081,9 @@ int fit_on_device(hk_ctx* ctx, Slot& sl, const hk_fit_desc* desc, const double* 
         int rc = ensure_inpaint_scratch(sl, plane, height, stride);
         if (rc) return rc;
         char* aux = static_cast<char*>(sl.aux);
-        a.flag = hk::inpaint_flag_plane(aux + 4 * plane, height, stride);
+        a.flag = hk::inpaint_flag_plane(aux + plane, height, stride);
         if (!d_off) {
-            a.offset = reinterpret_cast<float*>(aux + plane);
+            a.offset = reinterpret_cast<float*>(aux);
             p.scratch_params = !d_gain && !d_r2;
         }
     }
@@ -1901,8 +1902,8 @@ int hk_inpaint_dev_counts(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job
             if (rc) return rc;
             char* aux = static_cast<char*>(sl.aux);
             float* const caller_off = a.offset;
-            a.flag = job->scratch ? job_scratch_flag(job) + off : hk::inpaint_flag_plane(aux + 4 * plane, a.height, a.stride);
-            if (!a.offset) a.offset = job->scratch ? job_scratch_offset(job) + off : reinterpret_cast<float*>(aux + plane);
+            a.flag = job->scratch ? job_scratch_flag(job) + off : hk::inpaint_flag_plane(aux + plane, a.height, a.stride);
+            if (!a.offset) a.offset = job->scratch ? job_scratch_offset(job) + off : reinterpret_cast<float*>(aux);
             a.fail_count = d_fail;
             HK_HIP(hipMemsetAsync(d_fail, 0, sizeof(unsigned long long), sl.stream));
             HK_HIP(hk::launch_fit_apply(a, desc->model, r2, sl.stream));
