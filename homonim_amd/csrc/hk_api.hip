@@ -976,9 +976,7 @@ static int inpaint_band(Slot& sl, const hk::FitArgs& a, const hk_fit_desc* desc,
     // The failing pixels' offsets are in-painted IN PLACE (round 5; a separate `filled` plane cost a pass-through of every source
     // pixel): sources are read only where the flag is 1, targets written only where it is 0, and the closing pass -- which reads the
     // plane at the failing pixels only -- rewrites the caller's offset plane whole when there is one.
-    // n_fail (the failing VALID pixels) is a lower bound of the pixels to fill (nodata pixels are filled as well)
-    HK_HIP(hk::launch_inpaint_offsets(po, pg, pr, desc->r2_thresh, a.stride, a.height, a.width, aux + plane, stream, flags,
-                                      n_fail));
+    HK_HIP(hk::launch_inpaint_offsets(po, pg, pr, desc->r2_thresh, a.stride, a.height, a.width, aux + plane, stream, flags, n_fail));
     // closing pass: the failing pixels take the in-painted offsets and recomputed gains (kernel_model.py:370-371).  Which
     // pixels failed is in the flag plane the in-painting just used, so the build WITHOUT the R2 work runs (the R2 plane, if
     // the caller keeps one, was written by the pass that counted and is not changed by the branch)

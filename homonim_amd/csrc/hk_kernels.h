@@ -200,7 +200,7 @@ hipError_t launch_partial_mask(const float* in, int nd_mode, float nodata, const
 size_t inpaint_workspace_bytes(int height, long long stride);
 // `flag_ready` (nullable): source flags already written by the fit kernel (FitArgs::flag; 1 byte per pixel, row stride
 // `stride`) -- gain / r2 are then not read.  inpaint_flag_plane(): the workspace's own flag plane, for a fit to write into.
-// `n_targets`: the number of pixels to fill if the caller knows it (0 = unknown; unused since the tiled search serves every rate).
+// `n_targets`: the number of failing pixels if the caller knows it (0 = unknown): picks the order in which a tile's targets are searched.
 unsigned char* inpaint_flag_plane(void* workspace, int height, long long stride);
 hipError_t launch_inpaint_offsets(float* offset, const float* gain, const float* r2, float thresh, long long stride,
                                   int height, int width, void* workspace, hipStream_t stream,
