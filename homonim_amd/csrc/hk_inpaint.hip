@@ -496,7 +496,10 @@ inpaint_fill_tile_kernel(float* plane, const unsigned long long* __restrict__ tb
     // wave-uniform: the widest reach of a search stays inside the row -- the group that starts at step max_dist requests the one
     // after it (steps max_dist + 4 .. + 7) ahead, and a group's wide load covers 4 entries: 7 + 4 columns beyond max_dist
     const bool interior = x0 - max_dist - 12 >= 0 && x0 + WAVE - 1 + max_dist + 12 < width;
-    const bool fast_ok = fast && x0 - FAST_HALO >= 0 && x0 + WAVE - 1 + FAST_HALO < width;  // (no packed search reads a column outside the raster)
+    // Columns outside the raster are staged as "no source in reach": GDAL re-checks the edge column there, which changes nothing (the
+    // edge column was the farthest candidate of its side already) -- except for the right quadrants of the LAST column, whose first
+    // and only candidate is the re-checked own column: they find nothing here, do not settle and go through fill_one().
+    const bool fast_ok = fast;
     for (int j = tid; j < (int)(sizeof(FastTables) / 8); j += 256)
         reinterpret_cast<unsigned long long*>(&ftl)[j] = reinterpret_cast<const unsigned long long*>(ftab)[j];
     const int n_tiles = (height + ROWS - 1) / ROWS;
@@ -508,7 +511,12 @@ inpaint_fill_tile_kernel(float* plane, const unsigned long long* __restrict__ tb
             for (int j = tid; j < ROWS * (FAST_COLS / 4); j += 256) {
                 const int r = j / (FAST_COLS / 4), c4 = j - r * (FAST_COLS / 4), xs = xb - FAST_HALO + 4 * c4;
                 uint4 v = make_uint4(0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu);  // (outside the raster: no source in reach)
-                if (y0 + r < height && xs >= 0 && xs + 3 < stride) v = *reinterpret_cast<const uint4*>(tb + (long long)(y0 + r) * stride + xs);
+                if (y0 + r < height && xs >= 0 && xs < width) {  // (xs + 3 < stride: rows are padded to quads)
+                    v = *reinterpret_cast<const uint4*>(tb + (long long)(y0 + r) * stride + xs);
+                    if (xs + 3 >= width) {  // the quad straddles the raster's last column: the padding holds no entries
+                        v.y = xs + 1 < width ? v.y : 0x7fff7fffu, v.z = xs + 2 < width ? v.z : 0x7fff7fffu, v.w = 0x7fff7fffu;
+                    }
+                }
                 *reinterpret_cast<uint4*>(&tile[r * FAST_PITCH + 4 * c4]) =
                     make_uint4(fast_stage_word(v.x), fast_stage_word(v.y), fast_stage_word(v.z), fast_stage_word(v.w));
             }
