@@ -1124,6 +1124,24 @@ def main():
             'parity_spot_check': r2_['parity'],
         }
 
+    # The in-painting branch of the gain-offset model (kernel_model.py:361-371; r2_inpaint_thresh = 0.25 is the model's default)
+    # on rasters whose reference is noisy: 35 % / 94 % of the pixels fail the r2 mask (--nodata 3 / 4).  Reported beside, never as `value`.
+    inpaint_variants = None
+    if args.config == 2 and args.nodata == 0 and world == 1 and not args.no_nan_variant and not args.params and not args.no_thresh \
+            and (args.model, args.kernel, args.size, args.bands) == ('gain-offset', 5, 16384, 4):
+        import copy
+        inpaint_variants = {}
+        for nd, steps in ((3, 6), (4, 4)):
+            a4 = copy.copy(args)
+            a4.nodata, a4.steps, a4.warmup, a4.power_probe = nd, steps, 2, False
+            r4 = run_resident(a4, ctx, dist, rank, world)
+            inpaint_variants['--nodata %d' % nd] = {
+                'workload': 'the same rasters with a noisy reference: %s of the pixels fail the r2 mask and are in-painted' % ('35 %' if nd == 3 else '94 %'),
+                'r2_mask_failures_per_step': r4['config'].get('r2_mask_failures_per_step'),
+                'value': round(r4['value'], 1), 'steps': steps, 'ms_per_step': round(r4['elapsed'] / steps * 1e3, 4),
+                'parity_spot_check': r4['parity'],
+            }
+
     # BASELINE.json's other configurations, driver-timed beside the headline: a few steps each of configs[1], [3], [4] with
     # their own parity spot checks -- compact records, never `value` (their full lines: --config N)
     other = None
@@ -1201,6 +1219,8 @@ def main():
         out['host_placement'] = topology.summary(placement)   # of rank 0; every rank binds to its own GPU's node
         if nan_variant is not None:
             out['nodata_nan_variant'] = nan_variant
+        if inpaint_variants is not None:
+            out['inpainting_variants'] = inpaint_variants
         if other is not None:
             out['other_configs'] = other
         if res.get('power') is not None:

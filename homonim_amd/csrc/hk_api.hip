@@ -303,7 +303,17 @@ struct hk_ctx {
     int xcd_remap = 0;
     // the last gain-offset call with a threshold found pixels failing the r2 mask: real imagery usually does, block after
     // block, so the next call materialises the parameters in its first pass instead of re-running it for the in-painting
+    // (device-job calls: the library sees the failure counts only when hk_inpaint_dev* is called, and a caller whose counts are all
+    // zero never calls it -- so there the expectation is a COUNT of launches it still covers, re-armed by every in-painting call that
+    // found failing pixels: EXPECT_DEV_LAUNCHES launches after the last such call the certificate-only build is tried again)
     std::atomic<int> expect_r2_failures{0};
+    static constexpr int EXPECT_DEV_LAUNCHES = 8;
+    bool expecting_failures_dev() {  // one device-job launch of gain-offset with a threshold asks
+        int e = expect_r2_failures.load(std::memory_order_relaxed);
+        while (e > 0)
+            if (expect_r2_failures.compare_exchange_weak(e, e - 1, std::memory_order_relaxed)) return true;
+        return false;
+    }
     // certificate-only build of the gain-offset kernel (hk_fit_kernel.h launch_one): tried first unless it recently had to
     // be re-run; every re-run doubles the number of eligible launches that go straight to the full build (<= 1024)
     std::atomic<int> cert_skip{0}, cert_penalty{1};
@@ -1795,7 +1805,7 @@ int hk_fit_apply_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* job
                                         "needs the parameters of the whole block)");
     // a band the certificate-only build cannot settle comes back with FIT_RETRY_BIT in its counter; hk_inpaint_dev /
     // hk_inpaint_dev_counts run it again with the full build
-    a.cert_only = cert_only_eligible(a, desc) && !ctx->expect_r2_failures.load() && ctx->try_cert_only();
+    a.cert_only = cert_only_eligible(a, desc) && !ctx->expecting_failures_dev() && ctx->try_cert_only();
     if (!a.cert_only && desc->model == HK_MODEL_GAIN_OFFSET && a.has_thresh && job->scratch) {
         // the complete build leaves the in-painting's inputs in the job's scratch (hk_inpaint_dev_counts starts from them)
         a.flag = job_scratch_flag(job);
@@ -1922,7 +1932,7 @@ int hk_inpaint_dev_counts(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job
     }
     if (retried) ctx->cert_only_retried();
     else if (ctx->cert_skip.load(std::memory_order_relaxed) == 0) ctx->cert_only_settled();
-    ctx->expect_r2_failures.store(total > 0 ? 1 : 0);
+    ctx->expect_r2_failures.store(total > 0 ? hk_ctx::EXPECT_DEV_LAUNCHES : 0);
     if (n_fail_out) *n_fail_out = total;
     return HK_OK;
 }
@@ -2211,7 +2221,7 @@ int hk_fit_apply_batch_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_jo
         if ((job->out_rows || job->out_cols) && a.has_thresh)
             return fail(HK_ERR_UNSUPPORTED, "a store window is not supported together with r2_inpaint_thresh (the in-painting "
                                             "needs the parameters of the whole block)");
-        if (j == 0) cert_only = cert_only_eligible(a, desc) && !ctx->expect_r2_failures.load() && ctx->try_cert_only();
+        if (j == 0) cert_only = cert_only_eligible(a, desc) && !ctx->expecting_failures_dev() && ctx->try_cert_only();
         if (!cert_only && desc->model == HK_MODEL_GAIN_OFFSET && a.has_thresh && job->scratch) {
             // the complete build leaves the in-painting's inputs in the job's scratch (hk_inpaint_dev_counts starts from them)
             a.flag = job_scratch_flag(job);
