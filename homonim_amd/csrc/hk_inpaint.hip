@@ -191,7 +191,7 @@ __device__ __forceinline__ void fill_load_d0(const unsigned* __restrict__ trow, 
 template <bool INTERIOR = false>
 __device__ __forceinline__ float fill_one(int x, int y, long long row, const float* offset, long long stride, int width,
                                           int max_dist, const unsigned* __restrict__ tb, const unsigned* __restrict__ tie,
-                                          const double* __restrict__ wtab) {
+                                          const double* __restrict__ wtab, bool no_below = false) {
         const long long i = row + x;
         float out = offset[i];  // a target without any source in reach keeps its value
         const int none2 = (max_dist + 1) * (max_dist + 1);  // qd = max_dist + 1: "nothing found yet" (a perfect square: no tie)
@@ -219,7 +219,13 @@ __device__ __forceinline__ float fill_one(int x, int y, long long row, const flo
             kf[q] = min(kf[q], key);
             kl[q] = min(kl[q], key ^ SRC_MASK);
         };
-        auto worst_qd2 = [&]() { return (int)(max(max(kf[0], kf[1]), max(kf[2], kf[3])) >> SRC_BITS); };
+        // `no_below` (the raster's last row): no source lies strictly below, the bottom quadrants stay empty whatever is searched --
+        // GDAL walks all max_dist columns for them; the top quadrants' bound ends the search with the same result (25 dependent
+        // round trips per pass at the very end of the launch otherwise: 0.2 ms per 16384^2 band)
+        auto worst_qd2 = [&]() {
+            const unsigned top = max(kf[0], kf[2]);
+            return (int)((no_below ? top : max(top, max(kf[1], kf[3]))) >> SRC_BITS);
+        };
         // Steps are taken in groups that end where GDAL re-derives its search bound (after steps 4, 8, 12, ...): the
         // bound is constant inside a group, so all of the group's table look-ups are issued before the checks, which then
         // run in the original order (ascending step; left quadrants before right ones).  The look-ups of the NEXT group are
@@ -468,38 +474,33 @@ __device__ __forceinline__ bool fill_fast(const unsigned* c0, const float* __res
 // TILED form of the search (round 3): a wave owns a tile of 64 columns x ROWS rows.  The per-row forms of rounds 1-2 started a
 // workgroup per 256-pixel row piece, and each lived for three dependent memory round trips (flag -> compaction behind two barriers
 // -> table words -> source values): PMC showed its waves WAITING 76 % of their 4.7 us life with the VALU 58 % busy.  Here a wave
-// takes the targets of its whole tile at once (one word of the column bit planes per lane), compacts them into a wave-private LDS
+// takes the targets of its whole tile at once (one word of a column bit plane per lane), compacts them into a wave-private LDS
 // list (ballot + popcount) and then searches 64 targets per pass -- full waves whatever the failure rate, one wave start per ROWS
-// rows.  Round 5: the workgroup stages its tile of the distance table in LDS and a pass runs the packed search on it (fill_fast);
-// the targets it cannot settle go back to the front of the list and take fill_one() at the end of the tile, 64 at a time.
+// rows.  Round 5: TWO kernels.  inpaint_fill_fast_kernel stages its tile of the distance table in LDS and runs the packed search
+// (fill_fast) on 8-row tiles; the targets it cannot settle are marked in a second bit plane (`sbits`: a tile owns one byte of its
+// columns' 64-row words, so plain stores do), and inpaint_fill_general_kernel takes fill_one() over that plane, 64 at a time from
+// 32-row tiles.  (As one kernel the general search cost the packed one 7 % of the step at 35 % failing pixels by its mere presence
+// -- 64 registers with spills against 34, four times the code -- although it ran for 0.01 % of the targets;
+// profiles/r05b_inpaint_packed.txt.)
 // The filled values are written IN PLACE: a filled pixel never acts as a source (sources are read where flag == 1, targets are
 // written where flag == 0), and the closing pass reads the plane only at the failing pixels.
-#ifndef HK_FILL_TILE_WAVES
-#define HK_FILL_TILE_WAVES 4
-#endif
-template <int ROWS, bool BY_COLUMN>
-__global__ void __launch_bounds__(256, (ROWS <= 8 ? 8 : (ROWS <= 16 ? HK_FILL_TILE_WAVES : 2)))
-inpaint_fill_tile_kernel(float* plane, const unsigned long long* __restrict__ tbits, long long stride, int height, int width,
-                         int max_dist_arg, const unsigned* __restrict__ tb, const unsigned* __restrict__ tie,
-                         const double* __restrict__ wtab, const FastTables* __restrict__ ftab, int fast, int cont_min) {
-    static_assert(ROWS == 8 || ROWS == 16 || ROWS == 32, "tiles divide the 64-row words of the bit planes; list + staged table fit the LDS of a CU at least twice");
+template <bool BY_COLUMN>
+__global__ void __launch_bounds__(256, 8)
+inpaint_fill_fast_kernel(float* plane, const unsigned long long* __restrict__ tbits, unsigned long long* __restrict__ sbits,
+                         long long stride, int height, int width, const unsigned* __restrict__ tb,
+                         const FastTables* __restrict__ ftab, int cont_min) {
+    constexpr int ROWS = 8;  // a tile = one byte of the bit planes' words; list + staged table + finish tables: eight workgroups per CU
     __shared__ unsigned short lst[256 / WAVE][ROWS * WAVE];
     __shared__ unsigned tile[ROWS * FAST_PITCH];
     __shared__ FastTables ftl;
+    __shared__ unsigned slow_rows[256 / WAVE][WAVE / 4];  // per column of the wave's tile one byte: its rows that did not settle
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
     const int xb = blockIdx.x * blockDim.x, x0 = xb + wv * WAVE, x_own = x0 + lane;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    // the search distance as a compile-time constant (the launcher passes FILL_MAX_DIST and nothing else): the first five steps become
-    // straight-line code, the "nothing found yet" and acceptance bounds immediates
-    const int max_dist = FILL_MAX_DIST;
-    (void)max_dist_arg;
-    // wave-uniform: the widest reach of a search stays inside the row -- the group that starts at step max_dist requests the one
-    // after it (steps max_dist + 4 .. + 7) ahead, and a group's wide load covers 4 entries: 7 + 4 columns beyond max_dist
-    const bool interior = x0 - max_dist - 12 >= 0 && x0 + WAVE - 1 + max_dist + 12 < width;
+    (void)lt;
     // Columns outside the raster are staged as "no source in reach": GDAL re-checks the edge column there, which changes nothing (the
     // edge column was the farthest candidate of its side already) -- except for the right quadrants of the LAST column, whose first
-    // and only candidate is the re-checked own column: they find nothing here, do not settle and go through fill_one().
-    const bool fast_ok = fast;
+    // and only candidate is the re-checked own column: they find nothing here, do not settle and go to the general search.
     for (int j = tid; j < (int)(sizeof(FastTables) / 8); j += 256)
         reinterpret_cast<unsigned long long*>(&ftl)[j] = reinterpret_cast<const unsigned long long*>(ftab)[j];
     const int n_tiles = (height + ROWS - 1) / ROWS;
@@ -507,34 +508,30 @@ inpaint_fill_tile_kernel(float* plane, const unsigned long long* __restrict__ tb
         const int y0 = tile_i * ROWS;
         // (never dereferenced before the raster's first pixel: sources and targets lie inside it)
         float* const origin = plane + ((long long)(y0 - FAST_HALO) * stride + (xb - FAST_HALO));
-        if (fast) {  // the tile's piece of the distance table, FAST_HALO columns either side (16-byte pieces: stride % 4 == 0)
-            for (int j = tid; j < ROWS * (FAST_COLS / 4); j += 256) {
-                const int r = j / (FAST_COLS / 4), c4 = j - r * (FAST_COLS / 4), xs = xb - FAST_HALO + 4 * c4;
-                uint4 v = make_uint4(0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu);  // (outside the raster: no source in reach)
-                if (y0 + r < height && xs >= 0 && xs < width) {  // (xs + 3 < stride: rows are padded to quads)
-                    v = *reinterpret_cast<const uint4*>(tb + (long long)(y0 + r) * stride + xs);
-                    if (xs + 3 >= width) {  // the quad straddles the raster's last column: the padding holds no entries
-                        v.y = xs + 1 < width ? v.y : 0x7fff7fffu, v.z = xs + 2 < width ? v.z : 0x7fff7fffu, v.w = 0x7fff7fffu;
-                    }
+        // the tile's piece of the distance table, FAST_HALO columns either side (16-byte pieces: stride % 4 == 0)
+        for (int j = tid; j < ROWS * (FAST_COLS / 4); j += 256) {
+            const int r = j / (FAST_COLS / 4), c4 = j - r * (FAST_COLS / 4), xs = xb - FAST_HALO + 4 * c4;
+            uint4 v = make_uint4(0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu);  // (outside the raster: no source in reach)
+            if (y0 + r < height && xs >= 0 && xs < width) {  // (xs + 3 < stride: rows are padded to quads)
+                v = *reinterpret_cast<const uint4*>(tb + (long long)(y0 + r) * stride + xs);
+                if (xs + 3 >= width) {  // the quad straddles the raster's last column: the padding holds no entries
+                    v.y = xs + 1 < width ? v.y : 0x7fff7fffu, v.z = xs + 2 < width ? v.z : 0x7fff7fffu, v.w = 0x7fff7fffu;
                 }
-                *reinterpret_cast<uint4*>(&tile[r * FAST_PITCH + 4 * c4]) =
-                    make_uint4(fast_stage_word(v.x), fast_stage_word(v.y), fast_stage_word(v.z), fast_stage_word(v.w));
             }
+            *reinterpret_cast<uint4*>(&tile[r * FAST_PITCH + 4 * c4]) =
+                make_uint4(fast_stage_word(v.x), fast_stage_word(v.y), fast_stage_word(v.z), fast_stage_word(v.w));
         }
-        // the tile's targets: bit r of the lane's word = row y0 + r of its column (rows past the raster are clear)
-        unsigned long long tgt_rows = 0ull;
-        if (x_own < width) {
-            tgt_rows = tbits[(long long)(y0 / WORD_ROWS) * stride + x_own] >> (y0 % WORD_ROWS);
-            tgt_rows &= (1ull << ROWS) - 1ull;
-        }
+        if (lane < WAVE / 4) slow_rows[wv][lane] = 0u;
+        // the tile's targets: bit r of the lane's byte = row y0 + r of its column (rows past the raster are clear)
+        unsigned tgt_rows = 0u;
+        if (x_own < width) tgt_rows = (unsigned)(tbits[(long long)(y0 / WORD_ROWS) * stride + x_own] >> (y0 % WORD_ROWS)) & 0xffu;
         int n = 0;  // wave-uniform: targets of the tile
         if constexpr (BY_COLUMN) {
             // COLUMN by column: a pass of 64 targets then covers a compact block of the tile (8 rows x a few columns) instead of a
             // piece of one row -- neighbours need searches of similar length, and a pass lasts as long as its longest search
             // (at 94 % failing pixels the step takes 9 % less; at 35 % the row order is 3 % faster: the launcher picks by the share of
             // failing pixels; both orders in one kernel cost the sparse case 2.5 % whichever way a tile decides)
-            const unsigned m = (unsigned)tgt_rows;
-            const int cnt = __popc(m);
+            const int cnt = __popc(tgt_rows);
             int pre = cnt;  // inclusive prefix over the lanes
 #pragma unroll
             for (int d = 1; d < WAVE; d <<= 1) {
@@ -543,58 +540,96 @@ inpaint_fill_tile_kernel(float* plane, const unsigned long long* __restrict__ tb
             }
             n = __shfl(pre, WAVE - 1);
             int pos = pre - cnt;
-            for (unsigned mm = m; mm; mm &= mm - 1u) lst[wv][pos++] = (unsigned short)(((__ffs((int)mm) - 1) << 6) | lane);
+            for (unsigned mm = tgt_rows; mm; mm &= mm - 1u) lst[wv][pos++] = (unsigned short)(((__ffs((int)mm) - 1) << 6) | lane);
         } else {
-#pragma unroll 4
+#pragma unroll
             for (int r = 0; r < ROWS; ++r) {
-                const bool target = (tgt_rows >> r) & 1ull;
+                const bool target = (tgt_rows >> r) & 1u;
                 const unsigned long long bal = __ballot(target);
                 if (target) lst[wv][n + (int)__popcll(bal & lt)] = (unsigned short)((r << 6) | lane);
                 n += (int)__popcll(bal);
             }
         }
-        __syncthreads();  // the staged table (and the first tile's ftl) for everyone; the list is the wave's own
-        int n_slow = n;
-        if (fast_ok) {
-            n_slow = 0;  // wave-uniform: targets handed on to fill_one(), packed at the front of the list (n_slow <= p: behind the reads)
-            for (int p = 0; p < n; p += WAVE) {
-                const bool act = p + lane < n;
-                const unsigned e = act ? lst[wv][p + lane] : 0u;
-                bool settled = false;
-                if (act) {
-                    const int r = (int)(e >> 6), xl = wv * WAVE + (int)(e & 63u);
-                    float v;
-                    const unsigned rel0 = (unsigned)(r + FAST_HALO) * (unsigned)stride + (unsigned)(xl + FAST_HALO);
-                    settled = fill_fast(&tile[r * FAST_PITCH + FAST_HALO + xl], origin, rel0, (int)stride, ftl, cont_min, v);
-                    if (settled) origin[rel0] = v;
-                }
-                const unsigned long long bal = __ballot(act && !settled);
-                if (act && !settled) lst[wv][n_slow + (int)__popcll(bal & lt)] = (unsigned short)e;
-                n_slow += (int)__popcll(bal);
+        __syncthreads();  // the staged table (and the first tile's ftl) for everyone; the list and slow_rows are the wave's own
+        for (int p = 0; p < n; p += WAVE) {
+            if (p + lane < n) {
+                const unsigned e = lst[wv][p + lane];
+                const int r = (int)(e >> 6), c = (int)(e & 63u), xl = wv * WAVE + c;
+                float v;
+                const unsigned rel0 = (unsigned)(r + FAST_HALO) * (unsigned)stride + (unsigned)(xl + FAST_HALO);
+                if (fill_fast(&tile[r * FAST_PITCH + FAST_HALO + xl], origin, rel0, (int)stride, ftl, cont_min, v)) origin[rel0] = v;
+                else atomicOr(&slow_rows[wv][c >> 2], 1u << (8 * (c & 3) + r));
             }
         }
-        // passes of 64 targets (an explicit request of pass p + 1's first look-ups while pass p searches was measured slower:
-        // 21.7 against 21.2 ms per step, profiles/r03_fill_tile.txt)
-        for (int p = 0; p < n_slow; p += WAVE) {
-            if (p + lane < n_slow) {
+        __syncthreads();  // (orders the wave's LDS atomics before the read below; the next tile re-uses list and staged table)
+        if (x_own < width)  // this tile's byte of the column's word in the plane of unsettled targets (little-endian)
+            reinterpret_cast<unsigned char*>(sbits + (long long)(y0 / WORD_ROWS) * stride + x_own)[(y0 % WORD_ROWS) / 8] =
+                (unsigned char)(slow_rows[wv][lane >> 2] >> (8 * (lane & 3)));
+    }
+}
+
+// The general search (fill_one) of the targets marked in `bits` -- what the packed search left over, or every target when the
+// packed search is off: 64 columns x ROWS rows per wave, its targets compacted into an LDS list, 64 per pass.
+#ifndef HK_FILL_TILE_WAVES
+#define HK_FILL_TILE_WAVES 8
+#endif
+template <int ROWS>
+__global__ void __launch_bounds__(256, (ROWS <= 32 ? HK_FILL_TILE_WAVES : 5))
+inpaint_fill_general_kernel(float* plane, const unsigned long long* __restrict__ bits, long long stride, int height, int width,
+                            const unsigned* __restrict__ tb, const unsigned* __restrict__ tie, const double* __restrict__ wtab) {
+    static_assert(ROWS == 16 || ROWS == 32 || ROWS == 64, "tiles divide the 64-row words of the bit planes");
+    __shared__ unsigned short lst[256 / WAVE][ROWS * WAVE];
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
+    const int x0 = blockIdx.x * blockDim.x + wv * WAVE, x_own = x0 + lane;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    // the search distance as a compile-time constant: the first five steps become straight-line code, the "nothing found yet" and
+    // acceptance bounds immediates
+    const int max_dist = FILL_MAX_DIST;
+    // wave-uniform: the widest reach of a search stays inside the row -- the group that starts at step max_dist requests the one
+    // after it (steps max_dist + 4 .. + 7) ahead, and a group's wide load covers 4 entries: 7 + 4 columns beyond max_dist
+    const bool interior = x0 - max_dist - 12 >= 0 && x0 + WAVE - 1 + max_dist + 12 < width;
+    const int n_tiles = (height + ROWS - 1) / ROWS;
+    // (from the raster's bottom upwards: the last rows, whose targets have no sources below and search longest, start first)
+    for (int tile_k = blockIdx.y; tile_k < n_tiles; tile_k += gridDim.y) {
+        const int y0 = (n_tiles - 1 - tile_k) * ROWS;
+        unsigned long long tgt_rows = 0ull;
+        if (x_own < width) {
+            tgt_rows = bits[(long long)(y0 / WORD_ROWS) * stride + x_own] >> (y0 % WORD_ROWS);
+            const int rows_in = min(ROWS, height - y0);  // (the packed search writes whole bytes only where it has a tile)
+            tgt_rows &= rows_in >= 64 ? ~0ull : (1ull << rows_in) - 1ull;
+        }
+        if (__ballot(tgt_rows != 0ull) == 0ull) continue;  // (wave-uniform; nothing of this wave's tile is left over: the usual case)
+        int n = 0;  // wave-uniform: targets of the tile so far
+#pragma unroll 4
+        for (int r = 0; r < ROWS; ++r) {
+            const bool target = (tgt_rows >> r) & 1ull;
+            const unsigned long long bal = __ballot(target);
+            if (target) lst[wv][n + (int)__popcll(bal & lt)] = (unsigned short)((r << 6) | lane);
+            n += (int)__popcll(bal);
+        }
+        // (the list is the wave's own: no workgroup barrier -- the LDS operations of a wave complete in order; the fence keeps the
+        // compiler from moving the reads of other lanes' entries above the writes)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (int p = 0; p < n; p += WAVE) {
+            if (p + lane < n) {
                 const unsigned e = lst[wv][p + lane];
                 const int x = x0 + (int)(e & 63u), y = y0 + (int)(e >> 6);
                 const long long row = (long long)y * stride;
-                const float v = interior ? fill_one<true>(x, y, row, plane, stride, width, max_dist, tb, tie, wtab)
-                                         : fill_one<false>(x, y, row, plane, stride, width, max_dist, tb, tie, wtab);
+                const bool last_row = y == height - 1;
+                const float v = interior ? fill_one<true>(x, y, row, plane, stride, width, max_dist, tb, tie, wtab, last_row)
+                                         : fill_one<false>(x, y, row, plane, stride, width, max_dist, tb, tie, wtab, last_row);
                 plane[row + x] = v;
             }
         }
-        __syncthreads();  // the next tile re-uses the list and the staged table
     }
 }
 
 // workspace: the distance table + source flags (1 byte per pixel) + the tie bitmap + the weight table
-// + the column bit words of sources and targets (one 64-bit word each per column and 64 rows; a plane of a few rows has more of
-// those than spare table bytes) + the packed search's table
+// + the column bit words of sources, targets and the targets the packed search left over (one 64-bit word each per column and
+// 64 rows; a plane of a few rows has more of those than spare table bytes) + the packed search's tables
 static size_t bit_words(int height, long long stride) { return (size_t)((height + WORD_ROWS - 1) / WORD_ROWS) * (size_t)stride; }
 size_t inpaint_workspace_bytes(int height, long long stride) {
-    return (size_t)height * stride * 5 + 1024 + TIE_N / 8 + 256 + WTAB_N * 8 + 256 + 2 * (bit_words(height, stride) * 8 + 256)
+    return (size_t)height * stride * 5 + 1024 + TIE_N / 8 + 256 + WTAB_N * 8 + 256 + 3 * (bit_words(height, stride) * 8 + 256)
            + sizeof(FastTables) + 256;
 }
 
@@ -622,37 +657,42 @@ hipError_t launch_inpaint_offsets(float* offset, const float* gain, const float*
     auto align256 = [](void* p) { return reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(p) + 255) / 256 * 256); };
     unsigned long long* bits = static_cast<unsigned long long*>(align256(wtab + WTAB_N));
     unsigned long long* tbits = static_cast<unsigned long long*>(align256(bits + bit_words(height, stride)));
-    FastTables* ftab = static_cast<FastTables*>(align256(tbits + bit_words(height, stride)));
+    unsigned long long* sbits = static_cast<unsigned long long*>(align256(tbits + bit_words(height, stride)));
+    FastTables* ftab = static_cast<FastTables*>(align256(sbits + bit_words(height, stride)));
     hipLaunchKernelGGL(fast_table_kernel, dim3((FTAB_N + 7 + 255) / 256), dim3(256), 0, stream, ftab);
     const dim3 gbits((width + 1023) / 1024, (height + WORD_ROWS - 1) / WORD_ROWS);  // four columns per thread
     hipLaunchKernelGGL(inpaint_bits_kernel, gbits, dim3(256), 0, stream, flag, stride, height, width, bits, tbits);
     const dim3 gtable((width + 511) / 512, (height + WORD_ROWS - 1) / WORD_ROWS);  // two columns per thread
     hipLaunchKernelGGL(inpaint_table_kernel, gtable, dim3(256), 0, stream, bits, stride, height, width, max_dist, tb);
-    // The TILED search (64 columns x ROWS rows per wave).  HK_FILL_TILE = 8 / 16 / 32: the tile height (8: eight workgroups per
-    // CU beside their staged tables); HK_FILL_FAST=0: without the packed search (A/B); HK_FILL_CONT: lanes that must still be open
-    // for the packed search to go on to the next group of columns.
+    // The packed search on 8-row tiles, then the general one over what it left.  HK_FILL_FAST=0: the general search for every target
+    // (A/B); HK_FILL_TILE = 16 / 32 / 64: the tile height of the general search; HK_FILL_CONT: lanes that must still be open for the
+    // packed search to go on to the next group of columns; HK_FILL_ORDER: 0 = the targets of a tile row by row, 1 = column by column,
+    // default: by the share of failing pixels.
     static const int tile_env = [] { const char* e = getenv("HK_FILL_TILE"); return e ? atoi(e) : -1; }();
     static const int fast_env = [] { const char* e = getenv("HK_FILL_FAST"); return e ? atoi(e) : 1; }();
-    // HK_FILL_ORDER: 0 = the targets of a tile row by row, 1 = column by column, default: by the share of failing pixels
     static const int order_env = [] { const char* e = getenv("HK_FILL_ORDER"); return e ? atoi(e) : -1; }();
-    const bool by_column = order_env >= 0 ? order_env != 0 : (double)n_targets > 0.6 * (double)height * (double)width;
     static const int cont_env = [] { const char* e = getenv("HK_FILL_CONT"); return e ? atoi(e) : 1; }();
-    const int tile_rows = tile_env > 0 ? tile_env : 8;
-    const int rows = tile_rows >= 32 ? 32 : (tile_rows >= 16 ? 16 : 8);
-    const int n_tiles = (height + rows - 1) / rows;
-    // a workgroup takes several tiles (it copies the finish tables into LDS once)
-    const int per_wg = 32 / rows, wgs_y = (n_tiles + per_wg - 1) / per_wg;
-    const dim3 gt((width + 255) / 256, wgs_y < 65535 ? wgs_y : 65535);
+    const bool by_column = order_env >= 0 ? order_env != 0 : (double)n_targets > 0.6 * (double)height * (double)width;
     // the packed search addresses the plane through 32-bit offsets from its tile and 24-bit multiplies by the row stride
-    const int fast = (fast_env && stride < (1ll << 23)) ? 1 : 0;
-#define HK_FILL_LAUNCH(R, C)                                                                                                          \
-    hipLaunchKernelGGL((inpaint_fill_tile_kernel<R, C>), gt, dim3(256), 0, stream, offset, tbits, stride, height, width, max_dist, tb, \
-                       tie, wtab, ftab, fast, cont_env)
-    if (rows == 32) HK_FILL_LAUNCH(32, false);
-    else if (rows == 16) HK_FILL_LAUNCH(16, false);
-    else if (by_column) HK_FILL_LAUNCH(8, true);
-    else HK_FILL_LAUNCH(8, false);
-#undef HK_FILL_LAUNCH
+    const bool fast = fast_env && stride < (1ll << 23);
+    if (fast) {
+        const int n_tiles8 = (height + 7) / 8, wgs_y = (n_tiles8 + 3) / 4;  // a workgroup takes four tiles (it copies the finish tables into LDS once)
+        const dim3 gf((width + 255) / 256, wgs_y < 65535 ? wgs_y : 65535);
+        if (by_column)
+            hipLaunchKernelGGL(inpaint_fill_fast_kernel<true>, gf, dim3(256), 0, stream, offset, tbits, sbits, stride, height, width, tb, ftab, cont_env);
+        else
+            hipLaunchKernelGGL(inpaint_fill_fast_kernel<false>, gf, dim3(256), 0, stream, offset, tbits, sbits, stride, height, width, tb, ftab, cont_env);
+    }
+    const unsigned long long* todo = fast ? sbits : tbits;
+    const int rows = tile_env >= 64 ? 64 : (tile_env >= 32 || tile_env <= 0 ? 32 : 16);
+    const int n_tiles = (height + rows - 1) / rows;
+    const dim3 gt((width + 255) / 256, n_tiles < 65535 ? n_tiles : 65535);
+    if (rows == 64)
+        hipLaunchKernelGGL(inpaint_fill_general_kernel<64>, gt, dim3(256), 0, stream, offset, todo, stride, height, width, tb, tie, wtab);
+    else if (rows == 32)
+        hipLaunchKernelGGL(inpaint_fill_general_kernel<32>, gt, dim3(256), 0, stream, offset, todo, stride, height, width, tb, tie, wtab);
+    else
+        hipLaunchKernelGGL(inpaint_fill_general_kernel<16>, gt, dim3(256), 0, stream, offset, todo, stride, height, width, tb, tie, wtab);
     return hipGetLastError();
 }
 
