@@ -1174,6 +1174,42 @@ def test_certificate_only_build_and_its_rerun_protocol(oc, monkeypatch):
             fresh2.close()
 
 
+def test_expectation_of_failures_expires_on_the_device_job_path(oc):
+    """ After an in-painting call that found failing pixels the context starts gain-offset launches with the complete kernel build
+    (true counts, in-painting inputs left in scratch).  On the device-job path the library sees the counts only inside
+    hk_inpaint_dev*, which a caller whose counts are all zero never calls -- the expectation must therefore run out by itself (a
+    count of launches), or every clean block after one noisy block pays the complete build forever.  Observable from outside:
+    the certificate-only build answers a raster with failing pixels with HK_COUNT_RETRY, the complete build with the count. """
+    RETRY = 1 << 63
+    clean_s, clean_r = onp.synth_pair(200, 900, 5, 'none')
+    noisy_r = clean_r.copy()
+    noisy_r[90:96, 300:330] = -2.0
+    desc = _hk.make_desc('gain-offset', (5, 5), False, 0.25, None, None)
+    _, _, exp_fail = oc.fit_apply('gain-offset', clean_s, None, noisy_r, None, (5, 5), False, 0.25)
+    c = _hk.Context(0, n_streams=1)
+    job, d = _dev_job_corr_only(c, clean_s, noisy_r, 0.25)
+    try:
+        def fit_only():
+            c.memset(d['fail'], 0, 8)
+            c.fit_apply_dev(desc, job)
+            c.stream_sync(0)
+            raw = np.zeros(1, np.uint64)
+            c.d2h(raw, d['fail'])
+            return int(raw[0])
+
+        assert fit_only() & RETRY                      # fresh context: certificate-only first
+        assert c.inpaint_dev(desc, job) == exp_fail    # re-run + in-painting: failures are expected from now on
+        raws = [fit_only() for _ in range(40)]         # ... launches nobody follows up with an in-painting call
+        assert all(r == exp_fail for r in raws[:8]), 'the expectation covers the next launches'
+        assert any(r & RETRY for r in raws), 'the expectation never ran out: the certificate-only build was not tried again'
+        first_retry = next(i for i, r in enumerate(raws) if r & RETRY)
+        assert all(r == exp_fail for r in raws[:first_retry])
+    finally:
+        for v in d.values():
+            c.dev_free(v)
+        c.close()
+
+
 def _exact_compare_sums(src, src_nodata, ref, ref_nodata):
     """ float64 sums of the reference's float32 per-pixel terms (compare.py:243-255) """
     s, r = np.array(src, np.float32), np.array(ref, np.float32)
