@@ -986,6 +986,25 @@ def test_r2_inpainting_of_noisy_pairs(ctx, oc, sd, frame, lo, hi):
             assert len(bad) == 0, f'{what}, noise {sd}: {len(bad)} pixels differ, first at {bad[:5].tolist()}'
 
 
+@pytest.mark.parametrize('h, w', [(7, 63), (8, 64), (9, 65), (70, 255), (64, 256), (65, 257), (23, 511), (130, 301), (16, 1030)])
+def test_r2_inpainting_at_tile_and_word_boundaries(ctx, oc, h, w):
+    """ Heights around the 8-row tiles of the packed search and the 64-row words of its bit planes, widths around the 64-column
+    waves, the 256-column workgroups and the 4-pixel quads of the staged table (a quad that straddles the last column), with
+    failing pixels everywhere -- the last column and the last row included, whose targets the packed search hands on. """
+    rng = np.random.default_rng(1000 * h + w)
+    src = rng.uniform(0.05, 1, (h, w)).astype(np.float32)
+    ref = (1.3 * src + 0.05 + rng.normal(0, 0.6, (h, w))).astype(np.float32)
+    exp_params, exp_corr, exp_fail = oc.fit_apply('gain-offset', src, None, ref, None, (3, 5), False, 0.25)
+    assert 0.1 * h * w < exp_fail < 0.98 * h * w
+    desc = _hk.make_desc('gain-offset', (3, 5), False, 0.25, None, None)
+    for _ in range(2):
+        params, corr, _, n_fail = ctx.fit_apply(desc, src, ref, 3, want_params=True, want_corr=True)
+        assert n_fail == exp_fail
+        for got, exp, what in ((params[1], exp_params[1], 'in-painted offsets'), (params[0], exp_params[0], 'gains'), (corr, exp_corr, 'corrected')):
+            bad = np.argwhere(~((got == exp) | (np.isnan(got) & np.isnan(exp))))
+            assert len(bad) == 0, f'{what}, {h} x {w}: {len(bad)} pixels differ, first at {bad[:5].tolist()}'
+
+
 def test_r2_inpainting_of_a_block_taller_than_a_grid_dimension(ctx, oc):
     """ 66 000 rows: the in-painting kernels stride over the rows (a launch has at most 65 535 workgroups along y), and the
     column bit words / distance table cover the whole height; failing patches near the top, the middle and the last rows. """
