@@ -10,8 +10,13 @@
 //     through those column tables -- strict `<` on the squared distance, so the first one met wins ties;
 //   * value = sum(v_q / d_q) / sum(1 / d_q) over the quadrants with d_q <= max_dist, in float64, cast to float32;
 //     targets without any source keep their value.  Filled pixels never act as sources.
-// GDAL runs this sequentially line by line; every target is independent given the column tables, so here it is one
-// thread per (column, row chunk) for the scans and one thread per pixel for the search.
+// GDAL runs this sequentially line by line; every target is independent given the column tables.  Here:
+//   inpaint_bits_kernel   the flags of a column as 64-row bit words (sources; targets)
+//   inpaint_table_kernel  the column table: squared row distances up / down per pixel, from the bit words
+//   inpaint_fill_fast_kernel     the PACKED search (16-bit keys on a table tile staged in LDS) for the targets with sources nearby
+//                                -- the usual case; what it cannot settle it marks in a third bit plane
+//   inpaint_fill_general_kernel  GDAL's search as it stands (32-bit keys, up to max_dist columns) for the marked targets
+// The filled values are written in place (sources are read where the flag is 1 only).
 #include "hk_kernels.h"
 
 #include <stdlib.h>
