@@ -71,7 +71,8 @@ _f32p, _f64p, _u64p = _P(C.c_float), _P(C.c_double), _P(C.c_uint64)
 # name -> (restype, argtypes); kept in one table so tests can check every symbol of the header is exported
 ABI_VERSION = 5   # HK_ABI_VERSION of the include/homonim_hk.h these mirrors were written against
 # entry points declared in include/homonim_hk_devtools.h (measurement / test aids), the rest in include/homonim_hk.h
-DEVTOOLS = ('hk_synth_fill_dev', 'hk_stream_probe_dev', 'hk_debug_stage_stamps', 'hk_r2_certificate_constants', 'hk_debug_staging_counters')
+DEVTOOLS = ('hk_synth_fill_dev', 'hk_stream_probe_dev', 'hk_debug_stage_stamps', 'hk_r2_certificate_constants', 'hk_debug_staging_counters',
+            'hk_debug_build_ledger')
 
 SIGNATURES = {
     'hk_abi_version': (C.c_int, []),
@@ -143,6 +144,7 @@ SIGNATURES = {
     'hk_selftest': (C.c_int, [C.c_void_p]),
     'hk_debug_stage_stamps': (C.c_int, [C.c_void_p, _P(C.c_uint64), C.c_int32]),
     'hk_debug_staging_counters': (C.c_int, [_P(C.c_uint64), C.c_int32]),
+    'hk_debug_build_ledger': (C.c_int, [C.c_char_p, C.c_size_t, _P(C.c_size_t), C.c_int32]),
 }  # yapf: disable
 
 COMM_ID_BYTES = 128   # HK_COMM_ID_BYTES = sizeof(ncclUniqueId)
@@ -764,6 +766,22 @@ def staging_counters(reset: bool = False):
     out = (C.c_uint64 * 2)()
     _check(load_library().hk_debug_staging_counters(out, 1 if reset else 0))
     return int(out[0]), int(out[1])
+
+
+def build_ledger(reset: bool = False) -> dict:
+    """ {kernel build: launches since the library was loaded or the last reset} for EVERY kernel build in the library, launched or
+    not (hk_debug_build_ledger; test aid -- tests/conftest.py keeps the ledger of which builds met the oracle).  Records of one name
+    (a kernel with several launch sites) are added up.  No device call: works without a GPU. """
+    lib = load_library()
+    need = C.c_size_t(0)
+    _check(lib.hk_debug_build_ledger(None, 0, C.byref(need), 0))
+    buf = C.create_string_buffer(int(need.value) + 4096)   # (room for nothing: records only appear when the library is loaded)
+    _check(lib.hk_debug_build_ledger(buf, len(buf), C.byref(need), 1 if reset else 0))
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, _, count = line.rpartition('\t')
+        out[name] = out.get(name, 0) + int(count)
+    return out
 
 
 def device_pci_bus_id(device: int) -> str:

@@ -1690,6 +1690,13 @@ int hk_debug_staging_counters(uint64_t out[2], int32_t reset) {
     return HK_OK;
 }
 
+int hk_debug_build_ledger(char* buf, size_t len, size_t* needed, int32_t reset) {
+    const size_t n = hk::ledger_text(buf, buf ? len : 0, reset != 0);
+    if (needed) *needed = n;
+    if (buf && n > len) return fail(HK_ERR_ARG, "ledger needs %zu bytes, the buffer has %zu", n, len);
+    return HK_OK;
+}
+
 int hk_dev_alloc(hk_ctx* ctx, size_t bytes, void** dptr) {
     if (!ctx || !dptr) return fail(HK_ERR_ARG, "NULL argument");
     HK_ENTER(ctx);

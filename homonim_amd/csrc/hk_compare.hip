@@ -110,8 +110,8 @@ hipError_t launch_compare_sums(const CompareArgs& a_in, void* workspace, double*
                ((((uintptr_t)a.src) | ((uintptr_t)a.ref)) % 16 == 0);
     const int blocks = a.height < COMPARE_BLOCKS ? a.height : COMPARE_BLOCKS;
     double* partials = static_cast<double*>(workspace);
-    hipLaunchKernelGGL(compare_partial_kernel, dim3(blocks, a.n_bands), dim3(COMPARE_THREADS), 0, stream, a, partials);
-    hipLaunchKernelGGL(compare_final_kernel, dim3(a.n_bands), dim3(64), 0, stream, partials, blocks, sums_out);
+    HK_LAUNCH(compare_partial_kernel, dim3(blocks, a.n_bands), dim3(COMPARE_THREADS), 0, stream, a, partials);
+    HK_LAUNCH(compare_final_kernel, dim3(a.n_bands), dim3(64), 0, stream, partials, blocks, sums_out);
     return hipGetLastError();
 }
 

@@ -76,7 +76,7 @@ static dim3 cast_grid(int height, int width) {
 hipError_t launch_cast_in(int dtype, const void* in, long long in_stride, float* out, long long out_stride, int height,
                           int width, hipStream_t stream) {
     const dim3 g = cast_grid(height, width), b(256);
-#define HK_CAST_IN(T) hipLaunchKernelGGL(cast_in_kernel<T>, g, b, 0, stream, static_cast<const T*>(in), in_stride, out, out_stride, height, width)
+#define HK_CAST_IN(T) HK_LAUNCH(cast_in_kernel<T>, g, b, 0, stream, static_cast<const T*>(in), in_stride, out, out_stride, height, width)
     switch (dtype) {
         case 1: HK_CAST_IN(unsigned char); break;
         case 2: HK_CAST_IN(unsigned short); break;
@@ -93,7 +93,7 @@ hipError_t launch_cast_in(int dtype, const void* in, long long in_stride, float*
 hipError_t launch_cast_out(int dtype, const float* in, long long in_stride, void* out, long long out_stride, int height,
                            int width, int has_nodata, double nodata, hipStream_t stream) {
     const dim3 g = cast_grid(height, width), b(256);
-#define HK_CAST_OUT(T) hipLaunchKernelGGL(cast_out_kernel<T>, g, b, 0, stream, in, in_stride, static_cast<T*>(out), out_stride, height, width, has_nodata, nodata)
+#define HK_CAST_OUT(T) HK_LAUNCH(cast_out_kernel<T>, g, b, 0, stream, in, in_stride, static_cast<T*>(out), out_stride, height, width, has_nodata, nodata)
     switch (dtype) {
         case 0: HK_CAST_OUT(float); break;
         case 1: HK_CAST_OUT(unsigned char); break;

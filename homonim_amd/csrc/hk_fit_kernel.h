@@ -1549,6 +1549,14 @@ inline size_t fit_lds_bytes_of(int kh, int ring_mode, bool ahead) {
     return 0;
 }
 
+// launch ledger (hk_kernels.h): one record per build of the fused kernel, on the list from the moment the library is loaded
+template <int MODEL, bool R2, int RW, bool DENSE, int RING, bool CERT_ONLY, int WPB, bool BATCH>
+struct FitBuildRecord {
+    static BuildRecord rec;
+};
+template <int MODEL, bool R2, int RW, bool DENSE, int RING, bool CERT_ONLY, int WPB, bool BATCH>
+BuildRecord FitBuildRecord<MODEL, R2, RW, DENSE, RING, CERT_ONLY, WPB, BATCH>::rec{MODEL, R2, RW, DENSE, RING, CERT_ONLY, WPB, BATCH};
+
 template <int MODEL, bool R2, int RW, bool DENSE, int RING, bool CERT_ONLY, int WPB>
 static hipError_t launch_wpb(const FitArgs& a, size_t lds, hipStream_t stream) {
     if (lds * WPB > 64 * 1024) {  // forced LDS ring on a tall kernel (testing): raise the 64 KiB dynamic-LDS default
@@ -1574,11 +1582,13 @@ static hipError_t launch_wpb(const FitArgs& a, size_t lds, hipStream_t stream) {
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 if (e != hipSuccess) return e;
             }
+            FitBuildRecord<MODEL, R2, RW, DENSE, RING, CERT_ONLY, WPB, true>::rec.hit();
             hipLaunchKernelGGL((fit_apply_kernel<MODEL, R2, RW, DENSE, RING, CERT_ONLY, WPB, true>), dim3(grid), dim3(WAVE * WPB),
                                (lds + (size_t)a.lds_pad) * WPB, stream, a);
             return hipGetLastError();
         }
     }
+    FitBuildRecord<MODEL, R2, RW, DENSE, RING, CERT_ONLY, WPB, false>::rec.hit();
     hipLaunchKernelGGL((fit_apply_kernel<MODEL, R2, RW, DENSE, RING, CERT_ONLY, WPB>), dim3(grid), dim3(WAVE * WPB),
                        (lds + (size_t)a.lds_pad) * WPB, stream, a);
     return hipGetLastError();

@@ -652,11 +652,11 @@ hipError_t launch_inpaint_offsets(float* offset, const float* gain, const float*
     const unsigned char* flag = flag_ready ? flag_ready : ws_flag;
     unsigned* tie = reinterpret_cast<unsigned*>(ws_flag + (plane + 255) / 256 * 256);
     double* wtab = reinterpret_cast<double*>(tie + (TIE_N / 32 + 64) / 64 * 64);
-    hipLaunchKernelGGL(tie_kernel, dim3((TIE_N / 32 + 255) / 256), dim3(256), 0, stream, tie, wtab);
+    HK_LAUNCH(tie_kernel, dim3((TIE_N / 32 + 255) / 256), dim3(256), 0, stream, tie, wtab);
     const int max_dist = FILL_MAX_DIST;
     static_assert(100 + 1 < (int)NONE_B, "the table's distance bytes");
     if (!flag_ready)  // else: the flag plane was written by the fit kernel (FitArgs::flag)
-        hipLaunchKernelGGL(inpaint_flag_kernel, dim3((width + 255) / 256, height < 1024 ? height : 1024), dim3(256), 0, stream,
+        HK_LAUNCH(inpaint_flag_kernel, dim3((width + 255) / 256, height < 1024 ? height : 1024), dim3(256), 0, stream,
                            gain, r2, thresh, stride, height, width, ws_flag);
     // column bit words behind the weight table (256-byte aligned): sources, then targets; the packed search's table behind them
     auto align256 = [](void* p) { return reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(p) + 255) / 256 * 256); };
@@ -664,11 +664,11 @@ hipError_t launch_inpaint_offsets(float* offset, const float* gain, const float*
     unsigned long long* tbits = static_cast<unsigned long long*>(align256(bits + bit_words(height, stride)));
     unsigned long long* sbits = static_cast<unsigned long long*>(align256(tbits + bit_words(height, stride)));
     FastTables* ftab = static_cast<FastTables*>(align256(sbits + bit_words(height, stride)));
-    hipLaunchKernelGGL(fast_table_kernel, dim3((FTAB_N + 7 + 255) / 256), dim3(256), 0, stream, ftab);
+    HK_LAUNCH(fast_table_kernel, dim3((FTAB_N + 7 + 255) / 256), dim3(256), 0, stream, ftab);
     const dim3 gbits((width + 1023) / 1024, (height + WORD_ROWS - 1) / WORD_ROWS);  // four columns per thread
-    hipLaunchKernelGGL(inpaint_bits_kernel, gbits, dim3(256), 0, stream, flag, stride, height, width, bits, tbits);
+    HK_LAUNCH(inpaint_bits_kernel, gbits, dim3(256), 0, stream, flag, stride, height, width, bits, tbits);
     const dim3 gtable((width + 511) / 512, (height + WORD_ROWS - 1) / WORD_ROWS);  // two columns per thread
-    hipLaunchKernelGGL(inpaint_table_kernel, gtable, dim3(256), 0, stream, bits, stride, height, width, max_dist, tb);
+    HK_LAUNCH(inpaint_table_kernel, gtable, dim3(256), 0, stream, bits, stride, height, width, max_dist, tb);
     // The packed search on 8-row tiles, then the general one over what it left.  HK_FILL_FAST=0: the general search for every target
     // (A/B); HK_FILL_TILE = 16 / 32 / 64: the tile height of the general search; HK_FILL_CONT: lanes that must still be open for the
     // packed search to go on to the next group of columns; HK_FILL_ORDER: 0 = the targets of a tile row by row, 1 = column by column,
@@ -684,20 +684,20 @@ hipError_t launch_inpaint_offsets(float* offset, const float* gain, const float*
         const int n_tiles8 = (height + 7) / 8, wgs_y = (n_tiles8 + 3) / 4;  // a workgroup takes four tiles (it copies the finish tables into LDS once)
         const dim3 gf((width + 255) / 256, wgs_y < 65535 ? wgs_y : 65535);
         if (by_column)
-            hipLaunchKernelGGL(inpaint_fill_fast_kernel<true>, gf, dim3(256), 0, stream, offset, tbits, sbits, stride, height, width, tb, ftab, cont_env);
+            HK_LAUNCH(inpaint_fill_fast_kernel<true>, gf, dim3(256), 0, stream, offset, tbits, sbits, stride, height, width, tb, ftab, cont_env);
         else
-            hipLaunchKernelGGL(inpaint_fill_fast_kernel<false>, gf, dim3(256), 0, stream, offset, tbits, sbits, stride, height, width, tb, ftab, cont_env);
+            HK_LAUNCH(inpaint_fill_fast_kernel<false>, gf, dim3(256), 0, stream, offset, tbits, sbits, stride, height, width, tb, ftab, cont_env);
     }
     const unsigned long long* todo = fast ? sbits : tbits;
     const int rows = tile_env >= 64 ? 64 : (tile_env >= 32 || tile_env <= 0 ? 32 : 16);
     const int n_tiles = (height + rows - 1) / rows;
     const dim3 gt((width + 255) / 256, n_tiles < 65535 ? n_tiles : 65535);
     if (rows == 64)
-        hipLaunchKernelGGL(inpaint_fill_general_kernel<64>, gt, dim3(256), 0, stream, offset, todo, stride, height, width, tb, tie, wtab);
+        HK_LAUNCH(inpaint_fill_general_kernel<64>, gt, dim3(256), 0, stream, offset, todo, stride, height, width, tb, tie, wtab);
     else if (rows == 32)
-        hipLaunchKernelGGL(inpaint_fill_general_kernel<32>, gt, dim3(256), 0, stream, offset, todo, stride, height, width, tb, tie, wtab);
+        HK_LAUNCH(inpaint_fill_general_kernel<32>, gt, dim3(256), 0, stream, offset, todo, stride, height, width, tb, tie, wtab);
     else
-        hipLaunchKernelGGL(inpaint_fill_general_kernel<16>, gt, dim3(256), 0, stream, offset, todo, stride, height, width, tb, tie, wtab);
+        HK_LAUNCH(inpaint_fill_general_kernel<16>, gt, dim3(256), 0, stream, offset, todo, stride, height, width, tb, tie, wtab);
     return hipGetLastError();
 }
 

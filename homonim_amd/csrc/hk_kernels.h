@@ -8,6 +8,39 @@ namespace hk {
 constexpr int PX = 4;      // pixels per lane per row (one 16-byte load)
 constexpr int WAVE = 64;   // gfx950 wavefront
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Launch ledger (test aid; include/homonim_hk_devtools.h hk_debug_build_ledger).  Every kernel BUILD of the library -- each
+// instantiation of the fused kernel's template, each kernel of the other translation units -- owns one BuildRecord that puts
+// itself on a process-wide list when the library is loaded (so a build nothing ever launched is on the list too) and counts
+// its launches.  The test-suite reads the list around every test and keeps a ledger of which builds were launched by a test
+// that compared its results with the oracle (tests/conftest.py, tests/test_zz_build_ledger.py).  One relaxed atomic add per launch.
+struct BuildRecord {
+    char name[88];
+    unsigned long long launches;  // (atomic adds; read by ledger_text)
+    BuildRecord* next;
+    explicit BuildRecord(const char* kernel_name);
+    // the fused kernel: "fit_apply_kernel<MODEL,R2,RW,DENSE,RING,CERT_ONLY,WPB,BATCH>"
+    BuildRecord(int model, bool r2, int rw, bool dense, int ring, bool cert_only, int wpb, bool batch);
+    void hit() { __atomic_fetch_add(&launches, 1ull, __ATOMIC_RELAXED); }
+};
+// one record per launch SITE of a kernel outside the fused template: the site's local tag type names the kernel
+template <typename Tag>
+struct SiteRecord {
+    static BuildRecord rec;
+};
+template <typename Tag>
+BuildRecord SiteRecord<Tag>::rec{Tag::name()};
+#define HK_LAUNCH(kern, ...)                                               \
+    do {                                                                   \
+        struct Tag_ {                                                      \
+            static const char* name() { return #kern; }                    \
+        };                                                                 \
+        ::hk::SiteRecord<Tag_>::rec.hit();                                 \
+        hipLaunchKernelGGL(kern, __VA_ARGS__);                             \
+    } while (0)
+// "name\tlaunches\n" per record, '\0'-terminated; returns the bytes needed (incl. the terminator) whatever `len` is
+size_t ledger_text(char* buf, size_t len, bool reset);
+
 // Device-side argument block of the fused fit(+apply) kernel.  One wave = one (band, row-segment, column-strip) unit.
 // Set in a band's r2-failure counter by the certificate-only build: the count is void, run the band again with
 // cert_only = 0.  (Counts themselves are < 2^63.)

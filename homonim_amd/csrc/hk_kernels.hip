@@ -3,7 +3,52 @@
 // workload, the stream probe and the self-test.
 #include "hk_fit_kernel.h"
 
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+
 namespace hk {
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Launch ledger (hk_kernels.h BuildRecord): the list's head and its lock are function-local statics, because the records of the
+// other translation units register from their own static initialisers, in no particular order relative to this file's.
+static BuildRecord*& ledger_head() {
+    static BuildRecord* head = nullptr;
+    return head;
+}
+static std::mutex& ledger_mu() {
+    static std::mutex mu;
+    return mu;
+}
+static void ledger_add(BuildRecord* r) {
+    std::lock_guard<std::mutex> lk(ledger_mu());
+    r->launches = 0;
+    r->next = ledger_head();
+    ledger_head() = r;
+}
+BuildRecord::BuildRecord(const char* kernel_name) {
+    snprintf(name, sizeof(name), "%s", kernel_name);
+    ledger_add(this);
+}
+BuildRecord::BuildRecord(int model, bool r2, int rw, bool dense, int ring, bool cert_only, int wpb, bool batch) {
+    snprintf(name, sizeof(name), "fit_apply_kernel<%d,%d,%d,%d,%d,%d,%d,%d>", model, (int)r2, rw, (int)dense, ring, (int)cert_only, wpb,
+             (int)batch);
+    ledger_add(this);
+}
+size_t ledger_text(char* buf, size_t len, bool reset) {
+    std::lock_guard<std::mutex> lk(ledger_mu());
+    size_t need = 1;
+    for (BuildRecord* r = ledger_head(); r; r = r->next) {
+        char line[128];
+        const unsigned long long n = reset ? __atomic_exchange_n(&r->launches, 0ull, __ATOMIC_RELAXED)
+                                           : __atomic_load_n(&r->launches, __ATOMIC_RELAXED);
+        const int m = snprintf(line, sizeof(line), "%s\t%llu\n", r->name, n);
+        if (buf && need + (size_t)m <= len) memcpy(buf + need - 1, line, (size_t)m);
+        need += (size_t)m;
+    }
+    if (buf && len) buf[(need <= len ? need : len) - 1] = '\0';
+    return need;
+}
 
 
 #ifdef HK_FIT_ONE_TU  // A/B tooling (tools/mkvariant*.sh): every instantiation in this translation unit
@@ -76,7 +121,7 @@ hipError_t launch_apply(const float* src, const float* gain, const float* offset
     const int threads = 256;
     const int gx = (width + threads * PX - 1) / (threads * PX);
     const int gy = height < 4096 ? height : 4096;
-    hipLaunchKernelGGL(apply_kernel, dim3(gx, gy), dim3(threads), 0, stream, src, gain, offset, out, height, width,
+    HK_LAUNCH(apply_kernel, dim3(gx, gy), dim3(threads), 0, stream, src, gain, offset, out, height, width,
                        stride);
     return hipGetLastError();
 }
@@ -133,7 +178,7 @@ hipError_t launch_synth_fill(float* src, float* ref, int n_bands, int height, in
                              long long band_stride, unsigned long long seed, int nodata_variant, hipStream_t stream) {
     const int threads = 256;
     const int gy = height < 2048 ? height : 2048;
-    hipLaunchKernelGGL(synth_kernel, dim3((width + threads - 1) / threads, gy, n_bands), dim3(threads), 0, stream, src,
+    HK_LAUNCH(synth_kernel, dim3((width + threads - 1) / threads, gy, n_bands), dim3(threads), 0, stream, src,
                        ref, n_bands, height, width, stride, band_stride, seed, nodata_variant);
     return hipGetLastError();
 }
@@ -164,7 +209,7 @@ __global__ void __launch_bounds__(256) stream_probe_kernel(const hk_v4* __restri
 hipError_t launch_stream_probe(const void* a, const void* b, void* out, size_t n_bytes, hipStream_t stream) {
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    hipLaunchKernelGGL(stream_probe_kernel, dim3(cus * 4), dim3(256), 0, stream, reinterpret_cast<const hk_v4*>(a),
+    HK_LAUNCH(stream_probe_kernel, dim3(cus * 4), dim3(256), 0, stream, reinterpret_cast<const hk_v4*>(a),
                        reinterpret_cast<const hk_v4*>(b), reinterpret_cast<hk_v4*>(out), n_bytes / 16);
     return hipGetLastError();
 }
@@ -275,7 +320,7 @@ __global__ void selftest_kernel(int* result) {
 }
 
 hipError_t launch_selftest(int* result_dev, hipStream_t stream) {
-    hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(WAVE), 0, stream, result_dev);
+    HK_LAUNCH(selftest_kernel, dim3(1), dim3(WAVE), 0, stream, result_dev);
     return hipGetLastError();
 }
 

@@ -65,9 +65,9 @@ hipError_t launch_partial_mask(const float* in, int nd_mode, float nodata, const
                                unsigned char* mask_out, hipStream_t stream) {
     const dim3 block(256), grid((width + 255) / 256, height < 1024 ? height : 1024);
     const int rhe = kh / 2 + 1, rwe = kw / 2 + 1;  // structuring element (kh + 2) x (kw + 2)
-    hipLaunchKernelGGL(mask_rows_kernel, grid, block, 0, stream, in, nd_mode, nodata, params, params + band_stride, stride,
+    HK_LAUNCH(mask_rows_kernel, grid, block, 0, stream, in, nd_mode, nodata, params, params + band_stride, stride,
                        height, width, rwe, rowcnt_ws);
-    hipLaunchKernelGGL(mask_cols_kernel, grid, block, 0, stream, rowcnt_ws, stride, height, width, rhe,
+    HK_LAUNCH(mask_cols_kernel, grid, block, 0, stream, rowcnt_ws, stride, height, width, rhe,
                        (kh + 2) * (kw + 2), params, band_stride, n_bands, src, params_out, corr_out, mask_out);
     return hipGetLastError();
 }

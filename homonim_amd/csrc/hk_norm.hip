@@ -758,44 +758,44 @@ hipError_t launch_block_norm_split(const NormArgs& a, void* workspace, double* x
     case 0: {
         hipError_t e = hipMemsetAsync(ws, 0, sizeof(NormWS) * (size_t)a.n_bands, stream);
         if (e != hipSuccess) return e;
-        if (rows) hipLaunchKernelGGL(norm_sample_kernel, bands, dim3(SAMPLE_THREADS), 0, stream, a, ws);
-        hipLaunchKernelGGL(split_put_shift_kernel, bands, block, 0, stream, ws, xchg);
+        if (rows) HK_LAUNCH(norm_sample_kernel, bands, dim3(SAMPLE_THREADS), 0, stream, a, ws);
+        HK_LAUNCH(split_put_shift_kernel, bands, block, 0, stream, ws, xchg);
         break;
     }
     case 1: {
-        hipLaunchKernelGGL(split_get_shift_kernel, bands, dim3(WAVE), 0, stream, ws, xchg, inv_world);
+        HK_LAUNCH(split_get_shift_kernel, bands, dim3(WAVE), 0, stream, ws, xchg, inv_world);
         if (rows) {
             const dim3 gstream(pass_waves(a.height, a.width), a.n_bands);
             float* mid = reinterpret_cast<float*>(static_cast<char*>(workspace) + align256(sizeof(NormWS) * (size_t)a.n_bands));
             const size_t cap_al = align256(mid_capacity((long long)a.height * a.width) * sizeof(float)) / sizeof(float);
             if (a.src_nd_mode == 0 && a.ref_nd_mode == 0)
-                hipLaunchKernelGGL(norm_stream_kernel<true>, gstream, dim3(WAVE), norm_stream_lds_pad(), stream, a, ws, mid, cap_al);
+                HK_LAUNCH(norm_stream_kernel<true>, gstream, dim3(WAVE), norm_stream_lds_pad(), stream, a, ws, mid, cap_al);
             else
-                hipLaunchKernelGGL(norm_stream_kernel<false>, gstream, dim3(WAVE), norm_stream_lds_pad(), stream, a, ws, mid, cap_al);
+                HK_LAUNCH(norm_stream_kernel<false>, gstream, dim3(WAVE), norm_stream_lds_pad(), stream, a, ws, mid, cap_al);
         }
-        hipLaunchKernelGGL(split_put_moments_kernel, bands, dim3(WAVE), 0, stream, ws, xchg);
+        HK_LAUNCH(split_put_moments_kernel, bands, dim3(WAVE), 0, stream, ws, xchg);
         break;
     }
     case 2:
-        hipLaunchKernelGGL(split_get_moments_kernel, bands, dim3(WAVE), 0, stream, ws, xchg, norm_out);
-        if (rows) hipLaunchKernelGGL(norm_full_hist_kernel<0>, gfull, block, 0, stream, a, ws);
-        hipLaunchKernelGGL(split_hist_kernel<0>, bands, block, 0, stream, ws, xchg, 1);
+        HK_LAUNCH(split_get_moments_kernel, bands, dim3(WAVE), 0, stream, ws, xchg, norm_out);
+        if (rows) HK_LAUNCH(norm_full_hist_kernel<0>, gfull, block, 0, stream, a, ws);
+        HK_LAUNCH(split_hist_kernel<0>, bands, block, 0, stream, ws, xchg, 1);
         break;
     case 3:
-        hipLaunchKernelGGL(split_hist_kernel<0>, bands, block, 0, stream, ws, xchg, 0);
-        hipLaunchKernelGGL(norm_select_kernel<0>, bands, block, 0, stream, ws, norm_out);
-        if (rows) hipLaunchKernelGGL(norm_full_hist_kernel<1>, gfull, block, 0, stream, a, ws);
-        hipLaunchKernelGGL(split_hist_kernel<1>, bands, block, 0, stream, ws, xchg, 1);
+        HK_LAUNCH(split_hist_kernel<0>, bands, block, 0, stream, ws, xchg, 0);
+        HK_LAUNCH(norm_select_kernel<0>, bands, block, 0, stream, ws, norm_out);
+        if (rows) HK_LAUNCH(norm_full_hist_kernel<1>, gfull, block, 0, stream, a, ws);
+        HK_LAUNCH(split_hist_kernel<1>, bands, block, 0, stream, ws, xchg, 1);
         break;
     case 4:
-        hipLaunchKernelGGL(split_hist_kernel<1>, bands, block, 0, stream, ws, xchg, 0);
-        hipLaunchKernelGGL(norm_select_kernel<1>, bands, block, 0, stream, ws, norm_out);
-        if (rows) hipLaunchKernelGGL(norm_full_hist_kernel<2>, gfull, block, 0, stream, a, ws);
-        hipLaunchKernelGGL(split_hist_kernel<2>, bands, block, 0, stream, ws, xchg, 1);
+        HK_LAUNCH(split_hist_kernel<1>, bands, block, 0, stream, ws, xchg, 0);
+        HK_LAUNCH(norm_select_kernel<1>, bands, block, 0, stream, ws, norm_out);
+        if (rows) HK_LAUNCH(norm_full_hist_kernel<2>, gfull, block, 0, stream, a, ws);
+        HK_LAUNCH(split_hist_kernel<2>, bands, block, 0, stream, ws, xchg, 1);
         break;
     case 5:
-        hipLaunchKernelGGL(split_hist_kernel<2>, bands, block, 0, stream, ws, xchg, 0);
-        hipLaunchKernelGGL(norm_select_kernel<2>, bands, block, 0, stream, ws, norm_out);
+        HK_LAUNCH(split_hist_kernel<2>, bands, block, 0, stream, ws, xchg, 0);
+        HK_LAUNCH(norm_select_kernel<2>, bands, block, 0, stream, ws, norm_out);
         break;
     default:
         return hipErrorInvalidValue;
@@ -813,24 +813,24 @@ hipError_t launch_block_norm(const NormArgs& a, void* workspace, double* norm_ou
     hipError_t e = hipMemsetAsync(ws, 0, sizeof(NormWS) * (size_t)a.n_bands, stream);
     if (e != hipSuccess) return e;
     const dim3 bands(a.n_bands), block(NORM_THREADS);
-    hipLaunchKernelGGL(norm_sample_kernel, bands, dim3(SAMPLE_THREADS), 0, stream, a, ws);
+    HK_LAUNCH(norm_sample_kernel, bands, dim3(SAMPLE_THREADS), 0, stream, a, ws);
     const dim3 gstream(a.grid_waves > 0 ? a.grid_waves : pass_waves(a.height, a.width), a.n_bands);
     if (a.src_nd_mode == 0 && a.ref_nd_mode == 0)
-        hipLaunchKernelGGL(norm_stream_kernel<true>, gstream, dim3(WAVE), norm_stream_lds_pad(), stream, a, ws, mid, cap_al);
+        HK_LAUNCH(norm_stream_kernel<true>, gstream, dim3(WAVE), norm_stream_lds_pad(), stream, a, ws, mid, cap_al);
     else
-        hipLaunchKernelGGL(norm_stream_kernel<false>, gstream, dim3(WAVE), norm_stream_lds_pad(), stream, a, ws, mid, cap_al);
-    hipLaunchKernelGGL(norm_stats_kernel, bands, dim3(STATS_THREADS), 0, stream, ws, norm_out, cap_al);
+        HK_LAUNCH(norm_stream_kernel<false>, gstream, dim3(WAVE), norm_stream_lds_pad(), stream, a, ws, mid, cap_al);
+    HK_LAUNCH(norm_stats_kernel, bands, dim3(STATS_THREADS), 0, stream, ws, norm_out, cap_al);
     // workgroups per compacted buffer: at least 8 float4 per thread of a full buffer (a 4096^2 block's buffers hold ~0.2 M values:
     // 256 workgroups would spend their time zeroing and merging 16 KB histograms -- 0.40 -> 0.15 ms for configs[3]'s 128 blocks)
     const size_t mid_wgs = cap_al / 4 / (NORM_THREADS * 8);
     // (at least 32 workgroups per buffer: a band that fell back has its full rasters histogrammed by the same grid)
     const dim3 gmid((unsigned)(mid_wgs < 32 ? 32 : (mid_wgs > MID_BLOCKS ? MID_BLOCKS : mid_wgs)), a.n_bands * 2);
-    hipLaunchKernelGGL(norm_mid_hist_kernel<0>, gmid, block, 0, stream, a, ws, mid, cap_al);
-    hipLaunchKernelGGL(norm_select_kernel<0>, bands, block, 0, stream, ws, norm_out);
-    hipLaunchKernelGGL(norm_mid_hist_kernel<1>, gmid, block, 0, stream, a, ws, mid, cap_al);
-    hipLaunchKernelGGL(norm_select_kernel<1>, bands, block, 0, stream, ws, norm_out);
-    hipLaunchKernelGGL(norm_mid_hist_kernel<2>, gmid, block, 0, stream, a, ws, mid, cap_al);
-    hipLaunchKernelGGL(norm_select_kernel<2>, bands, block, 0, stream, ws, norm_out);
+    HK_LAUNCH(norm_mid_hist_kernel<0>, gmid, block, 0, stream, a, ws, mid, cap_al);
+    HK_LAUNCH(norm_select_kernel<0>, bands, block, 0, stream, ws, norm_out);
+    HK_LAUNCH(norm_mid_hist_kernel<1>, gmid, block, 0, stream, a, ws, mid, cap_al);
+    HK_LAUNCH(norm_select_kernel<1>, bands, block, 0, stream, ws, norm_out);
+    HK_LAUNCH(norm_mid_hist_kernel<2>, gmid, block, 0, stream, a, ws, mid, cap_al);
+    HK_LAUNCH(norm_select_kernel<2>, bands, block, 0, stream, ws, norm_out);
     return hipGetLastError();
 }
 

@@ -445,18 +445,18 @@ hipError_t launch_upsample_apply(int mode, const float* src, long long src_strid
     a.out_stride = out_stride, a.height = height, a.width = width, a.kx = kx, a.ox = ox, a.rows = tab;
     const dim3 tgrid((height + 255) / 256), grid((width + 255) / 256, (height + UP_ROWS - 1) / UP_ROWS), block(256);
     if (mode == 1) {
-        hipLaunchKernelGGL(row_table_kernel<1>, tgrid, block, 0, stream, tab, height, ph, ky, oy);
-        hipLaunchKernelGGL(upsample_apply_kernel<1>, grid, block, 0, stream, a);
+        HK_LAUNCH(row_table_kernel<1>, tgrid, block, 0, stream, tab, height, ph, ky, oy);
+        HK_LAUNCH(upsample_apply_kernel<1>, grid, block, 0, stream, a);
     } else {
-        hipLaunchKernelGGL(row_table_kernel<3>, tgrid, block, 0, stream, tab, height, ph, ky, oy);
-        hipLaunchKernelGGL(upsample_apply_kernel<3>, grid, block, 0, stream, a);
+        HK_LAUNCH(row_table_kernel<3>, tgrid, block, 0, stream, tab, height, ph, ky, oy);
+        HK_LAUNCH(upsample_apply_kernel<3>, grid, block, 0, stream, a);
     }
     return hipGetLastError();
 }
 
 hipError_t launch_valid_plane(const float* in, long long in_stride, int nd_mode, float nodata, float* out,
                               long long out_stride, int height, int width, hipStream_t stream) {
-    hipLaunchKernelGGL(valid_plane_kernel, dim3((width + 255) / 256, height < 1024 ? height : 1024), dim3(256), 0, stream,
+    HK_LAUNCH(valid_plane_kernel, dim3((width + 255) / 256, height < 1024 ? height : 1024), dim3(256), 0, stream,
                        in, in_stride, nd_mode, nodata, out, out_stride, height, width);
     return hipGetLastError();
 }
@@ -464,7 +464,7 @@ hipError_t launch_valid_plane(const float* in, long long in_stride, int nd_mode,
 hipError_t launch_apply_space(const float* src, long long src_stride, int nd_mode, float nodata, const float* gain,
                               const float* offset, long long par_stride, const float* keep, float* out,
                               long long out_stride, int height, int width, hipStream_t stream) {
-    hipLaunchKernelGGL(apply_space_kernel, dim3((width + 255) / 256, height < 1024 ? height : 1024), dim3(256), 0, stream,
+    HK_LAUNCH(apply_space_kernel, dim3((width + 255) / 256, height < 1024 ? height : 1024), dim3(256), 0, stream,
                        src, src_stride, nd_mode, nodata, gain, offset, par_stride, keep, out, out_stride, height, width);
     return hipGetLastError();
 }
@@ -480,26 +480,26 @@ hipError_t launch_resample(int mode, const float* src, long long src_stride, lon
     const dim3 grid((dw + 255) / 256, dh, n_bands), block(256);
     const bool stretched = kx > 1.0 + 1e-9 || ky > 1.0 + 1e-9;  // an axis is down-sampled: the kernel support scales with it
     switch (mode) {
-        case 0: hipLaunchKernelGGL(resample_kernel<0>, grid, block, 0, stream, a); break;
+        case 0: HK_LAUNCH(resample_kernel<0>, grid, block, 0, stream, a); break;
         case 1:
-            if (stretched) hipLaunchKernelGGL(resample_conv_kernel<1>, grid, block, 0, stream, a);
-            else hipLaunchKernelGGL(resample_kernel<1>, grid, block, 0, stream, a);
+            if (stretched) HK_LAUNCH(resample_conv_kernel<1>, grid, block, 0, stream, a);
+            else HK_LAUNCH(resample_kernel<1>, grid, block, 0, stream, a);
             break;
-        case 2: hipLaunchKernelGGL(resample_conv_kernel<2>, grid, block, 0, stream, a); break;
+        case 2: HK_LAUNCH(resample_conv_kernel<2>, grid, block, 0, stream, a); break;
         case 3:
-            if (stretched) hipLaunchKernelGGL(resample_conv_kernel<3>, grid, block, 0, stream, a);
-            else hipLaunchKernelGGL(resample_kernel<3>, grid, block, 0, stream, a);
+            if (stretched) HK_LAUNCH(resample_conv_kernel<3>, grid, block, 0, stream, a);
+            else HK_LAUNCH(resample_kernel<3>, grid, block, 0, stream, a);
             break;
-        case 4: hipLaunchKernelGGL(resample_conv_kernel<4>, grid, block, 0, stream, a); break;
-        case 5: hipLaunchKernelGGL(resample_kernel<5>, grid, block, 0, stream, a); break;
-        case 6: hipLaunchKernelGGL(resample_kernel<6>, grid, block, 0, stream, a); break;
-        case 10: hipLaunchKernelGGL(resample_kernel<10>, grid, block, 0, stream, a); break;
-        case 11: hipLaunchKernelGGL(resample_kernel<11>, grid, block, 0, stream, a); break;
-        case 12: hipLaunchKernelGGL(resample_kernel<12>, grid, block, 0, stream, a); break;
-        case 8: hipLaunchKernelGGL(resample_kernel<8>, grid, block, 0, stream, a); break;
-        case 9: hipLaunchKernelGGL(resample_kernel<9>, grid, block, 0, stream, a); break;
-        case 13: hipLaunchKernelGGL(resample_kernel<13>, grid, block, 0, stream, a); break;
-        case 14: hipLaunchKernelGGL(resample_kernel<14>, grid, block, 0, stream, a); break;
+        case 4: HK_LAUNCH(resample_conv_kernel<4>, grid, block, 0, stream, a); break;
+        case 5: HK_LAUNCH(resample_kernel<5>, grid, block, 0, stream, a); break;
+        case 6: HK_LAUNCH(resample_kernel<6>, grid, block, 0, stream, a); break;
+        case 10: HK_LAUNCH(resample_kernel<10>, grid, block, 0, stream, a); break;
+        case 11: HK_LAUNCH(resample_kernel<11>, grid, block, 0, stream, a); break;
+        case 12: HK_LAUNCH(resample_kernel<12>, grid, block, 0, stream, a); break;
+        case 8: HK_LAUNCH(resample_kernel<8>, grid, block, 0, stream, a); break;
+        case 9: HK_LAUNCH(resample_kernel<9>, grid, block, 0, stream, a); break;
+        case 13: HK_LAUNCH(resample_kernel<13>, grid, block, 0, stream, a); break;
+        case 14: HK_LAUNCH(resample_kernel<14>, grid, block, 0, stream, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

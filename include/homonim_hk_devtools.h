@@ -58,6 +58,15 @@ int hk_debug_stage_stamps(hk_ctx* ctx, uint64_t out[16], int32_t reset);
  * the pinned staging ring. */
 int hk_debug_staging_counters(uint64_t out[2], int32_t reset);
 
+/* Test aid: the launch ledger.  Every kernel BUILD of the library -- each instantiation of the fused kernel's template
+ * ("fit_apply_kernel<MODEL,R2,RW,DENSE,RING,CERT_ONLY,WPB,BATCH>"), each kernel of the statistics / in-painting / re-sampling /
+ * mask / conversion / comparison units (one record per launch site, named after the kernel) -- is on a process-wide list from the
+ * moment the library is loaded and counts its launches.  Writes "name<TAB>launches<NEWLINE>" per record into buf (NUL-terminated);
+ * *needed = the bytes that takes (call with buf == NULL to size the buffer); reset != 0 clears the counts behind the reading.  No
+ * device call.  tests/conftest.py reads it around every GPU test; tests/test_zz_build_ledger.py fails on a build that no test
+ * comparing with the oracle ever launched. */
+int hk_debug_build_ledger(char* buf, size_t len, size_t* needed, int32_t reset);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,6 +14,8 @@ GOLDEN_DIR = os.path.join(REPO, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: test needs a real MI355X (run with -m gpu on the GPU box)')
+    config.addinivalue_line('markers', 'oracle: the test compares the results of the kernels it launches with the oracle, a golden '
+                                       'vector or a reference-held number (tests/test_zz_build_ledger.py counts only these)')
     # a fatal signal names its sender, thread and native frames (harness/abort_trace.py); in front of faulthandler
     try:
         from harness import abort_trace
@@ -66,6 +68,47 @@ def pytest_report_header(config):
         last = (_probe.get('output') or '').splitlines()[-1:] or ['']
         return f"first GPU process probe: rc {_probe.get('rc')} in {_probe.get('seconds')} s -- {last[0]}"
     return None
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Launch ledger (round 6).  The library counts the launches of every kernel build it holds (hk_debug_build_ledger: each instantiation
+# of the fused kernel's template, each kernel of the other units, launched or not).  Around every GPU test the counts are read; a
+# build counts as CHECKED only when it was launched inside a test that (a) carries the `oracle` marker -- its assertions compare the
+# launched kernels' results with the oracle, a golden vector or a reference-held number -- and (b) passed.  The last GPU test
+# (tests/test_zz_build_ledger.py) fails on any build that never was.  Kernels launched in child processes are not seen (their
+# tests are not marked).
+BUILD_LEDGER = {'checked': {}, 'unchecked': {}, 'gpu_tests': 0, 'gpu_tests_failed': 0}
+
+
+@pytest.hookimpl(hookwrapper=True, tryfirst=True)
+def pytest_runtest_makereport(item, call):
+    outcome = yield
+    rep = outcome.get_result()
+    if rep.when == 'call':
+        item._hk_call_passed = rep.passed
+
+
+@pytest.fixture(autouse=True)
+def _build_ledger(request):
+    node = request.node
+    if node.get_closest_marker('gpu') is None:
+        yield
+        return
+    from homonim_amd import _hk
+    before = _hk.build_ledger()
+    yield
+    after = _hk.build_ledger()
+    passed = bool(getattr(node, '_hk_call_passed', False))
+    BUILD_LEDGER['gpu_tests'] += 1
+    BUILD_LEDGER['gpu_tests_failed'] += 0 if passed else 1
+    book = BUILD_LEDGER['checked' if (passed and node.get_closest_marker('oracle') is not None) else 'unchecked']
+    test_name = node.nodeid.split('::', 1)[-1].split('[')[0]
+    for build, n in after.items():
+        d = n - before.get(build, 0)
+        if d > 0:
+            entry = book.setdefault(build, {'launches': 0, 'tests': set()})
+            entry['launches'] += d
+            entry['tests'].add(test_name)
 
 
 def _nodata(v):

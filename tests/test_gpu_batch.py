@@ -50,6 +50,7 @@ def _block_jobs(positions, bufs, norm, n, plane, B, stream):
 # kernels whose halo (utils.overlap_for_kernel) is a multiple of 4 pixels: a block processed in place starts 16-byte aligned
 @pytest.mark.parametrize('model,k,nodata_variant', [('gain-blk-offset', 15, 0), ('gain-blk-offset', 7, 1), ('gain', 7, 0),
                                                     ('gain', 15, 0), ('gain-offset', 7, 2), ('gain-blk-offset', 23, 1), ('gain-blk-offset', 31, 0)])   # (23 / 31: the batched builds of kernels wider than 15)
+@pytest.mark.oracle
 def test_blocks_of_a_raster_in_one_launch_equal_one_launch_per_block(ctx, oracle, model, k, nodata_variant):
     """ A 3-band 1536 x 1536 raster cut into the reference's blocks (raster_pair.py:342-428; edge blocks differ in shape and
     store window from interior ones): statistics and corrected planes of the batched launches == those of per-block launches,
@@ -290,6 +291,7 @@ def test_jobs_of_different_band_counts_and_shapes_in_one_launch(ctx):
         ctx.dev_free(norm_a), ctx.dev_free(norm_b)
 
 
+@pytest.mark.oracle
 def test_statistics_batch_with_a_smaller_plane_that_has_more_chunks(ctx, oracle):
     """ The streaming pass of the statistics strides every plane by its OWN wave count, which follows the number of 1 KB
     chunks (rows x ceil(ceil(w / 4) / 64)), not the number of pixels: 1090 x 1025 has fewer pixels than 1100 x 1024 but 5

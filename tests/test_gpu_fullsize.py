@@ -52,6 +52,7 @@ def _run(ctx, bufs, desc, stride, seg_rows, out_key):
     return int(fail[0])
 
 
+@pytest.mark.oracle
 @pytest.mark.parametrize('nodata_variant', [0, 1])
 def test_full_size_properties_and_oracle_windows(ctx, oracle, nodata_variant, monkeypatch):
     stride = SIZE
@@ -157,6 +158,7 @@ def _check_windows(oracle, model, k, thresh, nodata, src, ref, got_full, wins, w
     return n_checked, n_diff
 
 
+@pytest.mark.oracle
 def test_config1_gain_8192_four_bands(ctx, oracle):
     """ BASELINE.json configs[1] at full size: 4-band 8192 x 8192, Model.gain 5x5, one fused launch; windows of every
     band against the C oracle, corners included. """
@@ -188,6 +190,7 @@ def test_config1_gain_8192_four_bands(ctx, oracle):
             ctx.dev_free(bufs[k])
 
 
+@pytest.mark.oracle
 def test_config2_headline_launch_four_bands(ctx, oracle):
     """ BASELINE.json configs[2] exactly as it is benched: ONE fused launch over 4 bands of 16384 x 16384 (gain-offset 5x5 +
     r2 mask, plane offsets of up to 3.2 GB), windows of EVERY band -- the last one included -- against the C oracle, and the
@@ -248,6 +251,7 @@ def test_config2_headline_launch_four_bands(ctx, oracle):
             ctx.dev_free(bufs[name])
 
 
+@pytest.mark.oracle
 def test_config3_block_in_place_with_halo_15x15(ctx, oracle):
     """ BASELINE.json configs[3] at its block size: a 4096 x 4096 out-block with its 8-pixel halo (a 4112 x 4112 in-block in
     the interior of a 16384-wide raster), gain-blk-offset 15x15, statistics over the in-block on the device, processed
@@ -299,6 +303,7 @@ def test_config3_block_in_place_with_halo_15x15(ctx, oracle):
         ctx.dev_free(norm)
 
 
+@pytest.mark.oracle
 def test_config4_tiles_on_four_streams(ctx, oracle):
     """ BASELINE.json configs[4] at its tile size: 4-band 4096 x 4096 tiles, gain-offset 5x5 with the r2 mask, eight tiles in
     flight on the context's four streams at once; every tile's windows against the C oracle and clean failure counters. """
@@ -345,6 +350,7 @@ def test_config4_tiles_on_four_streams(ctx, oracle):
                 ctx.dev_free(d[k])
 
 
+@pytest.mark.oracle
 def test_config3_all_128_blocks_of_the_resident_raster(ctx, oracle):
     """ BASELINE.json configs[3] at its FULL count: the 8-band 16384 x 16384 raster resident in HBM, cut into the reference's own
     128 blocks (16 positions x 8 bands; homonim/raster_pair.py:342-428), every block normalised by its own device statistics
@@ -429,6 +435,7 @@ def test_config3_all_128_blocks_of_the_resident_raster(ctx, oracle):
         ctx.dev_free(norm)
 
 
+@pytest.mark.oracle
 def test_config4_all_64_tiles(ctx, oracle):
     """ BASELINE.json configs[4] at its FULL count: 64 independent 4-band 4096 x 4096 tiles resident in HBM (51 GB), one fused
     gain-offset 5x5 launch per tile dealt round four streams with the r2-mask counters checked per tile -- bench.py --config 4.

@@ -78,6 +78,7 @@ def test_selftest(ctx):
     ctx.selftest()
 
 
+@pytest.mark.oracle
 @pytest.mark.parametrize('case', GOLDEN_CASES, ids=case_id)
 def test_goldens_through_c_abi(ctx, goldens, case):
     """ Reference-generated golden vectors (oracle/gen_golden.py), fused fit+apply through the C ABI. """
@@ -96,6 +97,7 @@ def test_goldens_through_c_abi(ctx, goldens, case):
         np.testing.assert_array_equal(norm, norm_in)
 
 
+@pytest.mark.oracle
 @pytest.mark.parametrize('case', [c for c in GOLDEN_CASES if c['model'] == 'gain-blk-offset'], ids=case_id)
 def test_block_norm_vs_goldens(ctx, goldens, case):
     src = goldens[f"in_{case['variant']}_src"]
@@ -129,6 +131,7 @@ def test_block_norm_vs_goldens(ctx, goldens, case):
     ('gain-blk-offset', (15, 15), True, None),
     ('gain-blk-offset', (1, 1), False, None),
 ])
+@pytest.mark.oracle
 @pytest.mark.parametrize('shape, variant', [((300, 1003), 'frame+holes'), ((517, 640), 'none')])
 def test_multi_strip_multi_segment_vs_oracle(ctx, model, kernel_shape, find_r2, thresh, shape, variant):
     """ Rasters spanning several 248-column strips and 128-row segments, ragged widths, every kernel path
@@ -157,6 +160,7 @@ def test_multi_strip_multi_segment_vs_oracle(ctx, model, kernel_shape, find_r2, 
     ('gain', False, None), ('gain', True, None), ('gain-blk-offset', False, None), ('gain-blk-offset', True, None),
     ('gain-offset', False, None), ('gain-offset', True, None), ('gain-offset', False, 0.25), ('gain-offset', True, 0.25),
 ])
+@pytest.mark.oracle
 @pytest.mark.parametrize('kernel_shape', [(17, 17), (21, 9), (31, 31), (9, 21), (5, 19), (33, 35), (3, 25), (45, 13), (7, 41)])
 @pytest.mark.parametrize('variant', ['frame+holes', 'none'])
 def test_kernels_wider_than_15_vs_oracle(ctx, oc, model, find_r2, thresh, kernel_shape, variant):
@@ -187,6 +191,7 @@ def test_kernels_wider_than_15_vs_oracle(ctx, oc, model, find_r2, thresh, kernel
 
 @pytest.mark.parametrize('model, find_r2, thresh', [('gain', False, None), ('gain-blk-offset', True, None), ('gain-offset', False, 0.25),
                                                     ('gain-offset', True, None)])
+@pytest.mark.oracle
 @pytest.mark.parametrize('kernel_shape', [(63, 5), (129, 3), (35, 7), (255, 1), (33, 9), (61, 15), (5, 151), (9, 193), (3, 101), (1, 63), (41, 57)])
 def test_tall_kernels_vs_oracle(ctx, oc, model, find_r2, thresh, kernel_shape):
     """ The extremes of the shape space: very wide kernels (up to the 193 columns a strip's overlap lanes allow: 24 whole neighbour lanes
@@ -207,6 +212,7 @@ def test_tall_kernels_vs_oracle(ctx, oc, model, find_r2, thresh, kernel_shape):
         assert n_fail == exp_fail
 
 
+@pytest.mark.oracle
 @pytest.mark.parametrize('seed', range(180))
 def test_randomized_configurations_vs_oracle(ctx, oc, seed):
     """ A seeded sweep over the configuration space (model, odd kernel shape up to 17 x 15 -- seeds from 120: 17 to 63 rows by 17 to
@@ -267,6 +273,7 @@ def test_randomized_configurations_vs_oracle(ctx, oc, seed):
         assert n_fail == exp_fail == n_fail_fused, what
 
 
+@pytest.mark.oracle
 @pytest.mark.parametrize('shape', [(1, 1), (1, 7), (5, 1), (2, 3), (4, 250), (131, 5), (129, 249)])
 @pytest.mark.parametrize('model, kernel_shape', [('gain', (3, 3)), ('gain-offset', (5, 5)), ('gain-offset', (15, 15))])
 def test_tiny_and_ragged_shapes(ctx, shape, model, kernel_shape):
@@ -294,6 +301,7 @@ def test_all_masked_block(ctx):
             assert (norm == 0).all()  # kernel_model.py:225-226
 
 
+@pytest.mark.oracle
 def test_r2_fail_count_outlier(ctx):
     """ reference tests/test_kernel_model.py:166-203: one -100 outlier makes R2 < 0.5 in its k x k neighbourhood. """
     a = np.array(range(1, 201), dtype='float32').reshape(20, 10)
@@ -357,6 +365,7 @@ def test_find_r2_band(ctx, model, find_r2):
         assert np.nanmax(param_ra.array[2]) <= 1
 
 
+@pytest.mark.oracle
 def test_reference_param_tif_on_gpu(ctx):
     """ The reference's own PARAM GeoTIFF (real homonim+OpenCV+GDAL output), reproduced by the HIP path. """
     import os
@@ -386,6 +395,7 @@ def test_fit_apply_fused_equals_two_calls(ctx):
         assert_same_f32(corr3.array, corr2.array, 'corrected (no params)')
 
 
+@pytest.mark.oracle
 def test_concurrent_callers_share_one_model(ctx):
     """ homonim/fuse.py:396-401: many threads call fit/apply on ONE model object. """
     from concurrent.futures import ThreadPoolExecutor
@@ -433,6 +443,7 @@ def _oracle_process(src, ref, nodata, model, kernel_shape, max_block_mem, want_p
     ('gain-blk-offset', (5, 5), 0.25), ('gain-offset', (5, 5), 0.25), ('gain', (3, 3), None),
     ('gain-blk-offset', (15, 15), None),
 ])
+@pytest.mark.oracle
 @pytest.mark.parametrize('threads', [1, 4])
 def test_raster_fuse_process_multi_block(ctx, model, kernel_shape, thresh, threads):
     import warnings
@@ -502,6 +513,7 @@ def test_raster_fuse_uint8_output(ctx):
     ('gain', (5, 5), True, None), ('gain-offset', (5, 5), True, 0.25), ('gain-offset', (3, 7), False, None),
     ('gain-offset', (15, 15), True, 0.25), ('gain-offset', (9, 9), True, 0.25),
 ])
+@pytest.mark.oracle
 @pytest.mark.parametrize('shape', [(260, 1003), (131, 250), (64, 1024)])
 def test_dense_path_equals_general_path(ctx, model, kernel_shape, find_r2, thresh, shape, monkeypatch):
     """ nodata None on both rasters selects the DENSE kernels (geometric window count, no mask ring); results must be
@@ -529,6 +541,7 @@ def _fused_no_params(ctx, src, ref, nodata, k, thresh):
     return corr, n_fail
 
 
+@pytest.mark.oracle
 @pytest.mark.parametrize('thresh', [0.25, 0.5, 0.0, -1.0, float('-inf'), 0.9, 0.999, 0.9999999, 1.0, 2.0])
 @pytest.mark.parametrize('nodata, variant', [(np.nan, 'frame+holes'), (None, 'none')])
 def test_certified_r2_test_counts_exactly(ctx, oc, thresh, nodata, variant):
@@ -549,6 +562,7 @@ def test_certified_r2_test_counts_exactly(ctx, oc, thresh, nodata, variant):
     assert_close_ulp(corr, exp_corr, 'corrected', max_frac=1e-4)
 
 
+@pytest.mark.oracle
 def test_certified_r2_test_degenerate_windows(ctx, oc):
     """ flat reference (sstot == 0), single-valid-pixel windows, negative gains: never certified, always exact. """
     rng = np.random.default_rng(8)
@@ -594,6 +608,7 @@ def _adversarial_pair(kind, shape, seed):
     return src.astype(np.float32), ref.astype(np.float32)
 
 
+@pytest.mark.oracle
 @pytest.mark.parametrize('kind', ['flat-dn', 'marginal', 'integer', 'tiny', 'huge', 'small-gain'])
 @pytest.mark.parametrize('kernel_shape, nodata', [((5, 5), None), ((5, 5), np.nan), ((3, 7), None), ((15, 15), np.nan)])
 def test_r2_certificate_on_adversarial_rasters(ctx, oc, kind, kernel_shape, nodata):
@@ -623,6 +638,7 @@ def test_r2_certificate_on_adversarial_rasters(ctx, oc, kind, kernel_shape, noda
             assert_close_ulp(corr, exp_corr, 'corrected', max_frac=1e-3)
 
 
+@pytest.mark.oracle
 def test_block_norm_heavy_ties_take_the_fallback_select(ctx):
     """ Few distinct values: the [lo, hi] pivot window holds a third of the block, overflows the compaction buffer and
     routes the band through the full-raster radix select; the order statistics must still be exact. """
@@ -643,6 +659,7 @@ def test_block_norm_heavy_ties_take_the_fallback_select(ctx):
     assert n2[0] == pytest.approx(e2[0], rel=2e-6) and n2[1] == pytest.approx(e2[1], rel=2e-6, abs=1e-6)
 
 
+@pytest.mark.oracle
 @pytest.mark.parametrize('seed', range(40))
 def test_block_norm_randomized_vs_numpy(ctx, seed):
     """ Block statistics on random shapes (one pixel to a few hundred thousand, widths that are no multiple of 4), the three
@@ -710,6 +727,7 @@ def test_pinned_arrays_and_caller_outputs(ctx):
     ('gain-offset', (9, 3), False, None, None), ('gain-blk-offset', (15, 15), True, None, np.nan),
     ('gain', (1, 5), True, None, np.nan), ('gain-offset', (31, 31), False, None, np.nan),
 ])
+@pytest.mark.oracle
 def test_lds_ring_and_reload_modes_agree(ctx, model, kernel_shape, find_r2, thresh, nodata, monkeypatch):
     """ The leaving / centre rows come from a full LDS ring (mode 1, short kernels), from a centre-only LDS ring plus a
     re-loaded leaving row (mode 2, tall kernels) or are both re-loaded (mode 0); every mode must give the same bytes,
@@ -738,6 +756,7 @@ def test_lds_ring_and_reload_modes_agree(ctx, model, kernel_shape, find_r2, thre
     ('gain-offset', (5, 5), 0.25, None), ('gain-offset', (5, 5), 0.25, np.nan), ('gain-offset', (9, 9), 0.25, None),
     ('gain', (3, 3), None, np.nan), ('gain-blk-offset', (5, 7), None, np.nan),
 ])
+@pytest.mark.oracle
 def test_two_segment_sizes_equal_one_size(ctx, model, kernel_shape, thresh, nodata, monkeypatch):
     """ Large rasters are cut into long row segments followed by short ones (hk_api.hip fill_grid).  Forcing that
     policy onto a small raster (HK_WAVE_SLOTS: pretend the device holds few waves) must give the bytes of the one-size
@@ -794,6 +813,7 @@ def test_integer_inputs_equal_float32_inputs(ctx, dtype):
     assert_same_f32(c_v, c_c, 'strided view vs contiguous')
 
 
+@pytest.mark.oracle
 def test_output_dtype_conversion_matches_reference(ctx):
     """ The corrected block converted on the device == the reference's own RasterArray._convert_array_dtype
     (tests/golden/convert_dtype.npz).  gain 1x1 with ref == src reproduces the input exactly (gain 1, offset 0). """
@@ -840,6 +860,7 @@ def _mask_partial_cases():
         return json.load(f)
 
 
+@pytest.mark.oracle
 @pytest.mark.parametrize('case', _mask_partial_cases(), ids=lambda c: c['name'])
 def test_mask_partial_matches_reference(ctx, case):
     """ RefSpaceModel.apply / SrcSpaceModel.fit with mask_partial=True vs outputs of the reference's own classes. """
@@ -863,6 +884,7 @@ def test_mask_partial_matches_reference(ctx, case):
         assert_close_ulp(corr_ra.array, g[case['name'] + '_corr'], 'corrected', max_frac=1.0)
 
 
+@pytest.mark.oracle
 @pytest.mark.parametrize('kernel_shape', [(1, 1), (3, 3), (3, 5), (5, 5)])
 def test_mask_partial_erosion_properties(ctx, kernel_shape):
     """ reference tests/test_kernel_model.py:206-273: the output mask is the source mask eroded by (k + 2). """
@@ -917,6 +939,7 @@ def test_r2_inpainting_reference_test(ctx, kernel_shape):
     assert p1.array[0, p1.mask].var() < p0.array[0, p0.mask].var()
 
 
+@pytest.mark.oracle
 @pytest.mark.parametrize('want_params', [True, False])
 def test_r2_inpainting_vs_oracle(ctx, want_params):
     """ In-painted parameters and corrected block against the oracle's restatement of the same GDAL algorithm, with
@@ -937,6 +960,7 @@ def test_r2_inpainting_vs_oracle(ctx, want_params):
         assert_close_ulp(corr, onp.apply(src, exp_params), 'corrected after in-painting', max_frac=1e-3)
 
 
+@pytest.mark.oracle
 @pytest.mark.parametrize('h', [1, 2, 3, 5, 63, 64, 65])
 def test_r2_inpainting_of_blocks_of_a_few_rows(ctx, oc, h):
     """ Blocks of one to a few rows (and around the 64-row word height of the column table): the in-painting's bit words,
@@ -960,6 +984,7 @@ def test_r2_inpainting_of_blocks_of_a_few_rows(ctx, oc, h):
 
 @pytest.mark.parametrize('sd, frame, lo, hi', [(0.45, False, 0.15, 0.6), (0.45, True, 0.15, 0.6), (0.9, False, 0.6, 0.97),
                                                  (2.5, True, 0.9, 0.999), (0.3, False, 0.0005, 0.1)])
+@pytest.mark.oracle
 def test_r2_inpainting_of_noisy_pairs(ctx, oc, sd, frame, lo, hi):
     """ Failing pixels scattered all over a raster wide enough for the PACKED search (hk_inpaint.hip fill_fast: 16-bit keys, two
     quadrants per instruction) in the middle columns and the general one at the edges: from a few failing pixels among many sources
@@ -986,6 +1011,7 @@ def test_r2_inpainting_of_noisy_pairs(ctx, oc, sd, frame, lo, hi):
             assert len(bad) == 0, f'{what}, noise {sd}: {len(bad)} pixels differ, first at {bad[:5].tolist()}'
 
 
+@pytest.mark.oracle
 @pytest.mark.parametrize('h, w', [(7, 63), (8, 64), (9, 65), (70, 255), (64, 256), (65, 257), (23, 511), (130, 301), (16, 1030)])
 def test_r2_inpainting_at_tile_and_word_boundaries(ctx, oc, h, w):
     """ Heights around the 8-row tiles of the packed search and the 64-row words of its bit planes, widths around the 64-column
@@ -1005,6 +1031,7 @@ def test_r2_inpainting_at_tile_and_word_boundaries(ctx, oc, h, w):
             assert len(bad) == 0, f'{what}, {h} x {w}: {len(bad)} pixels differ, first at {bad[:5].tolist()}'
 
 
+@pytest.mark.oracle
 def test_r2_inpainting_of_a_block_taller_than_a_grid_dimension(ctx, oc):
     """ 66 000 rows: the in-painting kernels stride over the rows (a launch has at most 65 535 workgroups along y), and the
     column bit words / distance table cover the whole height; failing patches near the top, the middle and the last rows. """
@@ -1024,6 +1051,7 @@ def test_r2_inpainting_of_a_block_taller_than_a_grid_dimension(ctx, oc):
 
 @pytest.mark.parametrize('with_params, split_api, scratch', [(False, False, False), (True, False, False), (False, True, False),
                                                              (False, False, True), (True, False, True), (False, True, True)])
+@pytest.mark.oracle
 def test_device_resident_job_with_inpainting(ctx, oc, with_params, split_api, scratch):
     """ hk_fit_apply_dev + hk_inpaint_dev on a 3-band job resident in HBM: only the bands whose r2 mask has failures
     are in-painted; every band equals the oracle's whole reference branch.  Run twice: the second launch expects failures
@@ -1121,6 +1149,7 @@ def _dev_job_corr_only(c, src, ref, thresh, kernel_shape=(5, 5)):
     return job, d
 
 
+@pytest.mark.oracle
 def test_certificate_only_build_and_its_rerun_protocol(oc, monkeypatch):
     """ Gain-offset jobs that keep no R2 plane start with the certificate-only kernel build (hk_fit_kernel.h launch_one).
     On rasters it settles, the result equals the complete build's bit for bit; where it cannot, the band's counter comes
@@ -1242,6 +1271,7 @@ def _exact_compare_sums(src, src_nodata, ref, ref_nodata):
     ((300, 761), 'frame+holes', np.nan, np.nan), ((64, 64), 'none', None, None), ((1, 5), 'none', None, np.nan),
     ((257, 3), 'frame+holes', np.nan, None), ((2100, 1030), 'frame+holes', np.nan, np.nan),
 ])
+@pytest.mark.oracle
 def test_compare_sums_equal_exact_float64_sums(ctx, shape, variant, src_nodata, ref_nodata):
     """ hk_compare_sums against numpy: same float32 per-pixel terms, float64 accumulation (order-independent to 1e-13) """
     src, ref = onp.synth_pair(*shape, seed=3, nodata_variant=variant)
@@ -1254,6 +1284,7 @@ def test_compare_sums_equal_exact_float64_sums(ctx, shape, variant, src_nodata, 
     assert np.allclose(got, [float(ora[k]) for k in onp.COMPARE_KEYS], rtol=3e-6, atol=0)
 
 
+@pytest.mark.oracle
 def test_compare_sums_numeric_nodata_strided_rows_and_empty(ctx):
     rng = np.random.default_rng(8)
     big = np.round(rng.uniform(0, 255, (120, 400))).astype(np.float32)
@@ -1293,6 +1324,7 @@ def test_compare_sums_on_device_resident_bands(ctx):
             ctx.dev_free(v)
 
 
+@pytest.mark.oracle
 def test_raster_compare_matches_reference_statistics():
     """ RasterCompare.process against the statistics of the reference's own RasterCompare.process (compare.npz),
     block partition and thread pool included. """
@@ -1397,6 +1429,7 @@ def _ref_arrays():
     ('bilinear', (.45, -.5, .45, -.5), (340, 540)), ('nearest', (.5, 0., .5, 0.), (300, 480)),
     ('nearest', (2.2, 0.3, 1.9, -0.4), (70, 100)), ('average', (1., 0., 1., 0.), (150, 240)),
 ])
+@pytest.mark.oracle
 @pytest.mark.parametrize('nodata', [np.nan, None, 0.])
 def test_device_resamplers_equal_oracle(ctx, resampling, mapping, dst_shape, nodata):
     """ hk_reproject vs the oracle's restatement of the same GDAL kernels: bit-exact float32, NaN pattern included. """
@@ -1446,6 +1479,7 @@ def test_ref_space_apply_different_grids(ctx):
 
 @pytest.mark.parametrize('kernel_shape, mask_partial', [((1, 1), False), ((1, 1), True), ((3, 3), True), ((3, 5), True),
                                                         ((5, 5), True)])
+@pytest.mark.oracle
 def test_ref_and_src_masking_different_grids(ctx, kernel_shape, mask_partial):
     """ reference tests/test_kernel_model.py:206-273: mask_partial across grids -- the output mask equals the source mask
     averaged to the parameter grid (>= 1), eroded by (k + 2), brought back with nearest. """
@@ -1526,6 +1560,7 @@ def test_fit_apply_block_writes_the_out_block_in_place(ctx, model, kernel_shape,
         assert exp_fail > 1000
 
 
+@pytest.mark.oracle
 @pytest.mark.parametrize('model, kernel_shape', [('gain-blk-offset', (15, 15)), ('gain', (5, 5)), ('gain-offset', (7, 7))])
 def test_device_job_store_window(ctx, oc, model, kernel_shape):
     """ A block of a larger device-resident raster processed in place (BASELINE.json configs[3]): job = the in-block
@@ -1580,6 +1615,7 @@ def test_device_job_store_window(ctx, oc, model, kernel_shape):
         ctx.fit_apply_dev(desc, job)
 
 
+@pytest.mark.oracle
 @pytest.mark.parametrize('case', [c for c in _mask_partial_cases() if c['space'] == 'src'], ids=lambda c: c['name'])
 def test_src_space_fit_apply_honours_mask_partial(ctx, case):
     """ SrcSpaceModel.fit_apply on a shared grid with mask_partial=True (what RasterFuse(proc_crs='src') calls per block)
@@ -1614,6 +1650,7 @@ def test_src_space_fit_apply_honours_mask_partial(ctx, case):
     ('max', (2.2, 0.3, 1.9, -0.4), (40, 55)), ('min', (4., 0., 4., 0.), (20, 30)), ('sum', (2., 0., 2., 0.), (40, 60)),
     ('rms', (2.2, 0.3, 1.9, -0.4), (40, 55)), ('bilinear', (1.5, 0., .5, 0.), (160, 80)),
 ])
+@pytest.mark.oracle
 @pytest.mark.parametrize('nodata', [np.nan, None])
 def test_more_device_resamplers_equal_oracle(ctx, resampling, mapping, dst_shape, nodata):
     """ cubic / lanczos / max / min / sum / rms and the stretched (down-sampling) bilinear / cubic_spline kernels of
@@ -1633,6 +1670,7 @@ def test_more_device_resamplers_equal_oracle(ctx, resampling, mapping, dst_shape
 @pytest.mark.parametrize('resampling', ['mode', 'med', 'q1', 'q3'])
 @pytest.mark.parametrize('mapping, dst_shape, nodata', [((2., 0., 2., 0.), (40, 60), None), ((3., .5, 2.5, .25), (31, 39), np.nan),
                                                         ((6., 0., 6., 0.), (13, 20), np.nan), ((.5, 0., .5, 0.), (160, 240), None)])
+@pytest.mark.oracle
 def test_rank_order_resamplers_equal_oracle(ctx, resampling, mapping, dst_shape, nodata):
     """ GWKAverageOrMode's rank-order branches (mode, med, q1, q3) over the `average` footprint vs the oracle's restatement;
     integer-valued data so that `mode` has real ties. """
@@ -1717,6 +1755,7 @@ def test_south_up_and_mirrored_grids(ctx):
     ('gain', (15, 15), np.nan), ('gain', (11, 11), None), ('gain', (13, 7), np.nan), ('gain', (7, 5), np.nan),
     ('gain-blk-offset', (9, 9), np.nan), ('gain-blk-offset', (11, 5), np.nan), ('gain-blk-offset', (15, 15), 0.0),
 ])
+@pytest.mark.oracle
 def test_split_ring_agrees_with_the_other_ring_modes(ctx, model, kernel_shape, nodata, monkeypatch):
     """ Ring mode 3 (round 3): the rh newest rows of a tall kernel's window stay in registers, the rh + 1 older ones in an LDS
     ring -- no re-load of the leaving row.  Same bytes as the centre-ring / re-load modes, on rasters with a NaN frame and
@@ -1745,6 +1784,7 @@ def test_split_ring_agrees_with_the_other_ring_modes(ctx, model, kernel_shape, n
 
 # ----------------------------------------------------------------------------------------------------------------------
 # round 3: hygiene of the host layer
+@pytest.mark.oracle
 def test_a_tolerated_hip_failure_does_not_poison_the_next_launch(ctx):
     """ HIP keeps a per-thread last error until it is read and the launch wrappers report through hipGetLastError():
     registering memory that is page-locked already (the advertised `corr_out = ctx.pinned_empty(...)` use) must not make
@@ -1899,6 +1939,7 @@ def test_host_calls_and_device_jobs_on_one_stream_are_kept_apart():
         c1.close()
 
 
+@pytest.mark.oracle
 @pytest.mark.parametrize('find_r2', [False, True])
 def test_gain_blk_offset_with_degenerate_block_statistics(ctx, find_r2):
     """ the fused gain-blk-offset build without R2 normalises the window SUM (n0 * sum(s) + n1 * N) instead of
@@ -1925,6 +1966,7 @@ def test_gain_blk_offset_with_degenerate_block_statistics(ctx, find_r2):
     assert (np.isnan(gn) == np.isnan(norm)).all() and (gn[~np.isnan(norm)] == norm[~np.isnan(norm)]).all()
 
 
+@pytest.mark.oracle
 @pytest.mark.parametrize('shape', [(1, 1), (3, 7), (5, 300), (16, 40), (11, 11), (40, 1), (130, 259), (257, 65)])
 def test_split_ring_on_rasters_smaller_than_the_kernel_or_the_strip(ctx, shape):
     """ ring mode 3 on degenerate shapes: rasters smaller than the kernel, narrower than a lane quad, one wave segment + 1 row,

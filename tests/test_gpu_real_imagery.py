@@ -285,6 +285,7 @@ def test_fused_refspace_pipeline_equals_step_by_step(pair, model, kernel_shape, 
     np.testing.assert_array_equal(b_corr.array, convert_dtype(corr_ra.array, 'uint8', 0))
 
 
+@pytest.mark.oracle
 @pytest.mark.parametrize('image', [1, 2, 3, 4])
 def test_published_accuracy_table_of_the_real_stack(image):
     """ The reference PUBLISHES, for its own test rasters, what the real homonim + OpenCV + GDAL stack prints for
@@ -350,6 +351,7 @@ def _vrt_mosaic(tiles, layout, fill):
     return out
 
 
+@pytest.mark.oracle
 def test_published_mosaic_table_of_the_real_stack():
     """ The reference's tutorial notebook prints a SECOND accuracy table of the real homonim + OpenCV + GDAL stack
     (docs/tutorials/basic_correction.ipynb:299-334; tests/golden/notebook_table.json, oracle/gen_notebook_table_fixture.py):

@@ -53,6 +53,7 @@ def _slab_job(c, src, ref, r0, r1, stream=0):
 
 @pytest.mark.parametrize('variant, edges', [('frame+holes', (0, 300, 613)), ('none', (0, 37, 38, 400, 613)),
                                             ('frame+holes', (0, 3, 613)), ('frame+holes', (0, 200, 420, 613))])
+@pytest.mark.oracle
 def test_split_statistics_in_one_process_equal_the_whole_block(ctx, variant, edges):
     """ two to four contexts on this GPU, each with a slab of rows (one of them a single row / an all-nodata strip): the
     phases run in step, the exchange buffers are summed on the host. """
@@ -79,6 +80,7 @@ def test_split_statistics_in_one_process_equal_the_whole_block(ctx, variant, edg
             c.close()
 
 
+@pytest.mark.oracle
 def test_split_statistics_of_a_block_without_valid_pixels(ctx):
     src, ref = _block('frame+holes', 64, 200, 2)
     src[:] = np.nan
@@ -168,6 +170,7 @@ def test_split_statistics_through_rccl_over_several_gpus(ctx, tmp_path, world):
     np.testing.assert_allclose(norms[0], exp, rtol=1e-12, atol=0)
 
 
+@pytest.mark.oracle
 def test_split_statistics_with_a_slab_of_no_rows(ctx):
     """ a rank without rows of the block takes part with zeros (it used to be refused, leaving the others
     waiting inside the all-reduce) """

@@ -44,6 +44,7 @@ def test_chunked_staging_gives_the_same_bytes(tmp_path):
             assert np.array_equal(a, b, equal_nan=(a.dtype.kind == 'f')), f'{key} differs with {kb} KB chunks'
 
 
+@pytest.mark.oracle
 def test_staged_results_match_the_oracle(tmp_path):
     """ ... and they are the right bytes: the staged gain-offset call against the oracle, bit for bit. """
     got = _run_worker(tmp_path, 'oracle', 16)
