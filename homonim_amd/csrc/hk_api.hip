@@ -286,6 +286,7 @@ struct Slot {
     size_t tbl_bytes[TBL_RING] = {0, 0, 0, 0};
     hipEvent_t tbl_ev[TBL_RING] = {nullptr, nullptr, nullptr, nullptr};
     int tbl_next = 0;
+    bool direct_pending = false;  // copies queued straight from / to page-locked CALLER arrays since the last stream synchronisation
     bool busy = false;         // leased by a host-pointer call (SlotLease)
     int dev_inflight = 0;      // device-job entry points currently queuing on this stream (DevEnter): a lease waits for them
     bool dev_touched = false;  // device-resident jobs were queued on this stream since the last lease drained it
@@ -610,6 +611,7 @@ int stage_h2d(Slot& s, void* d_dst, size_t d_pitch, const void* h_src, size_t h_
             if (rc) return rc;
         }
         g_direct_copies.fetch_add(1, std::memory_order_relaxed);
+        s.direct_pending = true;
         if (flat) HK_HIP(hipMemcpyAsync(d_dst, h_src, rows * row_bytes, hipMemcpyHostToDevice, s.stream));
         else HK_HIP(hipMemcpy2DAsync(d_dst, d_pitch, h_src, h_pitch, row_bytes, rows, hipMemcpyHostToDevice, s.stream));
         return HK_OK;
@@ -659,6 +661,7 @@ int stage_d2h(Slot& s, void* h_dst, size_t h_pitch, const void* d_src, size_t d_
             if (rc) return rc;
         }
         g_direct_copies.fetch_add(1, std::memory_order_relaxed);
+        s.direct_pending = true;
         if (flat) HK_HIP(hipMemcpyAsync(h_dst, d_src, rows * row_bytes, hipMemcpyDeviceToHost, s.stream));
         else HK_HIP(hipMemcpy2DAsync(h_dst, h_pitch, d_src, d_pitch, row_bytes, rows, hipMemcpyDeviceToHost, s.stream));
         return HK_OK;
@@ -698,14 +701,17 @@ int stage_d2h(Slot& s, void* h_dst, size_t h_pitch, const void* d_src, size_t d_
 
 // A host-pointer call is ending WITHOUT stage_finish (an error return somewhere behind a stage_d2h): its queued chunks still name
 // the caller's output arrays, which the caller may free as soon as it sees the error -- the next call on this slot must not unpack
-// into them.  Let the copies that were queued complete (they write the ring, never the caller) and forget them.
+// into them.  Let the copies that were queued complete (they write the ring, never the caller) and forget them.  The same goes for
+// DIRECT copies (page-locked caller arrays, the RasterFuse default): they are still in flight on the caller's memory, which the
+// caller may unregister and free once it has the error -- the stream is drained before the call returns (round-5 advisor finding).
 void stage_abandon(Slot& s) {
-    bool any = false;
+    bool any = s.direct_pending;
     for (int i = 0; i < Slot::STAGE_N; ++i) any |= s.stage_state[i] != 0;
     if (!any) return;
     if (s.stream) (void)hipStreamSynchronize(s.stream);
     (void)hipGetLastError();
     for (int i = 0; i < Slot::STAGE_N; ++i) s.stage_state[i] = 0;
+    s.direct_pending = false;
 }
 
 // end of a host-pointer call: everything queued on the slot's stream has run and every output array is final
@@ -713,6 +719,7 @@ int stage_finish(Slot& s) {
     const int rc = stage_drain(s);
     if (rc) return rc;
     HK_HIP(hipStreamSynchronize(s.stream));
+    s.direct_pending = false;
     return HK_OK;
 }
 
@@ -800,11 +807,6 @@ float r2_fail_scale(float thresh) {
     return kf;
 }
 
-static int env_int_early(const char* name, int dflt) {
-    const char* e = getenv(name);
-    return e ? atoi(e) : dflt;
-}
-
 // kappa_f <= 1 - c_hi * (1 + 2^-50) with c_hi = r2_fail_above(): `g^2 den < kappa_f * sstot - (rounding slack)` then gives
 // ssres > c_hi * sstot in real arithmetic with room for the float64 comparison, i.e. the reference's decision is False
 // (PROOFS.md appendix A, the fail side).  Rounded DOWN to float32; -inf = failure is never certified that way.
@@ -829,7 +831,7 @@ void fill_args(hk::FitArgs& a, const hk_fit_desc* d, int xcd_remap) {
     a.has_thresh = (d->model == HK_MODEL_GAIN_OFFSET) ? d->has_r2_thresh : 0;
     a.r2_thresh = d->r2_thresh;
     a.r2_fail_scale = a.has_thresh ? r2_fail_scale(d->r2_thresh) : INFINITY;
-    a.r2_failcert_scale = (a.has_thresh && env_int_early("HK_FAIL_CERT", 1)) ? r2_failcert_scale(d->r2_thresh) : -INFINITY;
+    a.r2_failcert_scale = a.has_thresh ? r2_failcert_scale(d->r2_thresh) : -INFINITY;
     a.r2_pass_below = a.has_thresh ? r2_pass_scale(d->r2_thresh) : -INFINITY;
     a.r2_fail_above = a.has_thresh ? r2_fail_above(d->r2_thresh) : INFINITY;
     a.n_full = (float)(d->kh * d->kw);
@@ -837,10 +839,10 @@ void fill_args(hk::FitArgs& a, const hk_fit_desc* d, int xcd_remap) {
     a.inv_n_full = 1.0 / (double)(d->kh * d->kw);
     a.force_general = getenv("HK_FORCE_GENERAL") ? atoi(getenv("HK_FORCE_GENERAL")) : 0;
     // ring mode (hk_fit_kernel.h): full LDS ring while it leaves room for >= 11 waves per CU (kh <= 5), centre-only ring up
-    // to kh = HK_CRING_MAX_KH = 39 (1 KB per wave and row of the half-height; 33 - 39 rows: 3 - 13 % faster than re-loading, from 41 rows
+    // to kh = 39 (1 KB per wave and row of the half-height; 33 - 39 rows: 3 - 13 % faster than re-loading, from 41 rows
     // slower -- headline workload, round 5), everything re-loaded beyond -- that path exists
     // for kernels from 9 wide only (launch_rw), narrower ones keep the centre ring whatever their height (kh <= 255: 128 KB)
-    a.use_ring = (d->kh <= 5 && d->kw <= 7) ? 1 : ((d->kh <= env_int_early("HK_CRING_MAX_KH", 39) || d->kw <= 7) ? 2 : 0);
+    a.use_ring = (d->kh <= 5 && d->kw <= 7) ? 1 : ((d->kh <= 39 || d->kw <= 7) ? 2 : 0);
     // The memory-bound builds (no R2) prefer the full ring well beyond that: re-loading the leaving rows costs them more than
     // the waves the ring displaces -- gain 7x7 / 9x9 / 11x11 / 15x15 at 16384^2 x 4: 3.25 / 3.40 / 3.45 / 3.95 -> 2.54 / 2.58 /
     // 2.77 / 3.64 ms; gain-blk-offset (more arithmetic per pixel) only up to 7x7 (fit + statistics 5.11 -> 4.61 ms; 9x9 equal,
@@ -885,7 +887,6 @@ void fill_args(hk::FitArgs& a, const hk_fit_desc* d, int xcd_remap) {
     if (d->model == HK_MODEL_GAIN && !needs_r2(d) && d->kh <= 5 && d->kw <= 7 && d->src_nodata_mode == HK_NODATA_NONE &&
         d->ref_nodata_mode == HK_NODATA_NONE && !a.force_general)
         a.lds_pad = -1;
-    if (getenv("HK_LDS_PAD")) a.lds_pad = env_int_early("HK_LDS_PAD", 0);
     a.out_y0 = 0, a.out_y1 = a.height, a.out_x0 = 0, a.out_x1 = a.width;  // store window: the whole job (callers narrow it)
 }
 
@@ -912,7 +913,7 @@ void fill_grid(hk::FitArgs& a, int seg_rows) {
     const long long per_row_band = (long long)a.n_strips * a.n_bands;        // units per segment row
     if (seg_rows <= 0 && per_row_band * a.n_segs >= 6 * slots) {
         const int big = env_int("HK_SEG_BIG", 2 * uniform), tail = env_int("HK_SEG_TAIL", uniform / 2);
-        const double gens = env_int("HK_TAIL_GENS_X100", 125) / 100.0;
+        const double gens = 1.25;
         // image rows whose big-segment units make up `gens` generations of resident waves
         long long tail_rows = (long long)(gens * (double)slots / (double)per_row_band * big);
         tail_rows = (tail_rows + tail - 1) / tail * tail;
@@ -2206,7 +2207,7 @@ int hk_fit_apply_batch_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_jo
         }
         first[(size_t)n_jobs] = units;
         const long long slots = (long long)env_int("HK_WAVE_SLOTS", 256 * 12);
-        if (!any_explicit && units >= 6 * slots && env_int("HK_BATCH_SEGS", 1)) {
+        if (!any_explicit && units >= 6 * slots) {
             const long long tail_from = units - (long long)(1.25 * (double)slots);
             for (int32_t j = 0; j < n_jobs; ++j) seg_of[(size_t)j] = first[(size_t)j + 1] <= tail_from ? 2 * uniform : uniform / 2;
         }

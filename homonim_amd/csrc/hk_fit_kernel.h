@@ -359,7 +359,106 @@ __device__ __forceinline__ void hsum_wide(const T (&V)[PX], T (&H)[PX], const Wi
     });
 }
 
+// The float64 quantities of the kernels wider than 15 exchange their partial sums through a wave-private LDS LINE instead of
+// ds_bpermute (round 6).  A ds_bpermute_b32 moves 4 bytes per lane and occupies the CU's LDS crossbar for 2.6 ns whichever SIMD
+// issued it (profiles/r05_ubench_xlane.txt); at 31 wide a gain-offset wave-row issues ~100 of them = 260 ns of a pipe the CU's
+// four SIMDs share, against ~150 ns of VALU issue: the launch was bound THERE (6.6 ms for 4 x 16384^2), not by its re-loads.  A
+// lane now writes its seven partial sums once -- slot of 64 bytes: [suf1 suf2 | suf3 T | pre1 pre2 | pre3 T], T = the lane's four
+// columns -- with four ds_write_b128 and reads what it needs of its neighbours' slots with ds_read_b64 / ds_read_b128 (16 bytes
+// per lane in 1.85 ns): at 31 wide 4 writes + 8 reads instead of 20 ds_bpermute per quantity.  Same terms, same order of additions
+// as hsum_wide: bit-identical results.  `line` = this lane's slot; the F + 1 guard slots beyond either end of the wave are never
+// written: their readers are overlap lanes whose sums are discarded.
+constexpr size_t WLINE_SLOT = 64;
+inline size_t wline_bytes(int rw) { return (size_t)(WAVE + 2 * (rw / PX + 1)) * WLINE_SLOT; }  // F + 1 guard slots either side
+#ifndef HK_WLINE
+#define HK_WLINE 1
+#endif
+template <int E>
+__device__ __forceinline__ void hsum_wide_line(const double (&V)[PX], double (&H)[PX], const WideLanes& wl, int lane, char* line) {
+    constexpr int RV = 2 * PX + E;
+    double pre[PX + 1], suf[PX + 1];
+    pre[1] = V[0];
+    pre[2] = V[0] + V[1];
+    pre[3] = pre[2] + V[2];
+    suf[1] = V[3];
+    suf[2] = V[2] + V[3];
+    suf[3] = V[1] + suf[2];
+    pre[4] = suf[4] = pre[2] + suf[2];
+    hk_d2* const slot = reinterpret_cast<hk_d2*>(line);
+    slot[0] = hk_d2{suf[1], suf[2]};
+    slot[1] = hk_d2{suf[3], suf[4]};
+    slot[2] = hk_d2{pre[1], pre[2]};
+    slot[3] = hk_d2{pre[3], pre[4]};
+    xch_order();
+    double common = pre[PX];
+    if (wl.f >= 2) {  // wave-uniform
+        common = common + dpp_from_left(pre[PX]);
+        common = common + dpp_from_right(pre[PX]);
+    }
+    for (int j = 2; j < wl.f; ++j) {  // wave-uniform: the whole lanes beyond the DPP neighbours
+        common = common + *reinterpret_cast<const double*>(line - j * (int)WLINE_SLOT + 24);
+        common = common + *reinterpret_cast<const double*>(line + j * (int)WLINE_SLOT + 24);
+    }
+    static_for<2, 4>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        // the lanes F (j == 2) and F + 1 (j == 3) to the left / right
+        const char* const lb = line - (wl.f + j - 2) * (int)WLINE_SLOT;
+        const char* const rb = line + (wl.f + j - 2) * (int)WLINE_SLOT + 32;
+        double ls[PX + 1], rp[PX + 1];
+        constexpr bool L12 = need_left_at(RV, j, 1) || need_left_at(RV, j, 2), L34 = need_left_at(RV, j, 3) || need_left_at(RV, j, 4);
+        constexpr bool R12 = need_right_at(RV, j, 1) || need_right_at(RV, j, 2), R34 = need_right_at(RV, j, 3) || need_right_at(RV, j, 4);
+        if constexpr (L12) {
+            const hk_d2 v = *reinterpret_cast<const hk_d2*>(lb);
+            ls[1] = v.x, ls[2] = v.y;
+        }
+        if constexpr (L34) {
+            if constexpr (need_left_at(RV, j, 3)) {
+                const hk_d2 v = *reinterpret_cast<const hk_d2*>(lb + 16);
+                ls[3] = v.x, ls[4] = v.y;
+            } else {
+                ls[4] = *reinterpret_cast<const double*>(lb + 24);
+            }
+        }
+        if constexpr (R12) {
+            const hk_d2 v = *reinterpret_cast<const hk_d2*>(rb);
+            rp[1] = v.x, rp[2] = v.y;
+        }
+        if constexpr (R34) {
+            if constexpr (need_right_at(RV, j, 3)) {
+                const hk_d2 v = *reinterpret_cast<const hk_d2*>(rb + 16);
+                rp[3] = v.x, rp[4] = v.y;
+            } else {
+                rp[4] = *reinterpret_cast<const double*>(rb + 24);
+            }
+        }
+        if constexpr (lane_full_for_all(RV, j)) {
+            common = common + ls[PX];
+            common = common + rp[PX];
+        } else {
+            static_for<0, PX>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                constexpr int ll = left_len(RV, i, j), rl = right_len(RV, i, j);
+                if constexpr (ll > 0) {
+                    if constexpr (specific_before(RV, i, j, false, true)) H[i] = H[i] + ls[ll];
+                    else H[i] = ls[ll];
+                }
+                if constexpr (rl > 0) {
+                    if constexpr (specific_before(RV, i, j, true, true)) H[i] = H[i] + rp[rl];
+                    else H[i] = rp[rl];
+                }
+            });
+        }
+    });
+    static_for<0, PX>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        if constexpr (specific_before(RV, i, 4, false, true)) H[i] = common + H[i];
+        else H[i] = common;
+    });
+    xch_order();  // the next quantity rewrites the line: every read above has been issued (LDS operations of a wave run in order)
+}
+
 // RW >= 0: compile-time half-width; RW = -1 - E: wide kernel with rw mod 4 == E (hsum_wide).  DPP2: see hsum.
+// `xch`: the lane's slot of the LDS exchange line (XCH builds of hsum; the float64 sums of the wide kernels: hsum_wide_line)
 template <int RW, typename T, bool XCH = false, bool DPP2 = false>
 __device__ __forceinline__ void hsum_any(const T (&V)[PX], T (&H)[PX], const WideLanes& wl, int lane, char* xch = nullptr) {
     if constexpr ((HK_ABLATE & 4) != 0) {
@@ -367,7 +466,9 @@ __device__ __forceinline__ void hsum_any(const T (&V)[PX], T (&H)[PX], const Wid
         for (int i = 0; i < PX; ++i) H[i] = V[i];
     } else if constexpr (RW >= 0)
         hsum<RW, T, XCH, DPP2>(V, H, lane, xch);
-    else
+    else if constexpr (HK_WLINE && std::is_same<T, double>::value) {
+        hsum_wide_line<-1 - RW>(V, H, wl, lane, xch);
+    } else
         hsum_wide<-1 - RW, T>(V, H, wl, lane);
 }
 
@@ -688,6 +789,9 @@ constexpr int fit_min_waves() {
     // equal -- except kw / 2 mod 4 = 1 .. 3 beyond 15 wide, two registers short and as fast at two waves: profiles/r05_ab_cert_wide_waves.txt)
     if (MODEL == 2 && R2 && !DENSE && (RW < 0 || RW >= 4) && !(CERT_ONLY && HK_CERT_WIDE_3WAVES && RW >= -1)) return HK_FIT_MIN_WAVES_WIDE;
     if (HK_NOSPILL) {
+        // (round 6: with the LDS exchange line the compiler issues a quantity's neighbour reads together -- 8 to 25 registers more at
+        // the peak -- and the line's 4.5 KB per wave bound the occupancy of these builds near two waves per SIMD anyway)
+        if (HK_WLINE && RW < 0 && MODEL == 2) return 2;
         if (RW < 0 && R2 && !CERT_ONLY) return 2;                          // wider than 15 with the R2 work (10 - 28 spilled registers at three)
         if (MODEL == 2 && R2 && !DENSE && RW == 3) return 2;               // gain-offset + R2, 7 wide, NaN-aware
         if (MODEL != 2 && R2 && !DENSE && RW >= 4 && RING == 2) return 2;  // gain / gain-blk-offset + R2, 9-15 wide, NaN-aware
@@ -843,8 +947,9 @@ fit_apply_kernel(const FitArgs a_in) {
     // (profiles/r05_ab_dpp2_15wide.txt).  Kernels wider than 15 gain nothing from the same exchange (profiles/r05_ab_dpp_chain_wide.txt:
     // at 31 wide the launch moves 2.16 x its algorithmic bytes through the HBM -- the re-loaded leaving rows -- and is bound there).
     constexpr bool DPPX = HK_DPP2 && RW == 7 && MODEL != 1;
+    // (kernels wider than 15: the lane's 64-byte slot of the wave's exchange line, hsum_wide_line; one wave per workgroup there)
     [[maybe_unused]] char* const xch = reinterpret_cast<char*>(lds4 + (size_t)WPB * (size_t)(ring_rows * (ring2p ? 2 : 1) * WAVE)) +
-                                       (size_t)wave_in_wg * XCH_BYTES + 16 + lane * 16;
+                                       (RW < 0 ? (size_t)(lane + rw / PX + 1) * WLINE_SLOT : (size_t)wave_in_wg * XCH_BYTES + 16 + (size_t)lane * 16);
     const float ring_init = DENSE ? 0.f : __uint_as_float(RING_SENTINEL);
     {
         // four registers the compiler must treat as unrelated: one ds_write_b128 per slot and plane (the vectorised form of this
@@ -1602,6 +1707,7 @@ static hipError_t launch_build(const FitArgs& a, hipStream_t stream) {
     if constexpr (LOCKSTEP) {
         if (lds * HK_WPB_MEM <= 64 * 1024) return launch_wpb<MODEL, R2, RW, DENSE, RING, CERT_ONLY, HK_WPB_MEM>(a, lds, stream);
     }
+    if constexpr (RW < 0) return launch_wpb<MODEL, R2, RW, DENSE, RING, CERT_ONLY, 1>(a, lds + (HK_WLINE ? wline_bytes(a.rw) : 0), stream);
     return launch_wpb<MODEL, R2, RW, DENSE, RING, CERT_ONLY, 1>(a, lds + (xch_mask<MODEL, RW, RING, 1>() ? XCH_BYTES : 0), stream);
 }
 

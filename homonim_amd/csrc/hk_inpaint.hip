@@ -669,35 +669,23 @@ hipError_t launch_inpaint_offsets(float* offset, const float* gain, const float*
     HK_LAUNCH(inpaint_bits_kernel, gbits, dim3(256), 0, stream, flag, stride, height, width, bits, tbits);
     const dim3 gtable((width + 511) / 512, (height + WORD_ROWS - 1) / WORD_ROWS);  // two columns per thread
     HK_LAUNCH(inpaint_table_kernel, gtable, dim3(256), 0, stream, bits, stride, height, width, max_dist, tb);
-    // The packed search on 8-row tiles, then the general one over what it left.  HK_FILL_FAST=0: the general search for every target
-    // (A/B); HK_FILL_TILE = 16 / 32 / 64: the tile height of the general search; HK_FILL_CONT: lanes that must still be open for the
-    // packed search to go on to the next group of columns; HK_FILL_ORDER: 0 = the targets of a tile row by row, 1 = column by column,
-    // default: by the share of failing pixels.
-    static const int tile_env = [] { const char* e = getenv("HK_FILL_TILE"); return e ? atoi(e) : -1; }();
-    static const int fast_env = [] { const char* e = getenv("HK_FILL_FAST"); return e ? atoi(e) : 1; }();
-    static const int order_env = [] { const char* e = getenv("HK_FILL_ORDER"); return e ? atoi(e) : -1; }();
-    static const int cont_env = [] { const char* e = getenv("HK_FILL_CONT"); return e ? atoi(e) : 1; }();
-    const bool by_column = order_env >= 0 ? order_env != 0 : (double)n_targets > 0.6 * (double)height * (double)width;
+    // The packed search on 8-row tiles, then the general one (32-row tiles) over what it left.  The targets of a tile are listed
+    // column by column where more than 60 % of the pixels fail, row by row otherwise (HISTORY.md 53).
+    const bool by_column = (double)n_targets > 0.6 * (double)height * (double)width;
     // the packed search addresses the plane through 32-bit offsets from its tile and 24-bit multiplies by the row stride
-    const bool fast = fast_env && stride < (1ll << 23);
+    const bool fast = stride < (1ll << 23);
     if (fast) {
         const int n_tiles8 = (height + 7) / 8, wgs_y = (n_tiles8 + 3) / 4;  // a workgroup takes four tiles (it copies the finish tables into LDS once)
         const dim3 gf((width + 255) / 256, wgs_y < 65535 ? wgs_y : 65535);
         if (by_column)
-            HK_LAUNCH(inpaint_fill_fast_kernel<true>, gf, dim3(256), 0, stream, offset, tbits, sbits, stride, height, width, tb, ftab, cont_env);
+            HK_LAUNCH(inpaint_fill_fast_kernel<true>, gf, dim3(256), 0, stream, offset, tbits, sbits, stride, height, width, tb, ftab, 1);
         else
-            HK_LAUNCH(inpaint_fill_fast_kernel<false>, gf, dim3(256), 0, stream, offset, tbits, sbits, stride, height, width, tb, ftab, cont_env);
+            HK_LAUNCH(inpaint_fill_fast_kernel<false>, gf, dim3(256), 0, stream, offset, tbits, sbits, stride, height, width, tb, ftab, 1);
     }
     const unsigned long long* todo = fast ? sbits : tbits;
-    const int rows = tile_env >= 64 ? 64 : (tile_env >= 32 || tile_env <= 0 ? 32 : 16);
-    const int n_tiles = (height + rows - 1) / rows;
+    const int n_tiles = (height + 31) / 32;
     const dim3 gt((width + 255) / 256, n_tiles < 65535 ? n_tiles : 65535);
-    if (rows == 64)
-        HK_LAUNCH(inpaint_fill_general_kernel<64>, gt, dim3(256), 0, stream, offset, todo, stride, height, width, tb, tie, wtab);
-    else if (rows == 32)
-        HK_LAUNCH(inpaint_fill_general_kernel<32>, gt, dim3(256), 0, stream, offset, todo, stride, height, width, tb, tie, wtab);
-    else
-        HK_LAUNCH(inpaint_fill_general_kernel<16>, gt, dim3(256), 0, stream, offset, todo, stride, height, width, tb, tie, wtab);
+    HK_LAUNCH(inpaint_fill_general_kernel<32>, gt, dim3(256), 0, stream, offset, todo, stride, height, width, tb, tie, wtab);
     return hipGetLastError();
 }
 

@@ -272,11 +272,8 @@ __global__ void __launch_bounds__(SAMPLE_THREADS) norm_sample_kernel(const NormA
 }
 
 // Unused dynamic LDS per wave of the streaming pass: it only lowers the number of resident waves per CU (8 KB of queues per wave
-// = 20 waves per CU otherwise).  HK_NORM_LDS_PAD overrides (measurement).
-static size_t norm_stream_lds_pad() {
-    static const size_t pad = [] { const char* e = getenv("HK_NORM_LDS_PAD"); return e ? (size_t)atoi(e) : (size_t)HK_NORM_LDS_PAD_DEFAULT; }();
-    return pad;
-}
+// = 20 waves per CU otherwise).
+static size_t norm_stream_lds_pad() { return (size_t)HK_NORM_LDS_PAD_DEFAULT; }
 
 // Waves per band of the streaming pass: a function of the block SHAPE only (never of the batch size), so a block's
 // statistics are the same bits whichever launch it travels in; >= 16 chunks of 1 KB per raster per wave.

@@ -786,6 +786,7 @@ def test_two_segment_sizes_equal_one_size(ctx, model, kernel_shape, thresh, noda
 
 
 # -- typed rasters either side of the path (raster_array.py:178-188 read, :353-387 write) -------------------------------
+@pytest.mark.oracle
 @pytest.mark.parametrize('dtype', ['uint8', 'uint16', 'int16', 'int32', 'uint32', 'float64'])
 def test_integer_inputs_equal_float32_inputs(ctx, dtype):
     """ Integer / float64 rasters are converted to float32 on the device exactly as rasterio does on read. """
@@ -804,6 +805,12 @@ def test_integer_inputs_equal_float32_inputs(ctx, dtype):
         assert_same_f32(p_t, p_f, f'{model} params typed vs float32')
         assert_same_f32(c_t, c_f, f'{model} corrected typed vs float32')
         np.testing.assert_array_equal(n_t, n_f)
+        # ... and the oracle on the values rasterio would have handed the reference (raster_array.py:178-188: astype(float32))
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            exp, _ = onp.fit(model, src.astype(np.float32), src_nd, ref.astype(np.float32), None, k, True, None,
+                             norm_model=n_t if model == 'gain-blk-offset' else None)
+        assert_close_ulp(p_t, exp, f'{model} params of {dtype} rasters vs oracle')
     # strided (windowed) integer views are taken as they are
     big = np.zeros((400, 700), dtype)
     big[50:350, 100:617] = src

@@ -286,6 +286,52 @@ def test_fused_refspace_pipeline_equals_step_by_step(pair, model, kernel_shape, 
 
 
 @pytest.mark.oracle
+@pytest.mark.parametrize('model, kernel_shape, upsampling, mask_partial', [
+    ('gain-offset', (5, 5), 'cubic_spline', False), ('gain', (3, 3), 'bilinear', False), ('gain-offset', (3, 3), 'nearest', False),
+    ('gain', (3, 3), 'cubic_spline', True), ('gain-offset', (5, 5), 'average', True), ('gain-blk-offset', (5, 5), 'cubic_spline', False),
+])
+def test_fused_refspace_pipeline_vs_the_oracle_step_by_step(pair, model, kernel_shape, upsampling, mask_partial):
+    """ hk_refspace_fit_apply against the ORACLE's composition of the same steps (kernel_model.py:476-503): `average` down-sampling
+    of the source to the reference grid, the fit there, gain and offset brought back with the up-sampling method -- cubic spline and
+    bilinear fused into the apply kernel, the others through the general re-sampler + the re-masking apply --, mask_partial's
+    eroded full-coverage mask brought back with `nearest`.  Bit for bit (gain-blk-offset: the block statistics are the GPU's exact
+    float64 ones against numpy's float32 pairwise ones, 1e-5 relative). """
+    import warnings
+    from homonim_amd.geo import grid_mapping
+    from oracle import oracle_np as onp
+    src, src_tf, src_nodata, ref, ref_tf = pair
+    crs = CRS('EPSG:32735')
+    s, r = src[1].astype(np.float32), ref[1].astype(np.float32)
+    down, up = grid_mapping(src_tf, ref_tf), grid_mapping(ref_tf, src_tf)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        ds = onp.reproject(s, src_nodata, down, r.shape, dst_nodata=np.nan, resampling='average')
+        norm = onp.fit_block_norm(ds, np.nan, r, None) if model == 'gain-blk-offset' else None
+        params, _ = onp.fit(model, ds, np.nan, r, None, kernel_shape, False, None, norm_model=norm)
+        p_us = onp.reproject(params[:2], np.nan, up, s.shape, dst_nodata=np.nan, resampling=upsampling)
+        valid = onp.mask_of(s, src_nodata)
+        if mask_partial:
+            cover = onp.reproject(valid.astype(np.float32), None, down, r.shape, dst_nodata=None, resampling='average')
+            keep = onp.full_coverage_mask(cover >= 1, params[:2], kernel_shape)
+            valid = onp.reproject(keep.astype(np.float32), None, up, s.shape, dst_nodata=0, resampling='nearest').astype(bool)
+        exp = np.where(valid, p_us[0] * s + p_us[1], np.float32(np.nan)).astype(np.float32)
+        km = RefSpaceModel(model, kernel_shape, find_r2=False, mask_partial=mask_partial, r2_inpaint_thresh=None, upsampling=getattr(Resampling, upsampling))
+        corr_ra, param_ra = km.fit_apply(RasterArray(s, crs, src_tf, nodata=src_nodata), RasterArray(r, crs, ref_tf, nodata=None),
+                                         want_params=True)
+    got = corr_ra.array
+    assert (np.isnan(got) == np.isnan(exp)).all()
+    ok = ~np.isnan(exp)
+    assert ok.sum() > 0.3 * ok.size
+    if model == 'gain-blk-offset':
+        assert np.max(np.abs(got[ok] - exp[ok]) / np.maximum(np.abs(exp[ok]), 1e-6)) < 1e-5
+    else:
+        bad = int((got[ok] != exp[ok]).sum())
+        assert bad <= max(2, 1e-5 * int(ok.sum())), f'{bad} of {int(ok.sum())} corrected pixels differ from the oracle composition'
+        pe, pg = params[:2], param_ra.array[:2]
+        assert (((pe == pg) | (np.isnan(pe) & np.isnan(pg))).mean()) > 1 - 1e-5
+
+
+@pytest.mark.oracle
 @pytest.mark.parametrize('image', [1, 2, 3, 4])
 def test_published_accuracy_table_of_the_real_stack(image):
     """ The reference PUBLISHES, for its own test rasters, what the real homonim + OpenCV + GDAL stack prints for

@@ -172,3 +172,35 @@ def test_an_error_between_the_copies_leaves_no_pointer_behind(monkeypatch):
         assert (victim == -2.0).all(), 'a later call unpacked the failed call\'s result into its output array'
     finally:
         ctx.close()
+
+
+def test_an_error_behind_direct_copies_drains_them_before_the_call_returns(monkeypatch):
+    """ The same failure with PAGE-LOCKED caller arrays (RasterFuse's default: rasters registered for the block loop), whose copies
+    are queued straight on the caller's memory: when the failing call returns, no DMA may still be in flight on those arrays -- the
+    caller unregisters and frees them next (round-5 advisor finding: stage_abandon() only looked at staged chunks).  Observable:
+    the result copy was queued before the injected failure, so once the call has returned the output array holds the complete
+    result -- its LAST row included, checked first, at once -- and nothing writes it afterwards. """
+    ctx = _hk.Context(0, n_streams=1)
+    try:
+        h, w = 4096, 4096                              # 64 MB per plane: the result copy alone takes more than a millisecond
+        src, ref = onp.synth_pair(h, w, 3, 'none')
+        desc = _hk.make_desc('gain', (5, 5), False, None, None, None)
+        _, exp, _, _ = ctx.fit_apply(desc, src, ref, 2, want_params=False, want_corr=True)
+        ps, pr, victim = ctx.pinned_empty((h, w)), ctx.pinned_empty((h, w)), ctx.pinned_empty((h, w))
+        ps[:], pr[:], victim[:] = src, ref, -1.0
+        _hk.staging_counters(reset=True)
+        monkeypatch.setenv('HK_TEST_FAIL_AFTER_D2H', '1')
+        with pytest.raises(Exception, match='HK_TEST_FAIL_AFTER_D2H'):
+            ctx.fit_apply(desc, ps, pr, 2, want_params=False, want_corr=True, out_corr=victim)
+        last_row_done = np.array_equal(np.array(victim[-1]), exp[-1], equal_nan=True)
+        monkeypatch.delenv('HK_TEST_FAIL_AFTER_D2H')
+        direct, staged = _hk.staging_counters()
+        assert direct == 3 and staged == 0, (direct, staged)     # the three arrays went the direct way
+        assert last_row_done, 'the failed call returned while its result copy was still in flight on the caller\'s array'
+        assert np.array_equal(np.array(victim), exp, equal_nan=True)
+        victim[:] = -2.0
+        for _ in range(3):
+            _, got, _, _ = ctx.fit_apply(desc, src, ref, 2, want_params=False, want_corr=True)
+        assert (np.array(victim) == -2.0).all()
+    finally:
+        ctx.close()
