@@ -74,6 +74,10 @@ def parse_args():
     p.add_argument('--as-rank', default=None, metavar='R/N',
                    help='configs 3 / 4 on ONE GPU: run exactly the shard rank R of an N-rank launch would run, alone (no process group, no '
                         'peers) -- a projection aid for strong scaling, never a scaling measurement')
+    p.add_argument('--checksum', action='store_true',
+                   help='add `shard_checksum` to the line: the exact checksum (sum of the float32 bit patterns, modulo 2^64) and the pixel '
+                        'count of every corrected pixel this launch produced -- per rank and over all ranks; the union of N ranks\' shards '
+                        'equals the single-rank result iff the totals do (always on for N > 1)')
     p.add_argument('--no-projection', action='store_true',
                    help='configs 3 / 4 at one rank: skip the single-GPU projection (every rank\'s shard of an N = 2 / 4 / 8 launch timed alone)')
     args = p.parse_args()
@@ -284,6 +288,15 @@ def spot_check(ctx, model, k, thresh, nodata_variant, d_src, d_ref, d_corr, stri
     n_diff = int((got[ok] != exp[ok]).sum())
     return dict(window=[int(got.shape[0]), int(got.shape[1])], band=int(band), origin=[int(y0), int(x0)], bitwise_mismatches=n_diff,
                 max_rel_diff=rel, nan_pattern_equal=nan_ok, passed=bool(nan_ok and rel <= 1e-5))
+
+
+def windows_checksum(ctx, windows):
+    """ [(device pointer of the window's first pixel, row stride, height, width)] -> (sum of the pixels' bit patterns mod 2^64, pixels) """
+    total, px = 0, 0
+    for ptr, stride, h, w in windows:
+        total = (total + ctx.checksum_dev(ptr, stride, h, w)) & 0xFFFFFFFFFFFFFFFF
+        px += h * w
+    return total, px
 
 
 def merge_parity(records):
@@ -531,6 +544,9 @@ def run_resident(args, ctx, dist, rank, world):
     power = None
     if rank == 0 and world == 1 and getattr(args, 'power_probe', False):
         power = power_probe(lambda n: (run(n), ctx.sync()), elapsed / args.steps * 1e3)
+    checksum = None
+    if getattr(args, 'checksum', False) or world > 1:
+        checksum = windows_checksum(ctx, [(bufs['corr'] + 4 * b * band_stride, stride, H, W) for b in range(B)])
 
     for pair in events + [tuple(fail_ready)]:
         for e in pair:
@@ -560,7 +576,7 @@ def run_resident(args, ctx, dist, rank, world):
                       traffic_source=traffic_source, copy_gbps=copy_med, copy_gbps_best=copy_best,
                       kernel='hk::fit_apply_kernel' + (' + block statistics (hk_norm.hip)' if args.model == 'gain-blk-offset' else '')
                              + (' + in-painting passes (whole step)' if n_fail else '')),
-        parity=parity, power=power)
+        parity=parity, power=power, checksum=checksum)
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -672,6 +688,14 @@ def run_blocks(args, ctx, dist, rank, world):
         parity = spot_check(ctx, args.model, k, None, args.nodata, bufs['src'], bufs['ref'], bufs['corr'], stride, H, W, y0, x0,
                             256, 1000, nm[0], 0)
 
+    checksum = None
+    if getattr(args, 'checksum', False) or world > 1:   # the out-blocks this rank wrote, every band
+        wins = []
+        for bp in mine:
+            wo = bp.src_out_block
+            wins += [(bufs['corr'] + 4 * (b * band_stride + wo.row_off * stride + wo.col_off), stride, wo.height, wo.width) for b in range(B)]
+        checksum = windows_checksum(ctx, wins)
+
     projection = None
     if world == 1 and not args.no_projection and args.as_rank is None:
         # what rank r of an n-rank launch would run, alone on this GPU (tools: bench.py --config 3 --as-rank R/N)
@@ -707,7 +731,7 @@ def run_blocks(args, ctx, dist, rank, world):
         roofline=dict(achieved_bytes=ALGO_BYTES_PER_PX * my_px, avg_launch_ms=elapsed / args.steps * 1e3, traffic=None, traffic_source=None,
                       copy_gbps=copy_med, copy_gbps_best=copy_best,
                       kernel=f'one step of this rank: {len(mine)} x (block statistics + hk::fit_apply_kernel over {B} bands), wall time on {n_streams} streams'),
-        parity=parity, end_to_end=e2e, projection=projection)
+        parity=parity, end_to_end=e2e, projection=projection, checksum=checksum)
 
 
 def end_to_end_blocks(args, ctx, dist, bufs, nb, b0, stride, band_stride):
@@ -870,6 +894,10 @@ def run_tiles(args, ctx, dist, rank, world):
         d = tiles[0][0]
         parity = spot_check(ctx, args.model, k, thresh, args.nodata, d['src'], d['ref'], d['corr'], stride, n, n, n // 3, 1024,
                             min(n, 384), min(n - 1024, 1200), None, n_fail)
+    checksum = None
+    if getattr(args, 'checksum', False) or world > 1:   # this rank's tiles, every band
+        checksum = windows_checksum(ctx, [(d['corr'] + 4 * b * band_stride, stride, n, n) for d, job, counts, ev in tiles for b in range(B)])
+
     projection = None
     if world == 1 and not args.no_projection and args.as_rank is None and tiles:
         # what rank r of an n-rank launch would run, alone on this GPU (tools: bench.py --config 4 --as-rank R/N)
@@ -911,7 +939,7 @@ def run_tiles(args, ctx, dist, rank, world):
         roofline=dict(achieved_bytes=ALGO_BYTES_PER_PX * my_px, avg_launch_ms=elapsed / args.steps * 1e3, traffic=None, traffic_source=None,
                       copy_gbps=copy_med, copy_gbps_best=copy_best,
                       kernel=f'one step of this rank: {len(mine)} x hk::fit_apply_kernel on {n_streams} streams, wall time'),
-        parity=parity, end_to_end=e2e, projection=projection)
+        parity=parity, end_to_end=e2e, projection=projection, checksum=checksum)
 
 
 def end_to_end_tiles(args, ctx, dist, tiles, stride, band_stride, thresh, nd):
@@ -1053,25 +1081,34 @@ def main():
     # The library's own RCCL communicator over the ranks of this launch (the one data-path collective of the hot path, the
     # split-block statistics, runs on it): joined here so that every N > 1 run also proves RCCL over xGMI up -- one in-place
     # all-reduce of a float64 word per rank, which must come back as the number of ranks.
-    rccl_ranks, rccl_error = None, None
+    rccl_ranks, rccl_error, rccl_join_abandoned = None, None, False
     if dist.backend() == 'rccl':
         # Reported, never fatal, and never allowed to hang the run: the timed path has no collective, a rank's shard does not depend on
         # this communicator.  ncclCommInitRank returns only when EVERY rank has joined and has no timeout of its own, so a rank whose
         # librccl is missing (or whose bootstrap fails) would leave its peers waiting for ever: the join runs on a side thread with a
         # deadline, and the ranks agree over the launch's sockets (dist.sum_over_ranks) whether everybody got in before anybody queues
         # the all-reduce.
+        # The id travels over the launch's sockets on THIS thread (they carry one conversation at a time); only the call that can
+        # block without a deadline runs beside it.  A join that missed its deadline may still be inside ncclCommInitRank on `ctx`:
+        # such a run reports, skips the collectives and leaves the context open at exit instead of tearing it down under the thread.
         import threading
         joined = {}
+        try:
+            uid = dist.exchange_comm_id()
+        except Exception as ex:
+            uid, joined['err'] = None, f'{type(ex).__name__}: {ex}'
 
         def join():
             try:
-                dist.init_comm(ctx)
+                ctx.comm_init(uid, rank, world)
                 joined['ok'] = True
             except Exception as ex:
                 joined['err'] = f'{type(ex).__name__}: {ex}'
-        th = threading.Thread(target=join, daemon=True)
-        th.start()
-        th.join(timeout=float(os.environ.get('HK_BENCH_RCCL_TIMEOUT', '120')))
+        if uid is not None:
+            th = threading.Thread(target=join, daemon=True)
+            th.start()
+            th.join(timeout=float(os.environ.get('HK_BENCH_RCCL_TIMEOUT', '120')))
+            rccl_join_abandoned = th.is_alive()
         mine_ok = bool(joined.get('ok'))
         if not mine_ok:
             rccl_error = joined.get('err') or 'joining the communicator did not return within the deadline (a peer never joined?)'
@@ -1094,6 +1131,17 @@ def main():
             rccl_error = 'another rank could not join the communicator'
         if rccl_error:
             sys.stderr.write(f'bench.py: rank {rank}: the library\'s RCCL communicator is not usable: {rccl_error}\n')
+
+    # every rank's host placement travels to rank 0's line (a rank bound to the wrong socket shows there, not in a lost stderr)
+    placements = None
+    if world > 1:
+        placements = [json.loads(b.decode()) for b in dist.gather_bytes(json.dumps(topology.summary(placement)).encode())]
+    # Fault injection for the launch tests (tests/test_gpu_multirank.py): HK_BENCH_DIE_RANK=R ends rank R abruptly once the ranks
+    # have met -- the launch must end with a non-zero exit code within seconds, not sit in a barrier until a timeout.
+    if os.environ.get('HK_BENCH_DIE_RANK') == str(rank) and world > 1:
+        sys.stderr.write(f'bench.py: rank {rank}: HK_BENCH_DIE_RANK -- exiting abruptly\n')
+        sys.stderr.flush()
+        os._exit(17)
 
     runner = {1: run_resident, 2: run_resident, 3: run_blocks, 4: run_tiles}[args.config]
     if args.as_rank is not None:   # the shard of rank R of N, alone on this GPU: no group, no peers
@@ -1181,6 +1229,15 @@ def main():
             if r3.get('projection') is not None:   # every rank's shard of an N-rank launch alone on this GPU: a projection
                 other[str(cfg)]['projected_scaling_single_gpu'] = r3['projection']
 
+    # the corrected pixels of the whole launch as an exact checksum: every rank's (sum, pixels), gathered in rank order
+    shard_checksum = None
+    if res.get('checksum') is not None:
+        mine_ck = json.dumps(list(res['checksum'])).encode()
+        parts = [json.loads(b.decode()) for b in (dist.gather_bytes(mine_ck) if args.as_rank is None else [mine_ck])]
+        shard_checksum = dict(sum=sum(p[0] for p in parts) & 0xFFFFFFFFFFFFFFFF, pixels=sum(p[1] for p in parts),
+                              per_rank=[dict(sum=p[0], pixels=p[1]) for p in parts],
+                              what='sum of the float32 bit patterns of every corrected pixel the launch produced, modulo 2^64 (hk_debug_checksum_dev)')
+
     if rank == 0:
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
@@ -1217,6 +1274,10 @@ def main():
         if res.get('projection') is not None:
             out['projected_scaling_single_gpu'] = res['projection']
         out['host_placement'] = topology.summary(placement)   # of rank 0; every rank binds to its own GPU's node
+        if placements is not None:
+            out['host_placement_ranks'] = placements             # ... and says so: one record per rank, in rank order
+        if shard_checksum is not None:
+            out['shard_checksum'] = shard_checksum
         if nan_variant is not None:
             out['nodata_nan_variant'] = nan_variant
         if inpaint_variants is not None:
@@ -1234,10 +1295,14 @@ def main():
                 out['rccl_error'] = rccl_error
         print(json.dumps(out), flush=True)
 
-    ctx.close()
+    if not rccl_join_abandoned:
+        ctx.close()
     dist.finalize()
     if first_probe is not None and first_probe['fatal']:
         sys.exit(3)
+    if rccl_join_abandoned:   # a thread is still inside ncclCommInitRank on the context: the line is printed, the run is not green
+        sys.stdout.flush(), sys.stderr.flush()
+        os._exit(4)
 
 
 if __name__ == '__main__':

@@ -72,7 +72,7 @@ _f32p, _f64p, _u64p = _P(C.c_float), _P(C.c_double), _P(C.c_uint64)
 ABI_VERSION = 5   # HK_ABI_VERSION of the include/homonim_hk.h these mirrors were written against
 # entry points declared in include/homonim_hk_devtools.h (measurement / test aids), the rest in include/homonim_hk.h
 DEVTOOLS = ('hk_synth_fill_dev', 'hk_stream_probe_dev', 'hk_debug_stage_stamps', 'hk_r2_certificate_constants', 'hk_debug_staging_counters',
-            'hk_debug_build_ledger')
+            'hk_debug_build_ledger', 'hk_debug_checksum_dev')
 
 SIGNATURES = {
     'hk_abi_version': (C.c_int, []),
@@ -145,6 +145,7 @@ SIGNATURES = {
     'hk_debug_stage_stamps': (C.c_int, [C.c_void_p, _P(C.c_uint64), C.c_int32]),
     'hk_debug_staging_counters': (C.c_int, [_P(C.c_uint64), C.c_int32]),
     'hk_debug_build_ledger': (C.c_int, [C.c_char_p, C.c_size_t, _P(C.c_size_t), C.c_int32]),
+    'hk_debug_checksum_dev': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P(C.c_uint64)]),
 }  # yapf: disable
 
 COMM_ID_BYTES = 128   # HK_COMM_ID_BYTES = sizeof(ncclUniqueId)
@@ -563,6 +564,13 @@ class Context:
     def stream_probe_dev(self, a_dptr: int, b_dptr: int, out_dptr: int, nbytes: int, stream: int = 0):
         """ One launch of the flat 2-read 1-write float4 stream out = a + b over three device buffers (hk_stream_probe_dev). """
         _check(self._lib.hk_stream_probe_dev(self._h, C.c_void_p(a_dptr), C.c_void_p(b_dptr), C.c_void_p(out_dptr), nbytes, stream))
+
+    def checksum_dev(self, plane_dptr: int, stride: int, height: int, width: int, stream: int = 0) -> int:
+        """ Sum of the 32-bit patterns of a height x width window of a device-resident float32 plane, modulo 2^64
+        (hk_debug_checksum_dev: exact and order-free; synchronises the stream). """
+        out = C.c_uint64(0)
+        _check(self._lib.hk_debug_checksum_dev(self._h, C.c_void_p(plane_dptr), stride, height, width, stream, C.byref(out)))
+        return int(out.value)
 
     # -- device-resident helpers (bench / streaming) ------------------------------------------------------------------
     def dev_alloc(self, nbytes: int) -> int:

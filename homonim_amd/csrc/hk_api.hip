@@ -2432,6 +2432,29 @@ int hk_stream_probe_dev(hk_ctx* ctx, const void* a, const void* b, void* out, si
     return HK_OK;
 }
 
+int hk_debug_checksum_dev(hk_ctx* ctx, const float* plane, int64_t stride, int32_t height, int32_t width, int32_t stream,
+                          uint64_t* sum_out) {
+    if (!ctx || !plane || !sum_out) return fail(HK_ERR_ARG, "NULL argument");
+    if (height < 1 || width < 1 || stride < width) return fail(HK_ERR_ARG, "bad window %d x %d, stride %lld", height, width, (long long)stride);
+    if (stream < 0 || stream >= (int)ctx->slots.size()) return fail(HK_ERR_ARG, "bad stream index");
+    HK_ENTER(ctx);
+    DevEnter enter(ctx, stream);
+    Slot& sl = ctx->slots[stream];
+    // the slot's pinned counter word doubles as the device-visible accumulator's landing place
+    unsigned long long* d_acc = nullptr;
+    if (dev_malloc(reinterpret_cast<void**>(&d_acc), sizeof(unsigned long long)) != hipSuccess) return fail(HK_ERR_NOMEM, "hipMalloc(8) failed");
+    hipError_t e = hipMemsetAsync(d_acc, 0, sizeof(unsigned long long), sl.stream);
+    if (e == hipSuccess) e = hk::launch_checksum(plane, stride, height, width, d_acc, sl.stream);
+    unsigned long long host = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(sl.fail_host, d_acc, sizeof(host), hipMemcpyDeviceToHost, sl.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(sl.stream);
+    if (e == hipSuccess) host = *sl.fail_host;
+    (void)dev_free(d_acc);
+    if (e != hipSuccess) return fail(HK_ERR_HIP, "checksum: %s", hipGetErrorString(e));
+    *sum_out = host;
+    return HK_OK;
+}
+
 int hk_event_create(hk_ctx* ctx, hk_event** ev) {
     if (!ctx || !ev) return fail(HK_ERR_ARG, "NULL argument");
     HK_ENTER(ctx);

@@ -359,17 +359,18 @@ __device__ __forceinline__ void hsum_wide(const T (&V)[PX], T (&H)[PX], const Wi
     });
 }
 
-// The float64 quantities of the kernels wider than 15 exchange their partial sums through a wave-private LDS LINE instead of
+// The float64 quantities of the kernels wider than 15 exchange their partial sums through wave-private LDS LINES instead of
 // ds_bpermute (round 6).  A ds_bpermute_b32 moves 4 bytes per lane and occupies the CU's LDS crossbar for 2.6 ns whichever SIMD
 // issued it (profiles/r05_ubench_xlane.txt); at 31 wide a gain-offset wave-row issues ~100 of them = 260 ns of a pipe the CU's
-// four SIMDs share, against ~150 ns of VALU issue: the launch was bound THERE (6.6 ms for 4 x 16384^2), not by its re-loads.  A
-// lane now writes its seven partial sums once -- slot of 64 bytes: [suf1 suf2 | suf3 T | pre1 pre2 | pre3 T], T = the lane's four
-// columns -- with four ds_write_b128 and reads what it needs of its neighbours' slots with ds_read_b64 / ds_read_b128 (16 bytes
-// per lane in 1.85 ns): at 31 wide 4 writes + 8 reads instead of 20 ds_bpermute per quantity.  Same terms, same order of additions
-// as hsum_wide: bit-identical results.  `line` = this lane's slot; the F + 1 guard slots beyond either end of the wave are never
-// written: their readers are overlap lanes whose sums are discarded.
-constexpr size_t WLINE_SLOT = 64;
-inline size_t wline_bytes(int rw) { return (size_t)(WAVE + 2 * (rw / PX + 1)) * WLINE_SLOT; }  // F + 1 guard slots either side
+// four SIMDs share, against ~150 ns of VALU issue.  A lane now writes its seven partial sums -- T = its four columns, suf1..3,
+// pre1..3 -- into seven LINES of one float64 per lane (structure of arrays: consecutive lanes touch consecutive 8-byte words, no
+// bank conflict; a first version with one 64-byte slot per lane ran 16-way conflicts and lost 50 %, profiles/r06_wline.txt) and
+// reads its neighbours' entries with ds_read_b64: at 31 wide 7 writes + 10 reads of 8 bytes instead of 20 ds_bpermute_b32 per
+// quantity.  Same terms, same order of additions as hsum_wide: bit-identical results.  `line` = this lane's entry of line 0; every
+// line has WLINE_G guard entries either side that are never written: their readers are overlap lanes whose sums are discarded.
+constexpr int WLINE_G = 26;                                 // >= F + 1 for every admitted width (overlap lanes <= 24: F <= 24)
+constexpr int WLINE_STRIDE = (WAVE + 2 * WLINE_G) * 8;      // bytes per line
+constexpr size_t WLINE_BYTES = 7 * (size_t)WLINE_STRIDE;    // 6.3 KB per wave
 #ifndef HK_WLINE
 #define HK_WLINE 1
 #endif
@@ -384,11 +385,13 @@ __device__ __forceinline__ void hsum_wide_line(const double (&V)[PX], double (&H
     suf[2] = V[2] + V[3];
     suf[3] = V[1] + suf[2];
     pre[4] = suf[4] = pre[2] + suf[2];
-    hk_d2* const slot = reinterpret_cast<hk_d2*>(line);
-    slot[0] = hk_d2{suf[1], suf[2]};
-    slot[1] = hk_d2{suf[3], suf[4]};
-    slot[2] = hk_d2{pre[1], pre[2]};
-    slot[3] = hk_d2{pre[3], pre[4]};
+    auto at = [&](const char* p, int array) -> double { return *reinterpret_cast<const double*>(p + array * WLINE_STRIDE); };
+    *reinterpret_cast<double*>(line) = pre[4];
+#pragma unroll
+    for (int k = 1; k <= 3; ++k) {
+        *reinterpret_cast<double*>(line + k * WLINE_STRIDE) = suf[k];
+        *reinterpret_cast<double*>(line + (3 + k) * WLINE_STRIDE) = pre[k];
+    }
     xch_order();
     double common = pre[PX];
     if (wl.f >= 2) {  // wave-uniform
@@ -396,41 +399,20 @@ __device__ __forceinline__ void hsum_wide_line(const double (&V)[PX], double (&H
         common = common + dpp_from_right(pre[PX]);
     }
     for (int j = 2; j < wl.f; ++j) {  // wave-uniform: the whole lanes beyond the DPP neighbours
-        common = common + *reinterpret_cast<const double*>(line - j * (int)WLINE_SLOT + 24);
-        common = common + *reinterpret_cast<const double*>(line + j * (int)WLINE_SLOT + 24);
+        common = common + at(line - j * 8, 0);
+        common = common + at(line + j * 8, 0);
     }
     static_for<2, 4>([&](auto J) {
         constexpr int j = decltype(J)::value;
         // the lanes F (j == 2) and F + 1 (j == 3) to the left / right
-        const char* const lb = line - (wl.f + j - 2) * (int)WLINE_SLOT;
-        const char* const rb = line + (wl.f + j - 2) * (int)WLINE_SLOT + 32;
+        const char* const lb = line - (wl.f + j - 2) * 8;
+        const char* const rb = line + (wl.f + j - 2) * 8;
         double ls[PX + 1], rp[PX + 1];
-        constexpr bool L12 = need_left_at(RV, j, 1) || need_left_at(RV, j, 2), L34 = need_left_at(RV, j, 3) || need_left_at(RV, j, 4);
-        constexpr bool R12 = need_right_at(RV, j, 1) || need_right_at(RV, j, 2), R34 = need_right_at(RV, j, 3) || need_right_at(RV, j, 4);
-        if constexpr (L12) {
-            const hk_d2 v = *reinterpret_cast<const hk_d2*>(lb);
-            ls[1] = v.x, ls[2] = v.y;
-        }
-        if constexpr (L34) {
-            if constexpr (need_left_at(RV, j, 3)) {
-                const hk_d2 v = *reinterpret_cast<const hk_d2*>(lb + 16);
-                ls[3] = v.x, ls[4] = v.y;
-            } else {
-                ls[4] = *reinterpret_cast<const double*>(lb + 24);
-            }
-        }
-        if constexpr (R12) {
-            const hk_d2 v = *reinterpret_cast<const hk_d2*>(rb);
-            rp[1] = v.x, rp[2] = v.y;
-        }
-        if constexpr (R34) {
-            if constexpr (need_right_at(RV, j, 3)) {
-                const hk_d2 v = *reinterpret_cast<const hk_d2*>(rb + 16);
-                rp[3] = v.x, rp[4] = v.y;
-            } else {
-                rp[4] = *reinterpret_cast<const double*>(rb + 24);
-            }
-        }
+        static_for<1, PX + 1>([&](auto K) {
+            constexpr int k = decltype(K)::value;
+            if constexpr (need_left_at(RV, j, k)) ls[k] = at(lb, k == PX ? 0 : k);
+            if constexpr (need_right_at(RV, j, k)) rp[k] = at(rb, k == PX ? 0 : 3 + k);
+        });
         if constexpr (lane_full_for_all(RV, j)) {
             common = common + ls[PX];
             common = common + rp[PX];
@@ -454,7 +436,7 @@ __device__ __forceinline__ void hsum_wide_line(const double (&V)[PX], double (&H
         if constexpr (specific_before(RV, i, 4, false, true)) H[i] = common + H[i];
         else H[i] = common;
     });
-    xch_order();  // the next quantity rewrites the line: every read above has been issued (LDS operations of a wave run in order)
+    xch_order();  // the next quantity rewrites the lines: every read above has been issued (LDS operations of a wave run in order)
 }
 
 // RW >= 0: compile-time half-width; RW = -1 - E: wide kernel with rw mod 4 == E (hsum_wide).  DPP2: see hsum.
@@ -947,9 +929,9 @@ fit_apply_kernel(const FitArgs a_in) {
     // (profiles/r05_ab_dpp2_15wide.txt).  Kernels wider than 15 gain nothing from the same exchange (profiles/r05_ab_dpp_chain_wide.txt:
     // at 31 wide the launch moves 2.16 x its algorithmic bytes through the HBM -- the re-loaded leaving rows -- and is bound there).
     constexpr bool DPPX = HK_DPP2 && RW == 7 && MODEL != 1;
-    // (kernels wider than 15: the lane's 64-byte slot of the wave's exchange line, hsum_wide_line; one wave per workgroup there)
+    // (kernels wider than 15: the lane's entry of the wave's first exchange line, hsum_wide_line; one wave per workgroup there)
     [[maybe_unused]] char* const xch = reinterpret_cast<char*>(lds4 + (size_t)WPB * (size_t)(ring_rows * (ring2p ? 2 : 1) * WAVE)) +
-                                       (RW < 0 ? (size_t)(lane + rw / PX + 1) * WLINE_SLOT : (size_t)wave_in_wg * XCH_BYTES + 16 + (size_t)lane * 16);
+                                       (RW < 0 ? (size_t)(lane + WLINE_G) * 8 : (size_t)wave_in_wg * XCH_BYTES + 16 + (size_t)lane * 16);
     const float ring_init = DENSE ? 0.f : __uint_as_float(RING_SENTINEL);
     {
         // four registers the compiler must treat as unrelated: one ds_write_b128 per slot and plane (the vectorised form of this
@@ -1707,7 +1689,7 @@ static hipError_t launch_build(const FitArgs& a, hipStream_t stream) {
     if constexpr (LOCKSTEP) {
         if (lds * HK_WPB_MEM <= 64 * 1024) return launch_wpb<MODEL, R2, RW, DENSE, RING, CERT_ONLY, HK_WPB_MEM>(a, lds, stream);
     }
-    if constexpr (RW < 0) return launch_wpb<MODEL, R2, RW, DENSE, RING, CERT_ONLY, 1>(a, lds + (HK_WLINE ? wline_bytes(a.rw) : 0), stream);
+    if constexpr (RW < 0) return launch_wpb<MODEL, R2, RW, DENSE, RING, CERT_ONLY, 1>(a, lds + (HK_WLINE ? WLINE_BYTES : 0), stream);
     return launch_wpb<MODEL, R2, RW, DENSE, RING, CERT_ONLY, 1>(a, lds + (xch_mask<MODEL, RW, RING, 1>() ? XCH_BYTES : 0), stream);
 }
 

@@ -259,6 +259,9 @@ hipError_t launch_apply_space(const float* src, long long src_stride, int nd_mod
 // flat 2-read 1-write float4 stream (measurement aid: what the HBM gives the fused kernel's byte mix without its stencil)
 hipError_t launch_stream_probe(const void* a, const void* b, void* out, size_t n_bytes, hipStream_t stream);
 
+// sum of the bit patterns of a height x width window of a float32 plane, modulo 2^64, ADDED to *out_dev (test / bench aid)
+hipError_t launch_checksum(const float* plane, long long stride, int height, int width, unsigned long long* out_dev, hipStream_t stream);
+
 // returns 0 on pass; writes a diagnostic code otherwise
 hipError_t launch_selftest(int* result_dev, hipStream_t stream);
 

@@ -215,6 +215,26 @@ hipError_t launch_stream_probe(const void* a, const void* b, void* out, size_t n
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Exact, order-free checksum of a window of a float32 plane: the sum of its pixels' BIT PATTERNS modulo 2^64 (test / bench aid:
+// the union of N ranks' shards against the single-rank result without moving the rasters to the host).
+__global__ void __launch_bounds__(256) checksum_kernel(const unsigned* __restrict__ p, long long stride, int height, int width,
+                                                       unsigned long long* __restrict__ out) {
+    unsigned long long acc = 0ull;
+    for (int y = blockIdx.y; y < height; y += gridDim.y)
+        for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < width; x += gridDim.x * blockDim.x)
+            acc += p[(long long)y * stride + x];
+#pragma unroll
+    for (int d = WAVE / 2; d > 0; d >>= 1) acc += __shfl_xor(acc, d);
+    if ((threadIdx.x & (WAVE - 1)) == 0 && acc) atomicAdd(out, acc);
+}
+
+hipError_t launch_checksum(const float* plane, long long stride, int height, int width, unsigned long long* out_dev, hipStream_t stream) {
+    const int gx = (width + 255) / 256 < 64 ? (width + 255) / 256 : 64, gy = height < 1024 ? height : 1024;
+    HK_LAUNCH(checksum_kernel, dim3(gx, gy), dim3(256), 0, stream, reinterpret_cast<const unsigned*>(plane), stride, height, width, out_dev);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Self-test of the DPP wave shifts + the compile-time horizontal sums against a brute-force definition.
 template <int RW>
 __device__ int hsum_check(int lane) {

@@ -37,8 +37,31 @@ def env_ranks() -> Tuple[int, int, int]:
 
 
 def _launch_token() -> str:
+    """ What names THIS launch among the launches of this user on this node: the launcher's MASTER_PORT / TORCHELASTIC_RUN_ID /
+    HOMONIM_AMD_LAUNCH_ID; a launcher that sets none of them (mpirun, srun: RANK and WORLD_SIZE only) is named by the process that
+    started the ranks -- the ranks of one launch share their parent, two concurrent launches do not. """
     parts = [os.environ.get(k, '') for k in ('MASTER_PORT', 'TORCHELASTIC_RUN_ID', 'HOMONIM_AMD_LAUNCH_ID')]
+    if not any(parts):
+        parts = ['ppid', str(os.getppid())]
     return '_'.join(''.join(c if c.isalnum() else '-' for c in p) for p in parts)
+
+
+def _check_one_node(world: int):
+    """ The rendezvous is loopback TCP + a file of the local temporary directory: ONE node.  A launch that spans nodes is refused at
+    once, with the reason, instead of waiting out the rendezvous timeout (the hot path has no cross-node exchange either: its work
+    items are independent; run one launch per node on a shard of the block list, homonim_amd.fuse.shard). """
+    def env_int(key):
+        try:
+            return int(os.environ[key])
+        except (KeyError, ValueError):
+            return None
+    local_world, nnodes, group_world = env_int('LOCAL_WORLD_SIZE'), env_int('NNODES'), env_int('GROUP_WORLD_SIZE')
+    spans = (local_world is not None and local_world != world) or (nnodes or 1) > 1 or (group_world or 1) > 1
+    if spans:
+        raise RuntimeError(
+            f'homonim_amd.dist: this launch spans nodes (WORLD_SIZE={world}, LOCAL_WORLD_SIZE={local_world}, NNODES={nnodes}, '
+            f'GROUP_WORLD_SIZE={group_world}) -- the ranks of a launch meet over loopback TCP and must share one node; start one '
+            f'launch per node, each on its shard of the work (homonim_amd.fuse.shard)')
 
 
 def _private_dir() -> str:
@@ -93,6 +116,7 @@ def init(backend: Optional[str] = None) -> Tuple[int, int, int]:
         backend = {'gloo': 'host', 'nccl': 'rccl'}.get(backend, backend)
         if backend not in ('host', 'rccl'):
             raise ValueError(f"unknown HOMONIM_AMD_DIST_BACKEND {backend!r}: 'rccl' (one GPU per rank) or 'host'")
+        _check_one_node(world)
         path = os.path.join(_private_dir(), f'rdzv_{_launch_token()}')
         if rank == 0:
             server = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
@@ -168,9 +192,43 @@ def sum_over_ranks(value: float) -> float:
     return _reduce(value, 'SUM')
 
 
+def gather_bytes(payload: bytes) -> List[bytes]:
+    """ every rank's ``payload``, in rank order, on every rank. """
+    out = _exchange(payload, lambda parts: b''.join(struct.pack('<I', len(p)) + p for p in parts))
+    parts, pos = [], 0
+    while pos < len(out):
+        (n,) = struct.unpack('<I', out[pos:pos + 4])
+        parts.append(out[pos + 4:pos + 4 + n])
+        pos += 4 + n
+    return parts
+
+
 def broadcast_bytes(payload: Optional[bytes]) -> bytes:
     """ rank 0's ``payload`` on every rank. """
     return _exchange(payload if (_state['rank'] == 0 and payload is not None) else b'', lambda parts: parts[0])
+
+
+def exchange_comm_id() -> bytes:
+    """ The id of the library's RCCL communicator for this launch, made by rank 0 (``hk_comm_unique_id``) and handed to every rank
+    over the launch's sockets -- ON THE CALLING THREAD: the sockets carry one conversation at a time.  What may block without a
+    deadline is ``Context.comm_init(uid, rank, world)`` (ncclCommInitRank returns when every rank has joined); a caller that wants
+    a deadline runs only that on a side thread (bench.py). """
+    from homonim_amd import _hk
+    rank, world, _ = env_ranks()
+    if not _state['initialised']:
+        if world == 1:
+            return _hk.comm_unique_id()
+        raise RuntimeError('exchange_comm_id needs the ranks to have met (dist.init)')
+    payload = None
+    if rank == 0:   # a rank 0 that cannot make the id (no librccl) tells the others instead of leaving them in the exchange
+        try:
+            payload = b'\x01' + _hk.comm_unique_id()
+        except Exception as ex:
+            payload = b'\x00' + f'{type(ex).__name__}: {ex}'.encode()
+    blob = broadcast_bytes(payload)
+    if blob[:1] != b'\x01':
+        raise RuntimeError('rank 0 could not make the RCCL communicator id: ' + blob[1:].decode(errors='replace'))
+    return blob[1:]
 
 
 def init_comm(ctx, id_file: Optional[str] = None) -> Tuple[int, int]:
@@ -184,16 +242,7 @@ def init_comm(ctx, id_file: Optional[str] = None) -> Tuple[int, int]:
     rank, world, _ = env_ranks()
     id_file = id_file or os.environ.get('HOMONIM_AMD_COMM_FILE')
     if _state['initialised'] and id_file is None:
-        payload = None
-        if rank == 0:   # a rank 0 that cannot make the id (no librccl) tells the others instead of leaving them in the exchange
-            try:
-                payload = b'\x01' + _hk.comm_unique_id()
-            except Exception as ex:
-                payload = b'\x00' + f'{type(ex).__name__}: {ex}'.encode()
-        blob = broadcast_bytes(payload)
-        if blob[:1] != b'\x01':
-            raise RuntimeError('rank 0 could not make the RCCL communicator id: ' + blob[1:].decode(errors='replace'))
-        uid = blob[1:]
+        uid = exchange_comm_id()
     elif world == 1 and id_file is None:
         uid = _hk.comm_unique_id()
     else:

@@ -140,6 +140,19 @@ _device_cpus: Dict[int, List[int]] = {}
 _thread_device = None   # threading.local, made on first use
 
 
+def _process_baseline() -> Optional[List[int]]:
+    """ The CPUs the launcher / container allows this PROCESS, read from the main thread (thread-group leader) -- not from the calling
+    thread, which an earlier bind_current_thread() may have narrowed to another GPU's node -- and captured when this module is first
+    imported, i.e. before any binding of its own (bind_to_device narrows the main thread too). """
+    try:
+        return sorted(os.sched_getaffinity(os.getpid()))
+    except (AttributeError, OSError):
+        return None
+
+
+_BASELINE = _process_baseline()
+
+
 def bind_current_thread(device: int, sysfs_root: str = '/sys') -> bool:
     """ Run the CALLING thread on the cores next to HIP device `device` (one process driving several GPUs: RasterFuse with a device
     list deals its blocks to worker threads; the thread that packs a block into a GPU's pinned staging ring should run on that GPU's
@@ -155,16 +168,15 @@ def bind_current_thread(device: int, sysfs_root: str = '/sys') -> bool:
         return True
     cpus = _device_cpus.get(device)
     if cpus is None:
+        # `allowed` = the process's baseline, not this thread's current affinity: a pool worker already bound to GPU A's node
+        # that is the first to ask for GPU B would otherwise find no allowed CPU on B's node (round-5 advisor finding)
         try:
             from homonim_amd import _hk
-            try:
-                allowed = sorted(os.sched_getaffinity(0))
-            except (AttributeError, OSError):
-                allowed = None
-            cpus = placement_for(_hk.device_pci_bus_id(device), sysfs_root, allowed)['cpus']
+            cpus = placement_for(_hk.device_pci_bus_id(device), sysfs_root, _BASELINE)['cpus']
         except Exception:
             cpus = []
-        _device_cpus[device] = cpus
+        if cpus:   # an empty answer is not remembered: the next block asks again
+            _device_cpus[device] = cpus
     if not cpus:
         return False
     try:

@@ -58,6 +58,13 @@ int hk_debug_stage_stamps(hk_ctx* ctx, uint64_t out[16], int32_t reset);
  * the pinned staging ring. */
 int hk_debug_staging_counters(uint64_t out[2], int32_t reset);
 
+/* Test / bench aid: the exact, order-free checksum of a height x width window of a device-resident float32 plane (rows `stride`
+ * elements apart): the sum of the pixels' 32-bit patterns modulo 2^64.  The union of N ranks' shards of a raster is compared with
+ * the single-rank result through it (bench.py `shard_checksum`) without moving the rasters to the host.  Queued on pooled stream
+ * `stream`, which is synchronised before the call returns. */
+int hk_debug_checksum_dev(hk_ctx* ctx, const float* plane, int64_t stride, int32_t height, int32_t width, int32_t stream,
+                          uint64_t* sum_out);
+
 /* Test aid: the launch ledger.  Every kernel BUILD of the library -- each instantiation of the fused kernel's template
  * ("fit_apply_kernel<MODEL,R2,RW,DENSE,RING,CERT_ONLY,WPB,BATCH>"), each kernel of the statistics / in-painting / re-sampling /
  * mask / conversion / comparison units (one record per launch site, named after the kernel) -- is on a process-wide list from the

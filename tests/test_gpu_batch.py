@@ -389,9 +389,11 @@ def test_tiles_of_gain_offset_in_one_launch_equal_one_launch_per_tile(ctx, nodat
                         k += j.n_bands
                     ctx.stream_sync(jobs[0].stream)
                 ctx.memset(fail, 0, 8 * total_bands)
-            strip = lambda c: c & np.uint64((1 << 63) - 1)   # noqa: E731  (the re-run bit may differ between the two histories)
-            if rnd == 1 and thresh is not None:
-                assert np.array_equal(strip(counts[0]), strip(counts[1])) or True
+            if thresh is not None:
+                # a band's count is void where its history asked for the re-run (HK_COUNT_RETRY: certificate-only build); wherever
+                # BOTH histories counted, they counted the same pixels
+                both = ((counts[0] | counts[1]) >> np.uint64(63)) == 0
+                assert np.array_equal(counts[0][both], counts[1][both]), (rnd, counts)
             for d, B, h, w, stride in rasters:
                 a, b = np.empty((B, h, stride), np.float32), np.empty((B, h, stride), np.float32)
                 ctx.d2h(a, d['corr_a']), ctx.d2h(b, d['corr_b'])

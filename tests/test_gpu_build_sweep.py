@@ -138,10 +138,14 @@ def test_general_builds_on_rasters_without_nodata_vs_oracle(ctx, oc, model, find
 
 
 @pytest.mark.oracle
-@pytest.mark.parametrize('nodata_variant', [0, 1])
-def test_batched_builds_of_every_width_vs_oracle(oc, nodata_variant):
+@pytest.mark.parametrize('nodata_variant, ring', [(0, None), (1, None), (1, '1')])
+def test_batched_builds_of_every_width_vs_oracle(oc, nodata_variant, ring, monkeypatch):
     """ hk_fit_apply_batch_dev: the job-table builds (gain-blk-offset without R2, the block loop of a resident mosaic) of every kernel
-    width and ring mode the policy gives them, two jobs of different shapes per launch, every job against the oracle. """
+    width and ring mode the policy gives them -- and, forced (HK_USE_RING=1), the full ring on kernels up to 15 wide, four strips per
+    workgroup while the LDS holds them (5 rows) and one beyond (11 rows) --, two jobs of different shapes per launch, every job
+    against the oracle. """
+    if ring is not None:
+        monkeypatch.setenv('HK_USE_RING', ring)
     ctx = _hk.Context(0, n_streams=2)
     B = 2
     shapes = [(H, W), (H - 7, W - 36)]
@@ -158,7 +162,7 @@ def test_batched_builds_of_every_width_vs_oracle(oc, nodata_variant):
             s, r = np.empty((B, H, stride), np.float32), np.empty((B, H, stride), np.float32)
             ctx.d2h(s, bufs[j]['src']), ctx.d2h(r, bufs[j]['ref'])
             host.append((s, r))
-        for kh in (1, 5, 7, 9, 11, 15, 17, 41):
+        for kh in ((1, 5, 7, 9, 11, 15, 17, 41) if ring is None else (5, 11)):
             for kw in WIDTHS:
                 desc = _hk.make_desc('gain-blk-offset', (kh, kw), False, None, nd, nd)
                 jobs = []

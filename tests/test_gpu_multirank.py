@@ -197,3 +197,69 @@ def test_rank_binds_to_the_numa_node_of_its_gpu():
                 os.sched_setaffinity(int(tid), before)
             except OSError:
                 pass
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# round 6: the 8-rank dress rehearsal.  No 8-GPU node has been available to this project; the first scaling run will be a one-shot on a
+# machine nobody has touched.  Eight processes sharing this box's GPU (backend 'host') run everything of that launch but RCCL and a
+# second HBM stack: eight contexts, eight pinned rings, eight NUMA bindings, the rendezvous, the shard lists, the one JSON line.
+# (homonim/fuse.py:394-408: the pool the ranks replace; raster_pair.py:379-428: the work items they split.)
+def _bench(n, launcher, args, extra_env=None, timeout=900):
+    import json
+    import time
+    env = dict(os.environ, HOMONIM_AMD_DIST_BACKEND='host', PYTHONPATH=REPO, **(extra_env or {}))
+    for key in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR', 'LOCAL_WORLD_SIZE', 'GROUP_WORLD_SIZE'):
+        env.pop(key, None)
+    common = ['--gpus', str(n), '--no-cpu-baseline', '--no-end-to-end', '--no-nan-variant', '--no-other-configs', '--no-power-probe',
+              '--no-projection', '--checksum'] + args
+    if launcher == 'torchrun' and n > 1:   # the driver's launch
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+               '--master-port', str(29100 + (os.getpid() + 7 * n + len(args)) % 400), os.path.join(REPO, 'bench.py')] + common
+        env['MASTER_ADDR'] = '127.0.0.1'
+    else:                                   # plain: bench.py starts its own ranks
+        cmd = [sys.executable, os.path.join(REPO, 'bench.py')] + common
+    t0 = time.time()
+    run = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    lines = [ln for ln in run.stdout.strip().splitlines() if ln.startswith('{')]
+    return run, [json.loads(ln) for ln in lines], time.time() - t0
+
+
+@pytest.mark.parametrize('config, launcher', [(1, 'plain'), (2, 'torchrun'), (3, 'torchrun'), (4, 'plain')])
+def test_eight_ranks_dress_rehearsal(config, launcher):
+    """ `bench.py --gpus 8` at the BASELINE sizes, both ways it can be launched: configs 1 / 2 hold one full raster per rank (8 x 12.9 GB
+    of this GPU's 288 for config 2), configs 3 / 4 split the real lists (the reference's 128 blocks of 8 x 16384^2; 64 tiles of
+    4 x 4096^2).  One JSON line from rank 0, n_gpus 8, parity spot check green, every rank's host placement in the line -- and the
+    UNION of the eight shards is the single-rank result: exact checksum and pixel count of every corrected pixel (configs 3 / 4: the
+    totals; configs 1 / 2: rank 0's raster, the ranks' rasters differ by their seed). """
+    args = ['--config', str(config), '--steps', '2', '--warmup', '1']
+    run, lines, _ = _bench(8, launcher, args)
+    assert run.returncode == 0, run.stderr[-3000:]
+    assert len(lines) == 1, run.stdout[-2000:]
+    line = lines[0]
+    assert line['n_gpus'] == 8 and line['value'] > 0 and line['dist_backend'] == 'host'
+    assert line['parity_spot_check']['passed']
+    assert line['scaling'] == ('weak' if config in (1, 2) else 'strong')
+    ranks = line['host_placement_ranks']
+    assert len(ranks) == 8 and all(r['bus_id'] == ranks[0]['bus_id'] for r in ranks)      # (one GPU here; eight on the node)
+    ck = line['shard_checksum']
+    assert len(ck['per_rank']) == 8 and all(p['pixels'] > 0 for p in ck['per_rank'])
+    solo_run, solo_lines, _ = _bench(1, 'plain', args)
+    assert solo_run.returncode == 0, solo_run.stderr[-3000:]
+    solo = solo_lines[-1]['shard_checksum']
+    if config in (1, 2):
+        assert ck['per_rank'][0] == solo['per_rank'][0]
+        assert ck['pixels'] == 8 * solo['pixels']
+    else:
+        assert ck['pixels'] == solo['pixels'] and ck['sum'] == solo['sum'], 'the union of the eight shards is not the single-rank result'
+
+
+@pytest.mark.parametrize('launcher', ['plain', 'torchrun'])
+def test_a_rank_that_dies_ends_the_launch(launcher):
+    """ A rank that dies mid-run (HK_BENCH_DIE_RANK: gone without a word once the ranks have met) must end the whole launch with a
+    non-zero exit code within seconds -- its peers see the closed socket at their next exchange -- not leave seven processes in a
+    barrier until the 900 s rendezvous timeout. """
+    run, lines, seconds = _bench(8, launcher, ['--config', '1', '--steps', '2', '--warmup', '1'], extra_env={'HK_BENCH_DIE_RANK': '5'},
+                                 timeout=300)
+    assert run.returncode != 0, (run.stdout[-1000:], run.stderr[-2000:])
+    assert seconds < 150, f'the launch took {seconds:.0f} s to notice a dead rank'
+    assert 'HK_BENCH_DIE_RANK' in run.stderr

@@ -308,7 +308,7 @@ def test_fused_refspace_pipeline_vs_the_oracle_step_by_step(pair, model, kernel_
         ds = onp.reproject(s, src_nodata, down, r.shape, dst_nodata=np.nan, resampling='average')
         norm = onp.fit_block_norm(ds, np.nan, r, None) if model == 'gain-blk-offset' else None
         params, _ = onp.fit(model, ds, np.nan, r, None, kernel_shape, False, None, norm_model=norm)
-        p_us = onp.reproject(params[:2], np.nan, up, s.shape, dst_nodata=np.nan, resampling=upsampling)
+        p_us = np.stack([onp.reproject(params[b], np.nan, up, s.shape, dst_nodata=np.nan, resampling=upsampling) for b in range(2)])
         valid = onp.mask_of(s, src_nodata)
         if mask_partial:
             cover = onp.reproject(valid.astype(np.float32), None, down, r.shape, dst_nodata=None, resampling='average')
