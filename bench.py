@@ -61,7 +61,7 @@ def parse_args():
     p.add_argument('--batches', type=int, default=None,
                    help='configs 3 / 4: the jobs of a step in this many batched launches, one stream each (0 = one launch per job; '
                         'default 4 for config 3: -4 %%, 0 for config 4: no difference, profiles/r03_batch.txt)')
-    p.add_argument('--nodata', type=int, default=0, help='0: no nodata, 1: NaN frame + 0.1%% holes, 2: NaN frame only, 3 / 4: no nodata, noisy reference (35 %% / 85 %% of the pixels fail the r2 mask), 5: low-entropy data (64 source levels, exactly affine reference; the same instruction stream at a lower energy per launch)')
+    p.add_argument('--nodata', type=int, default=0, help='0: no nodata, 1: NaN frame + 0.1%% holes, 2: NaN frame only, 3 / 4: no nodata, noisy reference (35 %% / 85 %% of the pixels fail the r2 mask), 5: low-entropy data (64 source levels, exactly affine reference; the same instruction stream at a lower energy per launch), 6: NaN frame + ~1 %% of the area in round NaN blobs 32 - 128 px across, src and ref independently (cloud / shadow-mask-like)')
     p.add_argument('--no-thresh', action='store_true', help='gain-offset without r2_inpaint_thresh (no R2 work)')
     p.add_argument('--params', action='store_true', help='also materialise the gain / offset / R2 planes in the fused launch (find_r2=True; 24 B per pixel*band of HBM traffic, reported against the same 12 algorithmic bytes)')
     p.add_argument('--no-cpu-baseline', action='store_true')
@@ -273,7 +273,7 @@ def spot_check(ctx, model, k, thresh, nodata_variant, d_src, d_ref, d_corr, stri
     for name, ptr in (('src', d_src), ('ref', d_ref), ('corr', d_corr)):
         ctx.d2h(rows, ptr + 4 * (band * band_stride + y0 * stride))
         win[name] = rows[:, x0:x0 + ww].copy()
-    nodata = np.nan if nodata_variant in (1, 2) else None
+    nodata = np.nan if nodata_variant in (1, 2, 6) else None
     params, _ = onp.fit(model, win['src'], nodata, win['ref'], nodata, (k, k), False, thresh, norm_model=norm)
     exp = onp.apply(win['src'], params)
     # windows of interior pixels see the same data as on the GPU; drop the r-px rim of the downloaded window (plus the
@@ -409,7 +409,7 @@ def run_resident(args, ctx, dist, rank, world):
     band_stride = stride * H
     plane_bytes = 4 * band_stride * B
     thresh = 0.25 if (args.model == 'gain-offset' and not args.no_thresh) else None
-    nd = np.nan if args.nodata in (1, 2) else None
+    nd = np.nan if args.nodata in (1, 2, 6) else None
     desc = _hk.make_desc(args.model, (k, k), bool(args.params), thresh, nd, nd)
 
     # HK_BENCH_SKEW (bytes, a multiple of 16): plane i starts i * skew bytes into its allocation, so the six streams of a
@@ -453,10 +453,12 @@ def run_resident(args, ctx, dist, rank, world):
     fail_dev = [bufs['fail'], bufs['fail2']]
     fail_host = [ctx.pinned_empty((B,), np.uint64) for _ in range(2)]
     fail_ready = [ctx.event(), ctx.event()]
-    # ... and two scratch buffers (hk_dev_job.scratch): when failures are expected the launch leaves the in-painting's inputs
-    # (offsets + source flags) there, so the in-painting of step i does not run the fit again for them
+    # ... and, where pixels are EXPECTED to fail the r2 mask (the noisy-reference variants --nodata 3 / 4; real imagery), two scratch
+    # buffers (hk_dev_job.scratch): a job that carries scratch gets the in-painting's inputs (offsets + source flags, 5 bytes per
+    # pixel of stores) left there by its fit, so the in-painting of step i does not run the fit again for them.  The clean workloads
+    # carry none: their fit is the certificate build + list launch and moves the 12 algorithmic bytes.
     scratch = [None, None]
-    if thresh is not None and not os.environ.get('HK_BENCH_NO_SCRATCH'):
+    if thresh is not None and args.nodata in (3, 4):
         job.scratch_bytes = ctx.job_scratch_bytes(job)
         scratch = [ctx.dev_alloc(job.scratch_bytes) for _ in range(2)]
         bufs['scratch0'], bufs['scratch1'] = scratch
@@ -602,7 +604,7 @@ def run_blocks(args, ctx, dist, rank, world):
             raise SystemExit(f'block origin {win_in.col_off} is not 16-byte aligned: kernel {k}x{k} needs a halo that is a multiple of 4')
     stride = (W + 63) // 64 * 64 + int(os.environ.get('HK_BENCH_ROW_PAD', '0'))   # experiment: rows not a power of two apart
     band_stride = stride * H
-    nd = np.nan if args.nodata in (1, 2) else None
+    nd = np.nan if args.nodata in (1, 2, 6) else None
     desc = _hk.make_desc(args.model, (k, k), False, None, nd, nd)
     bufs = {name: ctx.dev_alloc(4 * band_stride * B) for name in ('src', 'ref', 'corr')}
     bufs['norm'] = ctx.dev_alloc(16 * B * max(1, len(mine)))
@@ -752,7 +754,7 @@ def end_to_end_blocks(args, ctx, dist, bufs, nb, b0, stride, band_stride):
         return dict(skipped='no band for this rank')
     ctx.d2h(src, bufs['src'] + 4 * band_stride * b0)
     ctx.d2h(ref, bufs['ref'] + 4 * band_stride * b0)
-    nd = np.nan if args.nodata in (1, 2) else None
+    nd = np.nan if args.nodata in (1, 2, 6) else None
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
         rf = RasterFuse(src[:, :, :W], ref[:, :, :W], src_nodata=nd, ref_nodata=nd)
@@ -781,7 +783,7 @@ def run_tiles(args, ctx, dist, rank, world):
     n = args.size
     B, k, T = args.bands, args.kernel, args.tiles
     thresh = 0.25 if (args.model == 'gain-offset' and not args.no_thresh) else None
-    nd = np.nan if args.nodata in (1, 2) else None
+    nd = np.nan if args.nodata in (1, 2, 6) else None
     desc = _hk.make_desc(args.model, (k, k), False, thresh, nd, nd)
     mine = shard(list(range(T)), rank, world, contiguous=True)
     stride = (n + 63) // 64 * 64 + int(os.environ.get('HK_BENCH_ROW_PAD', '0'))
@@ -808,7 +810,7 @@ def run_tiles(args, ctx, dist, rank, world):
         # the GPU to itself (half the priming rows, half the waves): 128 rows 12.4 ms per step against 13.4 at the library's 64
         # (profiles/r03_c4_segrows.txt; alone, a tile's launch takes 0.300 ms at 64 rows and 0.335 at 128)
         job.seg_rows, job.stream = (args.seg_rows or (128 if k <= 5 else 0)), j % n_streams
-        if thresh is not None:  # the in-painting's inputs stay with the tile until its counters have been looked at
+        if thresh is not None and args.nodata in (3, 4):  # failures expected: the in-painting's inputs stay with the tile until its counters have been looked at
             job.scratch_bytes = ctx.job_scratch_bytes(job)
             d['scratch'] = ctx.dev_alloc(job.scratch_bytes)
             job.scratch = d['scratch']
@@ -1156,21 +1158,28 @@ def main():
     # Through RasterFuse every raster has nodata = nan (raster_array.py:172-188), i.e. the product path runs the GENERAL
     # kernels; `value` is quoted on BASELINE.json's plain synthetic rasters.  The default run therefore adds a second,
     # shorter measurement of the same configuration on rasters with a NaN frame (reported beside, never as `value`).
-    nan_variant = None
+    nan_variant = blob_variant = None
     if args.config == 2 and args.nodata == 0 and world == 1 and not args.no_nan_variant and not args.params:
         import copy
-        a2 = copy.copy(args)
-        a2.nodata, a2.steps, a2.warmup, a2.power_probe = 2, min(args.steps, 20), 3, False
-        r2_ = run_resident(a2, ctx, dist, rank, world)
-        rl2 = r2_['roofline']
-        nan_variant = {
-            'workload': 'the same rasters with a 3-pixel NaN frame, src / ref nodata = nan (general kernels: the RasterFuse path)',
-            'value': round(r2_['value'], 1), 'steps': a2.steps, 'ms_per_step': round(r2_['elapsed'] / a2.steps * 1e3, 4),
-            'avg_launch_ms': round(rl2['avg_launch_ms'], 4),
-            'frac': round(rl2['achieved_bytes'] / (rl2['avg_launch_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-            'frac_of_copy': round(rl2['achieved_bytes'] / (rl2['avg_launch_ms'] * 1e-3) / 1e9 / rl2['copy_gbps'], 4) if rl2.get('copy_gbps') else None,
-            'parity_spot_check': r2_['parity'],
-        }
+
+        def variant(nd, workload):
+            a2 = copy.copy(args)
+            a2.nodata, a2.steps, a2.warmup, a2.power_probe = nd, min(args.steps, 20), 3, False
+            r2_ = run_resident(a2, ctx, dist, rank, world)
+            rl2 = r2_['roofline']
+            return {
+                'workload': workload,
+                'value': round(r2_['value'], 1), 'steps': a2.steps, 'ms_per_step': round(r2_['elapsed'] / a2.steps * 1e3, 4),
+                'avg_launch_ms': round(rl2['avg_launch_ms'], 4),
+                'frac': round(rl2['achieved_bytes'] / (rl2['avg_launch_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                'frac_of_copy': round(rl2['achieved_bytes'] / (rl2['avg_launch_ms'] * 1e-3) / 1e9 / rl2['copy_gbps'], 4) if rl2.get('copy_gbps') else None,
+                'parity_spot_check': r2_['parity'],
+            }
+        nan_variant = variant(2, 'the same rasters with a 3-pixel NaN frame, src / ref nodata = nan (general kernels: the RasterFuse path)')
+        # ... and what real nodata costs: the frame + ~1 % of the area in round holes 32 - 128 pixels across, source and reference
+        # independently (cloud / shadow masks; raster_array.py:298-308, utils.py:54-56)
+        blob_variant = variant(6, 'the same rasters with a 3-pixel NaN frame and ~1 % of the area in round NaN holes 32 - 128 px across '
+                                  '(src and ref independently), src / ref nodata = nan')
 
     # The in-painting branch of the gain-offset model (kernel_model.py:361-371; r2_inpaint_thresh = 0.25 is the model's default)
     # on rasters whose reference is noisy: 35 % / 94 % of the pixels fail the r2 mask (--nodata 3 / 4).  Reported beside, never as `value`.
@@ -1280,6 +1289,8 @@ def main():
             out['shard_checksum'] = shard_checksum
         if nan_variant is not None:
             out['nodata_nan_variant'] = nan_variant
+        if blob_variant is not None:
+            out['nodata_clustered_holes_variant'] = blob_variant
         if inpaint_variants is not None:
             out['inpainting_variants'] = inpaint_variants
         if other is not None:

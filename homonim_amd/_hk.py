@@ -69,7 +69,7 @@ _P = C.POINTER
 _f32p, _f64p, _u64p = _P(C.c_float), _P(C.c_double), _P(C.c_uint64)
 
 # name -> (restype, argtypes); kept in one table so tests can check every symbol of the header is exported
-ABI_VERSION = 5   # HK_ABI_VERSION of the include/homonim_hk.h these mirrors were written against
+ABI_VERSION = 6   # HK_ABI_VERSION of the include/homonim_hk.h these mirrors were written against
 # entry points declared in include/homonim_hk_devtools.h (measurement / test aids), the rest in include/homonim_hk.h
 DEVTOOLS = ('hk_synth_fill_dev', 'hk_stream_probe_dev', 'hk_debug_stage_stamps', 'hk_r2_certificate_constants', 'hk_debug_staging_counters',
             'hk_debug_build_ledger', 'hk_debug_checksum_dev')

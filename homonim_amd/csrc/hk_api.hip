@@ -286,6 +286,9 @@ struct Slot {
     size_t tbl_bytes[TBL_RING] = {0, 0, 0, 0};
     hipEvent_t tbl_ev[TBL_RING] = {nullptr, nullptr, nullptr, nullptr};
     int tbl_next = 0;
+    // gain-offset with the r2 mask: the wave-rows the certificate build leaves to the list launch (FitArgs::open_rows), one bit each
+    unsigned* open_rows = nullptr;
+    size_t open_rows_words = 0;
     bool direct_pending = false;  // copies queued straight from / to page-locked CALLER arrays since the last stream synchronisation
     bool busy = false;         // leased by a host-pointer call (SlotLease)
     int dev_inflight = 0;      // device-job entry points currently queuing on this stream (DevEnter): a lease waits for them
@@ -302,37 +305,13 @@ struct hk_ctx {
     std::mutex mu;
     std::condition_variable cv;
     int xcd_remap = 0;
-    // the last gain-offset call with a threshold found pixels failing the r2 mask: real imagery usually does, block after
-    // block, so the next call materialises the parameters in its first pass instead of re-running it for the in-painting
-    // (device-job calls: the library sees the failure counts only when hk_inpaint_dev* is called, and a caller whose counts are all
-    // zero never calls it -- so there the expectation is a COUNT of launches it still covers, re-armed by every in-painting call that
-    // found failing pixels: EXPECT_DEV_LAUNCHES launches after the last such call the certificate-only build is tried again)
+    // the last HOST-POINTER gain-offset call with a threshold found pixels failing the r2 mask: real imagery usually does, block
+    // after block, so the next call lets its first pass leave what the in-painting reads (offsets + source flags, 5 bytes per
+    // pixel of stores) instead of running it again when the count comes back non-zero.  Either choice gives the same results.
+    // (Rounds 3-5 also chose the kernel BUILD by it -- certificate-only or complete -- with a back-off and, on the device-job
+    // path, an expiry count; since round 6 the certificate build always runs first and hands the wave-rows it cannot settle to
+    // a list launch, and a device-resident job says by carrying `scratch` that it wants the in-painting's inputs left there.)
     std::atomic<int> expect_r2_failures{0};
-    static constexpr int EXPECT_DEV_LAUNCHES = 8;
-    bool expecting_failures_dev() {  // one device-job launch of gain-offset with a threshold asks
-        int e = expect_r2_failures.load(std::memory_order_relaxed);
-        while (e > 0)
-            if (expect_r2_failures.compare_exchange_weak(e, e - 1, std::memory_order_relaxed)) return true;
-        return false;
-    }
-    // certificate-only build of the gain-offset kernel (hk_fit_kernel.h launch_one): tried first unless it recently had to
-    // be re-run; every re-run doubles the number of eligible launches that go straight to the full build (<= 1024)
-    std::atomic<int> cert_skip{0}, cert_penalty{1};
-
-    bool try_cert_only() {
-        if (cert_disabled) return false;
-        int s = cert_skip.load(std::memory_order_relaxed);
-        while (s > 0)
-            if (cert_skip.compare_exchange_weak(s, s - 1, std::memory_order_relaxed)) return false;
-        return true;
-    }
-    void cert_only_settled() { cert_penalty.store(1, std::memory_order_relaxed); }
-    void cert_only_retried() {
-        const int p = std::min(cert_penalty.load(std::memory_order_relaxed) * 2, 1024);
-        cert_penalty.store(p, std::memory_order_relaxed);
-        cert_skip.store(p, std::memory_order_relaxed);
-    }
-    bool cert_disabled = false;  // HK_CERT_ONLY=0 in the environment (A/B measurements)
     // RCCL communicator of the one data-path collective (hk_comm_init; the split-block statistics)
     ncclComm_t comm = nullptr;
     int comm_rank = 0, comm_world = 0;
@@ -729,6 +708,7 @@ void slot_release(Slot& s) {
     if (s.norm_ws) (void)dev_free(s.norm_ws);
     if (s.aux) (void)dev_free(s.aux);
     if (s.comm_xchg) (void)dev_free(s.comm_xchg);
+    if (s.open_rows) (void)dev_free(s.open_rows);
     if (s.fail_host) (void)hipHostFree(s.fail_host);
     if (s.stage) (void)hipHostFree(s.stage);
     for (int i = 0; i < Slot::STAGE_N; ++i)
@@ -949,11 +929,54 @@ static int ensure_inpaint_scratch(Slot& sl, size_t plane, int height, long long 
     return HK_OK;
 }
 
-// The certificate-only build applies to gain-offset with the r2 mask when no R2 plane is asked for and the failures are
-// counted (the counter carries the re-run bit).
+// gain-offset with the r2 mask when nothing but the corrected block (and, from scratch, the offsets) is asked for and the failures
+// are counted: the CERTIFICATE build runs first (124 - 126 registers, four waves per SIMD: the division-free float32 certificate of
+// PROOFS.md appendix A settles a wave-row whose every valid pixel certainly passes) and marks the wave-rows it cannot settle in
+// a bit plane; the LIST launch -- the complete build on a persistent grid, one run of marked rows per wave at a time -- follows on
+// the same stream and does those rows with the reference's own R2 expression.  Together they write every row once and count every
+// failing pixel once; an empty bit plane (clean rasters) costs the list launch a few microseconds.  Rounds 3 - 5 instead voided the
+// whole band on the first open wave-row (HK_COUNT_RETRY in its counter), ran it again with the complete build and remembered, with
+// a back-off and an expiry count, which build to start the next launches with.  (The certificate has builds for the full and the
+// centre ring, its constants assume window counts below 2^16, and the in-painting's source flags do not fit its registers: other
+// shapes, R2 / gain output and launches that leave the in-painting's inputs run the complete build over the whole grid.)
 static_assert(HK_COUNT_RETRY == hk::FIT_RETRY_BIT, "public and kernel-side re-run bits differ");
-static bool cert_only_eligible(const hk::FitArgs& a, const hk_fit_desc* desc) {
-    return desc->model == HK_MODEL_GAIN_OFFSET && a.has_thresh && a.fail_count && !a.r2 && !a.offset_in && !a.flag;
+static bool cert_list_eligible(const hk::FitArgs& a, const hk_fit_desc* desc) {
+    return desc->model == HK_MODEL_GAIN_OFFSET && a.has_thresh && a.fail_count && !a.r2 && !a.gain && !a.flag && !a.offset_in &&
+           !a.jobs && (a.use_ring == 1 || a.use_ring == 2) && (long long)desc->kh * desc->kw <= 65535;
+}
+
+static int ensure_open_rows(hk_ctx* ctx, Slot& sl, size_t words) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (sl.open_rows && sl.open_rows_words >= words) return HK_OK;
+    if (sl.open_rows) {
+        HK_HIP(hipStreamSynchronize(sl.stream));
+        HK_HIP(dev_free(sl.open_rows));
+        sl.open_rows = nullptr, sl.open_rows_words = 0;
+    }
+    void* p = nullptr;
+    if (dev_malloc(&p, words * sizeof(unsigned)) != hipSuccess) return fail(HK_ERR_NOMEM, "hipMalloc(%zu) failed", words * sizeof(unsigned));
+    sl.open_rows = static_cast<unsigned*>(p), sl.open_rows_words = words;
+    return HK_OK;
+}
+
+// the fused launch of one job (fill_args + fill_grid done): certificate build + list launch where they apply, the one build otherwise
+static int launch_fit(hk_ctx* ctx, Slot& sl, hk::FitArgs& a, const hk_fit_desc* desc, bool r2) {
+    a.cert_only = 0, a.open_rows = nullptr, a.list_mode = 0;
+    if (!cert_list_eligible(a, desc)) {
+        HK_HIP(hk::launch_fit_apply(a, desc->model, r2, sl.stream));
+        return HK_OK;
+    }
+    const size_t words = (size_t)a.n_bands * (size_t)a.n_strips * (size_t)((a.height + 31) / 32);
+    const int rc = ensure_open_rows(ctx, sl, words);
+    if (rc) return rc;
+    hk::FitArgs c = a;
+    c.open_rows = sl.open_rows;
+    HK_HIP(hipMemsetAsync(c.open_rows, 0, words * sizeof(unsigned), sl.stream));
+    c.cert_only = 1;
+    HK_HIP(hk::launch_fit_apply(c, desc->model, r2, sl.stream));
+    c.cert_only = 0, c.list_mode = 1;
+    HK_HIP(hk::launch_fit_apply(c, desc->model, r2, sl.stream));
+    return HK_OK;
 }
 
 // `n_fail`: the band's r2-mask failure count.  `pre_offset` / `pre_flag` (both or neither): offsets and source flags (r2 > thresh) & (gain > 0) & valid left by the pass
@@ -980,7 +1003,7 @@ static int inpaint_band(Slot& sl, const hk::FitArgs& a, const hk_fit_desc* desc,
         hk::FitArgs b = a;
         b.gain = nullptr, b.r2 = nullptr, b.offset = scratch_off, b.corr = nullptr, b.fail_count = nullptr;
         b.flag = hk::inpaint_flag_plane(aux + plane, a.height, a.stride);
-        b.cert_only = 0;
+        b.cert_only = 0, b.open_rows = nullptr, b.list_mode = 0;
         HK_HIP(hk::launch_fit_apply(b, desc->model, r2, stream));
         po = scratch_off, flags = b.flag;
     }
@@ -997,7 +1020,7 @@ static int inpaint_band(Slot& sl, const hk::FitArgs& a, const hk_fit_desc* desc,
     c.fail_count = nullptr;  // already counted
     c.flag = nullptr;
     c.r2 = nullptr;
-    c.cert_only = 0;
+    c.cert_only = 0, c.open_rows = nullptr, c.list_mode = 0;
     if (drop_params) c.gain = c.offset = nullptr;  // nobody reads them after this
     HK_HIP(hk::launch_fit_apply(c, desc->model, false, stream));
     return HK_OK;
@@ -1014,28 +1037,13 @@ struct FitPending {
     bool active = false;  // gain-offset with a threshold: fit_finish() has to look at the counter
 };
 
-// second half of fit_on_device, once the failure counter is on the host: the certificate-only build's re-run and the
-// in-painting branch (kernel_model.py:361-371).  *requeued = the output planes were (re)written by work queued here.
+// second half of fit_on_device, once the failure counter is on the host: the in-painting branch (kernel_model.py:361-371).  *requeued = the output planes were (re)written by work queued here.
 int fit_finish(hk_ctx* ctx, Slot& sl, const hk_fit_desc* desc, FitPending& p, unsigned long long n_fail, bool* requeued) {
     *requeued = false;
     if (!p.active) return HK_OK;
     hk::FitArgs& a = p.a;
     const bool r2 = needs_r2(desc);
     const size_t plane = (size_t)a.stride * a.height * sizeof(float);
-    if (a.cert_only) {
-        if (n_fail & hk::FIT_RETRY_BIT) {  // the certificate left a wave-row open: the full build decides
-            ctx->cert_only_retried();
-            a.cert_only = 0;
-            HK_HIP(hipMemsetAsync(a.fail_count, 0, sizeof(unsigned long long), sl.stream));
-            HK_HIP(hk::launch_fit_apply(a, desc->model, r2, sl.stream));
-            HK_HIP(hipMemcpyAsync(sl.fail_host, a.fail_count, sizeof(n_fail), hipMemcpyDeviceToHost, sl.stream));
-            HK_HIP(hipStreamSynchronize(sl.stream));
-            n_fail = *sl.fail_host;
-            *requeued = true;
-        } else {
-            ctx->cert_only_settled();
-        }
-    }
     ctx->expect_r2_failures.store(n_fail > 0 ? 1 : 0);
     if (n_fail > 0) {
         const int rc = inpaint_band(sl, a, desc, r2, plane, n_fail, p.scratch_params, a.flag ? a.offset : nullptr, a.flag);
@@ -1096,8 +1104,10 @@ int fit_on_device(hk_ctx* ctx, Slot& sl, const hk_fit_desc* desc, const double* 
             p.scratch_params = !d_gain && !d_r2;
         }
     }
-    a.cert_only = cert_only_eligible(a, desc) && !p.scratch_params && ctx->try_cert_only();
-    HK_HIP(hk::launch_fit_apply(a, desc->model, r2, sl.stream));
+    {
+        const int lrc = launch_fit(ctx, sl, a, desc, r2);
+        if (lrc) return lrc;
+    }
     p.active = a.has_thresh != 0;
     if (defer || !p.active) return HK_OK;
 
@@ -1267,7 +1277,7 @@ int run_host(hk_ctx* ctx, const hk_fit_desc* desc, const hk_io_desc* io, const v
             n_fail = *sl.fail_host;  // (the in-painting passes do not count; a re-run of the complete build does)
         }
     }
-    if (r2_fail_count) *r2_fail_count = n_fail & ~hk::FIT_RETRY_BIT;
+    if (r2_fail_count) *r2_fail_count = n_fail;
     return HK_OK;
 }
 
@@ -1322,7 +1332,6 @@ int hk_ctx_create(int device_id, int n_streams, hk_ctx** out) {
     // runs of this many consecutive units (neighbouring strips) per XCD, 0 = plain round-robin (hk_fit_kernel.h); 16 measured
     // best across models on MI355X (gain 5x5: -12 %, gain-offset without the r2 mask: -4 %, VALU-bound variants: -1 %)
     ctx->xcd_remap = remap ? std::min(std::max(atoi(remap), 0), 256) : 16;
-    if (const char* e = getenv("HK_CERT_ONLY")) ctx->cert_disabled = atoi(e) == 0;
     for (auto& s : ctx->slots) {
         hipError_t e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
         if (e != hipSuccess) {
@@ -1811,16 +1820,13 @@ int hk_fit_apply_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* job
     if ((job->out_rows || job->out_cols) && a.has_thresh)
         return fail(HK_ERR_UNSUPPORTED, "a store window is not supported together with r2_inpaint_thresh (the in-painting "
                                         "needs the parameters of the whole block)");
-    // a band the certificate-only build cannot settle comes back with FIT_RETRY_BIT in its counter; hk_inpaint_dev /
-    // hk_inpaint_dev_counts run it again with the full build
-    a.cert_only = cert_only_eligible(a, desc) && !ctx->expecting_failures_dev() && ctx->try_cert_only();
-    if (!a.cert_only && desc->model == HK_MODEL_GAIN_OFFSET && a.has_thresh && job->scratch) {
-        // the complete build leaves the in-painting's inputs in the job's scratch (hk_inpaint_dev_counts starts from them)
+    if (desc->model == HK_MODEL_GAIN_OFFSET && a.has_thresh && job->scratch) {
+        // a job that carries scratch gets the in-painting's inputs -- offsets + source flags, 5 bytes per pixel -- left there by
+        // this pass (hk_inpaint_dev_counts starts from them): a caller that expects pixels to fail the r2 mask provides it
         a.flag = job_scratch_flag(job);
         if (!a.offset) a.offset = job_scratch_offset(job);
     }
-    HK_HIP(hk::launch_fit_apply(a, desc->model, needs_r2(desc), ctx->slots[job->stream].stream));
-    return HK_OK;
+    return launch_fit(ctx, ctx->slots[job->stream], a, desc, needs_r2(desc));
 }
 
 int hk_fail_counts_async(hk_ctx* ctx, const hk_dev_job* job, uint64_t* host_counts, hk_event* ready) {
@@ -1886,7 +1892,6 @@ int hk_inpaint_dev_counts(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job
     const bool r2 = needs_r2(desc);
     const size_t plane = (size_t)job->stride * job->height * sizeof(float);
     unsigned long long total = 0;
-    bool retried = false;
     for (int b = 0; b < job->n_bands; ++b) {
         unsigned long long n_fail = counts[b];
         if (n_fail == 0) continue;
@@ -1900,47 +1905,18 @@ int hk_inpaint_dev_counts(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job
         fill_args(a, desc, ctx->xcd_remap);
         fill_grid(a, job->seg_rows);
         std::unique_lock<std::mutex> lk(ctx->mu);  // the slot's scratch may be (re)allocated
-        // offsets + source flags left by the pass that counted: a count without the re-run bit comes from the complete
-        // build, which writes them whenever the job carries scratch (hk_fit_apply_dev)
+        // offsets + source flags left by the pass that counted, which writes them whenever the job carries scratch (hk_fit_apply_dev)
         float* pre_off = nullptr;
         const unsigned char* pre_flag = nullptr;
-        if (job->scratch && !(n_fail & hk::FIT_RETRY_BIT)) {
+        if (job->scratch) {
             pre_flag = job_scratch_flag(job) + off;
             pre_off = a.offset ? a.offset : job_scratch_offset(job) + off;
-        }
-        if (n_fail & hk::FIT_RETRY_BIT) {
-            // the certificate-only build gave up on this band (hk_fit_apply_dev): run the full build, which leaves the
-            // in-painting's inputs in scratch (the job's, else the slot's), and count again
-            if (!job->fail_count) return fail(HK_ERR_ARG, "a band needs its re-run but job->fail_count is NULL");
-            retried = true;
-            unsigned long long* d_fail = reinterpret_cast<unsigned long long*>(job->fail_count) + b;
-            rc = ensure_inpaint_scratch(sl, plane, a.height, a.stride);
-            if (rc) return rc;
-            char* aux = static_cast<char*>(sl.aux);
-            float* const caller_off = a.offset;
-            a.flag = job->scratch ? job_scratch_flag(job) + off : hk::inpaint_flag_plane(aux + plane, a.height, a.stride);
-            if (!a.offset) a.offset = job->scratch ? job_scratch_offset(job) + off : reinterpret_cast<float*>(aux);
-            a.fail_count = d_fail;
-            HK_HIP(hipMemsetAsync(d_fail, 0, sizeof(unsigned long long), sl.stream));
-            HK_HIP(hk::launch_fit_apply(a, desc->model, r2, sl.stream));
-            unsigned long long* const word = sl.pin<unsigned long long>(Slot::PIN_WORD);  // (pinned; one caller per stream)
-            HK_HIP(hipMemcpyAsync(word, d_fail, sizeof(n_fail), hipMemcpyDeviceToHost, sl.stream));
-            HK_HIP(hipMemsetAsync(d_fail, 0, sizeof(unsigned long long), sl.stream));
-            lk.unlock();  // other streams' callers need not wait for this stream to drain
-            HK_HIP(hipStreamSynchronize(sl.stream));
-            lk.lock();
-            n_fail = *word;
-            pre_off = a.offset, pre_flag = a.flag;
-            a.fail_count = nullptr, a.flag = nullptr, a.offset = caller_off;
         }
         total += n_fail;
         if (n_fail == 0) continue;
         rc = inpaint_band(sl, a, desc, r2, plane, n_fail, false, pre_off, pre_flag);
         if (rc) return rc;
     }
-    if (retried) ctx->cert_only_retried();
-    else if (ctx->cert_skip.load(std::memory_order_relaxed) == 0) ctx->cert_only_settled();
-    ctx->expect_r2_failures.store(total > 0 ? hk_ctx::EXPECT_DEV_LAUNCHES : 0);
     if (n_fail_out) *n_fail_out = total;
     return HK_OK;
 }
@@ -2184,7 +2160,7 @@ int hk_fit_apply_batch_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_jo
     hk::FitArgs a0;  // the launch's argument block: everything the jobs share, and job 0's own fields (which the table overrides)
     memset(&a0, 0, sizeof(a0));
     long long groups[2] = {0, 0}, total_px = 0;
-    bool cert_only = false, pad_by_size = false;
+    bool pad_by_size = false;
     // fill_grid()'s two segment heights, applied to the LAUNCH: the jobs run in order, so the jobs whose units make up the last
     // ~1.25 generations of resident waves get short segments (they level the end of the launch) and all earlier ones long
     // segments (half the priming rows).  Results do not depend on the segment height (exact running sums).
@@ -2229,12 +2205,7 @@ int hk_fit_apply_batch_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_jo
         if ((job->out_rows || job->out_cols) && a.has_thresh)
             return fail(HK_ERR_UNSUPPORTED, "a store window is not supported together with r2_inpaint_thresh (the in-painting "
                                             "needs the parameters of the whole block)");
-        if (j == 0) cert_only = cert_only_eligible(a, desc) && !ctx->expecting_failures_dev() && ctx->try_cert_only();
-        if (!cert_only && desc->model == HK_MODEL_GAIN_OFFSET && a.has_thresh && job->scratch) {
-            // the complete build leaves the in-painting's inputs in the job's scratch (hk_inpaint_dev_counts starts from them)
-            a.flag = job_scratch_flag(job);
-            if (!a.offset) a.offset = job_scratch_offset(job);
-        }
+        // (only models without the r2 mask have builds with the job-table look-up: no certificate, no in-painting inputs here)
         hk::FitJob& e = table[(size_t)j];
         memset(&e, 0, sizeof(e));
         e.src = a.src, e.ref = a.ref, e.gain = a.gain, e.offset = a.offset, e.r2 = a.r2, e.corr = a.corr, e.norm = a.norm;
@@ -2250,7 +2221,7 @@ int hk_fit_apply_batch_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_jo
         if (groups[0] > 0x7fffff00ll) return fail(HK_ERR_ARG, "the batch has too many wave units for one launch");
         if (j == 0) a0 = a;
     }
-    a0.cert_only = cert_only;
+    a0.cert_only = 0;
     a0.n_jobs = n_jobs;
     a0.batch_groups[0] = (int)groups[0], a0.batch_groups[1] = (int)groups[1];
     if (pad_by_size) a0.lds_pad = total_px >= (128ll << 20) ? 4096 : 0;  // fill_grid()'s occupancy policy, for the whole launch

@@ -366,7 +366,11 @@ __device__ __forceinline__ void hsum_wide(const T (&V)[PX], T (&H)[PX], const Wi
 // pre1..3 -- into seven LINES of one float64 per lane (structure of arrays: consecutive lanes touch consecutive 8-byte words, no
 // bank conflict; a first version with one 64-byte slot per lane ran 16-way conflicts and lost 50 %, profiles/r06_wline.txt) and
 // reads its neighbours' entries with ds_read_b64: at 31 wide 7 writes + 10 reads of 8 bytes instead of 20 ds_bpermute_b32 per
-// quantity.  Same terms, same order of additions as hsum_wide: bit-identical results.  `line` = this lane's entry of line 0; every
+// quantity.  Measured on the headline workload (profiles/r06_ab_wline.txt): 41 wide 9.54 -> 8.25 ms, 63 wide 13.2 -> 10.6 -- but 17 /
+// 21 / 31 wide 5.27 / 5.54 / 6.66 -> 5.88 / 6.03 / 7.43: there the wave also holds a centre ring of kh / 2 + 1 rows in LDS, the
+// lines' 6.3 KB cost it three of ten resident waves per CU, and at three whole neighbour lanes 17 LDS operations replace 20.  So
+// the lines serve the builds that re-load both rows (RING 0: kernels taller than 39 rows, no LDS ring), ds_bpermute the others.
+// Same terms, same order of additions as hsum_wide: bit-identical results.  `line` = this lane's entry of line 0; every
 // line has WLINE_G guard entries either side that are never written: their readers are overlap lanes whose sums are discarded.
 constexpr int WLINE_G = 26;                                 // >= F + 1 for every admitted width (overlap lanes <= 24: F <= 24)
 constexpr int WLINE_STRIDE = (WAVE + 2 * WLINE_G) * 8;      // bytes per line
@@ -374,6 +378,8 @@ constexpr size_t WLINE_BYTES = 7 * (size_t)WLINE_STRIDE;    // 6.3 KB per wave
 #ifndef HK_WLINE
 #define HK_WLINE 1
 #endif
+template <int RW, int RING>
+constexpr bool use_wline() { return HK_WLINE && RW < 0 && RING == 0; }
 template <int E>
 __device__ __forceinline__ void hsum_wide_line(const double (&V)[PX], double (&H)[PX], const WideLanes& wl, int lane, char* line) {
     constexpr int RV = 2 * PX + E;
@@ -441,14 +447,14 @@ __device__ __forceinline__ void hsum_wide_line(const double (&V)[PX], double (&H
 
 // RW >= 0: compile-time half-width; RW = -1 - E: wide kernel with rw mod 4 == E (hsum_wide).  DPP2: see hsum.
 // `xch`: the lane's slot of the LDS exchange line (XCH builds of hsum; the float64 sums of the wide kernels: hsum_wide_line)
-template <int RW, typename T, bool XCH = false, bool DPP2 = false>
+template <int RW, typename T, bool XCH = false, bool DPP2 = false, bool WLINE = false>
 __device__ __forceinline__ void hsum_any(const T (&V)[PX], T (&H)[PX], const WideLanes& wl, int lane, char* xch = nullptr) {
     if constexpr ((HK_ABLATE & 4) != 0) {
 #pragma unroll
         for (int i = 0; i < PX; ++i) H[i] = V[i];
     } else if constexpr (RW >= 0)
         hsum<RW, T, XCH, DPP2>(V, H, lane, xch);
-    else if constexpr (HK_WLINE && std::is_same<T, double>::value) {
+    else if constexpr (WLINE && std::is_same<T, double>::value) {
         hsum_wide_line<-1 - RW>(V, H, wl, lane, xch);
     } else
         hsum_wide<-1 - RW, T>(V, H, wl, lane);
@@ -771,9 +777,9 @@ constexpr int fit_min_waves() {
     // equal -- except kw / 2 mod 4 = 1 .. 3 beyond 15 wide, two registers short and as fast at two waves: profiles/r05_ab_cert_wide_waves.txt)
     if (MODEL == 2 && R2 && !DENSE && (RW < 0 || RW >= 4) && !(CERT_ONLY && HK_CERT_WIDE_3WAVES && RW >= -1)) return HK_FIT_MIN_WAVES_WIDE;
     if (HK_NOSPILL) {
-        // (round 6: with the LDS exchange line the compiler issues a quantity's neighbour reads together -- 8 to 25 registers more at
-        // the peak -- and the line's 4.5 KB per wave bound the occupancy of these builds near two waves per SIMD anyway)
-        if (HK_WLINE && RW < 0 && MODEL == 2) return 2;
+        // (round 6: with the LDS exchange lines the compiler issues a quantity's neighbour reads together -- 8 to 25 registers more
+        // at the peak -- in the builds that use them: kernels taller than 39 rows)
+        if (use_wline<RW, RING>() && MODEL == 2) return 2;
         if (RW < 0 && R2 && !CERT_ONLY) return 2;                          // wider than 15 with the R2 work (10 - 28 spilled registers at three)
         if (MODEL == 2 && R2 && !DENSE && RW == 3) return 2;               // gain-offset + R2, 7 wide, NaN-aware
         if (MODEL != 2 && R2 && !DENSE && RW >= 4 && RING == 2) return 2;  // gain / gain-blk-offset + R2, 9-15 wide, NaN-aware
@@ -782,9 +788,12 @@ constexpr int fit_min_waves() {
     return HK_FIT_MIN_WAVES;
 }
 
-template <int MODEL, bool R2, int RW, bool DENSE, int RING, bool CERT_ONLY, int WPB, bool BATCH = false>
-__global__ void __launch_bounds__(WAVE * WPB, (fit_min_waves<MODEL, R2, RW, DENSE, RING, CERT_ONLY>()))
-fit_apply_kernel(const FitArgs a_in) {
+// One unit of the fused kernel: the strip `strip` of band `band`, output rows [y0, y1) (priming rows included, the wave marches
+// from y0 - rh).  LIST: the unit is a run of a list launch -- rows that are not marked in FitArgs::open_rows are neither stored
+// nor counted (the certificate build settled them).
+template <int MODEL, bool R2, int RW, bool DENSE, int RING, bool CERT_ONLY, int WPB, bool LIST>
+__device__ __forceinline__ void fit_unit(const FitArgs& a, const int band, const int strip, const int y0, const int y1, const int lane,
+                                         const int wave_in_wg, float4* const lds4) {
     using CS = ColSums<MODEL, R2, DENSE>;
     // gain-blk-offset (kernel_model.py:276-303) normalises the source with the block's statistics, s' = s * n0 + n1 in
     // float64 (NumPy >= 2 promotion), and fits `gain` to it.  With R2 (BLK) s' is formed per pixel.  Without (BLKA, the
@@ -797,61 +806,12 @@ fit_apply_kernel(const FitArgs a_in) {
     constexpr bool USE_N = GO || R2 || BLKA;
     constexpr bool UNIFORM_N = GO || BLKA;  // builds that track wave-rows whose every window is complete and all-valid
     static_assert(!(DENSE && MODEL == 1), "gain-blk-offset re-derives its mask from the normalised source");
-    extern __shared__ float4 lds4[];
-
-    const int lane = threadIdx.x & (WAVE - 1), wave_in_wg = threadIdx.x >> 6;
-    int group = blockIdx.x;
-    if (a_in.xcd_remap) {
-        // workgroups go round-robin to the 8 XCDs (each with its own L2): hand every XCD runs of `xcd_remap` consecutive
-        // units, i.e. neighbouring strips of one segment, whose shared cache lines (strips start 16-byte-, not 128-byte-
-        // aligned, and overlap by two lanes) are then fetched from HBM once instead of once per strip
-        const int g = a_in.xcd_remap / WPB > 0 ? a_in.xcd_remap / WPB : 1, slot = blockIdx.x >> 3;
-        group = ((slot / g) * 8 + (blockIdx.x & 7)) * g + slot % g;
-    }
-    // Batched launch (FitArgs::jobs; the BATCH builds): the workgroup's job is the last one whose first workgroup is not beyond
-    // it -- a binary search over the job table with scalar loads (everything here is uniform over the workgroup) --, and the job's
-    // planes, shape and unit grid replace the launch's.  A build of its own: with the look-up compiled into every kernel (argument
-    // block copied and patched) the memory-bound builds lost up to 8 % (gain 5x5 at 8192^2 x 4; profiles/r03_batch.txt).
-    [[maybe_unused]] FitArgs a_job;
-    if constexpr (BATCH) {
-        constexpr int FG = WPB > 1 ? 1 : 0;
-        if (group >= a_in.batch_groups[FG]) return;  // the whole workgroup (grid padding)
-        int lo = 0, hi = a_in.n_jobs - 1;
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (a_in.jobs[mid].first_group[FG] <= group) lo = mid;
-            else hi = mid - 1;
-        }
-        const FitJob& e = a_in.jobs[lo];
-        group -= e.first_group[FG];
-        a_job = a_in;
-        a_job.src = e.src, a_job.ref = e.ref, a_job.gain = e.gain, a_job.offset = e.offset, a_job.r2 = e.r2, a_job.corr = e.corr;
-        a_job.norm = e.norm, a_job.fail_count = e.fail_count, a_job.flag = e.flag;
-        a_job.stride = e.stride, a_job.band_stride = e.band_stride, a_job.height = e.height, a_job.width = e.width;
-        a_job.n_bands = e.n_bands, a_job.seg_rows = e.seg_rows, a_job.n_strips = e.n_strips, a_job.n_segs = e.n_segs;
-        a_job.seg_rows_tail = e.seg_rows_tail, a_job.n_segs_big = e.n_segs_big;
-        a_job.out_y0 = e.out_y0, a_job.out_y1 = e.out_y1, a_job.out_x0 = e.out_x0, a_job.out_x1 = e.out_x1;
-    }
-    const FitArgs& a = BATCH ? a_job : a_in;
-    // a workgroup = WPB adjacent strips of one (segment, band); the strips of a row are padded to a multiple of WPB (a padded
-    // strip lies outside the raster: every lane loads a clamped quad and stores nothing -- it only keeps the barriers whole)
-    const int groups_per_row = (a.n_strips + WPB - 1) / WPB;
-    if (group >= groups_per_row * a.n_segs * a.n_bands) return;  // the whole workgroup
-    // segment-major order: the short tail segments (hk_api.hip fill_grid) are dispatched last
-    const int strip = (group % groups_per_row) * WPB + wave_in_wg;
-    const int t0 = group / groups_per_row;
-    const int band = t0 % a.n_bands;
-    const int seg = t0 / a.n_bands;
-
     const int rh = a.rh, kh = 2 * rh + 1;
     const int rw = RW >= 0 ? RW : a.rw;
     const int ol = RW >= 0 ? (RW + PX - 1) / PX : a.overlap_lanes;
     const int out_lanes = WAVE - 2 * ol;
     [[maybe_unused]] const WideLanes wl = make_wide_lanes(rw, lane);  // kernels wider than 15 (RW < 0) only
     const int x = (strip * out_lanes + lane - ol) * PX;
-    const bool big = seg < a.n_segs_big;
-    const int y0 = big ? seg * a.seg_rows : a.n_segs_big * a.seg_rows + (seg - a.n_segs_big) * a.seg_rows_tail;
-    const int y1 = min(y0 + (big ? a.seg_rows : a.seg_rows_tail), a.height);
     const int W = a.width, H = a.height;
 
     const float* __restrict__ sp = a.src + (long long)band * a.band_stride;
@@ -1055,7 +1015,6 @@ fit_apply_kernel(const FitArgs a_in) {
     zold_next.m = 0u, zold_next.clean = false;
     unsigned nfail = 0;
     [[maybe_unused]] int cert_skip = 0;  // wave-uniform: rows for which the r2-mask certificate is not attempted
-    [[maybe_unused]] bool gave_up = false;  // wave-uniform, certificate-only build: this wave has asked for the re-run
     int slot = 0;
     int slot2 = 0;  // RING 2: write slot of the centre ring
     const int ring_mod = ring2p ? ring_rows : kh;
@@ -1198,13 +1157,13 @@ fit_apply_kernel(const FitArgs a_in) {
             // one of those float64 quadruples is live beside S2 / R2 (12-16 VGPRs less at the pressure peak)
             double HS[PX], HR[PX];
             [[maybe_unused]] float Sf0[PX], Rf0[PX], Pf0[PX];
-            hsum_any<RW, double, (XCH & 1) != 0, DPPX>(cs.S, HS, wl, lane, xch);
+            hsum_any<RW, double, (XCH & 1) != 0, DPPX, use_wline<RW, RING>()>(cs.S, HS, wl, lane, xch);
             if constexpr (GO) {
 #pragma unroll
                 for (int i = 0; i < PX; ++i) Sf0[i] = (float)HS[i];
                 __builtin_amdgcn_sched_barrier(0);
             }
-            hsum_any<RW, double, (XCH & 2) != 0, DPPX>(cs.R, HR, wl, lane, xch);
+            hsum_any<RW, double, (XCH & 2) != 0, DPPX, use_wline<RW, RING>()>(cs.R, HR, wl, lane, xch);
             if constexpr (GO) {
 #pragma unroll
                 for (int i = 0; i < PX; ++i) Rf0[i] = (float)HR[i];
@@ -1212,13 +1171,13 @@ fit_apply_kernel(const FitArgs a_in) {
             }
             double HP[PX], HS2[PX], HR2[PX];
             float Nf[PX];
-            if constexpr (CS::NEED_P) hsum_any<RW, double, (XCH & 4) != 0, DPPX>(cs.P, HP, wl, lane, xch);
+            if constexpr (CS::NEED_P) hsum_any<RW, double, (XCH & 4) != 0, DPPX, use_wline<RW, RING>()>(cs.P, HP, wl, lane, xch);
             if constexpr (GO) {
 #pragma unroll
                 for (int i = 0; i < PX; ++i) Pf0[i] = (float)HP[i];
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if constexpr (CS::NEED_S2) hsum_any<RW, double, (XCH & 8) != 0, DPPX>(cs.S2, HS2, wl, lane, xch);
+            if constexpr (CS::NEED_S2) hsum_any<RW, double, (XCH & 8) != 0, DPPX, use_wline<RW, RING>()>(cs.S2, HS2, wl, lane, xch);
             // Certificate-only build: the window sum of ref^2 feeds nothing but the float32 r2-mask certificate, so its
             // horizontal stage runs in float32 on the rounded column sums (non-negative terms: <= 5 roundings, relative
             // error <= 4.03 * 2^-24 instead of 2^-24 -- DESIGN.md appendix A budgets it): four converts + nine float32 adds,
@@ -1230,7 +1189,7 @@ fit_apply_kernel(const FitArgs a_in) {
                 for (int i = 0; i < PX; ++i) V2[i] = (float)cs.R2s[i];
                 hsum_any<RW, float, false, DPPX>(V2, HR2f, wl, lane);
             } else if constexpr (CS::NEED_R2S) {
-                hsum_any<RW, double, (XCH & 16) != 0, DPPX>(cs.R2s, HR2, wl, lane, xch);
+                hsum_any<RW, double, (XCH & 16) != 0, DPPX, use_wline<RW, RING>()>(cs.R2s, HR2, wl, lane, xch);
                 if constexpr (CERT_ONLY) {
 #pragma unroll
                     for (int i = 0; i < PX; ++i) HR2f[i] = (float)HR2[i];
@@ -1321,10 +1280,11 @@ fit_apply_kernel(const FitArgs a_in) {
                             const double deny = __dsub_rn(__dmul_rn(Ndy, HS2[2 * j + 1]), (double)SS2.y);
                             const double qx = fast_quot((double)num2.x, denx), qy = fast_quot((double)num2.y, deny);
                             f2 g2 = {(float)qx, (float)qy};
-                            // a lane with a quotient too close to a float32 rounding boundary divides this pixel pair again,
-                            // the IEEE way, while the operands are still in registers.  The range test (zero / infinite /
-                            // NaN / denormal-float32 quotients) is left to the r2-mask certificate in the certificate-only
-                            // build, which refuses gains outside (2^-20, 2^20) and has no other consumer of them.
+                            // a lane with a quotient too close to a float32 rounding boundary, or outside the float32 normal range
+                            // (zero / infinite / NaN / denormal quotients), divides this pixel pair again, the IEEE way, while the
+                            // operands are still in registers.  The certificate build leaves the range test to its certificate,
+                            // which passes gains inside (2^-20, 2^20) only and has no other consumer of the rest (their rows are
+                            // marked for the list launch).
                             bool again = min(quot_guard(qx), quot_guard(qy)) < 2u * HK_DIV_GUARD + 1u;
                             if constexpr (!CERT_ONLY) again |= max(quot_range(qx), quot_range(qy)) > 0x0fd00000u;
                             if (again) {
@@ -1372,8 +1332,7 @@ fit_apply_kernel(const FitArgs a_in) {
                                     // whose every valid pixel is certain one way or the other needs no exact evaluation either:
                                     // on rasters with failing pixels (real imagery has them block after block) that is nearly
                                     // every row.
-                                    [[maybe_unused]] f2 rhs_f;
-                                    if constexpr (!CERT_ONLY) rhs_f = pk_fma(f2{a.r2_failcert_scale, a.r2_failcert_scale}, sst, -slack);
+                                    const f2 rhs_f = pk_fma(f2{a.r2_failcert_scale, a.r2_failcert_scale}, sst, -slack);
 #pragma unroll
                                     for (int e = 0; e < 2; ++e) {
                                         const bool m = (mcu >> (8 * (2 * j + e))) & 1u;
@@ -1382,21 +1341,17 @@ fit_apply_kernel(const FitArgs a_in) {
                                         // 2^-20 < g < 2^20 (also the `gain > 0` half of the decision), 2^-40 < N*T' < 2^60;
                                         // a masked pixel's quantities are arbitrary and must not count
                                         const unsigned gd = __float_as_uint(g2[e]) - 0x35800000u, td = __float_as_uint(NT[e]) - 0x2b800000u;
-                                        if constexpr (CERT_ONLY) {
-                                            gwin = max(gwin, UN ? gd : (m ? gd : 0u));
-                                            twin = max(twin, UN ? td : (m ? td : 0u));
-                                            uncertain |= m & !sure;
-                                        } else {
-                                            // a pixel whose gain is not positive (or NaN) fails whatever its R2: no error model,
-                                            // no window needed for it
-                                            const bool gpos = g2[e] > 0.f;
-                                            const bool sure_f = !gpos | ((lhs[e] < rhs_f[e]) & (lhs[e] > 0.f) & (sst[e] > slack[e]));
-                                            const bool mg = UN ? gpos : (m & gpos);
-                                            gwin = max(gwin, mg ? gd : 0u);
-                                            twin = max(twin, mg ? td : 0u);
-                                            uncertain |= m & !((sure & gpos) | sure_f);
-                                            cert_failed |= ((m & sure_f) ? 0xffu : 0u) << (8 * (2 * j + e));
-                                        }
+                                        // a pixel whose gain is not positive (or NaN) fails whatever its R2: no error model,
+                                        // no window needed for it
+                                        const bool gpos = g2[e] > 0.f;
+                                        // (the certificate build certifies PASSING rows only: the fail side and the source flags of the
+                                        // in-painting it feeds do not fit its 128 registers -- 3 to 10 spilled with them, measured)
+                                        const bool sure_f = CERT_ONLY ? false : (!gpos | ((lhs[e] < rhs_f[e]) & (lhs[e] > 0.f) & (sst[e] > slack[e])));
+                                        const bool mg = UN ? gpos : (m & gpos);
+                                        gwin = max(gwin, mg ? gd : 0u);
+                                        twin = max(twin, mg ? td : 0u);
+                                        uncertain |= m & !((sure & gpos) | sure_f);
+                                        cert_failed |= ((m & sure_f) ? 0xffu : 0u) << (8 * (2 * j + e));
                                     }
                                 }
                             }
@@ -1441,29 +1396,22 @@ fit_apply_kernel(const FitArgs a_in) {
                         bool exact = true;
                         if constexpr (GO) {
                             if (try_cert) {
-                                exact = __any(uncertain);
-                                if (exact) cert_skip = HK_CERT_SKIP;  // failing regions are coherent: skip the certificate for a few rows
-                                if constexpr (!CERT_ONLY) {
-                                    if (!exact) {  // every valid pixel of the wave-row is certified: the failing ones are known
-                                        passed &= ~cert_failed;
-                                        if (out_lane) nfail += (unsigned)__popc(cert_failed & 0x01010101u);
-                                    }
+                                exact = __any(uncertain & out_lane);
+                                if (!CERT_ONLY && exact) cert_skip = HK_CERT_SKIP;  // failing regions are coherent: skip the certificate for a few rows
+                                if (!exact) {  // every valid pixel of the wave-row is certified: the failing ones are known
+                                    passed &= ~cert_failed;
+                                    if (out_lane) nfail += (unsigned)__popc(cert_failed & 0x01010101u);
                                 }
                             }
                         }
                         if constexpr (CERT_ONLY) {
-                            // this build holds no exact evaluation (which would cost the whole kernel a wave per SIMD): a
-                            // wave-row the certificate cannot settle invalidates the launch -- the host sees the flag and
-                            // runs the full build instead (hk_api.hip), remembering to start with it next time.  The wave says
-                            // so ONCE (an atomic per uncertain row from every wave, all on one address, made such a launch take
-                            // 50 ms) and carries on, its results void.  Ending the wave here instead (s_endpgm, or a flag handed
-                            // out of this lambda) would cut an aborted launch from 3.3 to 0.13 ms but costs the 128-VGPR
-                            // allocation two spilled registers = +1.5 % on every clean launch; aborted launches are rare
-                            // (the host backs off after each).
+                            // this build holds no exact evaluation (which costs the whole kernel a wave per SIMD): a wave-row the
+                            // two-sided certificate cannot settle is marked for the LIST launch that follows (the complete build
+                            // over the runs of marked rows, FitArgs::open_rows) -- nothing of it is stored or counted here
                             if (exact) {
-                                if (!gave_up && lane == ol) atomicOr(a.fail_count + band, FIT_RETRY_BIT);  // first output lane
-                                gave_up = true;
-                                return;  // leaves this row's pointwise lambda (skipping its stage C also keeps the allocation spill-free)
+                                if (lane == ol)  // the first output lane (always active here: a strip has output columns)
+                                    atomicOr(a.open_rows + ((size_t)(band * a.n_strips + strip) * (size_t)((H + 31) >> 5) + (size_t)(y >> 5)), 1u << (y & 31));
+                                return;  // (skipping stage C also keeps the allocation spill-free)
                             }
                         } else if (exact) {
                             double sstot[PX], ssres[PX];
@@ -1585,16 +1533,25 @@ fit_apply_kernel(const FitArgs a_in) {
                     const long long row_off = out_base + (long long)y * a.stride;
                     auto at = [&](float* plane) { return reinterpret_cast<float4*>(reinterpret_cast<char*>(plane + row_off) + xbytes); };
                     if (a.corr && !((HK_ABLATE & 8) && c[0] != 123.456f)) store4_nt(at(a.corr), make_float4(c[0], c[1], c[2], c[3]));
-                    if (a.gain) store4_nt(at(a.gain), masked4(g));
+                    if constexpr (!CERT_ONLY) {  // (the certificate build serves launches without a gain / R2 plane: launch_one)
+                        if (a.gain) store4_nt(at(a.gain), masked4(g));
+                    }
                     if (a.offset) store4_nt(at(a.offset), masked4(o));
-                    if (R2 && a.r2) store4_nt(at(a.r2), masked4(r2v));
+                    if constexpr (!CERT_ONLY) {
+                        if (R2 && a.r2) store4_nt(at(a.r2), masked4(r2v));
+                    }
                     if constexpr (GO && R2 && !CERT_ONLY) {
                         // 1: source of the in-painting, 0: target, 2: invalid -- neither (what a fill would put there is reset to NaN anyway, kernel_model.py:367)
                         if (a.flag) *reinterpret_cast<unsigned*>(a.flag + row_off + (xbytes >> 2)) = passed | ((~mcu & 0x01010101u) << 1);
                     }
                 }
             };
-            if constexpr (UNIFORM_N) {
+            // list launch: a row of the run that is not marked was settled, stored and counted by the certificate build
+            bool skip_row = false;
+            if constexpr (LIST)  // wave-uniform (scalar load)
+                skip_row = ((a.open_rows[(size_t)(band * a.n_strips + strip) * (size_t)((H + 31) >> 5) + (size_t)(y >> 5)] >> (y & 31)) & 1u) == 0u;
+            if (skip_row) {
+            } else if constexpr (UNIFORM_N) {
                 if (n_uniform) pointwise(std::true_type{});
                 else pointwise(std::false_type{});
             } else {
@@ -1626,6 +1583,102 @@ fit_apply_kernel(const FitArgs a_in) {
     }
 }
 
+template <int MODEL, bool R2, int RW, bool DENSE, int RING, bool CERT_ONLY, int WPB, bool BATCH = false>
+__global__ void __launch_bounds__(WAVE * WPB, (fit_min_waves<MODEL, R2, RW, DENSE, RING, CERT_ONLY>()))
+fit_apply_kernel(const FitArgs a_in) {
+    extern __shared__ float4 lds4[];
+
+    const int lane = threadIdx.x & (WAVE - 1), wave_in_wg = threadIdx.x >> 6;
+    int group = blockIdx.x;
+    if (a_in.xcd_remap) {
+        // workgroups go round-robin to the 8 XCDs (each with its own L2): hand every XCD runs of `xcd_remap` consecutive
+        // units, i.e. neighbouring strips of one segment, whose shared cache lines (strips start 16-byte-, not 128-byte-
+        // aligned, and overlap by two lanes) are then fetched from HBM once instead of once per strip
+        const int g = a_in.xcd_remap / WPB > 0 ? a_in.xcd_remap / WPB : 1, slot = blockIdx.x >> 3;
+        group = ((slot / g) * 8 + (blockIdx.x & 7)) * g + slot % g;
+    }
+    // Batched launch (FitArgs::jobs; the BATCH builds): the workgroup's job is the last one whose first workgroup is not beyond
+    // it -- a binary search over the job table with scalar loads (everything here is uniform over the workgroup) --, and the job's
+    // planes, shape and unit grid replace the launch's.  A build of its own: with the look-up compiled into every kernel (argument
+    // block copied and patched) the memory-bound builds lost up to 8 % (gain 5x5 at 8192^2 x 4; profiles/r03_batch.txt).
+    [[maybe_unused]] FitArgs a_job;
+    if constexpr (BATCH) {
+        constexpr int FG = WPB > 1 ? 1 : 0;
+        if (group >= a_in.batch_groups[FG]) return;  // the whole workgroup (grid padding)
+        int lo = 0, hi = a_in.n_jobs - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (a_in.jobs[mid].first_group[FG] <= group) lo = mid;
+            else hi = mid - 1;
+        }
+        const FitJob& e = a_in.jobs[lo];
+        group -= e.first_group[FG];
+        a_job = a_in;
+        a_job.src = e.src, a_job.ref = e.ref, a_job.gain = e.gain, a_job.offset = e.offset, a_job.r2 = e.r2, a_job.corr = e.corr;
+        a_job.norm = e.norm, a_job.fail_count = e.fail_count, a_job.flag = e.flag;
+        a_job.stride = e.stride, a_job.band_stride = e.band_stride, a_job.height = e.height, a_job.width = e.width;
+        a_job.n_bands = e.n_bands, a_job.seg_rows = e.seg_rows, a_job.n_strips = e.n_strips, a_job.n_segs = e.n_segs;
+        a_job.seg_rows_tail = e.seg_rows_tail, a_job.n_segs_big = e.n_segs_big;
+        a_job.out_y0 = e.out_y0, a_job.out_y1 = e.out_y1, a_job.out_x0 = e.out_x0, a_job.out_x1 = e.out_x1;
+    }
+    const FitArgs& a = BATCH ? a_job : a_in;
+    // a workgroup = WPB adjacent strips of one (segment, band); the strips of a row are padded to a multiple of WPB (a padded
+    // strip lies outside the raster: every lane loads a clamped quad and stores nothing -- it only keeps the barriers whole)
+    const int groups_per_row = (a.n_strips + WPB - 1) / WPB;
+    if (group >= groups_per_row * a.n_segs * a.n_bands) return;  // the whole workgroup
+    // segment-major order: the short tail segments (hk_api.hip fill_grid) are dispatched last
+    const int strip = (group % groups_per_row) * WPB + wave_in_wg;
+    const int t0 = group / groups_per_row;
+    const int band = t0 % a.n_bands;
+    const int seg = t0 / a.n_bands;
+    const bool big = seg < a.n_segs_big;
+    const int y0 = big ? seg * a.seg_rows : a.n_segs_big * a.seg_rows + (seg - a.n_segs_big) * a.seg_rows_tail;
+    const int y1 = min(y0 + (big ? a.seg_rows : a.seg_rows_tail), a.height);
+    fit_unit<MODEL, R2, RW, DENSE, RING, CERT_ONLY, WPB, false>(a, band, strip, y0, y1, lane, wave_in_wg, lds4);
+}
+
+// LIST launch (round 6; the complete build of gain-offset with the r2 mask): the units are the runs of wave-rows the certificate
+// build marked in FitArgs::open_rows -- one bit per (band, strip, row), 32 rows per word.  A persistent grid of single waves: a
+// wave scans the words 64 at a time, takes every word that STARTS a run (non-zero, its predecessor in the strip zero), follows the
+// run over the next non-zero words and runs it like a row segment of its own -- 2 rh priming rows, then the rows from the run's
+// first to its last marked row, storing and counting the marked ones only.  A kernel of its own, so that the scan's state costs
+// the full-grid builds nothing.
+// (two waves per SIMD: with the scan's state a few of these builds are 1 - 3 registers short of the complete build's 168, and the
+// rows of a list launch are few where it matters -- where most rows are open, callers let the complete build run at once: job
+// scratch / the host path's expectation)
+template <int MODEL, bool R2, int RW, bool DENSE, int RING>
+__global__ void __launch_bounds__(WAVE, 2)
+fit_list_kernel(const FitArgs a) {
+    extern __shared__ float4 lds4[];
+    const int lane = threadIdx.x;
+    const int wps = (a.height + 31) >> 5;                     // words per (band, strip)
+    const int n_words = a.n_bands * a.n_strips * wps;
+    for (int chunk = (int)blockIdx.x * WAVE; chunk < n_words; chunk += (int)gridDim.x * WAVE) {
+        const int idx = chunk + lane;
+        const unsigned w = idx < n_words ? a.open_rows[idx] : 0u;
+        const unsigned before = (idx < n_words && idx % wps != 0) ? a.open_rows[idx - 1] : 0u;
+        unsigned long long starts = __ballot(w != 0u && before == 0u);
+        while (starts) {
+            const int pos = __ffsll((long long)starts) - 1;
+            starts &= starts - 1ull;
+            const int g = __builtin_amdgcn_readfirstlane(chunk + pos);
+            const int unit = g / wps, w0 = g - unit * wps;
+            const int band = unit / a.n_strips, strip = unit - band * a.n_strips;
+            unsigned last = a.open_rows[g];
+            const int y0 = w0 * 32 + (__ffs((int)last) - 1);
+            int e = w0;
+            while (e + 1 < wps) {
+                const unsigned nx = a.open_rows[g + (e + 1 - w0)];
+                if (nx == 0u) break;
+                last = nx, ++e;
+            }
+            const int y1 = min(e * 32 + 32 - __clz((int)last), a.height);
+            fit_unit<MODEL, R2, RW, DENSE, RING, false, 1, true>(a, band, strip, y0, y1, lane, 0, lds4);
+        }
+    }
+}
+
+
 // LDS bytes of one wave: the row ring of the mode (see fit_apply_kernel).  Validity travels inside the source plane
 // (RING_SENTINEL) and the 1/N table sits in global memory, so every build of a kernel shape needs the same amount: 10 KB at
 // 5x5 = 16 waves per CU (8 KB = 20 waves for the kernels that read the leaving row one iteration ahead).
@@ -1644,6 +1697,13 @@ struct FitBuildRecord {
 template <int MODEL, bool R2, int RW, bool DENSE, int RING, bool CERT_ONLY, int WPB, bool BATCH>
 BuildRecord FitBuildRecord<MODEL, R2, RW, DENSE, RING, CERT_ONLY, WPB, BATCH>::rec{MODEL, R2, RW, DENSE, RING, CERT_ONLY, WPB, BATCH};
 
+template <int MODEL, bool R2, int RW, bool DENSE, int RING>
+struct ListBuildRecord {
+    static BuildRecord rec;
+};
+template <int MODEL, bool R2, int RW, bool DENSE, int RING>
+BuildRecord ListBuildRecord<MODEL, R2, RW, DENSE, RING>::rec{"fit_list_kernel", MODEL, R2, RW, DENSE, RING};
+
 template <int MODEL, bool R2, int RW, bool DENSE, int RING, bool CERT_ONLY, int WPB>
 static hipError_t launch_wpb(const FitArgs& a, size_t lds, hipStream_t stream) {
     if (lds * WPB > 64 * 1024) {  // forced LDS ring on a tall kernel (testing): raise the 64 KiB dynamic-LDS default
@@ -1651,6 +1711,20 @@ static hipError_t launch_wpb(const FitArgs& a, size_t lds, hipStream_t stream) {
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
     }
+    if constexpr (MODEL == 2 && R2 && !CERT_ONLY && WPB == 1 && (RING == 1 || RING == 2)) {
+        // list launch (the rows the certificate build marked): a persistent grid of single waves; an empty bit plane costs microseconds
+        if (a.list_mode) {
+            if (lds > 64 * 1024) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fit_list_kernel<MODEL, R2, RW, DENSE, RING>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e != hipSuccess) return e;
+            }
+            ListBuildRecord<MODEL, R2, RW, DENSE, RING>::rec.hit();
+            hipLaunchKernelGGL((fit_list_kernel<MODEL, R2, RW, DENSE, RING>), dim3(256 * 8), dim3(WAVE), lds, stream, a);
+            return hipGetLastError();
+        }
+    }
+    if (a.list_mode) return hipErrorInvalidValue;  // (hk_api.hip asks for a list launch only where the certificate build exists)
     int grid = (a.n_strips + WPB - 1) / WPB * a.n_segs * a.n_bands;  // workgroups of WPB adjacent strips
     constexpr bool CAN_BATCH = fit_batch_build(MODEL, R2) && !CERT_ONLY;
     if (a.jobs) {
@@ -1689,7 +1763,7 @@ static hipError_t launch_build(const FitArgs& a, hipStream_t stream) {
     if constexpr (LOCKSTEP) {
         if (lds * HK_WPB_MEM <= 64 * 1024) return launch_wpb<MODEL, R2, RW, DENSE, RING, CERT_ONLY, HK_WPB_MEM>(a, lds, stream);
     }
-    if constexpr (RW < 0) return launch_wpb<MODEL, R2, RW, DENSE, RING, CERT_ONLY, 1>(a, lds + (HK_WLINE ? WLINE_BYTES : 0), stream);
+    if constexpr (RW < 0) return launch_wpb<MODEL, R2, RW, DENSE, RING, CERT_ONLY, 1>(a, lds + (use_wline<RW, RING>() ? WLINE_BYTES : 0), stream);
     return launch_wpb<MODEL, R2, RW, DENSE, RING, CERT_ONLY, 1>(a, lds + (xch_mask<MODEL, RW, RING, 1>() ? XCH_BYTES : 0), stream);
 }
 
@@ -1701,7 +1775,7 @@ static hipError_t launch_build(const FitArgs& a, hipStream_t stream) {
 template <int MODEL, bool R2, int RW, bool DENSE, int RING>
 static hipError_t launch_one(const FitArgs& a, hipStream_t stream) {
     if constexpr (MODEL == 2 && R2 && (RING == 1 || RING == 2)) {
-        if (a.cert_only && a.has_thresh && a.fail_count && !a.r2 && !a.offset_in)
+        if (a.cert_only && a.has_thresh && a.fail_count && a.open_rows && !a.r2 && !a.gain && !a.flag && !a.offset_in && !a.list_mode)
             return launch_build<MODEL, R2, RW, DENSE, RING, true>(a, stream);
     }
     return launch_build<MODEL, R2, RW, DENSE, RING, false>(a, stream);

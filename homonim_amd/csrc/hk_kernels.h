@@ -21,6 +21,8 @@ struct BuildRecord {
     explicit BuildRecord(const char* kernel_name);
     // the fused kernel: "fit_apply_kernel<MODEL,R2,RW,DENSE,RING,CERT_ONLY,WPB,BATCH>"
     BuildRecord(int model, bool r2, int rw, bool dense, int ring, bool cert_only, int wpb, bool batch);
+    // its list-launch twin: "fit_list_kernel<MODEL,R2,RW,DENSE,RING>"
+    BuildRecord(const char* kernel_name, int model, bool r2, int rw, bool dense, int ring);
     void hit() { __atomic_fetch_add(&launches, 1ull, __ATOMIC_RELAXED); }
 };
 // one record per launch SITE of a kernel outside the fused template: the site's local tag type names the kernel
@@ -100,8 +102,13 @@ struct FitArgs {
     float src_nodata, ref_nodata;
     int has_thresh;
     float r2_thresh;
-    int cert_only;          // gain-offset + r2 mask, no R2 plane, fail_count set: run the certificate-only build, which
-                            // ORs FIT_RETRY_BIT into fail_count[band] when the band has to be re-run (launch_one)
+    int cert_only;          // gain-offset + r2 mask, no R2 plane, fail_count and open_rows set: run the CERTIFICATE build (launch_one),
+                            // which settles a wave-row by the two-sided float32 certificate or marks it in `open_rows`
+    // Round 6: the wave-rows the certificate build cannot settle: one bit per (band, strip, row), 32 rows per word, word index
+    // (band * n_strips + strip) * ceil(height / 32) + row / 32 (zeroed before the certificate launch).
+    // list_mode != 0: THIS launch is the list launch -- the complete build on a persistent grid over the runs of marked rows.
+    unsigned* open_rows;
+    int list_mode;
     float r2_fail_scale;    // kappa of the division-free r2-mask certificate: 1 - r2_pass_scale(), rounded up (hk_api.hip)
     float r2_failcert_scale;  // kappa_f of its mirror image (certain FAILURE; complete build): 1 - r2_fail_above(), rounded down; -inf: none
     double r2_pass_below;   // exact evaluation without R2 output: ssres < r2_pass_below * sstot proves the r2 test true,

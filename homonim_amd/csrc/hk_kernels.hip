@@ -35,6 +35,10 @@ BuildRecord::BuildRecord(int model, bool r2, int rw, bool dense, int ring, bool 
              (int)batch);
     ledger_add(this);
 }
+BuildRecord::BuildRecord(const char* kernel_name, int model, bool r2, int rw, bool dense, int ring) {
+    snprintf(name, sizeof(name), "%s<%d,%d,%d,%d,%d>", kernel_name, model, (int)r2, rw, (int)dense, ring);
+    ledger_add(this);
+}
 size_t ledger_text(char* buf, size_t len, bool reset) {
     std::lock_guard<std::mutex> lk(ledger_mu());
     size_t need = 1;
@@ -162,11 +166,31 @@ __global__ void __launch_bounds__(256) synth_kernel(float* __restrict__ src, flo
             sv = 0.25f + (float)(h0 & 63ull) * 0.0078125f;
             r = 1.25f * sv + 0.125f;
         }
-        if (nodata_variant == 1 || nodata_variant == 2) {  // 1: NaN frame + 0.1 % holes, 2: NaN frame only
+        if (nodata_variant == 1 || nodata_variant == 2 || nodata_variant == 6) {  // 1: NaN frame + 0.1 % holes, 2: NaN frame only
             const bool frame = x < 3 || y < 3 || x >= width - 3 || y >= height - 3;
             const bool holes = nodata_variant == 1;
             if (frame || (holes && (h3 & 0xffffu) < 66u)) sv = qnan();            // ~0.1 %
             if (frame || (holes && ((h3 >> 16) & 0xffffu) < 66u)) r = qnan();
+            if (nodata_variant == 6) {
+                // 6: NaN frame + ~1 % of the area in round blobs 32 - 128 pixels across, source and reference independently -- what
+                // cloud / shadow masks look like (single-pixel holes at random are a worst case no sensor produces).  Every second
+                // 512 x 512 cell owns one blob (centre and radius hashed from the cell); a pixel looks at its cell and the 8 around it.
+                for (int salt = 0; salt < 2; ++salt) {
+                    bool in = false;
+                    for (int dy = -1; dy <= 1; ++dy)
+                        for (int dx = -1; dx <= 1; ++dx) {
+                            const long long cx = (x >> 9) + dx, cy = (y >> 9) + dy;
+                            const unsigned long long hc = mix64(((unsigned long long)band << 58) ^ ((unsigned long long)salt << 56) ^
+                                                                ((unsigned long long)(cy + 8) << 28) ^ (unsigned long long)(cx + 8) ^ mix64(seed ^ 0x6b10b5ull));
+                            if (hc & 1ull) {
+                                const long long bx = (cx << 9) + (long long)((hc >> 8) & 511ull), by = (cy << 9) + (long long)((hc >> 20) & 511ull);
+                                const long long rad = 16 + (long long)((hc >> 32) % 49ull), ddx = x - bx, ddy = y - by;
+                                in |= ddx * ddx + ddy * ddy <= rad * rad;
+                            }
+                        }
+                    if (in) (salt ? r : sv) = qnan();
+                }
+            }
         }
         const long long off = (long long)band * band_stride + (long long)y * stride + x;
         src[off] = sv;

@@ -68,8 +68,10 @@ typedef struct {
  */
 /* Version of this header's struct layouts and prototypes.  A consumer built against one header and loading a library of
  * another must not call further: structs grow at their end between versions (hk_out_window: 32 -> 40 bytes in version 3) and
- * carry no size field; version 5 added entry points (hk_device_pci_bus_id; hk_debug_staging_counters in the devtools header).  hk_abi_version() returns the library's HK_ABI_VERSION; compare it with the header's at load time. */
-#define HK_ABI_VERSION 5
+ * carry no size field; version 5 added entry points (hk_device_pci_bus_id; hk_debug_staging_counters in the devtools header); version 6: a raw
+ * r2-mask failure counter is always a count (HK_COUNT_RETRY is never set any more), and a device-resident job that carries `scratch`
+ * always gets the in-painting's inputs left there.  hk_abi_version() returns the library's HK_ABI_VERSION; compare it with the header's at load time. */
+#define HK_ABI_VERSION 6
 int hk_abi_version(void);
 const char* hk_backend_name(void);            /* "hip-gfx950" */
 const char* hk_last_error(void);              /* thread-local text of the last failure */
@@ -266,10 +268,11 @@ typedef struct {
      * out_col0 + out_cols must be multiples of 4 (or end at the job's last column).  Not with r2_inpaint_thresh. */
     int32_t out_row0, out_col0, out_rows, out_cols;
     /* Optional device scratch for gain-offset with an r2 threshold (else NULL / 0): hk_dev_job_scratch_bytes() bytes,
-     * 16-byte aligned, owned by the caller and tied to this job until its hk_inpaint_dev / hk_inpaint_dev_counts.  When the
-     * complete kernel build runs the job (r2-mask failures are expected, or the lighter build has just been sent back), it
-     * leaves the in-painting's inputs there -- offsets and the one-byte source flags (r2 > thresh) & (gain > 0) & valid
-     * (kernel_model.py:363) -- and the in-painting starts from them instead of running the fit once more. */
+     * 16-byte aligned, owned by the caller and tied to this job until its hk_inpaint_dev / hk_inpaint_dev_counts.  A job that
+     * carries it gets the in-painting's inputs left there by hk_fit_apply_dev -- offsets and the one-byte source flags
+     * (r2 > thresh) & (gain > 0) & valid (kernel_model.py:363), 5 bytes per pixel of stores -- and the in-painting starts from
+     * them instead of running the fit once more: provide it where pixels are expected to fail the r2 mask (real imagery:
+     * block after block), leave it NULL where they are not (the fit then runs its lighter build and moves 12 bytes per pixel). */
     void* scratch;
     uint64_t scratch_bytes;
 } hk_dev_job;
@@ -290,10 +293,10 @@ int hk_inpaint_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* job, 
  * copy of the job's counters into `host_counts` (n_bands values, pinned host memory: hk_host_alloc), their clearing and
  * the recording of `ready`; after hk_event_sync(ready) the caller passes the counts to hk_inpaint_dev_counts, which only
  * queues work.  Launch N + 1 (into a second counter buffer) may be queued before the counts of launch N are looked at.
- * A raw counter with HK_COUNT_RETRY set is not a count: gain-offset jobs that keep no R2 plane are first run with a
- * lighter kernel build that can only certify "no pixel fails", and the bit says it could not; hk_inpaint_dev /
- * hk_inpaint_dev_counts then run that band again with the complete build (job->fail_count must still be the job's
- * counter buffer) and report the true count in *n_fail_out.  Pass the counts on unchanged. */
+ * Pass the counts on unchanged.  (Up to ABI version 5 a raw counter could carry HK_COUNT_RETRY instead of a count: the lighter
+ * kernel build such jobs start with voided the whole band when it could not settle a wave-row.  Since version 6 that build marks
+ * the wave-rows it leaves open and a second launch of the complete build does exactly those: every counter is a count.  The
+ * constant stays defined for consumers written against the older header; the library never sets it.) */
 #define HK_COUNT_RETRY (1ull << 63)
 int hk_fail_counts_async(hk_ctx* ctx, const hk_dev_job* job, uint64_t* host_counts, hk_event* ready);
 /* 1 when the counts of a launch call for its second half (hk_inpaint_dev_counts): some band has failing pixels or must be

@@ -33,7 +33,8 @@ extern "C" {
 
 /* Fill device planes with the synthetic workload of SURVEY.md section 8(d) (src ~ U[0.05,1), ref = g*src+o+noise);
  * nodata_variant 0: none, 1: 3-px NaN frame + 0.1 % NaN holes, 2: frame only, 3 / 4: none, noisy reference (35 % / 85 % r2-mask failures), 5: low-entropy data (64 source levels, exactly affine reference:
- * the same instruction stream at a lower energy per launch).  Test/bench data only. */
+ * the same instruction stream at a lower energy per launch), 6: 3-px NaN frame + ~1 % of the area in round NaN blobs 32 - 128 px across, source and reference
+ * independently (cloud / shadow-mask-like).  Test/bench data only. */
 int hk_synth_fill_dev(hk_ctx* ctx, float* src, float* ref, int32_t n_bands, int32_t height, int32_t width,
                       int64_t stride, int64_t band_stride, uint64_t seed, int32_t nodata_variant, int32_t stream);
 

@@ -1061,9 +1061,9 @@ def test_r2_inpainting_of_a_block_taller_than_a_grid_dimension(ctx, oc):
 @pytest.mark.oracle
 def test_device_resident_job_with_inpainting(ctx, oc, with_params, split_api, scratch):
     """ hk_fit_apply_dev + hk_inpaint_dev on a 3-band job resident in HBM: only the bands whose r2 mask has failures
-    are in-painted; every band equals the oracle's whole reference branch.  Run twice: the second launch expects failures
-    (complete kernel build from the start).  `scratch`: the job carries hk_dev_job.scratch, so the pass that counts the
-    failures leaves offsets + source flags for the in-painting. """
+    are in-painted; every band equals the oracle's whole reference branch.  Run twice.  `scratch`: the job carries
+    hk_dev_job.scratch, so the pass that counts the failures (then the complete build) leaves offsets + source flags for the in-painting;
+    without, the certificate build + list launch count and the in-painting runs the fit once more for its inputs. """
     h, w, nb = 96, 300, 3
     stride = (w + 63) // 64 * 64
     band_stride = stride * h
@@ -1125,10 +1125,7 @@ def test_device_resident_job_with_inpainting(ctx, oc, with_params, split_api, sc
                 exp_params, exp_corr, exp_fail = oc.fit_apply('gain-offset', srcs[b], np.nan, refs[b], np.nan, (5, 5), False, 0.25)
                 exp_total += exp_fail
                 assert (exp_fail > 0) == (b == 1)
-                if int(counts[b]) >> 63:         # certificate-only build: "run this band again", done by hk_inpaint_dev*
-                    assert not with_params
-                else:
-                    assert int(counts[b]) == exp_fail
+                assert int(counts[b]) == exp_fail   # (a count, whichever builds ran: ABI 6)
                 assert_close_ulp(out['corr'][b, :, :w], exp_corr, f'band {b} corrected', max_frac=1e-3)
                 if with_params:
                     got = np.stack([out['gain'][b, :, :w], out['offset'][b, :, :w], out['r2'][b, :, :w]])
@@ -1157,111 +1154,72 @@ def _dev_job_corr_only(c, src, ref, thresh, kernel_shape=(5, 5)):
 
 
 @pytest.mark.oracle
-def test_certificate_only_build_and_its_rerun_protocol(oc, monkeypatch):
-    """ Gain-offset jobs that keep no R2 plane start with the certificate-only kernel build (hk_fit_kernel.h launch_one).
-    On rasters it settles, the result equals the complete build's bit for bit; where it cannot, the band's counter comes
-    back with HK_COUNT_RETRY, hk_inpaint_dev re-runs the band with the complete build (same results again), and the
-    context goes straight to the complete build for the next launches. """
-    RETRY = 1 << 63
-    clean_s, clean_r = onp.synth_pair(200, 900, 5, 'none')
-    noisy_r = clean_r.copy()
-    noisy_r[90:96, 300:330] = -2.0           # a patch the fit cannot explain: r2 failures
+@pytest.mark.parametrize('kernel_shape, nodata', [((5, 5), None), ((5, 5), np.nan), ((3, 7), None), ((15, 15), np.nan), ((9, 5), None), ((31, 31), np.nan)])
+def test_certificate_build_and_its_list_launch(oc, kernel_shape, nodata):
+    """ Gain-offset jobs that keep nothing but the corrected block start with the CERTIFICATE build (hk_fit_kernel.h launch_one:
+    a wave-row whose every valid pixel certainly passes the r2 mask is settled without the reference's R2 expression); the wave-rows
+    it cannot settle are marked in a bit plane and done by the LIST launch that follows -- the complete build over the runs of
+    marked rows.  Whatever the share of open rows -- none (clean), a patch, scattered failures, nearly all (noise) -- the two
+    launches together give the bytes of the complete build over the whole grid (which a job that also keeps the parameter planes
+    runs) and of the oracle, and the raw counter is the count (up to ABI 5 it could come back as HK_COUNT_RETRY).  With job scratch
+    the complete build runs and leaves the in-painting's inputs there: same results again. """
+    h, w = 200, 900
+    clean_s, clean_r = onp.synth_pair(h, w, 5, 'none' if nodata is None else 'frame+holes')
+    patch_r = clean_r.copy()
+    patch_r[90:96, 300:330] = -2.0                                    # a patch the fit cannot explain
+    rng = np.random.default_rng(4)
+    sparse_r = clean_r.copy()
+    sparse_r[rng.random((h, w)) < 0.002] = 7.0                         # failing windows all over: runs of a few rows everywhere
+    noisy_r = (clean_r + rng.normal(0, 0.5, (h, w))).astype(np.float32)  # most pixels fail: nearly every wave-row is open
     thresh = 0.25
-    desc = _hk.make_desc('gain-offset', (5, 5), False, thresh, None, None)
-
-    monkeypatch.setenv('HK_CERT_ONLY', '0')
-    full = _hk.Context(0, n_streams=1)       # complete build only
-    monkeypatch.delenv('HK_CERT_ONLY')
-    fresh = _hk.Context(0, n_streams=1)      # certificate-only first
+    desc = _hk.make_desc('gain-offset', kernel_shape, False, thresh, nodata, nodata)
+    c = _hk.Context(0, n_streams=1)
     try:
-        def run(c, src, ref):
+        def run(src, ref, keep_params=False, scratch=False):
             job, d = _dev_job_corr_only(c, src, ref, thresh)
             try:
+                if keep_params:   # parameter planes (R2 included): the complete build over the whole grid
+                    for k in ('gain', 'offset', 'r2'):
+                        d[k] = c.dev_alloc(4 * job.stride * job.height)
+                    job.gain, job.offset, job.r2 = d['gain'], d['offset'], d['r2']
+                if scratch:
+                    job.scratch_bytes = c.job_scratch_bytes(job)
+                    d['scratch'] = c.dev_alloc(job.scratch_bytes)
+                    job.scratch = d['scratch']
                 c.fit_apply_dev(desc, job)
                 c.stream_sync(0)
                 raw = np.zeros(1, np.uint64)
                 c.d2h(raw, d['fail'])
+                first = np.empty((job.height, job.stride), np.float32)
+                c.d2h(first, d['corr'])
                 n_fail = c.inpaint_dev(desc, job)
                 c.stream_sync(0)
                 corr = np.empty((job.height, job.stride), np.float32)
                 c.d2h(corr, d['corr'])
-                return int(raw[0]), n_fail, corr[:, :job.width].copy()
+                return int(raw[0]), n_fail, first[:, :job.width].copy(), corr[:, :job.width].copy()
             finally:
                 for v in d.values():
                     c.dev_free(v)
 
-        # (1) clean raster: settled by the certificate alone; same bytes as the complete build
-        raw_f, n_f, corr_f = run(full, clean_s, clean_r)
-        raw_c, n_c, corr_c = run(fresh, clean_s, clean_r)
-        assert raw_f == 0 and raw_c == 0 and n_f == 0 and n_c == 0
-        assert_same_f32(corr_c, corr_f, 'certificate-only vs complete build, clean raster')
-        _, exp_corr, exp_fail = oc.fit_apply('gain-offset', clean_s, None, clean_r, None, (5, 5), False, thresh)
-        assert exp_fail == 0
-        assert_close_ulp(corr_c, exp_corr, 'certificate-only build vs oracle', max_frac=1e-3)
-
-        # (2) failing pixels: the complete build counts them, the certificate-only one asks for the re-run; after
-        #     hk_inpaint_dev both hold the same in-painted result and the same count
-        raw_f, n_f, corr_f = run(full, clean_s, noisy_r)
-        raw_c, n_c, corr_c = run(fresh, clean_s, noisy_r)
-        _, exp_corr, exp_fail = oc.fit_apply('gain-offset', clean_s, None, noisy_r, None, (5, 5), False, thresh)
-        assert exp_fail > 0 and raw_f == exp_fail and n_f == exp_fail
-        assert raw_c & RETRY, 'the certificate-only build must give up on failing pixels'
-        assert n_c == exp_fail
-        assert_same_f32(corr_c, corr_f, 'certificate-only + re-run vs complete build, failing raster')
-        assert_close_ulp(corr_c, exp_corr, 'in-painted result vs oracle', max_frac=1e-3)
-
-        # (3) back-off: the launch after a re-run goes straight to the complete build (a true count, no re-run bit)
-        raw_c, n_c, corr_c2 = run(fresh, clean_s, noisy_r)
-        assert raw_c == exp_fail and n_c == exp_fail
-        assert_same_f32(corr_c2, corr_f, 'complete build after the back-off')
-
-        # (4) the host-pointer path (hk_fit_apply) does the re-run internally
-        fresh2 = _hk.Context(0, n_streams=1)
-        for c in (full, fresh2):
-            _, corr_h, _, n_h = c.fit_apply(desc, clean_s, noisy_r, 3, want_params=False, want_corr=True)
-            assert n_h == exp_fail
-            assert_same_f32(corr_h, corr_f, 'hk_fit_apply with failing pixels')
-            _, corr_h, _, n_h = c.fit_apply(desc, clean_s, clean_r, 3, want_params=False, want_corr=True)
-            assert n_h == 0
+        for name, ref in (('clean', clean_r), ('patch', patch_r), ('sparse', sparse_r), ('noisy', noisy_r)):
+            _, exp_corr, exp_fail = oc.fit_apply('gain-offset', clean_s, nodata, ref, nodata, kernel_shape, False, thresh)
+            raw_l, n_l, first_l, corr_l = run(clean_s, ref)                       # certificate build + list launch
+            raw_c, n_c, first_c, corr_c = run(clean_s, ref, keep_params=True)     # complete build over the whole grid
+            raw_s, n_s, first_s, corr_s = run(clean_s, ref, scratch=True)         # complete build, in-painting inputs in job scratch
+            assert raw_l == raw_c == raw_s == exp_fail == n_l == n_c == n_s, (name, raw_l, raw_c, raw_s, exp_fail)
+            assert (exp_fail == 0) == (name == 'clean')
+            assert_same_f32(first_l, first_c, f'{name}: first pass, certificate + list vs complete build')
+            assert_same_f32(first_s, first_c, f'{name}: first pass with job scratch vs complete build')
+            assert_same_f32(corr_l, corr_c, f'{name}: after in-painting, certificate + list vs complete build')
+            assert_same_f32(corr_s, corr_c, f'{name}: after in-painting from job scratch')
+            assert_close_ulp(corr_l, exp_corr, f'{name}: vs oracle', max_frac=1e-3)
+            # the host-pointer path (hk_fit_apply) runs the same pair of launches and the in-painting internally; the second call
+            # expects failures where the first found some (its first pass leaves the in-painting's inputs)
+            for _ in range(2):
+                _, corr_h, _, n_h = c.fit_apply(desc, clean_s, ref, 3, want_params=False, want_corr=True)
+                assert n_h == exp_fail
+                assert_same_f32(corr_h, corr_c, f'{name}: hk_fit_apply')
     finally:
-        full.close(), fresh.close()
-        if 'fresh2' in locals():
-            fresh2.close()
-
-
-def test_expectation_of_failures_expires_on_the_device_job_path(oc):
-    """ After an in-painting call that found failing pixels the context starts gain-offset launches with the complete kernel build
-    (true counts, in-painting inputs left in scratch).  On the device-job path the library sees the counts only inside
-    hk_inpaint_dev*, which a caller whose counts are all zero never calls -- the expectation must therefore run out by itself (a
-    count of launches), or every clean block after one noisy block pays the complete build forever.  Observable from outside:
-    the certificate-only build answers a raster with failing pixels with HK_COUNT_RETRY, the complete build with the count. """
-    RETRY = 1 << 63
-    clean_s, clean_r = onp.synth_pair(200, 900, 5, 'none')
-    noisy_r = clean_r.copy()
-    noisy_r[90:96, 300:330] = -2.0
-    desc = _hk.make_desc('gain-offset', (5, 5), False, 0.25, None, None)
-    _, _, exp_fail = oc.fit_apply('gain-offset', clean_s, None, noisy_r, None, (5, 5), False, 0.25)
-    c = _hk.Context(0, n_streams=1)
-    job, d = _dev_job_corr_only(c, clean_s, noisy_r, 0.25)
-    try:
-        def fit_only():
-            c.memset(d['fail'], 0, 8)
-            c.fit_apply_dev(desc, job)
-            c.stream_sync(0)
-            raw = np.zeros(1, np.uint64)
-            c.d2h(raw, d['fail'])
-            return int(raw[0])
-
-        assert fit_only() & RETRY                      # fresh context: certificate-only first
-        assert c.inpaint_dev(desc, job) == exp_fail    # re-run + in-painting: failures are expected from now on
-        raws = [fit_only() for _ in range(40)]         # ... launches nobody follows up with an in-painting call
-        assert all(r == exp_fail for r in raws[:8]), 'the expectation covers the next launches'
-        assert any(r & RETRY for r in raws), 'the expectation never ran out: the certificate-only build was not tried again'
-        first_retry = next(i for i, r in enumerate(raws) if r & RETRY)
-        assert all(r == exp_fail for r in raws[:first_retry])
-    finally:
-        for v in d.values():
-            c.dev_free(v)
         c.close()
 
 
@@ -1990,3 +1948,33 @@ def test_split_ring_on_rasters_smaller_than_the_kernel_or_the_strip(ctx, shape):
         got = _fit_via_abi(ctx, cfg, src, ref, norm_in=norm_in)
         assert_close_ulp(got[0], exp, f'{model} {k} on {shape}')
         assert_close_ulp(got[1], onp.apply(src, exp), f'{model} {k} on {shape}: corrected')
+
+
+@pytest.mark.oracle
+@pytest.mark.parametrize('model, kernel_shape, thresh', [('gain-offset', (5, 5), 0.25), ('gain-offset', (15, 15), 0.25), ('gain', (5, 5), None),
+                                                         ('gain-blk-offset', (15, 15), None), ('gain-offset', (31, 31), 0.25)])
+def test_clustered_holes_vs_oracle(ctx, oc, model, kernel_shape, thresh):
+    """ The synthetic workload's cloud / shadow-mask-like nodata (hk_synth_fill_dev variant 6: NaN frame + ~1 % of the area in round
+    holes 32 - 128 pixels across, source and reference independently; bench.py --nodata 6): wave-rows that leave a hole, run along
+    its edge or lie wholly inside one, against the C oracle (raster_array.py:298-308, utils.py:54-56). """
+    h, w = 1100, 1600
+    d_src, d_ref = ctx.dev_alloc(4 * h * w), ctx.dev_alloc(4 * h * w)
+    try:
+        ctx.synth_fill_dev(d_src, d_ref, 1, h, w, w, h * w, seed=4321, nodata_variant=6, stream=0)
+        ctx.stream_sync(0)
+        src, ref = np.empty((h, w), np.float32), np.empty((h, w), np.float32)
+        ctx.d2h(src, d_src), ctx.d2h(ref, d_ref)
+    finally:
+        ctx.dev_free(d_src), ctx.dev_free(d_ref)
+    holes = np.isnan(src[3:-3, 3:-3]).mean(), np.isnan(ref[3:-3, 3:-3]).mean()
+    assert all(0.002 < f < 0.05 for f in holes), holes
+    assert not np.array_equal(np.isnan(src), np.isnan(ref))           # independent masks
+    norm_in = oc.fit_block_norm(src, np.nan, ref, np.nan) if model == 'gain-blk-offset' else None
+    exp_p, exp_c, exp_fail = oc.fit_apply(model, src, np.nan, ref, np.nan, kernel_shape, False, thresh, norm_model=norm_in)
+    desc = _hk.make_desc(model, kernel_shape, False, thresh, np.nan, np.nan)
+    for want_params in (True, False):
+        params, corr, _, n_fail = ctx.fit_apply(desc, src, ref, exp_p.shape[0], want_params=want_params, want_corr=True, norm_in=norm_in)
+        assert_close_ulp(corr, exp_c, 'corrected')
+        if want_params:
+            assert_close_ulp(params, exp_p, 'params')
+        assert n_fail == (exp_fail if thresh is not None else 0)

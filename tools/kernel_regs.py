@@ -52,7 +52,7 @@ if __name__ == '__main__':
     ks = [k for obj in objs for k in kernels(obj)]
     grep = grep_text
     names = demangle([k['name'] for k in ks])
-    fit = [(k, n) for k, n in zip(ks, names) if 'fit_apply_kernel' in n]
+    fit = [(k, n) for k, n in zip(ks, names) if 'fit_apply_kernel' in n or 'fit_list_kernel' in n]
     bad = [(k, n) for k, n in fit if k['scratch'] or k['spills']]
     print(f'{len(ks)} kernels, {len(fit)} fused-kernel builds, {len(bad)} of them use scratch')
     for k, n in (bad if '--spills' in sys.argv else zip(ks, names)):

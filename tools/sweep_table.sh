@@ -17,6 +17,8 @@ run --kernel 7
 run --kernel 9
 run --kernel 15
 run --kernel 15 --nodata 1
+run --nodata 6
+run --kernel 15 --nodata 6
 run --model gain-blk-offset
 run --model gain-blk-offset --kernel 15 --bands 8
 run --nodata 3
