@@ -1978,3 +1978,20 @@ def test_clustered_holes_vs_oracle(ctx, oc, model, kernel_shape, thresh):
         if want_params:
             assert_close_ulp(params, exp_p, 'params')
         assert n_fail == (exp_fail if thresh is not None else 0)
+
+
+def test_checksum_of_a_device_window_is_the_sum_of_its_bit_patterns(ctx):
+    """ hk_debug_checksum_dev (bench.py `shard_checksum`: the union of N ranks' shards against the single-rank result): the sum of
+    the 32-bit patterns of a strided window, modulo 2^64 -- NaN payloads and negative zeros included. """
+    rng = np.random.default_rng(9)
+    h, w, stride = 301, 1003, 1024
+    a = rng.normal(0, 1e3, (h, stride)).astype(np.float32)
+    a[5, 7], a[6, 8], a[200, 1000] = np.nan, -0.0, np.float32('inf')
+    d = ctx.dev_alloc(4 * h * stride)
+    try:
+        ctx.h2d(d, a)
+        for y0, x0, hh, ww in ((0, 0, h, w), (17, 12, 100, 333), (300, 1002, 1, 1)):
+            exp = int(a[y0:y0 + hh, x0:x0 + ww].view(np.uint32).astype(np.uint64).sum(dtype=np.uint64))
+            assert ctx.checksum_dev(d + 4 * (y0 * stride + x0), stride, hh, ww) == exp
+    finally:
+        ctx.dev_free(d)

@@ -15,7 +15,7 @@ from conftest import BUILD_LEDGER, REPO
 pytestmark = pytest.mark.gpu
 
 # measurement / test aids of include/homonim_hk_devtools.h: no reference arithmetic to compare with
-AIDS = {'synth_kernel', 'stream_probe_kernel', 'selftest_kernel'}
+AIDS = {'synth_kernel', 'stream_probe_kernel', 'selftest_kernel', 'checksum_kernel'}
 
 
 def _write_report(path, universe):
