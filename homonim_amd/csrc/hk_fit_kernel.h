@@ -1332,7 +1332,8 @@ __device__ __forceinline__ void fit_unit(const FitArgs& a, const int band, const
                                     // whose every valid pixel is certain one way or the other needs no exact evaluation either:
                                     // on rasters with failing pixels (real imagery has them block after block) that is nearly
                                     // every row.
-                                    const f2 rhs_f = pk_fma(f2{a.r2_failcert_scale, a.r2_failcert_scale}, sst, -slack);
+                                    [[maybe_unused]] f2 rhs_f;
+                                    if constexpr (!CERT_ONLY) rhs_f = pk_fma(f2{a.r2_failcert_scale, a.r2_failcert_scale}, sst, -slack);
 #pragma unroll
                                     for (int e = 0; e < 2; ++e) {
                                         const bool m = (mcu >> (8 * (2 * j + e))) & 1u;
@@ -1341,17 +1342,23 @@ __device__ __forceinline__ void fit_unit(const FitArgs& a, const int band, const
                                         // 2^-20 < g < 2^20 (also the `gain > 0` half of the decision), 2^-40 < N*T' < 2^60;
                                         // a masked pixel's quantities are arbitrary and must not count
                                         const unsigned gd = __float_as_uint(g2[e]) - 0x35800000u, td = __float_as_uint(NT[e]) - 0x2b800000u;
-                                        // a pixel whose gain is not positive (or NaN) fails whatever its R2: no error model,
-                                        // no window needed for it
-                                        const bool gpos = g2[e] > 0.f;
-                                        // (the certificate build certifies PASSING rows only: the fail side and the source flags of the
-                                        // in-painting it feeds do not fit its 128 registers -- 3 to 10 spilled with them, measured)
-                                        const bool sure_f = CERT_ONLY ? false : (!gpos | ((lhs[e] < rhs_f[e]) & (lhs[e] > 0.f) & (sst[e] > slack[e])));
-                                        const bool mg = UN ? gpos : (m & gpos);
-                                        gwin = max(gwin, mg ? gd : 0u);
-                                        twin = max(twin, mg ? td : 0u);
-                                        uncertain |= m & !((sure & gpos) | sure_f);
-                                        cert_failed |= ((m & sure_f) ? 0xffu : 0u) << (8 * (2 * j + e));
+                                        if constexpr (CERT_ONLY) {
+                                            // the certificate build certifies PASSING rows only (the fail side and the source flags
+                                            // of the in-painting it feeds do not fit its 128 registers: 3 to 10 spilled with them)
+                                            gwin = max(gwin, UN ? gd : (m ? gd : 0u));
+                                            twin = max(twin, UN ? td : (m ? td : 0u));
+                                            uncertain |= m & !sure;
+                                        } else {
+                                            // a pixel whose gain is not positive (or NaN) fails whatever its R2: no error model,
+                                            // no window needed for it
+                                            const bool gpos = g2[e] > 0.f;
+                                            const bool sure_f = !gpos | ((lhs[e] < rhs_f[e]) & (lhs[e] > 0.f) & (sst[e] > slack[e]));
+                                            const bool mg = UN ? gpos : (m & gpos);
+                                            gwin = max(gwin, mg ? gd : 0u);
+                                            twin = max(twin, mg ? td : 0u);
+                                            uncertain |= m & !((sure & gpos) | sure_f);
+                                            cert_failed |= ((m & sure_f) ? 0xffu : 0u) << (8 * (2 * j + e));
+                                        }
                                     }
                                 }
                             }
