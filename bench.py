@@ -405,28 +405,16 @@ def run_resident(args, ctx, dist, rank, world):
     H = W = args.size
     B = args.bands
     k = args.kernel
-    stride = (W + 63) // 64 * 64 + int(os.environ.get('HK_BENCH_ROW_PAD', '0'))   # experiment: rows not a power of two apart
+    stride = (W + 63) // 64 * 64
     band_stride = stride * H
     plane_bytes = 4 * band_stride * B
     thresh = 0.25 if (args.model == 'gain-offset' and not args.no_thresh) else None
     nd = np.nan if args.nodata in (1, 2, 6) else None
     desc = _hk.make_desc(args.model, (k, k), bool(args.params), thresh, nd, nd)
 
-    # HK_BENCH_SKEW (bytes, a multiple of 16): plane i starts i * skew bytes into its allocation, so the six streams of a
-    # pixel position do not share their address bits below the allocation granule (experiment: DRAM channel aliasing)
-    skew = int(os.environ.get('HK_BENCH_SKEW', '0'))
     names = ('src', 'ref', 'corr') + (('gain', 'offset', 'r2') if args.params else ())
-    if os.environ.get('HK_BENCH_ONE_SLAB', '0') != '0':
-        # experiment: ONE allocation for all planes, back to back and 2 MB aligned.  The --params run (six planes, 24 B per
-        # pixel*band) is bimodal from PROCESS to process (5.1 / 6.2 ms) with either layout and with any HK_BENCH_SKEW
-        # (profiles/r02_params_slab.txt): not an address-phase effect inside the allocations
-        step = (plane_bytes + skew + (2 << 20) - 1) // (2 << 20) * (2 << 20)
-        slab = ctx.dev_alloc(step * len(names))
-        allocs = {name: slab for name in names[:1]}
-        bufs = {name: slab + i * step + i * skew for i, name in enumerate(names)}
-    else:
-        allocs = {name: ctx.dev_alloc(plane_bytes + skew * len(names)) for name in names}
-        bufs = {name: allocs[name] + i * skew for i, name in enumerate(names)}
+    allocs = {name: ctx.dev_alloc(plane_bytes) for name in names}
+    bufs = dict(allocs)
     bufs['fail'] = ctx.dev_alloc(8 * B)
     bufs['fail2'] = ctx.dev_alloc(8 * B)
     bufs['norm'] = ctx.dev_alloc(16 * B)
@@ -602,7 +590,7 @@ def run_blocks(args, ctx, dist, rank, world):
         win_in, win_out = bp.src_in_block, bp.src_out_block
         if (win_in.col_off % 4) or ((win_out.col_off - win_in.col_off) % 4):
             raise SystemExit(f'block origin {win_in.col_off} is not 16-byte aligned: kernel {k}x{k} needs a halo that is a multiple of 4')
-    stride = (W + 63) // 64 * 64 + int(os.environ.get('HK_BENCH_ROW_PAD', '0'))   # experiment: rows not a power of two apart
+    stride = (W + 63) // 64 * 64
     band_stride = stride * H
     nd = np.nan if args.nodata in (1, 2, 6) else None
     desc = _hk.make_desc(args.model, (k, k), False, None, nd, nd)
@@ -613,9 +601,7 @@ def run_blocks(args, ctx, dist, rank, world):
     copy_med, copy_best = probe_copy(ctx, bufs['src'], bufs['ref'], bufs['corr'], 4 * band_stride * B)
     n_streams = ctx.n_streams
 
-    # experiment (HK_BENCH_C3_BANDS_PER_JOB): fewer bands per launch, so that a job's statistics pass leaves its planes in the
-    # 256 MB Infinity Cache for its fit (a 4104 x 4104 in-block is 135 MB of src + ref per band)
-    bpj = int(os.environ.get('HK_BENCH_C3_BANDS_PER_JOB', str(B)))
+    bpj = B   # the bands of a block position share a launch
 
     def make_step(my_positions, norm_buf):
         """ the jobs of a rank that holds `my_positions` and the function that queues one step of them -> (step, jobs, batches) """
@@ -786,7 +772,7 @@ def run_tiles(args, ctx, dist, rank, world):
     nd = np.nan if args.nodata in (1, 2, 6) else None
     desc = _hk.make_desc(args.model, (k, k), False, thresh, nd, nd)
     mine = shard(list(range(T)), rank, world, contiguous=True)
-    stride = (n + 63) // 64 * 64 + int(os.environ.get('HK_BENCH_ROW_PAD', '0'))
+    stride = (n + 63) // 64 * 64
     band_stride = stride * n
     tile_bytes = 4 * band_stride * B
     n_streams = ctx.n_streams

@@ -770,6 +770,13 @@ constexpr int xch_mask() {
 #ifndef HK_CERT_WIDE_3WAVES
 #define HK_CERT_WIDE_3WAVES 1
 #endif
+// rows in flight of the kernels wider than 15: HK_PF_WIDE entering, HK_PO_WIDE leaving (see fit_unit; 1 / 1 measured best)
+#ifndef HK_PF_WIDE
+#define HK_PF_WIDE 1
+#endif
+#ifndef HK_PO_WIDE
+#define HK_PO_WIDE 1
+#endif
 template <int MODEL, bool R2, int RW, bool DENSE, int RING, bool CERT_ONLY>
 constexpr int fit_min_waves() {
     if (CERT_ONLY && RW >= 0 && RW <= 3) return 4;
@@ -780,6 +787,7 @@ constexpr int fit_min_waves() {
         // (round 6: with the LDS exchange lines the compiler issues a quantity's neighbour reads together -- 8 to 25 registers more
         // at the peak -- in the builds that use them: kernels taller than 39 rows)
         if (use_wline<RW, RING>() && MODEL == 2) return 2;
+        if (RW < 0 && (HK_PF_WIDE > 1 || HK_PO_WIDE > 1)) return 2;  // (rows in flight instead of a third wave: see fit_unit)
         if (RW < 0 && R2 && !CERT_ONLY) return 2;                          // wider than 15 with the R2 work (10 - 28 spilled registers at three)
         if (MODEL == 2 && R2 && !DENSE && RW == 3) return 2;               // gain-offset + R2, 7 wide, NaN-aware
         if (MODEL != 2 && R2 && !DENSE && RW >= 4 && RING == 2) return 2;  // gain / gain-blk-offset + R2, 9-15 wide, NaN-aware
@@ -836,7 +844,14 @@ __device__ __forceinline__ void fit_unit(const FitArgs& a, const int band, const
 #ifndef HK_PF_BLKA
 #define HK_PF_BLKA 1  // gain-blk-offset: 2 / 3 / 4 rows in flight measured the same at 15x15 (profiles/r03_blk15_ablation.txt)
 #endif
-    constexpr int PFD = (MODEL == 0 && !R2) ? HK_PF_GAIN : ((MODEL == 1 && !R2) ? HK_PF_BLKA : 1);
+    // Kernels wider than 15 (round 6, profiles/r06_pmcl_k31.txt): at 31 x 31 a wave spends 37 % of its life in s_waitcnt and 19 % in
+    // issue stalls with the VALU 22 % and the LDS array 45 % busy, and 82 % of its L2 requests go on to the fabric.  More rows in
+    // flight per wave (register queues of HK_PF_WIDE entering / HK_PO_WIDE leaving rows, two waves per SIMD for the registers) do
+    // NOT buy that time back: 2 / 2, 3 / 3, 4 / 4 and 3 / 1 rows all measured 5 - 15 % slower than one row each at three waves
+    // (profiles/r06_ab_prefetch.txt) -- the third wave covers more latency than the queues.  What did pay: the certificate builds of
+    // these widths now fetch their leaving row one iteration ahead like the others (it fits since the build lost its gain / R2
+    // stores): 17 / 21 / 31 wide 5.27 / 5.54 / 6.66 -> 4.94 / 5.23 / 6.22 ms.
+    constexpr int PFD = (MODEL == 0 && !R2) ? HK_PF_GAIN : ((MODEL == 1 && !R2) ? HK_PF_BLKA : (RW < 0 ? HK_PF_WIDE : 1));
     RowRaw q0 = load_row(sp, rp, a.stride, t_first, H, xq);
     [[maybe_unused]] RowRaw qq[PFD > 1 ? PFD - 1 : 1];
     if constexpr (PFD > 1) {
@@ -1004,10 +1019,18 @@ __device__ __forceinline__ void fit_unit(const FitArgs& a, const int band, const
     // RING 0 / 2: the re-loaded leaving row runs one iteration ahead where the registers allow it (not in the general
     // gain-offset kernels, which would spill)
     // (the builds of the kernels wider than 15 with the R2 work run at two waves per SIMD -- fit_min_waves -- and have the registers)
-    // ... and the certificate-only builds of those widths, which stay at three waves, do not: 4 - 6 registers short with the row in flight)
-    constexpr bool PF_OLD = !ring && !sring && (DENSE || MODEL != 2 || (RW < 0 && R2)) && !(RW < 0 && CERT_ONLY);
+    // ... and so do, since round 6, their certificate builds at three waves)
+    constexpr bool PF_OLD = !ring && !sring && (DENSE || MODEL != 2 || (RW < 0 && R2)) && !(RW < 0 && CERT_ONLY && HK_PO_WIDE < 1);
+    constexpr int POD = PF_OLD ? (RW < 0 ? (HK_PO_WIDE > 1 ? HK_PO_WIDE : 1) : 1) : 0;  // leaving rows in flight
     [[maybe_unused]] RowRaw qo_next;
-    if constexpr (PF_OLD) qo_next = load_row<HK_NT_LEAVE>(sp, rp, a.stride, t_first - kh, H, xq);
+    [[maybe_unused]] RowRaw qoq[POD > 1 ? POD - 1 : 1];
+    if constexpr (PF_OLD) {
+        qo_next = load_row<HK_NT_LEAVE>(sp, rp, a.stride, t_first - kh, H, xq);
+        if constexpr (POD > 1) {
+#pragma unroll
+            for (int d = 1; d < POD; ++d) qoq[d - 1] = load_row<HK_NT_LEAVE>(sp, rp, a.stride, t_first - kh + d, H, xq);
+        }
+    }
     // RING 1: the first leaving row is the zero row the ring was initialised with
     [[maybe_unused]] RowZ zold_next;
 #pragma unroll
@@ -1040,7 +1063,14 @@ __device__ __forceinline__ void fit_unit(const FitArgs& a, const int band, const
         if constexpr (PF_OLD) {
             // the leaving row is fetched one iteration ahead (it comes from L2 / the Infinity Cache): qo_next holds row t_old
             qo = qo_next;
-            qo_next = load_row<HK_NT_LEAVE>(sp, rp, a.stride, (HK_ABLATE & 1) ? t + 1 : t_old + 1, H, xq);
+            if constexpr (POD > 1) {
+                qo_next = qoq[0];
+#pragma unroll
+                for (int d = 1; d < POD - 1; ++d) qoq[d - 1] = qoq[d];
+                qoq[POD - 2] = load_row<HK_NT_LEAVE>(sp, rp, a.stride, t_old + POD, H, xq);
+            } else {
+                qo_next = load_row<HK_NT_LEAVE>(sp, rp, a.stride, (HK_ABLATE & 1) ? t + 1 : t_old + 1, H, xq);
+            }
         } else if constexpr (!ring && !sring) {
             qo = load_row<HK_NT_LEAVE>(sp, rp, a.stride, t_old, H, xq);
         }

@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/ab_batch.sh [config ...]: configs[3] / configs[4] with their jobs in 0 (one launch per job) / 1 / 2 / 4 batched launches
+# tools/ab/ab_batch.sh [config ...]: configs[3] / configs[4] with their jobs in 0 (one launch per job) / 1 / 2 / 4 batched launches
 run() { env $2 python3 bench.py $1 --no-cpu-baseline --no-end-to-end --no-other-configs --no-power-probe 2>/dev/null | tail -1 | python3 -c "
 import sys, json
 d = json.loads(sys.stdin.read()); r = d['roofline']

@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of library builds on one box:  tools/ab_libs.sh "<bench args>" lib1.so lib2.so ...   (each timed twice, interleaved)
+# A/B of library builds on one box:  tools/ab/ab_libs.sh "<bench args>" lib1.so lib2.so ...   (each timed twice, interleaved)
 args="$1"; shift
 run() { HOMONIM_AMD_LIB=$1 python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline $args 2>/dev/null | tail -1 | python3 -c "
 import sys, json

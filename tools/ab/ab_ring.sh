@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/ab_ring.sh lib "<bench args>" mode1 mode2 ...: HK_USE_RING modes of one library, twice each
+# tools/ab/ab_ring.sh lib "<bench args>" mode1 mode2 ...: HK_USE_RING modes of one library, twice each
 lib=$1; args="$2"; shift; shift
 run() { HK_USE_RING=$1 HOMONIM_AMD_LIB=$lib python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-nan-variant --no-other-configs --no-power-probe --no-end-to-end $args 2>/dev/null | tail -1 | python3 -c "
 import sys, json

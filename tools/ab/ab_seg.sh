@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/ab_seg.sh "<bench args>" seg1 seg2 ...
+# tools/ab/ab_seg.sh "<bench args>" seg1 seg2 ...
 args="$1"; shift
 run() { python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-nan-variant --no-other-configs --no-power-probe $args --seg-rows $1 2>/dev/null | tail -1 | python3 -c "
 import sys, json

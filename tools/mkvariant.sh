@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/mkvariant.sh NAME [-Dflag ...]: _ab/lib_NAME.so = current objects + hk_kernels.hip rebuilt with the given flags and EVERY
 # build of the fused kernel in that one translation unit (-DHK_FIT_ONE_TU; the product build has six, see mkvariant_tu.sh)
-# (dev subset: RW=2, RING=1 only -> seconds).  For A/B runs with tools/ab_quick.sh.
+# (dev subset: RW=2, RING=1 only -> seconds).  For A/B runs with tools/ab/ab_quick.sh.
 set -e
 cd "$(dirname "$0")/.."
 name=$1; shift

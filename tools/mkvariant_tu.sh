@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/mkvariant_tu.sh NAME MODEL R2 [-Dflag ...]: _ab/lib_NAME.so = the current objects with ONE translation unit of the fused kernel
-# (homonim_amd/csrc/hk_fit_tu.hip for MODEL 0|1|2, R2 0|1) rebuilt with the given flags.  For A/B runs with tools/ab_quick.sh.
+# (homonim_amd/csrc/hk_fit_tu.hip for MODEL 0|1|2, R2 0|1) rebuilt with the given flags.  For A/B runs with tools/ab/ab_quick.sh.
 set -e
 cd "$(dirname "$0")/.."
 name=$1; m=$2; r=$3; shift; shift; shift
