@@ -72,7 +72,7 @@ _f32p, _f64p, _u64p = _P(C.c_float), _P(C.c_double), _P(C.c_uint64)
 ABI_VERSION = 6   # HK_ABI_VERSION of the include/homonim_hk.h these mirrors were written against
 # entry points declared in include/homonim_hk_devtools.h (measurement / test aids), the rest in include/homonim_hk.h
 DEVTOOLS = ('hk_synth_fill_dev', 'hk_stream_probe_dev', 'hk_debug_stage_stamps', 'hk_r2_certificate_constants', 'hk_debug_staging_counters',
-            'hk_debug_build_ledger', 'hk_debug_checksum_dev')
+            'hk_debug_build_ledger', 'hk_debug_checksum_dev', 'hk_debug_fail_after_d2h')
 
 SIGNATURES = {
     'hk_abi_version': (C.c_int, []),
@@ -145,6 +145,7 @@ SIGNATURES = {
     'hk_debug_stage_stamps': (C.c_int, [C.c_void_p, _P(C.c_uint64), C.c_int32]),
     'hk_debug_staging_counters': (C.c_int, [_P(C.c_uint64), C.c_int32]),
     'hk_debug_build_ledger': (C.c_int, [C.c_char_p, C.c_size_t, _P(C.c_size_t), C.c_int32]),
+    'hk_debug_fail_after_d2h': (C.c_int, [C.c_int32]),
     'hk_debug_checksum_dev': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P(C.c_uint64)]),
 }  # yapf: disable
 
@@ -774,6 +775,11 @@ def staging_counters(reset: bool = False):
     out = (C.c_uint64 * 2)()
     _check(load_library().hk_debug_staging_counters(out, 1 if reset else 0))
     return int(out[0]), int(out[1])
+
+
+def debug_fail_after_d2h(on: bool):
+    """ Fault injection of the test-suite (hk_debug_fail_after_d2h): host-pointer fits fail behind their queued result copies. """
+    _check(load_library().hk_debug_fail_after_d2h(1 if on else 0))
 
 
 def build_ledger(reset: bool = False) -> dict:

@@ -483,6 +483,7 @@ PinnedRanges& pinned_ranges() {
 }
 // copies handed to the runtime straight from / to caller memory, and chunks that went through the staging ring (hk_debug_staging_counters)
 std::atomic<unsigned long long> g_direct_copies{0}, g_staged_chunks{0};
+std::atomic<int> g_fail_after_d2h{0};  // fault injection of the test-suite (hk_debug_fail_after_d2h)
 
 // is [p, p + bytes) inside one page-locked range of this library?
 bool host_is_pinned(const void* p, size_t bytes) { return bytes > 0 && pinned_ranges().covers(p, bytes); }
@@ -1256,11 +1257,10 @@ int run_host(hk_ctx* ctx, const hk_fit_desc* desc, const hk_io_desc* io, const v
     if (norm_out && blk)
         HK_HIP(hipMemcpyAsync(sl.pin<double>(Slot::PIN_NORM), d_norm, 2 * sizeof(double), hipMemcpyDeviceToHost, sl.stream));
     if ((rc = stage_out())) return rc;
-    {   // HK_TEST_FAIL_AFTER_D2H=1 (homonim_hk_devtools.h): the call fails HERE, its result copies queued and not yet unpacked --
-        // the state every HIP error between a stage_d2h and stage_finish leaves (tests/test_gpu_staging.py)
-        const char* e = getenv("HK_TEST_FAIL_AFTER_D2H");
-        if (e && atoi(e) != 0) return fail(HK_ERR_HIP, "HK_TEST_FAIL_AFTER_D2H: injected failure behind the result copies");
-    }
+    // hk_debug_fail_after_d2h(1) (homonim_hk_devtools.h): the call fails HERE, its result copies queued and not yet unpacked --
+    // the state every HIP error between a stage_d2h and stage_finish leaves (tests/test_gpu_staging.py)
+    if (g_fail_after_d2h.load(std::memory_order_relaxed))
+        return fail(HK_ERR_HIP, "hk_debug_fail_after_d2h: injected failure behind the result copies");
     *sl.fail_host = 0;
     if (pending.active) HK_HIP(hipMemcpyAsync(sl.fail_host, d_fail, sizeof(unsigned long long), hipMemcpyDeviceToHost, sl.stream));
     if ((rc = stage_finish(sl))) return rc;
@@ -1697,6 +1697,11 @@ int hk_debug_staging_counters(uint64_t out[2], int32_t reset) {
     if (!out) return fail(HK_ERR_ARG, "out is NULL");
     out[0] = g_direct_copies.load(), out[1] = g_staged_chunks.load();
     if (reset) g_direct_copies.store(0), g_staged_chunks.store(0);
+    return HK_OK;
+}
+
+int hk_debug_fail_after_d2h(int32_t on) {
+    g_fail_after_d2h.store(on != 0);
     return HK_OK;
 }
 

@@ -18,9 +18,6 @@
  *                       hk_host_alloc / hk_host_register holds all of it; with this switch the library also asks the HIP runtime
  *                       about every page of every row of such an array before the copy is queued and fails the call
  *                       (HK_ERR_ARG) if one is not page-locked host memory.  The test-suite runs with it.
- *   HK_TEST_FAIL_AFTER_D2H=1   (read at every call) fault injection for the test-suite: hk_fit / hk_fit_apply* on host pointers
- *                       fail right behind their queued result copies -- where a HIP error would leave them -- so that the
- *                       abandonment of those copies can be observed (no later call may write the failed call's output arrays).
  */
 #ifndef HOMONIM_HK_DEVTOOLS_H
 #define HOMONIM_HK_DEVTOOLS_H
@@ -65,6 +62,11 @@ int hk_debug_staging_counters(uint64_t out[2], int32_t reset);
  * `stream`, which is synchronised before the call returns. */
 int hk_debug_checksum_dev(hk_ctx* ctx, const float* plane, int64_t stride, int32_t height, int32_t width, int32_t stream,
                           uint64_t* sum_out);
+
+/* Test aid, fault injection: while on != 0, hk_fit / hk_fit_apply* on host pointers fail right behind their queued result copies --
+ * where a HIP error would leave them -- so that the abandonment of those copies can be observed (no later call may write the failed
+ * call's output arrays; no copy may still be in flight on them when the call returns).  Process-wide; switch it off again. */
+int hk_debug_fail_after_d2h(int32_t on);
 
 /* Test aid: the launch ledger.  Every kernel BUILD of the library -- each instantiation of the fused kernel's template
  * ("fit_apply_kernel<MODEL,R2,RW,DENSE,RING,CERT_ONLY,WPB,BATCH>"), each kernel of the statistics / in-painting / re-sampling /

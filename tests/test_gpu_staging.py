@@ -153,7 +153,7 @@ def test_a_view_over_two_registered_ranges_with_a_pageable_gap_is_staged():
 def test_an_error_between_the_copies_leaves_no_pointer_behind(monkeypatch):
     """ A host-pointer call that fails after it queued results for unpacking must not leave the caller's output pointer in the
     staging ring: the next call on that stream would unpack up to 8 MB into memory the caller has usually freed by then (round-4
-    advisor finding).  HK_TEST_FAIL_AFTER_D2H makes hk_fit_apply fail exactly there; afterwards the failed call's output array
+    advisor finding).  hk_debug_fail_after_d2h makes hk_fit_apply fail exactly there; afterwards the failed call's output array
     must stay as the caller left it, whatever runs on the context's streams. """
     ctx = _hk.Context(0, n_streams=1)   # one stream: the next call takes the failed call's slot
     try:
@@ -161,10 +161,12 @@ def test_an_error_between_the_copies_leaves_no_pointer_behind(monkeypatch):
         desc = _hk.make_desc('gain', (5, 5), False, None, None, None)
         _, exp, _, _ = ctx.fit_apply(desc, src, ref, 2, want_params=False, want_corr=True)
         victim = np.full(src.shape, -1.0, np.float32)
-        monkeypatch.setenv('HK_TEST_FAIL_AFTER_D2H', '1')
-        with pytest.raises(Exception, match='HK_TEST_FAIL_AFTER_D2H'):
-            ctx.fit_apply(desc, src, ref, 2, want_params=False, want_corr=True, out_corr=victim)
-        monkeypatch.delenv('HK_TEST_FAIL_AFTER_D2H')
+        _hk.debug_fail_after_d2h(True)
+        try:
+            with pytest.raises(Exception, match='hk_debug_fail_after_d2h'):
+                ctx.fit_apply(desc, src, ref, 2, want_params=False, want_corr=True, out_corr=victim)
+        finally:
+            _hk.debug_fail_after_d2h(False)
         victim[:] = -2.0   # "freed and re-used"
         for _ in range(6):   # more calls than the ring has chunks
             _, got, _, _ = ctx.fit_apply(desc, src, ref, 2, want_params=False, want_corr=True)
@@ -189,11 +191,13 @@ def test_an_error_behind_direct_copies_drains_them_before_the_call_returns(monke
         ps, pr, victim = ctx.pinned_empty((h, w)), ctx.pinned_empty((h, w)), ctx.pinned_empty((h, w))
         ps[:], pr[:], victim[:] = src, ref, -1.0
         _hk.staging_counters(reset=True)
-        monkeypatch.setenv('HK_TEST_FAIL_AFTER_D2H', '1')
-        with pytest.raises(Exception, match='HK_TEST_FAIL_AFTER_D2H'):
-            ctx.fit_apply(desc, ps, pr, 2, want_params=False, want_corr=True, out_corr=victim)
-        last_row_done = np.array_equal(np.array(victim[-1]), exp[-1], equal_nan=True)
-        monkeypatch.delenv('HK_TEST_FAIL_AFTER_D2H')
+        _hk.debug_fail_after_d2h(True)
+        try:
+            with pytest.raises(Exception, match='hk_debug_fail_after_d2h'):
+                ctx.fit_apply(desc, ps, pr, 2, want_params=False, want_corr=True, out_corr=victim)
+            last_row_done = np.array_equal(np.array(victim[-1]), exp[-1], equal_nan=True)
+        finally:
+            _hk.debug_fail_after_d2h(False)
         direct, staged = _hk.staging_counters()
         assert direct == 3 and staged == 0, (direct, staged)     # the three arrays went the direct way
         assert last_row_done, 'the failed call returned while its result copy was still in flight on the caller\'s array'
