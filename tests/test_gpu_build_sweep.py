@@ -73,8 +73,45 @@ CONFIGS = [  # (model, find_r2, thresh, nodata)
 ]
 
 
+def _dev_job_corrected_only(ctx, desc, src, ref):
+    """ hk_fit_apply_dev + hk_inpaint_dev of a device-resident job that keeps nothing but the corrected block and carries no scratch:
+    always the certificate build + its list launch (hk_api.hip launch_fit) -> (raw failure count, corrected block) """
+    h, w = src.shape
+    stride = (w + 3) // 4 * 4
+    pad = lambda a: np.ascontiguousarray(np.pad(a, ((0, 0), (0, stride - w))).astype(np.float32))  # noqa: E731
+    d = {k: ctx.dev_alloc(4 * stride * h) for k in ('src', 'ref', 'corr')}
+    d['fail'] = ctx.dev_alloc(8)
+    try:
+        ctx.h2d(d['src'], pad(src)), ctx.h2d(d['ref'], pad(ref))
+        ctx.memset(d['fail'], 0, 8)
+        job = _hk.DevJob()
+        job.src, job.ref, job.corr, job.fail_count = d['src'], d['ref'], d['corr'], d['fail']
+        job.gain = job.offset = job.r2 = job.norm = None
+        job.n_bands, job.height, job.width, job.stride, job.band_stride = 1, h, w, stride, stride * h
+        job.seg_rows, job.stream = 0, 0
+        ctx.fit_apply_dev(desc, job)
+        ctx.stream_sync(0)
+        raw = np.zeros(1, np.uint64)
+        ctx.d2h(raw, d['fail'])
+        ctx.inpaint_dev(desc, job)
+        ctx.stream_sync(0)
+        corr = np.empty((h, stride), np.float32)
+        ctx.d2h(corr, d['corr'])
+        return int(raw[0]), corr[:, :w].copy()
+    finally:
+        for v in d.values():
+            ctx.dev_free(v)
+
+
 def _check_shape(ctx, oc, model, find_r2, thresh, nodata, kshape, src, ref, what):
     norm = oc.fit_block_norm(src, nodata, ref, nodata) if model == 'gain-blk-offset' else None
+    if thresh is not None and kshape[0] in (3, 5, 9):
+        # with the r2 mask (one height per ring mode: the in-painting branch is the expensive part of this sweep): a patch the fit
+        # cannot explain, so that wave-rows stay open for the list launch, pixels fail and the in-painting branch runs -- in EVERY
+        # width's certificate / list / complete build, not only on the shapes the other tests happen to use
+        # (uncorrelated values, not a constant: a flat window has sstot = 0 exactly and its R2 is inf or NaN by the last bit of ssres)
+        ref = ref.copy()
+        ref[18:23, 90:131] = np.random.default_rng(5).uniform(-3, -1, (5, 41)).astype(np.float32)
     exp_p, exp_c, exp_fail = oc.fit_apply(model, src, nodata, ref, nodata, kshape, find_r2, thresh, norm_model=norm)
     desc = _hk.make_desc(model, kshape, find_r2, thresh, nodata, nodata)
     params, corr, _, n_fail = ctx.fit_apply(desc, src, ref, exp_p.shape[0], want_params=True, want_corr=True, norm_in=norm)
@@ -86,6 +123,11 @@ def _check_shape(ctx, oc, model, find_r2, thresh, nodata, kshape, src, ref, what
         _, corr_f, _, n_fail_f = ctx.fit_apply(desc, src, ref, exp_p.shape[0], want_params=False, want_corr=True, norm_in=norm)
         _same(corr_f, exp_c, f'{what}: corrected, fused')
         assert n_fail_f == (exp_fail if thresh is not None else 0), what
+        if thresh is not None and kshape[0] in (3, 5, 9):
+            assert exp_fail > 0, what
+            raw, corr_d = _dev_job_corrected_only(ctx, desc, src, ref)      # certificate build + list launch, then the in-painting
+            assert raw == exp_fail, (what, raw, exp_fail)
+            _same(corr_d, exp_c, f'{what}: corrected, device job (certificate build + list launch)')
 
 
 @pytest.mark.oracle
