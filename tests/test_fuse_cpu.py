@@ -255,6 +255,8 @@ assert dist.max_over_ranks(float(rank)) == world - 1
 assert dist.sum_over_ranks(float(rank)) == world * (world - 1) / 2
 blob = dist.broadcast_bytes(bytes(range(128)) if rank == 0 else None)
 assert blob == bytes(range(128))
+parts = dist.gather_bytes(b'rank %d' % rank + b'!' * rank)      # every rank's payload on every rank, in rank order
+assert parts == [b'rank %d' % r + b'!' * r for r in range(world)]
 slowest = dist.max_over_ranks(per_barrier_us)
 if rank == 0:
     print(json.dumps(dict(world=world, barrier_us=slowest)))
@@ -360,3 +362,36 @@ def test_a_rank_zero_without_rccl_tells_the_others(tmp_path):
                               stderr=subprocess.PIPE, text=True) for r in range(3)]
     outs = [p.communicate(timeout=100) for p in procs]
     assert all(p.returncode == 0 for p in procs), [e[-800:] for _, e in outs]
+
+
+def test_a_launch_that_spans_nodes_is_refused_at_once(monkeypatch):
+    """ The rendezvous is loopback TCP + a local file: a launch whose environment says it spans nodes (torchrun --nnodes 2:
+    LOCAL_WORLD_SIZE < WORLD_SIZE, GROUP_WORLD_SIZE 2) fails in dist.init with the reason, not after the 900 s rendezvous timeout
+    (round-5 advisor finding). """
+    from homonim_amd import dist
+    for env in (dict(WORLD_SIZE='16', LOCAL_WORLD_SIZE='8'), dict(WORLD_SIZE='8', LOCAL_WORLD_SIZE='8', GROUP_WORLD_SIZE='2'),
+                dict(WORLD_SIZE='8', NNODES='2')):
+        for k in ('WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'GROUP_WORLD_SIZE', 'NNODES'):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        monkeypatch.setenv('RANK', '1')
+        monkeypatch.setenv('HOMONIM_AMD_DIST_BACKEND', 'host')
+        with pytest.raises(RuntimeError, match='spans nodes'):
+            dist.init()
+    # one node, as torchrun describes it: accepted by the check
+    for k in ('LOCAL_WORLD_SIZE', 'GROUP_WORLD_SIZE', 'NNODES'):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv('LOCAL_WORLD_SIZE', '8'), monkeypatch.setenv('GROUP_WORLD_SIZE', '1')
+    dist._check_one_node(8)
+
+
+def test_a_launcher_that_names_no_launch_is_named_by_the_ranks_parent(monkeypatch):
+    """ mpirun / srun set RANK and WORLD_SIZE only: the rendezvous file is then named after the process that started the ranks, so
+    that two such launches of one user do not adopt each other's ranks (round-5 advisor finding). """
+    from homonim_amd import dist
+    for k in ('MASTER_PORT', 'TORCHELASTIC_RUN_ID', 'HOMONIM_AMD_LAUNCH_ID'):
+        monkeypatch.delenv(k, raising=False)
+    assert dist._launch_token() == f'ppid_{os.getppid()}'
+    monkeypatch.setenv('MASTER_PORT', '29500')
+    assert dist._launch_token().startswith('29500')

@@ -1,5 +1,6 @@
 """ Host placement (homonim_amd/topology.py): the sysfs parsers on a canned tree of a two-socket, eight-GPU node. """
 import os
+import sys
 
 import pytest
 
@@ -106,3 +107,33 @@ def test_a_worker_thread_binds_to_its_device_and_remembers_it(monkeypatch):
     assert os.sched_getaffinity(0) == before      # the calling (main) thread is untouched
     monkeypatch.setenv('HOMONIM_AMD_NO_BIND', '1')
     assert topology.bind_current_thread(0) is False
+
+
+def test_a_worker_bound_to_one_gpu_still_finds_the_cpus_of_another(monkeypatch, sysfs):
+    """ RasterFuse deals blocks round the models: a pool worker already bound to GPU A's node can be the first to ask for GPU B.  The
+    CPUs of B's node are taken from the PROCESS's baseline affinity, not from the calling thread's current one (which holds none of
+    them), and an empty answer is not remembered (round-5 advisor finding). """
+    import threading
+    import types
+    allowed = sorted(os.sched_getaffinity(0))
+    if len(allowed) < 2:
+        pytest.skip('needs two CPUs')
+    lo, hi = allowed[:1], allowed[-1:]
+    monkeypatch.setattr(topology, '_device_cpus', {})
+    monkeypatch.setattr(topology, '_thread_device', None)
+    monkeypatch.setattr(topology, '_BASELINE', allowed)
+    # devices 0 / 1 on two "nodes" made of the first / the last allowed CPU
+    monkeypatch.setattr(topology, 'placement_for', lambda bus, root='/sys', allowed_=None: dict(
+        bus_id=bus, numa_node=int(bus[-1]), cpus=[c for c in (lo if bus.endswith('0') else hi) if allowed_ is None or c in allowed_]))
+    fake_hk = types.SimpleNamespace(device_pci_bus_id=lambda d: f'0000:00:00.{d}')
+    import homonim_amd
+    monkeypatch.setattr(homonim_amd, '_hk', fake_hk, raising=False)
+    monkeypatch.setitem(sys.modules, 'homonim_amd._hk', fake_hk)
+    out = {}
+
+    def worker():
+        out['a'] = topology.bind_current_thread(0), sorted(os.sched_getaffinity(0))
+        out['b'] = topology.bind_current_thread(1), sorted(os.sched_getaffinity(0))   # asked from a thread that holds only `lo`
+    t = threading.Thread(target=worker)
+    t.start(), t.join()
+    assert out['a'] == (True, lo) and out['b'] == (True, hi), out
