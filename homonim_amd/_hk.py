@@ -637,7 +637,7 @@ class Context:
 
     def counts_pending(self, counts: np.ndarray) -> bool:
         """ Do the counters of a launch (``fail_counts_async``) call for its second half, ``inpaint_dev_counts``?  (failing
-        pixels in some band, or a band the lighter kernel build sent back: hk_counts_pending) """
+        pixels in some band: hk_counts_pending) """
         c = np.ascontiguousarray(counts, dtype=np.uint64)
         return bool(self._lib.hk_counts_pending(c.ctypes.data_as(_P(C.c_uint64)), int(c.size)))
 

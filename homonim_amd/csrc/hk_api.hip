@@ -1871,7 +1871,7 @@ int hk_r2_certificate_constants(float thresh, double* pass_below, double* fail_a
 int hk_counts_pending(const uint64_t* counts, int32_t n_bands) {
     if (!counts) return 0;
     for (int32_t b = 0; b < n_bands; ++b)
-        if (counts[b]) return 1;  // failing pixels, or HK_COUNT_RETRY
+        if (counts[b]) return 1;  // failing pixels
     return 0;
 }
 

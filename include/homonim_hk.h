@@ -299,9 +299,8 @@ int hk_inpaint_dev(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* job, 
  * constant stays defined for consumers written against the older header; the library never sets it.) */
 #define HK_COUNT_RETRY (1ull << 63)
 int hk_fail_counts_async(hk_ctx* ctx, const hk_dev_job* job, uint64_t* host_counts, hk_event* ready);
-/* 1 when the counts of a launch call for its second half (hk_inpaint_dev_counts): some band has failing pixels or must be
- * run again with the complete build; 0 when the launch's outputs are final.  Callers need not interpret the raw counters
- * (host-only, no device call). */
+/* 1 when the counts of a launch call for its second half (hk_inpaint_dev_counts): some band has failing pixels; 0 when the
+ * launch's outputs are final.  Callers need not interpret the raw counters (host-only, no device call). */
 int hk_counts_pending(const uint64_t* counts, int32_t n_bands);
 int hk_inpaint_dev_counts(hk_ctx* ctx, const hk_fit_desc* desc, const hk_dev_job* job, const uint64_t* counts,
                           uint64_t* n_fail_out);
