@@ -601,7 +601,7 @@ def run_blocks(args, ctx, dist, rank, world):
     copy_med, copy_best = probe_copy(ctx, bufs['src'], bufs['ref'], bufs['corr'], 4 * band_stride * B)
     n_streams = ctx.n_streams
 
-    bpj = B   # the bands of a block position share a launch
+    bpj = B   # the bands of a block position share a launch (fewer bands per job: no gain, also not for a rank's small shard -- profiles/r06_c3_rank.txt)
 
     def make_step(my_positions, norm_buf):
         """ the jobs of a rank that holds `my_positions` and the function that queues one step of them -> (step, jobs, batches) """
