@@ -931,7 +931,7 @@ static int ensure_inpaint_scratch(Slot& sl, size_t plane, int height, long long 
 }
 
 // gain-offset with the r2 mask when nothing but the corrected block (and, from scratch, the offsets) is asked for and the failures
-// are counted: the CERTIFICATE build runs first (124 - 126 registers, four waves per SIMD: the division-free float32 certificate of
+// are counted: the CERTIFICATE build runs first (118 - 126 registers, four waves per SIMD: the division-free float32 certificate of
 // PROOFS.md appendix A settles a wave-row whose every valid pixel certainly passes) and marks the wave-rows it cannot settle in
 // a bit plane; the LIST launch -- the complete build on a persistent grid, one run of marked rows per wave at a time -- follows on
 // the same stream and does those rows with the reference's own R2 expression.  Together they write every row once and count every

@@ -360,13 +360,12 @@ __device__ __forceinline__ void hsum_wide(const T (&V)[PX], T (&H)[PX], const Wi
 }
 
 // The float64 quantities of the kernels wider than 15 exchange their partial sums through wave-private LDS LINES instead of
-// ds_bpermute (round 6).  A ds_bpermute_b32 moves 4 bytes per lane and occupies the CU's LDS crossbar for 2.6 ns whichever SIMD
-// issued it (profiles/r05_ubench_xlane.txt); at 31 wide a gain-offset wave-row issues ~100 of them = 260 ns of a pipe the CU's
-// four SIMDs share, against ~150 ns of VALU issue.  A lane now writes its seven partial sums -- T = its four columns, suf1..3,
-// pre1..3 -- into seven LINES of one float64 per lane (structure of arrays: consecutive lanes touch consecutive 8-byte words, no
-// bank conflict; a first version with one 64-byte slot per lane ran 16-way conflicts and lost 50 %, profiles/r06_wline.txt) and
-// reads its neighbours' entries with ds_read_b64: at 31 wide 7 writes + 10 reads of 8 bytes instead of 20 ds_bpermute_b32 per
-// quantity.  Measured on the headline workload (profiles/r06_ab_wline.txt): 41 wide 9.54 -> 8.25 ms, 63 wide 13.2 -> 10.6 -- but 17 /
+// ds_bpermute (round 6).  A ds_bpermute_b32 moves 4 bytes per lane in 4 LDS-array cycles (2.6 ns of the CU's crossbar in
+// isolation, profiles/r05_ubench_xlane.txt); a ds_read_b64 moves 8 in 2.  A lane writes its seven partial sums -- T = its four
+// columns, suf1..3, pre1..3 -- into seven LINES of one float64 per lane (structure of arrays: consecutive lanes touch consecutive
+// 8-byte words, no bank conflict; a first version with one 64-byte slot per lane ran 16-way conflicts and lost 50 %,
+// profiles/r06_wline_aos.txt) and reads its neighbours' entries with ds_read_b64: at 31 wide 7 writes + 10 reads of 8 bytes
+// instead of 20 ds_bpermute_b32 per quantity, at 63 wide 7 + 18 instead of 36.  Measured on the headline workload (profiles/r06_ab_wline.txt): 41 wide 9.54 -> 8.25 ms, 63 wide 13.2 -> 10.6 -- but 17 /
 // 21 / 31 wide 5.27 / 5.54 / 6.66 -> 5.88 / 6.03 / 7.43: there the wave also holds a centre ring of kh / 2 + 1 rows in LDS, the
 // lines' 6.3 KB cost it three of ten resident waves per CU, and at three whole neighbour lanes 17 LDS operations replace 20.  So
 // the lines serve the builds that re-load both rows (RING 0: kernels taller than 39 rows, no LDS ring), ds_bpermute the others.
