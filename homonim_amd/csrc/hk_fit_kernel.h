@@ -518,11 +518,33 @@ __device__ __forceinline__ unsigned quot_range(double q) {
     return e ? e - 0x38100000u : 0u;
 }
 
+// A WAVE-UNIFORM global address as a scalar register pair that the optimiser cannot see through (SB builds, fit_scalar_bases()).
+// Row addresses are uniform (plane + row * stride) and a lane adds its 32-bit byte offset.  Left to itself the compiler
+// re-associates `(plane + lane offset) + row offset` and keeps `plane + lane offset` as a loop-invariant 64-bit VECTOR pair per
+// plane: two registers each (the headline's certificate build holds eight for its three planes).  Behind the opaque value the
+// lane's offset is added to a scalar row address at every access instead -- every build loses 2 to 10 registers that way
+// (profiles/r06b_scalar_base.txt), but most run the same or up to 5 % slower (`gain` 15 wide), so only the builds that gain an
+// occupancy step take it: the NaN-aware certificate builds wider than 15 with kw / 2 mod 4 = 1 .. 3, which were two registers short
+// of a third wave per SIMD (HISTORY.md 70).  The address space is kept: an opaque GENERIC pointer turns every access into a
+// flat_ instruction.
+typedef __attribute__((address_space(1))) char hk_gchar;
+__device__ __forceinline__ hk_gchar* row_address(const void* uniform_ptr) {
+    unsigned long long v = reinterpret_cast<unsigned long long>(uniform_ptr);
+    asm("" : "+s"(v));  // (not volatile: free to move with the access it serves)
+    return (hk_gchar*)v;
+}
+template <int MODEL, bool R2, int RW, bool DENSE, bool CERT_ONLY>
+constexpr bool fit_scalar_bases() { return MODEL == 2 && R2 && !DENSE && RW < -1 && CERT_ONLY; }
+
 // Streaming stores: the output planes are written once and never read by this launch -- non-temporal stores keep them
 // from displacing the rows the neighbouring strips still share in L2 (strip-march pattern: -2 %, tools/ubench_strips.hip)
 typedef float hk_v4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store4_nt(float4* p, float4 v) {
     __builtin_nontemporal_store(hk_v4{v.x, v.y, v.z, v.w}, reinterpret_cast<hk_v4*>(p));
+}
+typedef __attribute__((address_space(1))) hk_v4 hk_gv4;
+__device__ __forceinline__ void store4_nt(hk_gchar* p, float4 v) {
+    __builtin_nontemporal_store(hk_v4{v.x, v.y, v.z, v.w}, (hk_gv4*)p);
 }
 
 // RN64(1 / n) for window counts 0 .. HK_INV_N_MAX (entry 0 is never used for a stored pixel).  For a float32 t = M * 2^a (M a
@@ -556,13 +578,28 @@ constexpr unsigned RING_SENTINEL = 0x7fc0deadu;
 #ifndef HK_NT_LEAVE
 #define HK_NT_LEAVE true
 #endif
-template <bool NT = false>
+template <bool NT = false, bool SB = false>
 __device__ __forceinline__ RowRaw load_row(const float* __restrict__ sp, const float* __restrict__ rp, long long stride,
                                            int row, int height, unsigned xq) {
     const int rc = min(max(row, 0), height - 1);
+    RowRaw o;
+    if constexpr (SB) {
+        const hk_gchar* const ps = row_address(sp + (long long)rc * stride);
+        const hk_gchar* const pr = row_address(rp + (long long)rc * stride);
+        typedef __attribute__((address_space(1))) const hk_v4 gv4c;
+        hk_v4 sv, rv;
+        if constexpr (NT) {
+            sv = __builtin_nontemporal_load((gv4c*)(ps + xq));
+            rv = __builtin_nontemporal_load((gv4c*)(pr + xq));
+        } else {
+            sv = *(gv4c*)(ps + xq);
+            rv = *(gv4c*)(pr + xq);
+        }
+        o.s = make_float4(sv.x, sv.y, sv.z, sv.w), o.r = make_float4(rv.x, rv.y, rv.z, rv.w);
+        return o;
+    }
     const char* __restrict__ ps = reinterpret_cast<const char*>(sp + (long long)rc * stride);
     const char* __restrict__ pr = reinterpret_cast<const char*>(rp + (long long)rc * stride);
-    RowRaw o;
     if constexpr (NT) {
         typedef float f4v __attribute__((ext_vector_type(4)));
         const f4v sv = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(ps + xq));
@@ -780,8 +817,10 @@ template <int MODEL, bool R2, int RW, bool DENSE, int RING, bool CERT_ONLY>
 constexpr int fit_min_waves() {
     if (CERT_ONLY && RW >= 0 && RW <= 3) return 4;
     // (their certificate-only builds fit into 168 registers -- round 5: 17 wide on NaN-nodata rasters 6.46 -> 5.56 ms, 9 - 15 wide
-    // equal -- except kw / 2 mod 4 = 1 .. 3 beyond 15 wide, two registers short and as fast at two waves: profiles/r05_ab_cert_wide_waves.txt)
-    if (MODEL == 2 && R2 && !DENSE && (RW < 0 || RW >= 4) && !(CERT_ONLY && HK_CERT_WIDE_3WAVES && RW >= -1)) return HK_FIT_MIN_WAVES_WIDE;
+    // equal.  Beyond 15 wide with kw / 2 mod 4 = 1 .. 3 they were two registers short -- a loop-invariant 64-bit vector address pair
+    // per plane -- and take their row addresses as opaque scalars since round 6 (row_address, fit_scalar_bases): 19 / 21 / 23 wide
+    // on NaN-nodata rasters 6.45 -> 5.78 ms, 31 wide 7.1 -> 6.9, profiles/r06b_ab_scalar_base.txt)
+    if (MODEL == 2 && R2 && !DENSE && (RW < 0 || RW >= 4) && !(CERT_ONLY && HK_CERT_WIDE_3WAVES && RW < 0)) return HK_FIT_MIN_WAVES_WIDE;
     if (HK_NOSPILL) {
         // (round 6: with the LDS exchange lines the compiler issues a quantity's neighbour reads together -- 8 to 25 registers more
         // at the peak -- in the builds that use them: kernels taller than 39 rows)
@@ -810,6 +849,7 @@ __device__ __forceinline__ void fit_unit(const FitArgs& a, const int band, const
     // order of the float64 window summation itself a last-bit freedom of a float64 quantity whose
     // float32 quotient it moves with probability ~1e-8 per pixel; it halves the kernel's float64 work.
     constexpr bool GO = MODEL == 2, BLK = MODEL == 1 && R2, BLKA = MODEL == 1 && !R2;
+    constexpr bool SB = fit_scalar_bases<MODEL, R2, RW, DENSE, CERT_ONLY>();  // row addresses as opaque scalars (row_address)
     constexpr bool USE_N = GO || R2 || BLKA;
     constexpr bool UNIFORM_N = GO || BLKA;  // builds that track wave-rows whose every window is complete and all-valid
     static_assert(!(DENSE && MODEL == 1), "gain-blk-offset re-derives its mask from the normalised source");
@@ -851,11 +891,11 @@ __device__ __forceinline__ void fit_unit(const FitArgs& a, const int band, const
     // these widths now fetch their leaving row one iteration ahead like the others (it fits since the build lost its gain / R2
     // stores): 17 / 21 / 31 wide 5.27 / 5.54 / 6.66 -> 4.94 / 5.23 / 6.22 ms.
     constexpr int PFD = (MODEL == 0 && !R2) ? HK_PF_GAIN : ((MODEL == 1 && !R2) ? HK_PF_BLKA : (RW < 0 ? HK_PF_WIDE : 1));
-    RowRaw q0 = load_row(sp, rp, a.stride, t_first, H, xq);
+    RowRaw q0 = load_row<false, SB>(sp, rp, a.stride, t_first, H, xq);
     [[maybe_unused]] RowRaw qq[PFD > 1 ? PFD - 1 : 1];
     if constexpr (PFD > 1) {
 #pragma unroll
-        for (int d = 1; d < PFD; ++d) qq[d - 1] = load_row(sp, rp, a.stride, min(t_first + d, t_last), H, xq);
+        for (int d = 1; d < PFD; ++d) qq[d - 1] = load_row<false, SB>(sp, rp, a.stride, min(t_first + d, t_last), H, xq);
     }
 
     const bool full_wave = __all((int)(x >= 0 && x + PX <= W));        // no column of this strip needs zeroing
@@ -1024,10 +1064,10 @@ __device__ __forceinline__ void fit_unit(const FitArgs& a, const int band, const
     [[maybe_unused]] RowRaw qo_next;
     [[maybe_unused]] RowRaw qoq[POD > 1 ? POD - 1 : 1];
     if constexpr (PF_OLD) {
-        qo_next = load_row<HK_NT_LEAVE>(sp, rp, a.stride, t_first - kh, H, xq);
+        qo_next = load_row<HK_NT_LEAVE, SB>(sp, rp, a.stride, t_first - kh, H, xq);
         if constexpr (POD > 1) {
 #pragma unroll
-            for (int d = 1; d < POD; ++d) qoq[d - 1] = load_row<HK_NT_LEAVE>(sp, rp, a.stride, t_first - kh + d, H, xq);
+            for (int d = 1; d < POD; ++d) qoq[d - 1] = load_row<HK_NT_LEAVE, SB>(sp, rp, a.stride, t_first - kh + d, H, xq);
         }
     }
     // RING 1: the first leaving row is the zero row the ring was initialised with
@@ -1066,14 +1106,14 @@ __device__ __forceinline__ void fit_unit(const FitArgs& a, const int band, const
                 qo_next = qoq[0];
 #pragma unroll
                 for (int d = 1; d < POD - 1; ++d) qoq[d - 1] = qoq[d];
-                qoq[POD - 2] = load_row<HK_NT_LEAVE>(sp, rp, a.stride, t_old + POD, H, xq);
+                qoq[POD - 2] = load_row<HK_NT_LEAVE, SB>(sp, rp, a.stride, t_old + POD, H, xq);
             } else {
-                qo_next = load_row<HK_NT_LEAVE>(sp, rp, a.stride, (HK_ABLATE & 1) ? t + 1 : t_old + 1, H, xq);
+                qo_next = load_row<HK_NT_LEAVE, SB>(sp, rp, a.stride, (HK_ABLATE & 1) ? t + 1 : t_old + 1, H, xq);
             }
         } else if constexpr (!ring && !sring) {
-            qo = load_row<HK_NT_LEAVE>(sp, rp, a.stride, t_old, H, xq);
+            qo = load_row<HK_NT_LEAVE, SB>(sp, rp, a.stride, t_old, H, xq);
         }
-        if constexpr (RING == 0) qc = load_row(sp, rp, a.stride, y_c, H, xq);
+        if constexpr (RING == 0) qc = load_row<false, SB>(sp, rp, a.stride, y_c, H, xq);
 
         const RowZ znew = process_row<MODEL, DENSE, MODEL == 1 && R2>(q0, t >= 0 && t < H, colbits, full_wave, ts, tr, n0, n1);
         HK_STAMP(0);  // requests of this iteration issued, entering row arrived and classified
@@ -1081,9 +1121,9 @@ __device__ __forceinline__ void fit_unit(const FitArgs& a, const int band, const
             q0 = qq[0];
 #pragma unroll
             for (int d = 1; d < PFD - 1; ++d) qq[d - 1] = qq[d];
-            qq[PFD - 2] = load_row(sp, rp, a.stride, min(t + PFD, t_last), H, xq);
+            qq[PFD - 2] = load_row<false, SB>(sp, rp, a.stride, min(t + PFD, t_last), H, xq);
         } else {
-            q0 = load_row(sp, rp, a.stride, min(t + 1, t_last), H, xq);  // next row (see above)
+            q0 = load_row<false, SB>(sp, rp, a.stride, min(t + 1, t_last), H, xq);  // next row (see above)
         }
         if constexpr (UNIFORM_N && !DENSE) {
             if (!znew.clean) last_dirty = t;  // wave-uniform
@@ -1445,8 +1485,14 @@ __device__ __forceinline__ void fit_unit(const FitArgs& a, const int band, const
                             // two-sided certificate cannot settle is marked for the LIST launch that follows (the complete build
                             // over the runs of marked rows, FitArgs::open_rows) -- nothing of it is stored or counted here
                             if (exact) {
-                                if (lane == ol)  // the first output lane (always active here: a strip has output columns)
-                                    atomicOr(a.open_rows + ((size_t)(band * a.n_strips + strip) * (size_t)((H + 31) >> 5) + (size_t)(y >> 5)), 1u << (y & 31));
+                                if (lane == ol) {  // the first output lane (always active here: a strip has output columns)
+                                    // The word's address is formed HERE, from a value the optimiser cannot see through: hoisted out of the
+                                    // row loop its loop-invariant part sat in a register pair for the sake of this rare path (the two
+                                    // registers the NaN-aware builds wider than 15 lacked for a third wave per SIMD, HISTORY.md 70).
+                                    int unit_u = band * a.n_strips + strip;   // (wave-uniform: a scalar register)
+                                    if constexpr (SB) asm volatile("" : "+s"(unit_u));
+                                    atomicOr(a.open_rows + ((size_t)unit_u * (size_t)((H + 31) >> 5) + (size_t)(y >> 5)), 1u << (y & 31));
+                                }
                                 return;  // (skipping stage C also keeps the allocation spill-free)
                             }
                         } else if (exact) {
@@ -1567,7 +1613,10 @@ __device__ __forceinline__ void fit_unit(const FitArgs& a, const int band, const
                     // stride % 4 == 0: a quad never crosses the row end, columns >= W land in the row padding
                     // wave-uniform row offset (scalar) + this lane's 32-bit byte offset: no per-plane address registers
                     const long long row_off = out_base + (long long)y * a.stride;
-                    auto at = [&](float* plane) { return reinterpret_cast<float4*>(reinterpret_cast<char*>(plane + row_off) + xbytes); };
+                    auto at = [&](float* plane) {
+                        if constexpr (SB) return row_address(plane + row_off) + xbytes;
+                        else return reinterpret_cast<float4*>(reinterpret_cast<char*>(plane + row_off) + xbytes);
+                    };
                     if (a.corr && !((HK_ABLATE & 8) && c[0] != 123.456f)) store4_nt(at(a.corr), make_float4(c[0], c[1], c[2], c[3]));
                     if constexpr (!CERT_ONLY) {  // (the certificate build serves launches without a gain / R2 plane: launch_one)
                         if (a.gain) store4_nt(at(a.gain), masked4(g));
@@ -1624,7 +1673,7 @@ __global__ void __launch_bounds__(WAVE * WPB, (fit_min_waves<MODEL, R2, RW, DENS
 fit_apply_kernel(const FitArgs a_in) {
     extern __shared__ float4 lds4[];
 
-    const int lane = threadIdx.x & (WAVE - 1), wave_in_wg = threadIdx.x >> 6;
+    const int lane = threadIdx.x & (WAVE - 1), wave_in_wg = (WPB == 1 && fit_scalar_bases<MODEL, R2, RW, DENSE, CERT_ONLY>()) ? 0 : threadIdx.x >> 6;  // (a constant there: `strip` is scalar)
     int group = blockIdx.x;
     if (a_in.xcd_remap) {
         // workgroups go round-robin to the 8 XCDs (each with its own L2): hand every XCD runs of `xcd_remap` consecutive
