@@ -533,8 +533,11 @@ __device__ __forceinline__ hk_gchar* row_address(const void* uniform_ptr) {
     asm("" : "+s"(v));  // (not volatile: free to move with the access it serves)
     return (hk_gchar*)v;
 }
-template <int MODEL, bool R2, int RW, bool DENSE, bool CERT_ONLY>
-constexpr bool fit_scalar_bases() { return MODEL == 2 && R2 && !DENSE && RW < -1 && CERT_ONLY; }
+template <int MODEL, bool R2, int RW, bool DENSE, int RING, bool CERT_ONLY>
+constexpr bool fit_scalar_bases() {
+    return (MODEL == 2 && R2 && !DENSE && RW < -1 && CERT_ONLY) ||      // gain-offset + r2 mask, NaN-aware, wider than 15 (kw / 2 mod 4 != 0)
+           (MODEL == 0 && !R2 && !DENSE && RING == 3 && (RW == 5 || RW == 6));  // gain, NaN-aware split ring, 11 / 13 wide
+}
 
 // Streaming stores: the output planes are written once and never read by this launch -- non-temporal stores keep them
 // from displacing the rows the neighbouring strips still share in L2 (strip-march pattern: -2 %, tools/ubench_strips.hip)
@@ -829,7 +832,11 @@ constexpr int fit_min_waves() {
         if (RW < 0 && R2 && !CERT_ONLY) return 2;                          // wider than 15 with the R2 work (10 - 28 spilled registers at three)
         if (MODEL == 2 && R2 && !DENSE && RW == 3) return 2;               // gain-offset + R2, 7 wide, NaN-aware
         if (MODEL != 2 && R2 && !DENSE && RW >= 4 && RING == 2) return 2;  // gain / gain-blk-offset + R2, 9-15 wide, NaN-aware
-        if (RING == 3 && !DENSE && MODEL == 0 && RW >= 5) return 2;        // gain, NaN-aware split ring, 11-15 wide
+        // gain, NaN-aware split ring: 15 wide stays at two waves (175 registers); 11 / 13 wide take their row addresses as opaque
+        // scalars (fit_scalar_bases) and fit three: 3.33 -> 3.05 / 3.52 -> 3.40 ms on NaN-nodata rasters -- at 15 rows the ring's
+        // 16 KB allow ten waves per CU whatever the registers say and the tighter allocation ran 2 % slower
+        // (profiles/r06b_scalar_base.txt)
+        if (RING == 3 && !DENSE && MODEL == 0 && RW == 7) return 2;
     }
     return HK_FIT_MIN_WAVES;
 }
@@ -849,7 +856,7 @@ __device__ __forceinline__ void fit_unit(const FitArgs& a, const int band, const
     // order of the float64 window summation itself a last-bit freedom of a float64 quantity whose
     // float32 quotient it moves with probability ~1e-8 per pixel; it halves the kernel's float64 work.
     constexpr bool GO = MODEL == 2, BLK = MODEL == 1 && R2, BLKA = MODEL == 1 && !R2;
-    constexpr bool SB = fit_scalar_bases<MODEL, R2, RW, DENSE, CERT_ONLY>();  // row addresses as opaque scalars (row_address)
+    constexpr bool SB = fit_scalar_bases<MODEL, R2, RW, DENSE, RING, CERT_ONLY>();  // row addresses as opaque scalars (row_address)
     constexpr bool USE_N = GO || R2 || BLKA;
     constexpr bool UNIFORM_N = GO || BLKA;  // builds that track wave-rows whose every window is complete and all-valid
     static_assert(!(DENSE && MODEL == 1), "gain-blk-offset re-derives its mask from the normalised source");
@@ -1673,7 +1680,7 @@ __global__ void __launch_bounds__(WAVE * WPB, (fit_min_waves<MODEL, R2, RW, DENS
 fit_apply_kernel(const FitArgs a_in) {
     extern __shared__ float4 lds4[];
 
-    const int lane = threadIdx.x & (WAVE - 1), wave_in_wg = (WPB == 1 && fit_scalar_bases<MODEL, R2, RW, DENSE, CERT_ONLY>()) ? 0 : threadIdx.x >> 6;  // (a constant there: `strip` is scalar)
+    const int lane = threadIdx.x & (WAVE - 1), wave_in_wg = (WPB == 1 && fit_scalar_bases<MODEL, R2, RW, DENSE, RING, CERT_ONLY>()) ? 0 : threadIdx.x >> 6;  // (a constant there: `strip` is scalar)
     int group = blockIdx.x;
     if (a_in.xcd_remap) {
         // workgroups go round-robin to the 8 XCDs (each with its own L2): hand every XCD runs of `xcd_remap` consecutive
