@@ -533,6 +533,16 @@ __device__ __forceinline__ hk_gchar* row_address(const void* uniform_ptr) {
     asm("" : "+s"(v));  // (not volatile: free to move with the access it serves)
     return (hk_gchar*)v;
 }
+// A plane pointer READ FROM A TABLE in device memory (the job table of a batched launch) carries no address space the compiler
+// could infer: every access through it became a flat_ instruction -- which counts on the LDS counter too, so that a wait for the
+// row ring also waited for the global stream (the batched builds of configs[3] ran that way from round 3 to round 6).  The
+// planes live in device memory: the pointer is rebuilt as a global one behind an opaque scalar (a plain cast pair is folded away).
+template <typename T>
+__device__ __forceinline__ T* table_pointer(T* uniform_ptr) {
+    unsigned long long v = reinterpret_cast<unsigned long long>(uniform_ptr);
+    asm("" : "+s"(v));
+    return (T*)(__attribute__((address_space(1))) T*)v;
+}
 template <int MODEL, bool R2, int RW, bool DENSE, int RING, bool CERT_ONLY>
 constexpr bool fit_scalar_bases() {
     return (MODEL == 2 && R2 && !DENSE && RW < -1 && CERT_ONLY) ||      // gain-offset + r2 mask, NaN-aware, wider than 15 (kw / 2 mod 4 != 0)
@@ -1706,8 +1716,9 @@ fit_apply_kernel(const FitArgs a_in) {
         const FitJob& e = a_in.jobs[lo];
         group -= e.first_group[FG];
         a_job = a_in;
-        a_job.src = e.src, a_job.ref = e.ref, a_job.gain = e.gain, a_job.offset = e.offset, a_job.r2 = e.r2, a_job.corr = e.corr;
-        a_job.norm = e.norm, a_job.fail_count = e.fail_count, a_job.flag = e.flag;
+        a_job.src = table_pointer(e.src), a_job.ref = table_pointer(e.ref), a_job.gain = table_pointer(e.gain);
+        a_job.offset = table_pointer(e.offset), a_job.r2 = table_pointer(e.r2), a_job.corr = table_pointer(e.corr);
+        a_job.norm = table_pointer(e.norm), a_job.fail_count = table_pointer(e.fail_count), a_job.flag = table_pointer(e.flag);
         a_job.stride = e.stride, a_job.band_stride = e.band_stride, a_job.height = e.height, a_job.width = e.width;
         a_job.n_bands = e.n_bands, a_job.seg_rows = e.seg_rows, a_job.n_strips = e.n_strips, a_job.n_segs = e.n_segs;
         a_job.seg_rows_tail = e.seg_rows_tail, a_job.n_segs_big = e.n_segs_big;

@@ -349,9 +349,13 @@ __global__ void __launch_bounds__(WAVE) norm_stream_kernel(const NormArgs a, Nor
         const int lo4 = ok ? lane * PX : 0;
         // read once: non-temporal, so the pass does not push the rows a tall fit kernel of another stream is about to
         // re-read out of L2 / the memory-side cache (configs[3], four streams: -4 %)
+        // (explicitly global: a plane pointer that came out of a batched launch's plane table carries no address space the compiler
+        // could infer, and these were flat_load instructions -- which count on the LDS counter too, so that every wait for the
+        // compaction queues waited for the stream as well -- until round 6)
         typedef float f4v __attribute__((ext_vector_type(4)));
-        const f4v sv = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(sp + o + lo4));
-        const f4v rv = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(rp + o + lo4));
+        typedef __attribute__((address_space(1))) const f4v gf4v;
+        const f4v sv = __builtin_nontemporal_load((gf4v*)(sp + o + lo4));
+        const f4v rv = __builtin_nontemporal_load((gf4v*)(rp + o + lo4));
         s4 = make_float4(sv.x, sv.y, sv.z, sv.w), r4 = make_float4(rv.x, rv.y, rv.z, rv.w);
         x = ok ? (pc * WAVE + lane) * PX : pl.width;
         pit += G, py += dy, pc += dc;
