@@ -106,13 +106,19 @@ struct PlaneRef {
 __device__ __forceinline__ PlaneRef plane_of(const NormArgs& a, int p) {
     PlaneRef r;
     if (a.planes != nullptr) {
-        const NormPlane& e = a.planes[p];
-        r.sp = e.src, r.rp = e.ref, r.stride = e.stride, r.height = e.height, r.width = e.width;
+        const __attribute__((address_space(1))) NormPlane* const e = (const __attribute__((address_space(1))) NormPlane*)a.planes + p;  // (the table lives in device memory)
+        r.sp = e->src, r.rp = e->ref, r.stride = e->stride, r.height = e->height, r.width = e->width;
     } else {
         r.sp = a.src + (long long)p * a.band_stride, r.rp = a.ref + (long long)p * a.band_stride;
         r.stride = a.stride, r.height = a.height, r.width = a.width;
     }
     return r;
+}
+
+// element i of a plane: an explicitly GLOBAL load -- a plane pointer out of a batched launch's table carries no address space the
+// compiler could infer and would be read with flat_ instructions (tests/test_isa_cpu.py keeps the library free of them)
+__device__ __forceinline__ float plane_at(const float* plane, long long i) {
+    return *((__attribute__((address_space(1))) const float*)plane + i);
 }
 
 __device__ __forceinline__ double wave_sum(double v) {  // fixed butterfly order -> deterministic
@@ -200,7 +206,7 @@ __global__ void __launch_bounds__(SAMPLE_THREADS) norm_sample_kernel(const NormA
             const long long p = (long long)j * step + (long long)(hsh % (unsigned long long)step);
             if (p < total) {
                 const int y = (int)(p / pl.width), x = (int)(p % pl.width);
-                const float s = sp[(long long)y * pl.stride + x], r = rp[(long long)y * pl.stride + x];
+                const float s = plane_at(sp, (long long)y * pl.stride + x), r = plane_at(rp, (long long)y * pl.stride + x);
                 if (nvalid(s, a.src_nd_mode, a.src_nodata) && nvalid(r, a.ref_nd_mode, a.ref_nodata)) {
                     const float v = q ? r : s;
                     samp[atomicAdd(&cnt, 1u)] = v;
@@ -554,7 +560,7 @@ __global__ void __launch_bounds__(NORM_THREADS) norm_mid_hist_kernel(const NormA
         for (int y = blockIdx.x; y < pl.height; y += gridDim.x) {
             const long long row = (long long)y * pl.stride;
             for (int x = threadIdx.x; x < pl.width; x += NORM_THREADS) {
-                const float s = pl.sp[row + x], r = pl.rp[row + x];
+                const float s = plane_at(pl.sp, row + x), r = plane_at(pl.rp, row + x);
                 if (nvalid(s, a.src_nd_mode, a.src_nodata) && nvalid(r, a.ref_nd_mode, a.ref_nodata))
                     hist_add(hist, LEVEL, (f2key(q ? r : s) - kb) << ksh, pfx);
             }
@@ -609,7 +615,7 @@ __global__ void __launch_bounds__(NORM_THREADS) norm_full_hist_kernel(const Norm
     for (int y = blockIdx.x; y < pl.height; y += gridDim.x) {
         const long long row = (long long)y * pl.stride;
         for (int x = threadIdx.x; x < pl.width; x += NORM_THREADS) {
-            const float s = sp[row + x], r = rp[row + x];
+            const float s = plane_at(sp, row + x), r = plane_at(rp, row + x);
             if (nvalid(s, a.src_nd_mode, a.src_nodata) && nvalid(r, a.ref_nd_mode, a.ref_nodata))
                 hist_add(hist, LEVEL, (f2key(q ? r : s) - kb) << ksh, pfx);
         }
