@@ -10,6 +10,7 @@ Bars (DESIGN.md "Numerics contract"):
 * gain-blk-offset: same, given the same block normalisation; the normalisation itself (exact float64 statistics on
   the GPU vs numpy's float32 pairwise ones) within 2e-6 relative.
 """
+import os
 import warnings
 
 import numpy as np
@@ -223,7 +224,8 @@ def test_randomized_configurations_vs_oracle(ctx, oc, seed, monkeypatch):
     onto them (HK_WAVE_SLOTS / HK_SEG_BIG / HK_SEG_TAIL), any kernel shape of the first two groups.  The bar is the suite's: bit-exact
     but for <= 1e-5 of the pixels by <= 2 ulp (rounds 2 - 5 allowed this test 2e-3; nothing in it needs that). """
     import warnings
-    rng = np.random.default_rng(1000 + seed)
+    # (HK_TEST_SEED_BASE: soak runs over other draws of the same space -- profiles/r06b_soak.txt; the suite's own draws are 1000 + seed)
+    rng = np.random.default_rng(int(os.environ.get('HK_TEST_SEED_BASE', '1000')) + seed)
     model = ['gain', 'gain-blk-offset', 'gain-offset'][rng.integers(3)]
     if seed < 120 or (seed >= 180 and seed % 2):
         kshape = (int(rng.choice([1, 3, 5, 7, 9, 15, 17])), int(rng.choice([1, 3, 5, 7, 9, 13, 15])))
@@ -272,7 +274,11 @@ def test_randomized_configurations_vs_oracle(ctx, oc, seed, monkeypatch):
         assert (np.isnan(got_r2) == np.isnan(exp_r2)).all(), what
         ok = np.isfinite(exp_r2) & np.isfinite(got_r2)
         assert (np.isinf(got_r2) == np.isinf(exp_r2)).all(), what
-        assert np.allclose(got_r2[ok], exp_r2[ok], rtol=1e-3, atol=1e-3), what
+        # (... and wherever the gain's own denominator N*sum(s^2) - sum(s)^2 cancels: two valid pixels with sources 0.10686 and 0.10691
+        # make a gain of rounding noise and an R2 of 0.45 here against 0.97 in the oracle -- a soak over 960 other draws met three
+        # such windows, profiles/r06b_soak.txt; a handful of pixels may differ, a defect moves thousands)
+        n_bad = int(np.count_nonzero(~np.isclose(got_r2[ok], exp_r2[ok], rtol=1e-3, atol=1e-3)))
+        assert n_bad <= max(3, int(1e-5 * ok.sum())), f'{what}: R2 of {n_bad} pixels'
         params, exp_params = params[:2], exp_params[:2]
     assert_close_ulp(params, exp_params, 'params: ' + what)
     assert_close_ulp(corr, exp_corr, 'corrected: ' + what)
