@@ -305,7 +305,21 @@ __device__ __forceinline__ float bperm_at(float v, int addr) { return __int_as_f
 __device__ __forceinline__ double bperm_at(double v, int addr) {
     return __hiloint2double(__builtin_amdgcn_ds_bpermute(addr, __double2hiint(v)), __builtin_amdgcn_ds_bpermute(addr, __double2loint(v)));
 }
-template <int E, typename T>
+// The WHOLE lanes of a wide window: those at distance 1 .. F - 1, and the lanes F too where the window takes them whole for all four
+// outputs (rw mod 4 = 3: 23, 31, 39 ... wide).  W = the farthest whole lane.  For ODD W >= 3 (31 wide; 33 - 37 wide; ...) they can be
+// summed as PAIRS (round 6): A = T + T(right neighbour) is one DPP move per word away, and the window of 2 W + 1 lanes is W pairs --
+// the two next to the lane a DPP move away from A -- and the single lane at its right end: W - 1 values through the crossbar
+// instead of 2 W - 2 (31 wide: 16 ds_bpermute instead of 20 per float64 quantity).  31 wide 6.55 -> 6.28 ms, on NaN-nodata rasters
+// 7.05 -> 6.77, 33 - 37 wide -7 ... -8 %; even W gains nothing (the pairs save little and A delays the first fetch), and with the
+// decision taken inside the row loop the widths that do not pair ran 2 - 3 % slower (profiles/r06b_ab_pairs.txt): the paired
+// form is a BUILD of its own (RW = -5 - E instead of -1 - E; the centre-ring builds of every model, launch_wide).  As builds of
+// their own (profiles/r06b_ab_pair_builds.txt): gain-offset + r2 mask 31 wide 6.28 -> 5.88 ms, on NaN-nodata rasters 6.89 -> 6.41,
+// 33 / 35 wide 6.92 / 7.72 -> 6.25 / 6.79; without the r2 mask 31 wide 5.65 -> 5.19; gain-blk-offset 31 wide -3 %, gain 35 wide -6 %.
+__host__ __device__ constexpr int wide_e(int rw_code) { return rw_code >= -PX ? -1 - rw_code : -1 - PX - rw_code; }  // rw mod 4 of a wide build
+__host__ __device__ constexpr bool wide_paired(int rw_code) { return rw_code < -PX; }
+__host__ __device__ constexpr int wide_whole_lanes(int e, int f) { return lane_full_for_all(2 * PX + e, 2) ? f : f - 1; }
+__host__ __device__ constexpr bool wide_pairs(int e, int f) { return wide_whole_lanes(e, f) >= 3 && (wide_whole_lanes(e, f) & 1); }
+template <int E, typename T, bool PAIR = false>
 __device__ __forceinline__ void hsum_wide(const T (&V)[PX], T (&H)[PX], const WideLanes& wl, int lane) {
     constexpr int RV = 2 * PX + E;  // the virtual half-width whose lanes 2 and 3 stand for the lanes F and F + 1
     T pre[PX + 1], suf[PX + 1];     // pre[k] = V[0..k-1], suf[k] = V[4-k..3]
@@ -316,27 +330,45 @@ __device__ __forceinline__ void hsum_wide(const T (&V)[PX], T (&H)[PX], const Wi
     suf[2] = V[2] + V[3];
     suf[3] = V[1] + suf[2];
     pre[4] = suf[4] = pre[2] + suf[2];
-    // the lane's own four columns and the whole lanes at distance 1 .. F - 1
+    // the lane's own four columns and the whole lanes (PAIR: see above; the launch made sure that W is odd and >= 3)
+    constexpr bool FULL2 = lane_full_for_all(RV, 2);
     T common = pre[PX];
-    if (wl.f >= 2) {  // wave-uniform (F = 1: a tall kernel 9 - 15 wide on the everything-re-loaded path)
-        common = common + dpp_from_left(pre[PX]);
-        common = common + dpp_from_right(pre[PX]);
-    }
-    for (int j = 2; j < wl.f; ++j) {  // wave-uniform
-        common = common + bperm_from<T>(pre[PX], lane - j);
-        common = common + bperm_from<T>(pre[PX], lane + j);
+    if constexpr (PAIR) {
+        const int W = FULL2 ? wl.f : wl.f - 1;  // wave-uniform
+        // pairs (o, o + 1) for o = -W, ..., -3, [-1], [1], 3, ..., W - 2 (in brackets: a DPP move away from A)
+        const T A = pre[PX] + dpp_from_right(pre[PX]);
+        common = bperm_from<T>(pre[PX], lane + W);
+        common = common + dpp_from_left(A);
+        common = common + dpp_from_right(A);
+        for (int o = 3; o <= W - 2; o += 2) common = common + bperm_from<T>(A, lane + o);  // (wave-uniform trip counts)
+        for (int o = 3; o <= W; o += 2) common = common + bperm_from<T>(A, lane - o);
+    } else {
+        if (wl.f >= 2) {  // wave-uniform (F = 1: a tall kernel 9 - 15 wide on the everything-re-loaded path)
+            common = common + dpp_from_left(pre[PX]);
+            common = common + dpp_from_right(pre[PX]);
+        }
+        for (int j = 2; j < wl.f; ++j) {  // wave-uniform
+            common = common + bperm_from<T>(pre[PX], lane - j);
+            common = common + bperm_from<T>(pre[PX], lane + j);
+        }
     }
     static_for<2, 4>([&](auto J) {
         constexpr int j = decltype(J)::value;
         T ls[PX + 1], rp[PX + 1];
         static_for<1, PX + 1>([&](auto K) {
             constexpr int k = decltype(K)::value;
-            if constexpr (need_left_at(RV, j, k)) ls[k] = bperm_at(suf[k], j == 2 ? wl.lf1 + 4 : wl.lf1);
-            if constexpr (need_right_at(RV, j, k)) rp[k] = bperm_at(pre[k], j == 2 ? wl.rf : wl.rf + 4);
+            if constexpr (PAIR && j == 2 && k == PX && FULL2) {
+                // (the lanes F as a whole: part of the pairs above)
+            } else {
+                if constexpr (need_left_at(RV, j, k)) ls[k] = bperm_at(suf[k], j == 2 ? wl.lf1 + 4 : wl.lf1);
+                if constexpr (need_right_at(RV, j, k)) rp[k] = bperm_at(pre[k], j == 2 ? wl.rf : wl.rf + 4);
+            }
         });
         if constexpr (lane_full_for_all(RV, j)) {
-            common = common + ls[PX];
-            common = common + rp[PX];
+            if constexpr (!PAIR) {
+                common = common + ls[PX];
+                common = common + rp[PX];
+            }
         } else {
             static_for<0, PX>([&](auto I) {
                 constexpr int i = decltype(I)::value;
@@ -379,7 +411,7 @@ constexpr size_t WLINE_BYTES = 7 * (size_t)WLINE_STRIDE;    // 6.3 KB per wave
 #endif
 template <int RW, int RING>
 constexpr bool use_wline() { return HK_WLINE && RW < 0 && RING == 0; }
-template <int E>
+template <int E, bool PAIR = false>
 __device__ __forceinline__ void hsum_wide_line(const double (&V)[PX], double (&H)[PX], const WideLanes& wl, int lane, char* line) {
     constexpr int RV = 2 * PX + E;
     double pre[PX + 1], suf[PX + 1];
@@ -398,14 +430,26 @@ __device__ __forceinline__ void hsum_wide_line(const double (&V)[PX], double (&H
         *reinterpret_cast<double*>(line + (3 + k) * WLINE_STRIDE) = pre[k];
     }
     xch_order();
+    // the whole lanes: the same terms in the same order as hsum_wide (PAIR: pairs of neighbouring lanes, see there)
+    constexpr bool FULL2 = lane_full_for_all(RV, 2);
     double common = pre[PX];
-    if (wl.f >= 2) {  // wave-uniform
-        common = common + dpp_from_left(pre[PX]);
-        common = common + dpp_from_right(pre[PX]);
-    }
-    for (int j = 2; j < wl.f; ++j) {  // wave-uniform: the whole lanes beyond the DPP neighbours
-        common = common + at(line - j * 8, 0);
-        common = common + at(line + j * 8, 0);
+    if constexpr (PAIR) {
+        const int W = FULL2 ? wl.f : wl.f - 1;  // wave-uniform
+        const double tl = dpp_from_left(pre[PX]), tr = dpp_from_right(pre[PX]);
+        common = at(line + W * 8, 0);
+        common = common + (tl + pre[PX]);               // the pairs (-1, 0) and (1, 2)
+        common = common + (tr + at(line + 2 * 8, 0));
+        for (int o = 3; o <= W - 2; o += 2) common = common + (at(line + o * 8, 0) + at(line + (o + 1) * 8, 0));
+        for (int o = 3; o <= W; o += 2) common = common + (at(line - o * 8, 0) + at(line - (o - 1) * 8, 0));
+    } else {
+        if (wl.f >= 2) {  // wave-uniform
+            common = common + dpp_from_left(pre[PX]);
+            common = common + dpp_from_right(pre[PX]);
+        }
+        for (int j = 2; j < wl.f; ++j) {  // wave-uniform: the whole lanes beyond the DPP neighbours
+            common = common + at(line - j * 8, 0);
+            common = common + at(line + j * 8, 0);
+        }
     }
     static_for<2, 4>([&](auto J) {
         constexpr int j = decltype(J)::value;
@@ -415,12 +459,17 @@ __device__ __forceinline__ void hsum_wide_line(const double (&V)[PX], double (&H
         double ls[PX + 1], rp[PX + 1];
         static_for<1, PX + 1>([&](auto K) {
             constexpr int k = decltype(K)::value;
-            if constexpr (need_left_at(RV, j, k)) ls[k] = at(lb, k == PX ? 0 : k);
-            if constexpr (need_right_at(RV, j, k)) rp[k] = at(rb, k == PX ? 0 : 3 + k);
+            if constexpr (PAIR && j == 2 && k == PX && FULL2) {
+            } else {
+                if constexpr (need_left_at(RV, j, k)) ls[k] = at(lb, k == PX ? 0 : k);
+                if constexpr (need_right_at(RV, j, k)) rp[k] = at(rb, k == PX ? 0 : 3 + k);
+            }
         });
         if constexpr (lane_full_for_all(RV, j)) {
-            common = common + ls[PX];
-            common = common + rp[PX];
+            if constexpr (!PAIR) {
+                common = common + ls[PX];
+                common = common + rp[PX];
+            }
         } else {
             static_for<0, PX>([&](auto I) {
                 constexpr int i = decltype(I)::value;
@@ -444,7 +493,7 @@ __device__ __forceinline__ void hsum_wide_line(const double (&V)[PX], double (&H
     xch_order();  // the next quantity rewrites the lines: every read above has been issued (LDS operations of a wave run in order)
 }
 
-// RW >= 0: compile-time half-width; RW = -1 - E: wide kernel with rw mod 4 == E (hsum_wide).  DPP2: see hsum.
+// RW >= 0: compile-time half-width; RW = -1 - E: wide kernel with rw mod 4 == E (hsum_wide), RW = -5 - E: its paired form.  DPP2: see hsum.
 // `xch`: the lane's slot of the LDS exchange line (XCH builds of hsum; the float64 sums of the wide kernels: hsum_wide_line)
 template <int RW, typename T, bool XCH = false, bool DPP2 = false, bool WLINE = false>
 __device__ __forceinline__ void hsum_any(const T (&V)[PX], T (&H)[PX], const WideLanes& wl, int lane, char* xch = nullptr) {
@@ -454,9 +503,9 @@ __device__ __forceinline__ void hsum_any(const T (&V)[PX], T (&H)[PX], const Wid
     } else if constexpr (RW >= 0)
         hsum<RW, T, XCH, DPP2>(V, H, lane, xch);
     else if constexpr (WLINE && std::is_same<T, double>::value) {
-        hsum_wide_line<-1 - RW>(V, H, wl, lane, xch);
+        hsum_wide_line<wide_e(RW), wide_paired(RW)>(V, H, wl, lane, xch);
     } else
-        hsum_wide<-1 - RW, T>(V, H, wl, lane);
+        hsum_wide<wide_e(RW), T, wide_paired(RW)>(V, H, wl, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -545,7 +594,7 @@ __device__ __forceinline__ T* table_pointer(T* uniform_ptr) {
 }
 template <int MODEL, bool R2, int RW, bool DENSE, int RING, bool CERT_ONLY>
 constexpr bool fit_scalar_bases() {
-    return (MODEL == 2 && R2 && !DENSE && RW < -1 && CERT_ONLY) ||      // gain-offset + r2 mask, NaN-aware, wider than 15 (kw / 2 mod 4 != 0)
+    return (MODEL == 2 && R2 && !DENSE && RW < 0 && (wide_e(RW) != 0 || wide_paired(RW)) && CERT_ONLY) ||  // gain-offset + r2 mask, NaN-aware, wider than 15 (kw / 2 mod 4 != 0, or paired)
            (MODEL == 0 && !R2 && !DENSE && RING == 3 && (RW == 5 || RW == 6));  // gain, NaN-aware split ring, 11 / 13 wide
 }
 
@@ -1887,6 +1936,18 @@ static hipError_t launch_one(const FitArgs& a, hipStream_t stream) {
 // kernels wider than 15 (and the everything-re-loaded path from 9 wide): rw mod 4 picks the build, rw / 4 is a launch argument
 template <int MODEL, bool R2, bool DENSE, int RING>
 static hipError_t launch_wide(const FitArgs& a, hipStream_t stream) {
+    // the paired form of the whole-lane sums (hsum_wide): builds of their own on the centre ring (kernels up to 39 rows tall; the
+    // LDS-line variant of the taller ones reads the same number of entries either way)
+    if constexpr (RING == 2) {
+        if (wide_pairs(a.rw & 3, a.rw / PX)) {
+            switch (a.rw & 3) {
+                case 0: return launch_one<MODEL, R2, -5, DENSE, RING>(a, stream);
+                case 1: return launch_one<MODEL, R2, -6, DENSE, RING>(a, stream);
+                case 2: return launch_one<MODEL, R2, -7, DENSE, RING>(a, stream);
+                default: return launch_one<MODEL, R2, -8, DENSE, RING>(a, stream);
+            }
+        }
+    }
     switch (a.rw & 3) {
         case 0: return launch_one<MODEL, R2, -1, DENSE, RING>(a, stream);
         case 1: return launch_one<MODEL, R2, -2, DENSE, RING>(a, stream);

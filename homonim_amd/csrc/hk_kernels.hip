@@ -302,6 +302,19 @@ __device__ int hsum_wide_check(int lane) {
     for (int f = 1; f <= 6; ++f) {
         const int rw = PX * f + E, ol = (rw + PX - 1) / PX;
         const WideLanes wl = make_wide_lanes(rw, lane);
+        if (wide_pairs(E, f)) {   // (both forms where the width allows the paired one: the same sums)
+            double Hp[PX];
+            int Hpi[PX];
+            hsum_wide<E, double, true>(V, Hp, wl, lane);
+            hsum_wide<E, int, true>(Vi, Hpi, wl, lane);
+            if (lane >= ol && lane < WAVE - ol)
+                for (int i = 0; i < PX; ++i) {
+                    int ei = 0;
+                    double ed = 0.0;
+                    for (int d = -rw; d <= rw; ++d) ei += (lane * PX + i + d) * 3 + 1, ed += (double)((lane * PX + i + d) * 3 + 1) + 0.5;
+                    if (Hpi[i] != ei || Hp[i] != ed) bad = 1;
+                }
+        }
         hsum_wide<E, double>(V, Hd, wl, lane);
         hsum_wide<E, int>(Vi, Hi, wl, lane);
         if (lane >= ol && lane < WAVE - ol) {

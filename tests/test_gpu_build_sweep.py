@@ -145,6 +145,20 @@ def test_every_kernel_shape_of_a_configuration_vs_oracle(ctx, oc, model, find_r2
 
 
 @pytest.mark.oracle
+@pytest.mark.parametrize('model, find_r2, thresh, nodata', CONFIGS)
+def test_paired_builds_of_the_wide_kernels_vs_oracle(ctx, oc, model, find_r2, thresh, nodata):
+    """ Kernels 31 and 33 - 37 wide (odd counts of whole lanes either side, hk_fit_kernel.h wide_pairs) run builds of their own on the
+    centre ring, whose horizontal sums add the whole lanes as pairs (RW = -5 .. -8): every model configuration, every residue of
+    kw // 2 mod 4, certificate-only / list / complete, dense and NaN-aware, with open wave-rows and failing pixels at 3 and 9 rows. """
+    src, ref = _pair(17, nodata)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for kh in (3, 9, 17):
+            for kw in (31, 33, 35, 37):
+                _check_shape(ctx, oc, model, find_r2, thresh, nodata, (kh, kw), src, ref, f'paired: {model} r2={find_r2} thresh={thresh} nodata={nodata} {kh}x{kw}')
+
+
+@pytest.mark.oracle
 @pytest.mark.parametrize('ring', ['0', '1', '2', '3'])
 @pytest.mark.parametrize('model, find_r2, thresh, nodata', CONFIGS)
 def test_forced_ring_modes_of_every_width_vs_oracle(ctx, oc, model, find_r2, thresh, nodata, ring, monkeypatch):
@@ -205,7 +219,8 @@ def test_batched_builds_of_every_width_vs_oracle(oc, nodata_variant, ring, monke
             ctx.d2h(s, bufs[j]['src']), ctx.d2h(r, bufs[j]['ref'])
             host.append((s, r))
         for kh in ((1, 5, 7, 9, 11, 15, 17, 41) if ring is None else (5, 11)):
-            for kw in WIDTHS:
+            # (31 - 37 wide at two heights: the batched forms of the paired builds, test_paired_builds_of_the_wide_kernels_vs_oracle)
+            for kw in WIDTHS + ((31, 33, 35, 37) if ring is None and kh in (5, 17) else ()):
                 desc = _hk.make_desc('gain-blk-offset', (kh, kw), False, None, nd, nd)
                 jobs = []
                 for j, (h, w) in enumerate(shapes):
