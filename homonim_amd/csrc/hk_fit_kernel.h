@@ -594,7 +594,9 @@ __device__ __forceinline__ T* table_pointer(T* uniform_ptr) {
 }
 template <int MODEL, bool R2, int RW, bool DENSE, int RING, bool CERT_ONLY>
 constexpr bool fit_scalar_bases() {
-    return (MODEL == 2 && R2 && !DENSE && RW < 0 && (wide_e(RW) != 0 || wide_paired(RW)) && CERT_ONLY) ||  // gain-offset + r2 mask, NaN-aware, wider than 15 (kw / 2 mod 4 != 0, or paired)
+    // gain-offset + r2 mask, NaN-aware, wider than 15: the builds that are short of registers for a third wave without it (kw / 2 mod 4
+    // != 0 of the plain form, != 3 of the paired form -- that one needs 20 registers fewer anyway)
+    return (MODEL == 2 && R2 && !DENSE && RW < 0 && (wide_paired(RW) ? wide_e(RW) != 3 : wide_e(RW) != 0) && CERT_ONLY) ||
            (MODEL == 0 && !R2 && !DENSE && RING == 3 && (RW == 5 || RW == 6));  // gain, NaN-aware split ring, 11 / 13 wide
 }
 
